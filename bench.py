@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the GenPC geometric hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric "Chamfer Gpair-dist/sec", SURVEY.md section 8d headline):
+one STEP = one `chamfer_3DDist.forward` (both directions, i.e. 2*N*M pair
+evaluations) on one synthetic pair of clouds, B=1, N=M=16384, fp32, through the C
+ABI of libgenpc_hip.so, inputs resident in HBM.  `rng=default_rng(20250101)`,
+`A,B = rng.random((1,N,3),float32)-0.5`.  With --gpus N every rank runs the same
+per-rank workload on its own pair (independent scans shard with no data-path
+collective): weak scaling, value = total pair-dist/s over all ranks.
+
+One JSON line on stdout (rank 0).  Besides the contract fields:
+  roofline      the dominant kernel (nn_forward_kernel) against the fp32 VECTOR
+                roofline.  The kernel is VALU-bound (6.5 kflop per HBM byte); bound
+                is reported as "valu_fp32" with peak 157.3 TFLOP/s (the datasheet
+                fp32 vector figure, numerically equal to the dense f32 MFMA peak);
+                algorithmic flops = 8 per pair (3 sub, 3 mul, 2 add: SURVEY 8d).
+  roofline_hbm  the same launch against the 8 TB/s HBM roofline (algorithmic bytes
+                20*(N+M) per call); north_star asks for it; it is << 1 % by nature.
+  cpu_baseline  the CPU oracle (a port: the reference has no CPU path) timed on the
+                host cores on a bounded sample of the same workload.
+  extra         secondary measurements (EMD, backward, metric scans/s).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+N_PTS = 16384
+SEED = 20250101
+PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_PAIR = 8
+
+
+def make_pair(n, seed, device):
+    rng = np.random.default_rng(seed)
+    a = rng.random((1, n, 3), dtype=np.float32) - np.float32(0.5)
+    b = rng.random((1, n, 3), dtype=np.float32) - np.float32(0.5)
+    return torch.from_numpy(a).to(device), torch.from_numpy(b).to(device), a, b
+
+
+def time_events(fn, reps, stream):
+    """Average duration (ms) of `fn` over `reps` calls, HIP events on `stream`."""
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def cpu_baseline(a, b, budget_s=12.0):
+    """Oracle Chamfer forward on all host cores, repeated until ~budget_s."""
+    from oracle import oracle as O
+    O.build()
+    cores = O.num_threads()
+    n, m = a.shape[1], b.shape[1]
+    t0 = time.perf_counter()
+    O.chamfer_forward(a, b, 1)
+    first = time.perf_counter() - t0
+    reps = max(1, min(50, int(budget_s / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.chamfer_forward(a, b, 1)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(2.0 * n * m / dt / 1e9, 4), "unit": "Gpair-dist/s", "cores": cores, "kind": "port",
+            "sample": "oracle/genpc_oracle.c chamfer forward (OpenMP, %d threads), B=1 N=M=%d, %d calls of %.2f s"
+                      % (cores, n, reps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--points", type=int, default=N_PTS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    from genpc_amd import sharding
+    rank, local_rank, world = sharding.init()
+    if world != args.gpus and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    n_gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from genpc_amd import _lib, chamfer_3D
+    from genpc_amd.loss_functions import chamfer_3DDist, emdModule
+
+    n = args.points
+    A, B, a_np, b_np = make_pair(n, SEED + rank, dev)
+    dist1 = torch.empty(1, n, device=dev)
+    dist2 = torch.empty(1, n, device=dev)
+    idx1 = torch.empty(1, n, device=dev, dtype=torch.int32)
+    idx2 = torch.empty(1, n, device=dev, dtype=torch.int32)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        rc = chamfer_3D.forward(A, B, dist1, dist2, idx1, idx2)
+        if rc != 1:
+            raise RuntimeError("chamfer forward failed: " + _lib.last_error())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(elapsed, device=dev if world > 1 else "cpu")
+
+    pairs_per_step = 2.0 * n * n
+    value = n_gpus * pairs_per_step * args.steps / elapsed / 1e9
+
+    out = None
+    if rank == 0:
+        # live HIP-event timing of the dominant kernel on the launch stream
+        ms = time_events(step, max(20, min(args.steps, 200)), stream)
+        tflops = FLOP_PER_PAIR * pairs_per_step / (ms * 1e-3) / 1e12
+        alg_bytes = 20.0 * (n + n)        # 12 B read + 8 B written per point, both clouds
+        out = {
+            "metric": "chamfer_nn_pair_dist_throughput",
+            "value": round(value, 3),
+            "unit": "Gpair-dist/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "chamfer_3DDist.forward B=1 N=M=%d (both directions), one pair per rank" % n,
+                       "points": n, "batch": 1, "arith": "fma" if _lib.lib.genpc_get_arith() else "strict",
+                       "sharding": "independent scans per rank, no data-path collective"},
+            "roofline": {"bound": "valu_fp32", "achieved": round(tflops, 3), "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "kernel": "nn_forward_kernel(+nn_merge_kernel)", "ms_per_launch": round(ms, 5),
+                         "flop_per_pair": FLOP_PER_PAIR},
+            "roofline_hbm": {"bound": "hbm", "achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 3),
+                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6), "traffic": None,
+                             "algorithmic_bytes": alg_bytes},
+        }
+        if not args.no_extra:
+            extra = {}
+            cd = chamfer_3DDist()
+            Ag = A.clone().requires_grad_(True)
+            Bg = B.clone().requires_grad_(True)
+
+            def fb():
+                Ag.grad = None
+                Bg.grad = None
+                d1, d2, _, _ = cd(Ag, Bg)
+                (torch.sqrt(d1).mean() + torch.sqrt(d2).mean()).backward()
+            fb()
+            extra["chamfer_fwd_bwd_autograd_ms"] = round(time_events(fb, 20, stream), 4)
+            em = emdModule()
+            X = A + 0.5
+            Y = B + 0.5
+            em(X, Y, 0.005, 50)
+            extra["emd_fwd_n%d_eps0.005_it50_ms" % n] = round(time_events(lambda: em(X, Y, 0.005, 50), 5, stream), 4)
+            X2 = X[:, :2048].contiguous()
+            Y2 = Y[:, :2048].contiguous()
+            em(X2, Y2, 0.005, 50)
+            extra["emd_fwd_n2048_eps0.005_it50_ms"] = round(time_events(lambda: em(X2, Y2, 0.005, 50), 5, stream), 4)
+            for nn in (2048, 4096, 8192, 32768):
+                P, Q, _, _ = make_pair(nn, SEED, dev)
+                d1 = torch.empty(1, nn, device=dev)
+                d2 = torch.empty(1, nn, device=dev)
+                i1 = torch.empty(1, nn, device=dev, dtype=torch.int32)
+                i2 = torch.empty(1, nn, device=dev, dtype=torch.int32)
+                f = lambda: chamfer_3D.forward(P, Q, d1, d2, i1, i2)  # noqa: E731
+                f()
+                t = time_events(f, 50, stream)
+                extra["chamfer_fwd_n%d_gpair_s" % nn] = round(2.0 * nn * nn / (t * 1e-3) / 1e9, 2)
+            out["extra"] = extra
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a_np, b_np)
+    sharding.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    sharding.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""ctypes binding of libgenpc_hip.so (C ABI: include/genpc_hip.h).
+
+The library is the product; there is NO fallback.  If it is missing, was built
+for another ABI version or lacks a symbol, importing this module raises.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to it)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgenpc_hip.so")
+ABI_VERSION = 1
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> (restype, argtypes); must list every symbol include/genpc_hip.h declares
+# (tests/test_abi.py parses the header and checks this table and the .so).
+SIGNATURES = {
+    "genpc_abi_version": (_i, []),
+    "genpc_last_error": (ctypes.c_char_p, []),
+    "genpc_set_arith": (_i, [_i]),
+    "genpc_get_arith": (_i, []),
+    "genpc_release_workspace": (_i, []),
+    "genpc_chamfer_forward": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "genpc_nm_distance": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "genpc_chamfer_backward": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "genpc_emd_forward": (_i, [_i, _i, _i] + [_vp] * 14 + [_f, _i, _vp]),
+    "genpc_emd_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class GenpcLibraryError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise GenpcLibraryError(
+            "libgenpc_hip.so not found at %s -- run `python -m genpc_amd.build` "
+            "(hipcc, gfx950).  There is no CPU or PyTorch fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise GenpcLibraryError("libgenpc_hip.so lacks symbol %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.genpc_abi_version()
+    if got != ABI_VERSION:
+        raise GenpcLibraryError("libgenpc_hip.so ABI %d != expected %d (rebuild)" % (got, ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.genpc_last_error().decode("utf-8", "replace")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return _vp(0) if t is None else _vp(t.data_ptr())
+
+
+def stream_of(t):
+    """hipStream_t of torch's current stream on t's device, as void*."""
+    return _vp(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("genpc_amd: GPU tensors only (got a %s tensor); the "
+                               "HIP path has no CPU fallback" % t.device)
+
+
+def require(t, dtype, name):
+    if t.dtype != dtype:
+        raise TypeError("genpc_amd: %s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("genpc_amd: %s must be contiguous" % name)

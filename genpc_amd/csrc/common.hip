@@ -1,0 +1,112 @@
+// common.hip -- error state, arithmetic mode and the scratch pool.
+#include "common.h"
+#include "../../include/genpc_hip.h"
+
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+namespace genpc {
+
+static std::mutex g_mu;
+static std::string g_err;
+static int g_arith = GENPC_ARITH_FMA;
+
+struct Slot {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+struct Key {
+    int dev;
+    int slot;
+    hipStream_t stream;
+    bool operator==(const Key &o) const { return dev == o.dev && slot == o.slot && stream == o.stream; }
+};
+struct KeyHash {
+    size_t operator()(const Key &k) const {
+        return (size_t)k.dev * 1315423911u ^ (size_t)k.slot * 2654435761u ^ (size_t)(uintptr_t)k.stream;
+    }
+};
+static std::unordered_map<Key, Slot, KeyHash> g_pool;
+
+void set_error(const char *msg)
+{
+    std::lock_guard<std::mutex> l(g_mu);
+    g_err = msg;
+}
+
+bool check(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    fprintf(stderr, "genpc_hip: error in %s\n", buf);
+    set_error(buf);
+    return false;
+}
+
+int arith_mode() { return g_arith; }
+
+void *workspace(int slot, size_t bytes, hipStream_t stream)
+{
+    int dev = 0;
+    if (!check(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
+    std::lock_guard<std::mutex> l(g_mu);
+    Slot &s = g_pool[Key{dev, slot, stream}];
+    if (s.bytes >= bytes && s.ptr) return s.ptr;
+    if (s.ptr) {
+        // Work already enqueued on `stream` may still read the old block.
+        if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
+        (void)hipFree(s.ptr);
+        s.ptr = nullptr;
+        s.bytes = 0;
+    }
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        fprintf(stderr, "genpc_hip: error in %s\n", buf);
+        g_err = buf;
+        return nullptr;
+    }
+    s.ptr = p;
+    s.bytes = want;
+    return p;
+}
+
+}  // namespace genpc
+
+GENPC_API int genpc_abi_version(void) { return 1; }
+
+GENPC_API const char *genpc_last_error(void)
+{
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> l(genpc::g_mu);
+    copy = genpc::g_err;
+    return copy.c_str();
+}
+
+GENPC_API int genpc_set_arith(int mode)
+{
+    int prev = genpc::g_arith;
+    genpc::g_arith = mode ? GENPC_ARITH_FMA : GENPC_ARITH_STRICT;
+    return prev;
+}
+
+GENPC_API int genpc_get_arith(void) { return genpc::g_arith; }
+
+GENPC_API int genpc_release_workspace(void)
+{
+    std::lock_guard<std::mutex> l(genpc::g_mu);
+    bool ok = true;
+    for (auto &kv : genpc::g_pool) {
+        if (kv.second.ptr) {
+            (void)hipSetDevice(kv.first.dev);
+            ok &= (hipFree(kv.second.ptr) == hipSuccess);
+        }
+    }
+    genpc::g_pool.clear();
+    return ok ? 1 : 0;
+}

@@ -1,0 +1,391 @@
+// emd.hip -- auction-algorithm EMD (forward + backward) for gfx950.
+// Replaces loss_functions/emd/emd_cuda.cu of the reference.
+//
+// Round structure.  The reference runs 7 launches per round (clear, count,
+// prefix-sum, compact, Bid, GetMax, Assign: emd_cuda.cu:256-268).  Here a round is
+// three launches with launch shapes that do not depend on device-side state, so
+// the host never synchronises:
+//   bid      every unassigned point j finds its best and second-best object
+//            (value 3 - |x2_k - x1_j| - price_k, evaluated in double exactly as
+//            emd_cuda.cu:146 does) and atomically raises max_increments[best];
+//   getmax   among the bidders of an object, the highest j whose increment is
+//            within 1e-6 of the maximum is elected (atomicMax on max_idx; the
+//            reference's plain store is racy -- last writer wins -- and the oracle
+//            resolves it the same way, in favour of the highest j);
+//   assign   winners take the object, evict the previous owner, raise the price;
+//            the list of NEXT round's bidders (losers + evicted owners) is built
+//            here with wave-aggregated appends, which replaces the reference's
+//            four compaction kernels.
+// Bid layout.  P lanes cooperate on one bidder (P = 1..64, a power of two picked
+// per round from the number of bidders so that the grid stays full when few
+// points are left); lane p of a bidder visits objects k = p (mod P) of a tile of
+// (x,y,z,price) float4s staged in LDS -- consecutive lanes read consecutive 16 B
+// slots (conflict-free ds_read_b128), lanes of different bidders read the same
+// slot (broadcast).  Per-lane top-2 is v_max + v_med3; the P partial results are
+// merged with xor-shuffles.
+// Index ties.  With exactly equal top values the reference reports the
+// candidate that comes first in ITS thread-major scan order (emd_cuda.cu:108-118,
+// 136-139,165-173).  The fast path only needs the two top VALUES; when they are
+// equal (a tie for first place) the bidder's lanes re-scan and select the tied
+// object with the smallest (reference-thread, index) key, so assignments agree
+// with the oracle even on clouds with duplicated points.
+#include "common.h"
+#include "../../include/genpc_hip.h"
+
+namespace genpc {
+
+constexpr int kEBlock = 256;
+constexpr int kTile = 1024;        // objects per LDS tile (16 KiB as float4)
+
+template <int FMA>
+__device__ __forceinline__ float sqdist_e(float dx, float dy, float dz)
+{
+    if (FMA) {
+        float t = __fmul_rn(dy, dy);
+        t = __fmaf_rn(dx, dx, t);
+        return __fmaf_rn(dz, dz, t);
+    } else {
+        float a = __fmul_rn(dx, dx);
+        float b = __fmul_rn(dy, dy);
+        float c = __fmul_rn(dz, dz);
+        return __fadd_rn(__fadd_rn(a, b), c);
+    }
+}
+
+// emd_cuda.cu:142-146
+template <int FMA>
+__device__ __forceinline__ float bid_value(float x1, float y1, float z1, float x2, float y2, float z2, float price)
+{
+    float s = sqdist_e<FMA>(x2 - x1, y2 - y1, z2 - z1);
+    float r = __fsqrt_rn(s);
+    return (float)((3.0 - (double)r) - (double)price);
+}
+
+// float atomic max; increments are >= 0 in every sane call (eps >= 0), where the
+// int ordering of the bit patterns equals the float ordering even against the
+// -1e9 reset value.  Negative values take the CAS loop of emd_cuda.cu:10-20.
+__device__ __forceinline__ void atomic_max_float(float *addr, float val)
+{
+    if (val >= 0.0f) {
+        atomicMax((int *)addr, __float_as_int(val));
+    } else {
+        int ret = __float_as_int(*addr);
+        while (val > __int_as_float(ret)) {
+            int old = ret;
+            if ((ret = atomicCAS((int *)addr, old, __float_as_int(val))) == old) break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kEBlock) void emd_init_kernel(int b, int n, int *__restrict__ list, int *__restrict__ cnt_a,
+                                                           int *__restrict__ cnt_b)
+{
+    int t = blockIdx.x * kEBlock + threadIdx.x;
+    if (t < b * n) list[t] = t % n;
+    if (t < b) {
+        cnt_a[t] = n;
+        cnt_b[t] = 0;
+    }
+}
+
+// lanes-per-bidder for U bidders on a grid of G blocks per batch element
+__device__ __forceinline__ int pick_p(int U, int G)
+{
+    int P = 64;
+    while (P > 1 && ((long long)U * P + kEBlock - 1) / kEBlock > G) P >>= 1;
+    return P;
+}
+
+template <int FMA>
+__global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__restrict__ xyz1,
+                                                          const float *__restrict__ xyz2,
+                                                          const float *__restrict__ price, float eps,
+                                                          const int *__restrict__ list, const int *__restrict__ cnt,
+                                                          int *__restrict__ cnt_next, int *__restrict__ bid,
+                                                          float *__restrict__ bid_increments,
+                                                          float *__restrict__ max_increments)
+{
+    __shared__ float4 tile[kTile];
+    const int batch = blockIdx.y;
+    const int U = cnt[batch];
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt_next[batch] = 0;   // filled by this round's assign
+    if (U == 0) return;
+    const int G = gridDim.x;
+    const int P = pick_p(U, G);
+    const int per_wave = kWave / P;
+    const int per_block = kEBlock / P;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int p = lane & (P - 1);
+    const int g = lane / P;
+
+    const float *__restrict__ X1 = xyz1 + (size_t)batch * n * 3;
+    const float *__restrict__ X2 = xyz2 + (size_t)batch * n * 3;
+    const float *__restrict__ PR = price + (size_t)batch * n;
+    const int *__restrict__ L = list + (size_t)batch * n;
+
+    // reference partition, needed only to order exactly tied candidates
+    const int block_cnt = n / 256;
+    const int unass_per_block = (U + block_cnt - 1) / block_cnt;
+    const int thread_per_unass = 256 / unass_per_block;
+
+    for (int grp = blockIdx.x; (long long)grp * per_block < U; grp += G) {
+        const int u = grp * per_block + wave * per_wave + g;
+        const bool active = u < U;
+        const int j = L[active ? u : U - 1];
+        const float x1 = X1[(size_t)j * 3 + 0], y1 = X1[(size_t)j * 3 + 1], z1 = X1[(size_t)j * 3 + 2];
+        float best = -1e9f, better = -1e9f;
+        int best_i = -1;
+
+        for (int k2 = 0; k2 < n; k2 += kTile) {
+            const int end_k = min(n, k2 + kTile) - k2;
+            __syncthreads();
+            for (int t = threadIdx.x; t < end_k; t += kEBlock) {
+                const int k = k2 + t;
+                tile[t] = make_float4(X2[(size_t)k * 3 + 0], X2[(size_t)k * 3 + 1], X2[(size_t)k * 3 + 2], PR[k]);
+            }
+            __syncthreads();
+            for (int t = p; t < end_k; t += P) {
+                const float4 o = tile[t];
+                const float d = bid_value<FMA>(x1, y1, z1, o.x, o.y, o.z, o.w);
+                const bool gt = d > best;
+                better = __builtin_amdgcn_fmed3f(d, best, better);
+                best = fmaxf(best, d);
+                best_i = gt ? k2 + t : best_i;
+            }
+        }
+        // merge the P partial top-2s of a bidder (value-symmetric)
+        for (int off = 1; off < P; off <<= 1) {
+            const float ob = __shfl_xor(best, off, kWave);
+            const float obb = __shfl_xor(better, off, kWave);
+            const int oi = __shfl_xor(best_i, off, kWave);
+            float nb2;
+            if (best > ob) nb2 = fmaxf(better, ob);
+            else if (ob > best) nb2 = fmaxf(obb, best);
+            else nb2 = best;
+            const bool take = ob > best || (ob == best && (unsigned)oi < (unsigned)best_i);
+            best_i = take ? oi : best_i;
+            best = fmaxf(best, ob);
+            better = nb2;
+        }
+        // exact tie for first place: pick the candidate the reference's scan meets first
+        const bool tie = active && (best == better);
+        if (__any(tie)) {
+            unsigned long long key = ~0ull;
+            if (tie) {
+                for (int k = p; k < n; k += P) {
+                    const float d = bid_value<FMA>(x1, y1, z1, X2[(size_t)k * 3 + 0], X2[(size_t)k * 3 + 1],
+                                                   X2[(size_t)k * 3 + 2], PR[k]);
+                    if (d == best) {
+                        const int kt = k & 2047;                       // position in the reference's 2048-tile
+                        const int tile0 = k - kt;
+                        const int end_k = min(n, tile0 + 2048) - tile0;
+                        const int delta = (end_k + thread_per_unass - 1) / thread_per_unass;
+                        const unsigned long long kk = ((unsigned long long)(kt / delta) << 32) | (unsigned)k;
+                        key = kk < key ? kk : key;
+                    }
+                }
+            }
+            for (int off = 1; off < P; off <<= 1) {
+                const unsigned long long o = __shfl_xor(key, off, kWave);
+                key = o < key ? o : key;
+            }
+            if (tie) best_i = (int)(key & 0xffffffffu);
+        }
+        if (active && p == 0) {
+            const float inc = __fadd_rn(__fsub_rn(best, better), eps);
+            bid[(size_t)batch * n + j] = best_i;
+            bid_increments[(size_t)batch * n + j] = inc;
+            atomic_max_float(&max_increments[(size_t)batch * n + best_i], inc);
+        }
+    }
+}
+
+// emd_cuda.cu:181-194.  In the forced last round every bidder is "assigned", and
+// the owner recorded in assignment_inv is the last writer: elect the highest j.
+__global__ __launch_bounds__(kEBlock) void emd_getmax_kernel(int n, const int *__restrict__ list,
+                                                             const int *__restrict__ cnt, const int *__restrict__ bid,
+                                                             const float *__restrict__ bid_increments,
+                                                             const float *__restrict__ max_increments,
+                                                             int *__restrict__ max_idx, int last)
+{
+    const int batch = blockIdx.y;
+    const int U = cnt[batch];
+    for (int u = blockIdx.x * kEBlock + threadIdx.x; u < U; u += gridDim.x * kEBlock) {
+        const int j = list[(size_t)batch * n + u];
+        const int bid_id = bid[(size_t)batch * n + j];
+        const double bid_inc = (double)bid_increments[(size_t)batch * n + j];
+        const double max_inc = (double)max_increments[(size_t)batch * n + bid_id];
+        if (last || (bid_inc - 1e-6 <= max_inc && max_inc <= bid_inc + 1e-6))
+            atomicMax(&max_idx[(size_t)batch * n + bid_id], j);
+    }
+}
+
+// emd_cuda.cu:196-215 plus construction of the next round's bidder list.
+__global__ __launch_bounds__(kEBlock) void emd_assign_kernel(int n, const int *__restrict__ list,
+                                                             const int *__restrict__ cnt, int *__restrict__ list_next,
+                                                             int *__restrict__ cnt_next, int *__restrict__ assignment,
+                                                             int *__restrict__ assignment_inv, float *__restrict__ price,
+                                                             const int *__restrict__ bid,
+                                                             const float *__restrict__ bid_increments,
+                                                             float *__restrict__ max_increments,
+                                                             int *__restrict__ max_idx, int last)
+{
+    const int batch = blockIdx.y;
+    const int U = cnt[batch];
+    const size_t base = (size_t)batch * n;
+    for (int u = blockIdx.x * kEBlock + threadIdx.x; u < U; u += gridDim.x * kEBlock) {
+        const int j = list[base + u];
+        const int bid_id = bid[base + j];
+        const bool elected = max_idx[base + bid_id] == j;
+        if (last) {
+            // every remaining bidder takes its object (not a bijection, :201)
+            assignment[base + j] = bid_id;
+            atomicAdd(&price[base + bid_id], bid_increments[base + j]);
+            if (elected) {
+                assignment_inv[base + bid_id] = j;
+                max_increments[base + bid_id] = -1e9f;
+                max_idx[base + bid_id] = -1;
+            }
+        } else if (elected) {
+            const int prev = assignment_inv[base + bid_id];
+            if (prev != -1) {
+                assignment[base + prev] = -1;
+                const int pos = atomicAdd(&cnt_next[batch], 1);
+                list_next[base + pos] = prev;
+            }
+            assignment_inv[base + bid_id] = j;
+            assignment[base + j] = bid_id;
+            price[base + bid_id] = __fadd_rn(price[base + bid_id], bid_increments[base + j]);
+            max_increments[base + bid_id] = -1e9f;
+            // elections are per round; only this thread's own comparison above
+            // needed the value, every other bidder of the object compares != j
+            max_idx[base + bid_id] = -1;
+        } else {
+            const int pos = atomicAdd(&cnt_next[batch], 1);
+            list_next[base + pos] = j;
+        }
+    }
+}
+
+// emd_cuda.cu:217-226
+template <int FMA>
+__global__ __launch_bounds__(kEBlock) void emd_calc_dist_kernel(long long total, int n, const float *__restrict__ xyz1,
+                                                                const float *__restrict__ xyz2,
+                                                                float *__restrict__ dist,
+                                                                const int *__restrict__ assignment)
+{
+    const long long t = (long long)blockIdx.x * kEBlock + threadIdx.x;
+    if (t >= total) return;
+    const long long i = t / n;
+    const int k = assignment[t];
+    if (k < 0) {            // iters == 0: the reference would read out of bounds
+        dist[t] = 0.0f;
+        return;
+    }
+    const float *p1 = xyz1 + t * 3;
+    const float *p2 = xyz2 + (i * n + k) * 3;
+    dist[t] = sqdist_e<FMA>(p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]);
+}
+
+// emd_cuda.cu:284-300
+__global__ __launch_bounds__(kEBlock) void emd_grad_kernel(long long total, int n, const float *__restrict__ xyz1,
+                                                           const float *__restrict__ xyz2,
+                                                           const float *__restrict__ grad_dist,
+                                                           const int *__restrict__ idx, float *__restrict__ grad_xyz)
+{
+    const long long t = (long long)blockIdx.x * kEBlock + threadIdx.x;
+    if (t >= total) return;
+    const long long i = t / n;
+    const float *p1 = xyz1 + t * 3;
+    const float *p2 = xyz2 + (i * n + idx[t]) * 3;
+    const float g = __fmul_rn(grad_dist[t], 2.0f);
+    float *o = grad_xyz + t * 3;
+    o[0] = __fadd_rn(o[0], __fmul_rn(g, p1[0] - p2[0]));
+    o[1] = __fadd_rn(o[1], __fmul_rn(g, p1[1] - p2[1]));
+    o[2] = __fadd_rn(o[2], __fmul_rn(g, p1[2] - p2[2]));
+}
+
+}  // namespace genpc
+
+GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist,
+                                int *assignment, float *price, int *assignment_inv, int *bid,
+                                float *bid_increments, float *max_increments, int *unass_idx, int *unass_cnt,
+                                int *unass_cnt_sum, int *cnt_tmp, int *max_idx, float eps, int iters, void *stream)
+{
+    using namespace genpc;
+    (void)unass_cnt_sum;
+    if (n != m) {                      // emd_cuda.cu:236-239
+        fprintf(stderr, "Input Error! The two point clouds should have the same size.\n");
+        return -1;
+    }
+    if (b > 512) {                     // :241-244
+        fprintf(stderr, "Input Error! The batch size should be less than 512.\n");
+        return -1;
+    }
+    if (n % 256 != 0) {                // :246-249
+        fprintf(stderr, "Input Error! The size of the point clouds should be a multiple of 256.\n");
+        return -1;
+    }
+    if (b <= 0 || n <= 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)b * n;
+    if (total > 0x7fffffffLL) {
+        set_error("emd: B*n too large");
+        return 0;
+    }
+    int *list_b = (int *)workspace(1, (size_t)total * sizeof(int), st);
+    if (!list_b) return 0;
+    int *lists[2] = {unass_idx, list_b};
+    int *cnts[2] = {unass_cnt, cnt_tmp};
+    const bool fma = arith_mode() != 0;
+
+    const int lin_blocks = ceil_div((int)total, kEBlock);
+    hipLaunchKernelGGL(emd_init_kernel, dim3(lin_blocks), dim3(kEBlock), 0, st, b, n, lists[0], cnts[0], cnts[1]);
+
+    // Blocks per batch element for the bid kernel: ~4 blocks per CU overall,
+    // never more than the finest split (64 lanes per bidder, all n bidding).
+    int G = ceil_div(kNumCU * 4, b);
+    const int g_max = ceil_div(n * 64, kEBlock);
+    if (G > g_max) G = g_max;
+    if (G < 1) G = 1;
+    int GL = ceil_div(n, kEBlock);          // list-walking kernels
+    if (GL > 64) GL = 64;
+
+    for (int it = 0; it < iters; it++) {
+        const int cur = it & 1, nxt = cur ^ 1;
+        const int last = (it == iters - 1);
+        if (fma)
+            hipLaunchKernelGGL((emd_bid_kernel<1>), dim3(G, b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price,
+                               eps, (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
+                               max_increments);
+        else
+            hipLaunchKernelGGL((emd_bid_kernel<0>), dim3(G, b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price,
+                               eps, (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
+                               max_increments);
+        hipLaunchKernelGGL(emd_getmax_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
+                           (const int *)cnts[cur], (const int *)bid, (const float *)bid_increments,
+                           (const float *)max_increments, max_idx, last);
+        hipLaunchKernelGGL(emd_assign_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
+                           (const int *)cnts[cur], lists[nxt], cnts[nxt], assignment, assignment_inv, price,
+                           (const int *)bid, (const float *)bid_increments, max_increments, max_idx, last);
+    }
+    if (fma)
+        hipLaunchKernelGGL((emd_calc_dist_kernel<1>), dim3(lin_blocks), dim3(kEBlock), 0, st, total, n, xyz1, xyz2, dist,
+                           (const int *)assignment);
+    else
+        hipLaunchKernelGGL((emd_calc_dist_kernel<0>), dim3(lin_blocks), dim3(kEBlock), 0, st, total, n, xyz1, xyz2, dist,
+                           (const int *)assignment);
+    return check(hipGetLastError(), "emd forward launch") ? 1 : 0;
+}
+
+GENPC_API int genpc_emd_backward(int b, int n, const float *xyz1, const float *xyz2, float *gradxyz,
+                                 const float *graddist, const int *idx, void *stream)
+{
+    using namespace genpc;
+    if (b <= 0 || n <= 0) return 1;
+    const long long total = (long long)b * n;
+    hipLaunchKernelGGL(emd_grad_kernel, dim3((unsigned)ceil_div64(total, kEBlock)), dim3(kEBlock), 0,
+                       (hipStream_t)stream, total, n, xyz1, xyz2, graddist, idx, gradxyz);
+    return check(hipGetLastError(), "emd_grad_kernel launch") ? 1 : 0;
+}

@@ -1,0 +1,83 @@
+"""``emdModule`` / ``emdFunction`` with the reference's interface
+(loss_functions/emd/emd_module.py:29-95) on the gfx950 library.
+
+Input: xyz1 (prediction), xyz2 (ground truth): [B, n, 3], same n, n % 256 == 0,
+B <= 512; eps, iters as in the reference.  Output: dist [B, n] (squared distance
+to the assigned point; sqrt -> L2), assignment [B, n] int32 (not guaranteed to be
+a bijection: the last round force-assigns, emd_cuda.cu:201).  Gradient flows to
+xyz1 only (:83-87).
+
+Differences from the reference: scratch is allocated on the INPUT's device (the
+reference hard-codes "cuda" = current device, :41-54), and the return code is
+checked (-1 -> ValueError like the asserts at :36-39 would).
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from ... import _lib, emd
+
+
+def alloc_state(batchsize, n, m, device):
+    """The 12 scratch/output tensors of emd_module.py:43-54, same initial values."""
+    z = dict(device=device)
+    return dict(
+        dist=torch.zeros(batchsize, n, dtype=torch.float32, **z),
+        assignment=torch.full((batchsize, n), -1, dtype=torch.int32, **z),
+        assignment_inv=torch.full((batchsize, m), -1, dtype=torch.int32, **z),
+        price=torch.zeros(batchsize, m, dtype=torch.float32, **z),
+        bid=torch.zeros(batchsize, n, dtype=torch.int32, **z),
+        bid_increments=torch.zeros(batchsize, n, dtype=torch.float32, **z),
+        max_increments=torch.zeros(batchsize, m, dtype=torch.float32, **z),
+        unass_idx=torch.zeros(batchsize * n, dtype=torch.int32, **z),
+        max_idx=torch.zeros(batchsize * m, dtype=torch.int32, **z),
+        unass_cnt=torch.zeros(512, dtype=torch.int32, **z),
+        unass_cnt_sum=torch.zeros(512, dtype=torch.int32, **z),
+        cnt_tmp=torch.zeros(512, dtype=torch.int32, **z),
+    )
+
+
+class emdFunction(Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, eps, iters):
+        batchsize, n, _ = xyz1.size()
+        _, m, _ = xyz2.size()
+
+        assert n == m
+        assert xyz1.size()[0] == xyz2.size()[0]
+        assert n % 256 == 0
+        assert batchsize <= 512
+
+        _lib.require_gpu(xyz1, xyz2)
+        xyz1 = xyz1.contiguous().float()
+        xyz2 = xyz2.contiguous().float()
+        s = alloc_state(batchsize, n, m, xyz1.device)
+        rc = emd.forward(xyz1, xyz2, s["dist"], s["assignment"], s["price"], s["assignment_inv"],
+                         s["bid"], s["bid_increments"], s["max_increments"], s["unass_idx"],
+                         s["unass_cnt"], s["unass_cnt_sum"], s["cnt_tmp"], s["max_idx"], eps, iters)
+        if rc == -1:
+            raise ValueError("emd.forward: invalid shape (n != m, B > 512 or n % 256 != 0)")
+        if rc != 1:
+            raise RuntimeError("emd.forward failed: " + _lib.last_error())
+        ctx.save_for_backward(xyz1, xyz2, s["assignment"])
+        ctx.mark_non_differentiable(s["assignment"])
+        return s["dist"], s["assignment"]
+
+    @staticmethod
+    def backward(ctx, graddist, gradidx):
+        xyz1, xyz2, assignment = ctx.saved_tensors
+        graddist = graddist.contiguous()
+        gradxyz1 = torch.zeros_like(xyz1)
+        gradxyz2 = torch.zeros_like(xyz2)
+        rc = emd.backward(xyz1, xyz2, gradxyz1, graddist, assignment)
+        if rc != 1:
+            raise RuntimeError("emd.backward failed: " + _lib.last_error())
+        return gradxyz1, gradxyz2, None, None
+
+
+class emdModule(nn.Module):
+    def __init__(self):
+        super(emdModule, self).__init__()
+
+    def forward(self, input1, input2, eps, iters):
+        return emdFunction.apply(input1, input2, eps, iters)

@@ -1,0 +1,93 @@
+/*
+ * genpc_hip.h -- C ABI of libgenpc_hip.so, the MI355X (gfx950) implementation of
+ * GenPC's geometric hot path.
+ *
+ * Every entry point takes raw DEVICE pointers, plain sizes and a HIP stream
+ * (hipStream_t passed as void*; NULL = the legacy default stream, which is what
+ * the reference launches on).  No torch / ATen types cross this boundary.
+ *
+ * Contract (same as the reference's pybind modules):
+ *   - the CALLER allocates every buffer, outputs and scratch included;
+ *   - fp32 clouds are row-major contiguous [B,N,3]; indices are int32;
+ *   - launches are asynchronous on `stream`; nothing is retained after return;
+ *   - return 1 = ok, 0 = HIP error (message on stderr, genpc_last_error()),
+ *     -1 = invalid shape (EMD: n != m, B > 512, n % 256 != 0).
+ *
+ * Arithmetic mode (genpc_set_arith / genpc_get_arith), process-wide:
+ *   GENPC_ARITH_FMA (default)  d = fma(dz,dz, fma(dx,dx, dy*dy))  -- the
+ *       contraction nvcc's default -fmad=true applies to the reference's
+ *       `x2*x2+y2*y2+z2*z2`;
+ *   GENPC_ARITH_STRICT         d = (dx*dx + dy*dy) + dz*dz, no contraction.
+ *   Both are bit-reproduced by oracle/genpc_oracle.c (fma_mode 1 / 0).
+ */
+#ifndef GENPC_HIP_H
+#define GENPC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GENPC_ARITH_STRICT 0
+#define GENPC_ARITH_FMA 1
+
+/* Library / device ------------------------------------------------------- */
+int genpc_abi_version(void);              /* bumps when a signature changes */
+const char *genpc_last_error(void);       /* last HIP error string, "" if none */
+int genpc_set_arith(int mode);            /* returns the previous mode */
+int genpc_get_arith(void);
+/* Frees the per-device scratch pool (split-target partials, EMD lists). */
+int genpc_release_workspace(void);
+
+/* Chamfer3D -------------------------------------------------------------- *
+ * Replaces chamfer_cuda_forward (loss_functions/Chamfer3D/chamfer3D.cu:136-154,
+ * bound as chamfer_3D.forward in chamfer_cuda.cpp:17-19,31): for every point
+ * of xyz1[B,N,3] the squared distance to, and index of, its nearest point in
+ * xyz2[B,M,3] (dist1/idx1), and the converse (dist2/idx2).  Lowest index wins
+ * ties.  The argument order is the one the reference keeps in its commented-out
+ * raw-pointer prototype (chamfer3D.cu:135).                                  */
+int genpc_chamfer_forward(int b, int n, const float *xyz1, int m,
+                          const float *xyz2, float *dist1, int *idx1,
+                          float *dist2, int *idx2, void *stream);
+
+/* One direction only: result[B,N], result_i[B,N] for queries xyz[B,N,3] against
+ * targets xyz2[B,M,3].  This is NmDistanceKernel itself (chamfer3D.cu:12-134);
+ * the partial-matching losses (utils/loss_util.py:35-43) only consume this half. */
+int genpc_nm_distance(int b, int n, const float *xyz, int m, const float *xyz2,
+                      float *result, int *result_i, void *stream);
+
+/* Replaces chamfer_cuda_backward (chamfer3D.cu:176-195, chamfer_3D.backward in
+ * chamfer_cuda.cpp:22-26,32).  gradxyz1[B,N,3] / gradxyz2[B,M,3] must be zeroed
+ * by the caller (dist_chamfer_3D.py:56-57); the kernel accumulates into them. */
+int genpc_chamfer_backward(int b, int n, const float *xyz1, int m,
+                           const float *xyz2, const float *graddist1,
+                           const int *idx1, const float *graddist2,
+                           const int *idx2, float *gradxyz1, float *gradxyz2,
+                           void *stream);
+
+/* EMD (auction) ---------------------------------------------------------- *
+ * Replaces emd_cuda_forward (loss_functions/emd/emd_cuda.cu:228-282, bound as
+ * emd.forward in emd.cpp:12-17,27).  Same 14 caller-allocated buffers with the
+ * same initial state as emd_module.py:43-54 (assignment/assignment_inv = -1,
+ * the rest 0; unass_cnt/unass_cnt_sum/cnt_tmp are int32[512]).  On return:
+ * dist[B,n] squared distance to the assigned point, assignment[B,n],
+ * assignment_inv, price, bid, bid_increments, max_increments, max_idx hold the
+ * final auction state; unass_idx/unass_cnt/unass_cnt_sum/cnt_tmp hold the
+ * last round's compaction (order within unass_idx is unspecified, as in the
+ * reference).                                                               */
+int genpc_emd_forward(int b, int n, int m, const float *xyz1, const float *xyz2,
+                      float *dist, int *assignment, float *price,
+                      int *assignment_inv, int *bid, float *bid_increments,
+                      float *max_increments, int *unass_idx, int *unass_cnt,
+                      int *unass_cnt_sum, int *cnt_tmp, int *max_idx, float eps,
+                      int iters, void *stream);
+
+/* Replaces emd_cuda_backward (emd_cuda.cu:302-316, emd.backward in
+ * emd.cpp:19-23,28): gradxyz[B,n,3] (caller-zeroed) += 2*graddist*(xyz1-xyz2[idx]). */
+int genpc_emd_backward(int b, int n, const float *xyz1, const float *xyz2,
+                       float *gradxyz, const float *graddist, const int *idx,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENPC_HIP_H */

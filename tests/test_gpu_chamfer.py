@@ -1,0 +1,141 @@
+"""Parity of the HIP Chamfer path (through the C ABI, via the reference-shaped
+Python API) against the CPU oracle.  Bar: distances and indices BIT-EXACT in both
+arithmetic modes; gradients within 1e-6 relative (atomic accumulation order is
+unspecified in the reference as well); reductions within 2 ulp of the oracle's
+fp32 means."""
+import numpy as np
+import pytest
+
+from conftest import gen_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from genpc_amd import _lib
+    from genpc_amd.loss_functions import chamfer_3DDist
+    from genpc_amd.utils.loss_util import Completionloss
+    return dict(torch=torch, lib=_lib, cd=chamfer_3DDist(), CL=Completionloss)
+
+
+def run_hip(gp, a, b, mode):
+    torch = gp["torch"]
+    prev = gp["lib"].lib.genpc_set_arith(mode)
+    try:
+        d1, d2, i1, i2 = gp["cd"](torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+        torch.cuda.synchronize()
+    finally:
+        gp["lib"].lib.genpc_set_arith(prev)
+    return d1.cpu().numpy(), d2.cpu().numpy(), i1.cpu().numpy(), i2.cpu().numpy()
+
+
+def assert_same(got, exp):
+    for g, e, nme in zip(got, exp, ("dist1", "dist2", "idx1", "idx2")):
+        np.testing.assert_array_equal(g, e, err_msg=nme)
+
+
+@pytest.mark.parametrize("name", ["chamfer_seed1_b1_2048.npz", "chamfer_seed0_b2_1000x777.npz",
+                                  "chamfer_seed7_b3_5x3.npz", "chamfer_seed11_dups.npz"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_golden_fixtures(gp, golden, name, mode):
+    g = golden(name)
+    got = run_hip(gp, g["xyz1"], g["xyz2"], mode)
+    assert_same(got, [g[f"dist1_m{mode}"], g[f"dist2_m{mode}"], g[f"idx1_m{mode}"], g[f"idx2_m{mode}"]])
+
+
+@pytest.mark.parametrize("shape", [
+    ((1, 1, 3), (1, 1, 3)), ((1, 63, 3), (1, 65, 3)), ((2, 257, 3), (2, 31, 3)), ((3, 1000, 3), (3, 4097, 3)),
+    ((1, 8192, 3), (1, 8192, 3)), ((5, 300, 3), (5, 5000, 3)), ((64, 512, 3), (64, 640, 3))])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_vs_oracle_shapes(gp, oracle, shape, mode):
+    a, b = gen_pair(21, *shape)
+    assert_same(run_hip(gp, a, b, mode), oracle.chamfer_forward(a, b, mode))
+
+
+def test_survey_scalars_through_completionloss(gp, oracle, golden):
+    """BASELINE.md section 2 values, reproduced on the GPU in strict mode."""
+    torch = gp["torch"]
+    prev = gp["lib"].lib.genpc_set_arith(0)
+    try:
+        a, b = gen_pair(1, (1, 2048, 3), (1, 2048, 3))
+        A, B = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        l1 = gp["CL"]("cd_l1").get_loss(A, B).item()
+        l2 = gp["CL"]("cd_l2").get_loss(A, B).item()
+        assert abs(l1 - 0.04512813) < 1e-8 and abs(l2 - 0.0046723103) < 1e-9
+        g = golden("scan01184_fps2048.npz")
+        P, G = torch.from_numpy(g["partial"]).cuda(), torch.from_numpy(g["gt"]).cuda()
+        assert abs(gp["CL"]("cd_l1").get_loss(P, G).item() - 0.040335327) < 1e-8
+        assert abs(gp["CL"]("cd_l2").get_loss(P, G).item() - 0.0099346815) < 1e-9
+        cl = gp["CL"]("cd_l1")
+        d1, _, _, _ = oracle.chamfer_forward(g["partial"], g["gt"], 0)
+        assert abs(cl.chamfer_partial_l1(P, G).item() - float(oracle.cd_partial_l1(d1))) < 1e-8
+        assert abs(gp["CL"]("cd_l2").chamfer_partial_l2(P, G).item() - float(oracle.cd_partial_l2(d1))) < 1e-9
+    finally:
+        gp["lib"].lib.genpc_set_arith(prev)
+
+
+def test_duplicates_and_exact_hits(gp, oracle):
+    a, b = gen_pair(5, (2, 700, 3), (2, 900, 3))
+    b[:, 450:900] = b[:, 0:450]
+    a[:, :100] = b[:, 200:300]
+    got = run_hip(gp, a, b, 1)
+    assert_same(got, oracle.chamfer_forward(a, b, 1))
+    assert (got[0][:, :100] == 0).all() and (got[2] < 450).all()
+
+
+def test_empty_clouds_leave_zeros(gp):
+    torch = gp["torch"]
+    d1, d2, i1, i2 = gp["cd"](torch.zeros(2, 0, 3).cuda(), torch.rand(2, 7, 3).cuda())
+    assert d1.shape == (2, 0) and d2.shape == (2, 7) and float(d2.abs().sum()) == 0 and int(i2.abs().sum()) == 0
+
+
+def test_noncontiguous_input_and_stream(gp, oracle):
+    torch = gp["torch"]
+    a, b = gen_pair(9, (2, 500, 3), (2, 300, 3))
+    A = torch.from_numpy(np.ascontiguousarray(a.transpose(0, 2, 1))).cuda().transpose(1, 2)   # non-contiguous view
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d1, d2, i1, i2 = gp["cd"](A, torch.from_numpy(b).cuda())
+    s.synchronize()
+    assert_same([t.cpu().numpy() for t in (d1, d2, i1, i2)], oracle.chamfer_forward(a, b, 1))
+
+
+def test_backward_vs_oracle(gp, oracle):
+    torch = gp["torch"]
+    a, b = gen_pair(31, (3, 900, 3), (3, 1100, 3))
+    A = torch.from_numpy(a).cuda().requires_grad_(True)
+    B = torch.from_numpy(b).cuda().requires_grad_(True)
+    d1, d2, i1, i2 = gp["cd"](A, B)
+    rng = np.random.default_rng(2)
+    g1 = rng.random(d1.shape, dtype=np.float32)
+    g2 = rng.random(d2.shape, dtype=np.float32)
+    (d1 * torch.from_numpy(g1).cuda()).sum().add((d2 * torch.from_numpy(g2).cuda()).sum()).backward()
+    e1, e2 = oracle.chamfer_backward(a, b, g1, g2, i1.cpu().numpy(), i2.cpu().numpy())
+    np.testing.assert_allclose(A.grad.cpu().numpy(), e1, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(B.grad.cpu().numpy(), e2, rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_properties(gp):
+    """BASELINE sizes (16384 and 32768 points): size-independent properties.
+    (i) self-distance is exactly zero with idx = identity; (ii) a permutation of the
+    targets permutes the indices and leaves distances bit-identical; (iii) splitting
+    the targets in two and taking the element-wise min reproduces the joint result."""
+    torch = gp["torch"]
+    for n in (16384, 32768):
+        a, b = gen_pair(n, (1, n, 3), (1, n, 3))
+        A, B = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        d1, d2, i1, i2 = gp["cd"](A, A.clone())
+        assert float(d1.abs().max()) == 0 and bool((i1[0] == torch.arange(n, device="cuda", dtype=torch.int32)).all())
+        d1, d2, i1, i2 = gp["cd"](A, B)
+        perm = torch.randperm(n, device="cuda")
+        p1, p2, j1, j2 = gp["cd"](A, B[:, perm])
+        assert torch.equal(p1, d1) and torch.equal(perm[j1[0].long()].int(), i1[0])
+        h = n // 2 + 37
+        l1, _, li, _ = gp["cd"](A, B[:, :h].contiguous())
+        r1, _, ri, _ = gp["cd"](A, B[:, h:].contiguous())
+        take_r = r1 < l1
+        assert torch.equal(torch.where(take_r, r1, l1), d1)
+        assert torch.equal(torch.where(take_r, ri + h, li), i1)

@@ -1,0 +1,171 @@
+"""Cross-checks the C oracle against independent restatements: plain numpy fp32
+(no FMA: equals oracle mode 0 bit for bit), float64 brute force, analytic
+gradients, a pure-Python auction, and scipy's exact assignment as a bound."""
+import numpy as np
+import pytest
+
+from conftest import gen_pair
+
+
+def np_chamfer(a, b):
+    """fp32, dx = target - query, (dx*dx + dy*dy) + dz*dz, first arg-min."""
+    d = b[:, None, :, :] - a[:, :, None, :]           # [B,N,M,3]
+    sq = d * d
+    D = (sq[..., 0] + sq[..., 1]) + sq[..., 2]
+    return D.min(axis=2), D.argmin(axis=2).astype(np.int32)
+
+
+@pytest.mark.parametrize("shape", [((2, 257, 3), (2, 129, 3)), ((1, 3, 3), (1, 700, 3)), ((3, 64, 3), (3, 1, 3))])
+def test_chamfer_matches_numpy_fp32(oracle, shape):
+    a, b = gen_pair(3, *shape)
+    d1, d2, i1, i2 = oracle.chamfer_forward(a, b, 0)
+    nd1, ni1 = np_chamfer(a, b)
+    nd2, ni2 = np_chamfer(b, a)
+    np.testing.assert_array_equal(d1, nd1)
+    np.testing.assert_array_equal(i1, ni1)
+    np.testing.assert_array_equal(d2, nd2)
+    np.testing.assert_array_equal(i2, ni2)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_chamfer_close_to_float64(oracle, mode):
+    a, b = gen_pair(4, (1, 500, 3), (1, 400, 3))
+    d1, _, i1, _ = oracle.chamfer_forward(a, b, mode)
+    D = ((b.astype(np.float64)[:, None] - a.astype(np.float64)[:, :, None]) ** 2).sum(-1)
+    np.testing.assert_allclose(d1, D.min(axis=2), rtol=3e-7)
+    # the fp32 arg-min may differ from the fp64 one only at near-ties
+    picked = np.take_along_axis(D, i1[..., None].astype(np.int64), axis=2)[..., 0]
+    np.testing.assert_allclose(picked, D.min(axis=2), rtol=1e-6)
+
+
+def test_chamfer_duplicate_targets_lowest_index(oracle):
+    a, b = gen_pair(5, (1, 50, 3), (1, 40, 3))
+    b[0, 20:40] = b[0, 0:20]
+    _, _, i1, _ = oracle.chamfer_forward(b[:, :20].copy(), b, 0)
+    np.testing.assert_array_equal(i1[0], np.arange(20))
+    _, _, i1, _ = oracle.chamfer_forward(a, b, 1)
+    assert i1.max() < 20
+
+
+def test_chamfer_backward_analytic(oracle):
+    a, b = gen_pair(6, (2, 120, 3), (2, 90, 3))
+    d1, d2, i1, i2 = oracle.chamfer_forward(a, b, 0)
+    rng = np.random.default_rng(0)
+    g1 = rng.random(d1.shape, dtype=np.float32)
+    g2 = rng.random(d2.shape, dtype=np.float32)
+    gx1, gx2 = oracle.chamfer_backward(a, b, g1, g2, i1, i2)
+    A, Bm = a.astype(np.float64), b.astype(np.float64)
+    e1 = np.zeros_like(A)
+    e2 = np.zeros_like(Bm)
+    for bi in range(a.shape[0]):
+        for j in range(a.shape[1]):
+            v = 2 * g1[bi, j] * (A[bi, j] - Bm[bi, i1[bi, j]])
+            e1[bi, j] += v
+            e2[bi, i1[bi, j]] -= v
+        for k in range(b.shape[1]):
+            v = 2 * g2[bi, k] * (Bm[bi, k] - A[bi, i2[bi, k]])
+            e2[bi, k] += v
+            e1[bi, i2[bi, k]] -= v
+    np.testing.assert_allclose(gx1, e1, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gx2, e2, rtol=1e-5, atol=1e-6)
+
+
+def py_auction(x1, x2, eps, iters):
+    """Straight restatement of SURVEY.md appendix B for one batch element
+    (plain first-index arg-max; valid when bid values do not tie exactly)."""
+    n = x1.shape[0]
+    ass = np.full(n, -1, np.int64)
+    inv = np.full(n, -1, np.int64)
+    price = np.zeros(n, np.float32)
+    max_inc = np.zeros(n, np.float32)
+    max_idx = np.zeros(n, np.int64)
+    bid = np.zeros(n, np.int64)
+    inc = np.zeros(n, np.float32)
+    for it in range(iters):
+        last = it == iters - 1
+        U = np.nonzero(ass == -1)[0]
+        for j in U:
+            d = x2 - x1[j]
+            sq = d * d
+            s = (sq[:, 0] + sq[:, 1]) + sq[:, 2]
+            v = ((3.0 - np.sqrt(s).astype(np.float64)) - price.astype(np.float64)).astype(np.float32)
+            order = np.argsort(-v, kind="stable")
+            best, better = v[order[0]], v[order[1]]
+            bid[j] = order[0]
+            inc[j] = np.float32(np.float32(best - better) + np.float32(eps))
+            max_inc[bid[j]] = max(max_inc[bid[j]], inc[j])
+        for j in U:
+            if abs(float(inc[j]) - float(max_inc[bid[j]])) <= 1e-6:
+                max_idx[bid[j]] = j
+        for j in U:
+            b = bid[j]
+            if last or max_idx[b] == j:
+                prev = inv[b]
+                if not last and prev != -1:
+                    ass[prev] = -1
+                inv[b] = j
+                ass[j] = b
+                price[b] = np.float32(price[b] + inc[j])
+                max_inc[b] = np.float32(-1e9)
+    d = x1 - x2[ass]
+    sq = d * d
+    return (sq[:, 0] + sq[:, 1]) + sq[:, 2], ass.astype(np.int32)
+
+
+def test_emd_matches_python_auction(oracle):
+    a, b = gen_pair(8, (1, 256, 3), (1, 256, 3), 0.0)
+    d, ass = oracle.emd_forward(a, b, 0.005, 12, 0)
+    pd, pass_ = py_auction(a[0], b[0], 0.005, 12)
+    np.testing.assert_array_equal(ass[0], pass_)
+    np.testing.assert_array_equal(d[0], pd)
+
+
+def test_emd_converged_close_to_exact_assignment(oracle, golden):
+    from scipy.optimize import linear_sum_assignment
+    g = golden("emd_seed2_b1_256_conv.npz")
+    a, b = g["xyz1"], g["xyz2"]
+    d, ass = oracle.emd_forward(a, b, float(g["eps"]), int(g["iters"]), 0)
+    assert len(np.unique(ass[0])) == 256                      # converged: a bijection
+    C = np.sqrt(((a[0][:, None].astype(np.float64) - b[0][None].astype(np.float64)) ** 2).sum(-1))
+    r, c = linear_sum_assignment(C)
+    exact = C[r, c].mean()
+    got = float(np.sqrt(d).mean())
+    assert exact <= got + 1e-7 and got - exact < 0.002 * 3     # eps-optimality of the auction
+
+
+def test_emd_dist_consistent_with_assignment(oracle):
+    a, b = gen_pair(10, (2, 512, 3), (2, 512, 3), 0.0)
+    for mode in (0, 1):
+        d, ass = oracle.emd_forward(a, b, 0.005, 30, mode)
+        pick = np.take_along_axis(b, ass[..., None].astype(np.int64), axis=1)
+        e = (a.astype(np.float64) - pick) ** 2
+        np.testing.assert_allclose(d, e.sum(-1), rtol=1e-6, atol=1e-12)
+        assert (ass >= 0).all() and (ass < 512).all()
+
+
+def test_emd_backward(oracle):
+    a, b = gen_pair(12, (2, 256, 3), (2, 256, 3), 0.0)
+    d, ass = oracle.emd_forward(a, b, 0.005, 10)
+    g = np.random.default_rng(1).random(d.shape, dtype=np.float32)
+    gx = oracle.emd_backward(a, b, g, ass)
+    pick = np.take_along_axis(b, ass[..., None].astype(np.int64), axis=1)
+    np.testing.assert_allclose(gx, 2 * g[..., None] * (a - pick), rtol=1e-6, atol=1e-7)
+
+
+def test_fps_and_ply_reader(oracle, tmp_path):
+    pts = np.random.default_rng(3).random((500, 3))
+    p = tmp_path / "t.ply"
+    with open(p, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\ncomment x\nelement vertex 500\n"
+                b"property double x\nproperty double y\nproperty double z\nend_header\n")
+        f.write(pts.astype("<f8").tobytes())
+    np.testing.assert_array_equal(oracle.read_ply_xyz(str(p)), pts)
+    x = pts.astype(np.float32)
+    idx = oracle.fps(x, 32)
+    assert idx[0] == 0 and len(set(idx.tolist())) == 32
+    # each pick is the farthest point from the set picked so far
+    d = np.full(500, np.inf, np.float32)
+    for s in range(31):
+        dd = ((x - x[idx[s]]) ** 2)
+        d = np.minimum(d, (dd[:, 0] + dd[:, 1]) + dd[:, 2])
+        assert idx[s + 1] == int(np.argmax(d))

@@ -1,0 +1,133 @@
+// ubench_valu.hip -- VALU issue-rate microbenchmarks for gfx950 (MI355X).
+// Establishes the slot model DESIGN.md uses for the VALU-bound NN kernels:
+// how many lane-operations per clock per CU each instruction class sustains.
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o tools/ubench_valu && tools/ubench_valu
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+constexpr int ITERS = 4096;
+typedef float float2_ __attribute__((ext_vector_type(2)));
+
+#define BODY8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k(float *out, float s0, float s1)
+{
+    float v[8];
+    float2_ p[8];
+    double dv[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { v[i] = threadIdx.x * 1e-3f + i; p[i] = float2_{v[i], v[i] + 1}; dv[i] = v[i]; }
+    float a = s0, b = s1;
+    float2_ pa = {s0, s1}, pb = {s1, s0};
+    for (int it = 0; it < ITERS; it++) {
+        if (KIND == 0) {            // v_fma_f32, VGPR operands
+#define OP(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 1) {     // v_pk_fma_f32
+#define OP(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pa), "v"(pb));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 2) {     // v_sub_f32 with SGPR operand
+#define OP(i) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(v[i]) : "s"(s0));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 3) {     // v_min3_f32
+#define OP(i) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 4) {     // v_pk_add_f32
+#define OP(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pa));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 5) {     // v_pk_mul_f32
+#define OP(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pa));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 6) {     // v_sqrt_f32 (transcendental)
+#define OP(i) asm volatile("v_sqrt_f32 %0, %0" : "+v"(v[i]));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 7) {     // v_add_f64
+#define OP(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(dv[i]) : "v"((double)1.0));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 8) {     // v_cvt_f64_f32 + v_cvt_f32_f64 pair
+#define OP(i) asm volatile("v_cvt_f64_f32 %0, %1\n v_cvt_f32_f64 %1, %0" : "+v"(dv[i]), "+v"(v[i]));
+            BODY8(OP)
+#undef OP
+        } else if (KIND == 9) {     // v_cmp_lt_f32 + v_cndmask_b32 pair
+#define OP(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(v[i]) : "v"(a), "v"(b) : "vcc");
+            BODY8(OP)
+#undef OP
+        } else if (KIND == 10) {    // dependent chain: v_fma_f32 on ONE register
+            asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                         "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                         "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                         "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                         : "+v"(v[0]) : "v"(a), "v"(b));
+        } else if (KIND == 11) {    // v_med3_f32
+#define OP(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 12) {    // v_fmac_f32 e32 (2-operand encoding)
+#define OP(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        }
+    }
+    float acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc += v[i] + p[i].x + p[i].y + (float)dv[i];
+    if (acc == 12345.678f) out[0] = acc;
+}
+
+struct Case { const char *name; void (*fn)(float *, float, float); int ops_per_iter; int results_per_op; };
+
+int main()
+{
+    float *d;
+    CHECK(hipMalloc(&d, 1024));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s CUs %d clock %d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
+    Case cases[] = {
+        {"v_fma_f32 (vgpr)", k<0>, 16, 1}, {"v_pk_fma_f32", k<1>, 16, 2}, {"v_sub_f32 (sgpr src)", k<2>, 16, 1},
+        {"v_min3_f32", k<3>, 16, 1}, {"v_pk_add_f32", k<4>, 16, 2}, {"v_pk_mul_f32", k<5>, 16, 2},
+        {"v_sqrt_f32", k<6>, 16, 1}, {"v_add_f64", k<7>, 16, 1}, {"cvt f32<->f64 pair", k<8>, 16, 1},
+        {"v_cmp+v_cndmask pair", k<9>, 16, 1}, {"v_fma_f32 dependent chain", k<10>, 16, 1},
+        {"v_med3_f32", k<11>, 16, 1}, {"v_fmac_f32 e32", k<12>, 16, 1},
+    };
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int waves_per_simd : {1, 2, 4, 8}) {
+        int blocks = prop.multiProcessorCount * waves_per_simd;   // 256 thr = 4 waves = 1 per SIMD
+        printf("--- %d wave(s) per SIMD (%d blocks x 256)\n", waves_per_simd, blocks);
+        for (auto &c : cases) {
+            hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(256), 0, 0, d, 1.0f, 0.5f);
+            CHECK(hipDeviceSynchronize());
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; rep++) {
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(256), 0, 0, d, 1.0f, 0.5f);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            double insts = (double)blocks * 4 /*waves*/ * ITERS * c.ops_per_iter;      // wave-instructions
+            double lane_ops = insts * 64;
+            double per_s = lane_ops / (best * 1e-3);
+            printf("%-28s %8.3f ms  %7.2f T lane-inst/s  %6.2f lane-inst/clk/CU @2.4GHz  (x%d results)\n", c.name, best,
+                   per_s * 1e-12, per_s / (prop.multiProcessorCount * 2.4e9), c.results_per_op);
+        }
+    }
+    return 0;
+}
