@@ -1,36 +1,47 @@
 // chamfer.hip -- brute-force nearest neighbour (Chamfer3D forward/backward) for
 // gfx950.  Replaces loss_functions/Chamfer3D/chamfer3D.cu of the reference.
 //
-// Forward design (VALU-bound: ~6.5 fp32 issue slots per (query,target) pair,
-// 12 B of target per 64*R pairs -- HBM is idle):
-//   * a wave owns 64*R queries held in VGPRs (R per lane) and walks a slice of
-//     the targets; target coordinates are wave-uniform, so they are fetched
-//     with SCALAR loads (s_load_dwordxN through the scalar cache) and consumed
-//     as SGPR operands -- no LDS, no barriers, no VGPRs spent on targets;
-//   * both directions (A->B, B->A), all batch elements, all query chunks and
-//     all target slices are ONE launch; the grid is sized from the problem
-//     (the reference's fixed 32x16 grid leaves 94 % of an MI355X idle at B=1);
-//   * the running minimum stays in registers for the whole slice (the
-//     reference read-modify-writes result[] in global memory every 512 targets);
-//   * the inner loop tracks only the minimum VALUE per chunk of kChunk targets
-//     (v_min3_f32: half a slot per pair); the chunk that produced a new
-//     minimum is remembered and re-scanned once at the end to recover the
-//     FIRST index attaining it, which is the reference's strict-'<' tie-break
-//     (chamfer3D.cu:36,46,56,66,119,126);
+// Forward design.  The kernel is VALU-bound (6.5 kflop per HBM byte).
+// Measured issue model on MI355X (tools/ubench_valu.hip): v_fma/v_mul/v_add/v_sub
+// f32 with VGPR operands issue at ~105 lane-ops/clk/CU; every instruction with an
+// SGPR operand, v_min/v_min3/v_cmp/v_cndmask, packed-f32 and f64 ops issue at half
+// of that.  Hence:
+//   * a lane owns R queries in VGPRs; targets are staged per block in LDS (groups
+//     of four as x0..x3|y0..y3|z0..z3) and read with uniform-address (broadcast)
+//     ds_read_b128 -- three reads deliver four targets -- so that the
+//     three subtractions per pair keep VGPR operands and stay full rate (fetching
+//     the wave-uniform targets through the scalar cache as SGPR operands costs 10
+//     issue units per pair instead of 7 -- measured 1.4x slower at large batch);
+//   * the inner loop tracks only the minimum VALUE of a chunk of kChunk targets
+//     (one v_min3 per two pairs); per tile the chunk that produced a new minimum
+//     is re-scanned in LDS to recover the FIRST index attaining it, which is the
+//     reference's strict-'<' tie-break (chamfer3D.cu:36,46,56,66,119,126);
+//     per pair: 3 sub + mul + 2 fma (full rate) + 1/2 min3 (half rate) = 7 units;
+//   * both directions (A->B, B->A), all batch elements, all query blocks and all
+//     target slices are ONE launch sized from the problem (the reference's fixed
+//     32x16 grid leaves 94 % of an MI355X idle at B=1); the running minimum never
+//     leaves registers (the reference read-modify-writes result[] in global
+//     memory every 512 targets);
 //   * when targets are split into S>1 slices for occupancy, per-slice
-//     (min,argmin) go to scratch and a merge kernel folds them in slice order
-//     with strict '<' (earlier slice == lower index wins), so results do not
-//     depend on S.
-// Arithmetic is written with explicit __fmaf_rn/__fmul_rn/__fadd_rn so the
-// compiler cannot re-associate or contract differently from oracle/genpc_oracle.c.
+//     (min,argmin) go to scratch and the LAST block to finish a query block folds
+//     them in slice order with strict '<' (earlier slice == lower index wins), so
+//     results do not depend on S and no second launch is needed.  The hand-off is
+//     the agent-scope release -> ticket -> acquire recipe (per-XCD L2s are not
+//     coherent with each other).
+// Arithmetic is written with explicit __fmaf_rn/__fmul_rn/__fadd_rn and the file
+// is compiled with -ffp-contract=off, so the compiler cannot re-associate or
+// contract differently from oracle/genpc_oracle.c.
 #include "common.h"
 #include "../../include/genpc_hip.h"
 
+#include <stdlib.h>
+
 namespace genpc {
 
-constexpr int kChunk = 32;      // targets per min-only chunk (re-scan granularity)
-constexpr int kBlock = 256;     // 4 waves
+constexpr int kChunk = 32;       // targets per min-only chunk (re-scan granularity)
+constexpr int kBlock = 256;      // 4 waves
 constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kTile = 2048;      // targets per LDS tile (24 KiB: 12 B per target)
 
 template <int FMA>
 __device__ __forceinline__ float sqdist(float dx, float dy, float dz)
@@ -50,12 +61,14 @@ __device__ __forceinline__ float sqdist(float dx, float dy, float dz)
 struct NNDir {
     const float *q;    // queries  [B, nq, 3]
     const float *t;    // targets  [B, nt, 3]
-    float *out_d;      // [B, nq]            (S == 1) or scratch [S, B*nq]
+    float *out_d;      // final    [B, nq]
     int *out_i;
+    float *part_d;     // per-slice partials [S, B*nq] (S > 1)
+    int *part_i;
     int nq, nt;
-    int qchunks;       // ceil(nq / (64*R))
-    int wave_begin;    // first global wave id of this direction
-    int nwaves;        // slices * b * qchunks
+    int qblocks;       // ceil(nq / (256*R))
+    int block_begin;   // first block id of this direction
+    int unit_begin;    // first arrival counter of this direction
 };
 
 struct NNArgs {
@@ -64,25 +77,25 @@ struct NNArgs {
     int b;
     int slices;        // S
     int slice_len;     // targets per slice, multiple of kChunk
-    int total_waves;
+    int *arrive;       // [sum_d b*qblocks] arrival counters, zero between launches
+    int debug;         // experiment switches (GENPC_NN_DEBUG): 1 skip index recovery, 2 skip merge, 4 skip main loop
 };
 
-// One wave = one (direction, batch, query chunk, target slice) unit.
-// Waves of a block take consecutive query chunks of the SAME slice so that
-// they stream the same target bytes through the scalar cache together.
+// One block = one (direction, target slice, batch, 256*R-query block) unit; wave w
+// of the block owns queries [w*64*R, (w+1)*64*R) of that block.
 template <int R, int FMA>
 __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
 {
+    __shared__ float4 tile[kTile / 4 * 3 + 3];      // + one spare group for the pipeline's last prefetch
     const int lane = threadIdx.x & (kWave - 1);
-    int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)));
-    if (wid >= a.total_waves) return;
-    const int d = (a.ndir > 1 && wid >= a.dir[1].wave_begin) ? 1 : 0;
+    const int wave = threadIdx.x >> 6;
+    int bid = blockIdx.x;
+    const int d = (a.ndir > 1 && bid >= a.dir[1].block_begin) ? 1 : 0;
     const NNDir &D = a.dir[d];
-    wid -= D.wave_begin;
-    if (wid >= D.nwaves) return;
-    // wid = (slice * b + batch) * qchunks + qchunk
-    const int qc = wid % D.qchunks;
-    const int rest = wid / D.qchunks;
+    bid -= D.block_begin;
+    // bid = (slice * b + batch) * qblocks + qblock
+    const int qb = bid % D.qblocks;
+    const int rest = bid / D.qblocks;
     const int batch = rest % a.b;
     const int slice = rest / a.b;
 
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
 
     float qx[R], qy[R], qz[R], best[R];
     int bchunk[R];
-    const int q0 = qc * (kWave * R) + lane;
+    const int q0 = (qb * kWavesPerBlock + wave) * (kWave * R) + lane;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         int j = q0 + r * kWave;
@@ -108,94 +121,164 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
         bchunk[r] = k_begin;
     }
 
-    int k = k_begin;
-    // full chunks
-    for (; k + kChunk <= k_end; k += kChunk) {
-        const float *__restrict__ tp = T + (size_t)k * 3;
-        float m[R];
+    // LDS tile layout: groups of 4 targets as three float4s (x0..x3 | y0..y3 | z0..z3),
+    // so that every byte a ds_read_b128 fetches is used (12 B per target).
+    float *tile_f = (float *)tile;
+    for (int t0 = k_begin; t0 < k_end && !(a.debug & 4); t0 += kTile) {
+        const int tn = min(kTile, k_end - t0);
+        const int tn_pad = (tn + kChunk - 1) / kChunk * kChunk;
+        __syncthreads();                       // readers of the previous tile are done
+        for (int t = threadIdx.x; t < tn_pad; t += kBlock) {
+            float x, y, z;
+            if (t < tn) {
+                const float *tp = T + (size_t)(t0 + t) * 3;
+                x = tp[0]; y = tp[1]; z = tp[2];
+            } else {
+                // pad the ragged tail of the last chunk: a +inf distance never wins a strict '<'
+                x = y = z = __builtin_inff();
+            }
+            float *g = tile_f + (t >> 2) * 12 + (t & 3);
+            g[0] = x; g[4] = y; g[8] = z;
+        }
+        __syncthreads();
+
+        // Software pipeline: the three reads of group g+1 are issued before the
+        // VALU work of group g (the scheduler otherwise sinks each read next to its
+        // first use and every group eats a full LDS round trip).
+        float4 X = tile[0], Y = tile[1], Z = tile[2];
+        for (int c0 = 0; c0 < tn_pad; c0 += kChunk) {
+            const float4 *tl = tile + (c0 >> 2) * 3;
+            float m[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) m[r] = __builtin_inff();
+            for (int r = 0; r < R; r++) m[r] = __builtin_inff();
 #pragma unroll
-        for (int c = 0; c < kChunk; c += 2) {
-            const float ax = tp[c * 3 + 0], ay = tp[c * 3 + 1], az = tp[c * 3 + 2];
-            const float bx = tp[c * 3 + 3], by = tp[c * 3 + 4], bz = tp[c * 3 + 5];
+            for (int g = 0; g < kChunk / 4; g++) {
+                // one group past the end of the last chunk is read and dropped (the
+                // array has a spare group)
+                const float4 Xn = tl[g * 3 + 3], Yn = tl[g * 3 + 4], Zn = tl[g * 3 + 5];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const float d0 = sqdist<FMA>(X.x - qx[r], Y.x - qy[r], Z.x - qz[r]);
+                    const float d1 = sqdist<FMA>(X.y - qx[r], Y.y - qy[r], Z.y - qz[r]);
+                    const float d2 = sqdist<FMA>(X.z - qx[r], Y.z - qy[r], Z.z - qz[r]);
+                    const float d3 = sqdist<FMA>(X.w - qx[r], Y.w - qy[r], Z.w - qz[r]);
+                    m[r] = fminf(fminf(m[r], d0), d1);
+                    m[r] = fminf(fminf(m[r], d2), d3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                X = Xn; Y = Yn; Z = Zn;
+            }
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                float d0 = sqdist<FMA>(ax - qx[r], ay - qy[r], az - qz[r]);
-                float d1 = sqdist<FMA>(bx - qx[r], by - qy[r], bz - qz[r]);
-                m[r] = fminf(fminf(m[r], d0), d1);
+                const bool lt = m[r] < best[r];
+                best[r] = lt ? m[r] : best[r];
+                bchunk[r] = lt ? t0 + c0 : bchunk[r];
             }
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            bool lt = m[r] < best[r];
-            best[r] = lt ? m[r] : best[r];
-            bchunk[r] = lt ? k : bchunk[r];
-        }
-    }
-    // ragged tail (< kChunk targets)
-    if (k < k_end) {
-        float m[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) m[r] = __builtin_inff();
-        for (int kk = k; kk < k_end; kk++) {
-            const float ax = T[(size_t)kk * 3 + 0], ay = T[(size_t)kk * 3 + 1], az = T[(size_t)kk * 3 + 2];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                float d0 = sqdist<FMA>(ax - qx[r], ay - qy[r], az - qz[r]);
-                m[r] = fminf(m[r], d0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            bool lt = m[r] < best[r];
-            best[r] = lt ? m[r] : best[r];
-            bchunk[r] = lt ? k : bchunk[r];
         }
     }
 
-    // Recover the first index attaining best[r] inside the remembered chunk
-    // (per-lane gather; kChunk pairs per query, once per slice).
-    float *__restrict__ od = D.out_d + ((size_t)slice * a.b + batch) * nq;
-    int *__restrict__ oi = D.out_i + ((size_t)slice * a.b + batch) * nq;
+    if (a.slices > 1) {
+        // Publish this slice's (minimum, chunk) per query; the last block to arrive for
+        // this (direction, batch, query block) folds all S slices in slice order with
+        // strict '<' (earlier slice == lower index wins) and carries on alone.
+        const size_t bnq = (size_t)a.b * nq;
+        {
+            float *__restrict__ pd = D.part_d + (size_t)slice * bnq + (size_t)batch * nq;
+            int *__restrict__ pi = D.part_i + (size_t)slice * bnq + (size_t)batch * nq;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int j = q0 + r * kWave;
+                if (j < nq) {
+                    pd[j] = best[r];
+                    pi[j] = bchunk[r];
+                }
+            }
+        }
+        if (a.debug & 2) return;
+        int *cnt = a.arrive + D.unit_begin + batch * D.qblocks + qb;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int *s_ticket = (int *)tile;      // the tile is dead after the barrier above (one LDS object)
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (*s_ticket != a.slices - 1) return;
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        const float *pd = D.part_d + (size_t)batch * nq;
+        const int *pi = D.part_i + (size_t)batch * nq;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            int j = q0 + r * kWave;
+            j = j < nq ? j : nq - 1;
+            float bv = pd[j];
+            int bc = pi[j];
+            for (int s2 = 1; s2 < a.slices; s2++) {
+                const float v = pd[(size_t)s2 * bnq + j];
+                const int vc = pi[(size_t)s2 * bnq + j];
+                const bool lt = v < bv;
+                bv = lt ? v : bv;
+                bc = lt ? vc : bc;
+            }
+            best[r] = bv;
+            bchunk[r] = bc;
+        }
+    }
+
+    // Recover the FIRST index attaining best[r] inside the remembered chunk: same
+    // operands, same operations => bitwise-equal distance.  Done once per query (by
+    // the merging block when the targets were sliced), from global memory, as 24
+    // 16-byte loads per query.  Positions past the end of the cloud are clamped to
+    // its last target; positions past the end of the chunk's slice belong to the
+    // next slice.  Either can only match at a HIGHER position than the true first
+    // index, which lies inside the slice, and the lowest match wins.
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    float *__restrict__ od = D.out_d + (size_t)batch * nq;
+    int *__restrict__ oi = D.out_i + (size_t)batch * nq;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int base = bchunk[r];
-        int idx = base;
-        for (int c = kChunk - 1; c >= 0; c--) {
-            int kk = base + c;
-            if (kk < k_end) {
-                const float tx = T[(size_t)kk * 3 + 0], ty = T[(size_t)kk * 3 + 1], tz = T[(size_t)kk * 3 + 2];
-                float dd = sqdist<FMA>(tx - qx[r], ty - qy[r], tz - qz[r]);
-                idx = (dd == best[r]) ? kk : idx;
+        int first = 0;
+        if (!(a.debug & 1)) {
+            if (base + kChunk <= nt) {
+                const f4u *tp = (const f4u *)(T + (size_t)base * 3);
+#pragma unroll
+                for (int c8 = kChunk - 8; c8 >= 0; c8 -= 8) {
+                    f4u v[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) v[i] = tp[(c8 >> 2) * 3 + i];
+                    const float f[24] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
+                                         v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w,
+                                         v[4].x, v[4].y, v[4].z, v[4].w, v[5].x, v[5].y, v[5].z, v[5].w};
+#pragma unroll
+                    for (int c = 7; c >= 0; c--) {
+                        const float dd = sqdist<FMA>(f[c * 3 + 0] - qx[r], f[c * 3 + 1] - qy[r], f[c * 3 + 2] - qz[r]);
+                        first = (dd == best[r]) ? c8 + c : first;
+                    }
+                }
+            } else {
+                for (int c = kChunk - 1; c >= 0; c--) {
+                    int kk = base + c;
+                    kk = kk < nt ? kk : nt - 1;
+                    const float *tp = T + (size_t)kk * 3;
+                    const float dd = sqdist<FMA>(tp[0] - qx[r], tp[1] - qy[r], tp[2] - qz[r]);
+                    first = (dd == best[r]) ? c : first;
+                }
             }
         }
         const int j = q0 + r * kWave;
         if (j < nq) {
             od[j] = best[r];
-            oi[j] = idx;
+            oi[j] = base + first;
         }
     }
-}
-
-// Folds S per-slice partials in slice order; strict '<' keeps the lower index.
-__global__ __launch_bounds__(kBlock) void nn_merge_kernel(const float *__restrict__ pd, const int *__restrict__ pi,
-                                                          float *__restrict__ out_d, int *__restrict__ out_i,
-                                                          int total, int slices)
-{
-    int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= total) return;
-    float best = pd[j];
-    int bi = pi[j];
-    for (int s = 1; s < slices; s++) {
-        float v = pd[(size_t)s * total + j];
-        int vi = pi[(size_t)s * total + j];
-        bool lt = v < best;
-        best = lt ? v : best;
-        bi = lt ? vi : bi;
-    }
-    out_d[j] = best;
-    out_i[j] = bi;
 }
 
 // Chamfer backward, both directions in one launch (chamfer3D.cu:155-195).
@@ -236,26 +319,32 @@ __global__ __launch_bounds__(kBlock) void chamfer_grad_kernel(int b, int n, cons
     atomicAdd(&O2[j2 * 3 + 2], -vz);
 }
 
-constexpr int kR = 4;   // queries per lane
+struct NNConfig {
+    int r;                // queries per lane: 0 = pick, else 2 or 4
+    int blocks_per_cu;    // occupancy target used to pick the slice count
+};
 
-template <int FMA>
-static bool launch_forward(const NNArgs &a, hipStream_t st)
+// Tunables; GENPC_NN_R / GENPC_NN_WPS override for experiments.
+static NNConfig nn_config()
 {
-    int blocks = ceil_div(a.total_waves, kWavesPerBlock);
-    hipLaunchKernelGGL((nn_forward_kernel<kR, FMA>), dim3(blocks), dim3(kBlock), 0, st, a);
-    return check(hipGetLastError(), "nn_forward_kernel launch");
+    static NNConfig c = [] {
+        NNConfig k{0, 4};
+        if (const char *e = getenv("GENPC_NN_R")) k.r = atoi(e);
+        if (const char *e = getenv("GENPC_NN_WPS")) k.blocks_per_cu = atoi(e);
+        if (k.r != 2 && k.r != 4) k.r = 0;
+        if (k.blocks_per_cu < 1) k.blocks_per_cu = 1;
+        return k;
+    }();
+    return c;
 }
 
-// Slices: enough waves to give every SIMD a few, never slices shorter than 8 chunks.
-static int pick_slices(long long waves_unsplit, int nt_max)
+template <int R>
+static void launch_r(const NNArgs &a, int blocks, hipStream_t st)
 {
-    const long long want = (long long)kNumSIMD * 4;
-    if (waves_unsplit >= want) return 1;
-    long long s = ceil_div64(want, waves_unsplit > 0 ? waves_unsplit : 1);
-    long long max_s = nt_max / (kChunk * 8);
-    if (max_s < 1) max_s = 1;
-    if (s > max_s) s = max_s;
-    return (int)s;
+    if (arith_mode() != 0)
+        hipLaunchKernelGGL((nn_forward_kernel<R, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
+    else
+        hipLaunchKernelGGL((nn_forward_kernel<R, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
 }
 
 static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0, float *d0, int *i0,
@@ -263,77 +352,88 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
 {
     // A direction with no queries or no targets does nothing (the reference's
     // loops do not execute, outputs keep the caller's zeros).
+    const NNConfig cfg = nn_config();
     NNArgs a{};
     a.b = b;
+    static const int dbg = getenv("GENPC_NN_DEBUG") ? atoi(getenv("GENPC_NN_DEBUG")) : 0;
+    a.debug = dbg;
     const float *qs[2] = {q0, q1};
     const float *ts[2] = {t0, t1};
     float *ds[2] = {d0, d1};
     int *is[2] = {i0, i1};
     int nqs[2] = {n0, n1}, nts[2] = {m0, m1};
     int nd = 0;
-    long long waves = 0;
     int nt_max = 0;
     for (int d = 0; d < ndir; d++) {
         if (b <= 0 || nqs[d] <= 0 || nts[d] <= 0) continue;
         NNDir &D = a.dir[nd++];
         D.q = qs[d]; D.t = ts[d]; D.out_d = ds[d]; D.out_i = is[d];
         D.nq = nqs[d]; D.nt = nts[d];
-        D.qchunks = ceil_div(D.nq, kWave * kR);
-        waves += (long long)b * D.qchunks;
         if (D.nt > nt_max) nt_max = D.nt;
     }
     a.ndir = nd;
     if (nd == 0) return 1;
-    const int S = pick_slices(waves, nt_max);
-    a.slices = S;
-    a.slice_len = ceil_div(ceil_div(nt_max, S), kChunk) * kChunk;
-    // recompute S so that no slice is empty for the LONGEST target set; shorter
-    // target sets may have empty trailing slices (they write +inf, merged away).
+    // Slices are never shorter than 8 chunks.  R = 4 (fewer LDS reads per pair, more
+    // independent chains per lane) when the query blocks alone fill the chip; R = 2
+    // otherwise: twice the blocks, half the per-wave epilogue (measured on MI355X:
+    // 1x16384^2 87 us vs 97 us, 13x16384^2 870 us vs 835 us).
+    long long max_s = nt_max / (kChunk * 8);
+    if (max_s < 1) max_s = 1;
+    const long long want_blocks = (long long)kNumCU * cfg.blocks_per_cu;
+    int r = cfg.r;
+    if (!r) {
+        long long unsplit4 = 0;
+        for (int d = 0; d < nd; d++) unsplit4 += (long long)b * ceil_div(a.dir[d].nq, kBlock * 4);
+        r = unsplit4 >= kNumCU ? 4 : 2;
+    }
+    long long unsplit = 0;
+    for (int d = 0; d < nd; d++) unsplit += (long long)b * ceil_div(a.dir[d].nq, kBlock * r);
+    long long S = 1;
+    if (unsplit < want_blocks) S = ceil_div64(want_blocks, unsplit);
+    if (S > max_s) S = max_s;
+    a.slice_len = ceil_div(ceil_div(nt_max, (int)S), kChunk) * kChunk;
+    // no slice is empty for the LONGEST target set; a shorter target set may have
+    // empty trailing slices (they produce +inf and lose every strict '<')
     a.slices = ceil_div(nt_max, a.slice_len);
-    float *final_d[2] = {nullptr, nullptr};
-    int *final_i[2] = {nullptr, nullptr};
-    if (a.slices > 1) {
-        size_t tot = 0;
-        for (int d = 0; d < nd; d++) tot += (size_t)a.slices * b * a.dir[d].nq;
-        char *ws = (char *)workspace(0, tot * 8, st);
-        if (!ws) return 0;
-        float *wd = (float *)ws;
-        int *wi = (int *)(ws + tot * 4);
-        size_t off = 0;
-        for (int d = 0; d < nd; d++) {
-            final_d[d] = a.dir[d].out_d;
-            final_i[d] = a.dir[d].out_i;
-            a.dir[d].out_d = wd + off;
-            a.dir[d].out_i = wi + off;
-            off += (size_t)a.slices * b * a.dir[d].nq;
-        }
-    }
-    long long tw = 0;
+    long long tb = 0;
+    int units = 0;
+    size_t part = 0;
     for (int d = 0; d < nd; d++) {
-        // round each direction up to whole blocks so that the waves of a block
-        // share a slice and a direction
-        a.dir[d].wave_begin = (int)tw;
-        long long w = (long long)a.slices * b * a.dir[d].qchunks;
-        a.dir[d].nwaves = (int)w;
-        tw += ceil_div64(w, kWavesPerBlock) * kWavesPerBlock;
+        NNDir &D = a.dir[d];
+        D.qblocks = ceil_div(D.nq, kBlock * r);
+        D.block_begin = (int)tb;
+        D.unit_begin = units;
+        tb += (long long)a.slices * b * D.qblocks;
+        units += b * D.qblocks;
+        part += (size_t)a.slices * b * D.nq;
     }
-    if (tw > 0x7fffffffLL / 2) {
+    if (tb > 0x7fffffffLL) {
         set_error("chamfer: problem too large for one launch");
         return 0;
     }
-    a.total_waves = (int)tw;
-    bool ok = arith_mode() ? launch_forward<1>(a, st) : launch_forward<0>(a, st);
-    if (!ok) return 0;
     if (a.slices > 1) {
-        for (int d = 0; d < nd; d++) {
-            int total = b * a.dir[d].nq;
-            hipLaunchKernelGGL(nn_merge_kernel, dim3(ceil_div(total, kBlock)), dim3(kBlock), 0, st,
-                               (const float *)a.dir[d].out_d, (const int *)a.dir[d].out_i, final_d[d], final_i[d],
-                               total, a.slices);
+        // [arrival counters | partial distances | partial indices]; counters are
+        // zeroed when the block is (re)allocated and restored to zero by the merging
+        // block, so steady-state calls need no memset.
+        const size_t cnt_bytes = (size_t)1 << 16;
+        if ((size_t)units * sizeof(int) > cnt_bytes) {
+            set_error("chamfer: too many query blocks for the arrival-counter area");
+            return 0;
         }
-        if (!check(hipGetLastError(), "nn_merge_kernel launch")) return 0;
+        char *ws = (char *)workspace(0, cnt_bytes + part * 8, st, nullptr, cnt_bytes);
+        if (!ws) return 0;
+        a.arrive = (int *)ws;
+        float *wd = (float *)(ws + cnt_bytes);
+        int *wi = (int *)(ws + cnt_bytes + part * 4);
+        size_t off = 0;
+        for (int d = 0; d < nd; d++) {
+            a.dir[d].part_d = wd + off;
+            a.dir[d].part_i = wi + off;
+            off += (size_t)a.slices * b * a.dir[d].nq;
+        }
     }
-    return 1;
+    if (r == 4) launch_r<4>(a, (int)tb, st); else launch_r<2>(a, (int)tb, st);
+    return check(hipGetLastError(), "nn_forward_kernel launch") ? 1 : 0;
 }
 
 }  // namespace genpc

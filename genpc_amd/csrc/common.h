@@ -22,7 +22,9 @@ void set_error(const char *msg);
 // Stream-ordered use only: every consumer is enqueued on the same stream as
 // its producer, so reuse across calls on one stream is safe; calls on different
 // streams of one device get different slots.
-void *workspace(int slot, size_t bytes, hipStream_t stream);
+// If `zero_prefix` > 0 the first zero_prefix bytes of a NEWLY allocated block are
+// zeroed (stream-ordered) and *fresh is set; an existing block is returned as is.
+void *workspace(int slot, size_t bytes, hipStream_t stream, bool *fresh = nullptr, size_t zero_prefix = 0);
 int arith_mode();
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -47,8 +47,10 @@ bool check(hipError_t e, const char *what)
 
 int arith_mode() { return g_arith; }
 
-void *workspace(int slot, size_t bytes, hipStream_t stream)
+void *workspace(int slot, size_t bytes, hipStream_t stream, bool *fresh, size_t zero_prefix)
 {
+    if (fresh) *fresh = false;
+    if (zero_prefix > bytes) bytes = zero_prefix;
     int dev = 0;
     if (!check(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
     std::lock_guard<std::mutex> l(g_mu);
@@ -71,6 +73,15 @@ void *workspace(int slot, size_t bytes, hipStream_t stream)
         g_err = buf;
         return nullptr;
     }
+    if (zero_prefix) {
+        if (zero_prefix > want) zero_prefix = want;
+        if (hipMemsetAsync(p, 0, zero_prefix, stream) != hipSuccess) {
+            (void)hipFree(p);
+            g_err = "hipMemsetAsync(workspace)";
+            return nullptr;
+        }
+    }
+    if (fresh) *fresh = true;
     s.ptr = p;
     s.bytes = want;
     return p;
@@ -101,12 +112,16 @@ GENPC_API int genpc_release_workspace(void)
 {
     std::lock_guard<std::mutex> l(genpc::g_mu);
     bool ok = true;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
     for (auto &kv : genpc::g_pool) {
         if (kv.second.ptr) {
             (void)hipSetDevice(kv.first.dev);
+            (void)hipDeviceSynchronize();
             ok &= (hipFree(kv.second.ptr) == hipSuccess);
         }
     }
+    (void)hipSetDevice(cur);
     genpc::g_pool.clear();
     return ok ? 1 : 0;
 }

@@ -57,7 +57,7 @@ template <int FMA>
 __device__ __forceinline__ float bid_value(float x1, float y1, float z1, float x2, float y2, float z2, float price)
 {
     float s = sqdist_e<FMA>(x2 - x1, y2 - y1, z2 - z1);
-    float r = __fsqrt_rn(s);
+    float r = sqrtf(s);   // correctly rounded (hipcc default); __fsqrt_rn is the ~1 ulp native sqrt
     return (float)((3.0 - (double)r) - (double)price);
 }
 

@@ -47,7 +47,7 @@ def test_golden_fixtures(gp, golden, name, mode):
     np.testing.assert_array_equal(s["assignment"], g[f"assignment_m{mode}"])
     np.testing.assert_array_equal(s["dist"], g[f"dist_m{mode}"])
     np.testing.assert_array_equal(s["assignment_inv"], g[f"assignment_inv_m{mode}"])
-    np.testing.assert_allclose(s["price"], g[f"price_m{mode}"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(s["price"], g[f"price_m{mode}"], rtol=1e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("shape,iters", [((1, 256), 1), ((1, 256), 2), ((3, 768), 17), ((2, 2048), 50),

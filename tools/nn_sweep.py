@@ -1,0 +1,51 @@
+"""Experiment driver: times genpc_chamfer_forward for kernel variants selected
+through GENPC_NN_* environment variables (one subprocess per variant, since the
+library reads them once).  python tools/nn_sweep.py [sizes...]"""
+import itertools
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+CHILD = r'''
+import sys, json, os
+sys.path.insert(0, %r)
+import numpy as np, torch
+from genpc_amd import chamfer_3D
+out = {}
+for spec in sys.argv[1:]:
+    b, n = (int(x) for x in spec.split("x"))
+    rng = np.random.default_rng(20250101)
+    A = torch.from_numpy(rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5)).cuda()
+    B = torch.from_numpy(rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5)).cuda()
+    d1 = torch.empty(b, n, device="cuda"); d2 = torch.empty(b, n, device="cuda")
+    i1 = torch.empty(b, n, device="cuda", dtype=torch.int32); i2 = torch.empty(b, n, device="cuda", dtype=torch.int32)
+    for _ in range(5): chamfer_3D.forward(A, B, d1, d2, i1, i2)
+    torch.cuda.synchronize()
+    reps = 50
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): chamfer_3D.forward(A, B, d1, d2, i1, i2)
+    e1.record(); e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    out[spec] = [round(ms * 1e3, 1), round(2.0 * b * n * n / ms / 1e6, 1), int(i1.long().sum().item())]
+print(json.dumps(out))
+''' % ROOT
+
+
+def main():
+    sizes = sys.argv[1:] or ["1x2048", "1x16384", "1x32768", "13x16384"]
+    dbgs = [int(x) for x in os.environ.get("SWEEP_DEBUG", "0").split(",")]
+    rs = [int(x) for x in os.environ.get("SWEEP_R", "0,2,4").split(",")]
+    ws = [int(x) for x in os.environ.get("SWEEP_WPS", "2,4,8").split(",")]
+    for r, wps, dbg in itertools.product(rs, ws, dbgs):
+        env = dict(os.environ, GENPC_NN_R=str(r), GENPC_NN_WPS=str(wps), GENPC_NN_DEBUG=str(dbg))
+        p = subprocess.run([sys.executable, "-c", CHILD] + sizes, env=env, capture_output=True, text=True, timeout=300)
+        line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-300:]
+        print("R=%d blocks/CU=%d dbg=%d [us, Gpair/s, idxsum] %s" % (r, wps, dbg, line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

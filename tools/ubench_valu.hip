@@ -79,6 +79,71 @@ __global__ __launch_bounds__(256) void k(float *out, float s0, float s1)
 #define OP(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
             BODY8(OP) BODY8(OP)
 #undef OP
+
+        } else if (KIND == 13) {    // v_sub_f32 vgpr,vgpr
+#define OP(i) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 14) {    // v_add_f32 vgpr,vgpr
+#define OP(i) asm volatile("v_add_f32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 15) {    // v_mul_f32 vgpr,vgpr
+#define OP(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 16) {    // v_fma_f32 with an SGPR operand
+#define OP(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "s"(s0), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 17) {    // v_min_f32
+#define OP(i) asm volatile("v_min_f32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 18) {    // v_cmp_lt_f32 only
+#define OP(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(v[i]), "v"(a) : "vcc");
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 19) {    // v_cndmask_b32 only
+#define OP(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(a) : );
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 20) {    // v_mov_b32 v, s
+#define OP(i) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "s"(s0));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 21) {    // v_sub_f32 e64 with SGPR
+#define OP(i) asm volatile("v_sub_f32_e64 %0, %1, %0" : "+v"(v[i]) : "s"(s0));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 22) {    // v_fmac_f32 with SGPR src0
+#define OP(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "s"(s0), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 23) {    // v_fma_f32 as subtraction: fma(q, -1.0, s)
+#define OP(i) asm volatile("v_fma_f32 %0, %0, -1.0, %1" : "+v"(v[i]) : "s"(s0));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 24) {    // v_sub_f32 with inline constant
+#define OP(i) asm volatile("v_sub_f32 %0, 1.0, %0" : "+v"(v[i]));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 25) {    // v_mov_b32 v, v
+#define OP(i) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 26) {    // v_sub_f32 with SGPR, 16 independent destinations (no RAW within 8)
+#define OP(i) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(v[i]) : "s"(s0), "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 27) {    // v_min3_f32 independent dest
+#define OP(i) asm volatile("v_min3_f32 %0, %1, %2, %3" : "=v"(v[i]) : "v"(a), "v"(b), "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 28) {    // v_max3_f32 / v_min_f32 mix: v_min_f32 e64
+#define OP(i) asm volatile("v_min_f32_e64 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
         }
     }
     float acc = 0;
@@ -102,11 +167,17 @@ int main()
         {"v_sqrt_f32", k<6>, 16, 1}, {"v_add_f64", k<7>, 16, 1}, {"cvt f32<->f64 pair", k<8>, 16, 1},
         {"v_cmp+v_cndmask pair", k<9>, 16, 1}, {"v_fma_f32 dependent chain", k<10>, 16, 1},
         {"v_med3_f32", k<11>, 16, 1}, {"v_fmac_f32 e32", k<12>, 16, 1},
+        {"v_sub_f32 vgpr", k<13>, 16, 1}, {"v_add_f32 vgpr", k<14>, 16, 1}, {"v_mul_f32 vgpr", k<15>, 16, 1},
+        {"v_fma_f32 (sgpr src1)", k<16>, 16, 1}, {"v_min_f32", k<17>, 16, 1}, {"v_cmp_lt_f32", k<18>, 16, 1},
+        {"v_cndmask_b32", k<19>, 16, 1}, {"v_mov_b32 v,s", k<20>, 16, 1}, {"v_sub_f32_e64 sgpr", k<21>, 16, 1},
+        {"v_fmac_f32 sgpr src0", k<22>, 16, 1}, {"v_fma(q,-1,s)", k<23>, 16, 1}, {"v_sub_f32 1.0 const", k<24>, 16, 1},
+        {"v_mov_b32 v,v", k<25>, 16, 1}, {"v_sub sgpr indep dst", k<26>, 16, 1}, {"v_min3 indep dst", k<27>, 16, 1},
+        {"v_min_f32_e64", k<28>, 16, 1},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int waves_per_simd : {1, 2, 4, 8}) {
+    for (int waves_per_simd : {2, 8}) {
         int blocks = prop.multiProcessorCount * waves_per_simd;   // 256 thr = 4 waves = 1 per SIMD
         printf("--- %d wave(s) per SIMD (%d blocks x 256)\n", waves_per_simd, blocks);
         for (auto &c : cases) {
