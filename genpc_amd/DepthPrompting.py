@@ -1,0 +1,144 @@
+"""Geometric half of the reference's ``DepthPrompting`` stage (DepthPrompting.py)
+on the gfx950 library: camera set, ``getUvs`` (:239-271), ``paintPixels``
+(:292-339), ``getRawDepth`` (:341-391).  Same method names, argument meaning and
+return shapes; the image-generation half (inpainting, depth-conditioned diffusion)
+stays with the reference's stock torch modules and is out of scope here.
+
+Cameras are [C,12] tensors of 3x4 world->camera matrices instead of kaolin
+``Camera`` objects (kaolin is not a dependency): ``create_cameras`` restates
+utils/camera_utils.py:84-160 (fibonacci sphere, ``calculate_up_vector``, look-at).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_L = _lib.lib
+_p = _lib.ptr
+
+
+def fibonacci_sphere(samples, radius):
+    """utils/camera_utils.py:84-101."""
+    pts = []
+    phi = math.pi * (3.0 - math.sqrt(5.0))
+    for i in range(samples):
+        y = 1 - (i / float(samples - 1)) * 2
+        radius_y = math.sqrt(1 - y * y)
+        theta = phi * i
+        pts.append((math.cos(theta) * radius_y * radius, y * radius, math.sin(theta) * radius_y * radius))
+    return np.array(pts)
+
+
+def calculate_up_vector(eye_position, target_position):
+    """utils/camera_utils.py:104-113."""
+    gaze = np.asarray(target_position, np.float64) - np.asarray(eye_position, np.float64)
+    world_up = np.array([0.0, 1.0, 0.0])
+    side = np.cross(gaze, world_up)
+    if np.allclose(side, 0):
+        return np.array([0.0, 0.0, 1.0])
+    up = np.cross(side, gaze)
+    return up / np.linalg.norm(up)
+
+
+def look_at(eye, at, up):
+    """3x4 row-major world->camera matrix of a right-handed camera looking down -Z
+    (kaolin Camera.from_args extrinsics), fp32 like the oracle."""
+    eye, at, up = (np.asarray(x, np.float32) for x in (eye, at, up))
+    back = eye - at
+    back = back / np.sqrt((back * back).sum(dtype=np.float32))
+    right = np.cross(up, back).astype(np.float32)
+    right = right / np.sqrt((right * right).sum(dtype=np.float32))
+    upv = np.cross(back, right).astype(np.float32)
+    rows = np.stack([right, upv, back]).astype(np.float32)
+    t = -(rows @ eye).astype(np.float32)
+    return np.concatenate([rows, t[:, None]], axis=1).astype(np.float32).reshape(12)
+
+
+def create_cameras(num_views=1024, distance=1.6, fovy=49.1, device="cuda"):
+    """utils/camera_utils.py:115-160 for the fibonacci distribution -> (views[C,12]
+    tensor, eye_positions[C,3] numpy, focal)."""
+    eyes = fibonacci_sphere(num_views, distance)
+    views = np.stack([look_at(e, np.zeros(3), calculate_up_vector(e, np.zeros(3))) for e in eyes])
+    focal = 1.0 / math.tan(math.pi * fovy / 180 / 2)
+    return torch.from_numpy(views).to(device), eyes, focal
+
+
+class DepthPrompting:
+    """cfg needs: device, fovy, res, padding, rescale, point_size, mask_pixel_rate
+    (configs/config.yaml keys, unchanged)."""
+
+    def __init__(self, cfg, cameras=None, focal=None):
+        self.cfg = cfg
+        self.device = torch.device(cfg.device)
+        if cameras is None:
+            cameras, self.viewpoints, focal = create_cameras(
+                num_views=cfg.view_num, distance=cfg.distance, fovy=cfg.fovy, device=self.device)
+        self.cameras = cameras
+        self.focal = focal if focal is not None else 1.0 / math.tan(math.pi * cfg.fovy / 180 / 2)
+
+    # DepthPrompting.py:239-271
+    def getUvs(self, cams, points, rescale=True, padding=0.15, want_transformed=True):
+        cams = cams.reshape(-1, 12).contiguous().float()
+        points = points.contiguous().float()
+        _lib.check_tensors((("cams", cams), ("points", points)))
+        c, n = cams.shape[0], points.shape[0]
+        uv = torch.empty(c, n, 2, device=points.device)
+        depth = torch.empty(c, n, device=points.device)
+        tr = torch.empty(c, n, 3, device=points.device) if want_transformed else None
+        rc = _lib.on_device_of(points, _L.genpc_get_uvs, c, n, _p(cams), float(self.focal), 1e-2, 1e2, _p(points),
+                               _p(tr), _p(uv), _p(depth), int(bool(rescale)), float(np.float32(1 - 2 * padding)),
+                               _p(None))
+        if rc != 1:
+            raise RuntimeError("genpc_get_uvs failed: " + _lib.last_error())
+        return uv, depth, tr
+
+    def uvToPixels(self, uvs, res):
+        """DepthPrompting.py:179-184: (uv*res).long(), swap to (row, col), clip."""
+        uvs = uvs.contiguous().float()
+        pix = torch.empty(uvs.shape[0], 2, device=uvs.device, dtype=torch.int32)
+        rc = _lib.on_device_of(uvs, _L.genpc_uv_to_pixels, uvs.shape[0], _p(uvs), float(res), int(res) - 1, _p(pix))
+        if rc != 1:
+            raise RuntimeError("genpc_uv_to_pixels failed: " + _lib.last_error())
+        return pix
+
+    # DepthPrompting.py:292-339
+    def paintPixels(self, img, pixel_coords, pixel_colors, point_size):
+        """img [C,res,res] is painted in place; returns the vertically flipped image."""
+        n = pixel_coords.shape[0]
+        ch = img.shape[0]
+        if not torch.is_tensor(pixel_colors):
+            pixel_colors = pixel_colors * torch.ones((n, ch), device=img.device)
+        pixel_colors = pixel_colors.contiguous().float()
+        pix = pixel_coords.to(torch.int32).contiguous()
+        _lib.check_tensors((("img", img), ("pixel_colors", pixel_colors)), (("pixel_coords", pix),))
+        res = img.shape[1]
+        out = torch.empty_like(img)
+        owner = torch.empty(res * res, device=img.device, dtype=torch.int32)
+        rc = _lib.on_device_of(img, _L.genpc_paint_pixels, res, n, _p(pix), _p(pixel_colors), ch, int(point_size),
+                               _p(img), _p(out), _p(owner))
+        if rc != 1:
+            raise RuntimeError("genpc_paint_pixels failed: " + _lib.last_error())
+        return out
+
+    # DepthPrompting.py:341-391
+    def getRawDepth(self, point_pixels, point_depth, dataset=None, colors=None, res=512, point_size=1,
+                    mask_pixel_rate=3):
+        dev = point_depth.device
+        R = self.cfg.res
+        sparse_img, sparse_depth, all_temp = [torch.zeros((3, R, R), device=dev) for _ in range(3)]
+        visible_point_depth = 0.1 + 0.8 * (
+            1 - (point_depth - point_depth.min()) / (point_depth.max() - point_depth.min())
+        ).unsqueeze(1).expand(-1, 3)
+        sparse_img = self.paintPixels(sparse_img, point_pixels, colors, point_size=point_size)
+        sparse_depth = self.paintPixels(sparse_depth, point_pixels, visible_point_depth.contiguous(),
+                                        point_size=point_size)
+        all_front_mask = (self.paintPixels(all_temp, point_pixels, colors,
+                                           point_size=point_size * mask_pixel_rate) != 0).float()
+        all_back_mask = 1 - all_front_mask
+        front_mask = (sparse_img != 0).float()
+        back_mask = 1 - front_mask
+        hole_mask1 = ((all_back_mask * 255).int() ^ (back_mask * 255).int()).float() / 255
+        hole_mask2 = ((all_front_mask * 255).int() ^ (back_mask * 255).int()).float() / 255
+        return sparse_img, sparse_depth, hole_mask1, hole_mask2

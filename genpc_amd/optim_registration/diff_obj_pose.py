@@ -1,0 +1,79 @@
+"""The SE(3)+scale alignment loop of the reference's
+optim_registration/diff_obj_pose.py on the gfx950 library.
+
+``object_pose_optimization`` keeps the reference's name, hyper-parameters and
+return value (4x4 numpy ``[[sR, t],[0,1]]``, :464-468,:496-594) but takes the two
+clouds as tensors (the reference loads a GLB and a PLY through trimesh/open3d,
+which is I/O outside the hot path) and optimises the CHAMFER half of its loss:
+``3 * (partial_l1(pts, partial) + 0.5 partial_l1(partial, pts)) + 1e-3 |RR^T - I|_F``.
+The mask half needs pytorch3d's CUDA-only Pulsar renderer (absent, unpinned); see
+DESIGN.md.  The whole multi-start loop runs on the device without host
+synchronisation (4 launches per Adam step).
+"""
+import torch
+
+from .. import _lib
+
+_L = _lib.lib
+_p = _lib.ptr
+
+
+def pose_transform(vert_pos, center, params):
+    """ObjectPoseOptim.forward's point map (:419-423).  params = rot_6d|trans|log_scale."""
+    vert_pos = vert_pos.contiguous().float()
+    center = center.contiguous().float()
+    params = params.contiguous().float()
+    _lib.check_tensors((("vert_pos", vert_pos), ("center", center), ("params", params)))
+    pts = torch.empty_like(vert_pos)
+    rc = _lib.on_device_of(vert_pos, _L.genpc_pose_transform, vert_pos.shape[0], _p(vert_pos), _p(center),
+                           _p(params), _p(pts))
+    if rc != 1:
+        raise RuntimeError("genpc_pose_transform failed: " + _lib.last_error())
+    return pts
+
+
+def pose_cd_loss_grad(vert_pos, center, params, partial, cd_weight=3.0, reg_weight=0.001):
+    """-> (loss[3] = total, cd, |RR^T-I|_F ; grad[10]) for the current parameters."""
+    from .. import chamfer_3D
+    vert_pos = vert_pos.contiguous().float()
+    partial = partial.contiguous().float()
+    pts = pose_transform(vert_pos, center, params)
+    nc, np_ = vert_pos.shape[0], partial.shape[0]
+    dev = vert_pos.device
+    d1 = torch.empty(1, nc, device=dev)
+    d2 = torch.empty(1, np_, device=dev)
+    i1 = torch.empty(1, nc, device=dev, dtype=torch.int32)
+    i2 = torch.empty(1, np_, device=dev, dtype=torch.int32)
+    if chamfer_3D.forward(pts[None], partial[None], d1, d2, i1, i2) != 1:
+        raise RuntimeError("chamfer forward failed: " + _lib.last_error())
+    loss = torch.empty(3, device=dev)
+    grad = torch.empty(10, device=dev)
+    rc = _lib.on_device_of(vert_pos, _L.genpc_pose_cd_grad, nc, _p(vert_pos), _p(center.contiguous().float()),
+                           _p(params.contiguous().float()), np_, _p(partial), _p(d1), _p(i1), _p(d2), _p(i2),
+                           float(cd_weight), float(reg_weight), _p(loss), _p(grad))
+    if rc != 1:
+        raise RuntimeError("genpc_pose_cd_grad failed: " + _lib.last_error())
+    return loss, grad
+
+
+def object_pose_optimization(complete_xyz, partial_xyz, radius=0.005, lr=0.005, iters=300, render_size=224,
+                             vis=False, save_path=None, device=None, cam_bias_num=4, return_history=False):
+    """diff_obj_pose.py:496-594 (CD half).  complete_xyz [Nc,3], partial_xyz [Np,3]
+    GPU tensors.  radius / render_size / vis / save_path are accepted for signature
+    compatibility and unused (they parameterise the renderer)."""
+    complete_xyz = complete_xyz.contiguous().float()
+    partial_xyz = partial_xyz.contiguous().float()
+    _lib.check_tensors((("complete_xyz", complete_xyz), ("partial_xyz", partial_xyz)))
+    dev = complete_xyz.device
+    T = torch.empty(16, device=dev)
+    hist = torch.empty(cam_bias_num * (iters + 1), device=dev)
+    bp = torch.empty(10, device=dev)
+    rc = _lib.on_device_of(complete_xyz, _L.genpc_pose_optimize_cd, complete_xyz.shape[0], _p(complete_xyz),
+                           partial_xyz.shape[0], _p(partial_xyz), float(lr), int(iters), int(cam_bias_num),
+                           _p(T), _p(hist), _p(bp))
+    if rc != 1:
+        raise RuntimeError("genpc_pose_optimize_cd failed (rc=%d): %s" % (rc, _lib.last_error()))
+    final_transform = T.reshape(4, 4).cpu().numpy()
+    if return_history:
+        return final_transform, hist.reshape(cam_bias_num, iters + 1).cpu().numpy(), bp.cpu().numpy()
+    return final_transform

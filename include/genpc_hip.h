@@ -87,6 +87,70 @@ int genpc_emd_backward(int b, int n, const float *xyz1, const float *xyz2,
                        float *gradxyz, const float *graddist, const int *idx,
                        void *stream);
 
+/* Depth prompting: projection, splat, colour gather ------------------------ *
+ * Replaces DepthPrompting.getUvs (DepthPrompting.py:239-271) for the cameras the
+ * caller selects: view[C,12] are 3x4 row-major world->camera matrices (look-at,
+ * camera looks down -Z: kaolin Camera.from_args, utils/camera_utils.py:143-147),
+ * focal = 1/tan(fovy/2), near/far as kaolin's pinhole defaults (1e-2, 1e2).
+ * Outputs uv[C,N,2], depth[C,N] (NDC z), optional transformed[C,N,3] (NULL to
+ * skip) and optional bbox[C,4] = min_x, min_y, max_x, max_y of the NDC xy.
+ * rescale != 0: uv = (xy - bbox centre) / max extent * padmul + 0.5 with
+ * padmul = float(1 - 2*padding); else uv = (xy + 1) / 2.                       */
+int genpc_get_uvs(int c, int n, const float *view, float focal, float znear,
+                  float zfar, const float *xyz, float *transformed, float *uv,
+                  float *depth, int rescale, float padmul, float *bbox,
+                  void *stream);
+
+/* (uv * res).long(), swapped to (row, col), clipped to [0, clip_max]
+ * (DepthPrompting.py:179-184, ScaleAdapter.py:59-62).  pix[N,2] int32.          */
+int genpc_uv_to_pixels(int n, const float *uv, float res, int clip_max, int *pix,
+                       void *stream);
+
+/* Replaces DepthPrompting.paintPixels (DepthPrompting.py:292-339): paints
+ * colors[N,ch] into img[ch,res,res] IN PLACE with a (2*point_size-1)^2 square
+ * stamp, no z-test; on collisions the highest point index wins (the reference's
+ * CPU index_put order; undefined on its GPU path).  out[ch,res,res] receives the
+ * vertically flipped image the reference returns.  owner[res*res] is int32
+ * scratch.  Returns -1 on a non-positive res/ch/point_size.                     */
+int genpc_paint_pixels(int res, int n, const int *pix, const float *colors, int ch,
+                       int point_size, float *img, float *out, int *owner,
+                       void *stream);
+
+/* Replaces the Python loop of ScaleAdapter.colorPoint (ScaleAdapter.py:57-66):
+ * out[N,ch] = img[:, h-1-row, col] (the image is read flipped top-bottom).      */
+int genpc_gather_colors(int n, const int *pix, const float *img, int ch, int h,
+                        int w, float *out, void *stream);
+
+/* SE(3)+scale alignment ---------------------------------------------------- *
+ * Pose model of ObjectPoseOptim.forward (optim_registration/diff_obj_pose.py:
+ * 408-423): params[10] = rot_6d[6], trans[3], log_scale[1] (device memory),
+ * pts = (R ((v - center) s)^T)^T + center + trans.                             */
+int genpc_pose_transform(int n, const float *v, const float *center,
+                         const float *params, float *pts, void *stream);
+
+/* Chamfer half of compute_loss_function (diff_obj_pose.py:326-334) plus the
+ * orthogonality term (:543-545) and its analytic gradient:
+ *   loss = cd_weight * (mean sqrt(d1) + 0.5 mean sqrt(d2)) + reg_weight * |RR^T-I|_F
+ * with d1/i1 = NN of the transformed complete cloud in `partial` and d2/i2 the
+ * converse (one genpc_chamfer_forward call).  loss_out[3] = loss, cd, |RR^T-I|_F;
+ * grad[10] in parameter order.  All pointers are device memory.                 */
+int genpc_pose_cd_grad(int nc, const float *v, const float *center,
+                       const float *params, int np, const float *partial,
+                       const float *d1, const int *i1, const float *d2,
+                       const int *i2, float cd_weight, float reg_weight,
+                       float *loss_out, float *grad, void *stream);
+
+/* The multi-start Adam loop of object_pose_optimization (diff_obj_pose.py:516-594)
+ * with the Chamfer half of its loss: `starts` initial rotations R_y(90 deg * k),
+ * iters+1 Adam steps each (lr, 0.2 lr, 0.1 lr for rot/trans/log-scale), best start
+ * by lowest loss seen keeps its FINAL parameters.  Writes transform[16] =
+ * [[sR, t],[0,1]] row-major, history[starts*(iters+1)] (optional) and
+ * best_params[10] (optional); device memory, no host synchronisation.           */
+int genpc_pose_optimize_cd(int nc, const float *complete, int np,
+                           const float *partial, float lr, int iters, int starts,
+                           float *transform, float *history, float *best_params,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,420 @@
+/*
+ * genpc_oracle_geom.c -- CPU restatement of the projection / splat / colour-gather
+ * / pose-optimisation half of GenPC's geometric hot path (SURVEY.md 8a rows
+ * a13-a16).  TEST INFRASTRUCTURE ONLY, same rules as genpc_oracle.c.
+ *
+ * Parity status of these rows: "PARITY UNPINNED".  The reference implements them
+ * on top of third-party libraries that are neither in /root/reference nor in
+ * this image and for which the reference pins no version except kaolin 0.18.0
+ * (README.md:27): kaolin cameras (DepthPrompting.py:245, utils/camera_utils.py:
+ * 143-147), pytorch3d transforms and the Pulsar renderer (optim_registration/
+ * diff_obj_pose.py:396,419,426-433), torch autograd + torch.optim.Adam.  What is
+ * restated here is the reference's OWN arithmetic around those calls, plus the
+ * published algorithms of the small library functions on the path (look-at view
+ * matrix, OpenGL pinhole projection, 6D -> rotation Gram-Schmidt, Adam).  The
+ * analytic gradients are pinned against torch autograd (tests/test_oracle_pose.py).
+ *
+ * All arithmetic is fp32 with the operation order spelled out, so that the HIP
+ * kernels (genpc_amd/csrc/project.hip, pose.hip) can be compared bit for bit
+ * where no reduction order is involved.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* from genpc_oracle.c */
+void oracle_nm_distance(int b, int n, const float *xyz, int m, const float *xyz2,
+                        float *result, int *result_i, int fma_mode);
+
+/* ------------------------------------------------------------------------
+ * Cameras.  kaolin 0.18 Camera.from_args(eye, at, up, fov, width, height)
+ * (utils/camera_utils.py:143-147, DepthPrompting.py:123-131): look-at extrinsics
+ * for a right-handed camera looking down -Z, pinhole intrinsics from the vertical
+ * field of view with near = 1e-2, far = 1e2.  view[12] is the 3x4 row-major
+ * world -> camera matrix.
+ * ---------------------------------------------------------------------- */
+static void normalize3(float *v)
+{
+    float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    v[0] /= n; v[1] /= n; v[2] /= n;
+}
+
+static void cross3(const float *a, const float *b, float *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+ORACLE_API void oracle_look_at(const float *eye, const float *at, const float *up, float *view)
+{
+    float back[3] = {eye[0] - at[0], eye[1] - at[1], eye[2] - at[2]};
+    normalize3(back);
+    float right[3];
+    cross3(up, back, right);
+    normalize3(right);
+    float upv[3];
+    cross3(back, right, upv);
+    const float *rows[3] = {right, upv, back};
+    for (int r = 0; r < 3; r++) {
+        view[r * 4 + 0] = rows[r][0];
+        view[r * 4 + 1] = rows[r][1];
+        view[r * 4 + 2] = rows[r][2];
+        view[r * 4 + 3] = -(rows[r][0] * eye[0] + rows[r][1] * eye[1] + rows[r][2] * eye[2]);
+    }
+}
+
+/* utils/camera_utils.py:104-113 */
+ORACLE_API void oracle_calculate_up_vector(const double *eye, const double *target, double *up)
+{
+    double g[3] = {target[0] - eye[0], target[1] - eye[1], target[2] - eye[2]};
+    double wu[3] = {0, 1, 0};
+    double s[3] = {g[1] * wu[2] - g[2] * wu[1], g[2] * wu[0] - g[0] * wu[2], g[0] * wu[1] - g[1] * wu[0]};
+    /* np.allclose(cross, 0): |x| <= atol(1e-8) */
+    if (fabs(s[0]) <= 1e-8 && fabs(s[1]) <= 1e-8 && fabs(s[2]) <= 1e-8) {
+        up[0] = 0; up[1] = 0; up[2] = 1;
+        return;
+    }
+    up[0] = s[1] * g[2] - s[2] * g[1];
+    up[1] = s[2] * g[0] - s[0] * g[2];
+    up[2] = s[0] * g[1] - s[1] * g[0];
+    double n = sqrt(up[0] * up[0] + up[1] * up[1] + up[2] * up[2]);
+    up[0] /= n; up[1] /= n; up[2] /= n;
+}
+
+/* One point through one camera: view transform, then OpenGL-style projection and
+ * perspective divide -> NDC (x, y, z).  focal = 1/tan(fovy/2) (square image). */
+static inline void project_one(const float *V, float focal, float zn, float zf, const float *p, float *o)
+{
+    float xc = fmaf(V[2], p[2], fmaf(V[1], p[1], V[0] * p[0])) + V[3];
+    float yc = fmaf(V[6], p[2], fmaf(V[5], p[1], V[4] * p[0])) + V[7];
+    float zc = fmaf(V[10], p[2], fmaf(V[9], p[1], V[8] * p[0])) + V[11];
+    float w = -zc;
+    float A = (zf + zn) / (zn - zf);
+    float B = (2.0f * zf * zn) / (zn - zf);
+    o[0] = (focal * xc) / w;
+    o[1] = (focal * yc) / w;
+    o[2] = fmaf(A, zc, B) / w;
+}
+
+/* DepthPrompting.getUvs, DepthPrompting.py:239-271.  transformed may be NULL.
+ * padmul = float(1 - 2*padding).  bbox (optional) receives [C,4] = min_x, min_y,
+ * max_x, max_y of the NDC xy. */
+ORACLE_API void oracle_get_uvs(int c, int n, const float *view, float focal, float zn, float zf,
+                               const float *xyz, float *transformed, float *uv, float *depth,
+                               int rescale, float padmul, float *bbox)
+{
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)n * 3);
+    for (int i = 0; i < c; i++) {
+        const float *V = view + (size_t)i * 12;
+        float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+        for (int j = 0; j < n; j++) {
+            float *o = tmp + (size_t)j * 3;
+            project_one(V, focal, zn, zf, xyz + (size_t)j * 3, o);
+            mnx = o[0] < mnx ? o[0] : mnx;
+            mny = o[1] < mny ? o[1] : mny;
+            mxx = o[0] > mxx ? o[0] : mxx;
+            mxy = o[1] > mxy ? o[1] : mxy;
+        }
+        if (bbox) {
+            bbox[i * 4 + 0] = mnx; bbox[i * 4 + 1] = mny; bbox[i * 4 + 2] = mxx; bbox[i * 4 + 3] = mxy;
+        }
+        float cx = (mnx + mxx) / 2.0f, cy = (mny + mxy) / 2.0f;
+        float sx = mxx - mnx, sy = mxy - mny;
+        float sc = sx > sy ? sx : sy;
+        for (int j = 0; j < n; j++) {
+            const float *o = tmp + (size_t)j * 3;
+            size_t q = (size_t)i * n + j;
+            if (transformed) {
+                transformed[q * 3 + 0] = o[0]; transformed[q * 3 + 1] = o[1]; transformed[q * 3 + 2] = o[2];
+            }
+            if (rescale) {
+                uv[q * 2 + 0] = ((o[0] - cx) / sc) * padmul + 0.5f;
+                uv[q * 2 + 1] = ((o[1] - cy) / sc) * padmul + 0.5f;
+            } else {
+                uv[q * 2 + 0] = (o[0] + 1.0f) * 0.5f;
+                uv[q * 2 + 1] = (o[1] + 1.0f) * 0.5f;
+            }
+            depth[q] = o[2];
+        }
+    }
+    free(tmp);
+}
+
+/* uv -> pixel (row, col), DepthPrompting.py:179-184 / ScaleAdapter.py:59-62:
+ * (uv * res).long() truncates toward zero, columns swapped to (row = v, col = u),
+ * clipped to [0, res-1]. */
+ORACLE_API void oracle_uv_to_pixels(int n, const float *uv, float res, int clip_max, int *pix)
+{
+    for (int j = 0; j < n; j++) {
+        long pu = (long)(uv[j * 2 + 0] * res);
+        long pv = (long)(uv[j * 2 + 1] * res);
+        long r = pv < 0 ? 0 : (pv > clip_max ? clip_max : pv);
+        long cc = pu < 0 ? 0 : (pu > clip_max ? clip_max : pu);
+        pix[j * 2 + 0] = (int)r;
+        pix[j * 2 + 1] = (int)cc;
+    }
+}
+
+/* DepthPrompting.paintPixels, DepthPrompting.py:292-339.  img[C,res,res] is
+ * painted in place (no z-test); on collisions the write that comes LAST in the
+ * reference's index order wins -- point-major, so the highest point index (on the
+ * GPU torch's index_put leaves the winner undefined; this is the CPU order).  The
+ * square stamp covers offsets -(p-1)..(p-1).  out[C,res,res] = vertical flip. */
+ORACLE_API void oracle_paint_pixels(int res, int n, const int *pix, const float *colors, int ch,
+                                    int point_size, float *img, float *out)
+{
+    for (int j = 0; j < n; j++) {
+        int r0 = pix[j * 2 + 0], c0 = pix[j * 2 + 1];
+        for (int dx = -point_size + 1; dx < point_size; dx++)
+            for (int dy = -point_size + 1; dy < point_size; dy++) {
+                int r = r0 + dx, cc = c0 + dy;
+                if (r < 0 || r >= res || cc < 0 || cc >= res) continue;
+                for (int k = 0; k < ch; k++) img[((size_t)k * res + r) * res + cc] = colors[(size_t)j * ch + k];
+            }
+    }
+    for (int k = 0; k < ch; k++)
+        for (int r = 0; r < res; r++)
+            memcpy(out + ((size_t)k * res + r) * res, img + ((size_t)k * res + (res - 1 - r)) * res,
+                   sizeof(float) * (size_t)res);
+}
+
+/* ScaleAdapter.colorPoint, ScaleAdapter.py:58-66: colours[i] = flipped_img[:, row, col]
+ * with the image flipped top-bottom first (:57). */
+ORACLE_API void oracle_gather_colors(int n, const int *pix, const float *img, int ch, int h, int w, float *out)
+{
+    for (int j = 0; j < n; j++) {
+        int r = pix[j * 2 + 0], cc = pix[j * 2 + 1];
+        for (int k = 0; k < ch; k++) out[(size_t)j * ch + k] = img[((size_t)k * h + (h - 1 - r)) * w + cc];
+    }
+}
+
+/* ------------------------------------------------------------------------
+ * Pose model, optim_registration/diff_obj_pose.py:408-423.
+ * params = rot_6d[6], trans[3], log_scale[1].
+ * pytorch3d rotation_6d_to_matrix: a1 = d6[:3], a2 = d6[3:]; b1 = a1/|a1|;
+ * b2 = a2 - (b1.a2) b1; b2 /= |b2|; b3 = b1 x b2; R = rows (b1, b2, b3).
+ * F.normalize divides by max(|v|, 1e-12).
+ * ---------------------------------------------------------------------- */
+ORACLE_API void oracle_rot6d_to_matrix(const float *d6, float *R)
+{
+    float a1[3] = {d6[0], d6[1], d6[2]}, a2[3] = {d6[3], d6[4], d6[5]};
+    float n1 = sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+    n1 = n1 > 1e-12f ? n1 : 1e-12f;
+    float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    float dt = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    float b2[3] = {a2[0] - dt * b1[0], a2[1] - dt * b1[1], a2[2] - dt * b1[2]};
+    float n2 = sqrtf(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]);
+    n2 = n2 > 1e-12f ? n2 : 1e-12f;
+    b2[0] /= n2; b2[1] /= n2; b2[2] /= n2;
+    float b3[3];
+    cross3(b1, b2, b3);
+    for (int k = 0; k < 3; k++) { R[k] = b1[k]; R[3 + k] = b2[k]; R[6 + k] = b3[k]; }
+}
+
+/* pts = (R @ ((v - c) * s).T).T + c + t, diff_obj_pose.py:419-423 */
+static inline void pose_point(const float *R, float s, const float *c, const float *t, const float *v, float *o)
+{
+    float lx = (v[0] - c[0]) * s, ly = (v[1] - c[1]) * s, lz = (v[2] - c[2]) * s;
+    o[0] = fmaf(R[2], lz, fmaf(R[1], ly, R[0] * lx)) + c[0] + t[0];
+    o[1] = fmaf(R[5], lz, fmaf(R[4], ly, R[3] * lx)) + c[1] + t[1];
+    o[2] = fmaf(R[8], lz, fmaf(R[7], ly, R[6] * lx)) + c[2] + t[2];
+}
+
+ORACLE_API void oracle_pose_transform(int n, const float *v, const float *center, const float *params, float *pts)
+{
+    float R[9];
+    oracle_rot6d_to_matrix(params, R);
+    float s = expf(params[9]);
+    for (int j = 0; j < n; j++) pose_point(R, s, center, params + 6, v + (size_t)j * 3, pts + (size_t)j * 3);
+}
+
+/* Loss (CD half of compute_loss_function, diff_obj_pose.py:326-334, plus the
+ * orthogonality term :543-545) and its gradient with respect to the 10 parameters.
+ *   cd   = mean_j sqrt(d1[j]) + 0.5 * mean_k sqrt(d2[k])
+ *          d1: pts -> partial nearest neighbour, d2: partial -> pts
+ *   loss = cd_weight * cd + reg_weight * ||R R^T - I||_F
+ * Accumulation is in double here (the GPU reduces fp32 partial sums in an
+ * unspecified order; compare with a tolerance).  Points with d == 0 contribute no
+ * gradient (torch would produce inf * 0 = NaN there).
+ * out: loss_out[0] = loss, [1] = cd, [2] = ortho_err; grad[10]. */
+static void rot6d_backward(const float *d6, const double *gR, double *g6)
+{
+    /* forward in double */
+    double a1[3] = {d6[0], d6[1], d6[2]}, a2[3] = {d6[3], d6[4], d6[5]};
+    double n1 = sqrt(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+    double b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    double dt = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    double u[3] = {a2[0] - dt * b1[0], a2[1] - dt * b1[1], a2[2] - dt * b1[2]};
+    double n2 = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    double b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    const double *g1 = gR, *g2 = gR + 3, *g3 = gR + 6;
+    /* b3 = b1 x b2 */
+    double gb1[3], gb2[3];
+    /* d(b1 x b2)/db1 : g_b1 += b2 x g3 ; g_b2 += g3 x b1 */
+    gb1[0] = g1[0] + (b2[1] * g3[2] - b2[2] * g3[1]);
+    gb1[1] = g1[1] + (b2[2] * g3[0] - b2[0] * g3[2]);
+    gb1[2] = g1[2] + (b2[0] * g3[1] - b2[1] * g3[0]);
+    gb2[0] = g2[0] + (g3[1] * b1[2] - g3[2] * b1[1]);
+    gb2[1] = g2[1] + (g3[2] * b1[0] - g3[0] * b1[2]);
+    gb2[2] = g2[2] + (g3[0] * b1[1] - g3[1] * b1[0]);
+    /* b2 = u/|u| */
+    double dot2 = gb2[0] * b2[0] + gb2[1] * b2[1] + gb2[2] * b2[2];
+    double gu[3] = {(gb2[0] - dot2 * b2[0]) / n2, (gb2[1] - dot2 * b2[1]) / n2, (gb2[2] - dot2 * b2[2]) / n2};
+    /* u = a2 - (b1.a2) b1 */
+    double gub1 = gu[0] * b1[0] + gu[1] * b1[1] + gu[2] * b1[2];
+    double ga2[3] = {gu[0] - gub1 * b1[0], gu[1] - gub1 * b1[1], gu[2] - gub1 * b1[2]};
+    for (int k = 0; k < 3; k++) gb1[k] += -dt * gu[k] - gub1 * a2[k];
+    /* b1 = a1/|a1| */
+    double dot1 = gb1[0] * b1[0] + gb1[1] * b1[1] + gb1[2] * b1[2];
+    for (int k = 0; k < 3; k++) g6[k] = (gb1[k] - dot1 * b1[k]) / n1;
+    for (int k = 0; k < 3; k++) g6[3 + k] = ga2[k];
+}
+
+ORACLE_API void oracle_pose_loss_grad(int nc, const float *v, const float *center, const float *params,
+                                      int np_, const float *partial, const float *d1, const int *i1,
+                                      const float *d2, const int *i2, float cd_weight, float reg_weight,
+                                      float *loss_out, float *grad)
+{
+    float R[9];
+    oracle_rot6d_to_matrix(params, R);
+    float s = expf(params[9]);
+    const float *c = center, *t = params + 6;
+    double gt[3] = {0, 0, 0}, gs = 0, gR[9] = {0};
+    double sum1 = 0, sum2 = 0;
+    float p[3];
+    for (int j = 0; j < nc; j++) {
+        sum1 += sqrtf(d1[j]);
+        if (d1[j] == 0.0f) continue;
+        const float *vj = v + (size_t)j * 3;
+        pose_point(R, s, c, t, vj, p);
+        const float *q = partial + (size_t)i1[j] * 3;
+        double w = (double)cd_weight / nc * 0.5 / sqrt((double)d1[j]) * 2.0;
+        double g[3] = {w * (p[0] - q[0]), w * (p[1] - q[1]), w * (p[2] - q[2])};
+        double l[3] = {vj[0] - c[0], vj[1] - c[1], vj[2] - c[2]};
+        for (int a = 0; a < 3; a++) {
+            gt[a] += g[a];
+            for (int b = 0; b < 3; b++) gR[a * 3 + b] += g[a] * s * l[b];
+            gs += g[a] * (R[a * 3 + 0] * l[0] + R[a * 3 + 1] * l[1] + R[a * 3 + 2] * l[2]);
+        }
+    }
+    for (int k = 0; k < np_; k++) {
+        sum2 += sqrtf(d2[k]);
+        if (d2[k] == 0.0f) continue;
+        int j = i2[k];
+        const float *vj = v + (size_t)j * 3;
+        pose_point(R, s, c, t, vj, p);
+        const float *q = partial + (size_t)k * 3;
+        double w = (double)cd_weight * 0.5 / np_ * 0.5 / sqrt((double)d2[k]) * 2.0;
+        double g[3] = {-w * (q[0] - p[0]), -w * (q[1] - p[1]), -w * (q[2] - p[2])};
+        double l[3] = {vj[0] - c[0], vj[1] - c[1], vj[2] - c[2]};
+        for (int a = 0; a < 3; a++) {
+            gt[a] += g[a];
+            for (int b = 0; b < 3; b++) gR[a * 3 + b] += g[a] * s * l[b];
+            gs += g[a] * (R[a * 3 + 0] * l[0] + R[a * 3 + 1] * l[1] + R[a * 3 + 2] * l[2]);
+        }
+    }
+    double cd = sum1 / nc + 0.5 * sum2 / np_;
+    /* ortho_err = ||R R^T - I||_F ; d/dR = (2 (RR^T - I) R) / err  (E symmetric) */
+    double E[9], err2 = 0;
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+            double e = 0;
+            for (int k = 0; k < 3; k++) e += (double)R[a * 3 + k] * R[b * 3 + k];
+            e -= (a == b);
+            E[a * 3 + b] = e;
+            err2 += e * e;
+        }
+    double err = sqrt(err2);
+    if (err > 0)
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                double acc = 0;
+                for (int k = 0; k < 3; k++) acc += E[a * 3 + k] * R[k * 3 + b];
+                gR[a * 3 + b] += reg_weight * 2.0 * acc / err;
+            }
+    double g6[6];
+    rot6d_backward(params, gR, g6);
+    for (int k = 0; k < 6; k++) grad[k] = (float)g6[k];
+    for (int k = 0; k < 3; k++) grad[6 + k] = (float)gt[k];
+    grad[9] = (float)(gs * s);
+    loss_out[0] = (float)(cd_weight * cd + reg_weight * err);
+    loss_out[1] = (float)cd;
+    loss_out[2] = (float)err;
+}
+
+/* torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad), one
+ * step for the three parameter groups of diff_obj_pose.py:524-528 (lr, 0.2 lr,
+ * 0.1 lr).  step is 1-based. */
+ORACLE_API void oracle_adam_step(float *params, const float *grad, float *m, float *v, int step, float lr)
+{
+    const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+    double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    for (int k = 0; k < 10; k++) {
+        double l = k < 6 ? lr : (k < 9 ? (double)lr * 0.2 : (double)lr * 0.1);
+        m[k] = (float)(b1 * m[k] + (1.0 - b1) * grad[k]);
+        v[k] = (float)(b2 * v[k] + (1.0 - b2) * (double)grad[k] * grad[k]);
+        double denom = sqrt((double)v[k]) / sqrt(bc2) + eps;
+        params[k] = (float)(params[k] - (l / bc1) * (m[k] / denom));
+    }
+}
+
+/* The multi-start loop of object_pose_optimization, diff_obj_pose.py:516-588, CD
+ * half only (no renderer): starts x (iters+1) Adam steps from R_y(90 deg * start),
+ * trans = 0, log_scale = log(0.75); the start with the lowest loss seen keeps its
+ * FINAL parameters (:570-576 -- not the parameters at that lowest loss).  Returns
+ * T = [[s R, t],[0,1]] row-major in transform[16] (:464-468) and the loss history
+ * [starts, iters+1]. */
+ORACLE_API void oracle_pose_optimize_cd(int nc, const float *complete, int np_, const float *partial, float lr,
+                                        int iters, int starts, int fma_mode, float *transform, float *history,
+                                        float *best_params)
+{
+    float center[3] = {0, 0, 0};
+    {
+        double acc[3] = {0, 0, 0};
+        for (int j = 0; j < nc; j++)
+            for (int k = 0; k < 3; k++) acc[k] += complete[(size_t)j * 3 + k];
+        for (int k = 0; k < 3; k++) center[k] = (float)(acc[k] / nc);
+    }
+    float *pts = (float *)malloc(sizeof(float) * (size_t)nc * 3);
+    float *d1 = (float *)malloc(sizeof(float) * (size_t)nc);
+    int *i1 = (int *)malloc(sizeof(int) * (size_t)nc);
+    float *d2 = (float *)malloc(sizeof(float) * (size_t)np_);
+    int *i2 = (int *)malloc(sizeof(int) * (size_t)np_);
+    float best_loss = INFINITY;
+    for (int st = 0; st < starts; st++) {
+        /* get_init_rot('y', 90*start): R_y(theta), 6D = first two ROWS (matrix_to_rotation_6d) */
+        double th = st * 90.0 * M_PI / 180.0;
+        float params[10] = {(float)cos(th), 0.0f, (float)sin(th), 0.0f, 1.0f, 0.0f, 0, 0, 0, logf(0.75f)};
+        float m[10] = {0}, vv[10] = {0};
+        float local_best = INFINITY;
+        for (int it = 0; it <= iters; it++) {
+            oracle_pose_transform(nc, complete, center, params, pts);
+            oracle_nm_distance(1, nc, pts, np_, partial, d1, i1, fma_mode);
+            oracle_nm_distance(1, np_, partial, nc, pts, d2, i2, fma_mode);
+            float lo[3], grad[10];
+            oracle_pose_loss_grad(nc, complete, center, params, np_, partial, d1, i1, d2, i2, 3.0f, 0.001f, lo, grad);
+            if (history) history[(size_t)st * (iters + 1) + it] = lo[0];
+            if (lo[0] < local_best) local_best = lo[0];
+            oracle_adam_step(params, grad, m, vv, it + 1, lr);
+        }
+        if (local_best < best_loss) {
+            best_loss = local_best;
+            memcpy(best_params, params, sizeof(params));
+        }
+    }
+    float R[9];
+    oracle_rot6d_to_matrix(best_params, R);
+    float s = expf(best_params[9]);
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) transform[a * 4 + b] = R[a * 3 + b] * s;
+        transform[a * 4 + 3] = best_params[6 + a];
+    }
+    transform[12] = transform[13] = transform[14] = 0.0f;
+    transform[15] = 1.0f;
+    free(pts); free(d1); free(i1); free(d2); free(i2);
+}

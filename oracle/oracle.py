@@ -213,3 +213,138 @@ def read_ply_xyz(path):
         dt = np.dtype(props)
         data = np.frombuffer(f.read(nv * dt.itemsize), dtype=dt, count=nv)
     return np.stack([data["x"], data["y"], data["z"]], axis=1).astype(np.float64)
+
+
+# --------------------------------------------------------------------------
+# Projection / splat / colour gather / pose (genpc_oracle_geom.c)
+# --------------------------------------------------------------------------
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+def look_at(eye, at, up):
+    """-> view[12]: 3x4 row-major world->camera matrix (camera looks down -Z)."""
+    e, pe = _f(eye)
+    a, pa = _f(at)
+    u, pu = _f(up)
+    v = np.zeros(12, np.float32)
+    lib().oracle_look_at(pe, pa, pu, v.ctypes.data_as(_f32p))
+    return v
+
+
+def calculate_up_vector(eye, target):
+    e = np.ascontiguousarray(eye, np.float64)
+    t = np.ascontiguousarray(target, np.float64)
+    u = np.zeros(3, np.float64)
+    lib().oracle_calculate_up_vector(e.ctypes.data_as(_f64p), t.ctypes.data_as(_f64p), u.ctypes.data_as(_f64p))
+    return u
+
+
+def fibonacci_sphere(samples, radius):
+    """utils/camera_utils.py:84-101 restated (float64, like the reference)."""
+    import math
+    pts = []
+    phi = math.pi * (3.0 - math.sqrt(5.0))
+    for i in range(samples):
+        y = 1 - (i / float(samples - 1)) * 2
+        radius_y = math.sqrt(1 - y * y)
+        theta = phi * i
+        pts.append((math.cos(theta) * radius_y * radius, y * radius, math.sin(theta) * radius_y * radius))
+    return np.array(pts)
+
+
+def get_uvs(views, focal, xyz, rescale=True, padding=0.15, near=1e-2, far=1e2):
+    """DepthPrompting.getUvs -> uv[C,N,2], depth[C,N], transformed[C,N,3], bbox[C,4]."""
+    views, pv = _f(np.asarray(views, np.float32).reshape(-1, 12))
+    xyz, px = _f(xyz)
+    c, n = views.shape[0], xyz.shape[0]
+    tr = np.zeros((c, n, 3), np.float32)
+    uv = np.zeros((c, n, 2), np.float32)
+    dp = np.zeros((c, n), np.float32)
+    bb = np.zeros((c, 4), np.float32)
+    lib().oracle_get_uvs(c, n, pv, ctypes.c_float(focal), ctypes.c_float(near), ctypes.c_float(far), px,
+                         tr.ctypes.data_as(_f32p), uv.ctypes.data_as(_f32p), dp.ctypes.data_as(_f32p),
+                         int(bool(rescale)), ctypes.c_float(np.float32(1 - 2 * padding)), bb.ctypes.data_as(_f32p))
+    return uv, dp, tr, bb
+
+
+def uv_to_pixels(uv, res, clip_max=None):
+    uv, pu = _f(uv)
+    n = uv.shape[0]
+    pix = np.zeros((n, 2), np.int32)
+    lib().oracle_uv_to_pixels(n, pu, ctypes.c_float(res), int(res - 1 if clip_max is None else clip_max),
+                              pix.ctypes.data_as(_i32p))
+    return pix
+
+
+def paint_pixels(res, pix, colors, point_size, img=None):
+    """-> (flipped image [C,res,res], painted-in-place img)."""
+    pix, pp = _i(pix)
+    colors, pc = _f(colors)
+    ch = colors.shape[1]
+    if img is None:
+        img = np.zeros((ch, res, res), np.float32)
+    img, pi = _f(img)
+    out = np.zeros_like(img)
+    lib().oracle_paint_pixels(int(res), pix.shape[0], pp, pc, ch, int(point_size), pi, out.ctypes.data_as(_f32p))
+    return out, img
+
+
+def gather_colors(pix, img):
+    pix, pp = _i(pix)
+    img, pi = _f(img)
+    ch, h, w = img.shape
+    out = np.zeros((pix.shape[0], ch), np.float32)
+    lib().oracle_gather_colors(pix.shape[0], pp, pi, ch, h, w, out.ctypes.data_as(_f32p))
+    return out
+
+
+def rot6d_to_matrix(d6):
+    d, pd = _f(d6)
+    R = np.zeros(9, np.float32)
+    lib().oracle_rot6d_to_matrix(pd, R.ctypes.data_as(_f32p))
+    return R.reshape(3, 3)
+
+
+def pose_transform(v, center, params):
+    v, pv = _f(v)
+    c, pc = _f(center)
+    p, pp = _f(params)
+    out = np.zeros_like(v)
+    lib().oracle_pose_transform(v.shape[0], pv, pc, pp, out.ctypes.data_as(_f32p))
+    return out
+
+
+def pose_loss_grad(v, center, params, partial, d1, i1, d2, i2, cd_weight=3.0, reg_weight=0.001):
+    v, pv = _f(v)
+    c, pc = _f(center)
+    p, pp = _f(params)
+    q, pq = _f(partial)
+    d1, pd1 = _f(d1)
+    d2, pd2 = _f(d2)
+    i1, pi1 = _i(i1)
+    i2, pi2 = _i(i2)
+    lo = np.zeros(3, np.float32)
+    g = np.zeros(10, np.float32)
+    lib().oracle_pose_loss_grad(v.shape[0], pv, pc, pp, q.shape[0], pq, pd1, pi1, pd2, pi2,
+                                ctypes.c_float(cd_weight), ctypes.c_float(reg_weight),
+                                lo.ctypes.data_as(_f32p), g.ctypes.data_as(_f32p))
+    return lo, g
+
+
+def adam_step(params, grad, m, v, step, lr):
+    """In place on params/m/v (float32[10])."""
+    lib().oracle_adam_step(params.ctypes.data_as(_f32p), np.ascontiguousarray(grad, np.float32).ctypes.data_as(_f32p),
+                           m.ctypes.data_as(_f32p), v.ctypes.data_as(_f32p), int(step), ctypes.c_float(lr))
+
+
+def pose_optimize_cd(complete, partial, lr=0.01, iters=200, starts=4, fma_mode=1):
+    """-> (T[4,4], history[starts, iters+1], best_params[10])."""
+    c, pc = _f(complete)
+    q, pq = _f(partial)
+    T = np.zeros(16, np.float32)
+    hist = np.zeros((starts, iters + 1), np.float32)
+    bp = np.zeros(10, np.float32)
+    lib().oracle_pose_optimize_cd(c.shape[0], pc, q.shape[0], pq, ctypes.c_float(lr), int(iters), int(starts),
+                                  int(fma_mode), T.ctypes.data_as(_f32p), hist.ctypes.data_as(_f32p),
+                                  bp.ctypes.data_as(_f32p))
+    return T.reshape(4, 4), hist, bp
