@@ -64,6 +64,107 @@ def time_events(fn, reps, stream):
     return e0.elapsed_time(e1) / reps
 
 
+def pmc_traffic(n):
+    """HBM bytes per launch of nn_forward_kernel from the committed rocprofv3 PMC
+    passes (profiles/*_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate runs,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM).  None when no profile of
+    this size is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel") == "nn_forward_kernel" and d.get("points") == n and d.get("batch") == 1:
+            best = d.get("hbm_bytes_per_launch")
+    return best
+
+
+def extras(A, B, n, dev, stream):
+    """Secondary measurements (not the headline): other sizes, backward, EMD, the
+    streaming kernels against the HBM roofline, and scans/s of the alignment loop."""
+    from genpc_amd import chamfer_3D
+    from genpc_amd.loss_functions import chamfer_3DDist, emdModule
+    from genpc_amd.DepthPrompting import DepthPrompting, create_cameras
+    from genpc_amd.optim_registration.diff_obj_pose import object_pose_optimization
+    from genpc_amd.utils.loss_util import Completionloss
+    from types import SimpleNamespace
+    extra = {}
+    cd = chamfer_3DDist()
+    Ag = A.clone().requires_grad_(True)
+    Bg = B.clone().requires_grad_(True)
+
+    def fb():
+        Ag.grad = None
+        Bg.grad = None
+        d1, d2, _, _ = cd(Ag, Bg)
+        (torch.sqrt(d1).mean() + torch.sqrt(d2).mean()).backward()
+    fb()
+    extra["chamfer_fwd_bwd_autograd_ms"] = round(time_events(fb, 20, stream), 4)
+    for nn in (2048, 4096, 8192, 32768):
+        P, Q, _, _ = make_pair(nn, SEED, dev)
+        d1 = torch.empty(1, nn, device=dev)
+        d2 = torch.empty(1, nn, device=dev)
+        i1 = torch.empty(1, nn, device=dev, dtype=torch.int32)
+        i2 = torch.empty(1, nn, device=dev, dtype=torch.int32)
+        f = lambda: chamfer_3D.forward(P, Q, d1, d2, i1, i2)  # noqa: E731
+        f()
+        t = time_events(f, 50, stream)
+        extra["chamfer_fwd_B1_n%d_gpair_s" % nn] = round(2.0 * nn * nn / (t * 1e-3) / 1e9, 2)
+    # BASELINE config 3 shape: 13 scans x 16384 in one batched call
+    P13 = torch.rand(13, n, 3, device=dev) - 0.5
+    Q13 = torch.rand(13, n, 3, device=dev) - 0.5
+    o = [torch.empty(13, n, device=dev), torch.empty(13, n, device=dev),
+         torch.empty(13, n, device=dev, dtype=torch.int32), torch.empty(13, n, device=dev, dtype=torch.int32)]
+    f = lambda: chamfer_3D.forward(P13, Q13, o[0], o[1], o[2], o[3])  # noqa: E731
+    f()
+    t = time_events(f, 10, stream)
+    extra["chamfer_fwd_B13_n%d_gpair_s" % n] = round(13 * 2.0 * n * n / (t * 1e-3) / 1e9, 2)
+    em = emdModule()
+    X = A + 0.5
+    Y = B + 0.5
+    em(X, Y, 0.005, 50)
+    extra["emd_fwd_n%d_eps0.005_it50_ms" % n] = round(time_events(lambda: em(X, Y, 0.005, 50), 5, stream), 4)
+    X2 = X[:, :2048].contiguous()
+    Y2 = Y[:, :2048].contiguous()
+    em(X2, Y2, 0.005, 50)
+    extra["emd_fwd_n2048_eps0.005_it50_ms"] = round(time_events(lambda: em(X2, Y2, 0.005, 50), 5, stream), 4)
+    # metric pass of one completed scan (main.metric: CD-L1 + EMD at 16384 points)
+    cl1, cle = Completionloss("cd_l1"), Completionloss("emd")
+
+    def metric():
+        cl1.get_loss(X, Y)
+        cle.get_loss(X, Y)
+    metric()
+    extra["metric_cd_emd_n%d_scans_per_s" % n] = round(1e3 / time_events(metric, 5, stream), 2)
+    # alignment loop (diff_obj_pose CD half): 8192-point partial vs 16384-point complete,
+    # 4 starts x 201 Adam steps, then the metric above = one "completed scan"
+    C16 = A[0]
+    P8 = (B[0, :8192] * 0.9).contiguous()
+    object_pose_optimization(C16, P8, lr=0.01, iters=200)
+
+    def scan():
+        object_pose_optimization(C16, P8, lr=0.01, iters=200)
+        metric()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        scan()
+    torch.cuda.synchronize()
+    extra["registration_8k_vs_16k_4x201_plus_metric_scans_per_s"] = round(3.0 / (time.perf_counter() - t0), 3)
+    # HBM-bound streaming kernel: getUvs for the reference's 1024 cameras x 71372 points
+    cfg = SimpleNamespace(device=str(dev), fovy=49.1, res=256, padding=0.15, rescale=True, point_size=1,
+                          mask_pixel_rate=3, view_num=1024, distance=1.6)
+    dp = DepthPrompting(cfg)
+    pts = (torch.rand(71372, 3, device=dev) - 0.5) * 0.8
+    dp.getUvs(dp.cameras, pts, want_transformed=False)
+    t = time_events(lambda: dp.getUvs(dp.cameras, pts, want_transformed=False), 5, stream)
+    alg = 1024 * 71372 * (12 + 12 + 8 + 8)     # read xyz, write uv+depth, re-read+write uv
+    extra["get_uvs_1024x71372_hbm"] = {"GB_s": round(alg / (t * 1e-3) / 1e9, 1), "frac_of_8TBs": round(alg / (t * 1e-3) / 8e12, 4),
+                                       "ms": round(t, 4), "algorithmic_bytes": alg}
+    return extra
+
+
 def cpu_baseline(a, b, budget_s=12.0):
     """Oracle Chamfer forward on all host cores, repeated until ~budget_s."""
     from oracle import oracle as O
@@ -159,7 +260,7 @@ def main():
                        "sharding": "independent scans per rank, no data-path collective"},
             "roofline": {"bound": "valu_fp32", "achieved": round(tflops, 3), "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                         "kernel": "nn_forward_kernel(+nn_merge_kernel)", "ms_per_launch": round(ms, 5),
+                         "kernel": "nn_forward_kernel", "ms_per_launch": round(ms, 5),
                          "flop_per_pair": FLOP_PER_PAIR},
             "roofline_hbm": {"bound": "hbm", "achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 3),
                              "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -167,38 +268,8 @@ def main():
                              "algorithmic_bytes": alg_bytes},
         }
         if not args.no_extra:
-            extra = {}
-            cd = chamfer_3DDist()
-            Ag = A.clone().requires_grad_(True)
-            Bg = B.clone().requires_grad_(True)
-
-            def fb():
-                Ag.grad = None
-                Bg.grad = None
-                d1, d2, _, _ = cd(Ag, Bg)
-                (torch.sqrt(d1).mean() + torch.sqrt(d2).mean()).backward()
-            fb()
-            extra["chamfer_fwd_bwd_autograd_ms"] = round(time_events(fb, 20, stream), 4)
-            em = emdModule()
-            X = A + 0.5
-            Y = B + 0.5
-            em(X, Y, 0.005, 50)
-            extra["emd_fwd_n%d_eps0.005_it50_ms" % n] = round(time_events(lambda: em(X, Y, 0.005, 50), 5, stream), 4)
-            X2 = X[:, :2048].contiguous()
-            Y2 = Y[:, :2048].contiguous()
-            em(X2, Y2, 0.005, 50)
-            extra["emd_fwd_n2048_eps0.005_it50_ms"] = round(time_events(lambda: em(X2, Y2, 0.005, 50), 5, stream), 4)
-            for nn in (2048, 4096, 8192, 32768):
-                P, Q, _, _ = make_pair(nn, SEED, dev)
-                d1 = torch.empty(1, nn, device=dev)
-                d2 = torch.empty(1, nn, device=dev)
-                i1 = torch.empty(1, nn, device=dev, dtype=torch.int32)
-                i2 = torch.empty(1, nn, device=dev, dtype=torch.int32)
-                f = lambda: chamfer_3D.forward(P, Q, d1, d2, i1, i2)  # noqa: E731
-                f()
-                t = time_events(f, 50, stream)
-                extra["chamfer_fwd_n%d_gpair_s" % nn] = round(2.0 * nn * nn / (t * 1e-3) / 1e9, 2)
-            out["extra"] = extra
+            out["extra"] = extras(A, B, n, dev, stream)
+        out["roofline"]["traffic"] = pmc_traffic(n)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a_np, b_np)
     sharding.barrier()
