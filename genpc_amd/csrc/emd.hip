@@ -32,6 +32,8 @@
 #include "common.h"
 #include "../../include/genpc_hip.h"
 
+#include <stdlib.h>
+
 namespace genpc {
 
 constexpr int kEBlock = 256;
@@ -96,14 +98,14 @@ __device__ __forceinline__ int pick_p(int U, int G)
     return P;
 }
 
-template <int FMA>
+template <int FMA, int FILTER>
 __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__restrict__ xyz1,
                                                           const float *__restrict__ xyz2,
                                                           const float *__restrict__ price, float eps,
                                                           const int *__restrict__ list, const int *__restrict__ cnt,
                                                           int *__restrict__ cnt_next, int *__restrict__ bid,
                                                           float *__restrict__ bid_increments,
-                                                          float *__restrict__ max_increments)
+                                                          float *__restrict__ max_increments, int force_p)
 {
     __shared__ float4 tile[kTile];
     const int batch = blockIdx.y;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt_next[batch] = 0;   // filled by this round's assign
     if (U == 0) return;
     const int G = gridDim.x;
-    const int P = pick_p(U, G);
+    const int P = force_p > 0 ? force_p : pick_p(U, G);
     const int per_wave = kWave / P;
     const int per_block = kEBlock / P;
     const int lane = threadIdx.x & (kWave - 1);
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
         const float x1 = X1[(size_t)j * 3 + 0], y1 = X1[(size_t)j * 3 + 1], z1 = X1[(size_t)j * 3 + 2];
         float best = -1e9f, better = -1e9f;
         int best_i = -1;
+        float cb = __fsub_rn(3.000002f, better);
 
         for (int k2 = 0; k2 < n; k2 += kTile) {
             const int end_k = min(n, k2 + kTile) - k2;
@@ -145,13 +148,48 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                 tile[t] = make_float4(X2[(size_t)k * 3 + 0], X2[(size_t)k * 3 + 1], X2[(size_t)k * 3 + 2], PR[k]);
             }
             __syncthreads();
-            for (int t = p; t < end_k; t += P) {
-                const float4 o = tile[t];
-                const float d = bid_value<FMA>(x1, y1, z1, o.x, o.y, o.z, o.w);
-                const bool gt = d > best;
-                better = __builtin_amdgcn_fmed3f(d, best, better);
-                best = fmaxf(best, d);
-                best_i = gt ? k2 + t : best_i;
+            // Pre-filter.  A candidate can change this lane's (best, better) only if its
+            // value exceeds `better`, i.e. only if sqrt(s) < 3 - price - better.  That is
+            // tested conservatively in squared space with fp32 and no sqrt / fp64:
+            // cb = (3 + 2e-6) - better absorbs every rounding of the test itself (two fp32
+            // subtractions below 8: <= 4.8e-7; the square: 6e-8 relative; the correctly
+            // rounded sqrt of the exact path: 6e-8 relative), so a candidate that fails the
+            // test provably evaluates to d <= better and the exact update would be a
+            // no-op.  The exact path (double-precision expression of emd_cuda.cu:146)
+            // runs for the whole wave when any lane passes; for lanes that did not pass
+            // it is that same no-op.  Results are therefore bit-identical with and
+            // without the filter (GENPC_EMD_NOFILTER=1 disables it for A/B).
+            // Four objects per iteration (4*P divides every tile length: n % 256 == 0,
+            // P <= 64): the four LDS reads are in flight together and a group none of
+            // whose members can matter costs one branch.
+            for (int t = p; t < end_k; t += 4 * P) {
+                float4 o[4];
+                float sq[4];
+                bool maybe[4];
+                bool any4 = false;
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = tile[t + i * P];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    sq[i] = sqdist_e<FMA>(o[i].x - x1, o[i].y - y1, o[i].z - z1);
+                    const float tt = __fsub_rn(cb, o[i].w);
+                    maybe[i] = !FILTER || sq[i] < __fmul_rn(tt, tt);
+                    any4 |= maybe[i];
+                }
+                if (__any(any4)) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (__any(maybe[i])) {
+                            const float r = sqrtf(sq[i]);
+                            const float d = (float)((3.0 - (double)r) - (double)o[i].w);
+                            const bool gt = d > best;
+                            better = __builtin_amdgcn_fmed3f(d, best, better);
+                            best = fmaxf(best, d);
+                            best_i = gt ? k2 + t + i * P : best_i;
+                        }
+                    }
+                    cb = __fsub_rn(3.000002f, better);
+                }
             }
         }
         // merge the P partial top-2s of a bidder (value-symmetric)
@@ -343,26 +381,32 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     const int lin_blocks = ceil_div((int)total, kEBlock);
     hipLaunchKernelGGL(emd_init_kernel, dim3(lin_blocks), dim3(kEBlock), 0, st, b, n, lists[0], cnts[0], cnts[1]);
 
-    // Blocks per batch element for the bid kernel: ~4 blocks per CU overall,
+    // Blocks per batch element for the bid kernel: ~16 blocks per CU overall (the bid
+    // loop is latency-bound per wave -- LDS read, compare, branch -- and wants >= 8
+    // waves per SIMD: measured 13x16384, round 0: 3.9 ms at 4/CU, 1.8 ms at 16/CU),
     // never more than the finest split (64 lanes per bidder, all n bidding).
-    int G = ceil_div(kNumCU * 4, b);
+    int G = ceil_div(kNumCU * 16, b);
     const int g_max = ceil_div(n * 64, kEBlock);
     if (G > g_max) G = g_max;
     if (G < 1) G = 1;
+    if (getenv("GENPC_EMD_G")) G = atoi(getenv("GENPC_EMD_G"));
     int GL = ceil_div(n, kEBlock);          // list-walking kernels
     if (GL > 64) GL = 64;
 
     for (int it = 0; it < iters; it++) {
         const int cur = it & 1, nxt = cur ^ 1;
         const int last = (it == iters - 1);
-        if (fma)
-            hipLaunchKernelGGL((emd_bid_kernel<1>), dim3(G, b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price,
-                               eps, (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
-                               max_increments);
-        else
-            hipLaunchKernelGGL((emd_bid_kernel<0>), dim3(G, b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price,
-                               eps, (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
-                               max_increments);
+        {
+            typedef void (*bid_fn)(int, const float *, const float *, const float *, float, const int *, const int *,
+                                   int *, int *, float *, float *, int);
+            static const int force_p = getenv("GENPC_EMD_P") ? atoi(getenv("GENPC_EMD_P")) : 0;
+            static const bool nofilter = getenv("GENPC_EMD_NOFILTER") != nullptr;
+            bid_fn f = fma ? (nofilter ? emd_bid_kernel<1, 0> : emd_bid_kernel<1, 1>)
+                           : (nofilter ? emd_bid_kernel<0, 0> : emd_bid_kernel<0, 1>);
+            hipLaunchKernelGGL(f, dim3(G, b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price, eps,
+                               (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
+                               max_increments, force_p);
+        }
         hipLaunchKernelGGL(emd_getmax_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
                            (const int *)cnts[cur], (const int *)bid, (const float *)bid_increments,
                            (const float *)max_increments, max_idx, last);
@@ -377,6 +421,15 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
         hipLaunchKernelGGL((emd_calc_dist_kernel<0>), dim3(lin_blocks), dim3(kEBlock), 0, st, total, n, xyz1, xyz2, dist,
                            (const int *)assignment);
     return check(hipGetLastError(), "emd forward launch") ? 1 : 0;
+}
+
+// Diagnostic (not part of the public header): resident blocks per CU the runtime
+// reports for the bid kernel.
+extern "C" __attribute__((visibility("default"))) int genpc_debug_emd_bid_occupancy(void)
+{
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, genpc::emd_bid_kernel<1, 1>, genpc::kEBlock, 0);
+    return nb;
 }
 
 GENPC_API int genpc_emd_backward(int b, int n, const float *xyz1, const float *xyz2, float *gradxyz,

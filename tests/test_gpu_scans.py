@@ -1,0 +1,66 @@
+"""BASELINE config 1 and 3 on the reference's bundled scans (fixtures: deterministic
+FPS subsamples of data/*.ply and data/GT/*.ply, tests/golden/make_golden.py):
+CD-L1 / CD-L2 / EMD of the HIP path against the oracle's values, per scan."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tg():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from genpc_amd import _lib
+    from genpc_amd.loss_functions import chamfer_3DDist, emdModule
+    from genpc_amd.metric import evaluate_scans, evaluate_sharded
+    return dict(torch=torch, lib=_lib, cd=chamfer_3DDist(), emd=emdModule(), ev=evaluate_scans, evs=evaluate_sharded)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_config3_thirteen_scans_16384(tg, golden, mode):
+    torch = tg["torch"]
+    g = golden("scans13_fps16384.npz")
+    P, G = torch.from_numpy(g["partial"]).cuda(), torch.from_numpy(g["gt"]).cuda()
+    prev = tg["lib"].lib.genpc_set_arith(mode)
+    try:
+        d1, d2, i1, i2 = tg["cd"](P, G)
+        de, ass = tg["emd"](P, G, 0.005, 50)
+        table = tg["ev"](P, G).cpu().numpy()
+    finally:
+        tg["lib"].lib.genpc_set_arith(prev)
+    # index / assignment checksums: bit-exact integer work
+    np.testing.assert_array_equal(i1.long().sum(1).cpu().numpy(), g[f"idx1_sum_m{mode}"])
+    np.testing.assert_array_equal(i2.long().sum(1).cpu().numpy(), g[f"idx2_sum_m{mode}"])
+    np.testing.assert_array_equal(ass.long().sum(1).cpu().numpy(), g[f"assignment_sum_m{mode}"])
+    # scalars: same per-point values, fp32 means reduced in a different order
+    np.testing.assert_allclose(table[:, 0], g[f"cd_l1_m{mode}"], rtol=3e-7)
+    np.testing.assert_allclose(table[:, 1], g[f"cd_l2_m{mode}"], rtol=3e-7)
+    np.testing.assert_allclose(table[:, 2], g[f"emd_m{mode}"], rtol=3e-7)
+    # north_star: CD-L1 within 1e-5 of the reference arithmetic in either mode
+    np.testing.assert_allclose(table[:, 0], g["cd_l1_m0"], atol=1e-5)
+    # the mis-framed GT of 06830 is the only outlier
+    ids = list(g["ids"])
+    assert table[ids.index("06830"), 0] > 1.0 and np.delete(table[:, 0], ids.index("06830")).max() < 0.1
+
+
+def test_batched_equals_one_by_one(tg, golden):
+    torch = tg["torch"]
+    g = golden("scans13_fps16384.npz")
+    P, G = torch.from_numpy(g["partial"][:4]).cuda(), torch.from_numpy(g["gt"][:4]).cuda()
+    whole = tg["ev"](P, G)
+    for s in range(4):
+        one = tg["ev"](P[s:s + 1].contiguous(), G[s:s + 1].contiguous())
+        # same per-point values; torch reduces a [1,N] and a [4,N] mean in different orders
+        assert torch.allclose(one[0], whole[s], rtol=1e-6, atol=0)
+    sharded = tg["evs"](g["partial"][:4], g["gt"][:4])        # world size 1: same table
+    assert torch.allclose(sharded, whole, rtol=1e-6, atol=0)
+
+
+def test_config1_scan01184_2048(tg, golden):
+    torch = tg["torch"]
+    g = golden("scan01184_fps2048.npz")
+    P, G = torch.from_numpy(g["partial"]).cuda(), torch.from_numpy(g["gt"]).cuda()
+    t = tg["ev"](P, G).cpu().numpy()[0]
+    assert abs(t[0] - float(g["cd_l1_m1"])) < 2e-8 and abs(t[1] - float(g["cd_l2_m1"])) < 2e-9
+    assert abs(t[2] - float(g["emd_m1"])) < 2e-8

@@ -79,3 +79,19 @@ def test_emd_input_checks(oracle):
         oracle.emd_forward(np.zeros((1, 100, 3), np.float32), np.zeros((1, 100, 3), np.float32), 0.005, 2)
     with pytest.raises(ValueError):
         oracle.emd_forward(np.zeros((513, 256, 3), np.float32), np.zeros((513, 256, 3), np.float32), 0.005, 1)
+
+
+def test_config3_fixture_is_consistent(oracle, golden):
+    """The 13-scan fixture: shapes, the survey's full-resolution CD-L1 ordering
+    (06830 mis-framed, 06145 / 09868 the two best) and one scan re-derived."""
+    g = golden("scans13_fps16384.npz")
+    assert g["partial"].shape == (13, 16384, 3) and g["gt"].shape == (13, 16384, 3)
+    ids = list(g["ids"])
+    cd = g["cd_l1_m0"]
+    assert cd[ids.index("06830")] > 2.5
+    assert set(np.argsort(cd)[:2]) == {ids.index("06145"), ids.index("09868")}
+    assert np.abs(g["cd_l1_m0"] - g["cd_l1_m1"]).max() < 1e-7
+    i = ids.index("06145")
+    d1, d2, i1, i2 = oracle.chamfer_forward(g["partial"][i:i + 1], g["gt"][i:i + 1], 1)
+    assert oracle.cd_l1(d1, d2) == g["cd_l1_m1"][i]
+    assert int(i1.astype(np.int64).sum()) == int(g["idx1_sum_m1"][i])
