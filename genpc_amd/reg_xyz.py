@@ -1,0 +1,124 @@
+"""ICP + scale search of the reference's ``reg_xyz.py`` on the gfx950 library
+(SURVEY.md 8a row a17): ``icp_with_scaling`` (:24-38), ``icp_with_scaling_xyz``
+(:9-21), the coarse 11-scale sweep of ``reg`` (:146-173) and
+``iterative_scale_search`` (:60-96).  Same names, argument meaning and returned
+quantities; clouds are [N,3] GPU tensors (the reference passes open3d point clouds;
+open3d is absent and unpinned -- see DESIGN.md).  Voxel down-sampling, noise
+removal and the fusion tail of ``reg`` are the "next" rows of SURVEY 8f.
+
+Batching: the 11 coarse candidates share their first ICP (it does not depend on
+the scale) and run their second ICP as one K=11 batch; the 10x10x10 anisotropic
+search scores all 1000 candidates with one batched NN launch and solves ICP only
+for the winner, because the reference's score (:77-83) is computed on the scaled
+source, before and independently of the candidate's ICP result.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .loss_functions import chamfer_3DDist
+
+_L = _lib.lib
+_p = _lib.ptr
+
+
+def registration_icp(source, target, max_correspondence_distance, init=None, max_iteration=30,
+                     relative_fitness=1e-6, relative_rmse=1e-6):
+    """open3d.pipelines.registration.registration_icp(point-to-point) for K initial
+    transforms at once.  init: [4,4] or [K,4,4] (numpy / tensor, float64).
+    Returns (transformation [K,4,4] float64 numpy, fitness [K], inlier_rmse [K], iters [K]);
+    a single [4,4] init returns unbatched values."""
+    source = source.contiguous().float()
+    target = target.contiguous().float()
+    _lib.check_tensors((("source", source), ("target", target)))
+    dev = source.device
+    if init is None:
+        init = np.eye(4)
+    init_t = torch.as_tensor(np.asarray(init, np.float64)).reshape(-1, 4, 4).contiguous().to(dev)
+    k = init_t.shape[0]
+    out_T = torch.empty(k, 16, dtype=torch.float64, device=dev)
+    stats = torch.empty(k, 3, dtype=torch.float64, device=dev)
+    rc = _lib.on_device_of(source, _L.genpc_icp_batch, k, source.shape[0], _p(source), target.shape[0], _p(target),
+                           float(max_correspondence_distance), _p(init_t), int(max_iteration),
+                           float(relative_fitness), float(relative_rmse), _p(out_T), _p(stats))
+    if rc != 1:
+        raise RuntimeError("genpc_icp_batch failed (rc=%d): %s" % (rc, _lib.last_error()))
+    T = out_T.reshape(k, 4, 4).cpu().numpy()
+    st = stats.cpu().numpy()
+    if np.asarray(init).ndim == 2:
+        return T[0], float(st[0, 0]), float(st[0, 1]), int(st[0, 2])
+    return T, st[:, 0], st[:, 1], st[:, 2].astype(int)
+
+
+def icp_with_scaling_xyz(source, target, scales, max_correspondence_distance=0.05, init_transform=None):
+    """reg_xyz.py:9-21: the source is scaled per axis first (the reference does it in
+    place on the open3d cloud), then ICP.  Returns (transformation, scaled_source)."""
+    s = torch.as_tensor(np.asarray(scales, np.float64), device=source.device)
+    scaled = (source.double() * s).float()
+    T, _, _, _ = registration_icp(scaled, target, max_correspondence_distance,
+                                  np.eye(4) if init_transform is None else init_transform)
+    return T, scaled
+
+
+def icp_with_scaling(source, target, scale, max_correspondence_distance=0.05, init_transform=None):
+    """reg_xyz.py:24-38: ICP, then ICP again from result @ diag(scale).  `scale` may be
+    a sequence: the first ICP is shared and the second runs as one batch."""
+    init = np.eye(4) if init_transform is None else np.asarray(init_transform, np.float64)
+    T1, _, _, _ = registration_icp(source, target, max_correspondence_distance, init)
+    scales = np.atleast_1d(np.asarray(scale, np.float64))
+    inits = []
+    for sc in scales:
+        S = np.eye(4)
+        S[:3, :3] *= sc
+        inits.append(T1 @ S)
+    T2, fit, rmse, its = registration_icp(source, target, max_correspondence_distance, np.stack(inits))
+    if np.ndim(scale) == 0:
+        return T2[0]
+    return T2
+
+
+def _partial_cd_scores(src_b, tgt_b, cd_inv_weight):
+    """chamfer_partial_l1(src, tgt) + w * chamfer_partial_l1(tgt, src) per batch row."""
+    d1, d2, _, _ = chamfer_3DDist()(src_b, tgt_b)
+    return torch.sqrt(d1).mean(1) + torch.sqrt(d2).mean(1) * cd_inv_weight
+
+
+def coarse_scale_sweep(source_down, target_down, cd_inv_weight=0.5, scales=None, max_correspondence_distance=0.075):
+    """The 11-scale sweep of reg() (reg_xyz.py:146-173).  Returns (best_scale, best_loss,
+    coarse_transformation) with the reference's strict '<' (first minimum wins)."""
+    if scales is None:
+        scales = np.linspace(1.5, 0.8, 11)
+    T = icp_with_scaling(source_down, target_down, scales, max_correspondence_distance)      # [K,4,4]
+    inv = torch.as_tensor(np.linalg.inv(T), device=source_down.device)                        # :161-162
+    tgt = target_down.double()
+    tgt_k = (tgt @ inv[:, :3, :3].transpose(1, 2) + inv[:, None, :3, 3]).float().contiguous()
+    src_k = source_down.float()[None].expand(len(scales), -1, -1).contiguous()
+    cd = _partial_cd_scores(src_k, tgt_k, cd_inv_weight).cpu().numpy()
+    best = int(np.argmin(cd))             # np.argmin returns the first minimum == strict '<' update
+    return float(scales[best]), float(cd[best]), T[best]
+
+
+def iterative_scale_search(source_pcd, target_pcd, scale_ranges, scale_steps, init_transform=None, cd_inv_weight=0):
+    """reg_xyz.py:60-96.  Returns (best_scales_transformation [4,4], best_loss,
+    best_transformation [4,4]).  Candidate order z (outer), x, y (inner), strict '<'."""
+    source = source_pcd.contiguous().float()
+    target = target_pcd.contiguous().float()
+    _lib.check_tensors((("source", source), ("target", target)))
+    xs = np.linspace(scale_ranges[0][0], scale_ranges[0][1], scale_steps)
+    ys = np.linspace(scale_ranges[1][0], scale_ranges[1][1], scale_steps)
+    zs = np.linspace(scale_ranges[2][0], scale_ranges[2][1], scale_steps)
+    cand = np.array([[x, y, z] for z in zs for x in xs for y in ys], np.float64)
+    scales_t = torch.from_numpy(cand.astype(np.float32)).to(source.device)
+    scores = torch.empty(len(cand), device=source.device)
+    rc = _lib.on_device_of(source, _L.genpc_scale_search_scores, len(cand), source.shape[0], _p(source),
+                           target.shape[0], _p(target), _p(scales_t), float(cd_inv_weight), _p(scores))
+    if rc != 1:
+        raise RuntimeError("genpc_scale_search_scores failed (rc=%d): %s" % (rc, _lib.last_error()))
+    sc = scores.cpu().numpy()
+    best = int(np.argmin(sc))
+    best_scales = cand[best]
+    best_T, _ = icp_with_scaling_xyz(source, target, best_scales, max_correspondence_distance=0.075,
+                                     init_transform=np.eye(4) if init_transform is None else init_transform)
+    S = np.eye(4)
+    S[0, 0], S[1, 1], S[2, 2] = best_scales
+    return S, float(sc[best]), best_T

@@ -151,6 +151,27 @@ int genpc_pose_optimize_cd(int nc, const float *complete, int np,
                            float *transform, float *history, float *best_params,
                            void *stream);
 
+/* ICP + scale search --------------------------------------------------------- *
+ * Batched point-to-point ICP with the semantics of open3d's registration_icp as
+ * reg_xyz.py calls it (:18-20,28-37: TransformationEstimationPointToPoint, default
+ * criteria 30 iterations / 1e-6 / 1e-6): K candidates share source[ns,3] and
+ * target[nt,3] and differ in their initial transform init[K,16] (row-major 4x4,
+ * DOUBLE, device memory).  out_T[K,16] double, stats[K,3] double = fitness,
+ * inlier_rmse, iterations.  Correspondence: fp32 nearest neighbour with
+ * d2 <= max_dist^2.                                                            */
+int genpc_icp_batch(int k, int ns, const float *source, int nt, const float *target,
+                    double max_dist, const double *init, int max_iter,
+                    double rel_fitness, double rel_rmse, double *out_T,
+                    double *stats, void *stream);
+
+/* Scores of iterative_scale_search (reg_xyz.py:60-96) for K anisotropic scale
+ * candidates scales[K,3] in one batched NN launch:
+ *   scores[k] = mean sqrt(NN(source*scales[k] -> target))
+ *             + cd_inv_weight * mean sqrt(NN(target -> source*scales[k])).    */
+int genpc_scale_search_scores(int k, int ns, const float *source, int nt,
+                              const float *target, const float *scales,
+                              float cd_inv_weight, float *scores, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -418,3 +418,155 @@ ORACLE_API void oracle_pose_optimize_cd(int nc, const float *complete, int np_, 
     transform[15] = 1.0f;
     free(pts); free(d1); free(i1); free(d2); free(i2);
 }
+
+/* ------------------------------------------------------------------------
+ * Point-to-point ICP, the algorithm behind open3d.pipelines.registration.
+ * registration_icp as the reference calls it (reg_xyz.py:18-20,28-37): default
+ * ICPConvergenceCriteria (relative_fitness 1e-6, relative_rmse 1e-6, 30
+ * iterations), TransformationEstimationPointToPoint without scaling.  open3d is a
+ * third-party dependency that is neither in /root/reference nor in this image and
+ * that the reference does not pin: PARITY UNPINNED; this restates the published
+ * algorithm:
+ *   evaluate(T): p' = T p; 1-NN of p' in target; correspondence if d2 <= r^2;
+ *                fitness = #corr / #source, rmse = sqrt(mean d2 over corr)
+ *   loop: update = argmin_R,t sum |q - (R p' + t)|^2 (Kabsch / Umeyama, no
+ *         scale) ; T = update T ; evaluate ; stop when both |delta fitness| and
+ *         |delta rmse| < 1e-6.
+ * Numeric conventions of this build (shared with the HIP path): T is kept in
+ * double; p' is rounded to fp32; the NN is the fp32 NmDistance of genpc_oracle.c;
+ * sums are double.  The optimal rotation is obtained with Horn's quaternion
+ * method (largest eigenvector of the 4x4 N matrix, Jacobi sweeps), which equals
+ * the SVD solution with the reflection fix that Eigen::umeyama applies.
+ * ---------------------------------------------------------------------- */
+static void jacobi4(double A[4][4], double V[4][4])
+{
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) V[i][j] = (i == j);
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0;
+        for (int i = 0; i < 4; i++)
+            for (int j = i + 1; j < 4; j++) off += A[i][j] * A[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 3; p++)
+            for (int q = p + 1; q < 4; q++) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 4; k++) {
+                    double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 4; k++) {
+                    double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 4; k++) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+/* sums[17]: n, sum p[3], sum q[3], sum p q^T [9] (row-major, p index first), sum d2.
+ * Writes the 4x4 row-major update that maps p onto q in the least-squares sense. */
+ORACLE_API void oracle_kabsch_from_sums(const double *sums, double *update)
+{
+    double n = sums[0];
+    double mp[3] = {sums[1] / n, sums[2] / n, sums[3] / n};
+    double mq[3] = {sums[4] / n, sums[5] / n, sums[6] / n};
+    double S[3][3];
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) S[a][b] = sums[7 + a * 3 + b] - n * mp[a] * mq[b];
+    double N[4][4] = {
+        {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
+        {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
+        {S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
+        {S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]}};
+    double V[4][4];
+    jacobi4(N, V);
+    int best = 0;
+    for (int i = 1; i < 4; i++)
+        if (N[i][i] > N[best][best]) best = i;
+    double w = V[0][best], x = V[1][best], y = V[2][best], z = V[3][best];
+    double nn = sqrt(w * w + x * x + y * y + z * z);
+    w /= nn; x /= nn; y /= nn; z /= nn;
+    double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
+                      {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
+                      {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) update[a * 4 + b] = R[a][b];
+        update[a * 4 + 3] = mq[a] - (R[a][0] * mp[0] + R[a][1] * mp[1] + R[a][2] * mp[2]);
+    }
+    update[12] = update[13] = update[14] = 0;
+    update[15] = 1;
+}
+
+static void icp_evaluate(int ns, const float *source, int nt, const float *target, const double *T, float md2,
+                         int fma_mode, float *pts, float *d, int *idx, double *sums)
+{
+    for (int j = 0; j < ns; j++)
+        for (int a = 0; a < 3; a++)
+            pts[(size_t)j * 3 + a] = (float)(T[a * 4 + 0] * (double)source[(size_t)j * 3 + 0] +
+                                             T[a * 4 + 1] * (double)source[(size_t)j * 3 + 1] +
+                                             T[a * 4 + 2] * (double)source[(size_t)j * 3 + 2] + T[a * 4 + 3]);
+    oracle_nm_distance(1, ns, pts, nt, target, d, idx, fma_mode);
+    for (int k = 0; k < 17; k++) sums[k] = 0;
+    for (int j = 0; j < ns; j++) {
+        if (!(d[j] <= md2)) continue;
+        const float *p = pts + (size_t)j * 3, *q = target + (size_t)idx[j] * 3;
+        sums[0] += 1;
+        for (int a = 0; a < 3; a++) {
+            sums[1 + a] += p[a];
+            sums[4 + a] += q[a];
+            for (int b = 0; b < 3; b++) sums[7 + a * 3 + b] += (double)p[a] * (double)q[b];
+        }
+        sums[16] += d[j];
+    }
+}
+
+/* init / out_T: 4x4 row-major double.  stats[3] = fitness, inlier_rmse, iterations done. */
+ORACLE_API void oracle_icp(int ns, const float *source, int nt, const float *target, double max_dist,
+                           const double *init, int max_iter, double rel_fitness, double rel_rmse, int fma_mode,
+                           double *out_T, double *stats)
+{
+    float *pts = (float *)malloc(sizeof(float) * (size_t)ns * 3);
+    float *d = (float *)malloc(sizeof(float) * (size_t)ns);
+    int *idx = (int *)malloc(sizeof(int) * (size_t)ns);
+    double T[16], sums[17];
+    memcpy(T, init, sizeof T);
+    float md2 = (float)(max_dist * max_dist);
+    icp_evaluate(ns, source, nt, target, T, md2, fma_mode, pts, d, idx, sums);
+    double fitness = sums[0] / ns, rmse = sums[0] > 0 ? sqrt(sums[16] / sums[0]) : 0.0;
+    int it = 0;
+    for (; it < max_iter; it++) {
+        if (sums[0] < 1) break;
+        double U[16], Tn[16];
+        oracle_kabsch_from_sums(sums, U);
+        for (int a = 0; a < 4; a++)
+            for (int b = 0; b < 4; b++) {
+                double acc = 0;
+                for (int k = 0; k < 4; k++) acc += U[a * 4 + k] * T[k * 4 + b];
+                Tn[a * 4 + b] = acc;
+            }
+        memcpy(T, Tn, sizeof T);
+        icp_evaluate(ns, source, nt, target, T, md2, fma_mode, pts, d, idx, sums);
+        double f2 = sums[0] / ns, r2 = sums[0] > 0 ? sqrt(sums[16] / sums[0]) : 0.0;
+        int conv = fabs(fitness - f2) < rel_fitness && fabs(rmse - r2) < rel_rmse;
+        fitness = f2;
+        rmse = r2;
+        if (conv) {
+            it++;
+            break;
+        }
+    }
+    memcpy(out_T, T, sizeof T);
+    stats[0] = fitness;
+    stats[1] = rmse;
+    stats[2] = it;
+    free(pts); free(d); free(idx);
+}

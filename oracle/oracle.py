@@ -348,3 +348,25 @@ def pose_optimize_cd(complete, partial, lr=0.01, iters=200, starts=4, fma_mode=1
                                   int(fma_mode), T.ctypes.data_as(_f32p), hist.ctypes.data_as(_f32p),
                                   bp.ctypes.data_as(_f32p))
     return T.reshape(4, 4), hist, bp
+
+
+def kabsch_from_sums(sums):
+    s = np.ascontiguousarray(sums, np.float64)
+    u = np.zeros(16, np.float64)
+    lib().oracle_kabsch_from_sums(s.ctypes.data_as(_f64p), u.ctypes.data_as(_f64p))
+    return u.reshape(4, 4)
+
+
+def icp(source, target, max_dist, init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, fma_mode=1):
+    """Point-to-point ICP (open3d registration_icp semantics) -> (T[4,4] float64,
+    fitness, inlier_rmse, iterations)."""
+    s, ps = _f(source)
+    t, pt = _f(target)
+    init = np.eye(4) if init is None else init
+    i0 = np.ascontiguousarray(init, np.float64)
+    T = np.zeros(16, np.float64)
+    st = np.zeros(3, np.float64)
+    lib().oracle_icp(s.shape[0], ps, t.shape[0], pt, ctypes.c_double(max_dist), i0.ctypes.data_as(_f64p),
+                     int(max_iter), ctypes.c_double(rel_fitness), ctypes.c_double(rel_rmse), int(fma_mode),
+                     T.ctypes.data_as(_f64p), st.ctypes.data_as(_f64p))
+    return T.reshape(4, 4), float(st[0]), float(st[1]), int(st[2])

@@ -1,0 +1,95 @@
+"""a17: batched ICP and scale search on the GPU against the oracle's ICP
+(oracle_icp: same fp32 NN, double sums) -- transforms within 1e-6 (sums are reduced
+in another order), fitness / iteration counts equal -- and by outcome (known rigid
+motions and anisotropic scales recovered)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rg():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from genpc_amd import reg_xyz
+    return dict(torch=torch, R=reg_xyz)
+
+
+def rot(axis, deg):
+    a = np.asarray(axis, float)
+    a /= np.linalg.norm(a)
+    th = math.radians(deg)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
+
+
+def shape(seed, n):
+    rng = np.random.default_rng(seed)
+    u = rng.standard_normal((n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    return (u * np.array([0.5, 0.3, 0.2]) + 0.05 * np.abs(u[:, :1])).astype(np.float32)
+
+
+def test_icp_matches_oracle(rg, oracle):
+    torch = rg["torch"]
+    target = shape(5, 3000)
+    R0, t0 = rot([0.2, 1, 0.1], 6.0), np.array([0.02, -0.015, 0.01])
+    src = ((target[::2].astype(np.float64) - t0) @ R0).astype(np.float32)
+    for md in (0.075, 0.01):
+        T, fit, rmse, its = rg["R"].registration_icp(torch.from_numpy(src).cuda(), torch.from_numpy(target).cuda(), md)
+        oT, ofit, ormse, oits = oracle.icp(src, target, md)
+        assert fit == ofit and its == oits
+        np.testing.assert_allclose(T, oT, atol=1e-6)
+        assert abs(rmse - ormse) < 1e-7
+    T, fit, rmse, its = rg["R"].registration_icp(torch.from_numpy(src).cuda(), torch.from_numpy(target).cuda(), 0.075)
+    np.testing.assert_allclose(T[:3, :3], R0, atol=5e-3)
+    np.testing.assert_allclose(T[:3, 3], t0, atol=2e-3)
+
+
+def test_icp_batch_equals_singles(rg, oracle):
+    torch = rg["torch"]
+    target = shape(6, 2500)
+    src = (target[1::2].astype(np.float64) @ rot([0, 1, 0], 4.0).T * 1.02 + 0.01).astype(np.float32)
+    inits = []
+    for sc in np.linspace(1.5, 0.8, 11):
+        S = np.eye(4)
+        S[:3, :3] *= sc
+        inits.append(S)
+    S_, T_ = torch.from_numpy(src).cuda(), torch.from_numpy(target).cuda()
+    Tb, fb, rb, ib = rg["R"].registration_icp(S_, T_, 0.075, np.stack(inits))
+    for k in (0, 5, 10):
+        oT, ofit, ormse, oits = oracle.icp(src, target, 0.075, init=inits[k])
+        np.testing.assert_allclose(Tb[k], oT, atol=1e-6)
+        assert fb[k] == ofit and ib[k] == oits
+
+
+def test_coarse_sweep_and_scale_search(rg, oracle):
+    torch = rg["torch"]
+    target = shape(7, 3000)
+    true_scales = np.array([1.1111111, 0.9333333, 0.8444444])      # on the 10-step grid of [0.8, 1.2]
+    src = (target[::2].astype(np.float64) / true_scales).astype(np.float32)
+    S_, T_ = torch.from_numpy(src).cuda(), torch.from_numpy(target).cuda()
+    Sm, loss, Tb = rg["R"].iterative_scale_search(S_, T_, [(0.8, 1.2)] * 3, 10, cd_inv_weight=0.5)
+    np.testing.assert_allclose(np.diag(Sm)[:3], true_scales, atol=1e-6)
+    np.testing.assert_allclose(Tb, np.eye(4), atol=2e-3)
+    # scores of a 3x3x3 grid against the oracle's Chamfer on each scaled source
+    xs = np.linspace(0.8, 1.2, 3)
+    cand = np.array([[x, y, z] for z in xs for x in xs for y in xs])
+    exp = []
+    for c in cand:
+        sc = (src.astype(np.float64) * c).astype(np.float32)
+        d1, d2, _, _ = oracle.chamfer_forward(sc[None], target[None], 1)
+        exp.append(float(oracle.cd_partial_l1(d1)) + 0.5 * float(oracle.cd_partial_l1(d2)))
+    Sm3, loss3, _ = rg["R"].iterative_scale_search(S_, T_, [(0.8, 1.2)] * 3, 3, cd_inv_weight=0.5)
+    best = int(np.argmin(exp))
+    np.testing.assert_allclose(np.diag(Sm3)[:3], cand[best])
+    assert abs(loss3 - exp[best]) < 1e-6
+    # coarse sweep: the source is the target shrunk by 1/1.29 -> scale 1.29 wins
+    src2 = (target[::2].astype(np.float64) / 1.29).astype(np.float32)
+    bs, bl, Tc = rg["R"].coarse_scale_sweep(torch.from_numpy(src2).cuda(), T_, cd_inv_weight=0.5)
+    assert abs(bs - 1.29) < 1e-9
+    s = np.cbrt(np.linalg.det(Tc[:3, :3]))
+    assert abs(s - 1.29) < 1e-6
