@@ -38,6 +38,9 @@ namespace genpc {
 
 constexpr int kEBlock = 256;
 constexpr int kTile = 1024;        // objects per LDS tile (16 KiB as float4)
+constexpr int kZMax = 16;           // object slices per bidder group in the late-round split
+constexpr int kSplitMaxBidders = 4096;   // bidders per batch element the split scratch can hold
+constexpr int kArrivePerBatch = 1024;    // arrival counters per batch element (>= kSplitMaxBidders * 64 / 256)
 
 template <int FMA>
 __device__ __forceinline__ float sqdist_e(float dx, float dy, float dz)
@@ -90,6 +93,30 @@ __global__ __launch_bounds__(kEBlock) void emd_init_kernel(int b, int n, int *__
     }
 }
 
+// Folds (ob, obb, oi, obi) into (b, bb, bi, bbi): best / second-best values with the
+// index of an object attaining each.  Value-symmetric; on a tie for first place the
+// lower index is kept as `bi` (the reference's order is restored by the tie path).
+__device__ __forceinline__ void merge_top2(float &b, float &bb, int &bi, int &bbi, float ob, float obb, int oi, int obi)
+{
+    float nb2;
+    int nbi;
+    if (b > ob) {
+        nb2 = fmaxf(bb, ob);
+        nbi = ob > bb ? oi : bbi;
+    } else if (ob > b) {
+        nb2 = fmaxf(obb, b);
+        nbi = b > obb ? bi : obi;
+    } else {                       // equal first places: the other one is the second
+        nb2 = b;
+        nbi = ((unsigned)oi < (unsigned)bi) ? bi : oi;
+    }
+    const bool take = ob > b || (ob == b && (unsigned)oi < (unsigned)bi);
+    bi = take ? oi : bi;
+    b = fmaxf(b, ob);
+    bb = nb2;
+    bbi = nbi;
+}
+
 // lanes-per-bidder for U bidders on a grid of G blocks per batch element
 __device__ __forceinline__ int pick_p(int U, int G)
 {
@@ -105,7 +132,9 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                                                           const int *__restrict__ list, const int *__restrict__ cnt,
                                                           int *__restrict__ cnt_next, int *__restrict__ bid,
                                                           float *__restrict__ bid_increments,
-                                                          float *__restrict__ max_increments, int force_p)
+                                                          float *__restrict__ max_increments, int force_p,
+                                                          float4 *__restrict__ parts, int *__restrict__ arrive,
+                                                          int *__restrict__ second)
 {
     __shared__ float4 tile[kTile];
     const int batch = blockIdx.y;
@@ -131,16 +160,59 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
     const int unass_per_block = (U + block_cnt - 1) / block_cnt;
     const int thread_per_unass = 256 / unass_per_block;
 
-    for (int grp = blockIdx.x; (long long)grp * per_block < U; grp += G) {
+    // Work units.  NB blocks cover the U bidders at P lanes each.  When even the
+    // finest split (P = 64) leaves most of the grid idle -- the late rounds, where a
+    // few hundred bidders remain -- the OBJECTS are split as well: Z slices of tiles,
+    // unit = (bidder group, slice); a unit writes its partial top-2 and the last unit
+    // of a group to arrive merges them (agent-scope release -> ticket -> acquire, as
+    // in chamfer.hip).  Without this a late round is one block per CU walking all
+    // n/1024 tiles back to back: pure load latency (measured 50 us per round at
+    // n = 16384 for ~10 us of work).
+    const int NB = (int)(((long long)U * P + kEBlock - 1) / kEBlock);
+    const int ntiles = (n + kTile - 1) / kTile;
+    int Z = 1;
+    if (P == 64 && parts != nullptr) {
+        Z = G / NB;
+        Z = Z > ntiles ? ntiles : Z;
+        Z = Z > kZMax ? kZMax : Z;
+        Z = Z < 1 ? 1 : Z;
+        if ((long long)U > kSplitMaxBidders) Z = 1;     // parts[] holds kSplitMaxBidders bidders per batch
+    }
+    const int tps = (ntiles + Z - 1) / Z;               // tiles per slice
+    const int units = NB * Z;
+
+    for (int unit = blockIdx.x; unit < units; unit += G) {
+        const int grp = unit % NB;
+        const int zs = unit / NB;
         const int u = grp * per_block + wave * per_wave + g;
         const bool active = u < U;
         const int j = L[active ? u : U - 1];
         const float x1 = X1[(size_t)j * 3 + 0], y1 = X1[(size_t)j * 3 + 1], z1 = X1[(size_t)j * 3 + 2];
         float best = -1e9f, better = -1e9f;
-        int best_i = -1;
-        float cb = __fsub_rn(3.000002f, better);
+        int best_i = -1, better_i = -1;
+        // Seed of the pre-filter: the objects this point ranked first and second the
+        // last time it bid, re-valued at today's prices.  The second-best value over ALL
+        // objects is at least the smaller of any two distinct objects' values, so a
+        // candidate provably not above `seed` can be neither best nor strictly second.
+        // The filter is thereby selective from the first object on, whatever the length
+        // of a lane's sequence (without it, late rounds with 64 lanes per bidder
+        // evaluated every pair exactly).
+        float seed = -1e9f;
+        if (FILTER && second != nullptr) {
+            const int sa = bid[(size_t)batch * n + j], sc = second[(size_t)batch * n + j];
+            if (sc >= 0 && sa != sc && (unsigned)sa < (unsigned)n) {
+                const float da = bid_value<FMA>(x1, y1, z1, X2[(size_t)sa * 3 + 0], X2[(size_t)sa * 3 + 1],
+                                                X2[(size_t)sa * 3 + 2], PR[sa]);
+                const float dc = bid_value<FMA>(x1, y1, z1, X2[(size_t)sc * 3 + 0], X2[(size_t)sc * 3 + 1],
+                                                X2[(size_t)sc * 3 + 2], PR[sc]);
+                seed = fminf(da, dc);
+            }
+        }
+        float cb = __fsub_rn(3.000002f, fmaxf(better, seed));
+        const int k_lo = zs * tps * kTile;
+        const int k_hi = min(n, (zs + 1) * tps * kTile);
 
-        for (int k2 = 0; k2 < n; k2 += kTile) {
+        for (int k2 = k_lo; k2 < k_hi; k2 += kTile) {
             const int end_k = min(n, k2 + kTile) - k2;
             __syncthreads();
             for (int t = threadIdx.x; t < end_k; t += kEBlock) {
@@ -183,12 +255,15 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                             const float r = sqrtf(sq[i]);
                             const float d = (float)((3.0 - (double)r) - (double)o[i].w);
                             const bool gt = d > best;
+                            const bool gt2 = !gt && d > better;
+                            const int kk = k2 + t + i * P;
+                            better_i = gt ? best_i : (gt2 ? kk : better_i);
                             better = __builtin_amdgcn_fmed3f(d, best, better);
                             best = fmaxf(best, d);
-                            best_i = gt ? k2 + t + i * P : best_i;
+                            best_i = gt ? kk : best_i;
                         }
                     }
-                    cb = __fsub_rn(3.000002f, better);
+                    cb = __fsub_rn(3.000002f, fmaxf(better, seed));
                 }
             }
         }
@@ -197,14 +272,46 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
             const float ob = __shfl_xor(best, off, kWave);
             const float obb = __shfl_xor(better, off, kWave);
             const int oi = __shfl_xor(best_i, off, kWave);
-            float nb2;
-            if (best > ob) nb2 = fmaxf(better, ob);
-            else if (ob > best) nb2 = fmaxf(obb, best);
-            else nb2 = best;
-            const bool take = ob > best || (ob == best && (unsigned)oi < (unsigned)best_i);
-            best_i = take ? oi : best_i;
-            best = fmaxf(best, ob);
-            better = nb2;
+            const int obi = __shfl_xor(better_i, off, kWave);
+            merge_top2(best, better, best_i, better_i, ob, obb, oi, obi);
+        }
+        if (Z > 1) {
+            // publish this slice's top-2 per bidder, then let the last slice to arrive
+            // fold all Z of them (top-2 merging is associative and symmetric)
+            float4 *slot = parts + ((size_t)batch * kSplitMaxBidders + (active ? u : 0)) * kZMax;
+            if (active && p == 0) slot[zs] = make_float4(best, better, __int_as_float(best_i), __int_as_float(better_i));
+            int *cntp = arrive + (size_t)batch * kArrivePerBatch + grp;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                       // also: every lane is done with the tile
+            int *s_ticket = (int *)tile;
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                *s_ticket = __hip_atomic_fetch_add(cntp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            const int ticket = *s_ticket;
+            __syncthreads();                       // the ticket slot is tile memory: read before reuse
+            if (ticket != Z - 1) continue;         // block-uniform
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(cntp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            float mb = -1e9f, mbb = -1e9f;
+            int mi = -1, mbi = -1;
+            if (active && p == 0) {
+                for (int q = 0; q < Z; q++) {
+                    const float4 v = slot[q];
+                    merge_top2(mb, mbb, mi, mbi, v.x, v.y, __float_as_int(v.z), __float_as_int(v.w));
+                }
+            }
+            // hand the merged result to all P lanes of the bidder (the tie path below is cooperative)
+            const int src_lane = lane & ~(P - 1);
+            best = __shfl(mb, src_lane, kWave);
+            better = __shfl(mbb, src_lane, kWave);
+            best_i = __shfl(mi, src_lane, kWave);
+            better_i = __shfl(mbi, src_lane, kWave);
         }
         // exact tie for first place: pick the candidate the reference's scan meets first
         const bool tie = active && (best == better);
@@ -233,6 +340,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
         if (active && p == 0) {
             const float inc = __fadd_rn(__fsub_rn(best, better), eps);
             bid[(size_t)batch * n + j] = best_i;
+            if (second != nullptr) second[(size_t)batch * n + j] = better_i;
             bid_increments[(size_t)batch * n + j] = inc;
             atomic_max_float(&max_increments[(size_t)batch * n + best_i], inc);
         }
@@ -372,8 +480,27 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
         set_error("emd: B*n too large");
         return 0;
     }
-    int *list_b = (int *)workspace(1, (size_t)total * sizeof(int), st);
-    if (!list_b) return 0;
+    // [second bidder list | arrival counters (zeroed on allocation, restored by the
+    //  merging block) | per-slice partial top-2s]
+    const size_t list_bytes = ((size_t)total * sizeof(int) + 255) / 256 * 256;
+    // fixed size (32 batch elements) so that the zeroed prefix never moves between calls
+    const size_t arrive_bytes = (size_t)32 * kArrivePerBatch * sizeof(int);
+    // the late-round object split only matters when few batch elements are in flight
+    const bool want_split = b <= 32;
+    const size_t parts_bytes = want_split ? (size_t)b * kSplitMaxBidders * kZMax * sizeof(float4) : 0;
+    const size_t second_bytes = ((size_t)total * sizeof(int) + 255) / 256 * 256;
+    char *ws = (char *)workspace(1, arrive_bytes + list_bytes + second_bytes + parts_bytes, st, nullptr, arrive_bytes);
+    if (!ws) return 0;
+    int *arrive = (int *)ws;
+    int *list_b = (int *)(ws + arrive_bytes);
+    int *second = (int *)(ws + arrive_bytes + list_bytes);
+    float4 *parts = (float4 *)(ws + arrive_bytes + list_bytes + second_bytes);
+    // second-best object of each point's last bid (-1: has not bid yet)
+    if (!check(hipMemsetAsync(second, 0xff, (size_t)total * sizeof(int), st), "hipMemsetAsync(second)")) return 0;
+    static const bool noseed = getenv("GENPC_EMD_NOSEED") != nullptr;
+    if (noseed) second = nullptr;
+    static const bool nosplit = getenv("GENPC_EMD_NOSPLIT") != nullptr;
+    if (nosplit || !want_split) parts = nullptr;
     int *lists[2] = {unass_idx, list_b};
     int *cnts[2] = {unass_cnt, cnt_tmp};
     const bool fma = arith_mode() != 0;
@@ -398,14 +525,14 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
         const int last = (it == iters - 1);
         {
             typedef void (*bid_fn)(int, const float *, const float *, const float *, float, const int *, const int *,
-                                   int *, int *, float *, float *, int);
+                                   int *, int *, float *, float *, int, float4 *, int *, int *);
             static const int force_p = getenv("GENPC_EMD_P") ? atoi(getenv("GENPC_EMD_P")) : 0;
             static const bool nofilter = getenv("GENPC_EMD_NOFILTER") != nullptr;
             bid_fn f = fma ? (nofilter ? emd_bid_kernel<1, 0> : emd_bid_kernel<1, 1>)
                            : (nofilter ? emd_bid_kernel<0, 0> : emd_bid_kernel<0, 1>);
             hipLaunchKernelGGL(f, dim3(G, b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price, eps,
                                (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
-                               max_increments, force_p);
+                               max_increments, force_p, parts, arrive, second);
         }
         hipLaunchKernelGGL(emd_getmax_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
                            (const int *)cnts[cur], (const int *)bid, (const float *)bid_increments,
