@@ -37,10 +37,13 @@ class ScaleAdapter:
             raise RuntimeError("colorPoint failed: " + _lib.last_error())
         return out
 
-    def scaleReg(self, complete_xyz, partial_xyz, lr=0.01, iters=200):
-        """The diff_init step of reg() (reg_xyz.py:109-122): the inverse of the
-        pose-optimisation transform, as a [4,4] numpy array."""
-        import numpy as np
-        from .optim_registration.diff_obj_pose import object_pose_optimization
-        T = object_pose_optimization(complete_xyz, partial_xyz, lr=lr, iters=iters)
-        return np.linalg.inv(T)
+    def scaleReg(self, partial_xyz, complete_xyz):
+        """ScaleAdapter.py:74-75: reg(cfg, flag, cd_inv_weight=0.5, diff_init=True,
+        reg_fine_xyz=True) on tensors (partial = color_point.ply, complete = points
+        sampled from the generated mesh).  Returns reg()'s dict (aligned clouds and
+        transforms); the fusion tail (de-duplication, FPS, outlier removal, PLY output)
+        is the "next" row of SURVEY 8f."""
+        from .reg_xyz import reg
+        return reg(partial_xyz, complete_xyz, generative_model=getattr(self.cfg, "generative_model", "trellis"),
+                   dataset=getattr(self.cfg, "dataset", "redwood"), cd_inv_weight=0.5, diff_init=True,
+                   reg_fine_xyz=True)

@@ -122,3 +122,93 @@ def iterative_scale_search(source_pcd, target_pcd, scale_ranges, scale_steps, in
     S = np.eye(4)
     S[0, 0], S[1, 1], S[2, 2] = best_scales
     return S, float(sc[best]), best_T
+
+
+# ---------------------------------------------------------------------------
+# reg(): the composition of the stages above (reg_xyz.py:99-205) on tensors.
+# ---------------------------------------------------------------------------
+def get_rotate_matrix(axis, angle):
+    """utils/dataUtils.py:455-472 (degrees)."""
+    a = angle * np.pi / 180
+    c, s = np.cos(a), np.sin(a)
+    if axis == "x":
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    if axis == "y":
+        return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    if axis == "z":
+        return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+    raise ValueError("axis should be x,y,z")
+
+
+def normalize_numpy(xyz, range=1.0):
+    """utils/dataUtils.py:561-581 on a tensor: bbox-centre, divide by the largest
+    extent, scale to [-range, range].  Returns (normalised, centre, scale_factor)."""
+    vmin, vmax = xyz.min(0).values, xyz.max(0).values
+    center = (vmax + vmin) / 2.0
+    scale_factor = (vmax - vmin).max()
+    return (xyz - center) / scale_factor * (range / 0.5), center, scale_factor
+
+
+def voxel_down_sample(xyz, voxel_size):
+    """Counterpart of open3d's PointCloud.voxel_down_sample (reg_xyz.py:154-155; open3d
+    absent and unpinned): grid anchored at min_bound - voxel/2, one output point per
+    occupied voxel = mean of its points.  Output order: ascending voxel key (open3d's
+    is its hash-map order).  torch ops only -- format/plumbing layer."""
+    origin = xyz.min(0).values - voxel_size * 0.5
+    ijk = torch.floor((xyz - origin) / voxel_size).long()
+    dims = ijk.max(0).values + 1
+    key = (ijk[:, 0] * dims[1] + ijk[:, 1]) * dims[2] + ijk[:, 2]
+    uniq, inv = torch.unique(key, return_inverse=True)
+    out = torch.zeros(uniq.shape[0], 3, dtype=torch.float64, device=xyz.device)
+    out.index_add_(0, inv, xyz.double())
+    cnt = torch.zeros(uniq.shape[0], dtype=torch.float64, device=xyz.device)
+    cnt.index_add_(0, inv, torch.ones_like(inv, dtype=torch.float64))
+    return (out / cnt[:, None]).to(xyz.dtype)
+
+
+def _apply(T, xyz):
+    """open3d PointCloud.transform: p <- T[:3,:3] p + T[:3,3] (double, like open3d)."""
+    Tt = torch.as_tensor(np.asarray(T, np.float64), device=xyz.device)
+    return (xyz.double() @ Tt[:3, :3].T + Tt[:3, 3]).to(xyz.dtype)
+
+
+def reg(partial_xyz, complete_xyz, generative_model="trellis", dataset="redwood", cd_inv_weight=0.5,
+        diff_init=True, reg_fine_xyz=False, pose_points=(8000, 120000), pose_voxel=0.02):
+    """reg_xyz.py:99-205 without file I/O and without the fusion tail.
+    partial_xyz: the observed cloud (color_point.ply), complete_xyz: points sampled from
+    the generated mesh (glb2point).  Returns a dict with the aligned clouds
+    (`source`, `target`: both back in the partial cloud's original frame, as at
+    :200-205) and every intermediate transform."""
+    from .optim_registration.diff_obj_pose import object_pose_optimization
+    source = partial_xyz.contiguous().float()
+    target = complete_xyz.contiguous().float()
+    out = {}
+    diff_transform = np.eye(4)
+    if diff_init:                                                       # :109-122
+        T = object_pose_optimization(voxel_down_sample(target, pose_voxel), voxel_down_sample(source, pose_voxel),
+                                     radius=0.02, lr=0.01, iters=200, render_size=224)
+        diff_transform = np.linalg.inv(T.astype(np.float64))
+    out["diff_transform"] = diff_transform
+    source = _apply(diff_transform, source)                             # :126
+    target, _, _ = normalize_numpy(target, range=0.5)                   # :130
+    if generative_model in ("instantmesh",):                            # :132-137 (noise removal: SURVEY 8f f2)
+        target = (target.double() @ torch.as_tensor(get_rotate_matrix("x", 90).T, device=target.device)
+                  @ torch.as_tensor(get_rotate_matrix("y", 90).T, device=target.device)).float()
+    best_scale, best_loss, coarse = coarse_scale_sweep(voxel_down_sample(source, 0.03), voxel_down_sample(target, 0.03),
+                                                       cd_inv_weight=cd_inv_weight)            # :146-173
+    out.update(best_scale=best_scale, coarse_loss=best_loss, coarse_transformation=coarse)
+    if reg_fine_xyz:                                                    # :176-199
+        source = _apply(coarse, source)
+        tv = 0.04 if dataset in ("pcn", "kitti") else 0.03
+        src_s = source if dataset in ("pcn", "kitti") else voxel_down_sample(source, 0.03)
+        S, loss_xyz, T_xyz = iterative_scale_search(src_s, voxel_down_sample(target, tv), [(0.8, 1.2)] * 3, 10,
+                                                    init_transform=np.eye(4), cd_inv_weight=cd_inv_weight)
+        out.update(best_scales_transformation=S, xyz_loss=loss_xyz, best_transformation_xyz=T_xyz)
+        target = _apply(np.linalg.inv(S), target)
+        target = _apply(np.linalg.inv(T_xyz), target)
+        source = _apply(np.linalg.inv(coarse), source)
+    target = _apply(np.linalg.inv(coarse), target)                      # :201-205
+    target = _apply(np.linalg.inv(diff_transform), target)
+    source = _apply(np.linalg.inv(diff_transform), source)
+    out.update(source=source, target=target)
+    return out

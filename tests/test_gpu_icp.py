@@ -93,3 +93,42 @@ def test_coarse_sweep_and_scale_search(rg, oracle):
     assert abs(bs - 1.29) < 1e-9
     s = np.cbrt(np.linalg.det(Tc[:3, :3]))
     assert abs(s - 1.29) < 1e-6
+
+
+def test_voxel_down_sample_and_normalize(rg):
+    torch = rg["torch"]
+    xyz = torch.from_numpy(shape(3, 5000)).cuda()
+    v = rg["R"].voxel_down_sample(xyz, 0.03)
+    assert 100 < v.shape[0] < 5000
+    # every output is the mean of the inputs in its voxel
+    origin = xyz.min(0).values - 0.015
+    kin = torch.floor((xyz - origin) / 0.03).long()
+    kout = torch.floor((v - origin) / 0.03).long()
+    assert len({tuple(k) for k in kout.tolist()}) == v.shape[0]
+    k0 = kout[7]
+    sel = (kin == k0).all(1)
+    assert torch.allclose(xyz[sel].double().mean(0).float(), v[7], atol=1e-6)
+    nrm, c, s = rg["R"].normalize_numpy(xyz, range=0.5)
+    ext = nrm.max(0).values - nrm.min(0).values
+    assert abs(float(ext.max()) - 1.0) < 1e-6 and float((nrm.max(0).values + nrm.min(0).values).abs().max()) < 1e-6
+
+
+def test_reg_end_to_end(rg):
+    """Completed-scan unit: a complete cloud in its generator frame, and a partial
+    observation of the same object in a camera frame (anisotropically scaled, rotated,
+    shifted).  After reg() the aligned complete cloud explains the partial one."""
+    torch = rg["torch"]
+    from genpc_amd.utils.loss_util import Completionloss
+    complete = shape(21, 40000)
+    c = (complete.max(0) + complete.min(0)) / 2
+    complete = ((complete - c) / (complete.max(0) - complete.min(0)).max()).astype(np.float32)   # already "normalised"
+    R0 = rot([0.1, 1.0, 0.05], 8.0)
+    obs = (complete.astype(np.float64) * np.array([0.95, 1.1, 0.9]) * 0.8) @ R0.T + np.array([0.03, -0.02, 0.04])
+    partial = obs[obs[:, 2] > obs[:, 2].mean() - 0.05][::3].astype(np.float32)
+    res = rg["R"].reg(torch.from_numpy(partial).cuda(), torch.from_numpy(complete).cuda(), generative_model="trellis",
+                      dataset="redwood", cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=True)
+    assert torch.allclose(res["source"], torch.from_numpy(partial).cuda(), atol=1e-5)   # source returns to its frame
+    cl = Completionloss("cd_l1")
+    before = cl.chamfer_partial_l1(torch.from_numpy(partial).cuda()[None], torch.from_numpy(complete).cuda()[None]).item()
+    after = cl.chamfer_partial_l1(res["source"][None].contiguous(), res["target"][None].contiguous()).item()
+    assert after < 0.012 and after < 0.35 * before, (before, after)
