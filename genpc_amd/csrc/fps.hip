@@ -1,0 +1,178 @@
+// fps.hip -- farthest point sampling for gfx950 (the metric of
+// main.py:21-24 subsamples both clouds to 16384 points before CD/EMD, reg_xyz.py:215
+// samples 20000 fused points).  The reference calls fpsample.fps_sampling, a
+// third-party CPU extension with a RANDOM start index (not reproducible, unpinned);
+// this is the deterministic counterpart used by the fixtures: start index 0, fp32
+// squared distances, first arg-max.  Bit-exact with oracle_fps.
+//
+// FPS is k strictly sequential steps of (update N running minima, arg-max).  A
+// cloud is owned by W workgroups of 1024 threads (W = 1 for small clouds, up to 16);
+// every thread keeps its <= 16 points and their running minima in REGISTERS for the
+// whole run, so a step touches no memory except the current pivot's 12 bytes and an
+// 8-byte hand-off per workgroup.  Steps are synchronised with one publish/poll per
+// workgroup (8-byte agent-scope atomics on both sides, generation-tagged keys in a
+// double-buffered slot array -- no grid barrier, no fences, no reset between steps);
+// several clouds run side by side in one launch (grid.y).  All W workgroups of a
+// cloud must be co-resident: the launcher keeps W * clouds <= the CU count.
+#include "common.h"
+#include "../../include/genpc_hip.h"
+
+namespace genpc {
+
+constexpr int kFThreads = 1024;
+constexpr int kFMaxR = 16;
+constexpr int kFMaxW = 16;
+
+template <int FMA>
+__device__ __forceinline__ float sqdist_f(float dx, float dy, float dz)
+{
+    if (FMA) {
+        float t = __fmul_rn(dy, dy);
+        t = __fmaf_rn(dx, dx, t);
+        return __fmaf_rn(dz, dz, t);
+    } else {
+        float a = __fmul_rn(dx, dx);
+        float b = __fmul_rn(dy, dy);
+        float c = __fmul_rn(dz, dz);
+        return __fadd_rn(__fadd_rn(a, b), c);
+    }
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int off)
+{
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off, kWave);
+    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off, kWave);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// key = dist bits (32) | generation (12) | 0xFFFFF - index (20): max key == largest
+// distance, then (equal generation) lowest index.
+template <int FMA>
+__global__ __launch_bounds__(kFThreads) void fps_kernel(int n, int k, int W, const float *__restrict__ xyz,
+                                                        int *__restrict__ out_idx, unsigned long long *slots,
+                                                        int *__restrict__ err)
+{
+    __shared__ unsigned long long wkey[kFThreads / kWave];
+    __shared__ int s_cur;
+    const int cloud = blockIdx.y, wg = blockIdx.x, t = threadIdx.x;
+    const int lane = t & (kWave - 1), wave = t >> 6;
+    const float *__restrict__ X = xyz + (size_t)cloud * n * 3;
+    int *__restrict__ out = out_idx + (size_t)cloud * k;
+    unsigned long long *S = slots + (size_t)cloud * 2 * kFMaxW;
+    const int per = (n + W - 1) / W;
+    const int lo = wg * per;
+    const int hi = min(n, lo + per);
+    float px[kFMaxR], py[kFMaxR], pz[kFMaxR], d[kFMaxR];
+#pragma unroll
+    for (int r = 0; r < kFMaxR; r++) {
+        const int i = lo + t + r * kFThreads;
+        const bool ok = i < hi;
+        const int ii = ok ? i : (n - 1);
+        px[r] = X[(size_t)ii * 3 + 0];
+        py[r] = X[(size_t)ii * 3 + 1];
+        pz[r] = X[(size_t)ii * 3 + 2];
+        d[r] = ok ? __builtin_inff() : -1.0f;          // -1: never selected, never updated upward
+    }
+    int cur = 0;
+    for (int s = 0; s < k; s++) {
+        if (wg == 0 && t == 0) out[s] = cur;
+        const float cx = X[(size_t)cur * 3 + 0], cy = X[(size_t)cur * 3 + 1], cz = X[(size_t)cur * 3 + 2];
+        float bv = -1.0f;
+        int bi = 0;
+#pragma unroll
+        for (int r = 0; r < kFMaxR; r++) {
+            const float dd = sqdist_f<FMA>(px[r] - cx, py[r] - cy, pz[r] - cz);
+            const float v = d[r] < dd ? d[r] : dd;      // padding slots stay at -1
+            d[r] = v;
+            const bool gt = v > bv;                     // ascending index within a thread: first max
+            bv = gt ? v : bv;
+            bi = gt ? lo + t + r * kFThreads : bi;
+        }
+        const unsigned gen = (unsigned)(s % 4095) + 1u;
+        unsigned long long key = 0ull;
+        if (bv >= 0.0f)
+            key = ((unsigned long long)__float_as_uint(bv) << 32) | ((unsigned long long)gen << 20) |
+                  (unsigned long long)(0xFFFFFu - (unsigned)bi);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = shfl_xor_u64(key, off);
+            key = o > key ? o : key;
+        }
+        if (lane == 0) wkey[wave] = key;
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long kk = lane < kFThreads / kWave ? wkey[lane] : 0ull;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const unsigned long long o = shfl_xor_u64(kk, off);
+                kk = o > kk ? o : kk;
+            }
+            if (W > 1) {
+                unsigned long long *slot = S + (size_t)(s & 1) * kFMaxW;
+                if (lane == 0) __hip_atomic_store(slot + wg, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // poll the W slots of this step (lanes 0..W-1), bounded
+                unsigned long long v = 0ull;
+                int spins = 0;
+                for (;;) {
+                    bool ready = true;
+                    if (lane < W) {
+                        v = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ready = ((unsigned)(v >> 20) & 0xFFFu) == gen;
+                    }
+                    if (__all(ready)) break;
+                    if (++spins > (1 << 22)) {
+                        if (lane == 0) *err = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                kk = lane < W ? v : 0ull;
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+                    const unsigned long long o = shfl_xor_u64(kk, off);
+                    kk = o > kk ? o : kk;
+                }
+            }
+            if (lane == 0) s_cur = (int)(0xFFFFFu - (unsigned)(kk & 0xFFFFFu));
+        }
+        __syncthreads();
+        cur = s_cur;
+    }
+}
+
+}  // namespace genpc
+
+GENPC_API int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, void *stream)
+{
+    using namespace genpc;
+    if (c <= 0 || k <= 0) return 1;
+    if (n <= 0 || k > n || n > (1 << 20) || n > kFMaxW * kFMaxR * kFThreads) {
+        fprintf(stderr, "genpc_fps: need 0 < k <= n <= %d\n", kFMaxW * kFMaxR * kFThreads);
+        return -1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // workgroups per cloud: ~8 points per thread, never more than kFMaxR
+    int W = ceil_div(n, kFThreads * 8);
+    if (W > kFMaxW) W = kFMaxW;
+    if (W < 1) W = 1;
+    const int clouds_per_launch = W == 1 ? c : (kNumCU / W < 1 ? 1 : kNumCU / W);
+    const size_t slot_bytes = (size_t)c * 2 * kFMaxW * sizeof(unsigned long long);
+    char *ws = (char *)workspace(7, 256 + slot_bytes, st);
+    if (!ws) return 0;
+    int *err = (int *)ws;
+    unsigned long long *slots = (unsigned long long *)(ws + 256);
+    if (!check(hipMemsetAsync(ws, 0, 256 + slot_bytes, st), "hipMemsetAsync(fps)")) return 0;
+    const bool fma = arith_mode() != 0;
+    for (int c0 = 0; c0 < c; c0 += clouds_per_launch) {
+        const int cc = c - c0 < clouds_per_launch ? c - c0 : clouds_per_launch;
+        const float *x = xyz + (size_t)c0 * n * 3;
+        int *o = out_idx + (size_t)c0 * k;
+        unsigned long long *sl = slots + (size_t)c0 * 2 * kFMaxW;
+        if (fma)
+            hipLaunchKernelGGL(fps_kernel<1>, dim3(W, cc), dim3(kFThreads), 0, st, n, k, W, x, o, sl, err);
+        else
+            hipLaunchKernelGGL(fps_kernel<0>, dim3(W, cc), dim3(kFThreads), 0, st, n, k, W, x, o, sl, err);
+    }
+    if (!check(hipGetLastError(), "fps launch")) return 0;
+    return 1;
+}

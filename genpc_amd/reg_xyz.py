@@ -212,3 +212,34 @@ def reg(partial_xyz, complete_xyz, generative_model="trellis", dataset="redwood"
     source = _apply(np.linalg.inv(diff_transform), source)
     out.update(source=source, target=target)
     return out
+
+
+# ---------------------------------------------------------------------------
+# Fusion tail of reg() (reg_xyz.py:207-219), SURVEY 8f row f2.
+# ---------------------------------------------------------------------------
+def remove_close_points(source_xyz, target_xyz, distance_threshold=0.0001):
+    """reg_xyz.py:41-57: drop every target point whose nearest source point is closer
+    than sqrt(distance_threshold) (open3d's KD-tree returns SQUARED distances, so the
+    reference's 1e-4 is 0.01 units).  One NN launch instead of a Python loop of
+    KD-tree queries.  Returns (filtered target [K,3], keep mask [M])."""
+    from . import chamfer_3D
+    src = source_xyz.contiguous().float()
+    tgt = target_xyz.contiguous().float()
+    d = torch.empty(1, tgt.shape[0], device=tgt.device)
+    i = torch.empty(1, tgt.shape[0], device=tgt.device, dtype=torch.int32)
+    if chamfer_3D.nm_distance(tgt[None], src[None], d, i) != 1:
+        raise RuntimeError("nm_distance failed: " + _lib.last_error())
+    keep = ~(d[0] < distance_threshold)
+    return tgt[keep], keep
+
+
+def fuse(source_xyz, target_xyz, num_points=20000, distance_threshold=0.0001):
+    """reg_xyz.py:207-216: partial + (complete minus what the partial already covers),
+    farthest-point-sampled to `num_points`.  The statistical outlier filter that follows
+    in the reference (:217, open3d k-NN) is not part of this build."""
+    from .fps import fps_sampling
+    filtered, _ = remove_close_points(source_xyz, target_xyz, distance_threshold)
+    fused = torch.cat([source_xyz.float(), filtered], dim=0).contiguous()
+    if fused.shape[0] > num_points:
+        fused = fused[fps_sampling(fused, num_points).long()]
+    return fused

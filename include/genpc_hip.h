@@ -172,6 +172,14 @@ int genpc_scale_search_scores(int k, int ns, const float *source, int nt,
                               const float *target, const float *scales,
                               float cd_inv_weight, float *scores, void *stream);
 
+/* Farthest point sampling --------------------------------------------------- *
+ * Deterministic counterpart of fpsample.fps_sampling as the reference uses it
+ * (main.py:21-24, reg_xyz.py:215, DepthPrompting.py:88; third-party, random start):
+ * start index 0, fp32 squared distances in the library's arithmetic mode, first
+ * arg-max.  xyz[C,N,3] -> out_idx[C,k] int32, C clouds side by side.  Returns -1
+ * unless 0 < k <= n <= 262144.                                                  */
+int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -351,7 +351,13 @@ ORACLE_API int oracle_emd_backward(int b, int n, const float *xyz1,
  * a third-party Rust extension with a RANDOM start index, so its subsample is
  * not reproducible; this is the build's deterministic counterpart.
  * ---------------------------------------------------------------------- */
+ORACLE_API void oracle_fps_mode(int n, const float *xyz, int k, int fma_mode, int *out_idx);
 ORACLE_API void oracle_fps(int n, const float *xyz, int k, int *out_idx)
+{
+    oracle_fps_mode(n, xyz, k, 0, out_idx);
+}
+
+ORACLE_API void oracle_fps_mode(int n, const float *xyz, int k, int fma_mode, int *out_idx)
 {
     float *d = (float *)malloc(sizeof(float) * (size_t)n);
     for (int i = 0; i < n; i++) d[i] = INFINITY;
@@ -363,7 +369,7 @@ ORACLE_API void oracle_fps(int n, const float *xyz, int k, int *out_idx)
         int besti = 0;
         for (int i = 0; i < n; i++) {
             float dd = sqdist(xyz[i * 3 + 0] - cx, xyz[i * 3 + 1] - cy,
-                              xyz[i * 3 + 2] - cz, 0);
+                              xyz[i * 3 + 2] - cz, fma_mode);
             float v = d[i] < dd ? d[i] : dd;
             d[i] = v;
             if (v > bestv) {

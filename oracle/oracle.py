@@ -175,11 +175,12 @@ def emd_loss(dist):
 # --------------------------------------------------------------------------
 # Fixture helpers
 # --------------------------------------------------------------------------
-def fps(xyz, k):
-    """Deterministic farthest point sampling (start 0, first arg-max) -> idx[k]."""
+def fps(xyz, k, fma_mode=0):
+    """Deterministic farthest point sampling (start 0, first arg-max) -> idx[k].
+    fma_mode 0 is what the committed fixtures were subsampled with."""
     xyz, p = _f(xyz)
     out = np.zeros(k, np.int32)
-    lib().oracle_fps(xyz.shape[0], p, int(k), out.ctypes.data_as(_i32p))
+    lib().oracle_fps_mode(xyz.shape[0], p, int(k), int(fma_mode), out.ctypes.data_as(_i32p))
     return out
 
 

@@ -115,5 +115,36 @@ def main():
         np.savez_compressed(os.path.join(HERE, "scans13_fps16384.npz"), **out)
 
 
+def waymo():
+    """BASELINE config 4 inputs: the first 8 Waymo CAR crops resampled to 4096 points
+    (FPS when larger, pad-repeat when smaller: duplicated points exercise the tie
+    paths on real data), each scored against the next one."""
+    import glob
+    files = sorted(glob.glob(f"{REF}/data/waymo/CAR/*.ply"))[:8]
+    clouds, counts = [], []
+    for f in files:
+        p = O.read_ply_xyz(f).astype(np.float32)
+        counts.append(len(p))
+        if len(p) >= 4096:
+            clouds.append(p[O.fps(p, 4096)])
+        else:
+            clouds.append(p[np.arange(4096) % len(p)])
+    X = np.stack(clouds)
+    Y = np.roll(X, -1, axis=0).copy()
+    out = dict(files=np.array([os.path.basename(f) for f in files]), counts=np.array(counts), xyz1=X, xyz2=Y)
+    for mode in (0, 1):
+        d1, d2, i1, i2 = O.chamfer_forward(X, Y, mode)
+        d, ass, st = O.emd_forward(X, Y, 0.005, 50, mode, return_state=True)
+        out.update({f"cd_l1_m{mode}": np.array([O.cd_l1(d1[i], d2[i]) for i in range(8)], np.float32),
+                    f"idx1_m{mode}": i1, f"idx2_m{mode}": i2, f"dist1_m{mode}": d1,
+                    f"assignment_m{mode}": ass, f"emd_dist_m{mode}": d,
+                    f"emd_m{mode}": np.sqrt(d).mean(axis=1, dtype=np.float32)})
+        print("waymo mode", mode, counts, out[f"cd_l1_m{mode}"], out[f"emd_m{mode}"])
+    np.savez_compressed(os.path.join(HERE, "waymo_car8_4096.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--waymo" in sys.argv:
+        waymo()
+    else:
+        main()

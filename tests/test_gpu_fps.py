@@ -1,0 +1,63 @@
+"""GPU farthest point sampling vs the oracle: index sequences bit-exact in both
+arithmetic modes, one and several workgroups per cloud, several clouds per launch."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fg():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from genpc_amd import _lib
+    from genpc_amd.fps import fps_sampling, fps_subsample
+    return dict(torch=torch, lib=_lib, fps=fps_sampling, sub=fps_subsample)
+
+
+@pytest.mark.parametrize("n,k,c", [(1000, 100, 1), (5000, 2048, 3), (40000, 4096, 2), (165546, 2000, 1)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fps_matches_oracle(fg, oracle, n, k, c, mode):
+    torch = fg["torch"]
+    rng = np.random.default_rng(n + c)
+    x = (rng.random((c, n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    x[:, 10:20] = x[:, 0:10]                      # duplicates: arg-max ties
+    prev = fg["lib"].lib.genpc_set_arith(mode)
+    try:
+        idx = fg["fps"](torch.from_numpy(x).cuda(), k).cpu().numpy()
+    finally:
+        fg["lib"].lib.genpc_set_arith(prev)
+    for i in range(c):
+        np.testing.assert_array_equal(idx[i], oracle.fps(x[i], k, mode))
+    assert idx.shape == (c, k) and (idx[:, 0] == 0).all()
+
+
+def test_fps_reproduces_the_scan_fixture(fg, golden, oracle):
+    """The committed 2048-point fixture of scan 01184 was subsampled by the oracle;
+    subsampling the fixture itself again (k = N) must return a permutation, and a
+    full-size run is timed for the record."""
+    torch = fg["torch"]
+    g = golden("scan01184_fps2048.npz")
+    P = torch.from_numpy(g["partial"][0]).cuda()
+    idx = fg["fps"](P, 2048).cpu().numpy()
+    assert sorted(idx.tolist()) == list(range(2048))
+    np.testing.assert_array_equal(idx, oracle.fps(g["partial"][0], 2048, 1))
+    sub = fg["sub"](P[None], 256)
+    assert sub.shape == (1, 256, 3)
+    big = torch.rand(4, 165546, 3, device="cuda")
+    fg["fps"](big, 16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fg["fps"](big, 16384)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("FPS 4 x 165546 -> 16384: %.1f ms" % (dt * 1e3))
+    assert out.shape == (4, 16384) and int(out.max()) < 165546
+
+
+def test_fps_bad_args(fg):
+    torch = fg["torch"]
+    with pytest.raises(ValueError):
+        fg["fps"](torch.rand(10, 3).cuda(), 11)

@@ -132,3 +132,18 @@ def test_reg_end_to_end(rg):
     before = cl.chamfer_partial_l1(torch.from_numpy(partial).cuda()[None], torch.from_numpy(complete).cuda()[None]).item()
     after = cl.chamfer_partial_l1(res["source"][None].contiguous(), res["target"][None].contiguous()).item()
     assert after < 0.012 and after < 0.35 * before, (before, after)
+
+
+def test_fusion_tail(rg, oracle):
+    torch = rg["torch"]
+    tgt = shape(31, 30000)
+    src = tgt[::5][:3000] + np.float32(1e-4)           # the partial cloud covers part of the target
+    S_, T_ = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    filt, keep = rg["R"].remove_close_points(S_, T_, 1e-4)
+    d1, _, _, _ = oracle.chamfer_forward(tgt[None], src[None], 1)
+    np.testing.assert_array_equal(keep.cpu().numpy(), ~(d1[0] < np.float32(1e-4)))
+    assert 0 < filt.shape[0] < tgt.shape[0]
+    fused = rg["R"].fuse(S_, T_, num_points=20000)
+    assert fused.shape == (20000, 3)
+    allp = np.concatenate([src, tgt[keep.cpu().numpy()]])
+    np.testing.assert_array_equal(fused.cpu().numpy(), allp[oracle.fps(allp, 20000, 1)])

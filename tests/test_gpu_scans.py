@@ -64,3 +64,25 @@ def test_config1_scan01184_2048(tg, golden):
     t = tg["ev"](P, G).cpu().numpy()[0]
     assert abs(t[0] - float(g["cd_l1_m1"])) < 2e-8 and abs(t[1] - float(g["cd_l2_m1"])) < 2e-9
     assert abs(t[2] - float(g["emd_m1"])) < 2e-8
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_config4_waymo_cars_4096(tg, golden, mode):
+    """Waymo CAR crops at 4096 points (pad-repeated when smaller: exact duplicate
+    points, i.e. index ties in both Chamfer and the auction) -- bit-exact indices,
+    assignments and distances against the oracle."""
+    torch = tg["torch"]
+    g = golden("waymo_car8_4096.npz")
+    assert (g["counts"] < 4096).any() and (g["counts"] >= 4096).any()
+    X, Y = torch.from_numpy(g["xyz1"]).cuda(), torch.from_numpy(g["xyz2"]).cuda()
+    prev = tg["lib"].lib.genpc_set_arith(mode)
+    try:
+        d1, d2, i1, i2 = tg["cd"](X, Y)
+        de, ass = tg["emd"](X, Y, 0.005, 50)
+    finally:
+        tg["lib"].lib.genpc_set_arith(prev)
+    np.testing.assert_array_equal(i1.cpu().numpy(), g[f"idx1_m{mode}"])
+    np.testing.assert_array_equal(i2.cpu().numpy(), g[f"idx2_m{mode}"])
+    np.testing.assert_array_equal(d1.cpu().numpy(), g[f"dist1_m{mode}"])
+    np.testing.assert_array_equal(ass.cpu().numpy(), g[f"assignment_m{mode}"])
+    np.testing.assert_array_equal(de.cpu().numpy(), g[f"emd_dist_m{mode}"])
