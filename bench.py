@@ -120,7 +120,9 @@ def extras(A, B, n, dev, stream):
     f = lambda: chamfer_3D.forward(P13, Q13, o[0], o[1], o[2], o[3])  # noqa: E731
     f()
     t = time_events(f, 10, stream)
-    extra["chamfer_fwd_B13_n%d_gpair_s" % n] = round(13 * 2.0 * n * n / (t * 1e-3) / 1e9, 2)
+    g13 = 13 * 2.0 * n * n / (t * 1e-3) / 1e9
+    extra["chamfer_fwd_B13_n%d_gpair_s" % n] = round(g13, 2)
+    extra["chamfer_fwd_B13_n%d_frac_of_fp32_peak" % n] = round(FLOP_PER_PAIR * g13 * 1e9 / 1e12 / PEAK_FP32_TFLOPS, 4)
     em = emdModule()
     X = A + 0.5
     Y = B + 0.5
@@ -152,6 +154,32 @@ def extras(A, B, n, dev, stream):
         scan()
     torch.cuda.synchronize()
     extra["registration_8k_vs_16k_4x201_plus_metric_scans_per_s"] = round(3.0 / (time.perf_counter() - t0), 3)
+    # a17: the 1000-candidate anisotropic scale search of reg() (voxel-0.03 clouds are a few
+    # thousand points) -- one batched NN launch + one ICP -- and an 11-candidate coarse sweep
+    from genpc_amd import reg_xyz
+    src3k = (A[0, :3000] * 0.9).contiguous()
+    tgt3k = A[0, :4000].contiguous()
+    reg_xyz.iterative_scale_search(src3k, tgt3k, [(0.8, 1.2)] * 3, 10, cd_inv_weight=0.5)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        reg_xyz.iterative_scale_search(src3k, tgt3k, [(0.8, 1.2)] * 3, 10, cd_inv_weight=0.5)
+    torch.cuda.synchronize()
+    extra["scale_search_1000cand_3000x4000_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+    reg_xyz.coarse_scale_sweep(src3k, tgt3k, cd_inv_weight=0.5)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        reg_xyz.coarse_scale_sweep(src3k, tgt3k, cd_inv_weight=0.5)
+    torch.cuda.synchronize()
+    extra["coarse_sweep_11scales_2icp_each_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+    # f2: deterministic FPS, 4 clouds x 165546 -> 16384 (the metric's subsampling, main.py:21-24)
+    from genpc_amd.fps import fps_sampling
+    big = torch.rand(4, 165546, 3, device=dev)
+    fps_sampling(big, 64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fps_sampling(big, 16384)
+    torch.cuda.synchronize()
+    extra["fps_4x165546_to_16384_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
     # HBM-bound streaming kernel: getUvs for the reference's 1024 cameras x 71372 points
     cfg = SimpleNamespace(device=str(dev), fovy=49.1, res=256, padding=0.15, rescale=True, point_size=1,
                           mask_pixel_rate=3, view_num=1024, distance=1.6)
