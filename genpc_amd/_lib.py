@@ -10,7 +10,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgenpc_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -40,6 +40,7 @@ SIGNATURES = {
     "genpc_icp_batch": (_i, [_i, _i, _vp, _i, _vp, _d, _vp, _i, _d, _d, _vp, _vp, _vp]),
     "genpc_scale_search_scores": (_i, [_i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp]),
     "genpc_fps": (_i, [_i, _i, _vp, _i, _vp, _vp]),
+    "genpc_knn_mean_distance": (_i, [_i, _vp, _i, _vp, _vp]),
 }
 
 

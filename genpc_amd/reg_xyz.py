@@ -191,7 +191,8 @@ def reg(partial_xyz, complete_xyz, generative_model="trellis", dataset="redwood"
     out["diff_transform"] = diff_transform
     source = _apply(diff_transform, source)                             # :126
     target, _, _ = normalize_numpy(target, range=0.5)                   # :130
-    if generative_model in ("instantmesh",):                            # :132-137 (noise removal: SURVEY 8f f2)
+    if generative_model in ("instantmesh",):                            # :132-137
+        source, _ = remove_noise_from_point_cloud(source)
         target = (target.double() @ torch.as_tensor(get_rotate_matrix("x", 90).T, device=target.device)
                   @ torch.as_tensor(get_rotate_matrix("y", 90).T, device=target.device)).float()
     best_scale, best_loss, coarse = coarse_scale_sweep(voxel_down_sample(source, 0.03), voxel_down_sample(target, 0.03),
@@ -233,13 +234,40 @@ def remove_close_points(source_xyz, target_xyz, distance_threshold=0.0001):
     return tgt[keep], keep
 
 
-def fuse(source_xyz, target_xyz, num_points=20000, distance_threshold=0.0001):
-    """reg_xyz.py:207-216: partial + (complete minus what the partial already covers),
-    farthest-point-sampled to `num_points`.  The statistical outlier filter that follows
-    in the reference (:217, open3d k-NN) is not part of this build."""
+def fuse(source_xyz, target_xyz, num_points=20000, distance_threshold=0.0001, std_ratio=2.5):
+    """reg_xyz.py:207-217: partial + (complete minus what the partial already covers),
+    farthest-point-sampled to `num_points`, then the statistical outlier filter
+    (std_ratio 2.5 as at :217; None skips it)."""
     from .fps import fps_sampling
     filtered, _ = remove_close_points(source_xyz, target_xyz, distance_threshold)
     fused = torch.cat([source_xyz.float(), filtered], dim=0).contiguous()
     if fused.shape[0] > num_points:
         fused = fused[fps_sampling(fused, num_points).long()]
+    if std_ratio is not None:                                            # :217
+        fused, _ = remove_noise_from_point_cloud(fused, std_ratio=std_ratio)
     return fused
+
+
+def knn_mean_distance(xyz, k=20):
+    """Mean distance of every point to its k nearest points of the same cloud (the
+    point itself included) -- the statistic of open3d's remove_statistical_outlier."""
+    pts = xyz.contiguous().float()
+    _lib.check_tensors((("xyz", pts),))
+    out = torch.empty(pts.shape[0], device=pts.device)
+    rc = _lib.on_device_of(pts, _L.genpc_knn_mean_distance, pts.shape[0], _p(pts), int(k), _p(out))
+    if rc == -1:
+        raise ValueError("knn_mean_distance: k must be 8, 16, 20 or 32")
+    if rc != 1:
+        raise RuntimeError("genpc_knn_mean_distance failed: " + _lib.last_error())
+    return out
+
+
+def remove_noise_from_point_cloud(xyz, nb_neighbors=20, std_ratio=1.5):
+    """utils/dataUtils.py:648-662 (open3d remove_statistical_outlier) on a tensor: keeps
+    points whose mean k-NN distance is below mean + std_ratio * std (sample std, double).
+    Returns (filtered [K,3], keep mask [N])."""
+    m = knn_mean_distance(xyz, nb_neighbors).double()
+    mean = m.mean()
+    std = torch.sqrt(((m - mean) ** 2).sum() / (m.numel() - 1))
+    keep = m < mean + std_ratio * std
+    return xyz[keep], keep

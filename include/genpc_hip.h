@@ -180,6 +180,14 @@ int genpc_scale_search_scores(int k, int ns, const float *source, int nt,
  * unless 0 < k <= n <= 262144.                                                  */
 int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, void *stream);
 
+/* Statistical outlier filter ------------------------------------------------ *
+ * mean_out[N] = mean Euclidean distance of every point to its k nearest points of
+ * the same cloud, itself included (the per-point statistic of open3d's
+ * remove_statistical_outlier, utils/dataUtils.py:648-662 -> reg_xyz.py:134,217).
+ * k in {8, 16, 20, 32}; -1 otherwise.                                           */
+int genpc_knn_mean_distance(int n, const float *xyz, int k, float *mean_out,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -570,3 +570,55 @@ ORACLE_API void oracle_icp(int ns, const float *source, int nt, const float *tar
     stats[2] = it;
     free(pts); free(d); free(idx);
 }
+
+/* ------------------------------------------------------------------------
+ * Per-point statistic of open3d's remove_statistical_outlier (utils/dataUtils.py:
+ * 648-662; open3d absent, unpinned -- published algorithm restated): mean Euclidean
+ * distance to the k nearest points of the same cloud, the point itself included.
+ * fp32 squared distances in `fma_mode`, square roots and the sum (ascending) in
+ * double, result rounded to fp32.
+ * ---------------------------------------------------------------------- */
+static inline float sqd(float dx, float dy, float dz, int fma_mode)
+{
+    if (fma_mode) {
+        float t = dy * dy;
+        t = fmaf(dx, dx, t);
+        return fmaf(dz, dz, t);
+    }
+    float a = dx * dx, b = dy * dy, c = dz * dz;
+    float s = a + b;
+    return s + c;
+}
+
+ORACLE_API void oracle_knn_mean_distance(int n, const float *xyz, int k, int fma_mode, float *mean_out)
+{
+#pragma omp parallel
+    {
+        float *best = (float *)malloc(sizeof(float) * (size_t)k);
+#pragma omp for schedule(static)
+        for (int j = 0; j < n; j++) {
+            for (int i = 0; i < k; i++) best[i] = INFINITY;
+            float qx = xyz[(size_t)j * 3], qy = xyz[(size_t)j * 3 + 1], qz = xyz[(size_t)j * 3 + 2];
+            for (int u = 0; u < n; u++) {
+                float d = sqd(xyz[(size_t)u * 3] - qx, xyz[(size_t)u * 3 + 1] - qy, xyz[(size_t)u * 3 + 2] - qz, fma_mode);
+                if (d < best[k - 1]) {
+                    int i = k - 1;
+                    while (i > 0 && best[i - 1] > d) {
+                        best[i] = best[i - 1];
+                        i--;
+                    }
+                    best[i] = d;
+                }
+            }
+            double acc = 0;
+            int cnt = 0;
+            for (int i = 0; i < k; i++)
+                if (best[i] < INFINITY) {
+                    acc += sqrt((double)best[i]);
+                    cnt++;
+                }
+            mean_out[j] = (float)(acc / cnt);
+        }
+        free(best);
+    }
+}

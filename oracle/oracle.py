@@ -371,3 +371,19 @@ def icp(source, target, max_dist, init=None, max_iter=30, rel_fitness=1e-6, rel_
                      int(max_iter), ctypes.c_double(rel_fitness), ctypes.c_double(rel_rmse), int(fma_mode),
                      T.ctypes.data_as(_f64p), st.ctypes.data_as(_f64p))
     return T.reshape(4, 4), float(st[0]), float(st[1]), int(st[2])
+
+
+def knn_mean_distance(xyz, k=20, fma_mode=1):
+    """Mean distance to the k nearest points of the same cloud (self included)."""
+    x, px = _f(xyz)
+    out = np.zeros(x.shape[0], np.float32)
+    lib().oracle_knn_mean_distance(x.shape[0], px, int(k), int(fma_mode), out.ctypes.data_as(_f32p))
+    return out
+
+
+def statistical_outlier_mask(xyz, nb_neighbors=20, std_ratio=2.0, fma_mode=1):
+    """open3d remove_statistical_outlier: keep mask."""
+    m = knn_mean_distance(xyz, nb_neighbors, fma_mode).astype(np.float64)
+    mean = m.mean()
+    std = np.sqrt(((m - mean) ** 2).sum() / (len(m) - 1))
+    return m < mean + std_ratio * std

@@ -143,7 +143,30 @@ def test_fusion_tail(rg, oracle):
     d1, _, _, _ = oracle.chamfer_forward(tgt[None], src[None], 1)
     np.testing.assert_array_equal(keep.cpu().numpy(), ~(d1[0] < np.float32(1e-4)))
     assert 0 < filt.shape[0] < tgt.shape[0]
-    fused = rg["R"].fuse(S_, T_, num_points=20000)
+    fused = rg["R"].fuse(S_, T_, num_points=20000, std_ratio=None)
     assert fused.shape == (20000, 3)
     allp = np.concatenate([src, tgt[keep.cpu().numpy()]])
     np.testing.assert_array_equal(fused.cpu().numpy(), allp[oracle.fps(allp, 20000, 1)])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_statistical_outlier_filter(rg, oracle, mode):
+    torch = rg["torch"]
+    from genpc_amd import _lib
+    rng = np.random.default_rng(8)
+    pts = np.concatenate([shape(41, 6000), (rng.random((60, 3), dtype=np.float32) - 0.5) * 3]).astype(np.float32)
+    pts[100:110] = pts[0:10]                           # duplicates: several zero distances
+    prev = _lib.lib.genpc_set_arith(mode)
+    try:
+        m = rg["R"].knn_mean_distance(torch.from_numpy(pts).cuda(), 20).cpu().numpy()
+        filt, keep = rg["R"].remove_noise_from_point_cloud(torch.from_numpy(pts).cuda(), 20, 1.5)
+    finally:
+        _lib.lib.genpc_set_arith(prev)
+    np.testing.assert_array_equal(m, oracle.knn_mean_distance(pts, 20, mode))
+    np.testing.assert_array_equal(keep.cpu().numpy(), oracle.statistical_outlier_mask(pts, 20, 1.5, mode))
+    assert keep[:6000].float().mean() > 0.95 and keep[6000:].float().mean() < 0.2      # the far-away noise goes
+    with pytest.raises(ValueError):
+        rg["R"].knn_mean_distance(torch.from_numpy(pts).cuda(), 7)
+    tiny = torch.from_numpy(pts[:5]).cuda()            # fewer points than k: mean over what exists
+    mt = rg["R"].knn_mean_distance(tiny, 8).cpu().numpy()
+    np.testing.assert_array_equal(mt, oracle.knn_mean_distance(pts[:5], 8, 1))
