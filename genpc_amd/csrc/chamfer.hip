@@ -66,6 +66,7 @@ struct NNDir {
     unsigned long long *part;   // per-slice partials [S, B*nq] (S > 1): distance bits << 32 | chunk
     int nq, nt;
     int qblocks;       // ceil(nq / (256*R))
+    int slices;        // S for this direction: ceil(nt / slice_len)
     int block_begin;   // first block id of this direction
     int unit_begin;    // first arrival counter of this direction
 };
@@ -74,8 +75,7 @@ struct NNArgs {
     NNDir dir[2];
     int ndir;
     int b;
-    int slices;        // S
-    int slice_len;     // targets per slice, multiple of kChunk
+    int slice_len;     // targets per slice (all blocks of a launch do equal work), multiple of kChunk
     int *arrive;       // [sum_d b*qblocks] arrival counters, zero between launches
     int debug;         // experiment switches (GENPC_NN_DEBUG): 1 skip index recovery, 2 skip merge, 4 skip main loop
 };
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
         }
     }
 
-    if (a.slices > 1) {
+    if (D.slices > 1) {
         // Publish this slice's (minimum, chunk) per query; the last block to arrive for
         // this (direction, batch, query block) folds all S slices in slice order with
         // strict '<' (earlier slice == lower index wins) and carries on alone.
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
         if (threadIdx.x == 0)
             *s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (*s_ticket != a.slices - 1) return;
+        if (*s_ticket != D.slices - 1) return;
         if (threadIdx.x == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
             unsigned long long v = __hip_atomic_load(P + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             float bv = __uint_as_float((unsigned)(v >> 32));
             int bc = (int)(unsigned)v;
-            for (int s2 = 1; s2 < a.slices; s2++) {
+            for (int s2 = 1; s2 < D.slices; s2++) {
                 v = __hip_atomic_load(P + (size_t)s2 * bnq + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const float vv = __uint_as_float((unsigned)(v >> 32));
                 const bool lt = vv < bv;
@@ -365,12 +365,9 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     }
     a.ndir = nd;
     if (nd == 0) return 1;
-    // Slices are never shorter than 8 chunks.  R = 4 (fewer LDS reads per pair, more
-    // independent chains per lane) when the query blocks alone fill the chip; R = 2
-    // otherwise: twice the blocks, half the per-wave epilogue (measured on MI355X:
-    // 1x16384^2 87 us vs 97 us, 13x16384^2 870 us vs 835 us).
-    long long max_s = nt_max / (kChunk * 8);
-    if (max_s < 1) max_s = 1;
+    // R = 4 (fewer LDS reads per pair, more independent chains per lane) when the query
+    // blocks alone fill the chip; R = 2 otherwise: twice the blocks, half the per-wave
+    // epilogue (measured on MI355X: 1x16384^2 87 us vs 97 us, 13x16384^2 870 us vs 835 us).
     const long long want_blocks = (long long)kNumCU * cfg.blocks_per_cu;
     int r = cfg.r;
     if (!r) {
@@ -378,39 +375,52 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         for (int d = 0; d < nd; d++) unsplit4 += (long long)b * ceil_div(a.dir[d].nq, kBlock * 4);
         r = unsplit4 >= kNumCU ? 4 : 2;
     }
-    long long unsplit = 0;
-    for (int d = 0; d < nd; d++) unsplit += (long long)b * ceil_div(a.dir[d].nq, kBlock * r);
-    long long S = 1;
-    if (unsplit < want_blocks) S = ceil_div64(want_blocks, unsplit);
-    if (S > max_s) S = max_s;
-    // prefer slices of >= 512 targets when that still leaves two blocks per CU (measured
-    // 1x8192^2: 44 us with 512-target slices vs 51 us with 256)
-    const long long s512 = nt_max / (kChunk * 16);
-    if (S > s512 && s512 >= 1 && unsplit * s512 >= 2 * kNumCU) S = s512;
-    a.slice_len = ceil_div(ceil_div(nt_max, (int)S), kChunk) * kChunk;
-    // no slice is empty for the LONGEST target set; a shorter target set may have
-    // empty trailing slices (they produce +inf and lose every strict '<')
-    a.slices = ceil_div(nt_max, a.slice_len);
+    // One slice length for the whole launch, so that every block does the same amount
+    // of work, and per-direction slice counts S_d = ceil(nt_d / slice_len) (no empty
+    // slices when the two clouds differ in size).  slice_len is what makes the launch
+    // ~want_blocks blocks: sum_d b * qblocks_d * nt_d / want_blocks, but never below 8
+    // chunks, and not below 16 chunks (512 targets: below that the per-block staging /
+    // merge latency outweighs the parallelism; measured 1x8192^2 44 us vs 51 us) as long
+    // as two blocks per CU remain.
+    long long work = 0;          // blocks x targets if every block took one target
+    for (int d = 0; d < nd; d++) {
+        a.dir[d].qblocks = ceil_div(a.dir[d].nq, kBlock * r);
+        work += (long long)b * a.dir[d].qblocks * a.dir[d].nt;
+    }
+    auto blocks_at = [&](long long len) {
+        long long t = 0;
+        for (int d = 0; d < nd; d++) t += (long long)b * a.dir[d].qblocks * ceil_div64(a.dir[d].nt, len);
+        return t;
+    };
+    long long len = ceil_div64(ceil_div64(work, want_blocks), kChunk) * kChunk;
+    if (len < kChunk * 8) len = kChunk * 8;
+    if (len < kChunk * 16 && blocks_at(kChunk * 16) >= 2 * kNumCU) len = kChunk * 16;
+    if (len > nt_max) len = ceil_div64(nt_max, kChunk) * kChunk;
+    a.slice_len = (int)len;
     long long tb = 0;
     int units = 0;
     size_t part = 0;
+    bool any_split = false;
     for (int d = 0; d < nd; d++) {
         NNDir &D = a.dir[d];
-        D.qblocks = ceil_div(D.nq, kBlock * r);
+        D.slices = ceil_div(D.nt, a.slice_len);
         D.block_begin = (int)tb;
         D.unit_begin = units;
-        tb += (long long)a.slices * b * D.qblocks;
+        tb += (long long)D.slices * b * D.qblocks;
         units += b * D.qblocks;
-        part += (size_t)a.slices * b * D.nq;
+        if (D.slices > 1) {
+            part += (size_t)D.slices * b * D.nq;
+            any_split = true;
+        }
     }
     if (tb > 0x7fffffffLL) {
         set_error("chamfer: problem too large for one launch");
         return 0;
     }
-    if (a.slices > 1) {
-        // [arrival counters | partial distances | partial indices]; counters are
-        // zeroed when the block is (re)allocated and restored to zero by the merging
-        // block, so steady-state calls need no memset.
+    if (any_split) {
+        // [arrival counters | per-slice partials]; counters are zeroed when the block is
+        // (re)allocated and restored to zero by the merging block, so steady-state calls
+        // need no memset.
         const size_t cnt_bytes = (size_t)1 << 16;
         if ((size_t)units * sizeof(int) > cnt_bytes) {
             set_error("chamfer: too many query blocks for the arrival-counter area");
@@ -422,8 +432,10 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         unsigned long long *wp = (unsigned long long *)(ws + cnt_bytes);
         size_t off = 0;
         for (int d = 0; d < nd; d++) {
-            a.dir[d].part = wp + off;
-            off += (size_t)a.slices * b * a.dir[d].nq;
+            if (a.dir[d].slices > 1) {
+                a.dir[d].part = wp + off;
+                off += (size_t)a.dir[d].slices * b * a.dir[d].nq;
+            }
         }
     }
     if (r == 4) launch_r<4>(a, (int)tb, st); else launch_r<2>(a, (int)tb, st);
