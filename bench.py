@@ -154,6 +154,19 @@ def extras(A, B, n, dev, stream):
         scan()
     torch.cuda.synchronize()
     extra["registration_8k_vs_16k_4x201_plus_metric_scans_per_s"] = round(3.0 / (time.perf_counter() - t0), 3)
+    # the same, 8 scans in lock-step (one batched NN launch per Adam step) + batched metric
+    C8 = (torch.rand(8, n, 3, device=dev) - 0.5)
+    P8b = (C8[:, :8192] * 0.9).contiguous()
+    X8, Y8 = C8 + 0.5, (C8.flip(0) + 0.5).contiguous()
+    from genpc_amd.metric import evaluate_scans
+    object_pose_optimization(C8, P8b, lr=0.01, iters=200)
+    evaluate_scans(X8, Y8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    object_pose_optimization(C8, P8b, lr=0.01, iters=200)
+    evaluate_scans(X8, Y8)
+    torch.cuda.synchronize()
+    extra["registration_batch8_8k_vs_16k_4x201_plus_metric_scans_per_s"] = round(8.0 / (time.perf_counter() - t0), 3)
     # a17: the 1000-candidate anisotropic scale search of reg() (voxel-0.03 clouds are a few
     # thousand points) -- one batched NN launch + one ICP -- and an 11-candidate coarse sweep
     from genpc_amd import reg_xyz

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgenpc_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -37,6 +37,7 @@ SIGNATURES = {
     "genpc_pose_transform": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_pose_cd_grad": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "genpc_pose_optimize_cd": (_i, [_i, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
+    "genpc_pose_optimize_cd_batch": (_i, [_i, _i, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "genpc_icp_batch": (_i, [_i, _i, _vp, _i, _vp, _d, _vp, _i, _d, _d, _vp, _vp, _vp]),
     "genpc_scale_search_scores": (_i, [_i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp]),
     "genpc_fps": (_i, [_i, _i, _vp, _i, _vp, _vp]),

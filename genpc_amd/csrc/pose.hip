@@ -30,7 +30,7 @@ extern "C" int genpc_chamfer_forward(int b, int n, const float *xyz1, int m, con
 
 namespace genpc {
 
-int genpc_mean3(int n, const float *v, float *out, double *accum, hipStream_t st);
+int genpc_mean3(int b, int n, const float *v, float *out, double *accum, hipStream_t st);
 
 constexpr int kQBlock = 256;
 
@@ -63,11 +63,18 @@ __device__ __forceinline__ void pose_point(const float *R, float s, const float 
 }
 
 // diff_obj_pose.py:419-423
+// blockIdx.y = batch element; element e reads v + e*n*3, center + e*cstride,
+// params + e*pstride (strides in floats) and writes pts + e*n*3.
 __global__ __launch_bounds__(kQBlock) void pose_transform_kernel(int n, const float *__restrict__ v,
-                                                                 const float *__restrict__ center,
-                                                                 const float *__restrict__ params,
+                                                                 const float *__restrict__ center, int cstride,
+                                                                 const float *__restrict__ params, int pstride,
                                                                  float *__restrict__ pts)
 {
+    const int e = blockIdx.y;
+    v += (size_t)e * n * 3;
+    pts += (size_t)e * n * 3;
+    center += (size_t)e * cstride;
+    params += (size_t)e * pstride;
     float R[9];
     rot6d_to_matrix(params, R);
     const float s = expf(params[9]);
@@ -87,14 +94,22 @@ __global__ __launch_bounds__(kQBlock) void pose_transform_kernel(int n, const fl
 // nc <= t < nc+np: term of partial point t-nc (partial -> pts), attributed to the
 // complete point it matched.
 __global__ __launch_bounds__(kQBlock) void pose_grad_kernel(int nc, const float *__restrict__ v,
-                                                            const float *__restrict__ center,
-                                                            const float *__restrict__ params, int np,
+                                                            const float *__restrict__ center, int cstride,
+                                                            const float *__restrict__ params, int pstride, int np,
                                                             const float *__restrict__ partial,
                                                             const float *__restrict__ d1, const int *__restrict__ i1,
                                                             const float *__restrict__ d2, const int *__restrict__ i2,
                                                             float cd_weight, double *__restrict__ accum)
 {
     __shared__ double red[15][kQBlock / kWave];
+    const int e = blockIdx.y;
+    v += (size_t)e * nc * 3;
+    partial += (size_t)e * np * 3;
+    d1 += (size_t)e * nc; i1 += (size_t)e * nc;
+    d2 += (size_t)e * np; i2 += (size_t)e * np;
+    center += (size_t)e * cstride;
+    params += (size_t)e * pstride;
+    accum += (size_t)e * 16;
     float R[9];
     rot6d_to_matrix(params, R);
     const float s = expf(params[9]);
@@ -164,11 +179,15 @@ struct PoseState {       // device-resident
 
 // One thread: finish the gradient (orthogonality term + 6D backward), optionally
 // take the Adam step, record the loss, clear the accumulators.
-__global__ void pose_update_kernel(PoseState *__restrict__ S, double *__restrict__ accum, int nc, int np,
+__global__ void pose_update_kernel(int b, PoseState *__restrict__ S, double *__restrict__ accum, int nc, int np,
                                    float cd_weight, float reg_weight, float lr, int do_step,
-                                   float *__restrict__ history_slot)
+                                   float *__restrict__ history_slot, int history_stride)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= b) return;
+    S += e;
+    accum += (size_t)e * 16;
+    if (history_slot) history_slot += (size_t)e * history_stride;
     float Rf[9];
     rot6d_to_matrix(S->params, Rf);
     const double s = (double)expf(S->params[9]);
@@ -244,9 +263,12 @@ __global__ void pose_update_kernel(PoseState *__restrict__ S, double *__restrict
 
 // start < 0: global init.  Otherwise begin start `start` (get_init_rot('y', 90*start),
 // trans 0, log_scale log(0.75): diff_obj_pose.py:367,519).
-__global__ void pose_begin_kernel(PoseState *__restrict__ S, double *__restrict__ accum, int start)
+__global__ void pose_begin_kernel(int b, PoseState *__restrict__ S, double *__restrict__ accum, int start)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= b) return;
+    S += e;
+    accum += (size_t)e * 16;
     if (start < 0) {
         S->best_loss = __builtin_inff();
         for (int k = 0; k < 10; k++) S->best_params[k] = 0.0f;
@@ -266,10 +288,14 @@ __global__ void pose_begin_kernel(PoseState *__restrict__ S, double *__restrict_
 
 // end of a start: keep the FINAL parameters of the start with the lowest loss seen
 // (diff_obj_pose.py:570-576).  final != 0: also emit T = [[sR, t],[0,1]] (:464-468).
-__global__ void pose_end_kernel(PoseState *__restrict__ S, int final, float *__restrict__ transform,
+__global__ void pose_end_kernel(int b, PoseState *__restrict__ S, int final, float *__restrict__ transform,
                                 float *__restrict__ best_params)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= b) return;
+    S += e;
+    if (transform) transform += (size_t)e * 16;
+    if (best_params) best_params += (size_t)e * 10;
     if (!final) {
         if (S->local_best < S->best_loss) {
             S->best_loss = S->local_best;
@@ -305,8 +331,8 @@ GENPC_API int genpc_pose_transform(int n, const float *v, const float *center, c
 {
     using namespace genpc;
     if (n <= 0) return 1;
-    hipLaunchKernelGGL(pose_transform_kernel, dim3(lin_grid(n)), dim3(kQBlock), 0, (hipStream_t)stream, n, v, center,
-                       params, pts);
+    hipLaunchKernelGGL(pose_transform_kernel, dim3(lin_grid(n), 1), dim3(kQBlock), 0, (hipStream_t)stream, n, v, center,
+                       0, params, 0, pts);
     return check(hipGetLastError(), "pose_transform launch") ? 1 : 0;
 }
 
@@ -321,71 +347,90 @@ GENPC_API int genpc_pose_cd_grad(int nc, const float *v, const float *center, co
     if (!ws) return 0;
     double *accum = (double *)ws;
     PoseState *S = (PoseState *)(ws + 256);
-    if (!check(hipMemsetAsync(accum, 0, 15 * sizeof(double), st), "hipMemsetAsync(accum)")) return 0;
+    if (!check(hipMemsetAsync(accum, 0, 16 * sizeof(double), st), "hipMemsetAsync(accum)")) return 0;
     if (!check(hipMemcpyAsync(S->params, params, 10 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy params"))
         return 0;
-    hipLaunchKernelGGL(pose_grad_kernel, dim3(lin_grid((long long)nc + np)), dim3(kQBlock), 0, st, nc, v, center,
-                       params, np, partial, d1, i1, d2, i2, cd_weight, accum);
-    hipLaunchKernelGGL(pose_update_kernel, dim3(1), dim3(64), 0, st, S, accum, nc, np, cd_weight, reg_weight, 0.0f, 0,
-                       (float *)nullptr);
+    hipLaunchKernelGGL(pose_grad_kernel, dim3(lin_grid((long long)nc + np), 1), dim3(kQBlock), 0, st, nc, v, center, 0,
+                       params, 0, np, partial, d1, i1, d2, i2, cd_weight, accum);
+    hipLaunchKernelGGL(pose_update_kernel, dim3(1), dim3(64), 0, st, 1, S, accum, nc, np, cd_weight, reg_weight, 0.0f, 0,
+                       (float *)nullptr, 0);
     if (!check(hipMemcpyAsync(grad, S->grad, 10 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy grad")) return 0;
     if (!check(hipMemcpyAsync(loss_out, S->loss, 3 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy loss")) return 0;
     return check(hipGetLastError(), "pose_cd_grad launch") ? 1 : 0;
+}
+
+GENPC_API int genpc_pose_optimize_cd_batch(int b, int nc, const float *complete, int np, const float *partial,
+                                           float lr, int iters, int starts, float *transform, float *history,
+                                           float *best_params, void *stream)
+{
+    using namespace genpc;
+    if (b <= 0 || nc <= 0 || np <= 0 || iters < 0 || starts < 1) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    // scratch: accum[b,16] | state[b] | center[b,4] | pts[b,nc,3] | d1 | d2 | i1 | i2
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    size_t off = 0;
+    const size_t o_acc = off; off += up((size_t)b * 16 * sizeof(double));
+    const size_t o_state = off; off += up((size_t)b * sizeof(PoseState));
+    const size_t o_center = off; off += up((size_t)b * 4 * sizeof(float));
+    const size_t o_pts = off; off += up((size_t)b * nc * 12);
+    const size_t o_d1 = off; off += up((size_t)b * nc * 4);
+    const size_t o_d2 = off; off += up((size_t)b * np * 4);
+    const size_t o_i1 = off; off += up((size_t)b * nc * 4);
+    const size_t o_i2 = off; off += up((size_t)b * np * 4);
+    char *ws = (char *)workspace(4, off, st);
+    if (!ws) return 0;
+    double *accum = (double *)(ws + o_acc);
+    PoseState *S = (PoseState *)(ws + o_state);
+    float *center = (float *)(ws + o_center);
+    float *pts = (float *)(ws + o_pts);
+    float *d1 = (float *)(ws + o_d1), *d2 = (float *)(ws + o_d2);
+    int *i1 = (int *)(ws + o_i1), *i2 = (int *)(ws + o_i2);
+    constexpr int kStateFloats = (int)(sizeof(PoseState) / sizeof(float));
+    static_assert(sizeof(PoseState) % sizeof(float) == 0, "PoseState must be float-addressable");
+
+    // center = mean(vert_pos) per scan (diff_obj_pose.py:362)
+    if (!genpc_mean3(b, nc, complete, center, accum, st)) return 0;
+
+    const int gb = ceil_div(b, 64);
+    hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, -1);
+    const int g_t = lin_grid(nc), g_g = lin_grid((long long)nc + np);
+    const int hstride = starts * (iters + 1);
+    for (int s = 0; s < starts; s++) {
+        hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, s);
+        for (int it = 0; it <= iters; it++) {
+            hipLaunchKernelGGL(pose_transform_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
+                               (const float *)center, 4, (const float *)S->params, kStateFloats, pts);
+            if (genpc_chamfer_forward(b, nc, pts, np, partial, d1, i1, d2, i2, stream) != 1) return 0;
+            hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, st, nc, complete, (const float *)center,
+                               4, (const float *)S->params, kStateFloats, np, partial, (const float *)d1,
+                               (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, accum);
+            hipLaunchKernelGGL(pose_update_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, nc, np, 3.0f, 0.001f, lr, 1,
+                               history ? history + (size_t)s * (iters + 1) + it : (float *)nullptr, hstride);
+        }
+        hipLaunchKernelGGL(pose_end_kernel, dim3(gb), dim3(64), 0, st, b, S, 0, (float *)nullptr, (float *)nullptr);
+    }
+    hipLaunchKernelGGL(pose_end_kernel, dim3(gb), dim3(64), 0, st, b, S, 1, transform, best_params);
+    return check(hipGetLastError(), "pose_optimize_cd launch") ? 1 : 0;
 }
 
 GENPC_API int genpc_pose_optimize_cd(int nc, const float *complete, int np, const float *partial, float lr,
                                      int iters, int starts, float *transform, float *history, float *best_params,
                                      void *stream)
 {
-    using namespace genpc;
-    if (nc <= 0 || np <= 0 || iters < 0 || starts < 1) return -1;
-    hipStream_t st = (hipStream_t)stream;
-    // scratch: accum | state | center | pts | d1 | d2 | i1 | i2
-    const size_t off_state = 256, off_center = 512, off_pts = 1024;
-    const size_t off_d1 = off_pts + (size_t)nc * 12;
-    const size_t off_d2 = off_d1 + (size_t)nc * 4;
-    const size_t off_i1 = off_d2 + (size_t)np * 4;
-    const size_t off_i2 = off_i1 + (size_t)nc * 4;
-    const size_t total = off_i2 + (size_t)np * 4;
-    char *ws = (char *)workspace(4, total, st);
-    if (!ws) return 0;
-    double *accum = (double *)ws;
-    PoseState *S = (PoseState *)(ws + off_state);
-    float *center = (float *)(ws + off_center);
-    float *pts = (float *)(ws + off_pts);
-    float *d1 = (float *)(ws + off_d1), *d2 = (float *)(ws + off_d2);
-    int *i1 = (int *)(ws + off_i1), *i2 = (int *)(ws + off_i2);
-
-    // center = mean(complete) (diff_obj_pose.py:362): reuse the gradient reduction
-    // machinery would be overkill; a tiny dedicated pass instead.
-    if (!genpc_mean3(nc, complete, center, accum, st)) return 0;
-
-    hipLaunchKernelGGL(pose_begin_kernel, dim3(1), dim3(64), 0, st, S, accum, -1);
-    const int g_t = lin_grid(nc), g_g = lin_grid((long long)nc + np);
-    for (int s = 0; s < starts; s++) {
-        hipLaunchKernelGGL(pose_begin_kernel, dim3(1), dim3(64), 0, st, S, accum, s);
-        for (int it = 0; it <= iters; it++) {
-            hipLaunchKernelGGL(pose_transform_kernel, dim3(g_t), dim3(kQBlock), 0, st, nc, complete,
-                               (const float *)center, (const float *)S->params, pts);
-            if (genpc_chamfer_forward(1, nc, pts, np, partial, d1, i1, d2, i2, stream) != 1) return 0;
-            hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g), dim3(kQBlock), 0, st, nc, complete, (const float *)center,
-                               (const float *)S->params, np, partial, (const float *)d1, (const int *)i1,
-                               (const float *)d2, (const int *)i2, 3.0f, accum);
-            hipLaunchKernelGGL(pose_update_kernel, dim3(1), dim3(64), 0, st, S, accum, nc, np, 3.0f, 0.001f, lr, 1,
-                               history ? history + (size_t)s * (iters + 1) + it : (float *)nullptr);
-        }
-        hipLaunchKernelGGL(pose_end_kernel, dim3(1), dim3(64), 0, st, S, 0, (float *)nullptr, (float *)nullptr);
-    }
-    hipLaunchKernelGGL(pose_end_kernel, dim3(1), dim3(64), 0, st, S, 1, transform, best_params);
-    return check(hipGetLastError(), "pose_optimize_cd launch") ? 1 : 0;
+    return genpc_pose_optimize_cd_batch(1, nc, complete, np, partial, lr, iters, starts, transform, history,
+                                        best_params, stream);
 }
 
 namespace genpc {
 
+// accum[e*16 + 0..2] += sum of v[e, :, 0..2]
 __global__ __launch_bounds__(kQBlock) void mean3_accum_kernel(int n, const float *__restrict__ v,
                                                               double *__restrict__ accum)
 {
     __shared__ double red[3][kQBlock / kWave];
+    const int e = blockIdx.y;
+    v += (size_t)e * n * 3;
+    accum += (size_t)e * 16;
     double a[3] = {0.0, 0.0, 0.0};
     for (int j = blockIdx.x * kQBlock + threadIdx.x; j < n; j += gridDim.x * kQBlock) {
         a[0] += (double)v[(size_t)j * 3 + 0];
@@ -408,19 +453,20 @@ __global__ __launch_bounds__(kQBlock) void mean3_accum_kernel(int n, const float
     }
 }
 
-__global__ void mean3_finish_kernel(int n, double *__restrict__ accum, float *__restrict__ out)
+__global__ void mean3_finish_kernel(int b, int n, double *__restrict__ accum, float *__restrict__ out)
 {
-    if (threadIdx.x < 3 && blockIdx.x == 0) {
-        out[threadIdx.x] = (float)(accum[threadIdx.x] / n);
-        accum[threadIdx.x] = 0.0;
-    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b * 3) return;
+    const int e = t / 3, k = t % 3;
+    out[e * 4 + k] = (float)(accum[(size_t)e * 16 + k] / n);
+    accum[(size_t)e * 16 + k] = 0.0;
 }
 
-int genpc_mean3(int n, const float *v, float *out, double *accum, hipStream_t st)
+int genpc_mean3(int b, int n, const float *v, float *out, double *accum, hipStream_t st)
 {
-    if (!check(hipMemsetAsync(accum, 0, 3 * sizeof(double), st), "hipMemsetAsync(mean)")) return 0;
-    hipLaunchKernelGGL(mean3_accum_kernel, dim3(lin_grid(n)), dim3(kQBlock), 0, st, n, v, accum);
-    hipLaunchKernelGGL(mean3_finish_kernel, dim3(1), dim3(64), 0, st, n, accum, out);
+    if (!check(hipMemsetAsync(accum, 0, (size_t)b * 16 * sizeof(double), st), "hipMemsetAsync(mean)")) return 0;
+    hipLaunchKernelGGL(mean3_accum_kernel, dim3(lin_grid(n), b), dim3(kQBlock), 0, st, n, v, accum);
+    hipLaunchKernelGGL(mean3_finish_kernel, dim3(ceil_div(b * 3, 64)), dim3(64), 0, st, b, n, accum, out);
     return check(hipGetLastError(), "mean3 launch") ? 1 : 0;
 }
 

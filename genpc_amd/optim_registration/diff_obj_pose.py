@@ -59,21 +59,31 @@ def pose_cd_loss_grad(vert_pos, center, params, partial, cd_weight=3.0, reg_weig
 def object_pose_optimization(complete_xyz, partial_xyz, radius=0.005, lr=0.005, iters=300, render_size=224,
                              vis=False, save_path=None, device=None, cam_bias_num=4, return_history=False):
     """diff_obj_pose.py:496-594 (CD half).  complete_xyz [Nc,3], partial_xyz [Np,3]
-    GPU tensors.  radius / render_size / vis / save_path are accepted for signature
+    GPU tensors -- or [B,Nc,3] / [B,Np,3]: B scans optimised in lock-step, one batched
+    NN launch per Adam step (returns [B,4,4]).  radius / render_size / vis / save_path are accepted for signature
     compatibility and unused (they parameterise the renderer)."""
-    complete_xyz = complete_xyz.contiguous().float()
-    partial_xyz = partial_xyz.contiguous().float()
+    batched = complete_xyz.dim() == 3
+    complete_xyz = (complete_xyz if batched else complete_xyz[None]).contiguous().float()
+    partial_xyz = (partial_xyz if batched else partial_xyz[None]).contiguous().float()
     _lib.check_tensors((("complete_xyz", complete_xyz), ("partial_xyz", partial_xyz)))
+    if complete_xyz.shape[0] != partial_xyz.shape[0]:
+        raise ValueError("object_pose_optimization: batch sizes differ")
     dev = complete_xyz.device
-    T = torch.empty(16, device=dev)
-    hist = torch.empty(cam_bias_num * (iters + 1), device=dev)
-    bp = torch.empty(10, device=dev)
-    rc = _lib.on_device_of(complete_xyz, _L.genpc_pose_optimize_cd, complete_xyz.shape[0], _p(complete_xyz),
-                           partial_xyz.shape[0], _p(partial_xyz), float(lr), int(iters), int(cam_bias_num),
+    b = complete_xyz.shape[0]
+    T = torch.empty(b, 16, device=dev)
+    hist = torch.empty(b, cam_bias_num * (iters + 1), device=dev)
+    bp = torch.empty(b, 10, device=dev)
+    rc = _lib.on_device_of(complete_xyz, _L.genpc_pose_optimize_cd_batch, b, complete_xyz.shape[1], _p(complete_xyz),
+                           partial_xyz.shape[1], _p(partial_xyz), float(lr), int(iters), int(cam_bias_num),
                            _p(T), _p(hist), _p(bp))
     if rc != 1:
         raise RuntimeError("genpc_pose_optimize_cd failed (rc=%d): %s" % (rc, _lib.last_error()))
-    final_transform = T.reshape(4, 4).cpu().numpy()
+    final_transform = T.reshape(b, 4, 4).cpu().numpy()
+    h = hist.reshape(b, cam_bias_num, iters + 1).cpu().numpy()
+    if not batched:
+        final_transform, h, bpn = final_transform[0], h[0], bp[0].cpu().numpy()
+    else:
+        bpn = bp.cpu().numpy()
     if return_history:
-        return final_transform, hist.reshape(cam_bias_num, iters + 1).cpu().numpy(), bp.cpu().numpy()
+        return final_transform, h, bpn
     return final_transform

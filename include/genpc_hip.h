@@ -151,6 +151,14 @@ int genpc_pose_optimize_cd(int nc, const float *complete, int np,
                            float *transform, float *history, float *best_params,
                            void *stream);
 
+/* The same loop for B scans in lock-step: complete[B,nc,3], partial[B,np,3],
+ * transform[B,16], history[B,starts*(iters+1)] (optional), best_params[B,10]
+ * (optional).  One batched NN launch per step serves all B scans.               */
+int genpc_pose_optimize_cd_batch(int b, int nc, const float *complete, int np,
+                                 const float *partial, float lr, int iters,
+                                 int starts, float *transform, float *history,
+                                 float *best_params, void *stream);
+
 /* ICP + scale search --------------------------------------------------------- *
  * Batched point-to-point ICP with the semantics of open3d's registration_icp as
  * reg_xyz.py calls it (:18-20,28-37: TransformationEstimationPointToPoint, default

@@ -168,3 +168,22 @@ def test_pose_loop_full_size_property(gp):
     # this density (a property of the reference's schedule, not of the kernels)
     np.testing.assert_allclose(T[:3, :3] / s, Rt, atol=0.08)
     np.testing.assert_allclose(T[:3, 3], [0.02, -0.01, 0.015], atol=0.02)
+
+
+def test_pose_loop_batched_equals_singles(gp):
+    """B scans in lock-step (one batched NN launch per Adam step) give the same
+    transforms as B separate runs (fp64 reductions are atomics: last-bit noise only)."""
+    torch = gp["torch"]
+    cs, ps = [], []
+    for seed in (9, 10, 11):
+        c, p, _ = _shape(seed, 1500)
+        cs.append(c)
+        ps.append(p[:700])
+    C = torch.from_numpy(np.stack(cs)).cuda()
+    P = torch.from_numpy(np.stack(ps)).cuda()
+    Tb, hb, _ = gp["POSE"].object_pose_optimization(C, P, lr=0.01, iters=60, return_history=True)
+    assert Tb.shape == (3, 4, 4) and hb.shape == (3, 4, 61)
+    for i in range(3):
+        Ti, hi, _ = gp["POSE"].object_pose_optimization(C[i], P[i], lr=0.01, iters=60, return_history=True)
+        np.testing.assert_allclose(hb[i][:, :10], hi[:, :10], rtol=1e-5)
+        np.testing.assert_allclose(Tb[i], Ti, atol=2e-3)
