@@ -38,7 +38,7 @@ namespace genpc {
 
 constexpr int kEBlock = 256;
 constexpr int kTile = 1024;        // objects per LDS tile (16 KiB as float4)
-constexpr int kZMax = 16;           // object slices per bidder group in the late-round split
+constexpr int kZMax = 4;            // object slices per bidder group in the late-round split (measured best of 1..16)
 constexpr int kSplitMaxBidders = 4096;   // bidders per batch element the split scratch can hold
 constexpr int kArrivePerBatch = 1024;    // arrival counters per batch element (>= kSplitMaxBidders * 64 / 256)
 
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                                                           float *__restrict__ bid_increments,
                                                           float *__restrict__ max_increments, int force_p,
                                                           float4 *__restrict__ parts, int *__restrict__ arrive,
-                                                          int *__restrict__ second)
+                                                          int *__restrict__ second, int zmax)
 {
     __shared__ float4 tile[kTile];
     const int batch = blockIdx.y;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
     if (P == 64 && parts != nullptr) {
         Z = G / NB;
         Z = Z > ntiles ? ntiles : Z;
-        Z = Z > kZMax ? kZMax : Z;
+        Z = Z > zmax ? zmax : Z;
         Z = Z < 1 ? 1 : Z;
         if ((long long)U > kSplitMaxBidders) Z = 1;     // parts[] holds kSplitMaxBidders bidders per batch
     }
@@ -513,6 +513,7 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     // waves per SIMD: measured 13x16384, round 0: 3.9 ms at 4/CU, 1.8 ms at 16/CU),
     // never more than the finest split (64 lanes per bidder, all n bidding).
     int G = ceil_div(kNumCU * 16, b);
+    if (G > 1024) G = 1024;     // a single cloud: more blocks only add dispatch + hand-off latency (measured)
     const int g_max = ceil_div(n * 64, kEBlock);
     if (G > g_max) G = g_max;
     if (G < 1) G = 1;
@@ -525,14 +526,16 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
         const int last = (it == iters - 1);
         {
             typedef void (*bid_fn)(int, const float *, const float *, const float *, float, const int *, const int *,
-                                   int *, int *, float *, float *, int, float4 *, int *, int *);
+                                   int *, int *, float *, float *, int, float4 *, int *, int *, int);
+            static const int zmax_env = getenv("GENPC_EMD_ZMAX") ? atoi(getenv("GENPC_EMD_ZMAX")) : kZMax;
+            const int zmax = zmax_env < 1 ? 1 : (zmax_env > kZMax ? kZMax : zmax_env);
             static const int force_p = getenv("GENPC_EMD_P") ? atoi(getenv("GENPC_EMD_P")) : 0;
             static const bool nofilter = getenv("GENPC_EMD_NOFILTER") != nullptr;
             bid_fn f = fma ? (nofilter ? emd_bid_kernel<1, 0> : emd_bid_kernel<1, 1>)
                            : (nofilter ? emd_bid_kernel<0, 0> : emd_bid_kernel<0, 1>);
             hipLaunchKernelGGL(f, dim3(G, b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price, eps,
                                (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
-                               max_increments, force_p, parts, arrive, second);
+                               max_increments, force_p, parts, arrive, second, zmax);
         }
         hipLaunchKernelGGL(emd_getmax_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
                            (const int *)cnts[cur], (const int *)bid, (const float *)bid_increments,

@@ -48,7 +48,14 @@ class emdFunction(Function):
         assert n % 256 == 0
         assert batchsize <= 512
 
-        _lib.require_gpu(xyz1, xyz2)
+        # emd_module.py:41-42 moves its inputs to the GPU itself (`.contiguous().float().cuda()`);
+        # so does this, when there is a GPU -- there is no CPU implementation to fall back to
+        if not (xyz1.is_cuda and xyz2.is_cuda):
+            if not torch.cuda.is_available():
+                raise RuntimeError("genpc_amd: GPU tensors only (no GPU is available to move the inputs to); "
+                                   "the HIP path has no CPU fallback")
+            dev = xyz1.device if xyz1.is_cuda else (xyz2.device if xyz2.is_cuda else torch.device("cuda"))
+            xyz1, xyz2 = xyz1.to(dev), xyz2.to(dev)
         xyz1 = xyz1.contiguous().float()
         xyz2 = xyz2.contiguous().float()
         s = alloc_state(batchsize, n, m, xyz1.device)
