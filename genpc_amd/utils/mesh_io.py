@@ -1,0 +1,156 @@
+"""GLB mesh loading and surface sampling without trimesh: what
+``glb2point`` (utils/dataUtils.py:217-250) needs to turn a generated ``*.glb`` into
+the "complete" cloud that reg() aligns.  Host-side format code, numpy only.
+
+``load_glb``   binary glTF 2.0: JSON chunk + BIN chunk, every triangle primitive of
+               every mesh reachable from the default scene, node transforms applied
+               (matrix or translation / rotation / scale), concatenated like
+               ``trimesh.Scene.dump(concatenate=True)``.  Vertex colours (COLOR_0)
+               are returned when present; textures are not baked.
+``sample_surface``  area-weighted uniform sampling of a triangle mesh, the published
+               algorithm of ``trimesh.sample.sample_surface``: faces drawn with
+               probability proportional to area, points by the folded-parallelogram
+               trick.  trimesh draws from numpy's unseeded global RNG, so the
+               reference's samples are not reproducible; here a Generator is passed.
+"""
+import json
+import struct
+
+import numpy as np
+
+_COMPONENT = {5120: ("i1", 1), 5121: ("u1", 1), 5122: ("<i2", 2), 5123: ("<u2", 2), 5125: ("<u4", 4), 5126: ("<f4", 4)}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+def _accessor(gltf, bin_chunk, index):
+    acc = gltf["accessors"][index]
+    view = gltf["bufferViews"][acc["bufferView"]]
+    dtype, size = _COMPONENT[acc["componentType"]]
+    ncomp = _NCOMP[acc["type"]]
+    offset = view.get("byteOffset", 0) + acc.get("byteOffset", 0)
+    stride = view.get("byteStride", 0) or size * ncomp
+    count = acc["count"]
+    if stride == size * ncomp:
+        arr = np.frombuffer(bin_chunk, dtype=dtype, count=count * ncomp, offset=offset).reshape(count, ncomp)
+    else:
+        raw = np.frombuffer(bin_chunk, dtype="u1", count=(count - 1) * stride + size * ncomp, offset=offset)
+        idx = np.arange(count)[:, None] * stride + np.arange(size * ncomp)[None, :]
+        arr = raw[idx].copy().view(dtype).reshape(count, ncomp)
+    arr = arr.astype(np.float64) if dtype == "<f4" else arr
+    if acc.get("normalized") and dtype != "<f4":
+        arr = arr.astype(np.float64) / np.iinfo(np.dtype(dtype)).max
+    return arr
+
+
+def _node_matrix(node):
+    if "matrix" in node:
+        return np.array(node["matrix"], np.float64).reshape(4, 4).T        # glTF stores column-major
+    M = np.eye(4)
+    if "scale" in node:
+        M = np.diag(list(node["scale"]) + [1.0]) @ M
+    if "rotation" in node:
+        x, y, z, w = node["rotation"]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        T = np.eye(4)
+        T[:3, :3] = R
+        M = T @ M
+    if "translation" in node:
+        T = np.eye(4)
+        T[:3, 3] = node["translation"]
+        M = T @ M
+    return M
+
+
+def load_glb(path):
+    """-> (vertices float64 [N,3], faces int64 [M,3], colors float64 [N,3] in [0,1] or None)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    magic, version, length = struct.unpack_from("<4sII", data, 0)
+    if magic != b"glTF" or version != 2:
+        raise ValueError("%s: not a binary glTF 2.0 file" % path)
+    off, gltf, bin_chunk = 12, None, b""
+    while off < length:
+        clen, ctype = struct.unpack_from("<I4s", data, off)
+        chunk = data[off + 8: off + 8 + clen]
+        if ctype == b"JSON":
+            gltf = json.loads(chunk.decode("utf-8"))
+        elif ctype == b"BIN\x00":
+            bin_chunk = chunk
+        off += 8 + clen
+    if gltf is None:
+        raise ValueError("%s: no JSON chunk" % path)
+    verts, faces, cols, base = [], [], [], 0
+    any_color = False
+
+    def visit(ni, parent):
+        nonlocal base, any_color
+        node = gltf["nodes"][ni]
+        M = parent @ _node_matrix(node)
+        if "mesh" in node:
+            for prim in gltf["meshes"][node["mesh"]]["primitives"]:
+                if prim.get("mode", 4) != 4:
+                    continue                                   # triangles only
+                v = _accessor(gltf, bin_chunk, prim["attributes"]["POSITION"])[:, :3]
+                v = v @ M[:3, :3].T + M[:3, 3]
+                if "indices" in prim:
+                    fi = _accessor(gltf, bin_chunk, prim["indices"]).astype(np.int64).reshape(-1, 3)
+                else:
+                    fi = np.arange(len(v), dtype=np.int64).reshape(-1, 3)
+                if "COLOR_0" in prim["attributes"]:
+                    c = _accessor(gltf, bin_chunk, prim["attributes"]["COLOR_0"])[:, :3].astype(np.float64)
+                    any_color = True
+                else:
+                    c = np.full((len(v), 3), np.nan)
+                verts.append(v)
+                faces.append(fi + base)
+                cols.append(c)
+                base += len(v)
+        for child in node.get("children", []):
+            visit(child, M)
+
+    scenes = gltf.get("scenes")
+    roots = scenes[gltf.get("scene", 0)]["nodes"] if scenes else range(len(gltf.get("nodes", [])))
+    for r in roots:
+        visit(r, np.eye(4))
+    if not verts:
+        raise ValueError("%s: no triangle geometry" % path)
+    V, F = np.concatenate(verts), np.concatenate(faces)
+    C = np.nan_to_num(np.concatenate(cols), nan=0.5) if any_color else None
+    return V, F, C
+
+
+def sample_surface(vertices, faces, count, rng=None):
+    """-> (points [count,3], face_index [count]); area-weighted, uniform within a face."""
+    rng = np.random.default_rng() if rng is None else rng
+    tri = vertices[faces]                                       # [M,3,3]
+    origin, e1, e2 = tri[:, 0], tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    area = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1)
+    cum = np.cumsum(area)
+    face_index = np.searchsorted(cum, rng.random(count) * cum[-1])
+    face_index = np.minimum(face_index, len(faces) - 1)
+    r = rng.random((count, 2))
+    fold = r.sum(axis=1) > 1.0
+    r[fold] = 1.0 - r[fold]
+    pts = origin[face_index] + e1[face_index] * r[:, :1] + e2[face_index] * r[:, 1:]
+    return pts, face_index
+
+
+def glb2point(glb_path, num_points=16384, rng=None):
+    """utils/dataUtils.py:217-250 without open3d/trimesh: (points [n,3], colours [n,3]);
+    colours are barycentric blends of the vertex colours, 0.5 grey when the file has none."""
+    V, F, C = load_glb(glb_path)
+    pts, fi = sample_surface(V, F, num_points, rng)
+    if C is None:
+        return pts, np.full((num_points, 3), 0.5)
+    tri = V[F[fi]]
+    v0, v1, v2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], pts - tri[:, 0]
+    d00, d01, d11 = (v0 * v0).sum(1), (v0 * v1).sum(1), (v1 * v1).sum(1)
+    d20, d21 = (v2 * v0).sum(1), (v2 * v1).sum(1)
+    den = d00 * d11 - d01 * d01
+    b1 = (d11 * d20 - d01 * d21) / den
+    b2 = (d00 * d21 - d01 * d20) / den
+    bary = np.stack([1 - b1 - b2, b1, b2], axis=1)
+    col = (C[F[fi]] * bary[:, :, None]).sum(axis=1)
+    return pts, np.clip(col, 0, 1)

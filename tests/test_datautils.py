@@ -43,3 +43,69 @@ def test_normalize_and_rotate():
         np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-12)
         assert abs(np.linalg.det(R) - 1) < 1e-12
     np.testing.assert_allclose(D.get_rotate_matrix("y", 90) @ np.array([0, 0, 1.0]), [1, 0, 0], atol=1e-12)
+
+
+def _write_glb(path, verts, faces, colors=None, node=None, indices_u16=True):
+    """Minimal binary glTF writer for the tests (one mesh, one primitive, one node)."""
+    import json
+    import struct
+    v = np.asarray(verts, "<f4")
+    idx = np.asarray(faces, "<u2" if indices_u16 else "<u4").reshape(-1)
+    blobs = [v.tobytes(), idx.tobytes() + b"\x00" * (-len(idx.tobytes()) % 4)]
+    views = [{"buffer": 0, "byteOffset": 0, "byteLength": len(blobs[0])},
+             {"buffer": 0, "byteOffset": len(blobs[0]), "byteLength": len(idx.tobytes())}]
+    accs = [{"bufferView": 0, "componentType": 5126, "count": len(v), "type": "VEC3"},
+            {"bufferView": 1, "componentType": 5123 if indices_u16 else 5125, "count": len(idx), "type": "SCALAR"}]
+    attrs = {"POSITION": 0}
+    if colors is not None:
+        c = np.asarray(colors, "<f4")
+        views.append({"buffer": 0, "byteOffset": sum(map(len, blobs)), "byteLength": c.nbytes})
+        blobs.append(c.tobytes())
+        accs.append({"bufferView": 2, "componentType": 5126, "count": len(c), "type": "VEC3"})
+        attrs["COLOR_0"] = 2
+    n = dict(node or {})
+    n["mesh"] = 0
+    g = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [n],
+         "meshes": [{"primitives": [{"attributes": attrs, "indices": 1}]}], "accessors": accs, "bufferViews": views,
+         "buffers": [{"byteLength": sum(map(len, blobs))}]}
+    js = json.dumps(g).encode()
+    js += b" " * (-len(js) % 4)
+    binc = b"".join(blobs)
+    total = 12 + 8 + len(js) + 8 + len(binc)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4sII", b"glTF", 2, total))
+        f.write(struct.pack("<I4s", len(js), b"JSON") + js)
+        f.write(struct.pack("<I4s", len(binc), b"BIN\x00") + binc)
+
+
+def test_glb_loader_and_surface_sampling(tmp_path):
+    from genpc_amd.utils import mesh_io as M
+    verts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float)
+    faces = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]])
+    cols = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1]], float)
+    p = str(tmp_path / "t.glb")
+    node = {"translation": [1.0, 2.0, 3.0], "scale": [2.0, 2.0, 2.0], "rotation": [0.0, 0.0, 0.7071067811865476, 0.7071067811865476]}
+    _write_glb(p, verts, faces, cols, node)
+    V, F, C = M.load_glb(p)
+    Rz = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])            # 90 degrees about z
+    np.testing.assert_allclose(V, (verts * 2) @ Rz.T + [1, 2, 3], atol=1e-6)
+    np.testing.assert_array_equal(F, faces)
+    np.testing.assert_allclose(C, cols)
+    _write_glb(p, verts, faces, None, {"matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 5, 6, 7, 1]}, indices_u16=False)
+    V2, F2, C2 = M.load_glb(p)
+    np.testing.assert_allclose(V2, verts + [5, 6, 7], atol=1e-6)
+    assert C2 is None
+    rng = np.random.default_rng(0)
+    pts, fi = M.sample_surface(verts, faces, 40000, rng)
+    tri = verts[faces[fi]]
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    assert np.abs(((pts - tri[:, 0]) * n).sum(1)).max() < 1e-12       # on the face's plane ...
+    assert (pts >= -1e-12).all() and (pts.sum(1) <= 1 + 1e-9).all()    # ... and inside the tetrahedron's hull
+    area = 0.5 * np.linalg.norm(np.cross(verts[faces][:, 1] - verts[faces][:, 0], verts[faces][:, 2] - verts[faces][:, 0]), axis=1)
+    np.testing.assert_allclose(np.bincount(fi, minlength=4) / 40000, area / area.sum(), atol=0.01)
+    _write_glb(p, verts, faces, cols, None)
+    P, Cc = M.glb2point(p, 5000, np.random.default_rng(1))
+    assert P.shape == (5000, 3) and Cc.shape == (5000, 3) and Cc.min() >= 0 and Cc.max() <= 1
+    # on face (0,1,2) (z = 0) the colour is the barycentric blend of red / green / blue
+    on = np.abs(P[:, 2]) < 1e-12
+    np.testing.assert_allclose(Cc[on], np.stack([1 - P[on, 0] - P[on, 1], P[on, 0], P[on, 1]], 1), atol=1e-9)
