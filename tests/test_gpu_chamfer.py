@@ -139,3 +139,19 @@ def test_full_size_properties(gp):
         take_r = r1 < l1
         assert torch.equal(torch.where(take_r, r1, l1), d1)
         assert torch.equal(torch.where(take_r, ri + h, li), i1)
+
+
+def test_degenerate_and_extreme_shapes(gp, oracle):
+    """All points identical (every distance ties: index 0 must win everywhere), one
+    query against a long cloud and vice versa, sizes around the tiling constants."""
+    torch = gp["torch"]
+    z = np.zeros((2, 300, 3), np.float32) + np.float32(0.25)
+    d1, d2, i1, i2 = run_hip(gp, z, z[:, :77].copy(), 1)
+    assert (d1 == 0).all() and (d2 == 0).all() and (i1 == 0).all() and (i2 == 0).all()
+    for n, m in ((1, 70001), (70001, 1), (255, 2049), (2048, 2047), (513, 33)):
+        a, b = gen_pair(n * 7 + m, (1, n, 3), (1, m, 3))
+        assert_same(run_hip(gp, a, b, 1), oracle.chamfer_forward(a, b, 1))
+    a, b = gen_pair(99, (1, 400, 3), (1, 500, 3))
+    a *= np.float32(1e4)                       # large coordinates: same arithmetic, no overflow
+    b *= np.float32(1e4)
+    assert_same(run_hip(gp, a, b, 0), oracle.chamfer_forward(a, b, 0))

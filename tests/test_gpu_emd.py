@@ -131,3 +131,31 @@ def test_full_size_properties(gp):
     np.testing.assert_allclose(d[0].cpu().numpy(), (dd * dd).sum(-1).cpu().numpy(), rtol=1e-5, atol=1e-9)
     nn1, _, _, _ = chamfer_3DDist()(A, B)
     assert bool((d >= nn1).all())
+
+
+def test_extreme_ties_and_limits(gp, oracle):
+    """Every object at the same place (all bids tie exactly: the reference's
+    thread-major order decides every index), eps = 0, a single round, and the batch
+    limit of emd_cuda.cu:241-244."""
+    torch = gp["torch"]
+    a, _ = gen_pair(3, (2, 512, 3), (2, 512, 3), 0.0)
+    b = np.zeros_like(a) + np.float32(0.5)
+    for iters in (1, 7):
+        s = run_hip(gp, a, b, 0.005, iters, 1)
+        d, ass = oracle.emd_forward(a, b, 0.005, iters, 1)
+        np.testing.assert_array_equal(s["assignment"], ass)
+        np.testing.assert_array_equal(s["dist"], d)
+    a2, b2 = gen_pair(4, (1, 256, 3), (1, 256, 3), 0.0)
+    s = run_hip(gp, a2, b2, 0.0, 5, 1)
+    d, ass = oracle.emd_forward(a2, b2, 0.0, 5, 1)
+    np.testing.assert_array_equal(s["assignment"], ass)
+    z = lambda *sh: torch.zeros(*sh).cuda()
+    st = gp["alloc"](513, 256, 256, "cuda")
+    rc = gp["emd"].forward(z(513, 256, 3), z(513, 256, 3), st["dist"], st["assignment"], st["price"],
+                           st["assignment_inv"], st["bid"], st["bid_increments"], st["max_increments"], st["unass_idx"],
+                           st["unass_cnt"], st["unass_cnt_sum"], st["cnt_tmp"], st["max_idx"], 0.005, 2)
+    assert rc == -1
+    a3, b3 = gen_pair(5, (512, 256, 3), (512, 256, 3), 0.0)       # B = 512 is allowed
+    s = run_hip(gp, a3, b3, 0.005, 3, 1)
+    d, ass = oracle.emd_forward(a3, b3, 0.005, 3, 1)
+    np.testing.assert_array_equal(s["assignment"], ass)
