@@ -200,7 +200,7 @@ def extras(A, B, n, dev, stream):
     pts = (torch.rand(71372, 3, device=dev) - 0.5) * 0.8
     dp.getUvs(dp.cameras, pts, want_transformed=False)
     t = time_events(lambda: dp.getUvs(dp.cameras, pts, want_transformed=False), 5, stream)
-    alg = 1024 * 71372 * (12 + 12 + 8 + 8)     # read xyz, write uv+depth, re-read+write uv
+    alg = 1024 * 71372 * (12 + 12)             # per (camera, point): read xyz, write uv + depth
     extra["get_uvs_1024x71372_hbm"] = {"GB_s": round(alg / (t * 1e-3) / 1e9, 1), "frac_of_8TBs": round(alg / (t * 1e-3) / 8e12, 4),
                                        "ms": round(t, 4), "algorithmic_bytes": alg}
     return extra

@@ -6,9 +6,10 @@
 // getUvs: the reference materialises cam.transform(points) for all 1024 cameras
 // ([1024,N,3] fp32, 0.88 GB at N = 71k) and then consumes two rows
 // (DepthPrompting.py:154-165).  Here any subset of cameras is projected in two
-// passes over the points: pass 1 writes NDC xy / depth and reduces the per-camera
-// bounding box (wave shuffles -> one atomic per wave on order-preserving integer
-// keys), pass 2 rescales xy into uv in place.  `transformed` is optional.
+// passes over the points: pass 1 only reduces the per-camera bounding box of the
+// NDC xy (wave shuffles -> one atomic per wave on order-preserving integer keys),
+// pass 2 projects again, rescales and stores uv / depth -- 12 B per (camera, point)
+// through HBM instead of 28 with an in-place second pass.  `transformed` is optional.
 // Arithmetic (fma order, IEEE division) matches oracle/genpc_oracle_geom.c bit for
 // bit; min/max are exact, so uv is bit-exact too.
 #include "common.h"
@@ -29,12 +30,24 @@ __device__ __forceinline__ float key2f(unsigned k)
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
+__device__ __forceinline__ void project_point(const float *v, float focal, float A, float B, float px, float py,
+                                              float pz, float &ox, float &oy, float &oz)
+{
+    const float xc = __fadd_rn(__fmaf_rn(v[2], pz, __fmaf_rn(v[1], py, __fmul_rn(v[0], px))), v[3]);
+    const float yc = __fadd_rn(__fmaf_rn(v[6], pz, __fmaf_rn(v[5], py, __fmul_rn(v[4], px))), v[7]);
+    const float zc = __fadd_rn(__fmaf_rn(v[10], pz, __fmaf_rn(v[9], py, __fmul_rn(v[8], px))), v[11]);
+    const float w = -zc;
+    ox = __fmul_rn(focal, xc) / w;
+    oy = __fmul_rn(focal, yc) / w;
+    oz = __fmaf_rn(A, zc, B) / w;
+}
+
+// Pass 1: per-camera bounding box of the NDC xy, nothing stored per point.
 // keys[C,4]: min_x, min_y as keys, max_x, max_y as ~key, all reduced with atomicMin
 // from an all-ones initial state (one memset).
-__global__ __launch_bounds__(kPBlock) void project_kernel(int n, const float *__restrict__ view, float focal, float A,
-                                                          float B, const float *__restrict__ xyz,
-                                                          float *__restrict__ transformed, float *__restrict__ uv,
-                                                          float *__restrict__ depth, unsigned *__restrict__ keys)
+__global__ __launch_bounds__(kPBlock) void project_bbox_kernel(int n, const float *__restrict__ view, float focal,
+                                                               float A, float B, const float *__restrict__ xyz,
+                                                               unsigned *__restrict__ keys)
 {
     const int cam = blockIdx.y;
     const float *V = view + (size_t)cam * 12;
@@ -43,21 +56,8 @@ __global__ __launch_bounds__(kPBlock) void project_kernel(int n, const float *__
     for (int k = 0; k < 12; k++) v[k] = V[k];
     unsigned mnx = 0xffffffffu, mny = 0xffffffffu, mxx = 0xffffffffu, mxy = 0xffffffffu;
     for (int j = blockIdx.x * kPBlock + threadIdx.x; j < n; j += gridDim.x * kPBlock) {
-        const float px = xyz[(size_t)j * 3 + 0], py = xyz[(size_t)j * 3 + 1], pz = xyz[(size_t)j * 3 + 2];
-        const float xc = __fadd_rn(__fmaf_rn(v[2], pz, __fmaf_rn(v[1], py, __fmul_rn(v[0], px))), v[3]);
-        const float yc = __fadd_rn(__fmaf_rn(v[6], pz, __fmaf_rn(v[5], py, __fmul_rn(v[4], px))), v[7]);
-        const float zc = __fadd_rn(__fmaf_rn(v[10], pz, __fmaf_rn(v[9], py, __fmul_rn(v[8], px))), v[11]);
-        const float w = -zc;
-        const float ox = __fdiv_rn(__fmul_rn(focal, xc), w);
-        const float oy = __fdiv_rn(__fmul_rn(focal, yc), w);
-        const float oz = __fdiv_rn(__fmaf_rn(A, zc, B), w);
-        const size_t q = (size_t)cam * n + j;
-        if (transformed) {
-            transformed[q * 3 + 0] = ox; transformed[q * 3 + 1] = oy; transformed[q * 3 + 2] = oz;
-        }
-        uv[q * 2 + 0] = ox;
-        uv[q * 2 + 1] = oy;
-        depth[q] = oz;
+        float ox, oy, oz;
+        project_point(v, focal, A, B, xyz[(size_t)j * 3 + 0], xyz[(size_t)j * 3 + 1], xyz[(size_t)j * 3 + 2], ox, oy, oz);
         const unsigned kx = f2key(ox), ky = f2key(oy);
         mnx = min(mnx, kx); mny = min(mny, ky);
         mxx = min(mxx, ~kx); mxy = min(mxy, ~ky);
@@ -77,33 +77,50 @@ __global__ __launch_bounds__(kPBlock) void project_kernel(int n, const float *__
     }
 }
 
-// DepthPrompting.py:246-266
-__global__ __launch_bounds__(kPBlock) void rescale_uv_kernel(int n, float *__restrict__ uv,
-                                                             const unsigned *__restrict__ keys, int rescale,
-                                                             float padmul, float *__restrict__ bbox)
+// Pass 2: project again (the cloud is a few hundred KB and stays in L2 across the
+// cameras; recomputing costs nothing next to a 28 B/point round trip through HBM),
+// rescale (DepthPrompting.py:246-266) and store uv, depth and, if asked, the NDC point.
+__global__ __launch_bounds__(kPBlock) void project_write_kernel(int n, const float *__restrict__ view, float focal,
+                                                                float A, float B, const float *__restrict__ xyz,
+                                                                const unsigned *__restrict__ keys, int rescale,
+                                                                float padmul, float *__restrict__ transformed,
+                                                                float *__restrict__ uv, float *__restrict__ depth,
+                                                                float *__restrict__ bbox)
 {
     const int cam = blockIdx.y;
-    const float mnx = key2f(keys[cam * 4 + 0]), mny = key2f(keys[cam * 4 + 1]);
-    const float mxx = key2f(~keys[cam * 4 + 2]), mxy = key2f(~keys[cam * 4 + 3]);
-    if (bbox && blockIdx.x == 0 && threadIdx.x == 0) {
-        bbox[cam * 4 + 0] = mnx; bbox[cam * 4 + 1] = mny; bbox[cam * 4 + 2] = mxx; bbox[cam * 4 + 3] = mxy;
+    const float *V = view + (size_t)cam * 12;
+    float v[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) v[k] = V[k];
+    float cx = 0.0f, cy = 0.0f, sc = 1.0f;
+    if (rescale || bbox) {
+        const float mnx = key2f(keys[cam * 4 + 0]), mny = key2f(keys[cam * 4 + 1]);
+        const float mxx = key2f(~keys[cam * 4 + 2]), mxy = key2f(~keys[cam * 4 + 3]);
+        if (bbox && blockIdx.x == 0 && threadIdx.x == 0) {
+            bbox[cam * 4 + 0] = mnx; bbox[cam * 4 + 1] = mny; bbox[cam * 4 + 2] = mxx; bbox[cam * 4 + 3] = mxy;
+        }
+        cx = __fadd_rn(mnx, mxx) / 2.0f;
+        cy = __fadd_rn(mny, mxy) / 2.0f;
+        const float sx = __fsub_rn(mxx, mnx), sy = __fsub_rn(mxy, mny);
+        sc = sx > sy ? sx : sy;
     }
-    const float cx = __fdiv_rn(__fadd_rn(mnx, mxx), 2.0f), cy = __fdiv_rn(__fadd_rn(mny, mxy), 2.0f);
-    const float sx = __fsub_rn(mxx, mnx), sy = __fsub_rn(mxy, mny);
-    const float sc = sx > sy ? sx : sy;
     for (int j = blockIdx.x * kPBlock + threadIdx.x; j < n; j += gridDim.x * kPBlock) {
+        float ox, oy, oz;
+        project_point(v, focal, A, B, xyz[(size_t)j * 3 + 0], xyz[(size_t)j * 3 + 1], xyz[(size_t)j * 3 + 2], ox, oy, oz);
         const size_t q = (size_t)cam * n + j;
-        const float ox = uv[q * 2 + 0], oy = uv[q * 2 + 1];
+        if (transformed) {
+            transformed[q * 3 + 0] = ox; transformed[q * 3 + 1] = oy; transformed[q * 3 + 2] = oz;
+        }
         float u, vv;
         if (rescale) {
-            u = __fadd_rn(__fmul_rn(__fdiv_rn(__fsub_rn(ox, cx), sc), padmul), 0.5f);
-            vv = __fadd_rn(__fmul_rn(__fdiv_rn(__fsub_rn(oy, cy), sc), padmul), 0.5f);
+            u = __fadd_rn(__fmul_rn(__fsub_rn(ox, cx) / sc, padmul), 0.5f);
+            vv = __fadd_rn(__fmul_rn(__fsub_rn(oy, cy) / sc, padmul), 0.5f);
         } else {
             u = __fmul_rn(__fadd_rn(ox, 1.0f), 0.5f);
             vv = __fmul_rn(__fadd_rn(oy, 1.0f), 0.5f);
         }
-        uv[q * 2 + 0] = u;
-        uv[q * 2 + 1] = vv;
+        *reinterpret_cast<float2 *>(uv + q * 2) = make_float2(u, vv);
+        depth[q] = oz;
     }
 }
 
@@ -192,10 +209,10 @@ GENPC_API int genpc_get_uvs(int c, int n, const float *view, float focal, float 
     const float B = (2.0f * zfar * znear) / (znear - zfar);
     // enough blocks per camera to fill the chip when few cameras are projected
     int gx = grid_for(n, c >= 64 ? 16 : 2048 / c);
-    hipLaunchKernelGGL(project_kernel, dim3(gx, c), dim3(kPBlock), 0, st, n, view, focal, A, B, xyz, transformed, uv,
-                       depth, keys);
-    hipLaunchKernelGGL(rescale_uv_kernel, dim3(gx, c), dim3(kPBlock), 0, st, n, uv, (const unsigned *)keys, rescale,
-                       padmul, bbox);
+    if (rescale || bbox)
+        hipLaunchKernelGGL(project_bbox_kernel, dim3(gx, c), dim3(kPBlock), 0, st, n, view, focal, A, B, xyz, keys);
+    hipLaunchKernelGGL(project_write_kernel, dim3(gx, c), dim3(kPBlock), 0, st, n, view, focal, A, B, xyz,
+                       (const unsigned *)keys, rescale, padmul, transformed, uv, depth, bbox);
     return check(hipGetLastError(), "get_uvs launch") ? 1 : 0;
 }
 
