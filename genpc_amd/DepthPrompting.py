@@ -94,6 +94,36 @@ class DepthPrompting:
             raise RuntimeError("genpc_get_uvs failed: " + _lib.last_error())
         return uv, depth, tr
 
+    # DepthPrompting.py:273-290 -- with a z-buffer definition instead of open3d's HPR
+    def getVisiblePoints(self, points, cams=None, tol=1e-4, res=None, uvs=None, depths=None, point_size=2):
+        """Visibility of every point from every camera: [C,N] bool and the per-camera
+        counts [C].  The reference uses open3d.hidden_point_removal (Katz' operator, CPU,
+        third-party); this is a z-buffer test at `res` x `res` (cfg.cam_res by default):
+        visible = no point whose (2*point_size-1)^2 stamp covers the pixel is nearer by more
+        than `tol` (NDC depth)."""
+        if uvs is None:
+            uvs, depths, _ = self.getUvs(self.cameras if cams is None else cams, points,
+                                         rescale=self.cfg.rescale, padding=self.cfg.padding, want_transformed=False)
+        res = int(res or getattr(self.cfg, "cam_res", 256))
+        c, n = depths.shape
+        vis = torch.empty(c, n, device=depths.device, dtype=torch.uint8)
+        cnt = torch.empty(c, device=depths.device, dtype=torch.int32)
+        rc = _lib.on_device_of(depths, _L.genpc_zbuffer_visibility, c, n, _p(uvs.contiguous()), _p(depths.contiguous()),
+                               res, int(point_size), float(tol), _p(vis), _p(cnt))
+        if rc != 1:
+            raise RuntimeError("genpc_zbuffer_visibility failed: " + _lib.last_error())
+        return vis.bool(), cnt
+
+    # DepthPrompting.py:87-98
+    def viewpoint_select(self, xyz, tol=1e-4):
+        """FPS to cfg.downsample_num points, visibility from all cameras, the camera that
+        sees the most points."""
+        from .fps import fps_sampling
+        k = min(int(getattr(self.cfg, "downsample_num", 10000)), xyz.shape[0])
+        xyz_fps = xyz[fps_sampling(xyz.contiguous().float(), k).long()]
+        _, counts = self.getVisiblePoints(xyz_fps, self.cameras, tol=tol)
+        return int(torch.argmax(counts))
+
     def uvToPixels(self, uvs, res):
         """DepthPrompting.py:179-184: (uv*res).long(), swap to (row, col), clip."""
         uvs = uvs.contiguous().float()

@@ -185,6 +185,61 @@ __global__ __launch_bounds__(kPBlock) void gather_colors_kernel(int n, const int
     for (int k = 0; k < ch; k++) out[(size_t)j * ch + k] = img[((size_t)k * h + (h - 1 - r)) * w + c];
 }
 
+// Visibility by z-buffer.  The reference asks open3d for
+// Katz' hidden-point-removal operator (spherical flipping + convex hull per view,
+// DepthPrompting.py:273-290): CPU, qhull, third-party.  This is the GPU counterpart
+// with a DIFFERENT, simpler definition: a point is visible from a camera when no
+// other point that lands in the same pixel of a res x res image is nearer by more
+// than `tol` (NDC depth); a point occludes a (2*point_size-1)^2 stamp of pixels.
+// Pass 1: per-pixel minimum depth (atomicMin on order-preserving keys); pass 2:
+// compare at the point's own pixel and count.
+__global__ __launch_bounds__(kPBlock) void zbuf_min_kernel(int n, const float *__restrict__ uv,
+                                                           const float *__restrict__ depth, int res, int point_size,
+                                                           unsigned *__restrict__ zbuf)
+{
+    const int cam = blockIdx.y;
+    for (int j = blockIdx.x * kPBlock + threadIdx.x; j < n; j += gridDim.x * kPBlock) {
+        const size_t q = (size_t)cam * n + j;
+        long long pu = (long long)__fmul_rn(uv[q * 2 + 0], (float)res);
+        long long pv = (long long)__fmul_rn(uv[q * 2 + 1], (float)res);
+        pu = pu < 0 ? 0 : (pu > res - 1 ? res - 1 : pu);
+        pv = pv < 0 ? 0 : (pv > res - 1 ? res - 1 : pv);
+        // every point occludes a (2*point_size-1)^2 stamp, like paintPixels, so that a
+        // sparse front surface has no pin-holes
+        const unsigned key = f2key(depth[q]);
+        for (int dy = -point_size + 1; dy < point_size; dy++)
+            for (int dx = -point_size + 1; dx < point_size; dx++) {
+                const long long r = pv + dy, cc = pu + dx;
+                if (r < 0 || r >= res || cc < 0 || cc >= res) continue;
+                atomicMin(&zbuf[((size_t)cam * res + r) * res + cc], key);
+            }
+    }
+}
+
+__global__ __launch_bounds__(kPBlock) void zbuf_test_kernel(int n, const float *__restrict__ uv,
+                                                            const float *__restrict__ depth, int res, float tol,
+                                                            const unsigned *__restrict__ zbuf,
+                                                            unsigned char *__restrict__ visible,
+                                                            int *__restrict__ counts)
+{
+    const int cam = blockIdx.y;
+    int local = 0;
+    for (int j = blockIdx.x * kPBlock + threadIdx.x; j < n; j += gridDim.x * kPBlock) {
+        const size_t q = (size_t)cam * n + j;
+        long long pu = (long long)__fmul_rn(uv[q * 2 + 0], (float)res);
+        long long pv = (long long)__fmul_rn(uv[q * 2 + 1], (float)res);
+        pu = pu < 0 ? 0 : (pu > res - 1 ? res - 1 : pu);
+        pv = pv < 0 ? 0 : (pv > res - 1 ? res - 1 : pv);
+        const float zmin = key2f(zbuf[((size_t)cam * res + pv) * res + pu]);
+        const bool vis = depth[q] <= __fadd_rn(zmin, tol);
+        visible[q] = vis ? 1 : 0;
+        local += vis ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && local) atomicAdd(&counts[cam], local);
+}
+
 static int grid_for(long long n, int cap)
 {
     long long g = ceil_div64(n, kPBlock);
@@ -250,4 +305,31 @@ GENPC_API int genpc_gather_colors(int n, const int *pix, const float *img, int c
     hipLaunchKernelGGL(gather_colors_kernel, dim3(ceil_div(n, kPBlock)), dim3(kPBlock), 0, (hipStream_t)stream, n, pix,
                        img, ch, h, w, out);
     return check(hipGetLastError(), "gather_colors launch") ? 1 : 0;
+}
+
+GENPC_API int genpc_zbuffer_visibility(int c, int n, const float *uv, const float *depth, int res, int point_size,
+                                       float tol, unsigned char *visible, int *counts, void *stream)
+{
+    using namespace genpc;
+    if (c <= 0 || n <= 0) return 1;
+    if (res <= 0 || point_size < 1) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    // cameras are processed in groups that keep the z-buffer scratch at <= 64 MiB
+    int group = (int)(((size_t)64 << 20) / ((size_t)res * res * sizeof(unsigned)));
+    if (group < 1) group = 1;
+    if (group > c) group = c;
+    unsigned *zbuf = (unsigned *)workspace(8, (size_t)group * res * res * sizeof(unsigned), st);
+    if (!zbuf) return 0;
+    if (!check(hipMemsetAsync(counts, 0, (size_t)c * sizeof(int), st), "hipMemsetAsync(counts)")) return 0;
+    for (int c0 = 0; c0 < c; c0 += group) {
+        const int cc = c - c0 < group ? c - c0 : group;
+        if (!check(hipMemsetAsync(zbuf, 0xff, (size_t)cc * res * res * sizeof(unsigned), st), "hipMemsetAsync(zbuf)"))
+            return 0;
+        const int gx = grid_for(n, cc >= 64 ? 16 : 2048 / cc);
+        const float *u = uv + (size_t)c0 * n * 2, *d = depth + (size_t)c0 * n;
+        hipLaunchKernelGGL(zbuf_min_kernel, dim3(gx, cc), dim3(kPBlock), 0, st, n, u, d, res, point_size, zbuf);
+        hipLaunchKernelGGL(zbuf_test_kernel, dim3(gx, cc), dim3(kPBlock), 0, st, n, u, d, res, tol,
+                           (const unsigned *)zbuf, visible + (size_t)c0 * n, counts + c0);
+    }
+    return check(hipGetLastError(), "zbuffer_visibility launch") ? 1 : 0;
 }

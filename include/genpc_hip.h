@@ -121,6 +121,16 @@ int genpc_paint_pixels(int res, int n, const int *pix, const float *colors, int 
 int genpc_gather_colors(int n, const int *pix, const float *img, int ch, int h,
                         int w, float *out, void *stream);
 
+/* Visibility (viewpoint selection, DepthPrompting.py:87-98,273-290).  NOT the
+ * reference's operator: open3d's hidden_point_removal (Katz: spherical flipping +
+ * convex hull) is replaced by a z-buffer test -- a point is visible from camera c
+ * when no point whose (2*point_size-1)^2 pixel stamp covers its pixel of a res x res
+ * image is nearer by more than tol (NDC depth).  uv[C,N,2] / depth[C,N] as produced
+ * by genpc_get_uvs; visible[C,N] bytes, counts[C] = visible points per camera.   */
+int genpc_zbuffer_visibility(int c, int n, const float *uv, const float *depth,
+                             int res, int point_size, float tol,
+                             unsigned char *visible, int *counts, void *stream);
+
 /* SE(3)+scale alignment ---------------------------------------------------- *
  * Pose model of ObjectPoseOptim.forward (optim_registration/diff_obj_pose.py:
  * 408-423): params[10] = rot_6d[6], trans[3], log_scale[1] (device memory),

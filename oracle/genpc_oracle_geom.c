@@ -622,3 +622,38 @@ ORACLE_API void oracle_knn_mean_distance(int n, const float *xyz, int k, int fma
         free(best);
     }
 }
+
+/* Z-buffer visibility (the build's counterpart of DepthPrompting.getVisiblePoints;
+ * NOT Katz' operator, see include/genpc_hip.h): per camera, per pixel minimum depth,
+ * visible = depth <= zmin + tol. */
+ORACLE_API void oracle_zbuffer_visibility(int c, int n, const float *uv, const float *depth, int res, int point_size,
+                                          float tol, unsigned char *visible, int *counts)
+{
+    float *zb = (float *)malloc(sizeof(float) * (size_t)res * res);
+    int *px = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < c; i++) {
+        for (int k = 0; k < res * res; k++) zb[k] = INFINITY;
+        for (int j = 0; j < n; j++) {
+            size_t q = (size_t)i * n + j;
+            long pu = (long)(uv[q * 2 + 0] * (float)res), pv = (long)(uv[q * 2 + 1] * (float)res);
+            pu = pu < 0 ? 0 : (pu > res - 1 ? res - 1 : pu);
+            pv = pv < 0 ? 0 : (pv > res - 1 ? res - 1 : pv);
+            px[j] = (int)(pv * res + pu);
+            for (int dy = -point_size + 1; dy < point_size; dy++)
+                for (int dx = -point_size + 1; dx < point_size; dx++) {
+                    long r = pv + dy, cc = pu + dx;
+                    if (r < 0 || r >= res || cc < 0 || cc >= res) continue;
+                    if (depth[q] < zb[r * res + cc]) zb[r * res + cc] = depth[q];
+                }
+        }
+        int cnt = 0;
+        for (int j = 0; j < n; j++) {
+            size_t q = (size_t)i * n + j;
+            int v = depth[q] <= zb[px[j]] + tol;
+            visible[q] = (unsigned char)v;
+            cnt += v;
+        }
+        counts[i] = cnt;
+    }
+    free(zb); free(px);
+}

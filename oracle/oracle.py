@@ -387,3 +387,14 @@ def statistical_outlier_mask(xyz, nb_neighbors=20, std_ratio=2.0, fma_mode=1):
     mean = m.mean()
     std = np.sqrt(((m - mean) ** 2).sum() / (len(m) - 1))
     return m < mean + std_ratio * std
+
+
+def zbuffer_visibility(uv, depth, res, tol, point_size=2):
+    uv, pu = _f(uv)
+    depth, pd = _f(depth)
+    c, n = depth.shape
+    vis = np.zeros((c, n), np.uint8)
+    cnt = np.zeros(c, np.int32)
+    lib().oracle_zbuffer_visibility(c, n, pu, pd, int(res), int(point_size), ctypes.c_float(tol),
+                                    vis.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), cnt.ctypes.data_as(_i32p))
+    return vis.astype(bool), cnt

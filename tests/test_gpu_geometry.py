@@ -187,3 +187,35 @@ def test_pose_loop_batched_equals_singles(gp):
         Ti, hi, _ = gp["POSE"].object_pose_optimization(C[i], P[i], lr=0.01, iters=60, return_history=True)
         np.testing.assert_allclose(hb[i][:, :10], hi[:, :10], rtol=1e-5)
         np.testing.assert_allclose(Tb[i], Ti, atol=2e-3)
+
+
+def test_zbuffer_visibility_and_viewpoint_select(gp, oracle):
+    """f3 with the z-buffer definition: bit-exact vs the oracle's restatement of the
+    same definition; on a closed surface about half the points face any camera; the
+    selected view of a hemisphere shell looks at its open side's opposite."""
+    torch = gp["torch"]
+    rng = np.random.default_rng(2)
+    u = rng.standard_normal((20000, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    sphere = (u * 0.4).astype(np.float32)
+    dp = gp["dp"]
+    uv, depth, _ = dp.getUvs(dp.cameras, torch.from_numpy(sphere).cuda(), want_transformed=False)
+    vis, cnt = dp.getVisiblePoints(None, uvs=uv, depths=depth, tol=2e-4, res=256, point_size=3)
+    ovis, ocnt = oracle.zbuffer_visibility(uv.cpu().numpy(), depth.cpu().numpy(), 256, 2e-4, 3)
+    np.testing.assert_array_equal(vis.cpu().numpy(), ovis)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), ocnt)
+    # every visible point of a sphere faces the camera, and the far side is hidden
+    eyes = gp["DP"].fibonacci_sphere(16, 1.6)
+    facing = (sphere @ eyes[3]) > 0
+    v3 = vis[3].cpu().numpy()
+    # (points near the limb are occluded by their nearer neighbours' stamps: ~half of the facing side survives)
+    assert v3[facing].mean() > 0.4 and v3[~facing].mean() < 0.03, (v3[facing].mean(), v3[~facing].mean())
+    # viewpoint_select = FPS subsample -> visibility from all cameras -> arg-max of the counts
+    from genpc_amd.fps import fps_sampling
+    cap = torch.from_numpy(sphere[sphere[:, 1] > 0.15]).cuda()
+    gp["cfg"].downsample_num = 3000
+    gp["cfg"].cam_res = 128
+    best = dp.viewpoint_select(cap)
+    sub = cap[fps_sampling(cap, 3000).long()]
+    _, counts = dp.getVisiblePoints(sub, dp.cameras, tol=1e-4)
+    assert best == int(torch.argmax(counts)) and int(counts.max()) > 1500
