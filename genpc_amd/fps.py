@@ -11,7 +11,9 @@ _p = _lib.ptr
 
 
 def fps_sampling(points, k):
-    """points: [N,3] or [C,N,3] GPU tensor -> int32 indices [k] or [C,k]."""
+    """points: [N,3] or [C,N,3] GPU tensor -> int32 indices [k] or [C,k].  The first
+    index is always 0; the kernel writes -1 there if its inter-workgroup hand-off timed
+    out (another kernel kept the cloud's workgroups from being co-resident)."""
     single = points.dim() == 2
     pts = (points[None] if single else points).contiguous().float()
     _lib.check_tensors((("points", pts),))

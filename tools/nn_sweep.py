@@ -16,12 +16,14 @@ import numpy as np, torch
 from genpc_amd import chamfer_3D
 out = {}
 for spec in sys.argv[1:]:
-    b, n = (int(x) for x in spec.split("x"))
+    dims = [int(x) for x in spec.split("x")]
+    b, n = dims[0], dims[1]
+    m = dims[2] if len(dims) > 2 else n
     rng = np.random.default_rng(20250101)
     A = torch.from_numpy(rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5)).cuda()
-    B = torch.from_numpy(rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5)).cuda()
-    d1 = torch.empty(b, n, device="cuda"); d2 = torch.empty(b, n, device="cuda")
-    i1 = torch.empty(b, n, device="cuda", dtype=torch.int32); i2 = torch.empty(b, n, device="cuda", dtype=torch.int32)
+    B = torch.from_numpy(rng.random((b, m, 3), dtype=np.float32) - np.float32(0.5)).cuda()
+    d1 = torch.empty(b, n, device="cuda"); d2 = torch.empty(b, m, device="cuda")
+    i1 = torch.empty(b, n, device="cuda", dtype=torch.int32); i2 = torch.empty(b, m, device="cuda", dtype=torch.int32)
     for _ in range(5): chamfer_3D.forward(A, B, d1, d2, i1, i2)
     torch.cuda.synchronize()
     reps = 50
@@ -30,7 +32,7 @@ for spec in sys.argv[1:]:
     for _ in range(reps): chamfer_3D.forward(A, B, d1, d2, i1, i2)
     e1.record(); e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    out[spec] = [round(ms * 1e3, 1), round(2.0 * b * n * n / ms / 1e6, 1), int(i1.long().sum().item())]
+    out[spec] = [round(ms * 1e3, 1), round(2.0 * b * n * m / ms / 1e6, 1), int(i1.long().sum().item())]
 print(json.dumps(out))
 ''' % ROOT
 
