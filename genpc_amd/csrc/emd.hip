@@ -37,7 +37,8 @@
 namespace genpc {
 
 constexpr int kEBlock = 256;
-constexpr int kTile = 1024;        // objects per LDS tile (16 KiB as float4)
+constexpr int kTile = 2048;        // objects per LDS tile (32 KiB as float4)
+constexpr int kLoadsPerThread = kTile / 256;
 constexpr int kZMax = 4;            // object slices per bidder group in the late-round split (measured best of 1..16)
 constexpr int kSplitMaxBidders = 4096;   // bidders per batch element the split scratch can hold
 constexpr int kArrivePerBatch = 1024;    // arrival counters per batch element (>= kSplitMaxBidders * 64 / 256)
@@ -212,14 +213,29 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
         const int k_lo = zs * tps * kTile;
         const int k_hi = min(n, (zs + 1) * tps * kTile);
 
+        // Tiles are staged through registers one tile ahead: the global loads of tile
+        // t+1 are in flight while tile t is scanned (a round with few bidders is otherwise
+        // a chain of load -> barrier -> short scan -> barrier per tile: pure latency).
+        float4 pre[kLoadsPerThread];
+        auto fetch = [&](int k2) {
+#pragma unroll
+            for (int i = 0; i < kLoadsPerThread; i++) {
+                const int k = k2 + threadIdx.x + i * kEBlock;
+                const int kk = k < n ? k : n - 1;
+                pre[i] = make_float4(X2[(size_t)kk * 3 + 0], X2[(size_t)kk * 3 + 1], X2[(size_t)kk * 3 + 2], PR[kk]);
+            }
+        };
+        if (k_lo < k_hi) fetch(k_lo);
         for (int k2 = k_lo; k2 < k_hi; k2 += kTile) {
             const int end_k = min(n, k2 + kTile) - k2;
-            __syncthreads();
-            for (int t = threadIdx.x; t < end_k; t += kEBlock) {
-                const int k = k2 + t;
-                tile[t] = make_float4(X2[(size_t)k * 3 + 0], X2[(size_t)k * 3 + 1], X2[(size_t)k * 3 + 2], PR[k]);
+            __syncthreads();                               // the previous tile has been scanned
+#pragma unroll
+            for (int i = 0; i < kLoadsPerThread; i++) {
+                const int t = threadIdx.x + i * kEBlock;
+                if (t < end_k) tile[t] = pre[i];
             }
             __syncthreads();
+            if (k2 + kTile < k_hi) fetch(k2 + kTile);
             // Pre-filter.  A candidate can change this lane's (best, better) only if its
             // value exceeds `better`, i.e. only if sqrt(s) < 3 - price - better.  That is
             // tested conservatively in squared space with fp32 and no sqrt / fp64:
