@@ -18,7 +18,7 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-    "-ffp-contract=off",          # arithmetic is spelled out; nothing may re-fuse it
+    "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",          # arithmetic is spelled out; nothing may re-fuse it
     "-fno-fast-math", "-fvisibility=hidden", "-fgpu-rdc" if False else "-fno-gpu-rdc",
     "-Wall", "-Wno-unused-function",
 ]

@@ -273,6 +273,389 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// MFMA path.  |q - t|^2 = |q|^2 + (|t|^2 - 2 q.t): the bracket is a K = 4 product of
+// (qx, qy, qz, 1) with (-2tx, -2ty, -2tz, |t|^2), which v_mfma_f32_32x32x2_f32
+// evaluates for 32 targets x 32 queries in two instructions (bitwise a k-ordered
+// fmaf chain, MI355X guide) at the fp32 matrix rate -- 1024 pairs per 128 SIMD
+// cycles, against ~7 issue units per pair on the VALU path.  The value is only an
+// APPROXIMATION of the reference's fl((x2-x1)^2 + ...) (different roundings), so it
+// is used as a filter with a rigorous error bound, never as the result:
+//   * coordinates are centred on the target cloud's first point c (q' = fl(q - c),
+//     t' = fl(t - c)), so magnitudes -- and the bound -- scale with the cloud's
+//     extent, not with its offset from the origin;
+//   * lane l of a wave holds, per MFMA pair, 16 approximate values of query l&31
+//     against rows {8i + 4(l>>5) + 0..3} of a 32-target tile; it keeps the three
+//     smallest minima over its (tile, half) units, with the tile index for two of them
+//     (Top3); lanes l and l^32, then the target slices, fold their lists;
+//   * with a1 <= a2 <= a3 the folded minima: every unit outside the first (first
+//     two) listed tile(s) has approximate value >= a2 (a3).  nn_safe() proves from
+//     the bound that the reference's minimum lies inside the listed tile(s); those
+//     32 (64) targets are then evaluated with the reference's exact arithmetic, in
+//     index order -> bitwise the reference's (distance, first index).  Queries for
+//     which the proof fails (three tiles within the bound: exact ties on gridded
+//     data, non-finite input) are re-done exhaustively by the merging block.
+// Error bound, u = 2^-24, T = max |t'|, per target: the chain rounds four times on
+// partial sums <= 2|q'||t'| + |t'|^2 and |t'|^2 itself carries 3 roundings, |q'|^2
+// three: |a + |q'|^2 - |q' - t'|^2| <= E1 = u (8|q'|T + 7T^2 + 3|q'|^2); centring
+// moves each point by <= u|p'|: |sqrt(D') - sqrt(D)| <= eta = u (|q'| + T); the
+// reference's value is D (1 + theta), |theta| <= 6u (three subtractions, squared,
+// three to five roundings of non-negative terms).  All evaluated in fp64 with u
+// inflated by 1 %.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMTile = 2048;     // targets per LDS tile on the MFMA path (2 planes x 8 B)
+
+struct Top3 {
+    float a1, a2, a3;   // three smallest unit minima (a3: bound for everything unlisted)
+    int c1, c2;         // first target index of the tiles of a1, a2 (-1: unknown)
+};
+
+__device__ __forceinline__ void top3_init(Top3 &s)
+{
+    s.a1 = s.a2 = s.a3 = __builtin_inff();
+    s.c1 = s.c2 = -1;
+}
+
+__device__ __forceinline__ void top3_insert(Top3 &s, float m, int id)
+{
+    const bool lt1 = m < s.a1, lt2 = m < s.a2;
+    s.a3 = __builtin_amdgcn_fmed3f(s.a2, s.a3, m);
+    s.a2 = __builtin_amdgcn_fmed3f(s.a1, s.a2, m);
+    s.c2 = lt1 ? s.c1 : (lt2 ? id : s.c2);
+    s.c1 = lt1 ? id : s.c1;
+    asm("v_min_f32 %0, %1, %2" : "=v"(s.a1) : "v"(s.a1), "v"(m));
+}
+
+// True when every target whose approximate value is >= a_rest provably has a
+// reference distance above that of the target that produced a_best.
+__device__ __forceinline__ bool nn_safe(float a_best, float a_rest, float qq, float tmax2)
+{
+    const double u = 1.01 * 5.9604644775390625e-8;
+    const double T = sqrt((double)tmax2), qn = sqrt((double)qq);
+    const double E1 = u * (8.0 * qn * T + 7.0 * T * T + 3.0 * (double)qq);
+    const double eta = u * (qn + T);
+    double up = (double)a_best + (double)qq + E1;
+    up = sqrt(up > 0.0 ? up : 0.0) + eta;
+    up = up * up * (1.0 + 6.0 * u);
+    double lo = (double)a_rest + (double)qq - E1;
+    lo = sqrt(lo > 0.0 ? lo : 0.0) - eta;
+    lo = lo > 0.0 ? lo : 0.0;
+    lo = lo * lo * (1.0 - 6.0 * u);
+    return lo > up;      // false for NaN
+}
+
+// Exact (reference arithmetic) minimum and FIRST index over targets [base, base+len)
+// of a cloud of nt targets, positions past the end clamped to the last target.
+template <int FMA, int LEN>
+__device__ __forceinline__ void rescan_chunk(const float *__restrict__ T, int nt, int base, float qx, float qy,
+                                             float qz, float &bd, int &bi)
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    bd = __builtin_inff();
+    bi = base;
+    if (base + LEN <= nt) {
+        const f4u *tp = (const f4u *)(T + (size_t)base * 3);
+#pragma unroll
+        for (int c8 = LEN - 8; c8 >= 0; c8 -= 8) {
+            f4u v[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) v[i] = tp[(c8 >> 2) * 3 + i];
+            const float f[24] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
+                                 v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w,
+                                 v[4].x, v[4].y, v[4].z, v[4].w, v[5].x, v[5].y, v[5].z, v[5].w};
+#pragma unroll
+            for (int c = 7; c >= 0; c--) {
+                const float dd = sqdist<FMA>(f[c * 3 + 0] - qx, f[c * 3 + 1] - qy, f[c * 3 + 2] - qz);
+                const bool le = dd <= bd;
+                bd = le ? dd : bd;
+                bi = le ? base + c8 + c : bi;
+            }
+        }
+    } else {
+        for (int c = LEN - 1; c >= 0; c--) {
+            int kk = base + c;
+            kk = kk < nt ? kk : nt - 1;
+            const float *tp = T + (size_t)kk * 3;
+            const float dd = sqdist<FMA>(tp[0] - qx, tp[1] - qy, tp[2] - qz);
+            const bool le = dd <= bd;
+            bd = le ? dd : bd;
+            bi = le ? kk : bi;
+        }
+    }
+}
+
+// One block = one (direction, target slice, batch, 128*Q-query block) unit; wave w
+// owns Q tiles of 32 queries.  U = MFMA tiles per bookkeeping unit (re-scan
+// granularity 32*U targets).
+template <int Q, int U, int FMA>
+__global__ __launch_bounds__(kBlock) void nn_mfma_kernel(NNArgs a)
+{
+    constexpr int kC = 32 * U;
+    __shared__ float2 plane[2][kMTile + 2 * kC];  // + two spare units for the pipeline's last fetches
+    __shared__ float s_red[kWavesPerBlock];
+    __shared__ int s_fi[kWavesPerBlock];
+    __shared__ int s_misc[2];                 // [0] arrival ticket, [1] number of flagged queries
+    __shared__ int s_flag[kWavesPerBlock * Q * 32];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    int bid = blockIdx.x;
+    const int d = (a.ndir > 1 && bid >= a.dir[1].block_begin) ? 1 : 0;
+    const NNDir &D = a.dir[d];
+    bid -= D.block_begin;
+    const int qb = bid % D.qblocks;
+    const int rest = bid / D.qblocks;
+    const int batch = rest % a.b;
+    const int slice = rest / a.b;
+
+    const int nq = D.nq, nt = D.nt;
+    const float *__restrict__ Qp = D.q + (size_t)batch * nq * 3;
+    const float *__restrict__ T = D.t + (size_t)batch * nt * 3;
+    const float cx = T[0], cy = T[1], cz = T[2];
+
+    const int k_begin = slice * a.slice_len;
+    int k_end = k_begin + a.slice_len;
+    if (k_end > nt) k_end = nt;
+
+    float qx[Q], qy[Q], qz[Q], b0[Q], b1[Q], qq[Q];
+    Top3 st[Q];
+    const int q0 = (qb * kWavesPerBlock + wave) * (32 * Q) + col;
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+        int j = q0 + r * 32;
+        if (j >= nq) j = nq - 1;
+        qx[r] = Qp[(size_t)j * 3 + 0];
+        qy[r] = Qp[(size_t)j * 3 + 1];
+        qz[r] = Qp[(size_t)j * 3 + 2];
+        const float px = qx[r] - cx, py = qy[r] - cy, pz = qz[r] - cz;
+        qq[r] = __fmaf_rn(pz, pz, __fmaf_rn(py, py, __fmul_rn(px, px)));
+        b0[r] = half ? py : px;          // k = 0 (x) on lanes 0..31, k = 1 (y) on lanes 32..63
+        b1[r] = half ? 1.0f : pz;        // k = 2 (z),               k = 3 (|t|^2 x 1)
+        top3_init(st[r]);
+    }
+
+    f32x16 acc0[U * Q], acc1[U * Q];
+    float2 A[U];
+    auto fetch = [&](int rb) {
+#pragma unroll
+        for (int s = 0; s < U; s++) A[s] = plane[half][rb + s * 32 + col];
+    };
+    // MFMAs of the unit whose rows are in A, then the rows of unit `next` into A
+    auto issue = [&](int next, f32x16 (&dst)[U * Q]) {
+#pragma unroll
+        for (int s = 0; s < U; s++) {
+#pragma unroll
+            for (int r = 0; r < Q; r++) {
+                f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s].x, b0[r], c, 0, 0, 0);
+                dst[s * Q + r] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s].y, b1[r], c, 0, 0, 0);
+            }
+        }
+        fetch(next);
+    };
+    auto reduce = [&](const f32x16 (&src)[U * Q], int id) {
+#pragma unroll
+        for (int r = 0; r < Q; r++) {
+            float m;
+#pragma unroll
+            for (int s = 0; s < U; s++) {
+                const f32x16 &c = src[s * Q + r];
+                // raw v_min3: fminf() would first canonicalise every MFMA output (v_max x,x)
+                if (s == 0) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(c[0]), "v"(c[1]), "v"(c[2]));
+                else        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(c[0]), "v"(c[1]));
+#pragma unroll
+                for (int i = (s == 0 ? 3 : 2); i + 1 < 16; i += 2)
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(c[i]), "v"(c[i + 1]));
+                if (s == 0) asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(c[15]));
+            }
+            top3_insert(st[r], m, id);
+        }
+    };
+
+    float tmax2 = 0.0f;
+    for (int t0 = k_begin; t0 < k_end && !(a.debug & 4); t0 += kMTile) {
+        const int tn = min(kMTile, k_end - t0);
+        const int tn_pad = (tn + 2 * kC - 1) / (2 * kC) * (2 * kC);
+        __syncthreads();
+        for (int t = threadIdx.x; t < tn_pad; t += kBlock) {
+            float ax = 0.0f, ay = 0.0f, az = 0.0f, tt = __builtin_inff();   // padding: +inf never wins
+            if (t < tn) {
+                const float *tp = T + (size_t)(t0 + t) * 3;
+                const float x = tp[0] - cx, y = tp[1] - cy, z = tp[2] - cz;
+                tt = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
+                tmax2 = fmaxf(tmax2, tt);
+                ax = -2.0f * x; ay = -2.0f * y; az = -2.0f * z;
+            }
+            plane[0][t] = make_float2(ax, az);
+            plane[1][t] = make_float2(ay, tt);
+        }
+        __syncthreads();
+        // Two-stage software pipeline over bookkeeping units: the MFMAs of unit i+1 are
+        // issued before the VALU minima of unit i, into the other accumulator set.
+        fetch(0);
+        issue(kC, acc0);
+        for (int rb = 0; rb < tn_pad; rb += 2 * kC) {
+            issue(rb + 2 * kC, acc1);          // past the end: spare rows, results dropped
+            __builtin_amdgcn_sched_barrier(0);
+            reduce(acc0, t0 + rb);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(rb + 3 * kC, acc0);
+            __builtin_amdgcn_sched_barrier(0);
+            reduce(acc1, t0 + rb + kC);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // lanes l and l^32 hold the two halves of the same queries: fold (both end up equal)
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+        const float o1 = __shfl_xor(st[r].a1, 32), o2 = __shfl_xor(st[r].a2, 32), o3 = __shfl_xor(st[r].a3, 32);
+        const int oc1 = __shfl_xor(st[r].c1, 32), oc2 = __shfl_xor(st[r].c2, 32);
+        Top3 lo = st[r], hi = st[r];
+        if (half) { lo.a1 = o1; lo.a2 = o2; lo.a3 = o3; lo.c1 = oc1; lo.c2 = oc2; }
+        else      { hi.a1 = o1; hi.a2 = o2; hi.a3 = o3; hi.c1 = oc1; hi.c2 = oc2; }
+        top3_insert(lo, hi.a1, hi.c1);
+        top3_insert(lo, hi.a2, hi.c2);
+        top3_insert(lo, hi.a3, -1);
+        st[r] = lo;
+    }
+    // slice maximum of |t'|^2
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, o));
+    __syncthreads();
+    if (lane == 0) s_red[wave] = tmax2;
+    __syncthreads();
+    tmax2 = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+
+    if (D.slices > 1) {
+        // Per query and slice three 8-byte words (a1,c1) (a2,c2) (a3,tmax2), agent-scope
+        // atomic stores / loads on both sides (see the VALU kernel); the last block to
+        // arrive folds the slices in slice order.
+        const size_t bnq = (size_t)a.b * nq;
+        unsigned long long *P = D.part + (size_t)batch * nq;
+        if (!half) {
+#pragma unroll
+            for (int r = 0; r < Q; r++) {
+                const int j = q0 + r * 32;
+                if (j < nq) {
+                    unsigned long long *p = P + (size_t)slice * 3 * bnq + j;
+                    __hip_atomic_store(p, ((unsigned long long)__float_as_uint(st[r].a1) << 32) | (unsigned)st[r].c1,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p + bnq, ((unsigned long long)__float_as_uint(st[r].a2) << 32) | (unsigned)st[r].c2,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p + 2 * bnq,
+                                       ((unsigned long long)__float_as_uint(st[r].a3) << 32) | __float_as_uint(tmax2),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (a.debug & 2) return;
+        int *cnt = a.arrive + D.unit_begin + batch * D.qblocks + qb;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_misc[0] = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_misc[0] != D.slices - 1) return;
+        if (threadIdx.x == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int r = 0; r < Q; r++) {
+            int j = q0 + r * 32;
+            j = j < nq ? j : nq - 1;
+            Top3 f;
+            top3_init(f);
+            float tm = 0.0f;
+            for (int s2 = 0; s2 < D.slices; s2++) {
+                const unsigned long long *p = P + (size_t)s2 * 3 * bnq + j;
+                const unsigned long long w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w1 = __hip_atomic_load(p + bnq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w2 = __hip_atomic_load(p + 2 * bnq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                top3_insert(f, __uint_as_float((unsigned)(w0 >> 32)), (int)(unsigned)w0);
+                top3_insert(f, __uint_as_float((unsigned)(w1 >> 32)), (int)(unsigned)w1);
+                top3_insert(f, __uint_as_float((unsigned)(w2 >> 32)), -1);
+                tm = fmaxf(tm, __uint_as_float((unsigned)w2));
+            }
+            st[r] = f;
+            tmax2 = tm;      // the same for every query of the block
+        }
+    }
+
+    // Decide, re-scan the listed tile(s) exactly, or flag the query for the exhaustive pass.
+    float *__restrict__ od = D.out_d + (size_t)batch * nq;
+    int *__restrict__ oi = D.out_i + (size_t)batch * nq;
+    __syncthreads();
+    if (threadIdx.x == 0) s_misc[1] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+        const Top3 &f = st[r];
+        bool two = false, flag = false;
+        if (!nn_safe(f.a1, f.a2, qq[r], tmax2) || (a.debug & 16)) {
+            two = true;
+            if (!nn_safe(f.a1, f.a3, qq[r], tmax2) || f.c2 < 0) flag = true;
+        }
+        if (f.c1 < 0 || (a.debug & 8)) flag = true;
+        const int j = q0 + r * 32;
+        if (flag) {
+            if (!half && j < nq) s_flag[atomicAdd(&s_misc[1], 1)] = j;
+            continue;
+        }
+        // lanes 0..31 take the first tile, lanes 32..63 the second (when needed and different)
+        const int base = half ? f.c2 : f.c1;
+        float bd = __builtin_inff();
+        int bi = 0;
+        if ((!half || (two && f.c2 != f.c1)) && !(a.debug & 1)) rescan_chunk<FMA, kC>(T, nt, base, qx[r], qy[r], qz[r], bd, bi);
+        const float obd = __shfl_xor(bd, 32);
+        const int obi = __shfl_xor(bi, 32);
+        if (!half && j < nq) {
+            const bool other = obd < bd || (obd == bd && obi < bi);
+            od[j] = other ? obd : bd;
+            oi[j] = other ? obi : bi;
+        }
+    }
+    __syncthreads();
+    const int nflag = s_misc[1];
+    for (int fidx = 0; fidx < nflag; fidx++) {
+        // exhaustive, reference arithmetic, whole block on one query
+        const int j = s_flag[fidx];
+        const float x = Qp[(size_t)j * 3 + 0], y = Qp[(size_t)j * 3 + 1], z = Qp[(size_t)j * 3 + 2];
+        float bd = __builtin_inff();
+        int bi = 0x7fffffff;
+        for (int k = threadIdx.x; k < nt; k += kBlock) {
+            const float *tp = T + (size_t)k * 3;
+            const float dd = sqdist<FMA>(tp[0] - x, tp[1] - y, tp[2] - z);
+            const bool lt = dd < bd;
+            bd = lt ? dd : bd;
+            bi = lt ? k : bi;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float obd = __shfl_xor(bd, o);
+            const int obi = __shfl_xor(bi, o);
+            const bool other = obd < bd || (obd == bd && obi < bi);
+            bd = other ? obd : bd;
+            bi = other ? obi : bi;
+        }
+        __syncthreads();
+        if (lane == 0) { s_red[wave] = bd; s_fi[wave] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kWavesPerBlock; w++) {
+                const bool other = s_red[w] < bd || (s_red[w] == bd && s_fi[w] < bi);
+                bd = other ? s_red[w] : bd;
+                bi = other ? s_fi[w] : bi;
+            }
+            od[j] = bd;
+            // every distance NaN (non-finite input): the reference keeps target 0's distance and index 0
+            if (bi == 0x7fffffff) {
+                od[j] = sqdist<FMA>(T[0] - x, T[1] - y, T[2] - z);
+                bi = 0;
+            }
+            oi[j] = bi;
+        }
+    }
+}
+
 // Chamfer backward, both directions in one launch (chamfer3D.cu:155-195).
 // Thread j < B*N: direction 1 term of point j of cloud 1; B*N <= j < B*(N+M):
 // direction 2 term of point j-B*N of cloud 2.  Accumulates with fp32 atomics
@@ -312,22 +695,39 @@ __global__ __launch_bounds__(kBlock) void chamfer_grad_kernel(int b, int n, cons
 }
 
 struct NNConfig {
-    int r;                // queries per lane: 0 = pick, else 2 or 4
+    int r;                // VALU path, queries per lane: 0 = pick, else 2 or 4
     int blocks_per_cu;    // occupancy target used to pick the slice count
+    int mfma;             // 1: MFMA filter + exact re-scan (default), 0: VALU path
+    int q;                // MFMA path, 32-query tiles per wave: 0 = pick, else 1 or 2
+    int u;                // MFMA path, tiles per bookkeeping unit: 0 = pick, else 1 or 2
 };
 
 // Tunables; GENPC_NN_R / GENPC_NN_WPS override for experiments.
 static NNConfig nn_config()
 {
     static NNConfig c = [] {
-        NNConfig k{0, 4};
+        NNConfig k{0, 4, 1, 0, 0};
         if (const char *e = getenv("GENPC_NN_R")) k.r = atoi(e);
+        if (const char *e = getenv("GENPC_NN_PATH")) k.mfma = (e[0] == 'v') ? 0 : 1;
+        if (const char *e = getenv("GENPC_NN_Q")) k.q = atoi(e);
+        if (const char *e = getenv("GENPC_NN_U")) k.u = atoi(e);
+        if (k.q != 1 && k.q != 2) k.q = 0;
+        if (k.u != 1 && k.u != 2) k.u = 0;
         if (const char *e = getenv("GENPC_NN_WPS")) k.blocks_per_cu = atoi(e);
         if (k.r != 2 && k.r != 4) k.r = 0;
         if (k.blocks_per_cu < 1) k.blocks_per_cu = 1;
         return k;
     }();
     return c;
+}
+
+template <int Q, int U>
+static void launch_mfma(const NNArgs &a, int blocks, hipStream_t st)
+{
+    if (arith_mode() != 0)
+        hipLaunchKernelGGL((nn_mfma_kernel<Q, U, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
+    else
+        hipLaunchKernelGGL((nn_mfma_kernel<Q, U, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
 }
 
 template <int R>
@@ -375,6 +775,17 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         for (int d = 0; d < nd; d++) unsplit4 += (long long)b * ceil_div(a.dir[d].nq, kBlock * 4);
         r = unsplit4 >= kNumCU ? 4 : 2;
     }
+    // MFMA path: a block covers 128*Q queries; Q = 2 halves the LDS reads and the blocks.
+    int q = cfg.q;
+    if (cfg.mfma && !q) {
+        long long unsplit2 = 0;
+        for (int d = 0; d < nd; d++) unsplit2 += (long long)b * ceil_div(a.dir[d].nq, 256);
+        q = 1;       // measured: Q = 2 is slower at every size from 1x2048^2 to 13x16384^2
+        (void)unsplit2;
+    }
+    const int qper = cfg.mfma ? 128 * q : kBlock * r;       // queries per block
+    const int gran = cfg.mfma ? 64 : kChunk;                // slice granularity (a U = 2 unit)
+    const int pwords = cfg.mfma ? 3 : 1;                    // 8-byte words per (slice, query)
     // One slice length for the whole launch, so that every block does the same amount
     // of work, and per-direction slice counts S_d = ceil(nt_d / slice_len) (no empty
     // slices when the two clouds differ in size).  slice_len is what makes the launch
@@ -384,7 +795,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // as two blocks per CU remain.
     long long work = 0;          // blocks x targets if every block took one target
     for (int d = 0; d < nd; d++) {
-        a.dir[d].qblocks = ceil_div(a.dir[d].nq, kBlock * r);
+        a.dir[d].qblocks = ceil_div(a.dir[d].nq, qper);
         work += (long long)b * a.dir[d].qblocks * a.dir[d].nt;
     }
     auto blocks_at = [&](long long len) {
@@ -392,11 +803,14 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         for (int d = 0; d < nd; d++) t += (long long)b * a.dir[d].qblocks * ceil_div64(a.dir[d].nt, len);
         return t;
     };
-    long long len = ceil_div64(ceil_div64(work, want_blocks), kChunk) * kChunk;
+    long long len = ceil_div64(ceil_div64(work, want_blocks), gran) * gran;
     if (len < kChunk * 8) len = kChunk * 8;
     if (len < kChunk * 16 && blocks_at(kChunk * 16) >= 2 * kNumCU) len = kChunk * 16;
-    if (len > nt_max) len = ceil_div64(nt_max, kChunk) * kChunk;
+    if (len > nt_max) len = ceil_div64(nt_max, gran) * gran;
     a.slice_len = (int)len;
+    // bookkeeping per 64 targets once a block has enough of them to amortise the coarser
+    // re-scan (measured: 1x2048^2 14.5 vs 16.0 us, 1x16384^2 63.6 vs 61.2, 13x16384^2 644 vs 590)
+    const int u = cfg.u ? cfg.u : (len >= 2048 ? 2 : 1);
     long long tb = 0;
     int units = 0;
     size_t part = 0;
@@ -409,7 +823,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         tb += (long long)D.slices * b * D.qblocks;
         units += b * D.qblocks;
         if (D.slices > 1) {
-            part += (size_t)D.slices * b * D.nq;
+            part += (size_t)D.slices * b * D.nq * pwords;
             any_split = true;
         }
     }
@@ -434,11 +848,18 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         for (int d = 0; d < nd; d++) {
             if (a.dir[d].slices > 1) {
                 a.dir[d].part = wp + off;
-                off += (size_t)a.dir[d].slices * b * a.dir[d].nq;
+                off += (size_t)a.dir[d].slices * b * a.dir[d].nq * pwords;
             }
         }
     }
-    if (r == 4) launch_r<4>(a, (int)tb, st); else launch_r<2>(a, (int)tb, st);
+    if (cfg.mfma) {
+        if (q == 2) { if (u == 2) launch_mfma<2, 2>(a, (int)tb, st); else launch_mfma<2, 1>(a, (int)tb, st); }
+        else        { if (u == 2) launch_mfma<1, 2>(a, (int)tb, st); else launch_mfma<1, 1>(a, (int)tb, st); }
+    } else if (r == 4) {
+        launch_r<4>(a, (int)tb, st);
+    } else {
+        launch_r<2>(a, (int)tb, st);
+    }
     return check(hipGetLastError(), "nn_forward_kernel launch") ? 1 : 0;
 }
 

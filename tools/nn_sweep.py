@@ -42,6 +42,18 @@ def main():
     dbgs = [int(x) for x in os.environ.get("SWEEP_DEBUG", "0").split(",")]
     rs = [int(x) for x in os.environ.get("SWEEP_R", "0,2,4").split(",")]
     ws = [int(x) for x in os.environ.get("SWEEP_WPS", "2,4,8").split(",")]
+    # SWEEP_VARIANTS="GENPC_NN_PATH=valu;GENPC_NN_Q=1,GENPC_NN_U=2;..." runs exactly those environments
+    if os.environ.get("SWEEP_VARIANTS"):
+        for var in os.environ["SWEEP_VARIANTS"].split(";"):
+            env = dict(os.environ)
+            for kv in var.split(","):
+                if kv:
+                    k, v = kv.split("=")
+                    env[k] = v
+            p = subprocess.run([sys.executable, "-c", CHILD] + sizes, env=env, capture_output=True, text=True, timeout=300)
+            line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-300:]
+            print("%s [us, Gpair/s, idxsum] %s" % (var or "default", line), flush=True)
+        return
     for r, wps, dbg in itertools.product(rs, ws, dbgs):
         env = dict(os.environ, GENPC_NN_R=str(r), GENPC_NN_WPS=str(wps), GENPC_NN_DEBUG=str(dbg))
         p = subprocess.run([sys.executable, "-c", CHILD] + sizes, env=env, capture_output=True, text=True, timeout=300)
