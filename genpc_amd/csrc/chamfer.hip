@@ -31,54 +31,18 @@
 // Arithmetic is written with explicit __fmaf_rn/__fmul_rn/__fadd_rn and the file
 // is compiled with -ffp-contract=off, so the compiler cannot re-associate or
 // contract differently from oracle/genpc_oracle.c.
-#include "common.h"
+#include "nn.h"
 #include "../../include/genpc_hip.h"
 
 #include <stdlib.h>
+#include <algorithm>
 
 namespace genpc {
 
-constexpr int kChunk = 32;       // targets per min-only chunk (re-scan granularity)
-constexpr int kBlock = 256;      // 4 waves
-constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kTile = 2048;      // targets per LDS tile (24 KiB: 12 B per target)
 
-template <int FMA>
-__device__ __forceinline__ float sqdist(float dx, float dy, float dz)
-{
-    if (FMA) {
-        float t = __fmul_rn(dy, dy);
-        t = __fmaf_rn(dx, dx, t);
-        return __fmaf_rn(dz, dz, t);
-    } else {
-        float a = __fmul_rn(dx, dx);
-        float b = __fmul_rn(dy, dy);
-        float c = __fmul_rn(dz, dz);
-        return __fadd_rn(__fadd_rn(a, b), c);
-    }
-}
 
-struct NNDir {
-    const float *q;    // queries  [B, nq, 3]
-    const float *t;    // targets  [B, nt, 3]
-    float *out_d;      // final    [B, nq]
-    int *out_i;
-    unsigned long long *part;   // per-slice partials [S, B*nq] (S > 1): distance bits << 32 | chunk
-    int nq, nt;
-    int qblocks;       // ceil(nq / (256*R))
-    int slices;        // S for this direction: ceil(nt / slice_len)
-    int block_begin;   // first block id of this direction
-    int unit_begin;    // first arrival counter of this direction
-};
 
-struct NNArgs {
-    NNDir dir[2];
-    int ndir;
-    int b;
-    int slice_len;     // targets per slice (all blocks of a launch do equal work), multiple of kChunk
-    int *arrive;       // [sum_d b*qblocks] arrival counters, zero between launches
-    int debug;         // experiment switches (GENPC_NN_DEBUG): 1 skip index recovery, 2 skip merge, 4 skip main loop
-};
 
 // One block = one (direction, target slice, batch, 256*R-query block) unit; wave w
 // of the block owns queries [w*64*R, (w+1)*64*R) of that block.
@@ -302,29 +266,8 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
 // reference's value is D (1 + theta), |theta| <= 6u (three subtractions, squared,
 // three to five roundings of non-negative terms).  All evaluated in fp64 with u
 // inflated by 1 %.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMTile = 2048;     // targets per LDS tile on the MFMA path (2 planes x 8 B)
 
-struct Top3 {
-    float a1, a2, a3;   // three smallest unit minima (a3: bound for everything unlisted)
-    int c1, c2;         // first target index of the tiles of a1, a2 (-1: unknown)
-};
-
-__device__ __forceinline__ void top3_init(Top3 &s)
-{
-    s.a1 = s.a2 = s.a3 = __builtin_inff();
-    s.c1 = s.c2 = -1;
-}
-
-__device__ __forceinline__ void top3_insert(Top3 &s, float m, int id)
-{
-    const bool lt1 = m < s.a1, lt2 = m < s.a2;
-    s.a3 = __builtin_amdgcn_fmed3f(s.a2, s.a3, m);
-    s.a2 = __builtin_amdgcn_fmed3f(s.a1, s.a2, m);
-    s.c2 = lt1 ? s.c1 : (lt2 ? id : s.c2);
-    s.c1 = lt1 ? id : s.c1;
-    asm("v_min_f32 %0, %1, %2" : "=v"(s.a1) : "v"(s.a1), "v"(m));
-}
 
 // True when every target whose approximate value is >= a_rest provably has a
 // reference distance above that of the target that produced a_best.
@@ -346,43 +289,6 @@ __device__ __forceinline__ bool nn_safe(float a_best, float a_rest, float qq, fl
 
 // Exact (reference arithmetic) minimum and FIRST index over targets [base, base+len)
 // of a cloud of nt targets, positions past the end clamped to the last target.
-template <int FMA, int LEN>
-__device__ __forceinline__ void rescan_chunk(const float *__restrict__ T, int nt, int base, float qx, float qy,
-                                             float qz, float &bd, int &bi)
-{
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    bd = __builtin_inff();
-    bi = base;
-    if (base + LEN <= nt) {
-        const f4u *tp = (const f4u *)(T + (size_t)base * 3);
-#pragma unroll
-        for (int c8 = LEN - 8; c8 >= 0; c8 -= 8) {
-            f4u v[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) v[i] = tp[(c8 >> 2) * 3 + i];
-            const float f[24] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
-                                 v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w,
-                                 v[4].x, v[4].y, v[4].z, v[4].w, v[5].x, v[5].y, v[5].z, v[5].w};
-#pragma unroll
-            for (int c = 7; c >= 0; c--) {
-                const float dd = sqdist<FMA>(f[c * 3 + 0] - qx, f[c * 3 + 1] - qy, f[c * 3 + 2] - qz);
-                const bool le = dd <= bd;
-                bd = le ? dd : bd;
-                bi = le ? base + c8 + c : bi;
-            }
-        }
-    } else {
-        for (int c = LEN - 1; c >= 0; c--) {
-            int kk = base + c;
-            kk = kk < nt ? kk : nt - 1;
-            const float *tp = T + (size_t)kk * 3;
-            const float dd = sqdist<FMA>(tp[0] - qx, tp[1] - qy, tp[2] - qz);
-            const bool le = dd <= bd;
-            bd = le ? dd : bd;
-            bi = le ? kk : bi;
-        }
-    }
-}
 
 // One block = one (direction, target slice, batch, 128*Q-query block) unit; wave w
 // owns Q tiles of 32 queries.  U = MFMA tiles per bookkeeping unit (re-scan
@@ -697,7 +603,7 @@ __global__ __launch_bounds__(kBlock) void chamfer_grad_kernel(int b, int n, cons
 struct NNConfig {
     int r;                // VALU path, queries per lane: 0 = pick, else 2 or 4
     int blocks_per_cu;    // occupancy target used to pick the slice count
-    int mfma;             // 1: MFMA filter + exact re-scan (default), 0: VALU path
+    int mfma;             // 2: split-bf16 MFMA filter (default), 1: fp32 MFMA filter, 0: VALU path
     int q;                // MFMA path, 32-query tiles per wave: 0 = pick, else 1 or 2
     int u;                // MFMA path, tiles per bookkeeping unit: 0 = pick, else 1 or 2
 };
@@ -706,12 +612,12 @@ struct NNConfig {
 static NNConfig nn_config()
 {
     static NNConfig c = [] {
-        NNConfig k{0, 4, 1, 0, 0};
+        NNConfig k{0, 4, 2, 0, 0};
         if (const char *e = getenv("GENPC_NN_R")) k.r = atoi(e);
-        if (const char *e = getenv("GENPC_NN_PATH")) k.mfma = (e[0] == 'v') ? 0 : 1;
+        if (const char *e = getenv("GENPC_NN_PATH")) k.mfma = (e[0] == 'v') ? 0 : (e[0] == 'm' ? 1 : 2);
         if (const char *e = getenv("GENPC_NN_Q")) k.q = atoi(e);
         if (const char *e = getenv("GENPC_NN_U")) k.u = atoi(e);
-        if (k.q != 1 && k.q != 2) k.q = 0;
+        if (k.q != 1 && k.q != 2 && k.q != 4) k.q = 0;
         if (k.u != 1 && k.u != 2) k.u = 0;
         if (const char *e = getenv("GENPC_NN_WPS")) k.blocks_per_cu = atoi(e);
         if (k.r != 2 && k.r != 4) k.r = 0;
@@ -768,7 +674,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // R = 4 (fewer LDS reads per pair, more independent chains per lane) when the query
     // blocks alone fill the chip; R = 2 otherwise: twice the blocks, half the per-wave
     // epilogue (measured on MI355X: 1x16384^2 87 us vs 97 us, 13x16384^2 870 us vs 835 us).
-    const long long want_blocks = (long long)kNumCU * cfg.blocks_per_cu;
+    long long want_blocks = (long long)kNumCU * cfg.blocks_per_cu;
     int r = cfg.r;
     if (!r) {
         long long unsplit4 = 0;
@@ -780,12 +686,14 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     if (cfg.mfma && !q) {
         long long unsplit2 = 0;
         for (int d = 0; d < nd; d++) unsplit2 += (long long)b * ceil_div(a.dir[d].nq, 256);
-        q = 1;       // measured: Q = 2 is slower at every size from 1x2048^2 to 13x16384^2
+        // fp32 MFMA: Q = 2 measured slower at every size from 1x2048^2 to 13x16384^2
+        q = cfg.mfma == 2 ? 4 : 1;
         (void)unsplit2;
     }
+    if (cfg.mfma == 2 && !getenv("GENPC_NN_WPS")) want_blocks = (long long)kNumCU * (q == 4 ? 2 : (q == 2 ? 3 : 4));   // resident blocks per CU (VGPRs)
     const int qper = cfg.mfma ? 128 * q : kBlock * r;       // queries per block
-    const int gran = cfg.mfma ? 64 : kChunk;                // slice granularity (a U = 2 unit)
-    const int pwords = cfg.mfma ? 3 : 1;                    // 8-byte words per (slice, query)
+    const int gran = cfg.mfma == 2 ? 128 : (cfg.mfma ? 64 : kChunk);   // slice granularity: one bookkeeping unit
+    int pwords = cfg.mfma ? 3 : 1;                          // 8-byte words per (slice, query)
     // One slice length for the whole launch, so that every block does the same amount
     // of work, and per-direction slice counts S_d = ceil(nt_d / slice_len) (no empty
     // slices when the two clouds differ in size).  slice_len is what makes the launch
@@ -811,6 +719,26 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // bookkeeping per 64 targets once a block has enough of them to amortise the coarser
     // re-scan (measured: 1x2048^2 14.5 vs 16.0 us, 1x16384^2 63.6 vs 61.2, 13x16384^2 644 vs 590)
     const int u = cfg.u ? cfg.u : (len >= 2048 ? 2 : 1);
+    // split-bf16 path: candidate lists per lane so that a query has >= 8 lists in all
+    // (2 lane halves, or the slices once folded)
+    // split-bf16 path: NL candidate lists per lane so that a query has >= 4 lists in all
+    // (slices x NL once the lane halves are folded), and at most kMaxLists = 16 of them
+    int nl = 1;
+    if (cfg.mfma == 2) {
+        for (;;) {
+            int smin = 1 << 30, smax = 0;
+            for (int d = 0; d < nd; d++) {
+                const int sd = ceil_div(a.dir[d].nt, (int)len);
+                smin = std::min(smin, sd);
+                smax = std::max(smax, sd);
+            }
+            nl = smin >= 4 ? 1 : (smin >= 2 || q == 4 ? 2 : 4);
+            if (smax * nl <= 16) break;
+            len = ceil_div64(ceil_div64(nt_max, 16 / nl), gran) * gran;
+        }
+        a.slice_len = (int)len;
+        pwords = 3 * nl;
+    }
     long long tb = 0;
     int units = 0;
     size_t part = 0;
@@ -822,7 +750,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         D.unit_begin = units;
         tb += (long long)D.slices * b * D.qblocks;
         units += b * D.qblocks;
-        if (D.slices > 1) {
+        if (D.slices > 1 || cfg.mfma == 2) {      // the bf16 path always hands its lists to a second launch
             part += (size_t)D.slices * b * D.nq * pwords;
             any_split = true;
         }
@@ -846,13 +774,15 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         unsigned long long *wp = (unsigned long long *)(ws + cnt_bytes);
         size_t off = 0;
         for (int d = 0; d < nd; d++) {
-            if (a.dir[d].slices > 1) {
+            if (a.dir[d].slices > 1 || cfg.mfma == 2) {
                 a.dir[d].part = wp + off;
                 off += (size_t)a.dir[d].slices * b * a.dir[d].nq * pwords;
             }
         }
     }
-    if (cfg.mfma) {
+    if (cfg.mfma == 2) {
+        return launch_nn_bf16(a, q, cfg.u == 2 ? 2 : 4, nl, tb, st);
+    } else if (cfg.mfma) {
         if (q == 2) { if (u == 2) launch_mfma<2, 2>(a, (int)tb, st); else launch_mfma<2, 1>(a, (int)tb, st); }
         else        { if (u == 2) launch_mfma<1, 2>(a, (int)tb, st); else launch_mfma<1, 1>(a, (int)tb, st); }
     } else if (r == 4) {

@@ -1,0 +1,186 @@
+// nn.h -- declarations shared by the nearest-neighbour kernels (chamfer.hip: VALU and
+// fp32-MFMA paths, nn_bf16.hip: split-bf16 MFMA path): launch descriptor, the
+// reference's distance arithmetic, candidate lists and the exact re-scan.
+#pragma once
+#include "common.h"
+
+namespace genpc {
+
+constexpr int kChunk = 32;       // targets per min-only chunk (re-scan granularity)
+constexpr int kBlock = 256;      // 4 waves
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+template <int FMA>
+__device__ __forceinline__ float sqdist(float dx, float dy, float dz)
+{
+    if (FMA) {
+        float t = __fmul_rn(dy, dy);
+        t = __fmaf_rn(dx, dx, t);
+        return __fmaf_rn(dz, dz, t);
+    } else {
+        float a = __fmul_rn(dx, dx);
+        float b = __fmul_rn(dy, dy);
+        float c = __fmul_rn(dz, dz);
+        return __fadd_rn(__fadd_rn(a, b), c);
+    }
+}
+
+struct NNDir {
+    const float *q;    // queries  [B, nq, 3]
+    const float *t;    // targets  [B, nt, 3]
+    float *out_d;      // final    [B, nq]
+    int *out_i;
+    unsigned long long *part;   // per-slice partials [S, B*nq] (S > 1): distance bits << 32 | chunk
+    int nq, nt;
+    // split-bf16 path (nn_bf16.hip): records written by nn_split_kernel
+    const uint4 *arec;      // targets [B][4 planes][nt] x 16 B
+    const uint4 *brec;      // queries [B][3 planes][nq] x 16 B
+    const float *qqv;       // |q'|^2 [B][nq]
+    const float *tmaxp;     // per split-block max |t'|^2 [B][ceil(nt/256)]
+    int fin_begin;          // first nn_finish_kernel block of this direction
+    int qblocks;       // ceil(nq / (256*R))
+    int slices;        // S for this direction: ceil(nt / slice_len)
+    int block_begin;   // first block id of this direction
+    int unit_begin;    // first arrival counter of this direction
+};
+
+struct NNArgs {
+    NNDir dir[2];
+    int ndir;
+    int b;
+    int slice_len;     // targets per slice (all blocks of a launch do equal work), multiple of kChunk
+    int *arrive;       // [sum_d b*qblocks] arrival counters, zero between launches
+    int debug;         // experiment switches (GENPC_NN_DEBUG): 1 skip index recovery, 2 skip merge, 4 skip main loop
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Top3 {
+    float a1, a2, a3;   // three smallest unit minima (a3: bound for everything unlisted)
+    int c1, c2;         // first target index of the tiles of a1, a2 (-1: unknown)
+};
+
+__device__ __forceinline__ void top3_init(Top3 &s)
+{
+    s.a1 = s.a2 = s.a3 = __builtin_inff();
+    s.c1 = s.c2 = -1;
+}
+
+__device__ __forceinline__ void top3_insert(Top3 &s, float m, int id)
+{
+    const bool lt1 = m < s.a1, lt2 = m < s.a2;
+    s.a3 = __builtin_amdgcn_fmed3f(s.a2, s.a3, m);
+    s.a2 = __builtin_amdgcn_fmed3f(s.a1, s.a2, m);
+    s.c2 = lt1 ? s.c1 : (lt2 ? id : s.c2);
+    s.c1 = lt1 ? id : s.c1;
+    asm("v_min_f32 %0, %1, %2" : "=v"(s.a1) : "v"(s.a1), "v"(m));
+}
+
+template <int FMA, int LEN>
+__device__ __forceinline__ void rescan_chunk(const float *__restrict__ T, int nt, int base, float qx, float qy,
+                                             float qz, float &bd, int &bi)
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    bd = __builtin_inff();
+    bi = base;
+    if (base + LEN <= nt) {
+        const f4u *tp = (const f4u *)(T + (size_t)base * 3);
+#pragma unroll
+        for (int c8 = LEN - 8; c8 >= 0; c8 -= 8) {
+            f4u v[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) v[i] = tp[(c8 >> 2) * 3 + i];
+            const float f[24] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
+                                 v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w,
+                                 v[4].x, v[4].y, v[4].z, v[4].w, v[5].x, v[5].y, v[5].z, v[5].w};
+#pragma unroll
+            for (int c = 7; c >= 0; c--) {
+                const float dd = sqdist<FMA>(f[c * 3 + 0] - qx, f[c * 3 + 1] - qy, f[c * 3 + 2] - qz);
+                const bool le = dd <= bd;
+                bd = le ? dd : bd;
+                bi = le ? base + c8 + c : bi;
+            }
+        }
+    } else {
+        for (int c = LEN - 1; c >= 0; c--) {
+            int kk = base + c;
+            kk = kk < nt ? kk : nt - 1;
+            const float *tp = T + (size_t)kk * 3;
+            const float dd = sqdist<FMA>(tp[0] - qx, tp[1] - qy, tp[2] - qz);
+            const bool le = dd <= bd;
+            bd = le ? dd : bd;
+            bi = le ? kk : bi;
+        }
+    }
+}
+
+// The whole block evaluates query j against every target with the reference's
+// arithmetic and writes (distance, first index): the last resort of the filtered
+// paths (three or more tiles within the error bound, non-finite input).
+template <int FMA>
+__device__ __forceinline__ void nn_exhaustive(const float *__restrict__ Qp, const float *__restrict__ T, int nt, int j,
+                                              float *__restrict__ od, int *__restrict__ oi, float *s_red, int *s_fi)
+{
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const float x = Qp[(size_t)j * 3 + 0], y = Qp[(size_t)j * 3 + 1], z = Qp[(size_t)j * 3 + 2];
+    float bd = __builtin_inff();
+    int bi = 0x7fffffff;
+    for (int k = threadIdx.x; k < nt; k += kBlock) {
+        const float *tp = T + (size_t)k * 3;
+        const float dd = sqdist<FMA>(tp[0] - x, tp[1] - y, tp[2] - z);
+        const bool lt = dd < bd;
+        bd = lt ? dd : bd;
+        bi = lt ? k : bi;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float obd = __shfl_xor(bd, o);
+        const int obi = __shfl_xor(bi, o);
+        const bool other = obd < bd || (obd == bd && obi < bi);
+        bd = other ? obd : bd;
+        bi = other ? obi : bi;
+    }
+    __syncthreads();
+    if (lane == 0) { s_red[wave] = bd; s_fi[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; w++) {
+            const bool other = s_red[w] < bd || (s_red[w] == bd && s_fi[w] < bi);
+            bd = other ? s_red[w] : bd;
+            bi = other ? s_fi[w] : bi;
+        }
+        // every distance NaN (non-finite input): keep target 0, as a strict '<' scan does
+        if (bi == 0x7fffffff) {
+            bd = sqdist<FMA>(T[0] - x, T[1] - y, T[2] - z);
+            bi = 0;
+        }
+        od[j] = bd;
+        oi[j] = bi;
+    }
+}
+
+// Largest approximate value a target can have and still beat (or tie) the target that
+// produced a_best, given |approx + |q'|^2 - |q'-t'|^2| <= u (kQT |q'| T + kTT T^2 + 3 |q'|^2)
+// (see the derivation above nn_mfma_kernel in chamfer.hip).  Units whose minimum is above
+// the returned value cannot contain the reference's nearest neighbour.  NaN when the
+// inputs are not finite (every comparison with it then fails -> exhaustive path).
+__device__ __forceinline__ float nn_tau(float a_best, float qq, float tmax2, double kQT, double kTT)
+{
+    const double u = 1.01 * 5.9604644775390625e-8;
+    const double T = sqrt((double)tmax2), qn = sqrt((double)qq);
+    const double E1 = u * (kQT * qn * T + kTT * T * T + 3.0 * (double)qq);
+    const double eta = u * (qn + T);
+    double up = (double)a_best + (double)qq + E1;
+    up = sqrt(up > 0.0 ? up : 0.0) + eta;
+    up = up * up * (1.0 + 6.0 * u);                    // >= reference distance of the best target
+    double r = sqrt(up / (1.0 - 6.0 * u)) + eta;       // a target with |q'-t'| above r is out
+    const double tau = r * r - (double)qq + E1;
+    // round up to float
+    float tf = (float)tau;
+    if ((double)tf < tau) tf = __uint_as_float(__float_as_uint(tf) + (tf >= 0.0f ? 1 : -1));
+    return tf;
+}
+
+int launch_nn_bf16(NNArgs &a, int q, int u, int nl, long long total_blocks, hipStream_t st);
+
+}  // namespace genpc
