@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to it)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgenpc_hip.so")
+# GENPC_LIB: an alternative build of the same library (kernel experiments only)
+LIB_PATH = os.environ.get("GENPC_LIB") or os.path.join(_HERE, "lib", "libgenpc_hip.so")
 ABI_VERSION = 7
 
 _vp = ctypes.c_void_p

@@ -671,6 +671,8 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     }
     a.ndir = nd;
     if (nd == 0) return 1;
+    int path = cfg.mfma;
+    if (path == 2 && nt_max >= (1 << 25)) path = 1;      // finish kernel packs tile indices in 21 bits
     // R = 4 (fewer LDS reads per pair, more independent chains per lane) when the query
     // blocks alone fill the chip; R = 2 otherwise: twice the blocks, half the per-wave
     // epilogue (measured on MI355X: 1x16384^2 87 us vs 97 us, 13x16384^2 870 us vs 835 us).
@@ -683,17 +685,17 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     }
     // MFMA path: a block covers 128*Q queries; Q = 2 halves the LDS reads and the blocks.
     int q = cfg.q;
-    if (cfg.mfma && !q) {
+    if (path && !q) {
         long long unsplit2 = 0;
         for (int d = 0; d < nd; d++) unsplit2 += (long long)b * ceil_div(a.dir[d].nq, 256);
         // fp32 MFMA: Q = 2 measured slower at every size from 1x2048^2 to 13x16384^2
-        q = cfg.mfma == 2 ? 4 : 1;
+        q = path == 2 ? 4 : 1;
         (void)unsplit2;
     }
-    if (cfg.mfma == 2 && !getenv("GENPC_NN_WPS")) want_blocks = (long long)kNumCU * (q == 4 ? 2 : (q == 2 ? 3 : 4));   // resident blocks per CU (VGPRs)
-    const int qper = cfg.mfma ? 128 * q : kBlock * r;       // queries per block
-    const int gran = cfg.mfma == 2 ? 128 : (cfg.mfma ? 64 : kChunk);   // slice granularity: one bookkeeping unit
-    int pwords = cfg.mfma ? 3 : 1;                          // 8-byte words per (slice, query)
+    if (path == 2 && !getenv("GENPC_NN_WPS")) want_blocks = (long long)kNumCU * (q == 4 ? 2 : (q == 2 ? 3 : 4));   // resident blocks per CU (VGPRs)
+    const int qper = path ? 128 * q : kBlock * r;       // queries per block
+    const int gran = path == 2 ? 128 : (path ? 64 : kChunk);   // slice granularity: one bookkeeping unit
+    int pwords = path ? 3 : 1;                          // 8-byte words per (slice, query)
     // One slice length for the whole launch, so that every block does the same amount
     // of work, and per-direction slice counts S_d = ceil(nt_d / slice_len) (no empty
     // slices when the two clouds differ in size).  slice_len is what makes the launch
@@ -719,23 +721,38 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // bookkeeping per 64 targets once a block has enough of them to amortise the coarser
     // re-scan (measured: 1x2048^2 14.5 vs 16.0 us, 1x16384^2 63.6 vs 61.2, 13x16384^2 644 vs 590)
     const int u = cfg.u ? cfg.u : (len >= 2048 ? 2 : 1);
-    // split-bf16 path: candidate lists per lane so that a query has >= 8 lists in all
-    // (2 lane halves, or the slices once folded)
-    // split-bf16 path: NL candidate lists per lane so that a query has >= 4 lists in all
-    // (slices x NL once the lane halves are folded), and at most kMaxLists = 16 of them
+    // split-bf16 path: the launch runs in rounds of `want_blocks` resident blocks, so the
+    // slice count is chosen to minimise rounds x (targets per block + a fixed per-block
+    // cost worth ~192 targets), over the slice counts that keep a query's candidate lists
+    // (slices x NL, NL lists per lane so that there are at least 4) within kMaxLists = 16.
     int nl = 1;
-    if (cfg.mfma == 2) {
-        for (;;) {
+    if (path == 2) {
+        auto lists_of = [&](long long l, int &nl_out) {
             int smin = 1 << 30, smax = 0;
             for (int d = 0; d < nd; d++) {
-                const int sd = ceil_div(a.dir[d].nt, (int)len);
+                const int sd = (int)ceil_div64(a.dir[d].nt, l);
                 smin = std::min(smin, sd);
                 smax = std::max(smax, sd);
             }
-            nl = smin >= 4 ? 1 : (smin >= 2 || q == 4 ? 2 : 4);
-            if (smax * nl <= 16) break;
-            len = ceil_div64(ceil_div64(nt_max, 16 / nl), gran) * gran;
+            nl_out = smin >= 4 ? 1 : (smin >= 2 || q == 4 ? 2 : 4);
+            return smax * nl_out;
+        };
+        long long best_len = 0;
+        double best_cost = 0.0;
+        for (int sc = 1; sc <= 16; sc++) {
+            const long long l = ceil_div64(ceil_div64(nt_max, sc), gran) * gran;
+            if (sc > 1 && l < 256) break;
+            int nl_c;
+            if (lists_of(l, nl_c) > 16) continue;
+            const long long rounds = ceil_div64(blocks_at(l), want_blocks);
+            const double cost = (double)rounds * (double)(std::min<long long>(l, nt_max) + 192);
+            if (!best_len || cost < best_cost * 0.98) {      // prefer fewer slices unless clearly better
+                best_len = l;
+                best_cost = cost;
+            }
         }
+        len = best_len;
+        (void)lists_of(len, nl);
         a.slice_len = (int)len;
         pwords = 3 * nl;
     }
@@ -750,7 +767,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         D.unit_begin = units;
         tb += (long long)D.slices * b * D.qblocks;
         units += b * D.qblocks;
-        if (D.slices > 1 || cfg.mfma == 2) {      // the bf16 path always hands its lists to a second launch
+        if (D.slices > 1 || path == 2) {      // the bf16 path always hands its lists to a second launch
             part += (size_t)D.slices * b * D.nq * pwords;
             any_split = true;
         }
@@ -774,15 +791,18 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         unsigned long long *wp = (unsigned long long *)(ws + cnt_bytes);
         size_t off = 0;
         for (int d = 0; d < nd; d++) {
-            if (a.dir[d].slices > 1 || cfg.mfma == 2) {
+            if (a.dir[d].slices > 1 || path == 2) {
                 a.dir[d].part = wp + off;
                 off += (size_t)a.dir[d].slices * b * a.dir[d].nq * pwords;
             }
         }
     }
-    if (cfg.mfma == 2) {
-        return launch_nn_bf16(a, q, cfg.u == 2 ? 2 : 4, nl, tb, st);
-    } else if (cfg.mfma) {
+    if (path == 2) {
+        // pre-split targets + LDS-DMA (one more launch) once every target is staged by many blocks
+        static const int pre_env = getenv("GENPC_NN_PRE") ? atoi(getenv("GENPC_NN_PRE")) : -1;
+        const int pre = pre_env >= 0 ? pre_env : 0;      // measured: 13x16384^2 401+8 us vs 410 us, 1x16384^2 35+5 vs 36 -- does not pay
+        return launch_nn_bf16(a, q, pre, nl, tb, st);
+    } else if (path) {
         if (q == 2) { if (u == 2) launch_mfma<2, 2>(a, (int)tb, st); else launch_mfma<2, 1>(a, (int)tb, st); }
         else        { if (u == 2) launch_mfma<1, 2>(a, (int)tb, st); else launch_mfma<1, 1>(a, (int)tb, st); }
     } else if (r == 4) {

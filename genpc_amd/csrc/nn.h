@@ -32,11 +32,10 @@ struct NNDir {
     int *out_i;
     unsigned long long *part;   // per-slice partials [S, B*nq] (S > 1): distance bits << 32 | chunk
     int nq, nt;
-    // split-bf16 path (nn_bf16.hip): records written by nn_split_kernel
-    const uint4 *arec;      // targets [B][4 planes][nt] x 16 B
-    const uint4 *brec;      // queries [B][3 planes][nq] x 16 B
-    const float *qqv;       // |q'|^2 [B][nq]
-    const float *tmaxp;     // per split-block max |t'|^2 [B][ceil(nt/256)]
+    // split-bf16 path (nn_bf16.hip)
+    float *tmaxp;           // partial maxima of |t'|^2 [B][ntmax] (per slice, or per split block)
+    const uint4 *arec;      // pre-split targets [B][4 planes][ntp] x 16 B
+    int ntp, ntmax;         // nt rounded up to 128; entries of tmaxp per batch element
     int fin_begin;          // first nn_finish_kernel block of this direction
     int qblocks;       // ceil(nq / (256*R))
     int slices;        // S for this direction: ceil(nt / slice_len)
@@ -181,6 +180,6 @@ __device__ __forceinline__ float nn_tau(float a_best, float qq, float tmax2, dou
     return tf;
 }
 
-int launch_nn_bf16(NNArgs &a, int q, int u, int nl, long long total_blocks, hipStream_t st);
+int launch_nn_bf16(NNArgs &a, int q, int pre, int nl, long long total_blocks, hipStream_t st);
 
 }  // namespace genpc

@@ -38,29 +38,16 @@
 namespace genpc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int kBTile = 512;            // targets per LDS tile: 4 planes x 16 B = 32 KiB
+#ifndef GENPC_BTILE
+#define GENPC_BTILE 512
+#endif
+constexpr int kBTile = GENPC_BTILE;    // targets per LDS tile: 4 planes x 16 B = 32 KiB at 512
 constexpr double kQT16 = 27.0, kTT16 = 17.0;
 constexpr int kMaxLists = 16;          // slices x lists per lane, when sliced (planner: chamfer.hip)
 
-// ---------------------------------------------------------------------------
-struct SplitJob {
-    const float *src;     // [B, n, 3]
-    void *out;            // kind 0: uint2 [B][3][n] (12 bf16 pieces), kind 1: uint4 [B][3][n]
-    float *aux;           // kind 0: per-block max |t'|^2 [B][bpb], kind 1: |q'|^2 [B][n]
-    int n, kind, bpb, block_begin;
-};
-
-struct SplitArgs {
-    SplitJob job[4];
-    int njobs;
-    const float *centre;  // direction-0 targets [B, cn, 3]
-    int cn;
-};
-
-__device__ __forceinline__ unsigned bf16_rn(float v)
+__device__ __forceinline__ unsigned bf16_rn(float v)      // v_cvt_pk_bf16_f32 (round to nearest even)
 {
-    const unsigned u = __float_as_uint(v);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
 }
 
 __device__ __forceinline__ void split3(float v, unsigned &h, unsigned &m, unsigned &l)
@@ -72,6 +59,13 @@ __device__ __forceinline__ void split3(float v, unsigned &h, unsigned &m, unsign
     l = bf16_rn(r2);
 }
 
+__device__ __forceinline__ uint4 a_vec(float v)    // [h,h,h,m,m,m,l,l]
+{
+    unsigned h, m, l;
+    split3(v, h, m, l);
+    return make_uint4(h | (h << 16), h | (m << 16), m | (m << 16), l | (l << 16));
+}
+
 __device__ __forceinline__ uint4 b_vec(float v)    // [h,m,l,h,m,l,h,m]
 {
     unsigned h, m, l;
@@ -79,11 +73,30 @@ __device__ __forceinline__ uint4 b_vec(float v)    // [h,m,l,h,m,l,h,m]
     return make_uint4(h | (m << 16), l | (h << 16), m | (l << 16), h | (m << 16));
 }
 
+// ---------------------------------------------------------------------------
+// Pre-split path (large launches): the four operand vectors of every target are written
+// once (64 B per target, planes X|Y|Z|T of [B][ntp] rows, ntp = nt rounded up to 128 with
+// padding rows that can never win) and the filter kernel streams them into LDS with
+// global_load_lds_dwordx4, no VGPRs or VALU on the way.  Without it every query block
+// re-derives the vectors of the targets it stages (~50 VALU ops per target).
+struct SplitJob {
+    const float *src;     // targets [B, n, 3]
+    uint4 *out;           // [B][4][np]
+    float *tmax;          // per-block max |t'|^2 [B][bpb]
+    int n, np, bpb, block_begin;
+};
+
+struct SplitArgs {
+    SplitJob job[2];
+    int njobs;
+    const float *centre;  // direction-0 targets [B, cn, 3]
+    int cn;
+};
+
 __global__ __launch_bounds__(kBlock) void nn_split_kernel(SplitArgs a)
 {
     __shared__ float s_red[kWavesPerBlock];
-    int j = 0;
-    while (j + 1 < a.njobs && (int)blockIdx.x >= a.job[j + 1].block_begin) j++;
+    const int j = (a.njobs > 1 && (int)blockIdx.x >= a.job[1].block_begin) ? 1 : 0;
     const SplitJob &J = a.job[j];
     const int local = blockIdx.x - J.block_begin;
     const int batch = local / J.bpb, blk = local % J.bpb;
@@ -91,37 +104,31 @@ __global__ __launch_bounds__(kBlock) void nn_split_kernel(SplitArgs a)
     const float *c = a.centre + (size_t)batch * a.cn * 3;
     const float cx = c[0], cy = c[1], cz = c[2];
     float tt = 0.0f;
-    if (i < J.n) {
-        const float *p = J.src + ((size_t)batch * J.n + i) * 3;
-        const float x = p[0] - cx, y = p[1] - cy, z = p[2] - cz;
-        tt = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
-        if (J.kind == 0) {
-            uint2 *o = (uint2 *)J.out + (size_t)batch * 3 * J.n + i;
-            unsigned xh, xm, xl, yh, ym, yl, zh, zm, zl, th, tm, tl;
-            split3(-2.0f * x, xh, xm, xl);
-            split3(-2.0f * y, yh, ym, yl);
-            split3(-2.0f * z, zh, zm, zl);
+    if (i < J.np) {
+        uint4 X = make_uint4(0u, 0u, 0u, 0u), Y = X, Z = X, W = make_uint4(0x7f80u, 0u, 0u, 0u);   // padding row
+        if (i < J.n) {
+            const float *p = J.src + ((size_t)batch * J.n + i) * 3;
+            const float x = p[0] - cx, y = p[1] - cy, z = p[2] - cz;
+            tt = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
+            unsigned th, tm, tl;
             split3(tt, th, tm, tl);
-            o[0] = make_uint2(xh | (xm << 16), xl | (yh << 16));
-            o[(size_t)J.n] = make_uint2(ym | (yl << 16), zh | (zm << 16));
-            o[(size_t)2 * J.n] = make_uint2(zl | (th << 16), tm | (tl << 16));
-        } else {
-            uint4 *o = (uint4 *)J.out + (size_t)batch * 3 * J.n + i;
-            o[0] = b_vec(x);
-            o[(size_t)J.n] = b_vec(y);
-            o[(size_t)2 * J.n] = b_vec(z);
-            J.aux[(size_t)batch * J.n + i] = tt;
+            X = a_vec(-2.0f * x);
+            Y = a_vec(-2.0f * y);
+            Z = a_vec(-2.0f * z);
+            W = make_uint4(th | (tm << 16), tl, 0u, 0u);
         }
+        uint4 *o = J.out + (size_t)batch * 4 * J.np + i;
+        o[0] = X;
+        o[(size_t)J.np] = Y;
+        o[(size_t)2 * J.np] = Z;
+        o[(size_t)3 * J.np] = W;
     }
-    if (J.kind == 0) {
-        float m = tt;
+    float m = tt;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if ((threadIdx.x & (kWave - 1)) == 0) s_red[threadIdx.x >> 6] = m;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            J.aux[(size_t)batch * J.bpb + blk] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    }
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & (kWave - 1)) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) J.tmax[(size_t)batch * J.bpb + blk] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
 }
 
 // ---------------------------------------------------------------------------
@@ -138,11 +145,13 @@ __device__ __forceinline__ float min16(float m, const f32x16 &c)
 // LDS port -- 128 B/clk/CU -- would cap Q = 1 at the MFMA rate of ONE query tile).
 // U = target tiles per bookkeeping unit, NL = candidate lists per lane (units are
 // dealt round-robin to the lists).
-template <int Q, int U, int NL, int FMA>
+template <int Q, int U, int NL, int FMA, int PRE>
 __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
 {
     constexpr int kC = 32 * U;
-    __shared__ uint4 plane[4][kBTile];
+    constexpr int kRows = kBTile + 64;          // + two spare tiles: the pipeline fetches two tiles ahead
+    __shared__ uint4 plane[PRE ? 2 : 1][4][kRows];   // pre-split path: double buffered, filled by LDS-DMA
+    const uint4 *pb = &plane[0][0][0];          // buffer holding the current LDS tile
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -158,14 +167,14 @@ __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
     const int nq = D.nq, nt = D.nt;
     const float *__restrict__ Qp = D.q + (size_t)batch * nq * 3;
     const float *__restrict__ T = D.t + (size_t)batch * nt * 3;
-    const uint2 *__restrict__ AR = (const uint2 *)D.arec + (size_t)batch * 3 * nt;
-    const uint4 *__restrict__ BR = D.brec + (size_t)batch * 3 * nq;
+    // both clouds are centred on the first point of the direction-0 target cloud
+    const float *cptr = a.dir[0].t + (size_t)batch * a.dir[0].nt * 3;
+    const float cx = cptr[0], cy = cptr[1], cz = cptr[2];
 
     const int k_begin = slice * a.slice_len;
     int k_end = k_begin + a.slice_len;
     if (k_end > nt) k_end = nt;
 
-    float qx[Q], qy[Q], qz[Q], qq[Q];
     bf16x8 b0[Q], b1[Q];
     Top3 lst[Q][NL];
     const int q0 = (qb * kWavesPerBlock + wave) * (32 * Q) + col;
@@ -173,135 +182,182 @@ __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
     for (int r = 0; r < Q; r++) {
         int j = q0 + r * 32;
         if (j >= nq) j = nq - 1;
-        qx[r] = Qp[(size_t)j * 3 + 0];
-        qy[r] = Qp[(size_t)j * 3 + 1];
-        qz[r] = Qp[(size_t)j * 3 + 2];
-        qq[r] = D.qqv[(size_t)batch * nq + j];
-        const uint4 v0 = BR[(size_t)half * nq + j];                       // X (lanes < 32) | Y
-        const uint4 v1 = half ? make_uint4(0x3f803f80u, 0x00003f80u, 0u, 0u) : BR[(size_t)2 * nq + j];   // Z | ones
+        // lanes < 32 carry the X and Z vectors of the query, lanes >= 32 Y and the ones
+        const float c0 = Qp[(size_t)j * 3 + half] - (half ? cy : cx);
+        const float c1 = Qp[(size_t)j * 3 + 2] - cz;
+        const uint4 v0 = b_vec(c0);
+        const uint4 v1 = half ? make_uint4(0x3f803f80u, 0x00003f80u, 0u, 0u) : b_vec(c1);
         b0[r] = __builtin_bit_cast(bf16x8, v0);
         b1[r] = __builtin_bit_cast(bf16x8, v1);
 #pragma unroll
         for (int n = 0; n < NL; n++) top3_init(lst[r][n]);
     }
 
-    // One accumulator chain per query tile, all on the same 32-target tile; the rows of
-    // the next tile are in A0/A1 while the current tile's accumulators are reduced.
+    // One accumulator chain per query tile, all on the same 32-target tile.  The rows of
+    // the next two tiles are in registers (set p = tile parity) while the current
+    // tile's accumulators are reduced.
     f32x16 acc[Q];
-    uint4 A0, A1;
-    auto fetch = [&](int row) {
-        A0 = plane[half][row + col];
-        A1 = plane[2 + half][row + col];
+    uint4 A0[2], A1[2];
+    auto fetch = [&](int p, int row) {
+        A0[p] = pb[half * kRows + row + col];
+        A1[p] = pb[(2 + half) * kRows + row + col];
     };
-    auto m1 = [&](int r) {
+    auto m1 = [&](int p, int r) {
         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0), b0[r], z, 0, 0, 0);
+        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0[p]), b0[r], z, 0, 0, 0);
     };
-    auto m2 = [&](int r) {
-        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1), b1[r], acc[r], 0, 0, 0);
+    auto m2 = [&](int p, int r) {
+        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1[p]), b1[r], acc[r], 0, 0, 0);
     };
-    // One target tile: the accumulators hold tile `row`; while they are folded into the
-    // running unit minima m[] the chains of tile row + 32 are started, skewed by one slot
-    // so that the second instruction of a chain issues one slot (8 v_min3 + one MFMA)
-    // after the first and no MFMA waits on its predecessor:
-    //   slot r:  4 min3(acc[r]) | M2(r-1) | 4 min3(acc[r]) | M1(r)
-    auto step = [&](int row, int tn_pad, float (&m)[Q]) {
-        const bool more = row + 32 < tn_pad;
+    // One target tile (index parity p): the accumulators hold tile `row`; while they are
+    // folded into the running unit minima m[] the chains of tile row + 32 (set p^1) are
+    // started, skewed by one slot so that no MFMA waits on its predecessor:
+    //   slot r:  8 v_min3(acc[r]) | M2(r-1) | M1(r)
+    // and the rows of tile row + 64 are fetched into set p.  No branches: the last tile
+    // of an LDS tile uses `last` (reduce only); fetches past the end read the spare rows.
+    auto step = [&](auto p_tag, auto last_tag, int row, float (&m)[Q][4]) {
+        constexpr int p = decltype(p_tag)::value;
+        constexpr bool last = decltype(last_tag)::value;
+        if (!last) fetch(p, row + 64);
 #pragma unroll
         for (int r = 0; r < Q; r++) {
             const f32x16 &c = acc[r];
             __builtin_amdgcn_sched_barrier(0);
+            // four independent minimum chains: back-to-back dependent VALU ops of one wave
+            // do not issue at rate
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m[r]) : "v"(m[r]), "v"(c[e]), "v"(c[e + 1]));
+            for (int e = 0; e < 16; e += 2)
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m[r][(e >> 1) & 3]) : "v"(m[r][(e >> 1) & 3]), "v"(c[e]), "v"(c[e + 1]));
             __builtin_amdgcn_sched_barrier(0);
-            if (more && r > 0) m2(r - 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 8; e < 16; e += 2) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m[r]) : "v"(m[r]), "v"(c[e]), "v"(c[e + 1]));
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) m1(r);
+            if (!last) {
+                if (r > 0) m2(p ^ 1, r - 1);
+                m1(p ^ 1, r);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) {
-            m2(Q - 1);
-            if (row + 64 < tn_pad) fetch(row + 64);      // rows of the tile after next
-        }
+        if (!last) m2(p ^ 1, Q - 1);
     };
 
-    // pieces of the next tile, kBTile / kBlock targets per thread
+    // raw coordinates of the next LDS tile, kBTile / kBlock targets per thread
     constexpr int kPer = kBTile / kBlock;
-    uint2 pre[kPer][3];
+    float pre[kPer][3];
     auto prefetch = [&](int t0) {
 #pragma unroll
         for (int i = 0; i < kPer; i++) {
             int t = t0 + i * kBlock + threadIdx.x;
             t = t < nt ? t : nt - 1;
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) pre[i][pl] = AR[(size_t)pl * nt + t];
+            for (int k = 0; k < 3; k++) pre[i][k] = T[(size_t)t * 3 + k];
         }
     };
-    if (k_begin < k_end) prefetch(k_begin);
+    float tmax2 = 0.0f;
+    // pre-split path: wave w copies plane w of a tile, 64 rows (1 KiB) per instruction
+    const uint4 *__restrict__ AR = D.arec + ((size_t)batch * 4 + wave) * D.ntp;
+    auto dma = [&](int buf, int t0, int rows) {
+#pragma unroll
+        for (int i = 0; i < kBTile / 64; i++) {
+            if (i * 64 < rows)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(AR + t0 + i * 64 + lane),
+                                                 (__attribute__((address_space(3))) void *)&plane[buf][wave][i * 64], 16, 0, 0);
+        }
+    };
+    auto rows_of = [&](int t0) {
+        const int tn = min(kBTile, k_end - t0);
+        return (tn + kC - 1) / kC * kC;
+    };
+    if (PRE) {
+        if (k_begin < k_end) dma(0, k_begin, rows_of(k_begin));
+    } else if (k_begin < k_end) {
+        prefetch(k_begin);
+    }
+    int tile_i = 0;
     for (int t0 = k_begin; t0 < k_end && !(a.debug & 4); t0 += kBTile) {
         const int tn = min(kBTile, k_end - t0);
         const int tn_pad = (tn + kC - 1) / kC * kC;
-        __syncthreads();                 // every wave is done reading the previous tile
+        if (PRE) {
+            // this tile's DMAs (issued one tile ago) have landed; everyone is done with the other buffer
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            pb = &plane[tile_i & 1][0][0];
+            if (t0 + kBTile < k_end) dma((tile_i & 1) ^ 1, t0 + kBTile, rows_of(t0 + kBTile));
+            tile_i++;
+        } else if (!(a.debug & 64)) {
+            __syncthreads();                 // every wave is done reading the previous tile
+        }
 #pragma unroll
-        for (int i = 0; i < kPer; i++) {
+        for (int i = 0; i < (PRE ? 0 : kPer); i++) {
             const int t = i * kBlock + threadIdx.x;
-            if (t < tn_pad) {
-                const uint2 p0 = pre[i][0], p1 = pre[i][1], p2 = pre[i][2];
-                uint4 X, Y, Z, W;
-                X.x = __builtin_amdgcn_perm(p0.x, p0.x, 0x01000100u);     // xh xh
-                X.y = p0.x;                                               // xh xm
-                X.z = __builtin_amdgcn_perm(p0.x, p0.x, 0x03020302u);     // xm xm
-                X.w = __builtin_amdgcn_perm(p0.y, p0.y, 0x01000100u);     // xl xl
-                Y.x = __builtin_amdgcn_perm(p0.y, p0.y, 0x03020302u);     // yh yh
-                Y.y = __builtin_amdgcn_perm(p0.y, p1.x, 0x01000706u);     // yh ym
-                Y.z = __builtin_amdgcn_perm(p1.x, p1.x, 0x01000100u);     // ym ym
-                Y.w = __builtin_amdgcn_perm(p1.x, p1.x, 0x03020302u);     // yl yl
-                Z.x = __builtin_amdgcn_perm(p1.y, p1.y, 0x01000100u);     // zh zh
-                Z.y = p1.y;                                               // zh zm
-                Z.z = __builtin_amdgcn_perm(p1.y, p1.y, 0x03020302u);     // zm zm
-                Z.w = __builtin_amdgcn_perm(p2.x, p2.x, 0x01000100u);     // zl zl
-                W.x = __builtin_amdgcn_perm(p2.x, p2.y, 0x01000706u);     // th tm
-                W.y = p2.y >> 16;                                         // tl 0
-                W.z = 0u;
-                W.w = 0u;
+            if (t < tn_pad && !(a.debug & 64)) {
+                // centre, |t'|^2, three bf16 pieces of -2x', -2y', -2z', |t'|^2, the four operand vectors
+                const float x = pre[i][0] - cx, y = pre[i][1] - cy, z = pre[i][2] - cz;
+                const float tt = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
+                unsigned th, tm, tl;
+                split3(tt, th, tm, tl);
+                uint4 X = a_vec(-2.0f * x), Y = a_vec(-2.0f * y), Z = a_vec(-2.0f * z);
+                uint4 W = make_uint4(th | (tm << 16), tl, 0u, 0u);
                 if (t >= tn) {
                     // padding: |t'|^2 = +inf (bf16 0x7f80) x 1 never wins, the other terms are 0
                     X = Y = Z = make_uint4(0u, 0u, 0u, 0u);
                     W = make_uint4(0x7f80u, 0u, 0u, 0u);
+                } else {
+                    tmax2 = fmaxf(tmax2, tt);
                 }
-                plane[0][t] = X;
-                plane[1][t] = Y;
-                plane[2][t] = Z;
-                plane[3][t] = W;
+                plane[0][0][t] = X;
+                plane[0][1][t] = Y;
+                plane[0][2][t] = Z;
+                plane[0][3][t] = W;
             }
         }
-        if (t0 + kBTile < k_end) prefetch(t0 + kBTile);
-        __syncthreads();
-        // prologue of the LDS tile: chains of target tile 0, rows of tile 1
-        fetch(0);
+        if (!PRE) {
+            if (t0 + kBTile < k_end && !(a.debug & 64)) prefetch(t0 + kBTile);
+            if (!(a.debug & 64)) __syncthreads();
+        }
+        // prologue of the LDS tile: chains of target tile 0, rows of tiles 0 and 1
+        fetch(0, 0);
+        fetch(1, 32);
 #pragma unroll
-        for (int r = 0; r < Q; r++) m1(r);
+        for (int r = 0; r < Q; r++) m1(0, r);
 #pragma unroll
-        for (int r = 0; r < Q; r++) m2(r);
-        if (32 < tn_pad) fetch(32);
+        for (int r = 0; r < Q; r++) m2(0, r);
         for (int rb0 = 0; rb0 < tn_pad; rb0 += NL * kC) {
 #pragma unroll
             for (int n = 0; n < NL; n++) {
                 const int rb = rb0 + n * kC;
                 if (rb < tn_pad) {
-                    float m[Q];
+                    float m[Q][4];
 #pragma unroll
-                    for (int r = 0; r < Q; r++) m[r] = __builtin_inff();
+                    for (int r = 0; r < Q; r++) m[r][0] = m[r][1] = m[r][2] = m[r][3] = __builtin_inff();
 #pragma unroll
-                    for (int g = 0; g < U; g++) step(rb + 32 * g, tn_pad, m);
+                    for (int g = 0; g < U - 1; g++) {
+                        if (g & 1) step(std::integral_constant<int, 1>{}, std::false_type{}, rb + 32 * g, m);
+                        else step(std::integral_constant<int, 0>{}, std::false_type{}, rb + 32 * g, m);
+                    }
+                    // U is even: the last tile of a unit has parity 1
+                    if (rb + kC < tn_pad) step(std::integral_constant<int, 1>{}, std::false_type{}, rb + kC - 32, m);
+                    else step(std::integral_constant<int, 1>{}, std::true_type{}, rb + kC - 32, m);
 #pragma unroll
-                    for (int r = 0; r < Q; r++) top3_insert(lst[r][n], m[r], t0 + rb);
+                    for (int r = 0; r < Q; r++) {
+                        float mm;
+                        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(mm) : "v"(m[r][0]), "v"(m[r][1]), "v"(m[r][2]));
+                        asm("v_min_f32 %0, %1, %2" : "=v"(mm) : "v"(mm), "v"(m[r][3]));
+                        if (!(a.debug & 128)) top3_insert(lst[r][n], mm, t0 + rb + half);      // bit 0: which 16 rows of each tile
+                        else lst[r][n].a1 = mm;
+                    }
                 }
             }
         }
+    }
+
+    // max |t'|^2 of the slice, for the bound in nn_finish_kernel (every query block sees
+    // the same targets: the first one publishes)
+    if (!PRE && qb == 0) {
+        __shared__ float s_red[kWavesPerBlock];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, o));
+        if (lane == 0) s_red[wave] = tmax2;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            D.tmaxp[(size_t)batch * D.slices + slice] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     }
 
     // Publish the lists: the two lane halves folded, NL lists of three 8-byte words
@@ -329,6 +385,52 @@ __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
     }
 }
 
+// Exact (reference arithmetic) minimum and first index over the 16 targets
+// base + 8i + 4h + (0..3), i = 0..3, of a 32-target tile: the rows whose approximate
+// values lane half h of the filter held.  Positions past the end are clamped to the
+// last target.
+template <int FMA>
+__device__ __forceinline__ void rescan_half(const float *__restrict__ T, int nt, int base, int h, float qx, float qy,
+                                            float qz, float &bd, int &bi)
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    bd = __builtin_inff();
+    bi = base;
+    if (base + 32 <= nt) {
+        f4u v[12];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const f4u *tp = (const f4u *)(T + (size_t)(base + 8 * i + 4 * h) * 3);
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[i * 3 + k] = tp[k];
+        }
+#pragma unroll
+        for (int i = 3; i >= 0; i--) {
+            const float f[12] = {v[i * 3].x, v[i * 3].y, v[i * 3].z, v[i * 3].w, v[i * 3 + 1].x, v[i * 3 + 1].y,
+                                 v[i * 3 + 1].z, v[i * 3 + 1].w, v[i * 3 + 2].x, v[i * 3 + 2].y, v[i * 3 + 2].z, v[i * 3 + 2].w};
+#pragma unroll
+            for (int c = 3; c >= 0; c--) {
+                const float dd = sqdist<FMA>(f[c * 3 + 0] - qx, f[c * 3 + 1] - qy, f[c * 3 + 2] - qz);
+                const bool le = dd <= bd;
+                bd = le ? dd : bd;
+                bi = le ? base + 8 * i + 4 * h + c : bi;
+            }
+        }
+    } else {
+        for (int i = 3; i >= 0; i--) {
+            for (int c = 3; c >= 0; c--) {
+                int kk = base + 8 * i + 4 * h + c;
+                kk = kk < nt ? kk : nt - 1;
+                const float *tp = T + (size_t)kk * 3;
+                const float dd = sqdist<FMA>(tp[0] - qx, tp[1] - qy, tp[2] - qz);
+                const bool le = dd <= bd;
+                bd = le ? dd : bd;
+                bi = le ? kk : bi;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Second launch: one block per 64 queries (4 threads per query).  Gathers the query's
 // lists, derives the acceptance threshold tau from the smallest approximate value,
@@ -347,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     __shared__ float s_a[4][kFQ];
     __shared__ int s_qflag[kFQ];
     __shared__ int s_flagged[kFQ];
-    __shared__ unsigned s_work[kFWork];          // query slot << 22 | first target / 32
+    __shared__ unsigned s_work[kFWork];          // query slot << 22 | tile (first target / 32) << 1 | lane half
     __shared__ float s_red[kWavesPerBlock];
     __shared__ int s_fi[kWavesPerBlock];
     __shared__ int s_misc[2];                    // work items, flagged queries
@@ -389,12 +491,11 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
 #pragma unroll
     for (int k = 0; k < kMaxLists / 4; k++) amin = fminf(amin, __uint_as_float((unsigned)(w0[k] >> 32)));
     s_a[part][ql] = amin;
-    // max |t'|^2 over the whole target cloud (per-block maxima of the split kernel)
+    // max |t'|^2 over the whole target cloud (per-slice maxima of the filter kernel)
     float tmax2 = 0.0f;
     {
-        const int nblk = (nt + kBlock - 1) / kBlock;
-        const float *tp = D.tmaxp + (size_t)batch * nblk;
-        for (int i = threadIdx.x; i < nblk; i += kBlock) tmax2 = fmaxf(tmax2, tp[i]);
+        const float *tp = D.tmaxp + (size_t)batch * D.ntmax;
+        for (int i = threadIdx.x; i < D.ntmax; i += kBlock) tmax2 = fmaxf(tmax2, tp[i]);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, o));
         if (lane == 0) s_red[wave] = tmax2;
@@ -408,7 +509,12 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     __syncthreads();
     tmax2 = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     const float abest = fminf(fminf(s_a[0][ql], s_a[1][ql]), fminf(s_a[2][ql], s_a[3][ql]));
-    const float qq = D.qqv[(size_t)batch * nq + j];
+    float qq;
+    {
+        const float *cptr = a.dir[0].t + (size_t)batch * a.dir[0].nt * 3;
+        const float x = Qp[(size_t)j * 3 + 0] - cptr[0], y = Qp[(size_t)j * 3 + 1] - cptr[1], z = Qp[(size_t)j * 3 + 2] - cptr[2];
+        qq = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
+    }
     float tau = nn_tau(abest, qq, tmax2, kQT16, kTT16);
     if (a.debug & 16) tau = __builtin_inff();          // test hook: every listed tile is evaluated
     bool flag = (a.debug & 8) != 0 || !(tau == tau);   // test hook / non-finite input: exhaustive pass
@@ -420,11 +526,13 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
             if (c < 0) {
                 flag = true;
             } else if (live) {
-                const int left = (nt - c + 31) >> 5;
+                // c = first target of the unit | lane half: rows 8i + 4h + (0..3) of each tile
+                const int h = c & 1, c0 = c & ~1;
+                const int left = (nt - c0 + 31) >> 5;
                 const int n2 = left < upieces ? left : upieces;
                 const int w = atomicAdd(&s_misc[0], n2);
                 if (w + n2 <= kFWork) {
-                    for (int k = 0; k < n2; k++) s_work[w + k] = ((unsigned)ql << 22) | (unsigned)((c >> 5) + k);
+                    for (int k = 0; k < n2; k++) s_work[w + k] = ((unsigned)ql << 22) | (unsigned)((((c0 >> 5) + k) << 1) | h);
                 } else {
                     flag = true;
                 }
@@ -455,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         const float4 qv = s_q[slot];
         float dd;
         int ii;
-        rescan_chunk<FMA, 32>(T, nt, (int)(it & 0x3fffffu) << 5, qv.x, qv.y, qv.z, dd, ii);
+        rescan_half<FMA>(T, nt, (int)((it & 0x3fffffu) >> 1) << 5, (int)(it & 1u), qv.x, qv.y, qv.z, dd, ii);
         atomicMin(&s_best[slot], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii);
     }
     __syncthreads();
@@ -473,80 +581,75 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Qp, T, nt, s_flagged[fidx], od, oi, s_red, s_fi);
 }
 
-template <int Q, int U, int NL>
-static void launch_main(const NNArgs &a, int blocks, hipStream_t st)
+template <int Q, int U, int NL, int PRE>
+static void launch_main2(const NNArgs &a, int blocks, hipStream_t st)
 {
     if (arith_mode() != 0)
-        hipLaunchKernelGGL((nn_bf16_kernel<Q, U, NL, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
+        hipLaunchKernelGGL((nn_bf16_kernel<Q, U, NL, 1, PRE>), dim3(blocks), dim3(kBlock), 0, st, a);
     else
-        hipLaunchKernelGGL((nn_bf16_kernel<Q, U, NL, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
+        hipLaunchKernelGGL((nn_bf16_kernel<Q, U, NL, 0, PRE>), dim3(blocks), dim3(kBlock), 0, st, a);
 }
 
-// Writes the split records of every direction's queries and targets (workspace slot 9),
-// then launches the filter.  q / nl as chosen by the planner in chamfer.hip.
-int launch_nn_bf16(NNArgs &a, int q, int u, int nl, long long total_blocks, hipStream_t st)
+template <int Q, int U, int NL>
+static void launch_main(const NNArgs &a, int blocks, int pre, hipStream_t st)
 {
-    SplitArgs sa{};
-    sa.centre = a.dir[0].t;
-    sa.cn = a.dir[0].nt;
-    size_t bytes = 0;
+    if (pre) launch_main2<Q, U, NL, 1>(a, blocks, st);
+    else launch_main2<Q, U, NL, 0>(a, blocks, st);
+}
+
+// Launches (the target split when `pre`,) the filter and the finish kernel.  q / nl / pre as
+// chosen by the planner in chamfer.hip.
+int launch_nn_bf16(NNArgs &a, int q, int pre, int nl, long long total_blocks, hipStream_t st)
+{
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    size_t off_a[2], off_t[2], off_b[2], off_q[2];
+    size_t bytes = 0;
+    size_t off_t[2], off_a[2] = {0, 0};
     for (int d = 0; d < a.ndir; d++) {
-        const NNDir &D = a.dir[d];
-        off_a[d] = bytes; bytes = align(bytes + (size_t)a.b * 3 * D.nt * sizeof(uint2));
-        off_t[d] = bytes; bytes = align(bytes + (size_t)a.b * ceil_div(D.nt, kBlock) * sizeof(float));
-        off_b[d] = bytes; bytes = align(bytes + (size_t)a.b * 3 * D.nq * sizeof(uint4));
-        off_q[d] = bytes; bytes = align(bytes + (size_t)a.b * D.nq * sizeof(float));
+        NNDir &D = a.dir[d];
+        D.ntp = (D.nt + 127) / 128 * 128;
+        D.ntmax = pre ? ceil_div(D.ntp, kBlock) : D.slices;
+        off_t[d] = bytes;
+        bytes = align(bytes + (size_t)a.b * D.ntmax * sizeof(float));
+        if (pre) {
+            off_a[d] = bytes;
+            bytes = align(bytes + (size_t)a.b * 4 * D.ntp * sizeof(uint4));
+        }
     }
     char *ws = (char *)workspace(9, bytes, st);
     if (!ws) return 0;
-    long long sb = 0;
     for (int d = 0; d < a.ndir; d++) {
-        NNDir &D = a.dir[d];
-        D.arec = (const uint4 *)(ws + off_a[d]);
-        D.tmaxp = (const float *)(ws + off_t[d]);
-        D.brec = (const uint4 *)(ws + off_b[d]);
-        D.qqv = (const float *)(ws + off_q[d]);
-        SplitJob &ja = sa.job[sa.njobs++];
-        ja.src = D.t; ja.out = ws + off_a[d]; ja.aux = (float *)(ws + off_t[d]);
-        ja.n = D.nt; ja.kind = 0; ja.bpb = ceil_div(D.nt, kBlock); ja.block_begin = (int)sb;
-        sb += (long long)a.b * ja.bpb;
-        SplitJob &jb = sa.job[sa.njobs++];
-        jb.src = D.q; jb.out = ws + off_b[d]; jb.aux = (float *)(ws + off_q[d]);
-        jb.n = D.nq; jb.kind = 1; jb.bpb = ceil_div(D.nq, kBlock); jb.block_begin = (int)sb;
-        sb += (long long)a.b * jb.bpb;
+        a.dir[d].tmaxp = (float *)(ws + off_t[d]);
+        a.dir[d].arec = (const uint4 *)(ws + off_a[d]);
     }
-    if (sb > 0x7fffffffLL) {
-        set_error("chamfer: problem too large for one launch");
-        return 0;
-    }
-    hipLaunchKernelGGL(nn_split_kernel, dim3((unsigned)sb), dim3(kBlock), 0, st, sa);
-    const int blocks = (int)total_blocks;
-    if (u == 2) {
-        if (q == 4) {
-            if (nl == 2) launch_main<4, 2, 2>(a, blocks, st);
-            else launch_main<4, 2, 1>(a, blocks, st);
-        } else if (q == 2) {
-            if (nl == 4) launch_main<2, 2, 4>(a, blocks, st);
-            else if (nl == 2) launch_main<2, 2, 2>(a, blocks, st);
-            else launch_main<2, 2, 1>(a, blocks, st);
-        } else {
-            if (nl == 4) launch_main<1, 2, 4>(a, blocks, st);
-            else if (nl == 2) launch_main<1, 2, 2>(a, blocks, st);
-            else launch_main<1, 2, 1>(a, blocks, st);
+    if (pre) {
+        SplitArgs sa{};
+        sa.centre = a.dir[0].t;
+        sa.cn = a.dir[0].nt;
+        long long sb = 0;
+        for (int d = 0; d < a.ndir; d++) {
+            SplitJob &J = sa.job[sa.njobs++];
+            J.src = a.dir[d].t; J.out = (uint4 *)(ws + off_a[d]); J.tmax = a.dir[d].tmaxp;
+            J.n = a.dir[d].nt; J.np = a.dir[d].ntp; J.bpb = a.dir[d].ntmax; J.block_begin = (int)sb;
+            sb += (long long)a.b * J.bpb;
         }
-    } else if (q == 4) {
-        if (nl == 2) launch_main<4, 4, 2>(a, blocks, st);
-        else launch_main<4, 4, 1>(a, blocks, st);
+        if (sb > 0x7fffffffLL) {
+            set_error("chamfer: problem too large for one launch");
+            return 0;
+        }
+        hipLaunchKernelGGL(nn_split_kernel, dim3((unsigned)sb), dim3(kBlock), 0, st, sa);
+    }
+    const int blocks = (int)total_blocks;
+    if (q == 4) {
+        if (nl == 2) launch_main<4, 4, 2>(a, blocks, pre, st);
+        else launch_main<4, 4, 1>(a, blocks, pre, st);
     } else if (q == 2) {
-        if (nl == 4) launch_main<2, 4, 4>(a, blocks, st);
-        else if (nl == 2) launch_main<2, 4, 2>(a, blocks, st);
-        else launch_main<2, 4, 1>(a, blocks, st);
+        if (nl == 4) launch_main<2, 4, 4>(a, blocks, pre, st);
+        else if (nl == 2) launch_main<2, 4, 2>(a, blocks, pre, st);
+        else launch_main<2, 4, 1>(a, blocks, pre, st);
     } else {
-        if (nl == 4) launch_main<1, 4, 4>(a, blocks, st);
-        else if (nl == 2) launch_main<1, 4, 2>(a, blocks, st);
-        else launch_main<1, 4, 1>(a, blocks, st);
+        if (nl == 4) launch_main<1, 4, 4>(a, blocks, pre, st);
+        else if (nl == 2) launch_main<1, 4, 2>(a, blocks, pre, st);
+        else launch_main<1, 4, 1>(a, blocks, pre, st);
     }
     if (!check(hipGetLastError(), "nn_bf16_kernel launch")) return 0;
     long long fb = 0;
@@ -559,9 +662,9 @@ int launch_nn_bf16(NNArgs &a, int q, int u, int nl, long long total_blocks, hipS
         return 0;
     }
     if (arith_mode() != 0)
-        hipLaunchKernelGGL((nn_finish_kernel<1>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, u);
+        hipLaunchKernelGGL((nn_finish_kernel<1>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, 4);
     else
-        hipLaunchKernelGGL((nn_finish_kernel<0>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, u);
+        hipLaunchKernelGGL((nn_finish_kernel<0>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, 4);
     return check(hipGetLastError(), "nn_finish_kernel launch") ? 1 : 0;
 }
 
