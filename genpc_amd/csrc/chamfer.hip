@@ -603,7 +603,7 @@ __global__ __launch_bounds__(kBlock) void chamfer_grad_kernel(int b, int n, cons
 struct NNConfig {
     int r;                // VALU path, queries per lane: 0 = pick, else 2 or 4
     int blocks_per_cu;    // occupancy target used to pick the slice count
-    int mfma;             // 2: split-bf16 MFMA filter (default), 1: fp32 MFMA filter, 0: VALU path
+    int mfma;             // 3: two-piece f16 MFMA filter (default), 2: three-piece bf16, 1: fp32 MFMA filter, 0: VALU path
     int q;                // MFMA path, 32-query tiles per wave: 0 = pick, else 1 or 2
     int u;                // MFMA path, tiles per bookkeeping unit: 0 = pick, else 1 or 2
 };
@@ -612,9 +612,9 @@ struct NNConfig {
 static NNConfig nn_config()
 {
     static NNConfig c = [] {
-        NNConfig k{0, 4, 2, 0, 0};
+        NNConfig k{0, 4, 3, 0, 0};
         if (const char *e = getenv("GENPC_NN_R")) k.r = atoi(e);
-        if (const char *e = getenv("GENPC_NN_PATH")) k.mfma = (e[0] == 'v') ? 0 : (e[0] == 'm' ? 1 : 2);
+        if (const char *e = getenv("GENPC_NN_PATH")) k.mfma = (e[0] == 'v') ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'b' ? 2 : 3));
         if (const char *e = getenv("GENPC_NN_Q")) k.q = atoi(e);
         if (const char *e = getenv("GENPC_NN_U")) k.u = atoi(e);
         if (k.q != 1 && k.q != 2 && k.q != 4) k.q = 0;
@@ -672,6 +672,8 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     a.ndir = nd;
     if (nd == 0) return 1;
     int path = cfg.mfma;
+    const bool f16 = path == 3;      // same planning as the bf16 path, other kernel
+    if (f16) path = 2;
     if (path == 2 && nt_max >= (1 << 25)) path = 1;      // finish kernel packs tile indices in 21 bits
     // R = 4 (fewer LDS reads per pair, more independent chains per lane) when the query
     // blocks alone fill the chip; R = 2 otherwise: twice the blocks, half the per-wave
@@ -799,6 +801,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     }
     if (path == 2) {
         // pre-split targets + LDS-DMA (one more launch) once every target is staged by many blocks
+        if (f16) return launch_nn_f16(a, q, nl, tb, st);
         static const int pre_env = getenv("GENPC_NN_PRE") ? atoi(getenv("GENPC_NN_PRE")) : -1;
         const int pre = pre_env >= 0 ? pre_env : 0;      // measured: 13x16384^2 401+8 us vs 410 us, 1x16384^2 35+5 vs 36 -- does not pay
         return launch_nn_bf16(a, q, pre, nl, tb, st);

@@ -1,0 +1,305 @@
+// nn_f16.hip -- nearest-neighbour filter with ONE v_mfma_f32_32x32x16_f16 per 32x32 tile.
+//
+// Same filter-and-prove scheme as nn_bf16.hip (which needs two chained bf16
+// instructions per tile: three 8-bit pieces per operand, 27 products).  An f16 piece
+// carries 11 bits, so two pieces v = h + l (h = RN16(v), l = RN16(v - h), residual
+// <= 2^-22 |v|) and all four products per coordinate fit the K = 16 of a single
+// instruction:
+//     lanes  0..31 (k 0..7):   A = [xh,xh,xl,xl, yh,yh,yl,yl]   B = [qxh,qxl,qxh,qxl, qyh,qyl,qyh,qyl]
+//     lanes 32..63 (k 8..15):  A = [zh,zh,zl,zl, Th,Tl,0,0]     B = [qzh,qzl,qzh,qzl, 2^8,2^8,0,0]
+// with x.. the pieces of -2 s x', q.. of s q', T of s^2 |t'|^2 2^-8.  f16 has a narrow
+// exponent range, so each block scales by a power of two s (exact) that puts the largest
+// centred coordinate of ITS queries and ITS target slice in [2^10, 2^11): products stay
+// below 2^23, |t'|^2 s^2 2^-8 below 3 x 2^14, small coordinates may reach f16 subnormals,
+// which the instruction does not flush (tools/ubench_mfma_f16.hip) -- their absolute
+// error, <= 2^-25 in scaled units, is far below the bound.  The result s^2 (|t'|^2 -
+// 2 q'.t') is unscaled (two exact multiplications) when a unit minimum is recorded.
+//
+// Error bound, u = 2^-24, T = max |t'|: residuals 4u per operand -> 16u |q'|T on
+// -2 q'.t' and 4u T^2 on |t'|^2; the instruction's summation, measured at <= 3.1 u
+// sum|terms| (adversarial cancellation, profiles/r01_ubench_mfma_f16.txt), budgeted at
+// 6.5u (2|q'|T + T^2); three fp32 roundings each in |t'|^2 and |q'|^2; one unit on T^2
+// for subnormal pieces:  E1 = u (30 |q'| T + 15 T^2 + 3 |q'|^2).
+#include "nn.h"
+
+#include <stdlib.h>
+
+namespace genpc {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+constexpr int kHTile = 1024;           // targets per LDS tile: 2 planes x 16 B = 32 KiB
+constexpr double kQTh = 30.0, kTTh = 15.0;
+
+__device__ __forceinline__ unsigned f16_bits(float v) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v); }
+
+// v = h + l in f16 (v already scaled into range); returns h | l << 16
+__device__ __forceinline__ unsigned split2(float v)
+{
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+
+__device__ __forceinline__ unsigned dup_lo(unsigned v) { return __builtin_amdgcn_perm(v, v, 0x01000100u); }
+__device__ __forceinline__ unsigned dup_hi(unsigned v) { return __builtin_amdgcn_perm(v, v, 0x03020302u); }
+
+// largest power of two s with s * m < 2^11 (m > 0 finite), 1 otherwise
+__device__ __forceinline__ float scale_for(float m)
+{
+    if (!(m > 0.0f) || !(m < __builtin_inff())) return 1.0f;
+    const int e = __builtin_amdgcn_frexp_expf(m);       // m = f * 2^e, f in [0.5, 1)
+    return __builtin_ldexpf(1.0f, 11 - e);
+}
+
+// One block = one (direction, target slice, batch, 128*Q-query block) unit; wave w owns Q
+// tiles of 32 queries.  U = target tiles per bookkeeping unit, NL = candidate lists per lane.
+template <int Q, int U, int NL>
+__global__ __launch_bounds__(kBlock) void nn_f16_kernel(NNArgs a)
+{
+    constexpr int kC = 32 * U;
+    constexpr int kRows = kHTile + 64;          // + two spare tiles: the pipeline fetches two tiles ahead
+    __shared__ uint4 plane[2][kRows];
+    __shared__ float s_red[kWavesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    int bid = blockIdx.x;
+    const int d = (a.ndir > 1 && bid >= a.dir[1].block_begin) ? 1 : 0;
+    const NNDir &D = a.dir[d];
+    bid -= D.block_begin;
+    const int qb = bid % D.qblocks;
+    const int rest = bid / D.qblocks;
+    const int batch = rest % a.b;
+    const int slice = rest / a.b;
+
+    const int nq = D.nq, nt = D.nt;
+    const float *__restrict__ Qp = D.q + (size_t)batch * nq * 3;
+    const float *__restrict__ T = D.t + (size_t)batch * nt * 3;
+    // both clouds are centred on the first point of the direction-0 target cloud
+    const float *cptr = a.dir[0].t + (size_t)batch * a.dir[0].nt * 3;
+    const float cx = cptr[0], cy = cptr[1], cz = cptr[2];
+
+    const int k_begin = slice * a.slice_len;
+    int k_end = k_begin + a.slice_len;
+    if (k_end > nt) k_end = nt;
+
+    // centred queries of this lane; the block's largest |coordinate| over queries and slice
+    float qc0[Q], qc1[Q];
+    float mx = 0.0f;
+    const int q0 = (qb * kWavesPerBlock + wave) * (32 * Q) + col;
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+        int j = q0 + r * 32;
+        if (j >= nq) j = nq - 1;
+        // lanes < 32 carry x and y of the query, lanes >= 32 z
+        qc0[r] = Qp[(size_t)j * 3 + (half ? 2 : 0)] - (half ? cz : cx);
+        qc1[r] = half ? 0.0f : Qp[(size_t)j * 3 + 1] - cy;
+        mx = fmaxf(mx, fmaxf(fabsf(qc0[r]), fabsf(qc1[r])));
+    }
+    for (int t = k_begin + threadIdx.x; t < k_end; t += kBlock) {
+        const float *tp = T + (size_t)t * 3;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(tp[0] - cx), fabsf(tp[1] - cy)), fabsf(tp[2] - cz)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const float sc = scale_for(mx);             // NaN input: comparisons fail -> 1
+    const float isc = 1.0f / sc;                 // exact (power of two)
+    const float tsc = -2.0f * sc;
+
+    h16x8 bq[Q];
+    Top3 lst[Q][NL];
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+        const unsigned p0 = split2(qc0[r] * sc), p1 = split2(qc1[r] * sc);
+        // [h,l,h,l | h,l,h,l]; lanes >= 32: z pieces, then 2^8 twice (f16 0x5c00), zeros
+        const uint4 v = half ? make_uint4(p0, p0, 0x5c005c00u, 0u) : make_uint4(p0, p0, p1, p1);
+        bq[r] = __builtin_bit_cast(h16x8, v);
+#pragma unroll
+        for (int n = 0; n < NL; n++) top3_init(lst[r][n]);
+    }
+
+    // One accumulator per query tile, all on the same 32-target tile.  The rows of the next
+    // two tiles are in registers (set p = tile parity) while the current tile's
+    // accumulators are reduced.
+    f32x16 acc[Q];
+    uint4 A[2];
+    auto fetch = [&](int p, int row) { A[p] = plane[half][row + col]; };
+    auto mm = [&](int p, int r) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, A[p]), bq[r], z, 0, 0, 0);
+    };
+    // One target tile (index parity p): fold the accumulators of tile `row` into the running
+    // unit minima (four independent chains per query tile) and start tile row + 32 (set
+    // p^1): slot r = 8 v_min3(acc[r]) | MFMA(r).  No branches: the last tile of an LDS tile
+    // uses `last` (reduce only); fetches past the end read the spare rows.
+    auto step = [&](auto p_tag, auto last_tag, int row, float (&m)[Q][4]) {
+        constexpr int p = decltype(p_tag)::value;
+        constexpr bool last = decltype(last_tag)::value;
+        if (!last) fetch(p, row + 64);
+#pragma unroll
+        for (int r = 0; r < Q; r++) {
+            const f32x16 &c = acc[r];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 16; e += 2)
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m[r][(e >> 1) & 3]) : "v"(m[r][(e >> 1) & 3]), "v"(c[e]), "v"(c[e + 1]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last) mm(p ^ 1, r);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // raw coordinates of the next LDS tile, kHTile / kBlock targets per thread
+    constexpr int kPer = kHTile / kBlock;
+    float pre[kPer][3];
+    auto prefetch = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < kPer; i++) {
+            int t = t0 + i * kBlock + threadIdx.x;
+            t = t < nt ? t : nt - 1;
+#pragma unroll
+            for (int k = 0; k < 3; k++) pre[i][k] = T[(size_t)t * 3 + k];
+        }
+    };
+    float tmax2 = 0.0f;
+    if (k_begin < k_end) prefetch(k_begin);
+    for (int t0 = k_begin; t0 < k_end && !(a.debug & 4); t0 += kHTile) {
+        const int tn = min(kHTile, k_end - t0);
+        const int tn_pad = (tn + kC - 1) / kC * kC;
+        __syncthreads();                 // every wave is done reading the previous tile
+#pragma unroll
+        for (int i = 0; i < kPer; i++) {
+            const int t = i * kBlock + threadIdx.x;
+            if (t < tn_pad) {
+                // centre, scale, two f16 pieces of -2s x', -2s y', -2s z', s^2 |t'|^2 2^-8
+                const float x = pre[i][0] - cx, y = pre[i][1] - cy, z = pre[i][2] - cz;
+                const float xs = x * sc, ys = y * sc, zs = z * sc;
+                const float tts = __fmaf_rn(zs, zs, __fmaf_rn(ys, ys, __fmul_rn(xs, xs)));
+                const unsigned px = split2(x * tsc), py = split2(y * tsc), pz = split2(z * tsc);
+                const unsigned pt = split2(tts * 0.00390625f);
+                uint4 V0 = make_uint4(dup_lo(px), dup_hi(px), dup_lo(py), dup_hi(py));
+                uint4 V1 = make_uint4(dup_lo(pz), dup_hi(pz), pt, 0u);
+                if (t >= tn) {
+                    // padding: |t'|^2 = +inf (f16 0x7c00) x 2^8 never wins, the other terms are 0
+                    V0 = make_uint4(0u, 0u, 0u, 0u);
+                    V1 = make_uint4(0u, 0u, 0x7c00u, 0u);
+                } else {
+                    tmax2 = fmaxf(tmax2, __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
+                }
+                plane[0][t] = V0;
+                plane[1][t] = V1;
+            }
+        }
+        if (t0 + kHTile < k_end) prefetch(t0 + kHTile);
+        __syncthreads();
+        // prologue of the LDS tile: target tile 0, rows of tiles 0 and 1
+        fetch(0, 0);
+        fetch(1, 32);
+#pragma unroll
+        for (int r = 0; r < Q; r++) mm(0, r);
+        for (int rb0 = 0; rb0 < tn_pad; rb0 += NL * kC) {
+#pragma unroll
+            for (int n = 0; n < NL; n++) {
+                const int rb = rb0 + n * kC;
+                if (rb < tn_pad) {
+                    float m[Q][4];
+#pragma unroll
+                    for (int r = 0; r < Q; r++) m[r][0] = m[r][1] = m[r][2] = m[r][3] = __builtin_inff();
+#pragma unroll
+                    for (int g = 0; g < U - 1; g++) {
+                        if (g & 1) step(std::integral_constant<int, 1>{}, std::false_type{}, rb + 32 * g, m);
+                        else step(std::integral_constant<int, 0>{}, std::false_type{}, rb + 32 * g, m);
+                    }
+                    // U is even: the last tile of a unit has parity 1
+                    if (rb + kC < tn_pad) step(std::integral_constant<int, 1>{}, std::false_type{}, rb + kC - 32, m);
+                    else step(std::integral_constant<int, 1>{}, std::true_type{}, rb + kC - 32, m);
+#pragma unroll
+                    for (int r = 0; r < Q; r++) {
+                        float v;
+                        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(v) : "v"(m[r][0]), "v"(m[r][1]), "v"(m[r][2]));
+                        asm("v_min_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(m[r][3]));
+                        v = (v * isc) * isc;       // unscale: s^2 (|t'|^2 - 2 q'.t') -> |t'|^2 - 2 q'.t'
+                        top3_insert(lst[r][n], v, t0 + rb + half);      // bit 0: which 16 rows of each tile
+                    }
+                }
+            }
+        }
+    }
+
+    // max |t'|^2 of the slice, for the bound in nn_finish_kernel (every query block sees
+    // the same targets: the first one publishes)
+    if (qb == 0) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, o));
+        __syncthreads();
+        if (lane == 0) s_red[wave] = tmax2;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            D.tmaxp[(size_t)batch * D.slices + slice] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    }
+
+    // Publish the lists: the two lane halves folded, NL lists of three 8-byte words
+    // (a1,c1) (a2,c2) (a3,-) per query and slice, for nn_finish_kernel.
+    const size_t bnq = (size_t)a.b * nq;
+    unsigned long long *P = D.part + (size_t)batch * nq;
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+#pragma unroll
+        for (int n = 0; n < NL; n++) {
+            Top3 &f = lst[r][n];
+            const float o1 = __shfl_xor(f.a1, 32), o2 = __shfl_xor(f.a2, 32), o3 = __shfl_xor(f.a3, 32);
+            const int oc1 = __shfl_xor(f.c1, 32), oc2 = __shfl_xor(f.c2, 32);
+            top3_insert(f, o1, oc1);
+            top3_insert(f, o2, oc2);
+            top3_insert(f, o3, -1);
+            const int j = q0 + r * 32;
+            if (!half && j < nq) {
+                unsigned long long *p = P + (size_t)(slice * NL + n) * 3 * bnq + j;
+                p[0] = ((unsigned long long)__float_as_uint(f.a1) << 32) | (unsigned)f.c1;
+                p[bnq] = ((unsigned long long)__float_as_uint(f.a2) << 32) | (unsigned)f.c2;
+                p[2 * bnq] = (unsigned long long)__float_as_uint(f.a3) << 32;
+            }
+        }
+    }
+}
+
+template <int Q, int NL>
+static void launch_main(const NNArgs &a, int blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL>), dim3(blocks), dim3(kBlock), 0, st, a);
+}
+
+// Launches the filter and the finish kernel.  q / nl as chosen by the planner in chamfer.hip.
+int launch_nn_f16(NNArgs &a, int q, int nl, long long total_blocks, hipStream_t st)
+{
+    size_t bytes = 0;
+    size_t off_t[2];
+    for (int d = 0; d < a.ndir; d++) {
+        a.dir[d].ntmax = a.dir[d].slices;
+        off_t[d] = bytes;
+        bytes += ((size_t)a.b * a.dir[d].ntmax * sizeof(float) + 255) & ~(size_t)255;
+    }
+    char *ws = (char *)workspace(9, bytes, st);
+    if (!ws) return 0;
+    for (int d = 0; d < a.ndir; d++) a.dir[d].tmaxp = (float *)(ws + off_t[d]);
+    const int blocks = (int)total_blocks;
+    if (q == 4) {
+        if (nl == 2) launch_main<4, 2>(a, blocks, st);
+        else launch_main<4, 1>(a, blocks, st);
+    } else if (q == 2) {
+        if (nl == 4) launch_main<2, 4>(a, blocks, st);
+        else if (nl == 2) launch_main<2, 2>(a, blocks, st);
+        else launch_main<2, 1>(a, blocks, st);
+    } else {
+        if (nl == 4) launch_main<1, 4>(a, blocks, st);
+        else if (nl == 2) launch_main<1, 2>(a, blocks, st);
+        else launch_main<1, 1>(a, blocks, st);
+    }
+    if (!check(hipGetLastError(), "nn_f16_kernel launch")) return 0;
+    return launch_nn_finish(a, nl, 4, (float)kQTh, (float)kTTh, st);
+}
+
+}  // namespace genpc
