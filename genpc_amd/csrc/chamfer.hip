@@ -275,11 +275,12 @@ __device__ __forceinline__ bool nn_safe(float a_best, float a_rest, float qq, fl
 {
     const double u = 1.01 * 5.9604644775390625e-8;
     const double T = sqrt((double)tmax2), qn = sqrt((double)qq);
-    const double E1 = u * (8.0 * qn * T + 7.0 * T * T + 3.0 * (double)qq);
+    const double kSub = 64.0 * 1.401298464324817e-45;      // subnormal results round absolutely (see nn_tau)
+    const double E1 = u * (8.0 * qn * T + 7.0 * T * T + 3.0 * (double)qq) + kSub;
     const double eta = u * (qn + T);
     double up = (double)a_best + (double)qq + E1;
     up = sqrt(up > 0.0 ? up : 0.0) + eta;
-    up = up * up * (1.0 + 6.0 * u);
+    up = up * up * (1.0 + 6.0 * u) + kSub;
     double lo = (double)a_rest + (double)qq - E1;
     lo = sqrt(lo > 0.0 ? lo : 0.0) - eta;
     lo = lo > 0.0 ? lo : 0.0;
@@ -608,6 +609,9 @@ struct NNConfig {
     int u;                // MFMA path, tiles per bookkeeping unit: 0 = pick, else 1 or 2
 };
 
+// genpc_nn_tune() overrides (-1: use the environment / default)
+static int g_tune_path = -1, g_tune_hooks = -1;
+
 // Tunables; GENPC_NN_R / GENPC_NN_WPS override for experiments.
 static NNConfig nn_config()
 {
@@ -650,11 +654,12 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
 {
     // A direction with no queries or no targets does nothing (the reference's
     // loops do not execute, outputs keep the caller's zeros).
-    const NNConfig cfg = nn_config();
+    NNConfig cfg = nn_config();
+    if (g_tune_path >= 0) cfg.mfma = g_tune_path;
     NNArgs a{};
     a.b = b;
     static const int dbg = getenv("GENPC_NN_DEBUG") ? atoi(getenv("GENPC_NN_DEBUG")) : 0;
-    a.debug = dbg;
+    a.debug = g_tune_hooks >= 0 ? g_tune_hooks : dbg;
     const float *qs[2] = {q0, q1};
     const float *ts[2] = {t0, t1};
     float *ds[2] = {d0, d1};
@@ -817,6 +822,14 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
 }
 
 }  // namespace genpc
+
+GENPC_API int genpc_nn_tune(int path, int hooks)
+{
+    const int prev = genpc::g_tune_path >= 0 ? genpc::g_tune_path : genpc::nn_config().mfma;
+    if (path >= 0 && path <= 3) genpc::g_tune_path = path;
+    if (hooks >= 0) genpc::g_tune_hooks = hooks;
+    return prev;
+}
 
 GENPC_API int genpc_chamfer_forward(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1,
                                     int *idx1, float *dist2, int *idx2, void *stream)

@@ -167,11 +167,15 @@ __device__ __forceinline__ float nn_tau(float a_best, float qq, float tmax2, dou
 {
     const double u = 1.01 * 5.9604644775390625e-8;
     const double T = sqrt((double)tmax2), qn = sqrt((double)qq);
-    const double E1 = u * (kQT * qn * T + kTT * T * T + 3.0 * (double)qq);
+    // kSub: fp32 results below 2^-126 round to a multiple of 2^-149 instead of relatively
+    // (squared distances of clouds ~1e-19 across are subnormal); 64 such roundings of slack
+    // keep the bound valid there -- it then admits every tile and the queries go exhaustive.
+    const double kSub = 64.0 * 1.401298464324817e-45;
+    const double E1 = u * (kQT * qn * T + kTT * T * T + 3.0 * (double)qq) + kSub;
     const double eta = u * (qn + T);
     double up = (double)a_best + (double)qq + E1;
     up = sqrt(up > 0.0 ? up : 0.0) + eta;
-    up = up * up * (1.0 + 6.0 * u);                    // >= reference distance of the best target
+    up = up * up * (1.0 + 6.0 * u) + kSub;             // >= reference distance of the best target
     double r = sqrt(up / (1.0 - 6.0 * u)) + eta;       // a target with |q'-t'| above r is out
     const double tau = r * r - (double)qq + E1;
     // round up to float
@@ -182,6 +186,6 @@ __device__ __forceinline__ float nn_tau(float a_best, float qq, float tmax2, dou
 
 int launch_nn_bf16(NNArgs &a, int q, int pre, int nl, long long total_blocks, hipStream_t st);
 int launch_nn_f16(NNArgs &a, int q, int nl, long long total_blocks, hipStream_t st);
-int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, hipStream_t st);
+int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float t2min, hipStream_t st);
 
 }  // namespace genpc

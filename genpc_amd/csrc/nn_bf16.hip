@@ -442,7 +442,7 @@ constexpr int kFQ = 64;                // queries per finish block
 constexpr int kFWork = 2048;           // work-item capacity (64 queries x 32 pieces)
 
 template <int FMA>
-__global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int upieces, float kqt, float ktt)
+__global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int upieces, float kqt, float ktt, float t2min)
 {
     __shared__ unsigned long long s_best[kFQ];   // (distance bits << 32 | index): atomic min == (distance, first index)
     __shared__ float4 s_q[kFQ];
@@ -516,6 +516,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         qq = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
     }
     float tau = nn_tau(abest, qq, tmax2, (double)kqt, (double)ktt);
+    if (!(tmax2 >= t2min)) tau = __builtin_nanf("");      // below the magnitudes the filter's bound covers: exhaustive
     if (a.debug & 16) tau = __builtin_inff();          // test hook: every listed tile is evaluated
     bool flag = (a.debug & 8) != 0 || !(tau == tau);   // test hook / non-finite input: exhaustive pass
     int ncand = 0;
@@ -652,11 +653,12 @@ int launch_nn_bf16(NNArgs &a, int q, int pre, int nl, long long total_blocks, hi
         else launch_main<1, 4, 1>(a, blocks, pre, st);
     }
     if (!check(hipGetLastError(), "nn_bf16_kernel launch")) return 0;
-    return launch_nn_finish(a, nl, 4, (float)kQT16, (float)kTT16, st);
+    // the bf16 MFMA may flush subnormal products (<= 1.2e-38 each): negligible against u T^2 only for T^2 >= 2^-60
+    return launch_nn_finish(a, nl, 4, (float)kQT16, (float)kTT16, 8.673617379884035e-19f, st);
 }
 
 // Second launch of the filtered paths.  kqt / ktt: coefficients of the filter's error bound.
-int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, hipStream_t st)
+int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float t2min, hipStream_t st)
 {
     long long fb = 0;
     for (int d = 0; d < a.ndir; d++) {
@@ -668,9 +670,9 @@ int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, hipSt
         return 0;
     }
     if (arith_mode() != 0)
-        hipLaunchKernelGGL((nn_finish_kernel<1>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, upieces, kqt, ktt);
+        hipLaunchKernelGGL((nn_finish_kernel<1>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, upieces, kqt, ktt, t2min);
     else
-        hipLaunchKernelGGL((nn_finish_kernel<0>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, upieces, kqt, ktt);
+        hipLaunchKernelGGL((nn_finish_kernel<0>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, upieces, kqt, ktt, t2min);
     return check(hipGetLastError(), "nn_finish_kernel launch") ? 1 : 0;
 }
 

@@ -299,7 +299,7 @@ int launch_nn_f16(NNArgs &a, int q, int nl, long long total_blocks, hipStream_t 
         else launch_main<1, 1>(a, blocks, st);
     }
     if (!check(hipGetLastError(), "nn_f16_kernel launch")) return 0;
-    return launch_nn_finish(a, nl, 4, (float)kQTh, (float)kTTh, st);
+    return launch_nn_finish(a, nl, 4, (float)kQTh, (float)kTTh, 0.0f, st);
 }
 
 }  // namespace genpc

@@ -37,6 +37,13 @@ int genpc_set_arith(int mode);            /* returns the previous mode */
 int genpc_get_arith(void);
 /* Frees the per-device scratch pool (split-target partials, EMD lists). */
 int genpc_release_workspace(void);
+/* Nearest-neighbour kernel selection, for tests and experiments: every path returns
+ * the same bits.  path: 3 one-f16-MFMA filter (default), 2 split-bf16 MFMA filter,
+ * 1 fp32-MFMA filter, 0 VALU brute force, < 0 keep.  hooks: bit mask of test hooks
+ * (8: every query takes the exhaustive pass, 16: every listed tile is evaluated
+ * exactly), < 0 keep.  Returns the previous path.  Environment: GENPC_NN_PATH
+ * (valu | mfma32 | bf16 | f16), GENPC_NN_DEBUG.                                 */
+int genpc_nn_tune(int path, int hooks);
 
 /* Chamfer3D -------------------------------------------------------------- *
  * Replaces chamfer_cuda_forward (loss_functions/Chamfer3D/chamfer3D.cu:136-154,

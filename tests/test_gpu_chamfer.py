@@ -155,3 +155,57 @@ def test_degenerate_and_extreme_shapes(gp, oracle):
     a *= np.float32(1e4)                       # large coordinates: same arithmetic, no overflow
     b *= np.float32(1e4)
     assert_same(run_hip(gp, a, b, 0), oracle.chamfer_forward(a, b, 0))
+
+
+PATHS = {"valu": 0, "mfma32": 1, "bf16": 2, "f16": 3}
+
+
+def run_path(gp, a, b, mode, path, hooks=0):
+    """Runs one nearest-neighbour kernel family (genpc_nn_tune) and restores the default."""
+    lib = gp["lib"].lib
+    prev = lib.genpc_nn_tune(path, hooks)
+    try:
+        return run_hip(gp, a, b, mode)
+    finally:
+        lib.genpc_nn_tune(prev, 0)
+
+
+@pytest.mark.parametrize("path", list(PATHS))
+@pytest.mark.parametrize("mode", [0, 1])
+def test_every_kernel_family_is_bit_exact(gp, oracle, path, mode):
+    """The VALU brute force and the three MFMA filters (fp32, split-bf16, two-piece f16)
+    must all return the oracle's bits: ragged sizes, several slices, unequal clouds."""
+    for shape in (((2, 777, 3), (2, 4097, 3)), ((1, 5000, 3), (1, 130, 3)), ((3, 64, 3), (3, 64, 3))):
+        a, b = gen_pair(77, *shape)
+        assert_same(run_path(gp, a, b, mode, PATHS[path]), oracle.chamfer_forward(a, b, mode))
+
+
+@pytest.mark.parametrize("path", ["mfma32", "bf16", "f16"])
+@pytest.mark.parametrize("hooks", [8, 16])
+def test_filter_fallback_paths(gp, oracle, path, hooks):
+    """Test hooks of the filtered paths: 8 sends every query through the exhaustive
+    pass, 16 makes the finish step evaluate every listed tile -- same bits either way."""
+    a, b = gen_pair(3, (2, 600, 3), (2, 1500, 3))
+    assert_same(run_path(gp, a, b, 1, PATHS[path], hooks), oracle.chamfer_forward(a, b, 1))
+
+
+@pytest.mark.parametrize("path", ["mfma32", "bf16", "f16"])
+def test_filter_adversarial_inputs(gp, oracle, path):
+    """Inputs chosen against the filters' error bounds and the f16 path's scaling:
+    exact ties on an integer grid (many tiles within the bound -> exhaustive pass, first
+    index must win), clouds far from the origin and from each other, tiny and huge
+    coordinate scales, a cloud that is a single repeated point plus one outlier."""
+    rng = np.random.default_rng(12)
+    grid = rng.integers(0, 6, size=(1, 3000, 3)).astype(np.float32)          # heavy exact ties
+    assert_same(run_path(gp, grid[:, :1400].copy(), grid[:, 1400:].copy(), 1, PATHS[path]),
+                oracle.chamfer_forward(grid[:, :1400].copy(), grid[:, 1400:].copy(), 1))
+    a, b = gen_pair(41, (1, 900, 3), (1, 1300, 3))
+    for scale, off_a, off_b in ((1.0, 1000.0, 1000.0), (1.0, 0.0, 300.0), (1e-18, 0.0, 0.0), (1e12, 0.0, 0.0),
+                                (1e-3, 5.0, 5.0)):
+        aa = (a * np.float32(scale) + np.float32(off_a)).astype(np.float32)
+        bb = (b * np.float32(scale) + np.float32(off_b)).astype(np.float32)
+        assert_same(run_path(gp, aa, bb, 1, PATHS[path]), oracle.chamfer_forward(aa, bb, 1))
+    c = np.zeros((1, 500, 3), np.float32) + np.float32(0.3)
+    c[0, 317] = (7.0, -2.0, 1.0)
+    assert_same(run_path(gp, a, c, 1, PATHS[path]), oracle.chamfer_forward(a, c, 1))
+    assert_same(run_path(gp, c, a, 1, PATHS[path]), oracle.chamfer_forward(c, a, 1))
