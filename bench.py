@@ -14,11 +14,13 @@ per-rank workload on its own pair (independent scans shard with no data-path
 collective): weak scaling, value = total pair-dist/s over all ranks.
 
 One JSON line on stdout (rank 0).  Besides the contract fields:
-  roofline      the dominant kernel (nn_forward_kernel) against the fp32 VECTOR
-                roofline.  The kernel is VALU-bound (6.5 kflop per HBM byte); bound
-                is reported as "valu_fp32" with peak 157.3 TFLOP/s (the datasheet
-                fp32 vector figure, numerically equal to the dense f32 MFMA peak);
-                algorithmic flops = 8 per pair (3 sub, 3 mul, 2 add: SURVEY 8d).
+  roofline      the dominant kernel (nn_f16_kernel, the MFMA filter that evaluates every
+                pair) against the dense f16 MFMA roofline, 2500 TFLOP/s: one K = 16
+                product per pair = 32 flop/pair of matrix work (DESIGN.md section 4.1);
+                duration = HIP events around that kernel alone (genpc_nn_profile).
+                "fp32_equivalent" prices the same launch at SURVEY 8d's 8 flop per pair
+                (3 sub, 3 mul, 2 add) against the 157.3 TFLOP/s fp32 vector / matrix peak,
+                the roofline a brute-force fp32 kernel would be held to.
   roofline_hbm  the same launch against the 8 TB/s HBM roofline (algorithmic bytes
                 20*(N+M) per call); north_star asks for it; it is << 1 % by nature.
   cpu_baseline  the CPU oracle (a port: the reference has no CPU path) timed on the
@@ -41,6 +43,8 @@ import torch  # noqa: E402
 N_PTS = 16384
 SEED = 20250101
 PEAK_FP32_TFLOPS = 157.3
+PEAK_F16_MFMA_TFLOPS = 2500.0
+MFMA_FLOP_PER_PAIR = 32      # K = 16 multiply-adds per pair on v_mfma_f32_32x32x16_f16
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_PAIR = 8
 
@@ -76,7 +80,7 @@ def pmc_traffic(n):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("kernel") == "nn_forward_kernel" and d.get("points") == n and d.get("batch") == 1:
+        if d.get("kernel") in ("nn_forward_kernel", "nn_f16_kernel") and d.get("points") == n and d.get("batch") == 1:
             best = d.get("hbm_bytes_per_launch")
     return best
 
@@ -281,7 +285,18 @@ def main():
     if rank == 0:
         # live HIP-event timing of the dominant kernel on the launch stream
         ms = time_events(step, max(20, min(args.steps, 200)), stream)
-        tflops = FLOP_PER_PAIR * pairs_per_step / (ms * 1e-3) / 1e12
+        # the filter kernel alone: HIP events inside the library, on the launch stream
+        _lib.lib.genpc_nn_profile(1)
+        kms = []
+        for _ in range(max(20, min(args.steps, 200))):
+            step()
+            kms.append(float(_lib.lib.genpc_nn_profile(1)))
+        _lib.lib.genpc_nn_profile(0)
+        kms = [k for k in kms if k > 0]
+        kernel_ms = sum(kms) / len(kms) if kms else ms
+        kernel_name = "nn_f16_kernel" if kms else "nn step (filter kernel not in use)"
+        tflops = MFMA_FLOP_PER_PAIR * pairs_per_step / (kernel_ms * 1e-3) / 1e12
+        tflops32 = FLOP_PER_PAIR * pairs_per_step / (kernel_ms * 1e-3) / 1e12
         alg_bytes = 20.0 * (n + n)        # 12 B read + 8 B written per point, both clouds
         out = {
             "metric": "chamfer_nn_pair_dist_throughput",
@@ -299,10 +314,13 @@ def main():
             "config": {"workload": "chamfer_3DDist.forward B=1 N=M=%d (both directions), one pair per rank" % n,
                        "points": n, "batch": 1, "arith": "fma" if _lib.lib.genpc_get_arith() else "strict",
                        "sharding": "independent scans per rank, no data-path collective"},
-            "roofline": {"bound": "valu_fp32", "achieved": round(tflops, 3), "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                         "kernel": "nn_forward_kernel", "ms_per_launch": round(ms, 5),
-                         "flop_per_pair": FLOP_PER_PAIR},
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_F16_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tflops / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": kernel_name, "ms_per_launch": round(kernel_ms, 5),
+                         "flop_per_pair": MFMA_FLOP_PER_PAIR, "mfma_dtype": "f16",
+                         "step_ms_events": round(ms, 5),
+                         "fp32_equivalent": {"flop_per_pair": FLOP_PER_PAIR, "achieved": round(tflops32, 3),
+                                             "peak": PEAK_FP32_TFLOPS, "frac": round(tflops32 / PEAK_FP32_TFLOPS, 4)}},
             "roofline_hbm": {"bound": "hbm", "achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 3),
                              "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6), "traffic": None,

@@ -27,6 +27,7 @@ SIGNATURES = {
     "genpc_get_arith": (_i, []),
     "genpc_release_workspace": (_i, []),
     "genpc_nn_tune": (_i, [_i, _i]),
+    "genpc_nn_profile": (ctypes.c_float, [_i]),
     "genpc_chamfer_forward": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_nm_distance": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "genpc_chamfer_backward": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

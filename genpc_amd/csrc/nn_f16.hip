@@ -21,6 +21,7 @@
 // 6.5u (2|q'|T + T^2); three fp32 roundings each in |t'|^2 and |q'|^2; one unit on T^2
 // for subnormal pieces:  E1 = u (30 |q'| T + 15 T^2 + 3 |q'|^2).
 #include "nn.h"
+#include "../../include/genpc_hip.h"
 
 #include <stdlib.h>
 
@@ -272,6 +273,10 @@ static void launch_main(const NNArgs &a, int blocks, hipStream_t st)
     hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL>), dim3(blocks), dim3(kBlock), 0, st, a);
 }
 
+// genpc_nn_profile(): HIP events around the filter kernel alone (bench.py's roofline line)
+static bool g_prof_on = false;
+static hipEvent_t g_prof_e0 = nullptr, g_prof_e1 = nullptr;
+
 // Launches the filter and the finish kernel.  q / nl as chosen by the planner in chamfer.hip.
 int launch_nn_f16(NNArgs &a, int q, int nl, long long total_blocks, hipStream_t st)
 {
@@ -286,6 +291,10 @@ int launch_nn_f16(NNArgs &a, int q, int nl, long long total_blocks, hipStream_t 
     if (!ws) return 0;
     for (int d = 0; d < a.ndir; d++) a.dir[d].tmaxp = (float *)(ws + off_t[d]);
     const int blocks = (int)total_blocks;
+    if (g_prof_on) {
+        if (!g_prof_e0) { (void)hipEventCreate(&g_prof_e0); (void)hipEventCreate(&g_prof_e1); }
+        (void)hipEventRecord(g_prof_e0, st);
+    }
     if (q == 4) {
         if (nl == 2) launch_main<4, 2>(a, blocks, st);
         else launch_main<4, 1>(a, blocks, st);
@@ -298,8 +307,18 @@ int launch_nn_f16(NNArgs &a, int q, int nl, long long total_blocks, hipStream_t 
         else if (nl == 2) launch_main<1, 2>(a, blocks, st);
         else launch_main<1, 1>(a, blocks, st);
     }
+    if (g_prof_on) (void)hipEventRecord(g_prof_e1, st);
     if (!check(hipGetLastError(), "nn_f16_kernel launch")) return 0;
     return launch_nn_finish(a, nl, 4, (float)kQTh, (float)kTTh, 0.0f, st);
 }
 
 }  // namespace genpc
+
+GENPC_API float genpc_nn_profile(int enable)
+{
+    using namespace genpc;
+    float ms = -1.0f;
+    if (g_prof_on && g_prof_e1 && hipEventSynchronize(g_prof_e1) == hipSuccess) (void)hipEventElapsedTime(&ms, g_prof_e0, g_prof_e1);
+    g_prof_on = enable != 0;
+    return ms;
+}

@@ -44,6 +44,10 @@ int genpc_release_workspace(void);
  * exactly), < 0 keep.  Returns the previous path.  Environment: GENPC_NN_PATH
  * (valu | mfma32 | bf16 | f16), GENPC_NN_DEBUG.                                 */
 int genpc_nn_tune(int path, int hooks);
+/* Kernel-level timing for bench.py: while enabled, HIP events bracket the filter kernel
+ * (nn_f16_kernel) of every nearest-neighbour call on its stream.  Returns the duration
+ * in ms of the last bracketed launch (-1 if none), then sets the switch to `enable`. */
+float genpc_nn_profile(int enable);
 
 /* Chamfer3D -------------------------------------------------------------- *
  * Replaces chamfer_cuda_forward (loss_functions/Chamfer3D/chamfer3D.cu:136-154,
