@@ -404,10 +404,12 @@ __global__ __launch_bounds__(kBlock) void nn_mfma_kernel(NNArgs a)
         for (int rb = 0; rb < tn_pad; rb += 2 * kC) {
             issue(rb + 2 * kC, acc1);          // past the end: spare rows, results dropped
             __builtin_amdgcn_sched_barrier(0);
-            reduce(acc0, t0 + rb);
+            asm volatile("s_nop 7");           // a 16-pass MFMA result needs 19 wait states before the inline-asm
+            reduce(acc0, t0 + rb);             // v_min3 (not padded by the compiler): 8 here + the instructions between
             __builtin_amdgcn_sched_barrier(0);
             issue(rb + 3 * kC, acc0);
             __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7");
             reduce(acc1, t0 + rb + kC);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -677,6 +679,11 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     a.ndir = nd;
     if (nd == 0) return 1;
     int path = cfg.mfma;
+    double pairs = 0.0;
+    for (int d = 0; d < nd; d++) pairs += (double)b * a.dir[d].nq * a.dir[d].nt;
+    // measured on MI355X (tools/nn_sweep.py): below ~6M pairs the single-launch fp32-MFMA
+    // kernel wins (1x1024^2 11.0 vs 13.5 us), from 2048^2 on the two-launch f16 filter
+    if (path == 3 && pairs < 6e6 && g_tune_path < 0 && !getenv("GENPC_NN_PATH")) path = 1;
     const bool f16 = path == 3;      // same planning as the bf16 path, other kernel
     if (f16) path = 2;
     if (path == 2 && nt_max >= (1 << 25)) path = 1;      // finish kernel packs tile indices in 21 bits
@@ -696,9 +703,13 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         long long unsplit2 = 0;
         for (int d = 0; d < nd; d++) unsplit2 += (long long)b * ceil_div(a.dir[d].nq, 256);
         // fp32 MFMA: Q = 2 measured slower at every size from 1x2048^2 to 13x16384^2
-        q = path == 2 ? 4 : 1;
+        // f16 / bf16 filters: 512-query blocks (Q = 4) once there is enough work to fill the chip with
+        // them (1x16384^2 37.8 vs 49.7 us), 256-query blocks below (1x8192^2 20.4 vs 21.6 us)
+        q = path == 2 ? (pairs >= 2e8 ? 4 : 2) : 1;
         (void)unsplit2;
     }
+    // bf16 / f16 filters: at least two accumulator chains per wave (see the hazard note in nn_f16.hip)
+    if (path == 2 && q < 2) q = 2;
     if (path == 2 && !getenv("GENPC_NN_WPS")) want_blocks = (long long)kNumCU * (q == 4 ? 2 : (q == 2 ? 3 : 4));   // resident blocks per CU (VGPRs)
     const int qper = path ? 128 * q : kBlock * r;       // queries per block
     const int gran = path == 2 ? 128 : (path ? 64 : kChunk);   // slice granularity: one bookkeeping unit

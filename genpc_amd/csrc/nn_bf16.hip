@@ -148,6 +148,7 @@ __device__ __forceinline__ float min16(float m, const f32x16 &c)
 template <int Q, int U, int NL, int FMA, int PRE>
 __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
 {
+    static_assert(Q >= 2, "one accumulator chain per wave violates the MFMA -> VALU wait states (nn_f16.hip)");
     constexpr int kC = 32 * U;
     constexpr int kRows = kBTile + 64;          // + two spare tiles: the pipeline fetches two tiles ahead
     __shared__ uint4 plane[PRE ? 2 : 1][4][kRows];   // pre-split path: double buffered, filled by LDS-DMA
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
         constexpr int p = decltype(p_tag)::value;
         constexpr bool last = decltype(last_tag)::value;
         if (!last) fetch(p, row + 64);
+        if (Q == 2) asm volatile("s_nop 3");      // MFMA -> inline-asm VALU read needs 11 wait states (nn_f16.hip)
 #pragma unroll
         for (int r = 0; r < Q; r++) {
             const f32x16 &c = acc[r];
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
         for (int r = 0; r < Q; r++) m1(0, r);
 #pragma unroll
         for (int r = 0; r < Q; r++) m2(0, r);
+        asm volatile("s_nop 15");           // wait states before the first inline-asm read of acc[0]
         for (int rb0 = 0; rb0 < tn_pad; rb0 += NL * kC) {
 #pragma unroll
             for (int n = 0; n < NL; n++) {
@@ -643,14 +646,10 @@ int launch_nn_bf16(NNArgs &a, int q, int pre, int nl, long long total_blocks, hi
     if (q == 4) {
         if (nl == 2) launch_main<4, 4, 2>(a, blocks, pre, st);
         else launch_main<4, 4, 1>(a, blocks, pre, st);
-    } else if (q == 2) {
+    } else {
         if (nl == 4) launch_main<2, 4, 4>(a, blocks, pre, st);
         else if (nl == 2) launch_main<2, 4, 2>(a, blocks, pre, st);
         else launch_main<2, 4, 1>(a, blocks, pre, st);
-    } else {
-        if (nl == 4) launch_main<1, 4, 4>(a, blocks, pre, st);
-        else if (nl == 2) launch_main<1, 4, 2>(a, blocks, pre, st);
-        else launch_main<1, 4, 1>(a, blocks, pre, st);
     }
     if (!check(hipGetLastError(), "nn_bf16_kernel launch")) return 0;
     // the bf16 MFMA may flush subnormal products (<= 1.2e-38 each): negligible against u T^2 only for T^2 >= 2^-60

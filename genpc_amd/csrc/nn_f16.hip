@@ -57,6 +57,13 @@ __device__ __forceinline__ float scale_for(float m)
 template <int Q, int U, int NL>
 __global__ __launch_bounds__(kBlock) void nn_f16_kernel(NNArgs a)
 {
+    // Hazard: the accumulators are consumed by inline-asm v_min3, which the compiler's hazard
+    // recognizer does not pad (an 8-pass MFMA result needs 11 wait states before a VALU
+    // read).  The pipeline supplies them by construction when Q >= 2: between the MFMA that
+    // writes acc[r] and the first read of acc[r] lie the other query tiles' slots, each 8
+    // v_min3 + one MFMA (Q = 2: plus an explicit s_nop).  With Q = 1 the read follows at
+    // once -- measured: 25 % wrong minima -- so that case is not instantiated.
+    static_assert(Q >= 2, "one accumulator chain per wave violates the MFMA -> VALU wait states");
     constexpr int kC = 32 * U;
     constexpr int kRows = kHTile + 64;          // + two spare tiles: the pipeline fetches two tiles ahead
     __shared__ uint4 plane[2][kRows];
@@ -140,6 +147,7 @@ __global__ __launch_bounds__(kBlock) void nn_f16_kernel(NNArgs a)
         constexpr int p = decltype(p_tag)::value;
         constexpr bool last = decltype(last_tag)::value;
         if (!last) fetch(p, row + 64);
+        if (Q == 2) asm volatile("s_nop 3");      // 8 v_min3 + MFMA + ds_read = 10 wait states, 11 needed
 #pragma unroll
         for (int r = 0; r < Q; r++) {
             const f32x16 &c = acc[r];
@@ -201,6 +209,7 @@ __global__ __launch_bounds__(kBlock) void nn_f16_kernel(NNArgs a)
         fetch(1, 32);
 #pragma unroll
         for (int r = 0; r < Q; r++) mm(0, r);
+        asm volatile("s_nop 15");           // wait states before the first inline-asm read of acc[0]
         for (int rb0 = 0; rb0 < tn_pad; rb0 += NL * kC) {
 #pragma unroll
             for (int n = 0; n < NL; n++) {
@@ -298,14 +307,10 @@ int launch_nn_f16(NNArgs &a, int q, int nl, long long total_blocks, hipStream_t 
     if (q == 4) {
         if (nl == 2) launch_main<4, 2>(a, blocks, st);
         else launch_main<4, 1>(a, blocks, st);
-    } else if (q == 2) {
+    } else {
         if (nl == 4) launch_main<2, 4>(a, blocks, st);
         else if (nl == 2) launch_main<2, 2>(a, blocks, st);
         else launch_main<2, 1>(a, blocks, st);
-    } else {
-        if (nl == 4) launch_main<1, 4>(a, blocks, st);
-        else if (nl == 2) launch_main<1, 2>(a, blocks, st);
-        else launch_main<1, 1>(a, blocks, st);
     }
     if (g_prof_on) (void)hipEventRecord(g_prof_e1, st);
     if (!check(hipGetLastError(), "nn_f16_kernel launch")) return 0;
