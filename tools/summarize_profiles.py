@@ -52,11 +52,18 @@ def main():
         shutil.copy(ks, os.path.join(dst, tag + "_bench_kernel_stats.csv"))
     for name, b, n, fetch, write, sq in (("chamfer_B1_16384", 1, 16384, "fetch", "write", "sq"),
                                          ("chamfer_B13_16384", 13, 16384, "fetch13", None, "sq13")):
-        d = {"kernel": "nn_forward_kernel", "batch": b, "points": n, "tag": tag,
+        # dominant kernel: the f16 MFMA filter; the finish kernel's counters are kept beside it
+        d = {"kernel": "nn_f16_kernel", "batch": b, "points": n, "tag": tag,
              "command": "rocprofv3 --pmc <counters> -- python3 tools/prof_chamfer.py %d %d" % (b, n)}
-        f = counters(os.path.join(src, fetch, "c_counter_collection.csv"), "nn_forward") if fetch else {}
-        w = counters(os.path.join(src, write, "c_counter_collection.csv"), "nn_forward") if write else {}
-        s = counters(os.path.join(src, sq, "c_counter_collection.csv"), "nn_forward") if sq else {}
+        f = counters(os.path.join(src, fetch, "c_counter_collection.csv"), "nn_f16_kernel") if fetch else {}
+        w = counters(os.path.join(src, write, "c_counter_collection.csv"), "nn_f16_kernel") if write else {}
+        s = counters(os.path.join(src, sq, "c_counter_collection.csv"), "nn_f16_kernel") if sq else {}
+        ff = counters(os.path.join(src, fetch, "c_counter_collection.csv"), "nn_finish_kernel") if fetch else {}
+        fw = counters(os.path.join(src, write, "c_counter_collection.csv"), "nn_finish_kernel") if write else {}
+        fs = counters(os.path.join(src, sq, "c_counter_collection.csv"), "nn_finish_kernel") if sq else {}
+        d["finish_kernel"] = {"FETCH_SIZE_KiB": ff.get("FETCH_SIZE"), "WRITE_SIZE_KiB": fw.get("WRITE_SIZE"), "sq": fs}
+        if ff and fw:
+            d["finish_kernel"]["hbm_bytes_per_launch"] = (2 * ff["FETCH_SIZE"] + fw["WRITE_SIZE"]) * 1024
         if f:
             d["FETCH_SIZE_KiB"] = f.get("FETCH_SIZE")
         if w:
