@@ -13,7 +13,7 @@ def header_prototypes():
     txt = open(os.path.join(ROOT, "include", "genpc_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(?:int|const char \*)\s*(genpc_\w+)\s*\(([^)]*)\)\s*;", txt):
+    for m in re.finditer(r"\b(?:int|float|const char \*)\s*(genpc_\w+)\s*\(([^)]*)\)\s*;", txt):
         args = m.group(2).strip()
         protos[m.group(1)] = 0 if args == "void" else len(args.split(","))
     return protos
