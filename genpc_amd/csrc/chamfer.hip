@@ -742,7 +742,8 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // split-bf16 path: the launch runs in rounds of `want_blocks` resident blocks, so the
     // slice count is chosen to minimise rounds x (targets per block + a fixed per-block
     // cost worth ~192 targets), over the slice counts that keep a query's candidate lists
-    // (slices x NL, NL lists per lane so that there are at least 4) within kMaxLists = 16.
+    // (slices x NL; NL = 2 lists per lane below three slices: a query is flagged only when THREE
+    // candidate units fall into one list) within kMaxLists = 16.
     int nl = 1;
     if (path == 2) {
         auto lists_of = [&](long long l, int &nl_out) {
@@ -752,7 +753,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
                 smin = std::min(smin, sd);
                 smax = std::max(smax, sd);
             }
-            nl_out = smin >= 4 ? 1 : (smin >= 2 || q == 4 ? 2 : 4);
+            nl_out = smin >= 3 ? 1 : 2;
             return smax * nl_out;
         };
         long long best_len = 0;

@@ -113,6 +113,11 @@ __device__ __forceinline__ void rescan_chunk(const float *__restrict__ T, int nt
     }
 }
 
+// MFMA row of target w (0..31) of a 32-target tile in the bf16 / f16 filters.  A lane of half h
+// holds output rows 8i + 4h + (0..3), i = 0..3: with this placement those are the 16 CONSECUTIVE
+// targets 16h .. 16h + 15, so the finish kernel re-reads one 192-byte run per (tile, half).
+__device__ __forceinline__ int tile_row(int w) { return 8 * ((w >> 2) & 3) + 4 * (w >> 4) + (w & 3); }
+
 // The whole block evaluates query j against every target with the reference's
 // arithmetic and writes (distance, first index): the last resort of the filtered
 // paths (three or more tiles within the error bound, non-finite input).

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void nn_split_kernel(SplitArgs a)
             Z = a_vec(-2.0f * z);
             W = make_uint4(th | (tm << 16), tl, 0u, 0u);
         }
-        uint4 *o = J.out + (size_t)batch * 4 * J.np + i;
+        uint4 *o = J.out + (size_t)batch * 4 * J.np + ((i & ~31) | tile_row(i & 31));
         o[0] = X;
         o[(size_t)J.np] = Y;
         o[(size_t)2 * J.np] = Z;
@@ -304,10 +304,11 @@ __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
                 } else {
                     tmax2 = fmaxf(tmax2, tt);
                 }
-                plane[0][0][t] = X;
-                plane[0][1][t] = Y;
-                plane[0][2][t] = Z;
-                plane[0][3][t] = W;
+                const int row = (t & ~31) | tile_row(t & 31);
+                plane[0][0][row] = X;
+                plane[0][1][row] = Y;
+                plane[0][2][row] = Z;
+                plane[0][3][row] = W;
             }
         }
         if (!PRE) {
@@ -388,48 +389,43 @@ __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
     }
 }
 
-// Exact (reference arithmetic) minimum and first index over the 16 targets
-// base + 8i + 4h + (0..3), i = 0..3, of a 32-target tile: the rows whose approximate
-// values lane half h of the filter held.  Positions past the end are clamped to the
-// last target.
+// Exact (reference arithmetic) minimum and first index over the 16 targets base + 16h ..
+// base + 16h + 15 of a 32-target tile: the rows whose approximate values lane half h of the
+// filter held (tile_row()).  Positions past the end are clamped to the last target.
 template <int FMA>
 __device__ __forceinline__ void rescan_half(const float *__restrict__ T, int nt, int base, int h, float qx, float qy,
                                             float qz, float &bd, int &bi)
 {
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int first = base + 16 * h;
     bd = __builtin_inff();
-    bi = base;
-    if (base + 32 <= nt) {
+    bi = first < nt ? first : nt - 1;
+    if (first + 16 <= nt) {
+        const f4u *tp = (const f4u *)(T + (size_t)first * 3);
         f4u v[12];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const f4u *tp = (const f4u *)(T + (size_t)(base + 8 * i + 4 * h) * 3);
+        for (int k = 0; k < 12; k++) v[k] = tp[k];
 #pragma unroll
-            for (int k = 0; k < 3; k++) v[i * 3 + k] = tp[k];
-        }
-#pragma unroll
-        for (int i = 3; i >= 0; i--) {
-            const float f[12] = {v[i * 3].x, v[i * 3].y, v[i * 3].z, v[i * 3].w, v[i * 3 + 1].x, v[i * 3 + 1].y,
-                                 v[i * 3 + 1].z, v[i * 3 + 1].w, v[i * 3 + 2].x, v[i * 3 + 2].y, v[i * 3 + 2].z, v[i * 3 + 2].w};
+        for (int g = 3; g >= 0; g--) {
+            const float f[12] = {v[g * 3].x, v[g * 3].y, v[g * 3].z, v[g * 3].w, v[g * 3 + 1].x, v[g * 3 + 1].y,
+                                 v[g * 3 + 1].z, v[g * 3 + 1].w, v[g * 3 + 2].x, v[g * 3 + 2].y, v[g * 3 + 2].z, v[g * 3 + 2].w};
 #pragma unroll
             for (int c = 3; c >= 0; c--) {
                 const float dd = sqdist<FMA>(f[c * 3 + 0] - qx, f[c * 3 + 1] - qy, f[c * 3 + 2] - qz);
                 const bool le = dd <= bd;
                 bd = le ? dd : bd;
-                bi = le ? base + 8 * i + 4 * h + c : bi;
+                bi = le ? first + 4 * g + c : bi;
             }
         }
     } else {
-        for (int i = 3; i >= 0; i--) {
-            for (int c = 3; c >= 0; c--) {
-                int kk = base + 8 * i + 4 * h + c;
-                kk = kk < nt ? kk : nt - 1;
-                const float *tp = T + (size_t)kk * 3;
-                const float dd = sqdist<FMA>(tp[0] - qx, tp[1] - qy, tp[2] - qz);
-                const bool le = dd <= bd;
-                bd = le ? dd : bd;
-                bi = le ? kk : bi;
-            }
+        for (int c = 15; c >= 0; c--) {
+            int kk = first + c;
+            kk = kk < nt ? kk : nt - 1;
+            const float *tp = T + (size_t)kk * 3;
+            const float dd = sqdist<FMA>(tp[0] - qx, tp[1] - qy, tp[2] - qz);
+            const bool le = dd <= bd;
+            bd = le ? dd : bd;
+            bi = le ? kk : bi;
         }
     }
 }
@@ -451,6 +447,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     __shared__ float4 s_q[kFQ];
     __shared__ float s_a[4][kFQ];
     __shared__ int s_qflag[kFQ];
+    __shared__ float s_tau[kFQ], s_qq[kFQ];
     __shared__ int s_flagged[kFQ];
     __shared__ unsigned s_work[kFWork];          // query slot << 22 | tile (first target / 32) << 1 | lane half
     __shared__ float s_red[kWavesPerBlock];
@@ -477,6 +474,8 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     const bool live = j < nq;
     j = live ? j : nq - 1;
 
+    const float *cptr = a.dir[0].t + (size_t)batch * a.dir[0].nt * 3;      // common centre of the filter
+    const float ccx = cptr[0], ccy = cptr[1], ccz = cptr[2];
     // this thread's lists: li = part + 4k
     unsigned long long w0[kMaxLists / 4], w1[kMaxLists / 4], w2[kMaxLists / 4];
     float amin = __builtin_inff();
@@ -512,15 +511,21 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     __syncthreads();
     tmax2 = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     const float abest = fminf(fminf(s_a[0][ql], s_a[1][ql]), fminf(s_a[2][ql], s_a[3][ql]));
-    float qq;
-    {
-        const float *cptr = a.dir[0].t + (size_t)batch * a.dir[0].nt * 3;
-        const float x = Qp[(size_t)j * 3 + 0] - cptr[0], y = Qp[(size_t)j * 3 + 1] - cptr[1], z = Qp[(size_t)j * 3 + 2] - cptr[2];
+    // the threshold is fp64 arithmetic (three square roots): once per query, shared through LDS
+    float qq = 0.0f;
+    if (part == 0) {
+        const float4 qv = s_q[ql];
+        const float x = qv.x - ccx, y = qv.y - ccy, z = qv.z - ccz;
         qq = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
+        float t = nn_tau(abest, qq, tmax2, (double)kqt, (double)ktt);
+        if (!(tmax2 >= t2min)) t = __builtin_nanf("");      // below the magnitudes the filter's bound covers: exhaustive
+        if (a.debug & 16) t = __builtin_inff();          // test hook: every listed tile is evaluated
+        s_tau[ql] = t;
+        s_qq[ql] = qq;
     }
-    float tau = nn_tau(abest, qq, tmax2, (double)kqt, (double)ktt);
-    if (!(tmax2 >= t2min)) tau = __builtin_nanf("");      // below the magnitudes the filter's bound covers: exhaustive
-    if (a.debug & 16) tau = __builtin_inff();          // test hook: every listed tile is evaluated
+    __syncthreads();
+    const float tau = s_tau[ql];
+    qq = s_qq[ql];
     bool flag = (a.debug & 8) != 0 || !(tau == tau);   // test hook / non-finite input: exhaustive pass
     int ncand = 0;
     // a listed tile whose minimum is not provably out becomes work items of 32 targets
@@ -647,8 +652,7 @@ int launch_nn_bf16(NNArgs &a, int q, int pre, int nl, long long total_blocks, hi
         if (nl == 2) launch_main<4, 4, 2>(a, blocks, pre, st);
         else launch_main<4, 4, 1>(a, blocks, pre, st);
     } else {
-        if (nl == 4) launch_main<2, 4, 4>(a, blocks, pre, st);
-        else if (nl == 2) launch_main<2, 4, 2>(a, blocks, pre, st);
+        if (nl == 2) launch_main<2, 4, 2>(a, blocks, pre, st);
         else launch_main<2, 4, 1>(a, blocks, pre, st);
     }
     if (!check(hipGetLastError(), "nn_bf16_kernel launch")) return 0;

@@ -198,8 +198,9 @@ __global__ __launch_bounds__(kBlock) void nn_f16_kernel(NNArgs a)
                 } else {
                     tmax2 = fmaxf(tmax2, __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
                 }
-                plane[0][t] = V0;
-                plane[1][t] = V1;
+                const int row = (t & ~31) | tile_row(t & 31);
+                plane[0][row] = V0;
+                plane[1][row] = V1;
             }
         }
         if (t0 + kHTile < k_end) prefetch(t0 + kHTile);
@@ -308,8 +309,7 @@ int launch_nn_f16(NNArgs &a, int q, int nl, long long total_blocks, hipStream_t 
         if (nl == 2) launch_main<4, 2>(a, blocks, st);
         else launch_main<4, 1>(a, blocks, st);
     } else {
-        if (nl == 4) launch_main<2, 4>(a, blocks, st);
-        else if (nl == 2) launch_main<2, 2>(a, blocks, st);
+        if (nl == 2) launch_main<2, 2>(a, blocks, st);
         else launch_main<2, 1>(a, blocks, st);
     }
     if (g_prof_on) (void)hipEventRecord(g_prof_e1, st);
