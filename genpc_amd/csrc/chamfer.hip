@@ -820,7 +820,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         // pre-split targets + LDS-DMA (one more launch) once every target is staged by many blocks
         if (f16) return launch_nn_f16(a, q, nl, tb, st);
         static const int pre_env = getenv("GENPC_NN_PRE") ? atoi(getenv("GENPC_NN_PRE")) : -1;
-        const int pre = pre_env >= 0 ? pre_env : 0;      // measured: 13x16384^2 401+8 us vs 410 us, 1x16384^2 35+5 vs 36 -- does not pay
+        const int pre = pre_env >= 0 ? pre_env : ((a.debug & 256) ? 1 : 0);      // measured: 13x16384^2 401+8 us vs 410 us, 1x16384^2 35+5 vs 36 -- does not pay
         return launch_nn_bf16(a, q, pre, nl, tb, st);
     } else if (path) {
         if (q == 2) { if (u == 2) launch_mfma<2, 2>(a, (int)tb, st); else launch_mfma<2, 1>(a, (int)tb, st); }

@@ -41,7 +41,7 @@ int genpc_release_workspace(void);
  * the same bits.  path: 3 one-f16-MFMA filter (default), 2 split-bf16 MFMA filter,
  * 1 fp32-MFMA filter, 0 VALU brute force, < 0 keep.  hooks: bit mask of test hooks
  * (8: every query takes the exhaustive pass, 16: every listed tile is evaluated
- * exactly), < 0 keep.  Returns the previous path.  Environment: GENPC_NN_PATH
+ * exactly, 256: bf16 path with pre-split targets staged by LDS-DMA), < 0 keep.  Returns the previous path.  Environment: GENPC_NN_PATH
  * (valu | mfma32 | bf16 | f16), GENPC_NN_DEBUG.                                 */
 int genpc_nn_tune(int path, int hooks);
 /* Kernel-level timing for bench.py: while enabled, HIP events bracket the filter kernel

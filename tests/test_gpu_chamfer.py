@@ -181,10 +181,11 @@ def test_every_kernel_family_is_bit_exact(gp, oracle, path, mode):
 
 
 @pytest.mark.parametrize("path", ["mfma32", "bf16", "f16"])
-@pytest.mark.parametrize("hooks", [8, 16])
+@pytest.mark.parametrize("hooks", [8, 16, 256])
 def test_filter_fallback_paths(gp, oracle, path, hooks):
     """Test hooks of the filtered paths: 8 sends every query through the exhaustive
-    pass, 16 makes the finish step evaluate every listed tile -- same bits either way."""
+    pass, 16 makes the finish step evaluate every listed tile, 256 (bf16) stages pre-split
+    targets with global_load_lds -- same bits every way."""
     a, b = gen_pair(3, (2, 600, 3), (2, 1500, 3))
     assert_same(run_path(gp, a, b, 1, PATHS[path], hooks), oracle.chamfer_forward(a, b, 1))
 
