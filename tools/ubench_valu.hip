@@ -144,6 +144,42 @@ __global__ __launch_bounds__(256) void k(float *out, float s0, float s1)
 #define OP(i) asm volatile("v_min_f32_e64 %0, %1, %0" : "+v"(v[i]) : "v"(a));
             BODY8(OP) BODY8(OP)
 #undef OP
+        } else if (KIND == 29) {    // v_minimum3_f32 (gfx950, IEEE-754-2019 minimum)
+#define OP(i) asm volatile("v_minimum3_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 30) {    // v_pk_min_f16
+#define OP(i) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 31) {    // v_pk_minimum3_f16 (gfx950)
+#define OP(i) asm volatile("v_pk_minimum3_f16 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 32) {    // v_min3_i32
+#define OP(i) asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 33) {    // v_pk_min_i16
+#define OP(i) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 34) {    // v_cvt_pkrtz_f16_f32
+#define OP(i) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 35) {    // v_min_u32
+#define OP(i) asm volatile("v_min_u32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 36) {    // v_perm_b32
+#define OP(i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 37) {    // v_and_or_b32
+#define OP(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
         }
     }
     float acc = 0;
@@ -172,7 +208,10 @@ int main()
         {"v_cndmask_b32", k<19>, 16, 1}, {"v_mov_b32 v,s", k<20>, 16, 1}, {"v_sub_f32_e64 sgpr", k<21>, 16, 1},
         {"v_fmac_f32 sgpr src0", k<22>, 16, 1}, {"v_fma(q,-1,s)", k<23>, 16, 1}, {"v_sub_f32 1.0 const", k<24>, 16, 1},
         {"v_mov_b32 v,v", k<25>, 16, 1}, {"v_sub sgpr indep dst", k<26>, 16, 1}, {"v_min3 indep dst", k<27>, 16, 1},
-        {"v_min_f32_e64", k<28>, 16, 1},
+        {"v_min_f32_e64", k<28>, 16, 1}, {"v_minimum3_f32", k<29>, 16, 1}, {"v_pk_min_f16", k<30>, 16, 2},
+        {"v_pk_minimum3_f16", k<31>, 16, 2}, {"v_min3_i32", k<32>, 16, 1}, {"v_pk_min_i16", k<33>, 16, 2},
+        {"v_cvt_pkrtz_f16_f32", k<34>, 16, 1}, {"v_min_u32", k<35>, 16, 1}, {"v_perm_b32", k<36>, 16, 1},
+        {"v_and_or_b32", k<37>, 16, 1},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
