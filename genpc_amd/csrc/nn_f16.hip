@@ -12,8 +12,8 @@
 // centred coordinate of ITS queries and ITS target slice in [2^10, 2^11): products stay
 // below 2^23, |t'|^2 s^2 2^-8 below 3 x 2^14, small coordinates may reach f16 subnormals,
 // which the instruction does not flush (tools/ubench_mfma_f16.hip) -- their absolute
-// error, <= 2^-25 in scaled units, is far below the bound.  The result s^2 (|t'|^2 -
-// 2 q'.t') is unscaled (two exact multiplications) when a unit minimum is recorded.
+// error, <= 2^-25 in scaled units, is far below the bound.  The list values s^2 (|t'|^2 -
+// 2 q'.t') are unscaled (two exact multiplications) when the lists are published.
 //
 // Error bound, u = 2^-24, T = max |t'|: residuals 4u per operand -> 16u |q'|T on
 // -2 q'.t' and 4u T^2 on |t'|^2; the instruction's summation, measured at <= 3.1 u
@@ -232,8 +232,7 @@ __global__ __launch_bounds__(kBlock) void nn_f16_kernel(NNArgs a)
                         float v;
                         asm("v_min3_f32 %0, %1, %2, %3" : "=v"(v) : "v"(m[r][0]), "v"(m[r][1]), "v"(m[r][2]));
                         asm("v_min_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(m[r][3]));
-                        v = (v * isc) * isc;       // unscale: s^2 (|t'|^2 - 2 q'.t') -> |t'|^2 - 2 q'.t'
-                        top3_insert(lst[r][n], v, t0 + rb + half);      // bit 0: which 16 rows of each tile
+                        top3_insert(lst[r][n], v, t0 + rb + half);      // scaled value; bit 0: which 16 rows of each tile
                     }
                 }
             }
@@ -261,6 +260,11 @@ __global__ __launch_bounds__(kBlock) void nn_f16_kernel(NNArgs a)
 #pragma unroll
         for (int n = 0; n < NL; n++) {
             Top3 &f = lst[r][n];
+            // unscale (the block's scale is one power of two, so the order was not affected):
+            // s^2 (|t'|^2 - 2 q'.t') -> |t'|^2 - 2 q'.t', two exact multiplications
+            f.a1 = (f.a1 * isc) * isc;
+            f.a2 = (f.a2 * isc) * isc;
+            f.a3 = (f.a3 * isc) * isc;
             const float o1 = __shfl_xor(f.a1, 32), o2 = __shfl_xor(f.a2, 32), o3 = __shfl_xor(f.a3, 32);
             const int oc1 = __shfl_xor(f.c1, 32), oc2 = __shfl_xor(f.c2, 32);
             top3_insert(f, o1, oc1);
