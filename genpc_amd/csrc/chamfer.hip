@@ -624,7 +624,7 @@ static NNConfig nn_config()
         if (const char *e = getenv("GENPC_NN_Q")) k.q = atoi(e);
         if (const char *e = getenv("GENPC_NN_U")) k.u = atoi(e);
         if (k.q != 1 && k.q != 2 && k.q != 4) k.q = 0;
-        if (k.u != 1 && k.u != 2) k.u = 0;
+        if (k.u != 1 && k.u != 2 && k.u != 4) k.u = 0;
         if (const char *e = getenv("GENPC_NN_WPS")) k.blocks_per_cu = atoi(e);
         if (k.r != 2 && k.r != 4) k.r = 0;
         if (k.blocks_per_cu < 1) k.blocks_per_cu = 1;
@@ -738,7 +738,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     a.slice_len = (int)len;
     // bookkeeping per 64 targets once a block has enough of them to amortise the coarser
     // re-scan (measured: 1x2048^2 14.5 vs 16.0 us, 1x16384^2 63.6 vs 61.2, 13x16384^2 644 vs 590)
-    const int u = cfg.u ? cfg.u : (len >= 2048 ? 2 : 1);
+    const int u = (cfg.u == 1 || cfg.u == 2) ? cfg.u : (len >= 2048 ? 2 : 1);
     // split-bf16 path: the launch runs in rounds of `want_blocks` resident blocks, so the
     // slice count is chosen to minimise rounds x (targets per block + a fixed per-block
     // cost worth ~192 targets), over the slice counts that keep a query's candidate lists
@@ -818,7 +818,13 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     }
     if (path == 2) {
         // pre-split targets + LDS-DMA (one more launch) once every target is staged by many blocks
-        if (f16) return launch_nn_f16(a, q, nl, tb, st);
+        if (f16) {
+            // bookkeeping unit: the finish kernel re-reads 16 targets per tile of every candidate unit --
+            // per QUERY, while the filter's work is per PAIR: short target clouds (many queries per
+            // pair) take 64-target units (half the re-read, +10 % filter VALU), long ones 128
+            const int fu = cfg.u == 2 || cfg.u == 4 ? cfg.u : (nt_max <= 8192 ? 2 : 4);
+            return launch_nn_f16(a, q, fu, nl, tb, st);
+        }
         static const int pre_env = getenv("GENPC_NN_PRE") ? atoi(getenv("GENPC_NN_PRE")) : -1;
         const int pre = pre_env >= 0 ? pre_env : ((a.debug & 256) ? 1 : 0);      // measured: 13x16384^2 401+8 us vs 410 us, 1x16384^2 35+5 vs 36 -- does not pay
         return launch_nn_bf16(a, q, pre, nl, tb, st);

@@ -282,17 +282,18 @@ __global__ __launch_bounds__(kBlock) void nn_f16_kernel(NNArgs a)
 }
 
 template <int Q, int NL>
-static void launch_main(const NNArgs &a, int blocks, hipStream_t st)
+static void launch_main(const NNArgs &a, int blocks, int u, hipStream_t st)
 {
-    hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL>), dim3(blocks), dim3(kBlock), 0, st, a);
+    if (u == 2) hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL>), dim3(blocks), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL>), dim3(blocks), dim3(kBlock), 0, st, a);
 }
 
 // genpc_nn_profile(): HIP events around the filter kernel alone (bench.py's roofline line)
 static bool g_prof_on = false;
 static hipEvent_t g_prof_e0 = nullptr, g_prof_e1 = nullptr;
 
-// Launches the filter and the finish kernel.  q / nl as chosen by the planner in chamfer.hip.
-int launch_nn_f16(NNArgs &a, int q, int nl, long long total_blocks, hipStream_t st)
+// Launches the filter and the finish kernel.  q / u / nl as chosen by the planner in chamfer.hip.
+int launch_nn_f16(NNArgs &a, int q, int u, int nl, long long total_blocks, hipStream_t st)
 {
     size_t bytes = 0;
     size_t off_t[2];
@@ -310,15 +311,15 @@ int launch_nn_f16(NNArgs &a, int q, int nl, long long total_blocks, hipStream_t 
         (void)hipEventRecord(g_prof_e0, st);
     }
     if (q == 4) {
-        if (nl == 2) launch_main<4, 2>(a, blocks, st);
-        else launch_main<4, 1>(a, blocks, st);
+        if (nl == 2) launch_main<4, 2>(a, blocks, u, st);
+        else launch_main<4, 1>(a, blocks, u, st);
     } else {
-        if (nl == 2) launch_main<2, 2>(a, blocks, st);
-        else launch_main<2, 1>(a, blocks, st);
+        if (nl == 2) launch_main<2, 2>(a, blocks, u, st);
+        else launch_main<2, 1>(a, blocks, u, st);
     }
     if (g_prof_on) (void)hipEventRecord(g_prof_e1, st);
     if (!check(hipGetLastError(), "nn_f16_kernel launch")) return 0;
-    return launch_nn_finish(a, nl, 4, (float)kQTh, (float)kTTh, 0.0f, st);
+    return launch_nn_finish(a, nl, u, (float)kQTh, (float)kTTh, 0.0f, st);
 }
 
 }  // namespace genpc

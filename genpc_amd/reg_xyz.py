@@ -107,7 +107,9 @@ def iterative_scale_search(source_pcd, target_pcd, scale_ranges, scale_steps, in
     xs = np.linspace(scale_ranges[0][0], scale_ranges[0][1], scale_steps)
     ys = np.linspace(scale_ranges[1][0], scale_ranges[1][1], scale_steps)
     zs = np.linspace(scale_ranges[2][0], scale_ranges[2][1], scale_steps)
-    cand = np.array([[x, y, z] for z in zs for x in xs for y in ys], np.float64)
+    # candidate order z (outer), x, y (inner)
+    gz, gx, gy = np.meshgrid(zs, xs, ys, indexing="ij")
+    cand = np.stack([gx.ravel(), gy.ravel(), gz.ravel()], axis=1).astype(np.float64)
     scales_t = torch.from_numpy(cand.astype(np.float32)).to(source.device)
     scores = torch.empty(len(cand), device=source.device)
     rc = _lib.on_device_of(source, _L.genpc_scale_search_scores, len(cand), source.shape[0], _p(source),
