@@ -745,6 +745,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // (slices x NL; NL = 2 lists per lane below three slices: a query is flagged only when THREE
     // candidate units fall into one list) within kMaxLists = 16.
     int nl = 1;
+    bool tight = false;
     if (path == 2) {
         auto lists_of = [&](long long l, int &nl_out) {
             int smin = 1 << 30, smax = 0;
@@ -756,20 +757,33 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
             nl_out = smin >= 3 ? 1 : 2;
             return smax * nl_out;
         };
+        // The f16 kernel's 512-query blocks (Q = 4) exist in two register budgets: 2 resident
+        // blocks per CU, or 3 (168 VGPRs, a little scratch: ~4 % faster per pair over many rounds,
+        // ~1 us slower when the launch is a single round).  All resident blocks share the VALU, so
+        // a round costs (resident blocks) x (targets per block + fixed part).
         long long best_len = 0;
         double best_cost = 0.0;
-        for (int sc = 1; sc <= 16; sc++) {
-            const long long l = ceil_div64(ceil_div64(nt_max, sc), gran) * gran;
-            if (sc > 1 && l < 256) break;
-            int nl_c;
-            if (lists_of(l, nl_c) > 16) continue;
-            const long long rounds = ceil_div64(blocks_at(l), want_blocks);
-            const double cost = (double)rounds * (double)(std::min<long long>(l, nt_max) + 192);
-            if (!best_len || cost < best_cost * 0.98) {      // prefer fewer slices unless clearly better
-                best_len = l;
-                best_cost = cost;
+        int best_res = 0;
+        const bool env_wps = getenv("GENPC_NN_WPS") != nullptr;
+        for (int res = (f16 && q == 4 && !env_wps) ? 3 : 0; res != 1 && res >= 0; res = (res == 3 ? 2 : -1)) {
+            const long long slots = res ? (long long)kNumCU * res : want_blocks;
+            const double per_block = res == 3 ? 3.0 * 0.96 : (res == 2 ? 2.0 : 1.0);
+            for (int sc = 1; sc <= 16; sc++) {
+                const long long l = ceil_div64(ceil_div64(nt_max, sc), gran) * gran;
+                if (sc > 1 && l < 256) break;
+                int nl_c;
+                if (lists_of(l, nl_c) > 16) continue;
+                const long long rounds = ceil_div64(blocks_at(l), slots);
+                if (res == 3 && rounds < 3) continue;         // few rounds: the leaner kernel wins
+                const double cost = (double)rounds * (double)(std::min<long long>(l, nt_max) + 192) * per_block;
+                if (!best_len || cost < best_cost * 0.98) {      // prefer fewer slices unless clearly better
+                    best_len = l;
+                    best_cost = cost;
+                    best_res = res;
+                }
             }
         }
+        tight = best_res == 3;
         len = best_len;
         (void)lists_of(len, nl);
         a.slice_len = (int)len;
@@ -823,7 +837,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
             // per QUERY, while the filter's work is per PAIR: short target clouds (many queries per
             // pair) take 64-target units (half the re-read, +10 % filter VALU), long ones 128
             const int fu = cfg.u == 2 || cfg.u == 4 ? cfg.u : (nt_max <= 8192 ? 2 : 4);
-            return launch_nn_f16(a, q, fu, nl, tb, st);
+            return launch_nn_f16(a, q, fu, nl, tight ? 1 : 0, tb, st);
         }
         static const int pre_env = getenv("GENPC_NN_PRE") ? atoi(getenv("GENPC_NN_PRE")) : -1;
         const int pre = pre_env >= 0 ? pre_env : ((a.debug & 256) ? 1 : 0);      // measured: 13x16384^2 401+8 us vs 410 us, 1x16384^2 35+5 vs 36 -- does not pay

@@ -199,7 +199,7 @@ __device__ __forceinline__ float nn_tau(float a_best, float qq, float tmax2, dou
 }
 
 int launch_nn_bf16(NNArgs &a, int q, int pre, int nl, long long total_blocks, hipStream_t st);
-int launch_nn_f16(NNArgs &a, int q, int u, int nl, long long total_blocks, hipStream_t st);
+int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, long long total_blocks, hipStream_t st);
 int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float t2min, hipStream_t st);
 
 }  // namespace genpc

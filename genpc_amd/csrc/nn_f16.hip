@@ -54,8 +54,10 @@ __device__ __forceinline__ float scale_for(float m)
 
 // One block = one (direction, target slice, batch, 128*Q-query block) unit; wave w owns Q
 // tiles of 32 queries.  U = target tiles per bookkeeping unit, NL = candidate lists per lane.
-template <int Q, int U, int NL>
-__global__ __launch_bounds__(kBlock) void nn_f16_kernel(NNArgs a)
+// W = waves per SIMD the register budget is held to (Q = 4: 182-202 VGPRs natural -> 2 waves; W = 3
+// caps at 168 with ~50-150 B of scratch: +1 us on a single-round launch, -4 % over many rounds)
+template <int Q, int U, int NL, int W>
+__global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
 {
     // Hazard: the accumulators are consumed by inline-asm v_min3, which the compiler's hazard
     // recognizer does not pad (an 8-pass MFMA result needs 11 wait states before a VALU
@@ -282,10 +284,16 @@ __global__ __launch_bounds__(kBlock) void nn_f16_kernel(NNArgs a)
 }
 
 template <int Q, int NL>
-static void launch_main(const NNArgs &a, int blocks, int u, hipStream_t st)
+static void launch_main(const NNArgs &a, int blocks, int u, bool tight, hipStream_t st)
 {
-    if (u == 2) hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL>), dim3(blocks), dim3(kBlock), 0, st, a);
-    else hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL>), dim3(blocks), dim3(kBlock), 0, st, a);
+    // tight: three waves per SIMD for the 512-query blocks (planner: launches of several rounds)
+    if (u == 2) {
+        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 3 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 2 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
+    } else {
+        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 3 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 2 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
+    }
 }
 
 // genpc_nn_profile(): HIP events around the filter kernel alone (bench.py's roofline line)
@@ -293,7 +301,7 @@ static bool g_prof_on = false;
 static hipEvent_t g_prof_e0 = nullptr, g_prof_e1 = nullptr;
 
 // Launches the filter and the finish kernel.  q / u / nl as chosen by the planner in chamfer.hip.
-int launch_nn_f16(NNArgs &a, int q, int u, int nl, long long total_blocks, hipStream_t st)
+int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, long long total_blocks, hipStream_t st)
 {
     size_t bytes = 0;
     size_t off_t[2];
@@ -311,11 +319,11 @@ int launch_nn_f16(NNArgs &a, int q, int u, int nl, long long total_blocks, hipSt
         (void)hipEventRecord(g_prof_e0, st);
     }
     if (q == 4) {
-        if (nl == 2) launch_main<4, 2>(a, blocks, u, st);
-        else launch_main<4, 1>(a, blocks, u, st);
+        if (nl == 2) launch_main<4, 2>(a, blocks, u, tight != 0, st);
+        else launch_main<4, 1>(a, blocks, u, tight != 0, st);
     } else {
-        if (nl == 2) launch_main<2, 2>(a, blocks, u, st);
-        else launch_main<2, 1>(a, blocks, u, st);
+        if (nl == 2) launch_main<2, 2>(a, blocks, u, false, st);
+        else launch_main<2, 1>(a, blocks, u, false, st);
     }
     if (g_prof_on) (void)hipEventRecord(g_prof_e1, st);
     if (!check(hipGetLastError(), "nn_f16_kernel launch")) return 0;
