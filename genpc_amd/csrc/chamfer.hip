@@ -231,8 +231,16 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
         }
         const int j = q0 + r * kWave;
         if (j < nq) {
-            od[j] = best[r];
-            oi[j] = base + first;
+            float dv = best[r];
+            int iv = base + first;
+            if (dv == __builtin_inff()) {
+                // no distance ever compared below +inf: if target 0's is NaN the reference's scan
+                // (best = d(0), then strict '<') ends with that NaN at index 0
+                const float d0 = sqdist<FMA>(T[0] - qx[r], T[1] - qy[r], T[2] - qz[r]);
+                if (d0 != d0) { dv = d0; iv = 0; }
+            }
+            od[j] = dv;
+            oi[j] = iv;
         }
     }
 }

@@ -210,3 +210,20 @@ def test_filter_adversarial_inputs(gp, oracle, path):
     c[0, 317] = (7.0, -2.0, 1.0)
     assert_same(run_path(gp, a, c, 1, PATHS[path]), oracle.chamfer_forward(a, c, 1))
     assert_same(run_path(gp, c, a, 1, PATHS[path]), oracle.chamfer_forward(c, a, 1))
+
+
+@pytest.mark.parametrize("path", list(PATHS))
+def test_non_finite_points(gp, oracle, path):
+    """NaN / inf coordinates: the reference's strict '<' never selects a NaN distance and keeps
+    target 0 when every distance is NaN; every kernel family must agree with the oracle
+    (indices exactly; distances equal or both NaN)."""
+    a, b = gen_pair(8, (1, 700, 3), (1, 900, 3))
+    a[0, 13] = np.nan                    # a query that sees only NaN distances
+    b[0, 5, 1] = np.nan                  # a target nobody can select
+    b[0, 77] = np.inf                    # an infinitely far target
+    got = run_path(gp, a, b, 1, PATHS[path])
+    exp = oracle.chamfer_forward(a, b, 1)
+    for g, e in zip(got[2:], exp[2:]):
+        np.testing.assert_array_equal(g, e)
+    for g, e in zip(got[:2], exp[:2]):
+        assert np.array_equal(g, e, equal_nan=True)
