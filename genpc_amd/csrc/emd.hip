@@ -550,7 +550,15 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
                                    int *, int *, float *, float *, int, float4 *, int *, int *, int);
             static const int zmax_env = getenv("GENPC_EMD_ZMAX") ? atoi(getenv("GENPC_EMD_ZMAX")) : kZMax;
             const int zmax = zmax_env < 1 ? 1 : (zmax_env > kZMax ? kZMax : zmax_env);
-            static const int force_p = getenv("GENPC_EMD_P") ? atoi(getenv("GENPC_EMD_P")) : 0;
+            // Lanes per bidder.  Round 0 has no filter seeds: the fewer lanes share a bidder, the sooner a
+            // lane's own second-best makes the filter selective (16 lanes: 186 us, 64: 298 us at
+            // n = 16384).  From round 1 on the seeds do that, and one bidder per wave (64 lanes)
+            // keeps one bidder's rare exact evaluations from stalling another's lanes (round 1:
+            // 95 us against 166 us at 32 lanes), even when that needs more units than blocks.  With
+            // many clouds in flight (b >= 32) fewer bidders per staged tile cost more than that (+2 %).
+            static const int env_p = getenv("GENPC_EMD_P") ? atoi(getenv("GENPC_EMD_P")) : 0;
+            static const int env_p0 = getenv("GENPC_EMD_P0") ? atoi(getenv("GENPC_EMD_P0")) : 0;
+            const int force_p = env_p > 0 ? env_p : (it == 0 ? env_p0 : (second != nullptr && b < 32 ? 64 : 0));
             static const bool nofilter = getenv("GENPC_EMD_NOFILTER") != nullptr;
             bid_fn f = fma ? (nofilter ? emd_bid_kernel<1, 0> : emd_bid_kernel<1, 1>)
                            : (nofilter ? emd_bid_kernel<0, 0> : emd_bid_kernel<0, 1>);
