@@ -185,6 +185,23 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
     for (int unit = blockIdx.x; unit < units; unit += G) {
         const int grp = unit % NB;
         const int zs = unit / NB;
+        const int k_lo = zs * tps * kTile;
+        const int k_hi = min(n, (zs + 1) * tps * kTile);
+        // Tiles are staged through registers one tile ahead: the global loads of tile
+        // t+1 are in flight while tile t is scanned (a round with few bidders is otherwise
+        // a chain of load -> barrier -> short scan -> barrier per tile: pure latency).  The first
+        // tile is requested before the bidder's own chain of loads (list -> point -> seed objects),
+        // on which it does not depend and behind whose waits it would otherwise queue.
+        float4 pre[kLoadsPerThread];
+        auto fetch = [&](int k2) {
+#pragma unroll
+            for (int i = 0; i < kLoadsPerThread; i++) {
+                const int k = k2 + threadIdx.x + i * kEBlock;
+                const int kk = k < n ? k : n - 1;
+                pre[i] = make_float4(X2[(size_t)kk * 3 + 0], X2[(size_t)kk * 3 + 1], X2[(size_t)kk * 3 + 2], PR[kk]);
+            }
+        };
+        if (k_lo < k_hi) fetch(k_lo);
         const int u = grp * per_block + wave * per_wave + g;
         const bool active = u < U;
         const int j = L[active ? u : U - 1];
@@ -210,22 +227,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
             }
         }
         float cb = __fsub_rn(3.000002f, fmaxf(better, seed));
-        const int k_lo = zs * tps * kTile;
-        const int k_hi = min(n, (zs + 1) * tps * kTile);
 
-        // Tiles are staged through registers one tile ahead: the global loads of tile
-        // t+1 are in flight while tile t is scanned (a round with few bidders is otherwise
-        // a chain of load -> barrier -> short scan -> barrier per tile: pure latency).
-        float4 pre[kLoadsPerThread];
-        auto fetch = [&](int k2) {
-#pragma unroll
-            for (int i = 0; i < kLoadsPerThread; i++) {
-                const int k = k2 + threadIdx.x + i * kEBlock;
-                const int kk = k < n ? k : n - 1;
-                pre[i] = make_float4(X2[(size_t)kk * 3 + 0], X2[(size_t)kk * 3 + 1], X2[(size_t)kk * 3 + 2], PR[kk]);
-            }
-        };
-        if (k_lo < k_hi) fetch(k_lo);
         for (int k2 = k_lo; k2 < k_hi; k2 += kTile) {
             const int end_k = min(n, k2 + kTile) - k2;
             __syncthreads();                               // the previous tile has been scanned
