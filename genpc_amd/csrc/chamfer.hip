@@ -87,6 +87,7 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
     // LDS tile layout: groups of 4 targets as three float4s (x0..x3 | y0..y3 | z0..z3),
     // so that every byte a ds_read_b128 fetches is used (12 B per target).
     float *tile_f = (float *)tile;
+    float nf = 0.0f;      // NaN once a target of the slice had a non-finite coordinate
     for (int t0 = k_begin; t0 < k_end && !(a.debug & 4); t0 += kTile) {
         const int tn = min(kTile, k_end - t0);
         const int tn_pad = (tn + kChunk - 1) / kChunk * kChunk;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
             if (t < tn) {
                 const float *tp = T + (size_t)(t0 + t) * 3;
                 x = tp[0]; y = tp[1]; z = tp[2];
+                nf = __fmaf_rn((fabsf(x) + fabsf(y)) + fabsf(z), 0.0f, nf);      // inf x 0 = NaN, NaN sticks
             } else {
                 // pad the ragged tail of the last chunk: a +inf distance never wins a strict '<'
                 x = y = z = __builtin_inff();
@@ -141,6 +143,10 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
         }
     }
 
+    // Non-finite input: the minimum-of-chunks scan silently skips NaN distances, the reference's
+    // tiled scan does not always (nn_exhaustive, nn.h).  A slice that saw a non-finite target marks
+    // its partials; queries of such a cloud, and non-finite queries, are answered exhaustively.
+    int bad = __syncthreads_or(nf != nf);
     if (D.slices > 1) {
         // Publish this slice's (minimum, chunk) per query; the last block to arrive for
         // this (direction, batch, query block) folds all S slices in slice order with
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
         for (int r = 0; r < R; r++) {
             const int j = q0 + r * kWave;
             if (j < nq) {
-                const unsigned long long v = ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned)bchunk[r];
+                const unsigned long long v = bad ? ~0ull : ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned)bchunk[r];
                 __hip_atomic_store(P + (size_t)slice * bnq + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -174,10 +180,13 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
             int j = q0 + r * kWave;
             j = j < nq ? j : nq - 1;
             unsigned long long v = __hip_atomic_load(P + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bad |= v == ~0ull;
             float bv = __uint_as_float((unsigned)(v >> 32));
             int bc = (int)(unsigned)v;
+            if (v == ~0ull) { bv = __builtin_inff(); bc = 0; }      // marked slice: no chunk to recover (the query goes exhaustive)
             for (int s2 = 1; s2 < D.slices; s2++) {
                 v = __hip_atomic_load(P + (size_t)s2 * bnq + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad |= v == ~0ull;
                 const float vv = __uint_as_float((unsigned)(v >> 32));
                 const bool lt = vv < bv;
                 bv = lt ? vv : bv;
@@ -198,6 +207,14 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     float *__restrict__ od = D.out_d + (size_t)batch * nq;
     int *__restrict__ oi = D.out_i + (size_t)batch * nq;
+    // the target tile is dead: its LDS holds the list of queries for the exhaustive pass
+    __syncthreads();
+    int *s_nflag = (int *)tile;
+    int *s_xfi = s_nflag + 4;
+    float *s_xred = (float *)(s_nflag + 8);
+    int *s_flag = s_nflag + 16;                  // up to kBlock * R entries
+    if (threadIdx.x == 0) *s_nflag = 0;
+    bad = __syncthreads_or(bad);                 // merged partials: every lane read the same marks
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int base = bchunk[r];
@@ -230,19 +247,19 @@ __global__ __launch_bounds__(kBlock) void nn_forward_kernel(NNArgs a)
             }
         }
         const int j = q0 + r * kWave;
+        const bool qbad = !((fabsf(qx[r]) + fabsf(qy[r])) + fabsf(qz[r]) < __builtin_inff());
         if (j < nq) {
-            float dv = best[r];
-            int iv = base + first;
-            if (dv == __builtin_inff()) {
-                // no distance ever compared below +inf: if target 0's is NaN the reference's scan
-                // (best = d(0), then strict '<') ends with that NaN at index 0
-                const float d0 = sqdist<FMA>(T[0] - qx[r], T[1] - qy[r], T[2] - qz[r]);
-                if (d0 != d0) { dv = d0; iv = 0; }
+            if (bad || qbad) {
+                s_flag[atomicAdd(s_nflag, 1)] = j;
+            } else {
+                od[j] = best[r];
+                oi[j] = base + first;
             }
-            od[j] = dv;
-            oi[j] = iv;
         }
     }
+    __syncthreads();
+    const int nflag = *s_nflag;
+    for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Q, T, nt, s_flag[fidx], od, oi, s_xred, s_xfi);
 }
 
 // ---------------------------------------------------------------------------
@@ -388,6 +405,7 @@ __global__ __launch_bounds__(kBlock) void nn_mfma_kernel(NNArgs a)
     };
 
     float tmax2 = 0.0f;
+    float nf = 0.0f;      // NaN once a target of the slice had a non-finite coordinate
     for (int t0 = k_begin; t0 < k_end && !(a.debug & 4); t0 += kMTile) {
         const int tn = min(kMTile, k_end - t0);
         const int tn_pad = (tn + 2 * kC - 1) / (2 * kC) * (2 * kC);
@@ -399,6 +417,7 @@ __global__ __launch_bounds__(kBlock) void nn_mfma_kernel(NNArgs a)
                 const float x = tp[0] - cx, y = tp[1] - cy, z = tp[2] - cz;
                 tt = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
                 tmax2 = fmaxf(tmax2, tt);
+                nf = __fmaf_rn(tt, 0.0f, nf);        // inf x 0 = NaN, NaN sticks (v_max drops NaNs)
                 ax = -2.0f * x; ay = -2.0f * y; az = -2.0f * z;
             }
             plane[0][t] = make_float2(ax, az);
@@ -436,7 +455,9 @@ __global__ __launch_bounds__(kBlock) void nn_mfma_kernel(NNArgs a)
         top3_insert(lo, hi.a3, -1);
         st[r] = lo;
     }
-    // slice maximum of |t'|^2
+    // slice maximum of |t'|^2; +inf when a target is not finite: every query is then answered by
+    // nn_exhaustive, which reproduces the reference's tile semantics for NaNs
+    if (nf != nf) tmax2 = __builtin_inff();
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, o));
     __syncthreads();
@@ -512,6 +533,7 @@ __global__ __launch_bounds__(kBlock) void nn_mfma_kernel(NNArgs a)
             if (!nn_safe(f.a1, f.a3, qq[r], tmax2) || f.c2 < 0) flag = true;
         }
         if (f.c1 < 0 || (a.debug & 8)) flag = true;
+        if (!(tmax2 < __builtin_inff()) || !(qq[r] < __builtin_inff())) flag = true;      // non-finite input
         const int j = q0 + r * 32;
         if (flag) {
             if (!half && j < nq) s_flag[atomicAdd(&s_misc[1], 1)] = j;
@@ -532,45 +554,11 @@ __global__ __launch_bounds__(kBlock) void nn_mfma_kernel(NNArgs a)
     }
     __syncthreads();
     const int nflag = s_misc[1];
-    for (int fidx = 0; fidx < nflag; fidx++) {
-        // exhaustive, reference arithmetic, whole block on one query
-        const int j = s_flag[fidx];
-        const float x = Qp[(size_t)j * 3 + 0], y = Qp[(size_t)j * 3 + 1], z = Qp[(size_t)j * 3 + 2];
-        float bd = __builtin_inff();
-        int bi = 0x7fffffff;
-        for (int k = threadIdx.x; k < nt; k += kBlock) {
-            const float *tp = T + (size_t)k * 3;
-            const float dd = sqdist<FMA>(tp[0] - x, tp[1] - y, tp[2] - z);
-            const bool lt = dd < bd;
-            bd = lt ? dd : bd;
-            bi = lt ? k : bi;
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float obd = __shfl_xor(bd, o);
-            const int obi = __shfl_xor(bi, o);
-            const bool other = obd < bd || (obd == bd && obi < bi);
-            bd = other ? obd : bd;
-            bi = other ? obi : bi;
-        }
-        __syncthreads();
-        if (lane == 0) { s_red[wave] = bd; s_fi[wave] = bi; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < kWavesPerBlock; w++) {
-                const bool other = s_red[w] < bd || (s_red[w] == bd && s_fi[w] < bi);
-                bd = other ? s_red[w] : bd;
-                bi = other ? s_fi[w] : bi;
-            }
-            od[j] = bd;
-            // every distance NaN (non-finite input): the reference keeps target 0's distance and index 0
-            if (bi == 0x7fffffff) {
-                od[j] = sqdist<FMA>(T[0] - x, T[1] - y, T[2] - z);
-                bi = 0;
-            }
-            oi[j] = bi;
-        }
+    if (a.stats && threadIdx.x == 0) {
+        atomicAdd(&a.stats[0], (unsigned long long)min(128 * Q, nq - qb * 128 * Q));
+        atomicAdd(&a.stats[1], (unsigned long long)nflag);
     }
+    for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Qp, T, nt, s_flag[fidx], od, oi, s_red, s_fi);
 }
 
 // Chamfer backward, both directions in one launch (chamfer3D.cu:155-195).
@@ -617,23 +605,33 @@ struct NNConfig {
     int mfma;             // 3: two-piece f16 MFMA filter (default), 2: three-piece bf16, 1: fp32 MFMA filter, 0: VALU path
     int q;                // MFMA path, 32-query tiles per wave: 0 = pick, else 1 or 2
     int u;                // MFMA path, tiles per bookkeeping unit: 0 = pick, else 1 or 2
+    bool env_path, env_wps;   // GENPC_NN_PATH / GENPC_NN_WPS were given
+    int dbg;              // GENPC_NN_DEBUG
+    int pre;              // GENPC_NN_PRE (-1: not given)
 };
 
-// genpc_nn_tune() overrides (-1: use the environment / default)
-static int g_tune_path = -1, g_tune_hooks = -1;
+// genpc_nn_tune() overrides (-1: use the environment / default).  Thread-local: a test that
+// switches kernel families does not change what other host threads launch.
+static thread_local int t_tune_path = -1, t_tune_hooks = -1;
 
-// Tunables; GENPC_NN_R / GENPC_NN_WPS override for experiments.
-static NNConfig nn_config()
+// Tunables; the environment is read ONCE, at first use (C++11 static initialisation is
+// thread-safe), never per launch.
+static const NNConfig &nn_config()
 {
-    static NNConfig c = [] {
-        NNConfig k{0, 4, 3, 0, 0};
+    static const NNConfig c = [] {
+        NNConfig k{0, 4, 3, 0, 0, false, false, 0, -1};
         if (const char *e = getenv("GENPC_NN_R")) k.r = atoi(e);
-        if (const char *e = getenv("GENPC_NN_PATH")) k.mfma = (e[0] == 'v') ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'b' ? 2 : 3));
+        if (const char *e = getenv("GENPC_NN_PATH")) {
+            k.mfma = (e[0] == 'v') ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'b' ? 2 : 3));
+            k.env_path = true;
+        }
         if (const char *e = getenv("GENPC_NN_Q")) k.q = atoi(e);
         if (const char *e = getenv("GENPC_NN_U")) k.u = atoi(e);
         if (k.q != 1 && k.q != 2 && k.q != 4) k.q = 0;
         if (k.u != 1 && k.u != 2 && k.u != 4) k.u = 0;
-        if (const char *e = getenv("GENPC_NN_WPS")) k.blocks_per_cu = atoi(e);
+        if (const char *e = getenv("GENPC_NN_WPS")) { k.blocks_per_cu = atoi(e); k.env_wps = true; }
+        if (const char *e = getenv("GENPC_NN_DEBUG")) k.dbg = atoi(e);
+        if (const char *e = getenv("GENPC_NN_PRE")) k.pre = atoi(e);
         if (k.r != 2 && k.r != 4) k.r = 0;
         if (k.blocks_per_cu < 1) k.blocks_per_cu = 1;
         return k;
@@ -644,7 +642,7 @@ static NNConfig nn_config()
 template <int Q, int U>
 static void launch_mfma(const NNArgs &a, int blocks, hipStream_t st)
 {
-    if (arith_mode() != 0)
+    if (a.fma)
         hipLaunchKernelGGL((nn_mfma_kernel<Q, U, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
     else
         hipLaunchKernelGGL((nn_mfma_kernel<Q, U, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
@@ -653,7 +651,7 @@ static void launch_mfma(const NNArgs &a, int blocks, hipStream_t st)
 template <int R>
 static void launch_r(const NNArgs &a, int blocks, hipStream_t st)
 {
-    if (arith_mode() != 0)
+    if (a.fma)
         hipLaunchKernelGGL((nn_forward_kernel<R, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
     else
         hipLaunchKernelGGL((nn_forward_kernel<R, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
@@ -665,11 +663,15 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // A direction with no queries or no targets does nothing (the reference's
     // loops do not execute, outputs keep the caller's zeros).
     NNConfig cfg = nn_config();
-    if (g_tune_path >= 0) cfg.mfma = g_tune_path;
+    if (t_tune_path >= 0) cfg.mfma = t_tune_path;
     NNArgs a{};
     a.b = b;
-    static const int dbg = getenv("GENPC_NN_DEBUG") ? atoi(getenv("GENPC_NN_DEBUG")) : 0;
-    a.debug = g_tune_hooks >= 0 ? g_tune_hooks : dbg;
+    a.fma = arith_mode() != 0 ? 1 : 0;
+    a.debug = t_tune_hooks >= 0 ? t_tune_hooks : cfg.dbg;
+    if (a.debug & 512) {
+        a.stats = (unsigned long long *)workspace(12, 256, nullptr, nullptr, 256);      // one block per device, shared by all streams
+        if (!a.stats) return 0;
+    }
     const float *qs[2] = {q0, q1};
     const float *ts[2] = {t0, t1};
     float *ds[2] = {d0, d1};
@@ -691,7 +693,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     for (int d = 0; d < nd; d++) pairs += (double)b * a.dir[d].nq * a.dir[d].nt;
     // measured on MI355X (tools/nn_sweep.py): below ~6M pairs the single-launch fp32-MFMA
     // kernel wins (1x1024^2 11.0 vs 13.5 us), from 2048^2 on the two-launch f16 filter
-    if (path == 3 && pairs < 6e6 && g_tune_path < 0 && !getenv("GENPC_NN_PATH")) path = 1;
+    if (path == 3 && pairs < 6e6 && t_tune_path < 0 && !cfg.env_path) path = 1;
     const bool f16 = path == 3;      // same planning as the bf16 path, other kernel
     if (f16) path = 2;
     if (path == 2 && nt_max >= (1 << 25)) path = 1;      // finish kernel packs tile indices in 21 bits
@@ -718,7 +720,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     }
     // bf16 / f16 filters: at least two accumulator chains per wave (see the hazard note in nn_f16.hip)
     if (path == 2 && q < 2) q = 2;
-    if (path == 2 && !getenv("GENPC_NN_WPS")) want_blocks = (long long)kNumCU * (q == 4 ? 2 : (q == 2 ? 3 : 4));   // resident blocks per CU (VGPRs)
+    if (path == 2 && !cfg.env_wps) want_blocks = (long long)kNumCU * (q == 4 ? 2 : (q == 2 ? 3 : 4));   // resident blocks per CU (VGPRs)
     const int qper = path ? 128 * q : kBlock * r;       // queries per block
     const int gran = path == 2 ? 128 : (path ? 64 : kChunk);   // slice granularity: one bookkeeping unit
     int pwords = path ? 3 : 1;                          // 8-byte words per (slice, query)
@@ -772,7 +774,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         long long best_len = 0;
         double best_cost = 0.0;
         int best_res = 0;
-        const bool env_wps = getenv("GENPC_NN_WPS") != nullptr;
+        const bool env_wps = cfg.env_wps;
         for (int res = (f16 && q == 4 && !env_wps) ? 3 : 0; res != 1 && res >= 0; res = (res == 3 ? 2 : -1)) {
             const long long slots = res ? (long long)kNumCU * res : want_blocks;
             const double per_block = res == 3 ? 3.0 * 0.96 : (res == 2 ? 2.0 : 1.0);
@@ -847,8 +849,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
             const int fu = cfg.u == 2 || cfg.u == 4 ? cfg.u : (nt_max <= 8192 ? 2 : 4);
             return launch_nn_f16(a, q, fu, nl, tight ? 1 : 0, tb, st);
         }
-        static const int pre_env = getenv("GENPC_NN_PRE") ? atoi(getenv("GENPC_NN_PRE")) : -1;
-        const int pre = pre_env >= 0 ? pre_env : ((a.debug & 256) ? 1 : 0);      // measured: 13x16384^2 401+8 us vs 410 us, 1x16384^2 35+5 vs 36 -- does not pay
+        const int pre = cfg.pre >= 0 ? cfg.pre : ((a.debug & 256) ? 1 : 0);      // measured: 13x16384^2 401+8 us vs 410 us, 1x16384^2 35+5 vs 36 -- does not pay
         return launch_nn_bf16(a, q, pre, nl, tb, st);
     } else if (path) {
         if (q == 2) { if (u == 2) launch_mfma<2, 2>(a, (int)tb, st); else launch_mfma<2, 1>(a, (int)tb, st); }
@@ -865,10 +866,21 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
 
 GENPC_API int genpc_nn_tune(int path, int hooks)
 {
-    const int prev = genpc::g_tune_path >= 0 ? genpc::g_tune_path : genpc::nn_config().mfma;
-    if (path >= 0 && path <= 3) genpc::g_tune_path = path;
-    if (hooks >= 0) genpc::g_tune_hooks = hooks;
+    const int prev = genpc::t_tune_path >= 0 ? genpc::t_tune_path : genpc::nn_config().mfma;
+    if (path >= 0 && path <= 3) genpc::t_tune_path = path;
+    if (hooks >= 0) genpc::t_tune_hooks = hooks;
     return prev;
+}
+
+GENPC_API int genpc_nn_stats(unsigned long long out[3], int reset, void *stream)
+{
+    using namespace genpc;
+    unsigned long long *dev = (unsigned long long *)workspace(12, 256, nullptr, nullptr, 256);
+    if (!dev) return 0;
+    if (!check(hipStreamSynchronize((hipStream_t)stream), "genpc_nn_stats sync")) return 0;
+    if (!check(hipMemcpy(out, dev, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost), "genpc_nn_stats copy")) return 0;
+    if (reset && !check(hipMemset(dev, 0, 256), "genpc_nn_stats reset")) return 0;
+    return 1;
 }
 
 GENPC_API int genpc_chamfer_forward(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1,

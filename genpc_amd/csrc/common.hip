@@ -2,6 +2,7 @@
 #include "common.h"
 #include "../../include/genpc_hip.h"
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -10,7 +11,12 @@ namespace genpc {
 
 static std::mutex g_mu;
 static std::string g_err;
-static int g_arith = GENPC_ARITH_FMA;
+// Arithmetic mode: a process-wide default (atomic: concurrent host threads -- the reference wraps
+// EMD in DataParallel, one Python thread per GPU -- may read it while another sets it) and a
+// per-thread override.  Every entry point reads the mode ONCE and hands it down, so a change made
+// by another thread never splits one call between two modes.
+static std::atomic<int> g_arith{GENPC_ARITH_FMA};
+static thread_local int t_arith = -1;
 
 struct Slot {
     void *ptr = nullptr;
@@ -45,7 +51,7 @@ bool check(hipError_t e, const char *what)
     return false;
 }
 
-int arith_mode() { return g_arith; }
+int arith_mode() { return t_arith >= 0 ? t_arith : g_arith.load(std::memory_order_relaxed); }
 
 void *workspace(int slot, size_t bytes, hipStream_t stream, bool *fresh, size_t zero_prefix)
 {
@@ -89,7 +95,7 @@ void *workspace(int slot, size_t bytes, hipStream_t stream, bool *fresh, size_t 
 
 }  // namespace genpc
 
-GENPC_API int genpc_abi_version(void) { return 8; }
+GENPC_API int genpc_abi_version(void) { return 9; }
 
 GENPC_API const char *genpc_last_error(void)
 {
@@ -101,12 +107,17 @@ GENPC_API const char *genpc_last_error(void)
 
 GENPC_API int genpc_set_arith(int mode)
 {
-    int prev = genpc::g_arith;
-    genpc::g_arith = mode ? GENPC_ARITH_FMA : GENPC_ARITH_STRICT;
+    return genpc::g_arith.exchange(mode ? GENPC_ARITH_FMA : GENPC_ARITH_STRICT);
+}
+
+GENPC_API int genpc_set_arith_thread(int mode)
+{
+    const int prev = genpc::t_arith;
+    genpc::t_arith = mode < 0 ? -1 : (mode ? GENPC_ARITH_FMA : GENPC_ARITH_STRICT);
     return prev;
 }
 
-GENPC_API int genpc_get_arith(void) { return genpc::g_arith; }
+GENPC_API int genpc_get_arith(void) { return genpc::arith_mode(); }
 
 GENPC_API int genpc_release_workspace(void)
 {

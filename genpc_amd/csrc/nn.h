@@ -50,6 +50,8 @@ struct NNArgs {
     int slice_len;     // targets per slice (all blocks of a launch do equal work), multiple of kChunk
     int *arrive;       // [sum_d b*qblocks] arrival counters, zero between launches
     int debug;         // experiment switches (GENPC_NN_DEBUG): 1 skip index recovery, 2 skip merge, 4 skip main loop
+    int fma;           // arithmetic mode of this call (read once at the entry point; host side only)
+    unsigned long long *stats;   // hook 512: [0] queries, [1] exhaustive re-dos, [2] exact pieces; else null
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -129,21 +131,48 @@ __device__ __forceinline__ int tile_row(int w) { return 8 * ((w >> 2) & 3) + 4 *
 
 // The whole block evaluates query j against every target with the reference's
 // arithmetic and writes (distance, first index): the last resort of the filtered
-// paths (three or more tiles within the error bound, non-finite input).
+// paths (three or more tiles within the error bound) and the ONLY path for non-finite
+// input, where the reference's tiling shows (chamfer3D.cu:15-36,126): targets are scanned
+// in tiles of 512, the first target of a tile initialises the tile's best unconditionally,
+// so a NaN distance there makes every later 'd<best' false and the tile's NaN then fails
+// 'result>best' -- the whole tile is dropped; for tile 0 the NaN is the result (index 0)
+// and is never replaced.  A NaN elsewhere only drops that target; with nothing below +inf
+// the first target stays.  Must be called by all threads of the block.
+constexpr int kRefTile = 512;    // chamfer3D.cu:13 `const int batch=512`
 template <int FMA>
 __device__ __forceinline__ void nn_exhaustive(const float *__restrict__ Qp, const float *__restrict__ T, int nt, int j,
                                               float *__restrict__ od, int *__restrict__ oi, float *s_red, int *s_fi)
 {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const float x = Qp[(size_t)j * 3 + 0], y = Qp[(size_t)j * 3 + 1], z = Qp[(size_t)j * 3 + 2];
+    // does any tile start with a NaN distance?
+    int dead = 0;
+    for (int k = threadIdx.x * kRefTile; k < nt; k += kBlock * kRefTile) {
+        const float *tp = T + (size_t)k * 3;
+        const float hd = sqdist<FMA>(tp[0] - x, tp[1] - y, tp[2] - z);
+        dead |= hd != hd;
+    }
+    dead = __syncthreads_or(dead);
     float bd = __builtin_inff();
     int bi = 0x7fffffff;
-    for (int k = threadIdx.x; k < nt; k += kBlock) {
-        const float *tp = T + (size_t)k * 3;
-        const float dd = sqdist<FMA>(tp[0] - x, tp[1] - y, tp[2] - z);
-        const bool lt = dd < bd;
-        bd = lt ? dd : bd;
-        bi = lt ? k : bi;
+    if (!dead) {
+        for (int k = threadIdx.x; k < nt; k += kBlock) {
+            const float *tp = T + (size_t)k * 3;
+            const float dd = sqdist<FMA>(tp[0] - x, tp[1] - y, tp[2] - z);
+            const bool lt = dd < bd;
+            bd = lt ? dd : bd;
+            bi = lt ? k : bi;
+        }
+    } else {
+        for (int k = threadIdx.x; k < nt; k += kBlock) {
+            const float *hp = T + (size_t)(k & ~(kRefTile - 1)) * 3;
+            const float hd = sqdist<FMA>(hp[0] - x, hp[1] - y, hp[2] - z);
+            const float *tp = T + (size_t)k * 3;
+            const float dd = sqdist<FMA>(tp[0] - x, tp[1] - y, tp[2] - z);
+            const bool lt = dd < bd && hd == hd;
+            bd = lt ? dd : bd;
+            bi = lt ? k : bi;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -162,9 +191,11 @@ __device__ __forceinline__ void nn_exhaustive(const float *__restrict__ Qp, cons
             bd = other ? s_red[w] : bd;
             bi = other ? s_fi[w] : bi;
         }
-        // every distance NaN (non-finite input): keep target 0, as a strict '<' scan does
-        if (bi == 0x7fffffff) {
-            bd = sqdist<FMA>(T[0] - x, T[1] - y, T[2] - z);
+        // tile 0 starts with a NaN: that NaN at index 0 is the result; nothing compared below
+        // +inf: the scan's unconditional first assignment (target 0) stands
+        const float d0 = sqdist<FMA>(T[0] - x, T[1] - y, T[2] - z);
+        if (d0 != d0 || bi == 0x7fffffff) {
+            bd = d0;
             bi = 0;
         }
         od[j] = bd;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void nn_split_kernel(SplitArgs a)
         o[(size_t)2 * J.np] = Z;
         o[(size_t)3 * J.np] = W;
     }
-    float m = tt;
+    float m = (tt * 0.0f != 0.0f) ? __builtin_inff() : tt;      // non-finite target: +inf (see nn_finish_kernel)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & (kWave - 1)) == 0) s_red[threadIdx.x >> 6] = m;
@@ -253,6 +253,7 @@ __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
         }
     };
     float tmax2 = 0.0f;
+    float nf = 0.0f;      // NaN once a target of the slice had a non-finite coordinate
     // pre-split path: wave w copies plane w of a tile, 64 rows (1 KiB) per instruction
     const uint4 *__restrict__ AR = D.arec + ((size_t)batch * 4 + wave) * D.ntp;
     auto dma = [&](int buf, int t0, int rows) {
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
                     W = make_uint4(0x7f80u, 0u, 0u, 0u);
                 } else {
                     tmax2 = fmaxf(tmax2, tt);
+                    nf = __fmaf_rn(tt, 0.0f, nf);
                 }
                 const int row = (t & ~31) | tile_row(t & 31);
                 plane[0][0][row] = X;
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
     // the same targets: the first one publishes)
     if (!PRE && qb == 0) {
         __shared__ float s_red[kWavesPerBlock];
+        if (nf != nf) tmax2 = __builtin_inff();      // non-finite targets: every query of the cloud goes exhaustive
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, o));
         if (lane == 0) s_red[wave] = tmax2;
@@ -519,6 +522,9 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         qq = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
         float t = nn_tau(abest, qq, tmax2, (double)kqt, (double)ktt);
         if (!(tmax2 >= t2min)) t = __builtin_nanf("");      // below the magnitudes the filter's bound covers: exhaustive
+        // non-finite targets anywhere in the cloud (the filter publishes +inf) or a non-finite query:
+        // the reference's result depends on its 512-target tiling, only nn_exhaustive reproduces it
+        if (!(tmax2 < __builtin_inff()) || !(qq < __builtin_inff())) t = __builtin_nanf("");
         if (a.debug & 16) t = __builtin_inff();          // test hook: every listed tile is evaluated
         s_tau[ql] = t;
         s_qq[ql] = qq;
@@ -587,13 +593,18 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     }
     __syncthreads();
     const int nflag = s_misc[1];
+    if (a.stats && threadIdx.x == 0) {
+        atomicAdd(&a.stats[0], (unsigned long long)min(kFQ, nq - fb * kFQ));
+        atomicAdd(&a.stats[1], (unsigned long long)nflag);
+        atomicAdd(&a.stats[2], (unsigned long long)nwork);
+    }
     for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Qp, T, nt, s_flagged[fidx], od, oi, s_red, s_fi);
 }
 
 template <int Q, int U, int NL, int PRE>
 static void launch_main2(const NNArgs &a, int blocks, hipStream_t st)
 {
-    if (arith_mode() != 0)
+    if (a.fma)
         hipLaunchKernelGGL((nn_bf16_kernel<Q, U, NL, 1, PRE>), dim3(blocks), dim3(kBlock), 0, st, a);
     else
         hipLaunchKernelGGL((nn_bf16_kernel<Q, U, NL, 0, PRE>), dim3(blocks), dim3(kBlock), 0, st, a);
@@ -672,7 +683,7 @@ int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float
         set_error("chamfer: problem too large for one launch");
         return 0;
     }
-    if (arith_mode() != 0)
+    if (a.fma)
         hipLaunchKernelGGL((nn_finish_kernel<1>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, upieces, kqt, ktt, t2min);
     else
         hipLaunchKernelGGL((nn_finish_kernel<0>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, upieces, kqt, ktt, t2min);

@@ -104,7 +104,9 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
         // lanes < 32 carry x and y of the query, lanes >= 32 z
         qc0[r] = Qp[(size_t)j * 3 + (half ? 2 : 0)] - (half ? cz : cx);
         qc1[r] = half ? 0.0f : Qp[(size_t)j * 3 + 1] - cy;
-        mx = fmaxf(mx, fmaxf(fabsf(qc0[r]), fabsf(qc1[r])));
+        // a query at infinity is answered by the exhaustive pass; it must not set the block's scale
+        const float m0 = fabsf(qc0[r]), m1 = fabsf(qc1[r]);
+        mx = fmaxf(mx, fmaxf(m0 < __builtin_inff() ? m0 : 0.0f, m1 < __builtin_inff() ? m1 : 0.0f));
     }
     for (int t = k_begin + threadIdx.x; t < k_end; t += kBlock) {
         const float *tp = T + (size_t)t * 3;
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
         }
     };
     float tmax2 = 0.0f;
+    float nf = 0.0f;      // NaN once a target of the slice had a non-finite coordinate
     if (k_begin < k_end) prefetch(k_begin);
     for (int t0 = k_begin; t0 < k_end && !(a.debug & 4); t0 += kHTile) {
         const int tn = min(kHTile, k_end - t0);
@@ -198,7 +201,9 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
                     V0 = make_uint4(0u, 0u, 0u, 0u);
                     V1 = make_uint4(0u, 0u, 0x7c00u, 0u);
                 } else {
-                    tmax2 = fmaxf(tmax2, __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
+                    const float tt = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
+                    tmax2 = fmaxf(tmax2, tt);
+                    nf = __fmaf_rn(tt, 0.0f, nf);        // inf x 0 = NaN, NaN sticks (v_max drops NaNs)
                 }
                 const int row = (t & ~31) | tile_row(t & 31);
                 plane[0][row] = V0;
@@ -244,6 +249,9 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
     // max |t'|^2 of the slice, for the bound in nn_finish_kernel (every query block sees
     // the same targets: the first one publishes)
     if (qb == 0) {
+        // non-finite targets: +inf tells nn_finish_kernel to answer every query of this cloud
+        // exhaustively (the reference's tile semantics for NaNs, nn_exhaustive in nn.h)
+        if (nf != nf) tmax2 = __builtin_inff();
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, o));
         __syncthreads();

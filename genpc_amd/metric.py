@@ -30,10 +30,14 @@ def evaluate_scans(pred, gt, eps=0.005, iters=50):
     return torch.stack([cd_l1, cd_l2, emd], dim=1)
 
 
-def evaluate_sharded(pred_np, gt_np, device=None, max_batch=16):
-    """Round-robin shard of the S scans over the ranks of the default process group;
-    every rank returns the full [S,3] table (scan order)."""
-    rank, local_rank, world = sharding.env_world()
+def evaluate_sharded(pred_np, gt_np, device=None, max_batch=16, metric_fn=None, backend=None):
+    """Round-robin shard of the S scans over the ranks of the default process group
+    (initialised here if the launcher's WORLD_SIZE > 1 and nobody did yet); every rank
+    returns the full [S,K] table (scan order).  metric_fn(pred[S',N,3], gt[S',N,3]) ->
+    [S',K] defaults to evaluate_scans (K = 3: CD-L1, CD-L2, EMD)."""
+    rank, local_rank, world = sharding.init(backend)
+    if metric_fn is None:
+        metric_fn = evaluate_scans
     if device is None:
         device = torch.device("cuda", local_rank)
     s_total = pred_np.shape[0]
@@ -43,8 +47,12 @@ def evaluate_sharded(pred_np, gt_np, device=None, max_batch=16):
         sel = mine[i:i + max_batch]
         p = torch.from_numpy(np.ascontiguousarray(pred_np[sel])).to(device)
         g = torch.from_numpy(np.ascontiguousarray(gt_np[sel])).to(device)
-        rows.append(evaluate_scans(p, g))
-    local = torch.cat(rows) if rows else torch.empty(0, 3, device=device)
+        rows.append(metric_fn(p, g))
+    if rows:
+        local = torch.cat(rows)
+    else:      # more ranks than scans: this rank owns none; K from a zero-scan call is not available
+        local = torch.empty(0, 3 if metric_fn is evaluate_scans else int(os.environ.get("GENPC_METRIC_COLUMNS", "3")),
+                            device=device)
     return sharding.gather_scan_metrics(local, s_total, rank, world)
 
 

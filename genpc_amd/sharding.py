@@ -75,8 +75,16 @@ def gather_scan_metrics(local, n_items, rank, world):
     (13 scans over 4 ranks), so rows are padded to the maximum before the gather."""
     k = local.shape[1] if local.dim() == 2 else 1
     local = local.reshape(-1, k)
-    if world == 1 or not dist.is_initialized():
+    n_mine = len(shard_indices(n_items, rank, world))
+    if local.shape[0] != n_mine:
+        raise ValueError("gather_scan_metrics: rank %d of %d owns %d of %d scans but was handed %d rows"
+                         % (rank, world, n_mine, n_items, local.shape[0]))
+    if world == 1:
         return local.clone()
+    if not dist.is_initialized():
+        # a [n_local, K] table passed off as the full one would misalign every scan id
+        raise RuntimeError("gather_scan_metrics: WORLD_SIZE is %d but torch.distributed is not initialised "
+                           "(call genpc_amd.sharding.init() first)" % world)
     per = (n_items + world - 1) // world
     pad = torch.full((per, k), float("nan"), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
@@ -87,4 +95,15 @@ def gather_scan_metrics(local, n_items, rank, world):
         idx = shard_indices(n_items, r, world)
         if idx:
             table[torch.tensor(idx, device=local.device)] = out[r][: len(idx)]
+    assert table.shape[0] == n_items
     return table
+
+
+def all_ranks(device="cpu"):
+    """The ranks that answer an all_gather, in order (bench.py's `ranks_seen`)."""
+    if not dist.is_initialized():
+        return [0]
+    mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device=device)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [int(t.item()) for t in out]

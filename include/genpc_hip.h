@@ -13,7 +13,9 @@
  *   - return 1 = ok, 0 = HIP error (message on stderr, genpc_last_error()),
  *     -1 = invalid shape (EMD: n != m, B > 512, n % 256 != 0).
  *
- * Arithmetic mode (genpc_set_arith / genpc_get_arith), process-wide:
+ * Arithmetic mode: genpc_set_arith sets the process-wide default, genpc_set_arith_thread
+ * an override for the calling host thread (< 0 removes it); genpc_get_arith returns what a
+ * call made by this thread would use.  An entry point reads the mode once, at entry.
  *   GENPC_ARITH_FMA (default)  d = fma(dz,dz, fma(dx,dx, dy*dy))  -- the
  *       contraction nvcc's default -fmad=true applies to the reference's
  *       `x2*x2+y2*y2+z2*z2`;
@@ -33,7 +35,8 @@ extern "C" {
 /* Library / device ------------------------------------------------------- */
 int genpc_abi_version(void);              /* bumps when a signature changes */
 const char *genpc_last_error(void);       /* last HIP error string, "" if none */
-int genpc_set_arith(int mode);            /* returns the previous mode */
+int genpc_set_arith(int mode);            /* process default; returns the previous one */
+int genpc_set_arith_thread(int mode);     /* calling thread only, < 0: follow the default; returns the previous override */
 int genpc_get_arith(void);
 /* Frees the per-device scratch pool (split-target partials, EMD lists). */
 int genpc_release_workspace(void);
@@ -41,9 +44,17 @@ int genpc_release_workspace(void);
  * the same bits.  path: 3 one-f16-MFMA filter (default), 2 split-bf16 MFMA filter,
  * 1 fp32-MFMA filter, 0 VALU brute force, < 0 keep.  hooks: bit mask of test hooks
  * (8: every query takes the exhaustive pass, 16: every listed tile is evaluated
- * exactly, 256: bf16 path with pre-split targets staged by LDS-DMA), < 0 keep.  Returns the previous path.  Environment: GENPC_NN_PATH
- * (valu | mfma32 | bf16 | f16), GENPC_NN_DEBUG.                                 */
+ * exactly, 256: bf16 path with pre-split targets staged by LDS-DMA, 512: count what the
+ * filtered paths do, see genpc_nn_stats), < 0 keep.  Applies to calls made by the CALLING
+ * host thread only (thread-local; other threads keep the defaults).  Returns the previous
+ * path.  Environment (read once, at first use): GENPC_NN_PATH (valu | mfma32 | bf16 |
+ * f16), GENPC_NN_DEBUG.                                                          */
 int genpc_nn_tune(int path, int hooks);
+/* Counters of the filtered nearest-neighbour paths, accumulated on the current device
+ * while hook 512 is set: out[0] queries answered, out[1] queries re-done by the exhaustive
+ * pass (filter proof failed: exact ties, non-finite input), out[2] exact re-evaluations of
+ * 16-/32-target pieces.  Synchronises `stream`; reset != 0 zeroes them afterwards.      */
+int genpc_nn_stats(unsigned long long out[3], int reset, void *stream);
 /* Kernel-level timing for bench.py: while enabled, HIP events bracket the filter kernel
  * (nn_f16_kernel) of every nearest-neighbour call on its stream.  Returns the duration
  * in ms of the last bracketed launch (-1 if none), then sets the switch to `enable`. */

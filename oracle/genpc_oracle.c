@@ -73,11 +73,22 @@ ORACLE_API void oracle_set_num_threads(int t)
  * Chamfer forward, one direction.
  * Follows loss_functions/Chamfer3D/chamfer3D.cu:12-134 (NmDistanceKernel):
  *   dx = xyz2[k] - xyz[j] (target minus query, :32-34), d = x2*x2+y2*y2+z2*z2
- *   (:35), strict '<' so the lowest index wins ties (:36,46,56,66,119), tiles of
- *   512 merged with 'result > best' (:126) which again keeps the earlier tile.
- *   The tiling therefore does not change the answer and is not restated.
+ *   (:35); targets are scanned in tiles of 512 (:13,15-16); inside a tile the
+ *   first target initialises `best` unconditionally and later ones replace it
+ *   on a strict '<' (:36,46,56,66,119: 'k==0 || d<best'), so the lowest index
+ *   wins ties; a tile's (best, best_i) replaces the running result on
+ *   'k2==0 || result>best' (:126), which keeps the earlier tile on ties.
+ *   For finite input the tiling does not change the answer.  For non-finite
+ *   input it does, and the restatement keeps it: a NaN distance at the FIRST
+ *   target of a tile makes that tile's best NaN (every later 'd<best' is
+ *   false), and 'result>NaN' is false, so the whole tile is dropped -- unless
+ *   it is tile 0, whose NaN becomes the result and is never replaced
+ *   ('NaN>best' is false).  A NaN distance elsewhere in a tile only drops
+ *   that one target.  The 4-way unrolling (:29-115) does not change the order
+ *   of the comparisons and is not restated.
  *   m == 0 leaves result untouched (the k2 loop body never runs).
  * ---------------------------------------------------------------------- */
+#define NM_TILE 512   /* chamfer3D.cu:13 `const int batch=512` */
 ORACLE_API void oracle_nm_distance(int b, int n, const float *xyz, int m,
                                    const float *xyz2, float *result,
                                    int *result_i, int fma_mode)
@@ -89,20 +100,29 @@ ORACLE_API void oracle_nm_distance(int b, int n, const float *xyz, int m,
 #pragma omp parallel for schedule(static)
         for (int j = 0; j < n; j++) {
             float x1 = q[j * 3 + 0], y1 = q[j * 3 + 1], z1 = q[j * 3 + 2];
-            float best = 0;
-            int best_i = 0;
-            for (int k = 0; k < m; k++) {
-                float x2 = t[k * 3 + 0] - x1;
-                float y2 = t[k * 3 + 1] - y1;
-                float z2 = t[k * 3 + 2] - z1;
-                float d = sqdist(x2, y2, z2, fma_mode);
-                if (k == 0 || d < best) {
-                    best = d;
-                    best_i = k;
+            float res = 0;
+            int res_i = 0;
+            for (int k2 = 0; k2 < m; k2 += NM_TILE) {
+                int end_k = (m < k2 + NM_TILE ? m : k2 + NM_TILE) - k2;
+                float best = 0;
+                int best_i = 0;
+                for (int k = 0; k < end_k; k++) {
+                    float x2 = t[(k2 + k) * 3 + 0] - x1;
+                    float y2 = t[(k2 + k) * 3 + 1] - y1;
+                    float z2 = t[(k2 + k) * 3 + 2] - z1;
+                    float d = sqdist(x2, y2, z2, fma_mode);
+                    if (k == 0 || d < best) {
+                        best = d;
+                        best_i = k + k2;
+                    }
+                }
+                if (k2 == 0 || res > best) {
+                    res = best;
+                    res_i = best_i;
                 }
             }
-            result[(size_t)i * n + j] = best;
-            result_i[(size_t)i * n + j] = best_i;
+            result[(size_t)i * n + j] = res;
+            result_i[(size_t)i * n + j] = res_i;
         }
     }
 }

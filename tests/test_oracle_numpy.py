@@ -169,3 +169,71 @@ def test_fps_and_ply_reader(oracle, tmp_path):
         dd = ((x - x[idx[s]]) ** 2)
         d = np.minimum(d, (dd[:, 0] + dd[:, 1]) + dd[:, 2])
         assert idx[s + 1] == int(np.argmax(d))
+
+
+def py_nm_distance_literal(q, t):
+    """Loop-for-loop reading of NmDistanceKernel's control flow for one batch element
+    (chamfer3D.cu:15-129), fp32 without contraction: tiles of 512, the 4-way unrolled
+    body with its 'k==0 ||' only on the first slot (:36), the scalar tail (:113-124) and
+    the 'k2==0 || result>best' merge (:126).  Slow; small cases only."""
+    f = np.float32
+    n, m = q.shape[0], t.shape[0]
+    res = np.zeros(n, np.float32)
+    res_i = np.zeros(n, np.int32)
+
+    def dist(j, k):
+        x2, y2, z2 = f(t[k, 0] - q[j, 0]), f(t[k, 1] - q[j, 1]), f(t[k, 2] - q[j, 2])
+        return f(f(f(x2 * x2) + f(y2 * y2)) + f(z2 * z2))
+
+    with np.errstate(invalid="ignore", over="ignore"):
+        for k2 in range(0, m, 512):
+            end_k = min(m, k2 + 512) - k2
+            end_ka = end_k - (end_k & 3)
+            for j in range(n):
+                best_i, best = 0, f(0)
+                for k in range(0, end_ka, 4):
+                    for s in range(4):
+                        d = dist(j, k2 + k + s)
+                        if (s == 0 and k == 0) or d < best:
+                            best, best_i = d, k + k2 + s
+                for k in range(end_ka, end_k):
+                    d = dist(j, k2 + k)
+                    if k == 0 or d < best:
+                        best, best_i = d, k + k2
+                if k2 == 0 or res[j] > best:
+                    res[j], res_i[j] = best, best_i
+    return res, res_i
+
+
+def test_chamfer_non_finite_follows_the_tile_structure(oracle):
+    """NaN / inf inputs: the oracle must reproduce what the reference's tiled scan does --
+    a NaN distance at the first target of a 512-tile discards that tile (tile 0: the result
+    is that NaN at index 0), a NaN elsewhere drops one target (chamfer3D.cu:30-36,126)."""
+    a, b = gen_pair(8, (1, 40, 3), (1, 1300, 3))
+    a[0, 13] = np.nan                  # query with only NaN distances -> (NaN, 0)
+    a[0, 14, 2] = np.inf               # query at infinity: every distance +inf -> (inf, 0)
+    b[0, 5, 1] = np.nan                # mid-tile: one target dropped
+    b[0, 512] = np.nan                 # tile 1 head: targets 512..1023 invisible
+    b[0, 1024, 0] = np.inf             # tile 2 head at +inf: tile lives on (inf is not NaN)
+    b[0, 1100, 0] = np.inf
+    a[0, 15, 0] = np.inf               # inf - inf = NaN against targets 1024 and 1100: tile 2 dead for this query
+    for blk in (b, b[:, :1024].copy(), b[:, :513].copy()):
+        d1, _, i1, _ = oracle.chamfer_forward(a, blk, 0)
+        e, ei = py_nm_distance_literal(a[0], blk[0])
+        np.testing.assert_array_equal(i1[0], ei)
+        assert np.array_equal(d1[0], e, equal_nan=True)
+    d1, _, i1, _ = oracle.chamfer_forward(a, b, 0)
+    assert np.isnan(d1[0, 13]) and i1[0, 13] == 0 and np.isinf(d1[0, 14]) and i1[0, 14] == 0
+    live = np.ones(1300, bool)
+    live[512:1024] = False
+    live[5] = False
+    assert not ((i1[0] >= 512) & (i1[0] < 1024)).any()
+    # the nearest target of tile 1 would have won for some query if the tile were visible
+    a2 = b[:, 600:640].copy() + np.float32(1e-4)
+    a2[np.isnan(a2)] = 0
+    d1, _, i1, _ = oracle.chamfer_forward(a2, b, 0)
+    assert not ((i1[0] >= 512) & (i1[0] < 1024)).any()
+    b0 = b.copy()
+    b0[0, 0, 2] = np.nan               # tile 0 head: every query ends with (NaN, 0)
+    d1, _, i1, _ = oracle.chamfer_forward(a, b0, 1)
+    assert np.isnan(d1).all() and (i1 == 0).all()

@@ -64,3 +64,62 @@ def test_shard_indices_partition():
         assert owned == list(range(n))
         sizes = [len(shard_indices(n, r, w)) for r in range(w)]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _stub_metric(p, g):
+    """Stand-in for evaluate_scans on CPU tensors: per scan (first x of pred, sum of gt, #points)."""
+    return torch.stack([p[:, 0, 0], g.sum(dim=(1, 2)), torch.full((p.shape[0],), float(p.shape[1]))], dim=1)
+
+
+def _worker_eval(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+    from genpc_amd import sharding
+    from genpc_amd.metric import evaluate_sharded
+    rng = np.random.default_rng(5)
+    pred = rng.random((13, 32, 3), dtype=np.float32)
+    gt = rng.random((13, 32, 3), dtype=np.float32)
+    # evaluate_sharded initialises the process group itself (gloo here, nccl = RCCL on GPUs)
+    table = evaluate_sharded(pred, gt, device=torch.device("cpu"), max_batch=3, metric_fn=_stub_metric, backend="gloo")
+    seen = sharding.all_ranks()
+    # a caller that skips init() must be told, not handed a misaligned table
+    sharding.shutdown()
+    err = None
+    try:
+        sharding.gather_scan_metrics(torch.zeros(len(sharding.shard_indices(13, rank, world)), 3), 13, rank, world)
+    except RuntimeError as e:
+        err = str(e)
+    q.put((rank, table.numpy().tolist(), seen, err))
+
+
+def test_evaluate_sharded_uneven_two_ranks():
+    """13 scans over 2 ranks (7 + 6), batches of 3, stub metric on CPU tensors: the gathered
+    table equals the single-process one, in scan order, on both ranks."""
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_eval, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(5)
+    pred = rng.random((13, 32, 3), dtype=np.float32)
+    gt = rng.random((13, 32, 3), dtype=np.float32)
+    exp = _stub_metric(torch.from_numpy(pred), torch.from_numpy(gt)).numpy()
+    for rank, table, seen, err in res:
+        np.testing.assert_array_equal(np.asarray(table, np.float32), exp)
+        assert seen == [0, 1]
+        assert err is not None and "not initialised" in err
+
+
+def test_gather_rejects_wrong_row_count():
+    from genpc_amd.sharding import gather_scan_metrics
+    with pytest.raises(ValueError):
+        gather_scan_metrics(torch.zeros(5, 3), 13, 0, 1)
