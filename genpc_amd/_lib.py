@@ -32,6 +32,7 @@ SIGNATURES = {
     "genpc_nn_profile": (ctypes.c_float, [_i]),
     "genpc_chamfer_forward": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_nm_distance": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "genpc_nm_distance_within": (_i, [_i, _i, _vp, _i, _vp, _f, _vp, _vp, _vp]),
     "genpc_chamfer_backward": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_emd_forward": (_i, [_i, _i, _i] + [_vp] * 14 + [_f, _i, _vp]),
     "genpc_emd_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -37,3 +37,13 @@ def nm_distance(xyz, xyz2, result, result_i):
     b, n, _ = xyz.shape
     m = xyz2.shape[1]
     return _lib.on_device_of(xyz, _L.genpc_nm_distance, b, n, _p(xyz), m, _p(xyz2), _p(result), _p(result_i))
+
+
+def nm_distance_within(xyz, xyz2, radius2, result, result_i):
+    """nm_distance with a search limit (squared): queries without a target within it get
+    (+inf, -1); the others exactly what nm_distance returns (reg_xyz.py:41-52)."""
+    _lib.check_tensors((("xyz", xyz), ("xyz2", xyz2), ("result", result)), (("result_i", result_i),))
+    b, n, _ = xyz.shape
+    m = xyz2.shape[1]
+    return _lib.on_device_of(xyz, _L.genpc_nm_distance_within, b, n, _p(xyz), m, _p(xyz2), float(radius2), _p(result),
+                             _p(result_i))

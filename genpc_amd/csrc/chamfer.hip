@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void chamfer_grad_kernel(int b, int n, cons
 struct NNConfig {
     int r;                // VALU path, queries per lane: 0 = pick, else 2 or 4
     int blocks_per_cu;    // occupancy target used to pick the slice count
-    int mfma;             // 3: two-piece f16 MFMA filter (default), 2: three-piece bf16, 1: fp32 MFMA filter, 0: VALU path
+    int mfma;             // 4: cell-sorted pruned search (opt-in: wins when most queries have a near target), 3: two-piece f16 MFMA filter (default), 2: three-piece bf16, 1: fp32 MFMA filter, 0: VALU path
     int q;                // MFMA path, 32-query tiles per wave: 0 = pick, else 1 or 2
     int u;                // MFMA path, tiles per bookkeeping unit: 0 = pick, else 1 or 2
     bool env_path, env_wps;   // GENPC_NN_PATH / GENPC_NN_WPS were given
@@ -622,7 +622,7 @@ static const NNConfig &nn_config()
         NNConfig k{0, 4, 3, 0, 0, false, false, 0, -1};
         if (const char *e = getenv("GENPC_NN_R")) k.r = atoi(e);
         if (const char *e = getenv("GENPC_NN_PATH")) {
-            k.mfma = (e[0] == 'v') ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'b' ? 2 : 3));
+            k.mfma = (e[0] == 'v') ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'b' ? 2 : (e[0] == 'f' ? 3 : 4)));
             k.env_path = true;
         }
         if (const char *e = getenv("GENPC_NN_Q")) k.q = atoi(e);
@@ -658,7 +658,8 @@ static void launch_r(const NNArgs &a, int blocks, hipStream_t st)
 }
 
 static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0, float *d0, int *i0,
-                      const float *q1, int n1, const float *t1, int m1, float *d1, int *i1, hipStream_t st)
+                      const float *q1, int n1, const float *t1, int m1, float *d1, int *i1, hipStream_t st,
+                      float radius2 = __builtin_inff())
 {
     // A direction with no queries or no targets does nothing (the reference's
     // loops do not execute, outputs keep the caller's zeros).
@@ -667,6 +668,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     NNArgs a{};
     a.b = b;
     a.fma = arith_mode() != 0 ? 1 : 0;
+    a.radius2 = radius2;
     a.debug = t_tune_hooks >= 0 ? t_tune_hooks : cfg.dbg;
     if (a.debug & 512) {
         a.stats = (unsigned long long *)workspace(12, 256, nullptr, nullptr, 256);      // one block per device, shared by all streams
@@ -694,6 +696,12 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // measured on MI355X (tools/nn_sweep.py): below ~6M pairs the single-launch fp32-MFMA
     // kernel wins (1x1024^2 11.0 vs 13.5 us), from 2048^2 on the two-launch f16 filter
     if (path == 3 && pairs < 6e6 && t_tune_path < 0 && !cfg.env_path) path = 1;
+    if (radius2 < __builtin_inff()) path = 4;      // only the cell search knows how to stop at a distance
+    if (path == 4) {
+        // three launches, O(N + M) work (nn_grid.hip); needs both directions to be each other's swap
+        if (nd == 1 || (a.dir[1].q == a.dir[0].t && a.dir[1].t == a.dir[0].q)) return launch_nn_grid(a, st);
+        path = 3;
+    }
     const bool f16 = path == 3;      // same planning as the bf16 path, other kernel
     if (f16) path = 2;
     if (path == 2 && nt_max >= (1 << 25)) path = 1;      // finish kernel packs tile indices in 21 bits
@@ -867,7 +875,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
 GENPC_API int genpc_nn_tune(int path, int hooks)
 {
     const int prev = genpc::t_tune_path >= 0 ? genpc::t_tune_path : genpc::nn_config().mfma;
-    if (path >= 0 && path <= 3) genpc::t_tune_path = path;
+    if (path >= 0 && path <= 4) genpc::t_tune_path = path;
     if (hooks >= 0) genpc::t_tune_hooks = hooks;
     return prev;
 }
@@ -895,6 +903,17 @@ GENPC_API int genpc_nm_distance(int b, int n, const float *xyz, int m, const flo
 {
     return genpc::nn_forward(b, 1, xyz, n, xyz2, m, result, result_i, nullptr, 0, nullptr, 0, nullptr, nullptr,
                              (hipStream_t)stream);
+}
+
+GENPC_API int genpc_nm_distance_within(int b, int n, const float *xyz, int m, const float *xyz2, float radius2,
+                                       float *result, int *result_i, void *stream)
+{
+    if (!(radius2 >= 0.0f)) {
+        genpc::set_error("genpc_nm_distance_within: radius2 must be >= 0");
+        return -1;
+    }
+    return genpc::nn_forward(b, 1, xyz, n, xyz2, m, result, result_i, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                             (hipStream_t)stream, radius2);
 }
 
 GENPC_API int genpc_chamfer_backward(int b, int n, const float *xyz1, int m, const float *xyz2,

@@ -52,6 +52,7 @@ struct NNArgs {
     int debug;         // experiment switches (GENPC_NN_DEBUG): 1 skip index recovery, 2 skip merge, 4 skip main loop
     int fma;           // arithmetic mode of this call (read once at the entry point; host side only)
     unsigned long long *stats;   // hook 512: [0] queries, [1] exhaustive re-dos, [2] exact pieces; else null
+    float radius2;     // grid path only: search limit (squared); +inf = none.  Queries with no target within it get (+inf, -1)
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -232,5 +233,6 @@ __device__ __forceinline__ float nn_tau(float a_best, float qq, float tmax2, dou
 int launch_nn_bf16(NNArgs &a, int q, int pre, int nl, long long total_blocks, hipStream_t st);
 int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, long long total_blocks, hipStream_t st);
 int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float t2min, hipStream_t st);
+int launch_nn_grid(const NNArgs &a, hipStream_t st);
 
 }  // namespace genpc

@@ -223,13 +223,17 @@ def reg(partial_xyz, complete_xyz, generative_model="trellis", dataset="redwood"
 def remove_close_points(source_xyz, target_xyz, distance_threshold=0.0001):
     """reg_xyz.py:41-57: drop every target point whose nearest source point is closer
     than sqrt(distance_threshold) (open3d's KD-tree returns SQUARED distances, so the
-    reference's 1e-4 is 0.01 units).  One NN launch instead of a Python loop of
-    KD-tree queries.  Returns (filtered target [K,3], keep mask [M])."""
+    reference's 1e-4 is 0.01 units).  One NN launch instead of a Python loop of KD-tree
+    queries (measured at 163840 x 16384: 147 us on the default MFMA filter; the radius-limited
+    cell search, chamfer_3D.nm_distance_within, gives the same mask in 156 us -- no gain yet).
+    Returns (filtered target [K,3], keep mask [M])."""
     from . import chamfer_3D
     src = source_xyz.contiguous().float()
     tgt = target_xyz.contiguous().float()
     d = torch.empty(1, tgt.shape[0], device=tgt.device)
     i = torch.empty(1, tgt.shape[0], device=tgt.device, dtype=torch.int32)
+    if tgt.shape[0] == 0 or src.shape[0] == 0:
+        return tgt, torch.ones(tgt.shape[0], dtype=torch.bool, device=tgt.device)
     if chamfer_3D.nm_distance(tgt[None], src[None], d, i) != 1:
         raise RuntimeError("nm_distance failed: " + _lib.last_error())
     keep = ~(d[0] < distance_threshold)

@@ -41,14 +41,16 @@ int genpc_get_arith(void);
 /* Frees the per-device scratch pool (split-target partials, EMD lists). */
 int genpc_release_workspace(void);
 /* Nearest-neighbour kernel selection, for tests and experiments: every path returns
- * the same bits.  path: 3 one-f16-MFMA filter (default), 2 split-bf16 MFMA filter,
- * 1 fp32-MFMA filter, 0 VALU brute force, < 0 keep.  hooks: bit mask of test hooks
+ * the same bits.  path: 4 cell-sorted pruned exact search (two launches, O(N + M) work when most
+ * queries have a target nearby; slower than the filters when many do not -- opt-in), 3 one-f16-MFMA
+ * filter (default), 2 split-bf16 MFMA filter, 1 fp32-MFMA filter (default below ~6 M pairs),
+ * 0 VALU brute force, < 0 keep.  hooks: bit mask of test hooks
  * (8: every query takes the exhaustive pass, 16: every listed tile is evaluated
  * exactly, 256: bf16 path with pre-split targets staged by LDS-DMA, 512: count what the
  * filtered paths do, see genpc_nn_stats), < 0 keep.  Applies to calls made by the CALLING
  * host thread only (thread-local; other threads keep the defaults).  Returns the previous
  * path.  Environment (read once, at first use): GENPC_NN_PATH (valu | mfma32 | bf16 |
- * f16), GENPC_NN_DEBUG.                                                          */
+ * f16 | grid), GENPC_NN_DEBUG.                                                          */
 int genpc_nn_tune(int path, int hooks);
 /* Counters of the filtered nearest-neighbour paths, accumulated on the current device
  * while hook 512 is set: out[0] queries answered, out[1] queries re-done by the exhaustive
@@ -76,6 +78,15 @@ int genpc_chamfer_forward(int b, int n, const float *xyz1, int m,
  * the partial-matching losses (utils/loss_util.py:35-43) only consume this half. */
 int genpc_nm_distance(int b, int n, const float *xyz, int m, const float *xyz2,
                       float *result, int *result_i, void *stream);
+
+/* Nearest neighbour with a search limit -- what the reference asks of open3d's KD-tree in
+ * remove_close_points (reg_xyz.py:41-52: search_knn_vector_3d(point, 1), keep the point unless the
+ * returned SQUARED distance is below the threshold): queries whose nearest target lies within
+ * radius2 (squared distance, <=) get exactly what genpc_nm_distance returns; the others get
+ * result = +inf, result_i = -1.  Runs on the cell-sorted search, which then never looks farther
+ * than the limit: O(N + M) whatever the overlap of the two clouds.  Returns -1 for radius2 < 0. */
+int genpc_nm_distance_within(int b, int n, const float *xyz, int m, const float *xyz2,
+                             float radius2, float *result, int *result_i, void *stream);
 
 /* Replaces chamfer_cuda_backward (chamfer3D.cu:176-195, chamfer_3D.backward in
  * chamfer_cuda.cpp:22-26,32).  gradxyz1[B,N,3] / gradxyz2[B,M,3] must be zeroed

@@ -157,7 +157,7 @@ def test_degenerate_and_extreme_shapes(gp, oracle):
     assert_same(run_hip(gp, a, b, 0), oracle.chamfer_forward(a, b, 0))
 
 
-PATHS = {"valu": 0, "mfma32": 1, "bf16": 2, "f16": 3}
+PATHS = {"valu": 0, "mfma32": 1, "bf16": 2, "f16": 3, "grid": 4}
 
 
 def run_path(gp, a, b, mode, path, hooks=0):

@@ -13,7 +13,7 @@ from conftest import ROOT, gen_pair
 
 pytestmark = pytest.mark.gpu
 
-PATHS = {"valu": 0, "mfma32": 1, "bf16": 2, "f16": 3}
+PATHS = {"valu": 0, "mfma32": 1, "bf16": 2, "f16": 3, "grid": 4}
 HOOK_COUNT = 512
 
 
@@ -148,6 +148,7 @@ def test_differential_fuzz_f16_vs_valu(gp, oracle, golden):
             acc[i] += st[i]
         acc[3] += 1
         assert_bits(run_hip(gp, a, b, mode), ref, "default dispatch, " + msg)
+        assert_bits(run_hip(gp, a, b, mode, PATHS["grid"]), ref, "cell-sorted search, " + msg)
         if case % 10 == 0 and a.shape[0] * a.shape[1] * b.shape[1] <= 6e7:
             assert_bits(ref, oracle.chamfer_forward(a, b, mode), "valu vs oracle, " + msg)
     tot = [sum(v[i] for v in per_kind.values()) for i in range(3)]
@@ -231,3 +232,32 @@ def test_non_finite_default_dispatch_large(gp, oracle):
         np.testing.assert_array_equal(gg, e)
     for gg, e in zip(got[:2], exp[:2]):
         assert np.array_equal(gg, e, equal_nan=True)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_radius_limited_search(gp, oracle, golden, mode):
+    """genpc_nm_distance_within: inside the limit the reference's bits, outside (+inf, -1) --
+    on a real scan against its ground truth (many queries far from every target), on random
+    clouds, with limits below, around and far above the cell size, 0 and +inf."""
+    import torch
+    from genpc_amd import chamfer_3D
+    g = golden("scans13_fps16384.npz")
+    cases = [(g["gt"][3:4], g["partial"][3:4, :6000].copy())]
+    a, b = gen_pair(91, (2, 5000, 3), (2, 3000, 3))
+    cases.append((a, b))
+    lib = gp["lib"]
+    prev = lib.genpc_set_arith(mode)
+    try:
+        for q, t in cases:
+            ed, _, ei, _ = oracle.chamfer_forward(q, t, mode)
+            Q, T = torch.from_numpy(np.ascontiguousarray(q)).cuda(), torch.from_numpy(np.ascontiguousarray(t)).cuda()
+            for r2 in (0.0, 1e-6, 1e-4, 3e-3, 0.05, 10.0, float("inf"), float(np.median(ed))):
+                d = torch.empty(q.shape[0], q.shape[1], device="cuda")
+                i = torch.empty(q.shape[0], q.shape[1], device="cuda", dtype=torch.int32)
+                assert chamfer_3D.nm_distance_within(Q, T, r2, d, i) == 1
+                inside = ed <= np.float32(r2)
+                np.testing.assert_array_equal(i.cpu().numpy(), np.where(inside, ei, -1))
+                np.testing.assert_array_equal(d.cpu().numpy(), np.where(inside, ed, np.float32(np.inf)))
+    finally:
+        lib.genpc_set_arith(prev)
+    assert lib.genpc_nm_distance_within(1, 4, None, 4, None, -1.0, None, None, None) == -1
