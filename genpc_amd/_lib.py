@@ -43,6 +43,9 @@ SIGNATURES = {
     "genpc_zbuffer_visibility": (_i, [_i, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "genpc_pose_transform": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_pose_cd_grad": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
+    "genpc_splat_image": (_i, [_i, _vp, _f, _i, _vp, _vp]),
+    "genpc_pose_loss_grad": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "genpc_pose_optimize_batch": (_i, [_i, _i, _vp, _i, _vp, _f, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp]),
     "genpc_pose_optimize_cd": (_i, [_i, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "genpc_pose_optimize_cd_batch": (_i, [_i, _i, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "genpc_icp_batch": (_i, [_i, _i, _vp, _i, _vp, _d, _vp, _i, _d, _d, _vp, _vp, _vp]),

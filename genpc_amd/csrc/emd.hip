@@ -118,6 +118,18 @@ __device__ __forceinline__ void merge_top2(float &b, float &bb, int &bi, int &bb
     bbi = nbi;
 }
 
+// Threshold of the bid pre-filter for m = max(better, seed): a candidate with squared distance sq
+// and price p >= 0 can only matter if fl32((3 - sqrtf(sq)) - p) > m.  With tt = fl(cb - p), the
+// test  sq < fl(tt * tt)  must pass whenever that holds.  Roundings: cb and tt (relative u each, on
+// magnitudes <= 3 + |m|), the square (u), the correctly rounded sqrtf (u), the fp32 rounding of the
+// value itself (2u |m|); with 0 <= p < 3 + |m| (otherwise tt <= 0 and nothing can matter) the test
+// is safe iff the slack added to (3 - m) is at least u (21 + 9 |m|).  2e-6 (1 + |m|) = 33.5 u (1 + |m|).
+// (The first version used the constant 2e-6: proven only for clouds in the unit cube, |m| <= 3.)
+__device__ __forceinline__ float filter_cb(float m)
+{
+    return __fadd_rn(__fsub_rn(3.0f, m), __fmul_rn(2e-6f, __fadd_rn(1.0f, fabsf(m))));
+}
+
 // lanes-per-bidder for U bidders on a grid of G blocks per batch element
 __device__ __forceinline__ int pick_p(int U, int G)
 {
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                 seed = fminf(da, dc);
             }
         }
-        float cb = __fsub_rn(3.000002f, fmaxf(better, seed));
+        float cb = filter_cb(fmaxf(better, seed));
 
         for (int k2 = k_lo; k2 < k_hi; k2 += kTile) {
             const int end_k = min(n, k2 + kTile) - k2;
@@ -241,9 +253,9 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
             // Pre-filter.  A candidate can change this lane's (best, better) only if its
             // value exceeds `better`, i.e. only if sqrt(s) < 3 - price - better.  That is
             // tested conservatively in squared space with fp32 and no sqrt / fp64:
-            // cb = (3 + 2e-6) - better absorbs every rounding of the test itself (two fp32
-            // subtractions below 8: <= 4.8e-7; the square: 6e-8 relative; the correctly
-            // rounded sqrt of the exact path: 6e-8 relative), so a candidate that fails the
+            // cb = (3 - better) + 2e-6 (1 + |better|) absorbs every rounding of the test itself at
+            // ANY magnitude of the clouds (filter_cb: the slack needed is u (21 + 9 |better|),
+            // u = 2^-24, the slack given 33 u (1 + |better|)), so a candidate that fails the
             // test provably evaluates to d <= better and the exact update would be a
             // no-op.  The exact path (double-precision expression of emd_cuda.cu:146)
             // runs for the whole wave when any lane passes; for lanes that did not pass
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                             best_i = gt ? kk : best_i;
                         }
                     }
-                    cb = __fsub_rn(3.000002f, fmaxf(better, seed));
+                    cb = filter_cb(fmaxf(better, seed));
                 }
             }
         }

@@ -13,7 +13,11 @@
 // workgroup (8-byte agent-scope atomics on both sides, generation-tagged keys in a
 // double-buffered slot array -- no grid barrier, no fences, no reset between steps);
 // several clouds run side by side in one launch (grid.y).  All W workgroups of a
-// cloud must be co-resident: the launcher keeps W * clouds <= the CU count.
+// cloud must be co-resident: multi-workgroup launches go through
+// hipLaunchCooperativeKernel (the runtime refuses a grid that cannot be resident at once)
+// and are sized from the device's real CU count.  The polls are bounded all the same: a
+// hand-off that times out aborts the cloud's run (every workgroup leaves its step loop),
+// raises the error word and writes -1 to out[0]; genpc_amd/fps.py raises on it.
 #include "common.h"
 #include "../../include/genpc_hip.h"
 
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(kFThreads) void fps_kernel(int n, int k, int W, con
                 const unsigned long long o = shfl_xor_u64(kk, off);
                 kk = o > kk ? o : kk;
             }
+            bool timed_out = false;
             if (W > 1) {
                 unsigned long long *slot = S + (size_t)(s & 1) * kFMaxW;
                 if (lane == 0) __hip_atomic_store(slot + wg, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -120,8 +125,9 @@ __global__ __launch_bounds__(kFThreads) void fps_kernel(int n, int k, int W, con
                         ready = ((unsigned)(v >> 20) & 0xFFFu) == gen;
                     }
                     if (__all(ready)) break;
-                    if (++spins > (1 << 22)) {
-                        if (lane == 0) *err = 1;
+                    if (++spins > (1 << 21)) {
+                        if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        timed_out = true;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
@@ -133,14 +139,17 @@ __global__ __launch_bounds__(kFThreads) void fps_kernel(int n, int k, int W, con
                     kk = o > kk ? o : kk;
                 }
             }
-            if (lane == 0) s_cur = (int)(0xFFFFFu - (unsigned)(kk & 0xFFFFFu));
+            if (lane == 0) s_cur = timed_out ? -1 : (int)(0xFFFFFu - (unsigned)(kk & 0xFFFFFu));
         }
         __syncthreads();
         cur = s_cur;
+        // aborted: this workgroup stops publishing, so its peers time out once and leave as well
+        // (one bounded spin per workgroup, not one per remaining step)
+        if (cur < 0) break;
     }
     // a hand-off that timed out (workgroups of a cloud not co-resident) poisons the
     // result visibly: index 0 is always 0 in a good run
-    if (wg == 0 && t == 0 && *err) out[0] = -1;
+    if (wg == 0 && t == 0 && (cur < 0 || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) out[0] = -1;
 }
 
 }  // namespace genpc
@@ -158,7 +167,17 @@ GENPC_API int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, voi
     int W = ceil_div(n, kFThreads * 8);
     if (W > kFMaxW) W = kFMaxW;
     if (W < 1) W = 1;
-    const int clouds_per_launch = W == 1 ? c : (kNumCU / W < 1 ? 1 : kNumCU / W);
+    // co-residency: one 1024-thread workgroup per CU, counted on THIS device (a partitioned or
+    // smaller part has fewer than the 256 CUs of a full MI355X)
+    int dev = 0, cus = 0;
+    if (!check(hipGetDevice(&dev), "hipGetDevice")) return 0;
+    if (!check(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return 0;
+    if (cus < 1) cus = 1;
+    if (W > cus) {
+        set_error("genpc_fps: the cloud needs more co-resident workgroups than the device has CUs");
+        return 0;
+    }
+    const int clouds_per_launch = W == 1 ? c : (cus / W < 1 ? 1 : cus / W);
     const size_t slot_bytes = (size_t)c * 2 * kFMaxW * sizeof(unsigned long long);
     char *ws = (char *)workspace(7, 256 + slot_bytes, st);
     if (!ws) return 0;
@@ -171,10 +190,18 @@ GENPC_API int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, voi
         const float *x = xyz + (size_t)c0 * n * 3;
         int *o = out_idx + (size_t)c0 * k;
         unsigned long long *sl = slots + (size_t)c0 * 2 * kFMaxW;
-        if (fma)
-            hipLaunchKernelGGL(fps_kernel<1>, dim3(W, cc), dim3(kFThreads), 0, st, n, k, W, x, o, sl, err);
-        else
-            hipLaunchKernelGGL(fps_kernel<0>, dim3(W, cc), dim3(kFThreads), 0, st, n, k, W, x, o, sl, err);
+        if (W == 1) {
+            if (fma)
+                hipLaunchKernelGGL(fps_kernel<1>, dim3(W, cc), dim3(kFThreads), 0, st, n, k, W, x, o, sl, err);
+            else
+                hipLaunchKernelGGL(fps_kernel<0>, dim3(W, cc), dim3(kFThreads), 0, st, n, k, W, x, o, sl, err);
+        } else {
+            // workgroups poll each other: the launch must be co-resident as a whole
+            int n_ = n, k_ = k, W_ = W;
+            void *args[] = {&n_, &k_, &W_, (void *)&x, (void *)&o, (void *)&sl, (void *)&err};
+            const void *fn = fma ? (const void *)fps_kernel<1> : (const void *)fps_kernel<0>;
+            if (!check(hipLaunchCooperativeKernel(fn, dim3(W, cc), dim3(kFThreads), args, 0, st), "fps cooperative launch")) return 0;
+        }
     }
     if (!check(hipGetLastError(), "fps launch")) return 0;
     return 1;

@@ -1,6 +1,8 @@
 // pose.hip -- the SE(3)+scale alignment loop of optim_registration/diff_obj_pose.py
 //  for gfx950: 7-DoF pose model (6D rotation, translation,
-// log-scale), Chamfer half of compute_loss_function, analytic backward, Adam.
+// log-scale), both halves of compute_loss_function (Chamfer, and the silhouette terms on an
+// own differentiable occupancy splat -- the reference's Pulsar renderer is absent and
+// unpinned, see the mask section below), analytic backward, Adam.
 //
 // The reference runs this through torch autograd: per iteration ~40 tiny kernels,
 // two chamfer_3DDist calls (each computing BOTH directions and dropping one,
@@ -170,7 +172,7 @@ struct PoseState {       // device-resident
     float m[10];
     float v[10];
     float grad[10];
-    float loss[3];       // total, cd, ortho_err
+    float loss[4];       // total, cd, ortho_err, mask_loss
     float local_best;
     float best_loss;
     float best_params[10];
@@ -239,12 +241,14 @@ __global__ void pose_update_kernel(int b, PoseState *__restrict__ S, double *__r
     for (int k = 0; k < 3; k++) grad[3 + k] = (float)ga2[k];
     for (int k = 0; k < 3; k++) grad[6 + k] = (float)accum[10 + k];
     grad[9] = (float)(accum[9] * s);
-    const float loss = (float)((double)cd_weight * cd + (double)reg_weight * err);
+    // accum[15]: mask_weight * mask_loss of this step (mask_loss_kernel), 0 without the mask term
+    const float loss = (float)((double)cd_weight * cd + (double)reg_weight * err + accum[15]);
     for (int k = 0; k < 10; k++) S->grad[k] = grad[k];
     S->loss[0] = loss;
     S->loss[1] = (float)cd;
     S->loss[2] = (float)err;
-    for (int k = 0; k < 15; k++) accum[k] = 0.0;
+    S->loss[3] = (float)accum[15];
+    for (int k = 0; k < 16; k++) accum[k] = 0.0;
     if (history_slot) *history_slot = loss;
     if (!do_step) return;
     if (loss < S->local_best) S->local_best = loss;       // diff_obj_pose.py:549-551
@@ -272,7 +276,7 @@ __global__ void pose_begin_kernel(int b, PoseState *__restrict__ S, double *__re
     if (start < 0) {
         S->best_loss = __builtin_inff();
         for (int k = 0; k < 10; k++) S->best_params[k] = 0.0f;
-        for (int k = 0; k < 15; k++) accum[k] = 0.0;
+        for (int k = 0; k < 16; k++) accum[k] = 0.0;
         return;
     }
     const double th = start * 90.0 * M_PI / 180.0;
@@ -316,6 +320,319 @@ __global__ void pose_end_kernel(int b, PoseState *__restrict__ S, int final, flo
         for (int k = 0; k < 10; k++) best_params[k] = S->best_params[k];
 }
 
+// ---------------------------------------------------------------------------
+// Silhouette ("mask") half of compute_loss_function (diff_obj_pose.py:286-336).
+// The reference compares Pulsar renders (pytorch3d, CUDA only, absent, unpinned) of the partial
+// cloud (:108-134) and of the posed complete cloud (:426-433); its clouds carry no colour on this
+// path, so the images are soft occupancy maps.  This build defines its OWN differentiable splat
+// with the reference's camera and radii -- restated with the loss in oracle/genpc_oracle_geom.c,
+// whose gradient is pinned to torch autograd (tests/test_oracle_pose.py):
+//   Zv = 3 - z;  u = S/2 (1 + 4 x / Zv);  v = S/2 (1 - 4 y / Zv);  rho = S/2 * 4 * radius / Zv
+//   a_i(pixel) = min(0.999, max(0, 1 - |pixel centre - (u, v)|^2 / rho^2));  I = 1 - prod_i (1 - a_i)
+// and keeps the reference's own torch code for what follows the render: statistical
+// normalisation, sigmoid soft masks, 30 MSE + BCE + 10 Dice (:204-217,261-278,238-259,304-311).
+//   mask_splat_kernel  one block per 56 x 56 image tile and scan: every point is posed (the
+//                      transform is fused), projected, and its log(1 - a) added to the tile in LDS
+//                      (no global atomics, no pre-zeroed image); writes L = sum log(1 - a)
+//   mask_loss_kernel   one block per scan: image statistics, the loss, and W = d loss / d I * T
+//                      (four passes over the 224^2 image, block reductions in fp64)
+//   mask_grad_kernel   one thread per point: gathers W over the pixels it covers, chains through
+//                      (u, v, rho) to the point and on to (R, s, t): same 13 accumulators as the
+//                      Chamfer gradient
+constexpr int kMaskTile = 56;
+constexpr float kMaskAmax = 0.999f;
+constexpr float kMaskFocal = 4.0f, kMaskEyeZ = 3.0f, kMaskZnear = 1e-4f, kMaskZfar = 5.0f;
+
+struct SplatPt {
+    float u, v, rho, zv;
+    bool ok;
+};
+
+__device__ __forceinline__ SplatPt splat_project(const float *p, float radius, float hs)
+{
+    SplatPt o;
+    o.zv = kMaskEyeZ - p[2];
+    o.ok = o.zv > kMaskZnear && o.zv < kMaskZfar;
+    const float iz = 1.0f / o.zv;
+    o.u = hs * (1.0f + kMaskFocal * p[0] * iz);
+    o.v = hs * (1.0f - kMaskFocal * p[1] * iz);
+    o.rho = hs * kMaskFocal * radius * iz;
+    return o;
+}
+
+// grid (tiles, b).  posed != 0: v is the complete cloud and is posed with params; else v is splatted as is.
+__global__ __launch_bounds__(kQBlock) void mask_splat_kernel(int n, const float *__restrict__ v,
+                                                             const float *__restrict__ center, int cstride,
+                                                             const float *__restrict__ params, int pstride, int posed,
+                                                             float radius, int S, float *__restrict__ L)
+{
+    __shared__ float tl[kMaskTile * kMaskTile];
+    const int e = blockIdx.y;
+    const int tiles_x = (S + kMaskTile - 1) / kMaskTile;
+    const int tx0 = (blockIdx.x % tiles_x) * kMaskTile, ty0 = (blockIdx.x / tiles_x) * kMaskTile;
+    v += (size_t)e * n * 3;
+    L += (size_t)e * S * S;
+    float R[9], s = 1.0f, c[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+    if (posed) {
+        center += (size_t)e * cstride;
+        params += (size_t)e * pstride;
+        rot6d_to_matrix(params, R);
+        s = expf(params[9]);
+        c[0] = center[0]; c[1] = center[1]; c[2] = center[2];
+        t[0] = params[6]; t[1] = params[7]; t[2] = params[8];
+    }
+    for (int i = threadIdx.x; i < kMaskTile * kMaskTile; i += kQBlock) tl[i] = 0.0f;
+    __syncthreads();
+    const float hs = 0.5f * S;
+    for (int j = threadIdx.x; j < n; j += kQBlock) {
+        float p[3] = {v[(size_t)j * 3 + 0], v[(size_t)j * 3 + 1], v[(size_t)j * 3 + 2]};
+        if (posed) {
+            float o[3];
+            pose_point(R, s, c, t, p[0], p[1], p[2], o);
+            p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
+        }
+        const SplatPt q = splat_project(p, radius, hs);
+        if (!q.ok) continue;
+        int c0 = (int)floorf(q.u - q.rho - 0.5f), c1 = (int)ceilf(q.u + q.rho - 0.5f);
+        int r0 = (int)floorf(q.v - q.rho - 0.5f), r1 = (int)ceilf(q.v + q.rho - 0.5f);
+        c0 = max(c0, tx0); c1 = min(c1, min(S, tx0 + kMaskTile) - 1);
+        r0 = max(r0, ty0); r1 = min(r1, min(S, ty0 + kMaskTile) - 1);
+        if (c0 > c1 || r0 > r1) continue;
+        const float ir2 = 1.0f / (q.rho * q.rho);
+        for (int r = r0; r <= r1; r++) {
+            const float dy = (float)r + 0.5f - q.v;
+            for (int cc = c0; cc <= c1; cc++) {
+                const float dx = (float)cc + 0.5f - q.u;
+                float a = 1.0f - (dx * dx + dy * dy) * ir2;
+                if (a <= 0.0f) continue;
+                a = fminf(a, kMaskAmax);
+                atomicAdd(&tl[(r - ty0) * kMaskTile + (cc - tx0)], logf(1.0f - a));
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kMaskTile * kMaskTile; i += kQBlock) {
+        const int r = ty0 + i / kMaskTile, cc = tx0 + i % kMaskTile;
+        if (r < S && cc < S) L[(size_t)r * S + cc] = tl[i];
+    }
+}
+
+constexpr int kMLThreads = 1024;
+
+// block-wide sums of up to four doubles (all threads get the totals)
+__device__ __forceinline__ void block_sum4(double (&x)[4], double (*red)[kMLThreads / kWave])
+{
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double y = x[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off, kWave);
+        if (lane == 0) red[k][wave] = y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double y = 0.0;
+        for (int w = 0; w < kMLThreads / kWave; w++) y += red[k][w];
+        x[k] = y;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Reference image of a scan (once per call): I_ref = 1 - exp(L); writes the soft mask
+// m_ref = sigmoid((I_ref - 0.1) / 0.05) over L and stats = (mean, unbiased std, sum m_ref).
+__global__ __launch_bounds__(kMLThreads) void mask_ref_kernel(int S, float *__restrict__ Lref, float *__restrict__ stats)
+{
+    __shared__ double red[4][kMLThreads / kWave];
+    const int e = blockIdx.x, P = S * S;
+    Lref += (size_t)e * P;
+    stats += (size_t)e * 4;
+    double a[4] = {0, 0, 0, 0};
+    for (int q = threadIdx.x; q < P; q += kMLThreads) a[0] += (double)(1.0f - expf(Lref[q]));
+    block_sum4(a, red);
+    const double mu = a[0] / P;
+    double b[4] = {0, 0, 0, 0};
+    for (int q = threadIdx.x; q < P; q += kMLThreads) {
+        const float I = 1.0f - expf(Lref[q]);
+        const double dd = (double)I - mu;
+        b[0] += dd * dd;
+        const float m = sigmoidf((I - 0.1f) * 20.0f);
+        b[1] += (double)m;
+        Lref[q] = m;
+    }
+    block_sum4(b, red);
+    if (threadIdx.x == 0) {
+        stats[0] = (float)mu;
+        stats[1] = (float)sqrt(b[0] / (P - 1));
+        stats[2] = (float)b[1];
+        stats[3] = 0.0f;
+    }
+}
+
+// Per scan: loss and W = mask_weight * d mask_loss / d I * T  (T = exp(L): what the backward splat
+// multiplies by 1 / (1 - a_i)); accum[15] += mask_weight * mask_loss.
+__global__ __launch_bounds__(kMLThreads) void mask_loss_kernel(int S, const float *__restrict__ L,
+                                                               const float *__restrict__ mref,
+                                                               const float *__restrict__ stats, float mask_weight,
+                                                               float *__restrict__ W, double *__restrict__ accum)
+{
+    __shared__ double red[4][kMLThreads / kWave];
+    const int e = blockIdx.x, P = S * S;
+    L += (size_t)e * P;
+    mref += (size_t)e * P;
+    W += (size_t)e * P;
+    stats += (size_t)e * 4;
+    accum += (size_t)e * 16;
+    const double mur = stats[0], sdr = stats[1], s_r = stats[2];
+    double a[4] = {0, 0, 0, 0};
+    for (int q = threadIdx.x; q < P; q += kMLThreads) a[0] += (double)(1.0f - expf(L[q]));
+    block_sum4(a, red);
+    const double mu = a[0] / P;
+    double b[4] = {0, 0, 0, 0};
+    for (int q = threadIdx.x; q < P; q += kMLThreads) {
+        const double dd = (double)(1.0f - expf(L[q])) - mu;
+        b[0] += dd * dd;
+    }
+    block_sum4(b, red);
+    const double sd = sqrt(b[0] / (P - 1));
+    const float k = (float)((sdr + 1e-6) / (sd + 1e-6));
+    const float muf = (float)mu, murf = (float)mur;
+    // loss terms
+    double c[4] = {0, 0, 0, 0};      // mse, bce, intersection, sum m
+    for (int q = threadIdx.x; q < P; q += kMLThreads) {
+        const float I = 1.0f - expf(L[q]);
+        float xn = (I - muf) * k + murf;
+        xn = fminf(fmaxf(xn, 0.0f), 1.0f);
+        const float m = sigmoidf((xn - 0.1f) * 20.0f), mr = mref[q];
+        const float lm = fmaxf(logf(m), -100.0f), l1m = fmaxf(logf(1.0f - m), -100.0f);
+        c[0] += (double)((m - mr) * (m - mr));
+        c[1] += (double)(-(mr * lm + (1.0f - mr) * l1m));
+        c[2] += (double)(m * mr);
+        c[3] += (double)m;
+    }
+    block_sum4(c, red);
+    const double den = c[3] + s_r + 1e-6, num = 2.0 * c[2] + 1e-6;
+    const double loss = 30.0 * c[0] / P + c[1] / P + 10.0 * (1.0 - num / den);
+    // G = d loss / d xn; sums for the statistics' share of the gradient
+    const float dice_a = (float)(-10.0 * 2.0 / den), dice_b = (float)(10.0 * num / (den * den));
+    const float invP = 1.0f / (float)P;
+    double g[4] = {0, 0, 0, 0};
+    for (int q = threadIdx.x; q < P; q += kMLThreads) {
+        const float I = 1.0f - expf(L[q]);
+        const float x0 = (I - muf) * k + murf;
+        float G = 0.0f;
+        if (x0 > 0.0f && x0 < 1.0f) {
+            const float m = sigmoidf((x0 - 0.1f) * 20.0f), mr = mref[q];
+            float dm = 60.0f * (m - mr) * invP;
+            float db = 0.0f;
+            if (logf(m) > -100.0f) db -= mr / m;
+            if (logf(1.0f - m) > -100.0f) db += (1.0f - mr) / (1.0f - m);
+            dm += db * invP + dice_a * mr + dice_b;
+            G = dm * m * (1.0f - m) * 20.0f;
+        }
+        g[0] += (double)G;
+        g[1] += (double)G * ((double)I - mu);
+        W[q] = G;                                  // finished below
+    }
+    block_sum4(g, red);
+    const float meanG = (float)(g[0] / P);
+    const float kk = sd > 0.0 ? (float)((sdr + 1e-6) / ((sd + 1e-6) * (sd + 1e-6)) / ((P - 1) * sd) * g[1]) : 0.0f;
+    for (int q = threadIdx.x; q < P; q += kMLThreads) {
+        const float T = expf(L[q]);
+        const float I = 1.0f - T;
+        const float dI = k * (W[q] - meanG) - kk * (I - muf);
+        W[q] = mask_weight * dI * T;
+    }
+    if (threadIdx.x == 0) accum[15] += (double)mask_weight * loss;
+}
+
+// grid (blocks, b): gradient of the mask term with respect to (R, s, t), into accum[0..12].
+__global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *__restrict__ v,
+                                                            const float *__restrict__ center, int cstride,
+                                                            const float *__restrict__ params, int pstride, float radius,
+                                                            int S, const float *__restrict__ W,
+                                                            double *__restrict__ accum)
+{
+    __shared__ double red[13][kQBlock / kWave];
+    const int e = blockIdx.y;
+    v += (size_t)e * n * 3;
+    W += (size_t)e * S * S;
+    center += (size_t)e * cstride;
+    params += (size_t)e * pstride;
+    accum += (size_t)e * 16;
+    float R[9];
+    rot6d_to_matrix(params, R);
+    const float s = expf(params[9]);
+    const float c[3] = {center[0], center[1], center[2]};
+    const float t[3] = {params[6], params[7], params[8]};
+    const float hs = 0.5f * S;
+    double a[13];
+#pragma unroll
+    for (int k = 0; k < 13; k++) a[k] = 0.0;
+    for (int j = blockIdx.x * kQBlock + threadIdx.x; j < n; j += gridDim.x * kQBlock) {
+        const float vx = v[(size_t)j * 3 + 0], vy = v[(size_t)j * 3 + 1], vz = v[(size_t)j * 3 + 2];
+        float p[3];
+        pose_point(R, s, c, t, vx, vy, vz, p);
+        const SplatPt q = splat_project(p, radius, hs);
+        if (!q.ok) continue;
+        const int c0 = max((int)floorf(q.u - q.rho - 0.5f), 0), c1 = min((int)ceilf(q.u + q.rho - 0.5f), S - 1);
+        const int r0 = max((int)floorf(q.v - q.rho - 0.5f), 0), r1 = min((int)ceilf(q.v + q.rho - 0.5f), S - 1);
+        const float ir2 = 1.0f / (q.rho * q.rho);
+        float gu = 0.0f, gv = 0.0f, gr = 0.0f;
+        for (int r = r0; r <= r1; r++) {
+            const float dy = (float)r + 0.5f - q.v;
+            for (int cc = c0; cc <= c1; cc++) {
+                const float dx = (float)cc + 0.5f - q.u;
+                const float d2 = dx * dx + dy * dy;
+                const float av = 1.0f - d2 * ir2;
+                if (av <= 0.0f || av >= kMaskAmax) continue;      // outside the disc / clamped: no gradient
+                const float w = W[(size_t)r * S + cc] / (1.0f - av);
+                gu += w * dx;
+                gv += w * dy;
+                gr += w * d2;
+            }
+        }
+        gu *= 2.0f * ir2; gv *= 2.0f * ir2; gr *= 2.0f * ir2 / q.rho;
+        const double iz = 1.0 / (double)q.zv;
+        const double f4 = (double)hs * kMaskFocal;
+        const double gzv = (double)gu * (-f4 * p[0] * iz * iz) + (double)gv * (f4 * p[1] * iz * iz) + (double)gr * (-(double)q.rho * iz);
+        const double g[3] = {(double)gu * f4 * iz, -(double)gv * f4 * iz, -gzv};
+        const double l[3] = {(double)(vx - c[0]), (double)(vy - c[1]), (double)(vz - c[2])};
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            a[10 + r] += g[r];
+#pragma unroll
+            for (int qq = 0; qq < 3; qq++) a[r * 3 + qq] += g[r] * (double)s * l[qq];
+            a[9] += g[r] * ((double)R[r * 3 + 0] * l[0] + (double)R[r * 3 + 1] * l[1] + (double)R[r * 3 + 2] * l[2]);
+        }
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        double x = a[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+        if (lane == 0) red[k][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 13) {
+        double x = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kQBlock / kWave; w2++) x += red[threadIdx.x][w2];
+        atomicAdd(&accum[threadIdx.x], x);
+    }
+}
+
+// image = 1 - exp(L)
+__global__ void mask_image_kernel(int P, const float *__restrict__ L, float *__restrict__ img)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < P) img[q] = 1.0f - expf(L[q]);
+}
+
 static int lin_grid(long long n)
 {
     long long g = ceil_div64(n, kQBlock);
@@ -336,37 +653,110 @@ GENPC_API int genpc_pose_transform(int n, const float *v, const float *center, c
     return check(hipGetLastError(), "pose_transform launch") ? 1 : 0;
 }
 
-GENPC_API int genpc_pose_cd_grad(int nc, const float *v, const float *center, const float *params, int np,
-                                 const float *partial, const float *d1, const int *i1, const float *d2, const int *i2,
-                                 float cd_weight, float reg_weight, float *loss_out, float *grad, void *stream)
+namespace genpc {
+
+static int mask_tiles(int S) { const int t = ceil_div(S, kMaskTile); return t * t; }
+
+// splat of the partial clouds + reference soft masks / statistics (once per call)
+static int mask_prepare_ref(int b, int np, const float *partial, float radius, int S, float *mref, float *stats,
+                            hipStream_t st)
+{
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kQBlock), 0, st, np, partial, (const float *)nullptr,
+                       0, (const float *)nullptr, 0, 0, radius, S, mref);
+    hipLaunchKernelGGL(mask_ref_kernel, dim3(b), dim3(kMLThreads), 0, st, S, mref, stats);
+    return check(hipGetLastError(), "mask reference launch") ? 1 : 0;
+}
+
+// the three launches of the mask term for the current parameters: accum += gradient, accum[15] += loss
+static int mask_step(int b, int nc, const float *complete, const float *center, int cstride, const float *params,
+                     int pstride, float radius, int S, float mask_weight, const float *mref, const float *stats,
+                     float *L, float *W, double *accum, hipStream_t st)
+{
+    const float rad = 1.1f * radius;      // diff_obj_pose.py:385: the posed cloud is drawn with 1.1 x the radius
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kQBlock), 0, st, nc, complete, center, cstride,
+                       params, pstride, 1, rad, S, L);
+    hipLaunchKernelGGL(mask_loss_kernel, dim3(b), dim3(kMLThreads), 0, st, S, (const float *)L, mref, stats, mask_weight,
+                       W, accum);
+    hipLaunchKernelGGL(mask_grad_kernel, dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride,
+                       params, pstride, rad, S, (const float *)W, accum);
+    return check(hipGetLastError(), "mask step launch") ? 1 : 0;
+}
+
+}  // namespace genpc
+
+GENPC_API int genpc_splat_image(int n, const float *pts, float radius, int size, float *img, void *stream)
+{
+    using namespace genpc;
+    if (n < 0 || size <= 0 || !(radius > 0.0f)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    float *L = (float *)workspace(14, (size_t)size * size * sizeof(float), st);
+    if (!L) return 0;
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(size), 1), dim3(kQBlock), 0, st, n, pts, (const float *)nullptr, 0,
+                       (const float *)nullptr, 0, 0, radius, size, L);
+    hipLaunchKernelGGL(mask_image_kernel, dim3(ceil_div(size * size, 256)), dim3(256), 0, st, size * size, (const float *)L, img);
+    return check(hipGetLastError(), "splat_image launch") ? 1 : 0;
+}
+
+GENPC_API int genpc_pose_loss_grad(int nc, const float *v, const float *center, const float *params, int np,
+                                   const float *partial, const float *d1, const int *i1, const float *d2, const int *i2,
+                                   float cd_weight, float reg_weight, float mask_weight, float radius, int render_size,
+                                   float *loss_out, float *grad, void *stream)
 {
     using namespace genpc;
     if (nc <= 0 || np <= 0) return -1;
+    const bool mask = mask_weight != 0.0f;
+    if (mask && (render_size <= 0 || !(radius > 0.0f))) return -1;
     hipStream_t st = (hipStream_t)stream;
-    char *ws = (char *)workspace(3, 256 + sizeof(PoseState), st);
+    const size_t P = mask ? (size_t)render_size * render_size : 0;
+    char *ws = (char *)workspace(3, 512 + sizeof(PoseState) + 3 * P * sizeof(float) + 256, st);
     if (!ws) return 0;
     double *accum = (double *)ws;
     PoseState *S = (PoseState *)(ws + 256);
+    float *stats = (float *)(ws + 256 + ((sizeof(PoseState) + 255) & ~(size_t)255));
+    float *mref = stats + 64, *L = mref + P, *W = L + P;
     if (!check(hipMemsetAsync(accum, 0, 16 * sizeof(double), st), "hipMemsetAsync(accum)")) return 0;
     if (!check(hipMemcpyAsync(S->params, params, 10 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy params"))
         return 0;
     hipLaunchKernelGGL(pose_grad_kernel, dim3(lin_grid((long long)nc + np), 1), dim3(kQBlock), 0, st, nc, v, center, 0,
                        params, 0, np, partial, d1, i1, d2, i2, cd_weight, accum);
+    if (mask) {
+        if (!mask_prepare_ref(1, np, partial, radius, render_size, mref, stats, st)) return 0;
+        if (!mask_step(1, nc, v, center, 0, params, 0, radius, render_size, mask_weight, mref, stats, L, W, accum, st)) return 0;
+    }
     hipLaunchKernelGGL(pose_update_kernel, dim3(1), dim3(64), 0, st, 1, S, accum, nc, np, cd_weight, reg_weight, 0.0f, 0,
                        (float *)nullptr, 0);
     if (!check(hipMemcpyAsync(grad, S->grad, 10 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy grad")) return 0;
-    if (!check(hipMemcpyAsync(loss_out, S->loss, 3 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy loss")) return 0;
-    return check(hipGetLastError(), "pose_cd_grad launch") ? 1 : 0;
+    if (!check(hipMemcpyAsync(loss_out, S->loss, 4 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy loss")) return 0;
+    return check(hipGetLastError(), "pose_loss_grad launch") ? 1 : 0;
 }
 
-GENPC_API int genpc_pose_optimize_cd_batch(int b, int nc, const float *complete, int np, const float *partial,
-                                           float lr, int iters, int starts, float *transform, float *history,
-                                           float *best_params, void *stream)
+GENPC_API int genpc_pose_cd_grad(int nc, const float *v, const float *center, const float *params, int np,
+                                 const float *partial, const float *d1, const int *i1, const float *d2, const int *i2,
+                                 float cd_weight, float reg_weight, float *loss_out, float *grad, void *stream)
+{
+    // loss_out[3]: total, cd, ortho (the Chamfer half alone)
+    using namespace genpc;
+    hipStream_t st = (hipStream_t)stream;
+    float *tmp = (float *)workspace(15, 256, st);
+    if (!tmp) return 0;
+    const int rc = genpc_pose_loss_grad(nc, v, center, params, np, partial, d1, i1, d2, i2, cd_weight, reg_weight, 0.0f,
+                                        0.0f, 0, tmp, grad, stream);
+    if (rc != 1) return rc;
+    return check(hipMemcpyAsync(loss_out, tmp, 3 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy loss") ? 1 : 0;
+}
+
+GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, int np, const float *partial,
+                                        float lr, int iters, int starts, float radius, int render_size,
+                                        float mask_weight, float *transform, float *history, float *best_params,
+                                        void *stream)
 {
     using namespace genpc;
     if (b <= 0 || nc <= 0 || np <= 0 || iters < 0 || starts < 1) return -1;
+    const bool mask = mask_weight != 0.0f;
+    if (mask && (render_size <= 0 || !(radius > 0.0f))) return -1;
     hipStream_t st = (hipStream_t)stream;
-    // scratch: accum[b,16] | state[b] | center[b,4] | pts[b,nc,3] | d1 | d2 | i1 | i2
+    const size_t P = mask ? (size_t)render_size * render_size : 0;
+    // scratch: accum[b,16] | state[b] | center[b,4] | pts[b,nc,3] | d1 | d2 | i1 | i2 | mask: stats, m_ref, L, W
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     size_t off = 0;
     const size_t o_acc = off; off += up((size_t)b * 16 * sizeof(double));
@@ -377,6 +767,10 @@ GENPC_API int genpc_pose_optimize_cd_batch(int b, int nc, const float *complete,
     const size_t o_d2 = off; off += up((size_t)b * np * 4);
     const size_t o_i1 = off; off += up((size_t)b * nc * 4);
     const size_t o_i2 = off; off += up((size_t)b * np * 4);
+    const size_t o_stats = off; off += up((size_t)b * 4 * sizeof(float));
+    const size_t o_mref = off; off += up((size_t)b * P * sizeof(float));
+    const size_t o_L = off; off += up((size_t)b * P * sizeof(float));
+    const size_t o_W = off; off += up((size_t)b * P * sizeof(float));
     char *ws = (char *)workspace(4, off, st);
     if (!ws) return 0;
     double *accum = (double *)(ws + o_acc);
@@ -385,11 +779,14 @@ GENPC_API int genpc_pose_optimize_cd_batch(int b, int nc, const float *complete,
     float *pts = (float *)(ws + o_pts);
     float *d1 = (float *)(ws + o_d1), *d2 = (float *)(ws + o_d2);
     int *i1 = (int *)(ws + o_i1), *i2 = (int *)(ws + o_i2);
+    float *stats = (float *)(ws + o_stats), *mref = (float *)(ws + o_mref), *L = (float *)(ws + o_L), *W = (float *)(ws + o_W);
     constexpr int kStateFloats = (int)(sizeof(PoseState) / sizeof(float));
     static_assert(sizeof(PoseState) % sizeof(float) == 0, "PoseState must be float-addressable");
 
     // center = mean(vert_pos) per scan (diff_obj_pose.py:362)
     if (!genpc_mean3(b, nc, complete, center, accum, st)) return 0;
+    // reference image of the partial cloud (render_reference_image, diff_obj_pose.py:108-134)
+    if (mask && !mask_prepare_ref(b, np, partial, radius, render_size, mref, stats, st)) return 0;
 
     const int gb = ceil_div(b, 64);
     hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, -1);
@@ -404,13 +801,24 @@ GENPC_API int genpc_pose_optimize_cd_batch(int b, int nc, const float *complete,
             hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, st, nc, complete, (const float *)center,
                                4, (const float *)S->params, kStateFloats, np, partial, (const float *)d1,
                                (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, accum);
+            if (mask && !mask_step(b, nc, complete, center, 4, S->params, kStateFloats, radius, render_size, mask_weight, mref,
+                                   stats, L, W, accum, st))
+                return 0;
             hipLaunchKernelGGL(pose_update_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, nc, np, 3.0f, 0.001f, lr, 1,
                                history ? history + (size_t)s * (iters + 1) + it : (float *)nullptr, hstride);
         }
         hipLaunchKernelGGL(pose_end_kernel, dim3(gb), dim3(64), 0, st, b, S, 0, (float *)nullptr, (float *)nullptr);
     }
     hipLaunchKernelGGL(pose_end_kernel, dim3(gb), dim3(64), 0, st, b, S, 1, transform, best_params);
-    return check(hipGetLastError(), "pose_optimize_cd launch") ? 1 : 0;
+    return check(hipGetLastError(), "pose_optimize launch") ? 1 : 0;
+}
+
+GENPC_API int genpc_pose_optimize_cd_batch(int b, int nc, const float *complete, int np, const float *partial,
+                                           float lr, int iters, int starts, float *transform, float *history,
+                                           float *best_params, void *stream)
+{
+    return genpc_pose_optimize_batch(b, nc, complete, np, partial, lr, iters, starts, 0.0f, 0, 0.0f, transform, history,
+                                     best_params, stream);
 }
 
 GENPC_API int genpc_pose_optimize_cd(int nc, const float *complete, int np, const float *partial, float lr,

@@ -24,6 +24,11 @@ def fps_sampling(points, k):
         raise ValueError("fps_sampling: need 0 < k <= N <= 262144 (k=%d, N=%d)" % (k, n))
     if rc != 1:
         raise RuntimeError("genpc_fps failed: " + _lib.last_error())
+    # index 0 is the start point of every cloud; the kernel writes -1 there when a hand-off
+    # between its workgroups timed out (the samples after it would be garbage)
+    if bool((out[:, 0] != 0).any()):
+        raise RuntimeError("genpc_fps: inter-workgroup hand-off timed out (workgroups of a cloud were not "
+                           "co-resident); no samples returned")
     return out[0] if single else out
 
 

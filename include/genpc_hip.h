@@ -202,6 +202,40 @@ int genpc_pose_optimize_cd_batch(int b, int nc, const float *complete, int np,
                                  int starts, float *transform, float *history,
                                  float *best_params, void *stream);
 
+/* Silhouette ("mask") half of the pose loss -------------------------------------- *
+ * The reference compares PulsarPointsRenderer images (pytorch3d, CUDA only -- absent here and
+ * unpinned) of the partial cloud (diff_obj_pose.py:108-134) and of the posed complete cloud
+ * (:426-433).  This library draws both with its OWN differentiable occupancy splat, same camera
+ * (eye (0,0,3) looking at the origin, focal 4 NDC) and radii (world units):
+ *   Zv = 3 - z;  u = S/2 (1 + 4 x / Zv);  v = S/2 (1 - 4 y / Zv);  rho = S/2 * 4 * radius / Zv
+ *   a_i = min(0.999, max(0, 1 - |pixel centre - (u, v)|^2 / rho^2));  img = 1 - prod_i (1 - a_i)
+ * genpc_splat_image writes img[size*size] (row-major, row 0 at the top) for pts[n,3].          */
+int genpc_splat_image(int n, const float *pts, float radius, int size, float *img, void *stream);
+
+/* compute_loss_function as a whole (diff_obj_pose.py:286-336) + the orthogonality term, and its
+ * analytic gradient:
+ *   loss = mask_weight * mask_loss + cd_weight * cd + reg_weight * |RR^T - I|_F
+ *   mask_loss = 30 MSE(m, m_ref) + BCE(m, m_ref) + 10 Dice(m, m_ref)  on the soft masks
+ *   m = sigmoid((normalised image - 0.1) / 0.05) of the posed cloud (splat radius 1.1 * radius,
+ *   :385) and of `partial` (radius, :118), statistical normalisation as at :204-217.
+ * d1/i1/d2/i2 as in genpc_pose_cd_grad.  mask_weight = 0 skips the mask term (render_size and
+ * radius are then ignored).  loss_out[4] = loss, cd, |RR^T-I|_F, mask_loss; grad[10].           */
+int genpc_pose_loss_grad(int nc, const float *v, const float *center, const float *params,
+                         int np, const float *partial, const float *d1, const int *i1,
+                         const float *d2, const int *i2, float cd_weight, float reg_weight,
+                         float mask_weight, float radius, int render_size, float *loss_out,
+                         float *grad, void *stream);
+
+/* object_pose_optimization's loop with the FULL objective for B scans in lock-step: as
+ * genpc_pose_optimize_cd_batch plus, per Adam step, the splat of the posed cloud, the mask loss
+ * and its gradient (three more launches; the reference image of `partial` is drawn once).
+ * radius / render_size: diff_obj_pose.py:496; mask_weight 1 is the reference's weight (:331).   */
+int genpc_pose_optimize_batch(int b, int nc, const float *complete, int np,
+                              const float *partial, float lr, int iters, int starts,
+                              float radius, int render_size, float mask_weight,
+                              float *transform, float *history, float *best_params,
+                              void *stream);
+
 /* ICP + scale search --------------------------------------------------------- *
  * Batched point-to-point ICP with the semantics of open3d's registration_icp as
  * reg_xyz.py calls it (:18-20,28-37: TransformationEstimationPointToPoint, default

@@ -420,6 +420,270 @@ ORACLE_API void oracle_pose_optimize_cd(int nc, const float *complete, int np_, 
 }
 
 /* ------------------------------------------------------------------------
+ * Silhouette ("mask") half of compute_loss_function, diff_obj_pose.py:286-336, and the
+ * renders it compares (:108-134 reference image of the partial cloud, :426-433 image of the
+ * posed complete cloud).
+ *
+ * WHAT IS RESTATED FROM THE REFERENCE (its own torch code):
+ *   normalize_images 'statistical' (:204-217): result' = clamp((result - mean) / (std + 1e-6)
+ *     * (std_ref + 1e-6) + mean_ref, 0, 1), torch.std = unbiased;
+ *   compute_soft_mask (:261-278): m = sigmoid((luminance - 0.1) / 0.05);
+ *   mask_loss = 30 MSE(m, m_ref) + BCE(m, m_ref) + 10 Dice(m, m_ref)   (:304-311,238-259),
+ *     F.binary_cross_entropy clamps its logs at -100; Dice smooth 1e-6;
+ *   total = mask_loss * 1 + cd * 3 (+ 1e-3 |RR^T - I|_F)   (:329-333,543-546).
+ * WHAT IS NOT: the renderer.  The reference renders with pytorch3d's PulsarPointsRenderer
+ * (CUDA only, absent here, unpinned): sphere splatting with a softmax in depth.  Its point clouds
+ * carry no colours on this path (load_point_cloud gives ones, :157-158), so the image is a soft
+ * occupancy map.  This build defines its OWN differentiable occupancy splat with the same
+ * camera and radii (PARITY UNPINNED against Pulsar):
+ *   camera (pytorch3d look_at_view_transform(eye=(0,0,3)) + PerspectiveCameras(focal 4, NDC),
+ *     from memory):  Zv = 3 - z;  u = S/2 (1 + 4 x / Zv);  v = S/2 (1 - 4 y / Zv);
+ *     rho = S/2 * 4 * radius / Zv (radius_world=True); points with Zv outside (1e-4, 5) are skipped;
+ *   coverage of pixel (r, c) by point i:  a = min(0.999, max(0, 1 - ((c + .5 - u)^2 + (r + .5 - v)^2) / rho^2));
+ *   image  I = 1 - prod_i (1 - a_i)   (all three channels equal: luminance = I).
+ * The posed cloud is splatted with 1.1 * radius (:385), the reference cloud with radius (:118).
+ * ---------------------------------------------------------------------- */
+#define MASK_AMAX 0.999
+static void splat_logt(int n, const float *pts, double radius, int S, double *logt)
+{
+    for (int q = 0; q < S * S; q++) logt[q] = 0.0;
+    const double hs = 0.5 * S;
+    for (int i = 0; i < n; i++) {
+        const double x = pts[(size_t)i * 3 + 0], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
+        const double zv = 3.0 - z;
+        if (!(zv > 1e-4) || !(zv < 5.0)) continue;
+        const double u = hs * (1.0 + 4.0 * x / zv), v = hs * (1.0 - 4.0 * y / zv), rho = hs * 4.0 * radius / zv;
+        int c0 = (int)floor(u - rho - 0.5), c1 = (int)ceil(u + rho - 0.5);
+        int r0 = (int)floor(v - rho - 0.5), r1 = (int)ceil(v + rho - 0.5);
+        if (c0 < 0) c0 = 0;
+        if (r0 < 0) r0 = 0;
+        if (c1 > S - 1) c1 = S - 1;
+        if (r1 > S - 1) r1 = S - 1;
+        for (int r = r0; r <= r1; r++)
+            for (int c = c0; c <= c1; c++) {
+                const double dx = c + 0.5 - u, dy = r + 0.5 - v;
+                double a = 1.0 - (dx * dx + dy * dy) / (rho * rho);
+                if (a <= 0.0) continue;
+                if (a > MASK_AMAX) a = MASK_AMAX;
+                logt[(size_t)r * S + c] += log(1.0 - a);
+            }
+    }
+}
+
+/* image of a cloud: I[S*S] */
+ORACLE_API void oracle_splat_image(int n, const float *pts, float radius, int S, float *img)
+{
+    double *logt = (double *)malloc(sizeof(double) * (size_t)S * S);
+    splat_logt(n, pts, radius, S, logt);
+    for (int q = 0; q < S * S; q++) img[q] = (float)(1.0 - exp(logt[q]));
+    free(logt);
+}
+
+/* torch.sigmoid on a float32 tensor: the soft masks are fp32 in the reference, and that shows:
+ * for (x - 0.1) / 0.05 > ~16.6 the result is exactly 1.0f, log(1 - m) is -inf and
+ * F.binary_cross_entropy's clamp at -100 decides the loss of that pixel (a pixel the posed cloud
+ * covers and the reference image does not costs 100 (1 - m_ref) / P, not 18 / P), while its
+ * gradient m (1 - m) is exactly 0.  The restatement keeps m and its logs in fp32 for that reason;
+ * everything around them accumulates in double. */
+static double sigm(double x) { return (double)(1.0f / (1.0f + expf(-(float)x))); }
+static double log_as_f32(double m) { return (double)logf((float)m); }
+
+/* mask_loss(result image I, reference image Iref) and d mask_loss / d I (NULL to skip). */
+static double mask_loss_images(int P, const double *I, const double *Iref, double *dLdI)
+{
+    double mu = 0, mur = 0;
+    for (int q = 0; q < P; q++) { mu += I[q]; mur += Iref[q]; }
+    mu /= P; mur /= P;
+    double var = 0, varr = 0;
+    for (int q = 0; q < P; q++) { var += (I[q] - mu) * (I[q] - mu); varr += (Iref[q] - mur) * (Iref[q] - mur); }
+    const double sd = sqrt(var / (P - 1)), sdr = sqrt(varr / (P - 1));
+    const double k = (sdr + 1e-6) / (sd + 1e-6);
+    double s_mse = 0, s_bce = 0, s_int = 0, s_m = 0, s_r = 0;
+    for (int q = 0; q < P; q++) {
+        double xn = (I[q] - mu) * k + mur;
+        xn = xn < 0 ? 0 : (xn > 1 ? 1 : xn);
+        const double m = sigm((xn - 0.1) / 0.05), mr = sigm((Iref[q] - 0.1) / 0.05);
+        double lm = log_as_f32(m), l1m = log_as_f32(1.0 - m);
+        if (lm < -100) lm = -100;
+        if (l1m < -100) l1m = -100;
+        s_mse += (m - mr) * (m - mr);
+        s_bce += -(mr * lm + (1.0 - mr) * l1m);
+        s_int += m * mr;
+        s_m += m;
+        s_r += mr;
+    }
+    const double den = s_m + s_r + 1e-6, num = 2.0 * s_int + 1e-6;
+    const double loss = 30.0 * s_mse / P + s_bce / P + 10.0 * (1.0 - num / den);
+    if (!dLdI) return loss;
+    /* G = d loss / d xn (through sigmoid and clamp), then through the statistics */
+    double *G = dLdI;
+    double sG = 0, sGd = 0;
+    for (int q = 0; q < P; q++) {
+        double xn = (I[q] - mu) * k + mur;
+        const int inside = xn > 0 && xn < 1;
+        xn = xn < 0 ? 0 : (xn > 1 ? 1 : xn);
+        const double m = sigm((xn - 0.1) / 0.05), mr = sigm((Iref[q] - 0.1) / 0.05);
+        double dm = 30.0 * 2.0 * (m - mr) / P;
+        /* BCE: -(mr/m - (1-mr)/(1-m)) / P where the logs are not clamped (torch's backward divides
+         * (m - mr) by max(m (1 - m), 1e-12): the same wherever m (1 - m) > 0, and where it is 0 the
+         * factor m (1 - m) of the sigmoid below makes the product 0 either way) */
+        double db = 0;
+        if (log_as_f32(m) > -100) db -= mr / m;
+        if (log_as_f32(1.0 - m) > -100) db += (1.0 - mr) / (1.0 - m);
+        dm += db / P;
+        dm += 10.0 * (-(2.0 * mr * den - num) / (den * den));
+        const double g = inside ? dm * m * (1.0 - m) / 0.05 : 0.0;
+        G[q] = g;
+        sG += g;
+        sGd += g * (I[q] - mu);
+    }
+    for (int q = 0; q < P; q++) {
+        double v = k * (G[q] - sG / P);
+        if (sd > 0) v -= (sdr + 1e-6) / ((sd + 1e-6) * (sd + 1e-6)) * (I[q] - mu) / ((P - 1) * sd) * sGd;
+        dLdI[q] = v;
+    }
+    return loss;
+}
+
+ORACLE_API float oracle_mask_loss(int S, const float *img, const float *ref)
+{
+    const int P = S * S;
+    double *a = (double *)malloc(sizeof(double) * 2 * (size_t)P);
+    for (int q = 0; q < P; q++) { a[q] = img[q]; a[P + q] = ref[q]; }
+    const double l = mask_loss_images(P, a, a + P, NULL);
+    free(a);
+    return (float)l;
+}
+
+/* Full loss and gradient: mask_weight * mask_loss + cd_weight * cd + reg_weight * |RR^T - I|_F.
+ * ref_img[S*S]: oracle_splat_image(partial, radius).  loss_out[4] = total, cd, ortho, mask. */
+ORACLE_API void oracle_pose_full_loss_grad(int nc, const float *v, const float *center, const float *params,
+                                           int np_, const float *partial, const float *d1, const int *i1,
+                                           const float *d2, const int *i2, float cd_weight, float reg_weight,
+                                           float mask_weight, float radius, int S, const float *ref_img,
+                                           float *loss_out, float *grad)
+{
+    float lo3[3], g_cd[10];
+    oracle_pose_loss_grad(nc, v, center, params, np_, partial, d1, i1, d2, i2, cd_weight, reg_weight, lo3, g_cd);
+    const int P = S * S;
+    float *pts = (float *)malloc(sizeof(float) * (size_t)nc * 3);
+    oracle_pose_transform(nc, v, center, params, pts);
+    double *logt = (double *)malloc(sizeof(double) * (size_t)P);
+    double *I = (double *)malloc(sizeof(double) * (size_t)P);
+    double *Ir = (double *)malloc(sizeof(double) * (size_t)P);
+    double *dLdI = (double *)malloc(sizeof(double) * (size_t)P);
+    const double rad = 1.1 * (double)radius;
+    splat_logt(nc, pts, rad, S, logt);
+    for (int q = 0; q < P; q++) { I[q] = 1.0 - exp(logt[q]); Ir[q] = ref_img[q]; }
+    const double ml = mask_loss_images(P, I, Ir, dLdI);
+    /* back through the splat to the points, then to (R, s, t) like the CD term */
+    float R[9];
+    oracle_rot6d_to_matrix(params, R);
+    const float s = expf(params[9]);
+    double gt[3] = {0, 0, 0}, gs = 0, gR[9] = {0};
+    const double hs = 0.5 * S;
+    for (int i = 0; i < nc; i++) {
+        const double x = pts[(size_t)i * 3 + 0], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
+        const double zv = 3.0 - z;
+        if (!(zv > 1e-4) || !(zv < 5.0)) continue;
+        const double u = hs * (1.0 + 4.0 * x / zv), vv = hs * (1.0 - 4.0 * y / zv), rho = hs * 4.0 * rad / zv;
+        int c0 = (int)floor(u - rho - 0.5), c1 = (int)ceil(u + rho - 0.5);
+        int r0 = (int)floor(vv - rho - 0.5), r1 = (int)ceil(vv + rho - 0.5);
+        if (c0 < 0) c0 = 0;
+        if (r0 < 0) r0 = 0;
+        if (c1 > S - 1) c1 = S - 1;
+        if (r1 > S - 1) r1 = S - 1;
+        double gu = 0, gv = 0, grho = 0;
+        for (int r = r0; r <= r1; r++)
+            for (int c = c0; c <= c1; c++) {
+                const double dx = c + 0.5 - u, dy = r + 0.5 - vv;
+                const double a = 1.0 - (dx * dx + dy * dy) / (rho * rho);
+                if (a <= 0.0 || a >= MASK_AMAX) continue;        /* clamped: no gradient */
+                const int q = r * S + c;
+                const double w = dLdI[q] * exp(logt[q]) / (1.0 - a);    /* dL/da_i */
+                gu += w * 2.0 * dx / (rho * rho);
+                gv += w * 2.0 * dy / (rho * rho);
+                grho += w * 2.0 * (dx * dx + dy * dy) / (rho * rho * rho);
+            }
+        /* u = hs (1 + 4x/zv), v = hs (1 - 4y/zv), rho = hs 4 rad / zv, zv = 3 - z */
+        const double gzv = gu * (-hs * 4.0 * x / (zv * zv)) + gv * (hs * 4.0 * y / (zv * zv)) + grho * (-rho / zv);
+        const double g[3] = {mask_weight * gu * hs * 4.0 / zv, mask_weight * gv * (-hs * 4.0 / zv), mask_weight * (-gzv)};
+        const float *vj = v + (size_t)i * 3;
+        const double l[3] = {vj[0] - center[0], vj[1] - center[1], vj[2] - center[2]};
+        for (int a = 0; a < 3; a++) {
+            gt[a] += g[a];
+            for (int b = 0; b < 3; b++) gR[a * 3 + b] += g[a] * s * l[b];
+            gs += g[a] * (R[a * 3 + 0] * l[0] + R[a * 3 + 1] * l[1] + R[a * 3 + 2] * l[2]);
+        }
+    }
+    double g6[6];
+    rot6d_backward(params, gR, g6);
+    for (int k = 0; k < 6; k++) grad[k] = g_cd[k] + (float)g6[k];
+    for (int k = 0; k < 3; k++) grad[6 + k] = g_cd[6 + k] + (float)gt[k];
+    grad[9] = g_cd[9] + (float)(gs * s);
+    loss_out[0] = lo3[0] + (float)(mask_weight * ml);
+    loss_out[1] = lo3[1];
+    loss_out[2] = lo3[2];
+    loss_out[3] = (float)ml;
+    free(pts); free(logt); free(I); free(Ir); free(dLdI);
+}
+
+/* object_pose_optimization with the full objective (diff_obj_pose.py:496-594):
+ * loss = mask_loss + 3 cd + 1e-3 |RR^T - I|_F, multi-start, best-of-starts as in
+ * oracle_pose_optimize_cd. */
+ORACLE_API void oracle_pose_optimize(int nc, const float *complete, int np_, const float *partial, float lr,
+                                     int iters, int starts, int fma_mode, float radius, int S, float mask_weight,
+                                     float *transform, float *history, float *best_params)
+{
+    float center[3] = {0, 0, 0};
+    {
+        double acc[3] = {0, 0, 0};
+        for (int j = 0; j < nc; j++)
+            for (int k = 0; k < 3; k++) acc[k] += complete[(size_t)j * 3 + k];
+        for (int k = 0; k < 3; k++) center[k] = (float)(acc[k] / nc);
+    }
+    float *pts = (float *)malloc(sizeof(float) * (size_t)nc * 3);
+    float *d1 = (float *)malloc(sizeof(float) * (size_t)nc);
+    int *i1 = (int *)malloc(sizeof(int) * (size_t)nc);
+    float *d2 = (float *)malloc(sizeof(float) * (size_t)np_);
+    int *i2 = (int *)malloc(sizeof(int) * (size_t)np_);
+    float *ref = (float *)malloc(sizeof(float) * (size_t)S * S);
+    oracle_splat_image(np_, partial, radius, S, ref);
+    float best_loss = INFINITY;
+    for (int st = 0; st < starts; st++) {
+        double th = st * 90.0 * M_PI / 180.0;
+        float params[10] = {(float)cos(th), 0.0f, (float)sin(th), 0.0f, 1.0f, 0.0f, 0, 0, 0, logf(0.75f)};
+        float m[10] = {0}, vv[10] = {0};
+        float local_best = INFINITY;
+        for (int it = 0; it <= iters; it++) {
+            oracle_pose_transform(nc, complete, center, params, pts);
+            oracle_nm_distance(1, nc, pts, np_, partial, d1, i1, fma_mode);
+            oracle_nm_distance(1, np_, partial, nc, pts, d2, i2, fma_mode);
+            float lo[4], grad[10];
+            oracle_pose_full_loss_grad(nc, complete, center, params, np_, partial, d1, i1, d2, i2, 3.0f, 0.001f,
+                                       mask_weight, radius, S, ref, lo, grad);
+            if (history) history[(size_t)st * (iters + 1) + it] = lo[0];
+            if (lo[0] < local_best) local_best = lo[0];
+            oracle_adam_step(params, grad, m, vv, it + 1, lr);
+        }
+        if (local_best < best_loss) {
+            best_loss = local_best;
+            memcpy(best_params, params, sizeof(params));
+        }
+    }
+    float R[9];
+    oracle_rot6d_to_matrix(best_params, R);
+    float s = expf(best_params[9]);
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) transform[a * 4 + b] = R[a * 3 + b] * s;
+        transform[a * 4 + 3] = best_params[6 + a];
+    }
+    transform[12] = transform[13] = transform[14] = 0.0f;
+    transform[15] = 1.0f;
+    free(pts); free(d1); free(i1); free(d2); free(i2); free(ref);
+}
+
+/* ------------------------------------------------------------------------
  * Point-to-point ICP, the algorithm behind open3d.pipelines.registration.
  * registration_icp as the reference calls it (reg_xyz.py:18-20,28-37): default
  * ICPConvergenceCriteria (relative_fitness 1e-6, relative_rmse 1e-6, 30

@@ -351,6 +351,55 @@ def pose_optimize_cd(complete, partial, lr=0.01, iters=200, starts=4, fma_mode=1
     return T.reshape(4, 4), hist, bp
 
 
+def splat_image(pts, radius, size):
+    """Own soft-occupancy splat (genpc_oracle_geom.c, PARITY UNPINNED against Pulsar) -> [size, size]."""
+    p, pp = _f(pts)
+    img = np.zeros((size, size), np.float32)
+    lib().oracle_splat_image(p.shape[0], pp, ctypes.c_float(radius), int(size), img.ctypes.data_as(_f32p))
+    return img
+
+
+def mask_loss(img, ref):
+    a, pa = _f(img)
+    r, pr = _f(ref)
+    lib().oracle_mask_loss.restype = ctypes.c_float
+    return float(lib().oracle_mask_loss(int(a.shape[0]), pa, pr))
+
+
+def pose_full_loss_grad(v, center, params, partial, d1, i1, d2, i2, radius, size, ref_img, cd_weight=3.0,
+                        reg_weight=0.001, mask_weight=1.0):
+    """-> (loss[4] = total, cd, ortho, mask ; grad[10])."""
+    v, pv = _f(v)
+    c, pc = _f(center)
+    p, pp = _f(params)
+    q, pq = _f(partial)
+    d1, pd1 = _f(d1)
+    d2, pd2 = _f(d2)
+    i1, pi1 = _i(i1)
+    i2, pi2 = _i(i2)
+    ref, pref = _f(ref_img)
+    lo = np.zeros(4, np.float32)
+    g = np.zeros(10, np.float32)
+    lib().oracle_pose_full_loss_grad(v.shape[0], pv, pc, pp, q.shape[0], pq, pd1, pi1, pd2, pi2,
+                                     ctypes.c_float(cd_weight), ctypes.c_float(reg_weight), ctypes.c_float(mask_weight),
+                                     ctypes.c_float(radius), int(size), pref, lo.ctypes.data_as(_f32p),
+                                     g.ctypes.data_as(_f32p))
+    return lo, g
+
+
+def pose_optimize(complete, partial, lr=0.01, iters=200, starts=4, radius=0.02, size=224, mask_weight=1.0, fma_mode=1):
+    """Full objective (mask + 3 cd + ortho) -> (T[4,4], history[starts, iters+1], best_params[10])."""
+    c, pc = _f(complete)
+    q, pq = _f(partial)
+    T = np.zeros(16, np.float32)
+    hist = np.zeros((starts, iters + 1), np.float32)
+    bp = np.zeros(10, np.float32)
+    lib().oracle_pose_optimize(c.shape[0], pc, q.shape[0], pq, ctypes.c_float(lr), int(iters), int(starts),
+                               int(fma_mode), ctypes.c_float(radius), int(size), ctypes.c_float(mask_weight),
+                               T.ctypes.data_as(_f32p), hist.ctypes.data_as(_f32p), bp.ctypes.data_as(_f32p))
+    return T.reshape(4, 4), hist, bp
+
+
 def kabsch_from_sums(sums):
     s = np.ascontiguousarray(sums, np.float64)
     u = np.zeros(16, np.float64)

@@ -159,3 +159,20 @@ def test_extreme_ties_and_limits(gp, oracle):
     s = run_hip(gp, a3, b3, 0.005, 3, 1)
     d, ass = oracle.emd_forward(a3, b3, 0.005, 3, 1)
     np.testing.assert_array_equal(s["assignment"], ass)
+
+
+@pytest.mark.parametrize("scale,offset", [(100.0, 0.0), (30.0, 250.0), (1000.0, -500.0), (1e-3, 0.0)])
+def test_unnormalised_clouds(gp, oracle, scale, offset):
+    """Clouds far outside the unit cube (bid values of magnitude 1e2..1e3, where a fixed 2e-6
+    slack in the bid pre-filter would be below one ulp): bids, increments, assignment and
+    distances still bit-exact against the oracle."""
+    a, b = gen_pair(77, (2, 1024, 3), (2, 1024, 3), 0.0)
+    a = (a * np.float32(scale) + np.float32(offset)).astype(np.float32)
+    b = (b * np.float32(scale) + np.float32(offset)).astype(np.float32)
+    for iters in (3, 50):
+        s = run_hip(gp, a, b, 0.005, iters, 1)
+        d, ass, st = oracle.emd_forward(a, b, 0.005, iters, 1, return_state=True)
+        np.testing.assert_array_equal(s["assignment"], ass)
+        np.testing.assert_array_equal(s["dist"], d)
+        np.testing.assert_array_equal(s["bid"], st["bid"])
+        np.testing.assert_array_equal(s["bid_increments"], st["bid_increments"])

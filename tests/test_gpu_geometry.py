@@ -122,14 +122,78 @@ def test_pose_transform_and_gradient(gp, oracle):
     d1, d2, i1, i2 = oracle.chamfer_forward(opts[None], partial[None], 1)
     lo, g = oracle.pose_loss_grad(complete, c, params, partial, d1[0], i1[0], d2[0], i2[0])
     np.testing.assert_allclose(loss.cpu().numpy(), lo, rtol=2e-5, atol=1e-6)
-    np.testing.assert_allclose(grad.cpu().numpy(), g, rtol=2e-3, atol=2e-5)
+    # The gradient is a sum of ~4500 signed per-point terms; the kernel forms them from the fp32
+    # posed points and fp32 reference distances (as torch's fp32 autograd would), the oracle from the
+    # same inputs: agreement is 1e-4 of the gradient's magnitude per parameter group (rotation,
+    # translation, scale), which is what cancellation in fp32 inputs allows.
+    gg, go = grad.cpu().numpy().astype(np.float64), g.astype(np.float64)
+    for sl in (slice(0, 6), slice(6, 9), slice(9, 10)):
+        assert np.abs(gg[sl] - go[sl]).max() <= 1e-4 * np.abs(go[sl]).max(), (sl, gg[sl], go[sl])
+
+
+def test_splat_image_vs_oracle(gp, oracle):
+    """The occupancy splat (the build's stand-in for the reference's Pulsar renders): image of a
+    cloud against the oracle's fp64 restatement, several radii and image sizes."""
+    torch = gp["torch"]
+    complete, partial, _ = _shape(5, 4000)
+    for radius, size in ((0.02, 224), (0.022, 224), (0.05, 96), (0.005, 224), (0.02, 57)):
+        img = gp["POSE"].splat_image(torch.from_numpy(partial).cuda(), radius, size).cpu().numpy()
+        ref = oracle.splat_image(partial, radius, size)
+        np.testing.assert_allclose(img, ref, atol=2e-4)      # fp32 (u, v, rho) against fp64: pixels on a disc's rim
+        assert img.shape == (size, size) and 0.005 < img.mean() < 0.9
+
+
+def test_full_loss_and_gradient_vs_oracle(gp, oracle):
+    """compute_loss_function as a whole (mask + 3 cd + ortho): loss terms and the 10-vector
+    gradient against the oracle (whose gradient is pinned to torch autograd)."""
+    torch = gp["torch"]
+    complete, partial, _ = _shape(3, 3000)
+    params = np.array([0.9, 0.1, -0.3, 0.05, 1.1, 0.2, 0.02, -0.01, 0.03, math.log(0.8)], np.float32)
+    c = complete.astype(np.float64).mean(0).astype(np.float32)
+    C, P, PR, CT = (torch.from_numpy(x).cuda() for x in (complete, partial, params, c))
+    for radius, size in ((0.02, 224), (0.03, 128)):
+        loss, grad = gp["POSE"].pose_loss_grad(C, CT, PR, P, radius, size)
+        opts = oracle.pose_transform(complete, c, params)
+        d1, d2, i1, i2 = oracle.chamfer_forward(opts[None], partial[None], 1)
+        ref = oracle.splat_image(partial, radius, size)
+        lo, g = oracle.pose_full_loss_grad(complete, c, params, partial, d1[0], i1[0], d2[0], i2[0], radius, size, ref)
+        np.testing.assert_allclose(loss.cpu().numpy(), lo, rtol=2e-4, atol=1e-5)
+        lo_cd, g_cd = oracle.pose_loss_grad(complete, c, params, partial, d1[0], i1[0], d2[0], i2[0])
+        gg, go = grad.cpu().numpy().astype(np.float64), g.astype(np.float64)
+        # the mask term must carry weight here, or the comparison says nothing about it
+        assert np.abs(go - g_cd).max() > 0.05 * np.abs(go).max()
+        for sl in (slice(0, 6), slice(6, 9), slice(9, 10)):
+            assert np.abs(gg[sl] - go[sl]).max() <= 2e-3 * np.abs(go[sl]).max(), (sl, gg[sl], go[sl])
+
+
+def test_pose_loop_full_objective(gp, oracle):
+    """object_pose_optimization with radius / render_size live (the reference's call: radius 0.02,
+    224 x 224): the early loss history tracks the oracle's loop, the same start wins, and the
+    result differs from the Chamfer-only run."""
+    torch = gp["torch"]
+    complete, partial, Rt = _shape(9, 1200)
+    C, P = torch.from_numpy(complete).cuda(), torch.from_numpy(partial).cuda()
+    T, hist, bp = gp["POSE"].object_pose_optimization(C, P, radius=0.02, lr=0.01, iters=60, render_size=224,
+                                                      return_history=True)
+    oT, ohist, obp = oracle.pose_optimize(complete, partial, lr=0.01, iters=60, starts=4, radius=0.02, size=224)
+    assert hist.shape == (4, 61) and np.isfinite(hist).all()
+    np.testing.assert_allclose(hist[:, :10], ohist[:, :10], rtol=5e-3)
+    best = int(np.argmin(ohist.min(1)))
+    assert int(np.argmin(hist.min(1))) == best
+    # the winning start ends where the oracle's does; the losing starts (rotated by 90 / 180 / 270
+    # degrees) wander: the loss jumps by 100 / P whenever a pixel's soft mask saturates (fp32
+    # sigmoid + BCE clamp, as in the reference), so late trajectories are not comparable
+    np.testing.assert_allclose(hist.min(1)[best], ohist.min(1)[best], rtol=0.02)
+    Tc, hc, _ = gp["POSE"].object_pose_optimization(C, P, radius=0.02, lr=0.01, iters=60, return_history=True, cd_only=True)
+    assert np.abs(hist[:, 0] - hc[:, 0]).min() > 1e-3        # the mask term is in the loss
+    assert T[3].tolist() == [0, 0, 0, 1]
 
 
 def test_pose_optimisation_loop(gp, oracle):
     torch = gp["torch"]
     complete, partial, Rt = _shape(9, 1200)
     T, hist, bp = gp["POSE"].object_pose_optimization(torch.from_numpy(complete).cuda(), torch.from_numpy(partial).cuda(),
-                                                      radius=0.02, lr=0.01, iters=200, return_history=True)
+                                                      radius=0.02, lr=0.01, iters=200, return_history=True, cd_only=True)
     oT, ohist, obp = oracle.pose_optimize_cd(complete, partial, lr=0.01, iters=200, starts=4)
     assert hist.shape == (4, 201)
     assert int(np.argmin(hist.min(1))) == int(np.argmin(ohist.min(1)))
@@ -152,7 +216,7 @@ def test_pose_loop_full_size_property(gp):
     from genpc_amd.utils.loss_util import Completionloss
     complete, partial, Rt = _shape(11, 32768)
     C, P = torch.from_numpy(complete).cuda(), torch.from_numpy(partial).cuda()
-    T = gp["POSE"].object_pose_optimization(C, P, lr=0.01, iters=200)
+    T = gp["POSE"].object_pose_optimization(C, P, lr=0.01, iters=200, cd_only=True)
     c = C.mean(0)
     Tt = torch.from_numpy(T).cuda()
     aligned = (C - c) @ Tt[:3, :3].T + c + Tt[:3, 3]
