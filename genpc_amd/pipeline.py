@@ -1,0 +1,79 @@
+"""The geometric stages of one completed scan, chained on the GPU (BASELINE config 2 without
+the two generators): what ``main.py`` does around the diffusion model and
+the image-to-3D model of the reference, on tensors instead of files.
+
+    stage 1  DepthPrompting (DepthPrompting.py:100-237): viewpoint selection, projection of the
+             partial cloud into the chosen camera, sparse colour / depth images and hole masks
+             -- the inputs of the depth-conditioned diffusion model (a stock torch module, out of
+             scope: its output image is an argument here)
+    stage 2  ScaleAdapter (ScaleAdapter.py:15-86): colours of the partial points from the
+             generated image (colorPoint), then reg(): pose initialisation, coarse scale sweep,
+             anisotropic scale search (reg_xyz.py:99-205) against the generated shape (the
+             image-to-3D model's output, an argument here), then the fusion tail (:207-219)
+    metric   main.metric (main.py:11-36): FPS to 16384 points, CD-L1 / CD-L2 / EMD against the
+             ground truth
+
+``complete_scan`` returns every intermediate product so that tests can check each stage
+against the oracle on the stage's actual input.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from .DepthPrompting import DepthPrompting
+from .ScaleAdapter import ScaleAdapter
+from .fps import fps_sampling
+from .metric import evaluate_scans
+from . import reg_xyz
+
+
+def default_cfg(device="cuda", view_num=1024):
+    """configs/config.yaml values of the reference that the geometric stages read."""
+    return SimpleNamespace(device=str(device), fovy=49.1, res=256, cam_res=256, padding=0.15, rescale=True, point_size=1,
+                           mask_pixel_rate=3, view_num=view_num, distance=1.6, downsample_num=10000,
+                           generative_model="trellis", dataset="redwood")
+
+
+def fps_to(xyz, k):
+    """main.py:21-24: farthest point sampling to k points (pad-repeat when the cloud is smaller)."""
+    n = xyz.shape[0]
+    if n >= k:
+        return xyz[fps_sampling(xyz.contiguous().float(), k).long()]
+    rep = xyz[torch.arange(k - n, device=xyz.device) % n]
+    return torch.cat([xyz, rep], dim=0)
+
+
+def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=None, dp=None, metric_points=16384,
+                  fused_points=20000, cd_only_pose=False):
+    """partial_xyz [Np,3]: the observed scan; generated_xyz [Ng,3]: points of the generated shape in
+    the generator's frame; generated_img [3,1024,1024]: the image the partial points take their
+    colours from.  Returns a dict of every stage's outputs."""
+    cfg = cfg or default_cfg(partial_xyz.device)
+    dp = dp or DepthPrompting(cfg)
+    sa = ScaleAdapter(cfg)
+    out = {}
+    # ---- stage 1: DepthPrompting.getImage (:100-170) ----
+    view = dp.viewpoint_select(partial_xyz)
+    cam = dp.cameras[view:view + 1]
+    uv, depth, _ = dp.getUvs(cam, partial_xyz, rescale=cfg.rescale, padding=cfg.padding, want_transformed=False)
+    pix = dp.uvToPixels(uv[0], cfg.res)
+    colors = torch.ones(partial_xyz.shape[0], 3, device=partial_xyz.device)
+    sparse_img, sparse_depth, hole1, hole2 = dp.getRawDepth(pix, depth[0], colors=colors, res=cfg.res,
+                                                            point_size=cfg.point_size, mask_pixel_rate=cfg.mask_pixel_rate)
+    out.update(view=view, uv=uv[0], depth=depth[0], pixels=pix, sparse_img=sparse_img, sparse_depth=sparse_depth,
+               hole_mask1=hole1, hole_mask2=hole2)
+    # ---- stage 2: ScaleAdapter.scaleAdapter (:15-86) ----
+    out["point_colors"] = sa.colorPoint(uv[0], generated_img)
+    res = reg_xyz.reg(partial_xyz, generated_xyz, generative_model=cfg.generative_model, dataset=cfg.dataset,
+                      cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=True, cd_only_pose=cd_only_pose)
+    out["reg"] = res
+    fused = reg_xyz.fuse(res["source"], res["target"], num_points=fused_points)
+    out["fused"] = fused
+    # ---- metric: main.metric (main.py:11-36) ----
+    if gt_xyz is not None:
+        pred = fps_to(fused, metric_points)
+        gt = fps_to(gt_xyz, metric_points)
+        out["pred_metric_points"] = pred
+        out["gt_metric_points"] = gt
+        out["metric"] = evaluate_scans(pred[None].contiguous(), gt[None].contiguous())[0]
+    return out

@@ -154,18 +154,23 @@ def normalize_numpy(xyz, range=1.0):
 def voxel_down_sample(xyz, voxel_size):
     """Counterpart of open3d's PointCloud.voxel_down_sample (reg_xyz.py:154-155; open3d
     absent and unpinned): grid anchored at min_bound - voxel/2, one output point per
-    occupied voxel = mean of its points.  Output order: ascending voxel key (open3d's
-    is its hash-map order).  torch ops only -- format/plumbing layer."""
-    origin = xyz.min(0).values - voxel_size * 0.5
-    ijk = torch.floor((xyz - origin) / voxel_size).long()
-    dims = ijk.max(0).values + 1
-    key = (ijk[:, 0] * dims[1] + ijk[:, 1]) * dims[2] + ijk[:, 2]
-    uniq, inv = torch.unique(key, return_inverse=True)
-    out = torch.zeros(uniq.shape[0], 3, dtype=torch.float64, device=xyz.device)
-    out.index_add_(0, inv, xyz.double())
-    cnt = torch.zeros(uniq.shape[0], dtype=torch.float64, device=xyz.device)
-    cnt.index_add_(0, inv, torch.ones_like(inv, dtype=torch.float64))
-    return (out / cnt[:, None]).to(xyz.dtype)
+    occupied voxel = mean of its points (double, point order).  Output order: ascending
+    voxel index (open3d's is its hash-map order).  One call into the HIP library
+    (csrc/voxel.hip: keys, radix sort, segmented mean)."""
+    pts = xyz.contiguous().float()
+    _lib.check_tensors((("xyz", pts),))
+    n = pts.shape[0]
+    out = torch.empty(n, 3, device=pts.device)
+    cnt = torch.empty(1, device=pts.device, dtype=torch.int32)
+    rc = _lib.on_device_of(pts, _L.genpc_voxel_down_sample, n, _p(pts), float(voxel_size), _p(out), _p(cnt))
+    if rc == -1:
+        raise ValueError("voxel_down_sample: voxel_size must be positive")
+    if rc != 1:
+        raise RuntimeError("genpc_voxel_down_sample failed: " + _lib.last_error())
+    k = int(cnt.item())
+    if k < 0:
+        raise ValueError("voxel_down_sample: non-finite coordinate, or more than 2^21 voxels along an axis")
+    return out[:k].to(xyz.dtype)
 
 
 def _apply(T, xyz):
@@ -175,7 +180,7 @@ def _apply(T, xyz):
 
 
 def reg(partial_xyz, complete_xyz, generative_model="trellis", dataset="redwood", cd_inv_weight=0.5,
-        diff_init=True, reg_fine_xyz=False, pose_points=(8000, 120000), pose_voxel=0.02):
+        diff_init=True, reg_fine_xyz=False, pose_points=(8000, 120000), pose_voxel=0.02, cd_only_pose=False):
     """reg_xyz.py:99-205 without file I/O and without the fusion tail.
     partial_xyz: the observed cloud (color_point.ply), complete_xyz: points sampled from
     the generated mesh (glb2point).  Returns a dict with the aligned clouds
@@ -188,7 +193,7 @@ def reg(partial_xyz, complete_xyz, generative_model="trellis", dataset="redwood"
     diff_transform = np.eye(4)
     if diff_init:                                                       # :109-122
         T = object_pose_optimization(voxel_down_sample(target, pose_voxel), voxel_down_sample(source, pose_voxel),
-                                     radius=0.02, lr=0.01, iters=200, render_size=224)
+                                     radius=0.02, lr=0.01, iters=200, render_size=224, cd_only=cd_only_pose)
         diff_transform = np.linalg.inv(T.astype(np.float64))
     out["diff_transform"] = diff_transform
     source = _apply(diff_transform, source)                             # :126

@@ -236,6 +236,18 @@ int genpc_pose_optimize_batch(int b, int nc, const float *complete, int np,
                               float *transform, float *history, float *best_params,
                               void *stream);
 
+/* Voxel-grid down-sampling ---------------------------------------------------- *
+ * Counterpart of open3d's PointCloud.voxel_down_sample, which reg() applies to both clouds
+ * before every ICP / scale search (reg_xyz.py:154-155,178-183; open3d absent, unpinned -- its
+ * published definition): grid anchored at min_bound - voxel_size / 2, index =
+ * floor((p - anchor) / voxel_size) in double, one output point per occupied voxel = the mean
+ * of its points accumulated in point order (double).  Output order: ascending (i, j, k).
+ * out[n,3] must hold up to n points; *out_count (device int) receives the number written, or
+ * -1 when a coordinate is not finite or the grid would exceed 2^21 cells along an axis.
+ * Returns -1 for voxel_size <= 0.                                                        */
+int genpc_voxel_down_sample(int n, const float *xyz, float voxel_size, float *out,
+                            int *out_count, void *stream);
+
 /* ICP + scale search --------------------------------------------------------- *
  * Batched point-to-point ICP with the semantics of open3d's registration_icp as
  * reg_xyz.py calls it (:18-20,28-37: TransformationEstimationPointToPoint, default

@@ -921,3 +921,54 @@ ORACLE_API void oracle_zbuffer_visibility(int c, int n, const float *uv, const f
     }
     free(zb); free(px);
 }
+
+
+/* ------------------------------------------------------------------------
+ * Voxel-grid down-sampling -- open3d's PointCloud.voxel_down_sample as reg() uses it
+ * (reg_xyz.py:154-155,178-183; open3d absent and unpinned: published definition).
+ *   anchor = min_bound - voxel / 2;  index = floor((p - anchor) / voxel)  (double);
+ *   one output point per occupied voxel: the mean of its points, summed in point order (double).
+ * Output order: ascending (i, j, k).  Returns the number of output points, -1 on a non-finite
+ * coordinate / an axis with more than 2^21 voxels.
+ * ---------------------------------------------------------------------- */
+typedef struct { unsigned long long key; int idx; } vox_t;
+static int vox_cmp(const void *a, const void *b)
+{
+    const vox_t *x = (const vox_t *)a, *y = (const vox_t *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+ORACLE_API int oracle_voxel_down_sample(int n, const float *xyz, float voxel_size, float *out)
+{
+    if (n <= 0) return 0;
+    const double voxel = voxel_size;
+    float mn[3] = {xyz[0], xyz[1], xyz[2]};
+    for (int i = 1; i < n; i++)
+        for (int k = 0; k < 3; k++)
+            if (xyz[(size_t)i * 3 + k] < mn[k]) mn[k] = xyz[(size_t)i * 3 + k];
+    vox_t *v = (vox_t *)malloc(sizeof(vox_t) * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        unsigned long long key = 0;
+        for (int k = 0; k < 3; k++) {
+            const double c = floor(((double)xyz[(size_t)i * 3 + k] - ((double)mn[k] - voxel * 0.5)) / voxel);
+            if (!(c >= 0.0 && c < 2097152.0)) { free(v); return -1; }
+            key = (key << 21) | (unsigned long long)c;
+        }
+        v[i].key = key;
+        v[i].idx = i;
+    }
+    qsort(v, (size_t)n, sizeof(vox_t), vox_cmp);
+    int m = 0;
+    for (int i = 0; i < n;) {
+        double s[3] = {0, 0, 0};
+        int j = i;
+        for (; j < n && v[j].key == v[i].key; j++)
+            for (int k = 0; k < 3; k++) s[k] += (double)xyz[(size_t)v[j].idx * 3 + k];
+        for (int k = 0; k < 3; k++) out[(size_t)m * 3 + k] = (float)(s[k] / (j - i));
+        m++;
+        i = j;
+    }
+    free(v);
+    return m;
+}

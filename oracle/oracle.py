@@ -447,3 +447,13 @@ def zbuffer_visibility(uv, depth, res, tol, point_size=2):
     lib().oracle_zbuffer_visibility(c, n, pu, pd, int(res), int(point_size), ctypes.c_float(tol),
                                     vis.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), cnt.ctypes.data_as(_i32p))
     return vis.astype(bool), cnt
+
+
+def voxel_down_sample(xyz, voxel_size):
+    """open3d-style voxel grid mean (published definition; unpinned) -> [K,3]."""
+    p, pp = _f(xyz)
+    out = np.zeros_like(p)
+    k = int(lib().oracle_voxel_down_sample(p.shape[0], pp, ctypes.c_float(voxel_size), out.ctypes.data_as(_f32p)))
+    if k < 0:
+        raise ValueError("voxel_down_sample: bad input")
+    return out[:k].copy()

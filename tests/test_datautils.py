@@ -1,6 +1,7 @@
 """Host-side format helpers (no GPU): PLY round trip in the layout of the
 reference's data/*.ply, normalisation and rotation helpers."""
 import numpy as np
+import pytest
 
 from genpc_amd.utils import dataUtils as D
 
@@ -109,3 +110,31 @@ def test_glb_loader_and_surface_sampling(tmp_path):
     # on face (0,1,2) (z = 0) the colour is the barycentric blend of red / green / blue
     on = np.abs(P[:, 2]) < 1e-12
     np.testing.assert_allclose(Cc[on], np.stack([1 - P[on, 0] - P[on, 1], P[on, 0], P[on, 1]], 1), atol=1e-9)
+
+
+def np_voxel_down_sample(xyz, voxel):
+    """open3d's published definition in numpy: double index arithmetic, per-voxel mean summed in
+    point order (np.add.at is sequential), ascending (i, j, k)."""
+    anchor = xyz.min(0).astype(np.float64) - voxel * 0.5
+    ijk = np.floor((xyz.astype(np.float64) - anchor) / voxel).astype(np.int64)
+    key = (ijk[:, 0] << 42) | (ijk[:, 1] << 21) | ijk[:, 2]
+    uniq, inv = np.unique(key, return_inverse=True)
+    s = np.zeros((uniq.shape[0], 3), np.float64)
+    np.add.at(s, inv, xyz.astype(np.float64))
+    cnt = np.bincount(inv, minlength=uniq.shape[0])
+    return (s / cnt[:, None]).astype(np.float32)
+
+
+def test_oracle_voxel_down_sample_matches_numpy(oracle):
+    rng = np.random.default_rng(2)
+    xyz = (rng.random((5000, 3), dtype=np.float32) - np.float32(0.5)) * np.float32([1.0, 0.6, 0.3])
+    xyz[100:140] = xyz[0:40]                      # repeated points
+    for voxel in (np.float32(0.02), np.float32(0.03), np.float32(0.2), np.float32(5.0)):
+        got = oracle.voxel_down_sample(xyz, voxel)
+        exp = np_voxel_down_sample(xyz, np.float64(voxel))
+        np.testing.assert_array_equal(got, exp)
+    assert oracle.voxel_down_sample(xyz, 5.0).shape == (1, 3)
+    with pytest.raises(ValueError):
+        bad = xyz.copy()
+        bad[3, 1] = np.nan
+        oracle.voxel_down_sample(bad, 0.03)

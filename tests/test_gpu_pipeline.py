@@ -1,0 +1,158 @@
+"""BASELINE config 2 (the geometric stages of one completed scan, chained, 8192-point partial
+scan) and config 5's per-rank shape (8 scans x 32768 points in lock-step through the full
+registration objective).  Every stage of the chain is checked against the oracle ON THE STAGE'S
+ACTUAL INPUT (the previous stage's GPU output); the end of the chain by outcome."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from genpc_amd import pipeline, reg_xyz
+    from genpc_amd.DepthPrompting import DepthPrompting
+    cfg = pipeline.default_cfg("cuda", view_num=256)
+    return dict(torch=torch, P=pipeline, R=reg_xyz, cfg=cfg, dp=DepthPrompting(cfg))
+
+
+def rot(axis, deg):
+    a = np.asarray(axis, np.float64)
+    a /= np.linalg.norm(a)
+    t = np.deg2rad(deg)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(t) * K + (1 - np.cos(t)) * K @ K
+
+
+def c2_inputs(golden, scan=0):
+    """One bundled scan: the 16384-point ground truth is the 'generated' shape after an unknown
+    similarity transform (what the image-to-3D model returns: its own frame and scale); the
+    partial scan is the observation at 8192 points."""
+    g = golden("scans13_fps16384.npz")
+    gt = g["gt"][scan]
+    partial = g["partial"][scan][:8192].copy()
+    c = (gt.max(0) + gt.min(0)) / 2
+    gen = (((gt - c) / (gt.max(0) - gt.min(0)).max()).astype(np.float64) @ rot([0.2, 1.0, 0.1], 9.0).T).astype(np.float32)
+    rng = np.random.default_rng(7)
+    img = rng.random((3, 1024, 1024), dtype=np.float32)
+    return partial, gen, img, gt
+
+
+def test_config2_chain_8192(env, oracle, golden):
+    torch = env["torch"]
+    partial, gen, img, gt = c2_inputs(golden)
+    Pt, Gt, It, GTt = (torch.from_numpy(x).cuda() for x in (partial, gen, img, gt))
+    out = env["P"].complete_scan(Pt, Gt, It, GTt, cfg=env["cfg"], dp=env["dp"])
+    cfg = env["cfg"]
+    # ---- stage 1: projection / pixels / splat against the oracle, on the chosen camera ----
+    view = out["view"]
+    cam = env["dp"].cameras[view:view + 1].cpu().numpy()
+    ouv, odepth, _, _ = oracle.get_uvs(cam, env["dp"].focal, partial, rescale=True, padding=cfg.padding)
+    np.testing.assert_array_equal(out["uv"].cpu().numpy(), ouv[0])
+    np.testing.assert_array_equal(out["depth"].cpu().numpy(), odepth[0])
+    opix = oracle.uv_to_pixels(ouv[0], cfg.res, cfg.res - 1)
+    np.testing.assert_array_equal(out["pixels"].cpu().numpy(), opix)
+    d = odepth[0]
+    grey = (np.float32(0.1) + np.float32(0.8) * (np.float32(1) - (d - d.min()) / (d.max() - d.min()))).astype(np.float32)
+    osparse, _ = oracle.paint_pixels(cfg.res, opix, np.repeat(grey[:, None], 3, 1), cfg.point_size)
+    np.testing.assert_allclose(out["sparse_depth"].cpu().numpy(), osparse, atol=1e-6)
+    assert float(out["hole_mask1"].sum()) > 0 and out["sparse_img"].shape == (3, cfg.res, cfg.res)
+    # ---- stage 2a: colours of the partial points from the generated image ----
+    opix1024 = oracle.uv_to_pixels(ouv[0], 1024, 1023)
+    np.testing.assert_array_equal(out["point_colors"].cpu().numpy(), oracle.gather_colors(opix1024, img))
+    # ---- stage 2b: registration by outcome: the aligned generated shape explains the scan ----
+    res = out["reg"]
+    src, tgt = res["source"].cpu().numpy(), res["target"].cpu().numpy()
+    np.testing.assert_allclose(src, partial, atol=1e-5)            # the scan returns to its own frame
+    d1, _, _, _ = oracle.chamfer_forward(src[None], tgt[None], 1)
+    cd_partial = float(np.sqrt(d1).mean())
+    assert cd_partial < 0.02, cd_partial
+    # ---- stage 2c: fusion tail against the oracle on the registered clouds ----
+    dd, _, _, _ = oracle.chamfer_forward(tgt[None], src[None], 1)
+    keep = ~(dd[0] < np.float32(1e-4))
+    allp = np.concatenate([src, tgt[keep]])
+    fused_no_filter = env["R"].fuse(res["source"], res["target"], num_points=20000, std_ratio=None).cpu().numpy()
+    sel = oracle.fps(allp, 20000, 1) if allp.shape[0] > 20000 else np.arange(allp.shape[0])
+    np.testing.assert_array_equal(fused_no_filter, allp[sel])
+    omask = oracle.statistical_outlier_mask(fused_no_filter, 20, 2.5, 1)
+    np.testing.assert_array_equal(out["fused"].cpu().numpy(), fused_no_filter[omask])
+    # ---- metric on the chain's own output ----
+    pred, gtm = out["pred_metric_points"].cpu().numpy(), out["gt_metric_points"].cpu().numpy()
+    e1, e2, _, _ = oracle.chamfer_forward(pred[None], gtm[None], 1)
+    ed, _ = oracle.emd_forward(pred[None], gtm[None], 0.005, 50, 1)
+    m = out["metric"].cpu().numpy()
+    np.testing.assert_allclose(m[0], oracle.cd_l1(e1, e2), rtol=3e-7)
+    np.testing.assert_allclose(m[1], oracle.cd_l2(e1, e2), rtol=3e-7)
+    np.testing.assert_allclose(m[2], oracle.emd_loss(ed), rtol=3e-7)
+    # the completed scan is far closer to the ground truth than the partial scan was
+    p1, p2, _, _ = oracle.chamfer_forward(env["P"].fps_to(Pt, 16384).cpu().numpy()[None], gtm[None], 1)
+    assert m[0] < 0.5 * float(oracle.cd_l1(p1, p2)), (m[0], float(oracle.cd_l1(p1, p2)))
+
+
+def test_voxel_down_sample_vs_oracle(env, oracle, golden):
+    torch = env["torch"]
+    g = golden("scans13_fps16384.npz")
+    for xyz in (g["gt"][2], g["partial"][5][:5000], np.repeat(g["gt"][1][:300], 7, axis=0)):
+        for voxel in (0.02, 0.03, 0.04, 0.5):
+            got = env["R"].voxel_down_sample(torch.from_numpy(np.ascontiguousarray(xyz)).cuda(), voxel).cpu().numpy()
+            np.testing.assert_array_equal(got, oracle.voxel_down_sample(xyz, voxel))
+    with pytest.raises(ValueError):
+        bad = g["gt"][0].copy()
+        bad[5, 2] = np.inf
+        env["R"].voxel_down_sample(torch.from_numpy(bad).cuda(), 0.03)
+
+
+def c5_scan(seed, n=32768):
+    """SURVEY 8d scan bench: a complete shape (ellipsoid + box union surface, max extent 1) and a
+    partial observation of it (the half facing +z), under a known similarity transform."""
+    rng = np.random.default_rng(1000 + seed)
+    u = rng.standard_normal((n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    ell = u * np.array([0.5, 0.3, 0.22])
+    box = (rng.random((n, 3)) - 0.5) * np.array([0.3, 0.5, 0.3])
+    face = rng.integers(0, 3, n)
+    box[np.arange(n), face] = np.sign(box[np.arange(n), face]) * np.array([0.15, 0.25, 0.15])[face]
+    pick = rng.random(n) < 0.6
+    complete = np.where(pick[:, None], ell, box + np.array([0.1, 0.0, 0.0]))
+    complete = (complete - (complete.max(0) + complete.min(0)) / 2) / (complete.max(0) - complete.min(0)).max()
+    # the loop starts at scale 0.75 and Adam moves log-scale by at most lr * 0.1 = 1e-3 per step
+    # (diff_obj_pose.py:367,524-528): 201 steps reach at most 0.75 e^0.2 = 0.916
+    s = rng.uniform(0.78, 0.9)
+    theta = rng.uniform(-12, 12)
+    t = rng.uniform(-0.04, 0.04, 3)
+    R = rot([0, 1, 0], theta)
+    c = complete.mean(0)
+    posed = ((complete - c) * s) @ R.T + c + t
+    front = posed[posed[:, 2] > np.median(posed[:, 2]) - 0.02]
+    partial = front[rng.integers(0, front.shape[0], n)]
+    return complete.astype(np.float32), partial.astype(np.float32), s, R, t
+
+
+def test_config5_rank_shape_8x32768(env):
+    """8 scans x 32768 points through object_pose_optimization (full objective) in lock-step:
+    every scan's scale / rotation / in-plane translation is recovered and the posed shape explains
+    the observation (translation ALONG the fixed camera's axis trades against scale in the
+    silhouette term and against the unobserved back half in the one-sided Chamfer term: it is
+    checked through the distance it leaves, not as a number)."""
+    torch = env["torch"]
+    from genpc_amd.optim_registration.diff_obj_pose import object_pose_optimization
+    scans = [c5_scan(s) for s in range(8)]
+    C = torch.from_numpy(np.stack([x[0] for x in scans])).cuda()
+    P = torch.from_numpy(np.stack([x[1] for x in scans])).cuda()
+    T = object_pose_optimization(C, P, radius=0.02, lr=0.01, iters=200, render_size=224)
+    assert T.shape == (8, 4, 4)
+    from genpc_amd.utils.loss_util import Completionloss
+    cl = Completionloss("cd_l1")
+    for i, (_, _, s, R, t) in enumerate(scans):
+        sc = np.cbrt(np.linalg.det(T[i][:3, :3].astype(np.float64)))
+        assert abs(sc - s) < 0.06, (i, sc, s)
+        np.testing.assert_allclose(T[i][:3, :3] / sc, R, atol=0.12)
+        np.testing.assert_allclose(T[i][:2, 3], t[:2], atol=0.03)
+        assert abs(T[i][2, 3] - t[2]) < 0.12
+        Tt = torch.from_numpy(T[i]).cuda()
+        c = C[i].mean(0)
+        aligned = (C[i] - c) @ Tt[:3, :3].T + c + Tt[:3, 3]
+        d = cl.chamfer_partial_l1(P[i][None].contiguous(), aligned[None].contiguous()).item()
+        assert d < 0.04, (i, d)          # 4 % of the object's extent after 201 steps (reg() refines from here)
