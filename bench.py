@@ -13,6 +13,12 @@ ABI of libgenpc_hip.so, inputs resident in HBM.  `rng=default_rng(20250101)`,
 per-rank workload on its own pair (independent scans shard with no data-path
 collective): weak scaling, value = total pair-dist/s over all ranks.
 
+`python bench.py --gpus N` without a torchrun environment starts the torchrun form itself as a
+child process (before anything touches a GPU) and exits with its code; a run whose realised
+world size differs from --gpus exits non-zero.  `--workload c4|c5` times the scan-sharded
+registration workloads of BASELINE configs 4 / 5 instead of the pair benchmark (strong scaling:
+the scans are dealt round-robin over the ranks, metric completed scans/s).
+
 One JSON line on stdout (rank 0).  Besides the contract fields:
   roofline      the dominant kernel (nn_f16_kernel, the MFMA filter that evaluates every
                 pair) against the dense f16 MFMA roofline, 2500 TFLOP/s: one K = 16
@@ -95,6 +101,8 @@ def extras(A, B, n, dev, stream):
     from genpc_amd.utils.loss_util import Completionloss
     from types import SimpleNamespace
     extra = {}
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED)          # every synthetic input of the extras is reproducible
     cd = chamfer_3DDist()
     Ag = A.clone().requires_grad_(True)
     Bg = B.clone().requires_grad_(True)
@@ -117,8 +125,8 @@ def extras(A, B, n, dev, stream):
         t = time_events(f, 50, stream)
         extra["chamfer_fwd_B1_n%d_gpair_s" % nn] = round(2.0 * nn * nn / (t * 1e-3) / 1e9, 2)
     # BASELINE config 3 shape: 13 scans x 16384 in one batched call
-    P13 = torch.rand(13, n, 3, device=dev) - 0.5
-    Q13 = torch.rand(13, n, 3, device=dev) - 0.5
+    P13 = torch.rand(13, n, 3, device=dev, generator=gen) - 0.5
+    Q13 = torch.rand(13, n, 3, device=dev, generator=gen) - 0.5
     o = [torch.empty(13, n, device=dev), torch.empty(13, n, device=dev),
          torch.empty(13, n, device=dev, dtype=torch.int32), torch.empty(13, n, device=dev, dtype=torch.int32)]
     f = lambda: chamfer_3D.forward(P13, Q13, o[0], o[1], o[2], o[3])  # noqa: E731
@@ -131,7 +139,25 @@ def extras(A, B, n, dev, stream):
     X = A + 0.5
     Y = B + 0.5
     em(X, Y, 0.005, 50)
-    extra["emd_fwd_n%d_eps0.005_it50_ms" % n] = round(time_events(lambda: em(X, Y, 0.005, 50), 5, stream), 4)
+    t_emd = time_events(lambda: em(X, Y, 0.005, 50), 5, stream)
+    extra["emd_fwd_n%d_eps0.005_it50_ms" % n] = round(t_emd, 4)
+    # roofline-shaped entry for the auction: algorithmic pairs = sum over rounds of (bidders x objects);
+    # bidders of round k - 1 = the list length a k-round call leaves in its ping-pong count buffers
+    from genpc_amd import emd as emd_abi
+    from genpc_amd.loss_functions.emd.emd_module import alloc_state
+    pairs = 0.0
+    for k in range(1, 51):
+        st = alloc_state(1, n, n, dev)
+        emd_abi.forward(X, Y, st["dist"], st["assignment"], st["price"], st["assignment_inv"], st["bid"],
+                        st["bid_increments"], st["max_increments"], st["unass_idx"], st["unass_cnt"], st["unass_cnt_sum"],
+                        st["cnt_tmp"], st["max_idx"], 0.005, k)
+        pairs += float((st["unass_cnt"] if (k - 1) % 2 == 0 else st["cnt_tmp"])[0].item()) * n
+    extra["emd_fwd_n%d_roofline" % n] = {
+        "bound": "valu-fp32", "unit": "TFLOP/s", "algorithmic_pairs_per_call": pairs, "pairs_over_n2": round(pairs / n / n, 3),
+        "flop_per_pair": FLOP_PER_PAIR, "ms_per_call": round(t_emd, 4),
+        "achieved": round(FLOP_PER_PAIR * pairs / (t_emd * 1e-3) / 1e12, 3), "peak": PEAK_FP32_TFLOPS,
+        "frac": round(FLOP_PER_PAIR * pairs / (t_emd * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+        "note": "50 rounds x 3 launches, latency-bound at B=1; the bid kernel's pre-filter skips most exact evaluations"}
     X2 = X[:, :2048].contiguous()
     Y2 = Y[:, :2048].contiguous()
     em(X2, Y2, 0.005, 50)
@@ -144,14 +170,14 @@ def extras(A, B, n, dev, stream):
         cle.get_loss(X, Y)
     metric()
     extra["metric_cd_emd_n%d_scans_per_s" % n] = round(1e3 / time_events(metric, 5, stream), 2)
-    # alignment loop (diff_obj_pose CD half): 8192-point partial vs 16384-point complete,
-    # 4 starts x 201 Adam steps, then the metric above = one "completed scan"
+    # alignment loop (diff_obj_pose, full objective: mask + 3 cd + ortho): 8192-point partial vs
+    # 16384-point complete, 4 starts x 201 Adam steps, then the metric above = one "completed scan"
     C16 = A[0]
     P8 = (B[0, :8192] * 0.9).contiguous()
-    object_pose_optimization(C16, P8, lr=0.01, iters=200)
+    object_pose_optimization(C16, P8, radius=0.02, lr=0.01, iters=200, render_size=224)
 
     def scan():
-        object_pose_optimization(C16, P8, lr=0.01, iters=200)
+        object_pose_optimization(C16, P8, radius=0.02, lr=0.01, iters=200, render_size=224)
         metric()
     t0 = time.perf_counter()
     for _ in range(3):
@@ -159,18 +185,26 @@ def extras(A, B, n, dev, stream):
     torch.cuda.synchronize()
     extra["registration_8k_vs_16k_4x201_plus_metric_scans_per_s"] = round(3.0 / (time.perf_counter() - t0), 3)
     # the same, 8 scans in lock-step (one batched NN launch per Adam step) + batched metric
-    C8 = (torch.rand(8, n, 3, device=dev) - 0.5)
+    C8 = (torch.rand(8, n, 3, device=dev, generator=gen) - 0.5)
     P8b = (C8[:, :8192] * 0.9).contiguous()
     X8, Y8 = C8 + 0.5, (C8.flip(0) + 0.5).contiguous()
     from genpc_amd.metric import evaluate_scans
-    object_pose_optimization(C8, P8b, lr=0.01, iters=200)
+    object_pose_optimization(C8, P8b, radius=0.02, lr=0.01, iters=200, render_size=224)
     evaluate_scans(X8, Y8)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    object_pose_optimization(C8, P8b, lr=0.01, iters=200)
+    object_pose_optimization(C8, P8b, radius=0.02, lr=0.01, iters=200, render_size=224)
     evaluate_scans(X8, Y8)
     torch.cuda.synchronize()
     extra["registration_batch8_8k_vs_16k_4x201_plus_metric_scans_per_s"] = round(8.0 / (time.perf_counter() - t0), 3)
+    # the same without the silhouette term (round 1's objective), for continuity
+    object_pose_optimization(C8, P8b, lr=0.01, iters=200, cd_only=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    object_pose_optimization(C8, P8b, lr=0.01, iters=200, cd_only=True)
+    evaluate_scans(X8, Y8)
+    torch.cuda.synchronize()
+    extra["registration_batch8_cd_only_scans_per_s"] = round(8.0 / (time.perf_counter() - t0), 3)
     # a17: the 1000-candidate anisotropic scale search of reg() (voxel-0.03 clouds are a few
     # thousand points) -- one batched NN launch + one ICP -- and an 11-candidate coarse sweep
     from genpc_amd import reg_xyz
@@ -190,7 +224,7 @@ def extras(A, B, n, dev, stream):
     extra["coarse_sweep_11scales_2icp_each_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
     # f2: deterministic FPS, 4 clouds x 165546 -> 16384 (the metric's subsampling, main.py:21-24)
     from genpc_amd.fps import fps_sampling
-    big = torch.rand(4, 165546, 3, device=dev)
+    big = torch.rand(4, 165546, 3, device=dev, generator=gen)
     fps_sampling(big, 64)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -201,12 +235,40 @@ def extras(A, B, n, dev, stream):
     cfg = SimpleNamespace(device=str(dev), fovy=49.1, res=256, padding=0.15, rescale=True, point_size=1,
                           mask_pixel_rate=3, view_num=1024, distance=1.6)
     dp = DepthPrompting(cfg)
-    pts = (torch.rand(71372, 3, device=dev) - 0.5) * 0.8
+    pts = (torch.rand(71372, 3, device=dev, generator=gen) - 0.5) * 0.8
     dp.getUvs(dp.cameras, pts, want_transformed=False)
     t = time_events(lambda: dp.getUvs(dp.cameras, pts, want_transformed=False), 5, stream)
     alg = 1024 * 71372 * (12 + 12)             # per (camera, point): read xyz, write uv + depth
-    extra["get_uvs_1024x71372_hbm"] = {"GB_s": round(alg / (t * 1e-3) / 1e9, 1), "frac_of_8TBs": round(alg / (t * 1e-3) / 8e12, 4),
-                                       "ms": round(t, 4), "algorithmic_bytes": alg}
+    extra["get_uvs_1024x71372_roofline"] = {"bound": "hbm", "achieved": round(alg / (t * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                            "unit": "GB/s", "frac": round(alg / (t * 1e-3) / 8e12, 4),
+                                            "frac_of_6.29TBs_achievable": round(alg / (t * 1e-3) / 6.29e12, 4),
+                                            "ms_per_launch_pair": round(t, 4), "algorithmic_bytes": alg}
+    # BASELINE config 2: the chained geometric stages of one completed scan (8192-point partial scan,
+    # 16384-point generated shape): DepthPrompting -> colorPoint -> reg -> fuse -> metric
+    from genpc_amd import pipeline
+    cfg2 = pipeline.default_cfg(str(dev), view_num=1024)
+    dp2 = DepthPrompting(cfg2)
+    part = (B[0, :8192] * 0.9 + 0.01).contiguous()
+    img = torch.rand(3, 1024, 1024, device=dev, generator=gen)
+    pipeline.complete_scan(part, A[0], img, A[0], cfg=cfg2, dp=dp2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        pipeline.complete_scan(part, A[0], img, A[0], cfg=cfg2, dp=dp2)
+    torch.cuda.synchronize()
+    extra["c2_pipeline_8192_scans_per_s"] = round(2.0 / (time.perf_counter() - t0), 3)
+    # BASELINE config 5 per-rank shape: 8 scans x 32768 points in lock-step, full objective + metric
+    sc = [synth_scan(k, 32768) for k in range(8)]
+    C5 = torch.from_numpy(np.stack([x[0] for x in sc])).to(dev)
+    P5 = torch.from_numpy(np.stack([x[1] for x in sc])).to(dev)
+    G5 = torch.from_numpy(np.stack([x[2] for x in sc])).to(dev)
+    object_pose_optimization(C5, P5, radius=0.02, lr=0.01, iters=200, render_size=224)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    object_pose_optimization(C5, P5, radius=0.02, lr=0.01, iters=200, render_size=224)
+    evaluate_scans(C5, G5)
+    torch.cuda.synchronize()
+    extra["c5_rank_8x32768_registration_plus_metric_scans_per_s"] = round(8.0 / (time.perf_counter() - t0), 3)
     return extra
 
 
@@ -229,24 +291,137 @@ def cpu_baseline(a, b, budget_s=12.0):
                       % (cores, n, reps, dt)}
 
 
+def maybe_spawn(args):
+    """`--gpus N` outside a torchrun environment: start the torchrun form as a CHILD process and
+    exit with its code.  Runs before anything initialises a GPU (no exec from a GPU process)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def synth_scan(seed, n):
+    """SURVEY 8d scan bench: a complete shape (ellipsoid + box union surface, max extent 1) and a
+    partial observation (the half facing the camera, resampled to n), under a similarity transform
+    the registration loop can reach (scale 0.78..0.9: 201 Adam steps from 0.75)."""
+    rng = np.random.default_rng(1000 + seed)
+    u = rng.standard_normal((n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    ell = u * np.array([0.5, 0.3, 0.22])
+    box = (rng.random((n, 3)) - 0.5) * np.array([0.3, 0.5, 0.3])
+    face = rng.integers(0, 3, n)
+    box[np.arange(n), face] = np.sign(box[np.arange(n), face]) * np.array([0.15, 0.25, 0.15])[face]
+    pick = rng.random(n) < 0.6
+    complete = np.where(pick[:, None], ell, box + np.array([0.1, 0.0, 0.0]))
+    complete = (complete - (complete.max(0) + complete.min(0)) / 2) / (complete.max(0) - complete.min(0)).max()
+    s = rng.uniform(0.78, 0.9)
+    th = np.deg2rad(rng.uniform(-12, 12))
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    t = rng.uniform(-0.04, 0.04, 3)
+    c = complete.mean(0)
+    posed = ((complete - c) * s) @ R.T + c + t
+    front = posed[posed[:, 2] > np.median(posed[:, 2]) - 0.02]
+    partial = front[rng.integers(0, front.shape[0], n)]
+    return complete.astype(np.float32), partial.astype(np.float32), posed.astype(np.float32)
+
+
+def run_scan_workload(args, rank, world, dev):
+    """BASELINE config 4 (59 scans x 4096 points over 4 ranks) / config 5 (64 scans x 32768 points over
+    8 ranks): scans dealt round-robin (genpc_amd.sharding), per rank registered in lock-step groups
+    of <= 8 (object_pose_optimization, full objective) and scored (CD-L1 / CD-L2 / EMD of the posed
+    complete shape against the ground-truth pose); one all_gather of the scalars at the end."""
+    from genpc_amd import sharding
+    from genpc_amd.metric import evaluate_scans
+    from genpc_amd.optim_registration.diff_obj_pose import object_pose_optimization
+    total, n = (59, 4096) if args.workload == "c4" else (64, 32768)
+    mine = sharding.shard_indices(total, rank, world)
+    scans = [synth_scan(sidx, n) for sidx in mine]
+    groups = []
+    for g0 in range(0, len(scans), 8):
+        grp = scans[g0:g0 + 8]
+        groups.append(tuple(torch.from_numpy(np.stack([x[k] for x in grp])).to(dev) for k in range(3)))
+
+    def step():
+        rows = []
+        for C, P, G in groups:
+            T = torch.from_numpy(object_pose_optimization(C, P, radius=0.02, lr=0.01, iters=200, render_size=224)).to(dev)
+            c = C.mean(1, keepdim=True)
+            aligned = ((C - c) @ T[:, :3, :3].transpose(1, 2) + c + T[:, None, :3, 3]).contiguous()
+            rows.append(evaluate_scans(aligned, G))
+        return torch.cat(rows) if rows else torch.empty(0, 3, device=dev)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        local = step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else "cpu")
+    table = sharding.gather_scan_metrics(local, total, rank, world)
+    ranks_seen = sharding.all_ranks(dev if world > 1 else "cpu")
+    if rank != 0:
+        return None
+    return {
+        "metric": "completed_scans_per_s", "value": round(total * args.steps / elapsed, 4), "unit": "scans/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ranks_seen": ranks_seen,
+        "config": {"workload": "%s: %d scans x %d points, diff_obj_pose registration (4 starts x 201 Adam steps, mask + "
+                               "3 cd + ortho) + CD/EMD metric, scans sharded round-robin" % (args.workload, total, n),
+                   "scans": total, "points": n, "sharding": "scan s -> rank s %% %d, all_gather of 3 scalars per scan" % world},
+        "extra": {"mean_cd_l1_vs_true_pose": round(float(table[:, 0].mean()), 6),
+                  "mean_emd_vs_true_pose": round(float(table[:, 2].mean()), 6)},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--points", type=int, default=N_PTS)
+    ap.add_argument("--workload", choices=("pairs", "c4", "c5"), default="pairs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.workload == "pairs" else 2
+    if args.warmup is None:
+        args.warmup = 20 if args.workload == "pairs" else 1
+    maybe_spawn(args)
 
     from genpc_amd import sharding
     rank, local_rank, world = sharding.init()
-    if world != args.gpus and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but the realised world size is %d" % (args.gpus, world), file=sys.stderr)
+        sharding.shutdown()
+        sys.exit(2)
     n_gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    if args.workload != "pairs":
+        out = run_scan_workload(args, rank, world, dev)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        sharding.shutdown()
+        return
 
     from genpc_amd import _lib, chamfer_3D
     from genpc_amd.loss_functions import chamfer_3DDist, emdModule
@@ -277,12 +452,23 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, device=dev if world > 1 else "cpu")
+    ranks_seen = sharding.all_ranks(dev if world > 1 else "cpu")
 
     pairs_per_step = 2.0 * n * n
     value = n_gpus * pairs_per_step * args.steps / elapsed / 1e9
 
     out = None
     if rank == 0:
+        # the timed step's output against the oracle (checker only): first and last 256 queries of
+        # each direction, every distance and index
+        from oracle import oracle as O
+        sel = np.r_[0:256, n - 256:n]
+        e1, _, j1, _ = O.chamfer_forward(a_np[:, sel], b_np, 1)
+        e2, _, j2, _ = O.chamfer_forward(b_np[:, sel], a_np, 1)
+        ok = (np.array_equal(dist1.cpu().numpy()[:, sel], e1) and np.array_equal(idx1.cpu().numpy()[:, sel], j1)
+              and np.array_equal(dist2.cpu().numpy()[:, sel], e2) and np.array_equal(idx2.cpu().numpy()[:, sel], j2))
+        if not ok:
+            raise RuntimeError("bench.py: the timed step's output differs from the oracle")
         # live HIP-event timing of the dominant kernel on the launch stream
         ms = time_events(step, max(20, min(args.steps, 200)), stream)
         # the filter kernel alone: HIP events inside the library, on the launch stream
@@ -311,6 +497,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "ranks_seen": ranks_seen,
+            "output_checked": "first and last 256 queries of both directions bit-exact vs the oracle",
             "config": {"workload": "chamfer_3DDist.forward B=1 N=M=%d (both directions), one pair per rank" % n,
                        "points": n, "batch": 1, "arith": "fma" if _lib.lib.genpc_get_arith() else "strict",
                        "sharding": "independent scans per rank, no data-path collective"},

@@ -831,13 +831,16 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         // [arrival counters | per-slice partials]; counters are zeroed when the block is
         // (re)allocated and restored to zero by the merging block, so steady-state calls
         // need no memset.
-        const size_t cnt_bytes = (size_t)1 << 16;
-        if ((size_t)units * sizeof(int) > cnt_bytes) {
-            set_error("chamfer: too many query blocks for the arrival-counter area");
-            return 0;
-        }
-        char *ws = (char *)workspace(0, cnt_bytes + part * 8, st, nullptr, cnt_bytes);
+        // Usually the counters fit the 64 KiB prefix that is zero between calls.  A launch with more
+        // query blocks than that (1000 scale-search candidates x 128 blocks) takes a larger area,
+        // which earlier calls used for partials: it is cleared on the stream first (the kernels hand
+        // every counter back as zero, so the 64 KiB invariant survives such a call).
+        const size_t cnt_min = (size_t)1 << 16;
+        size_t cnt_bytes = cnt_min;
+        if ((size_t)units * sizeof(int) > cnt_bytes) cnt_bytes = ((size_t)units * sizeof(int) + 255) & ~(size_t)255;
+        char *ws = (char *)workspace(0, cnt_bytes + part * 8, st, nullptr, cnt_min);
         if (!ws) return 0;
+        if (cnt_bytes > cnt_min && !check(hipMemsetAsync(ws, 0, cnt_bytes, st), "hipMemsetAsync(arrival counters)")) return 0;
         a.arrive = (int *)ws;
         unsigned long long *wp = (unsigned long long *)(ws + cnt_bytes);
         size_t off = 0;

@@ -35,6 +35,7 @@ namespace genpc {
 int genpc_mean3(int b, int n, const float *v, float *out, double *accum, hipStream_t st);
 
 constexpr int kQBlock = 256;
+constexpr int kAcc = 32;      // doubles per scan: [0..12] gradient sums, [13,14] Chamfer sums, [15] mask loss, [16,17] image sums, [18..27] mask sums
 
 // pytorch3d.transforms.rotation_6d_to_matrix (rows b1, b2, b1 x b2); F.normalize eps 1e-12
 __device__ __forceinline__ void rot6d_to_matrix(const float *d6, float *R)
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(kQBlock) void pose_grad_kernel(int nc, const float 
     d2 += (size_t)e * np; i2 += (size_t)e * np;
     center += (size_t)e * cstride;
     params += (size_t)e * pstride;
-    accum += (size_t)e * 16;
+    accum += (size_t)e * kAcc;
     float R[9];
     rot6d_to_matrix(params, R);
     const float s = expf(params[9]);
@@ -188,7 +189,7 @@ __global__ void pose_update_kernel(int b, PoseState *__restrict__ S, double *__r
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= b) return;
     S += e;
-    accum += (size_t)e * 16;
+    accum += (size_t)e * kAcc;
     if (history_slot) history_slot += (size_t)e * history_stride;
     float Rf[9];
     rot6d_to_matrix(S->params, Rf);
@@ -248,7 +249,7 @@ __global__ void pose_update_kernel(int b, PoseState *__restrict__ S, double *__r
     S->loss[1] = (float)cd;
     S->loss[2] = (float)err;
     S->loss[3] = (float)accum[15];
-    for (int k = 0; k < 16; k++) accum[k] = 0.0;
+    for (int k = 0; k < kAcc; k++) accum[k] = 0.0;
     if (history_slot) *history_slot = loss;
     if (!do_step) return;
     if (loss < S->local_best) S->local_best = loss;       // diff_obj_pose.py:549-551
@@ -272,11 +273,11 @@ __global__ void pose_begin_kernel(int b, PoseState *__restrict__ S, double *__re
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= b) return;
     S += e;
-    accum += (size_t)e * 16;
+    accum += (size_t)e * kAcc;
     if (start < 0) {
         S->best_loss = __builtin_inff();
         for (int k = 0; k < 10; k++) S->best_params[k] = 0.0f;
-        for (int k = 0; k < 16; k++) accum[k] = 0.0;
+        for (int k = 0; k < kAcc; k++) accum[k] = 0.0;
         return;
     }
     const double th = start * 90.0 * M_PI / 180.0;
@@ -331,15 +332,23 @@ __global__ void pose_end_kernel(int b, PoseState *__restrict__ S, int final, flo
 //   a_i(pixel) = min(0.999, max(0, 1 - |pixel centre - (u, v)|^2 / rho^2));  I = 1 - prod_i (1 - a_i)
 // and keeps the reference's own torch code for what follows the render: statistical
 // normalisation, sigmoid soft masks, 30 MSE + BCE + 10 Dice (:204-217,261-278,238-259,304-311).
-//   mask_splat_kernel  one block per 56 x 56 image tile and scan: every point is posed (the
-//                      transform is fused), projected, and its log(1 - a) added to the tile in LDS
-//                      (no global atomics, no pre-zeroed image); writes L = sum log(1 - a)
-//   mask_loss_kernel   one block per scan: image statistics, the loss, and W = d loss / d I * T
-//                      (four passes over the 224^2 image, block reductions in fp64)
-//   mask_grad_kernel   one thread per point: gathers W over the pixels it covers, chains through
-//                      (u, v, rho) to the point and on to (R, s, t): same 13 accumulators as the
-//                      Chamfer gradient
-constexpr int kMaskTile = 56;
+//   mask_project_kernel  every point posed (the transform is fused) and projected once: (u, v, rho)
+//   mask_splat_kernel    one block per 16 x 16 image tile and scan: the points whose disc touches
+//                        the tile are compacted into LDS 256 at a time, then one WAVE per point, one
+//                        lane per pixel of an 8 x 8 patch of its box, adds log(1 - a) to the tile in
+//                        LDS (native ds_add_f32); writes L = sum log(1 - a) and adds the tile's sums
+//                        of I and I^2 to the scan's accumulators.  (Measured: one thread per point
+//                        walking its own box 634 us per call at 16384 points -- every wave pays a
+//                        full box for its one in-tile lane; 64-bit fixed-point accumulation with
+//                        accurate logf on 32 x 32 tiles 234 us.)
+//   mask_sums_kernel     pixels over many blocks: the ten sums the loss and its gradient need
+//   mask_w_kernel        W = d loss / d I * T per pixel; the loss itself
+//   mask_grad_kernel     one thread per point: gathers W over the pixels it covers, chains through
+//                        (u, v, rho) to the point and on to (R, s, t): same 13 accumulators as the
+//                        Chamfer gradient
+constexpr int kMaskTile = 16;
+constexpr int kSplatBlock = 1024;  // 16 waves per tile: a wave per point leaves long dependent chains, four waves per SIMD hide them
+constexpr int kSplatPer = 2;       // points per thread and compaction round of the splat
 constexpr float kMaskAmax = 0.999f;
 constexpr float kMaskFocal = 4.0f, kMaskEyeZ = 3.0f, kMaskZnear = 1e-4f, kMaskZfar = 5.0f;
 
@@ -360,18 +369,16 @@ __device__ __forceinline__ SplatPt splat_project(const float *p, float radius, f
     return o;
 }
 
-// grid (tiles, b).  posed != 0: v is the complete cloud and is posed with params; else v is splatted as is.
-__global__ __launch_bounds__(kQBlock) void mask_splat_kernel(int n, const float *__restrict__ v,
-                                                             const float *__restrict__ center, int cstride,
-                                                             const float *__restrict__ params, int pstride, int posed,
-                                                             float radius, int S, float *__restrict__ L)
+// grid (blocks, b): uvr[e, j] = (u, v, rho, 0), rho = -1 for points the camera does not see.
+// posed != 0: v is the complete cloud and is posed with params first.
+__global__ __launch_bounds__(kQBlock) void mask_project_kernel(int n, const float *__restrict__ v,
+                                                               const float *__restrict__ center, int cstride,
+                                                               const float *__restrict__ params, int pstride, int posed,
+                                                               float radius, int S, float4 *__restrict__ uvr)
 {
-    __shared__ float tl[kMaskTile * kMaskTile];
     const int e = blockIdx.y;
-    const int tiles_x = (S + kMaskTile - 1) / kMaskTile;
-    const int tx0 = (blockIdx.x % tiles_x) * kMaskTile, ty0 = (blockIdx.x / tiles_x) * kMaskTile;
     v += (size_t)e * n * 3;
-    L += (size_t)e * S * S;
+    uvr += (size_t)e * n;
     float R[9], s = 1.0f, c[3] = {0, 0, 0}, t[3] = {0, 0, 0};
     if (posed) {
         center += (size_t)e * cstride;
@@ -381,10 +388,8 @@ __global__ __launch_bounds__(kQBlock) void mask_splat_kernel(int n, const float 
         c[0] = center[0]; c[1] = center[1]; c[2] = center[2];
         t[0] = params[6]; t[1] = params[7]; t[2] = params[8];
     }
-    for (int i = threadIdx.x; i < kMaskTile * kMaskTile; i += kQBlock) tl[i] = 0.0f;
-    __syncthreads();
     const float hs = 0.5f * S;
-    for (int j = threadIdx.x; j < n; j += kQBlock) {
+    for (int j = blockIdx.x * kQBlock + threadIdx.x; j < n; j += gridDim.x * kQBlock) {
         float p[3] = {v[(size_t)j * 3 + 0], v[(size_t)j * 3 + 1], v[(size_t)j * 3 + 2]};
         if (posed) {
             float o[3];
@@ -392,28 +397,90 @@ __global__ __launch_bounds__(kQBlock) void mask_splat_kernel(int n, const float 
             p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
         }
         const SplatPt q = splat_project(p, radius, hs);
-        if (!q.ok) continue;
-        int c0 = (int)floorf(q.u - q.rho - 0.5f), c1 = (int)ceilf(q.u + q.rho - 0.5f);
-        int r0 = (int)floorf(q.v - q.rho - 0.5f), r1 = (int)ceilf(q.v + q.rho - 0.5f);
-        c0 = max(c0, tx0); c1 = min(c1, min(S, tx0 + kMaskTile) - 1);
-        r0 = max(r0, ty0); r1 = min(r1, min(S, ty0 + kMaskTile) - 1);
-        if (c0 > c1 || r0 > r1) continue;
-        const float ir2 = 1.0f / (q.rho * q.rho);
-        for (int r = r0; r <= r1; r++) {
-            const float dy = (float)r + 0.5f - q.v;
-            for (int cc = c0; cc <= c1; cc++) {
-                const float dx = (float)cc + 0.5f - q.u;
-                float a = 1.0f - (dx * dx + dy * dy) * ir2;
-                if (a <= 0.0f) continue;
-                a = fminf(a, kMaskAmax);
-                atomicAdd(&tl[(r - ty0) * kMaskTile + (cc - tx0)], logf(1.0f - a));
+        uvr[j] = make_float4(q.u, q.v, q.ok ? q.rho : -1.0f, 0.0f);
+    }
+}
+
+// grid (tiles, b)
+__global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const float4 *__restrict__ uvr, int S,
+                                                             float *__restrict__ L, double *__restrict__ accum)
+{
+    __shared__ float acc[kMaskTile * kMaskTile];
+    __shared__ float4 list[kSplatBlock * kSplatPer];
+    __shared__ int s_cnt;
+    __shared__ double red[2][kSplatBlock / kWave];
+    const int e = blockIdx.y;
+    const int tiles_x = (S + kMaskTile - 1) / kMaskTile;
+    const int tx0 = (blockIdx.x % tiles_x) * kMaskTile, ty0 = (blockIdx.x / tiles_x) * kMaskTile;
+    const int tx1 = min(S, tx0 + kMaskTile) - 1, ty1 = min(S, ty0 + kMaskTile) - 1;
+    uvr += (size_t)e * n;
+    L += (size_t)e * S * S;
+    if (accum) accum += (size_t)e * kAcc;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int lx = lane & 7, ly = lane >> 3;          // a wave covers an 8 x 8 pixel patch of a point's box
+    for (int i = threadIdx.x; i < kMaskTile * kMaskTile; i += kSplatBlock) acc[i] = 0.0f;
+    for (int j0 = 0; j0 < n; j0 += kSplatBlock * kSplatPer) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        // kSplatPer points per thread and round: their loads are in flight together (a round is
+        // otherwise one L2 round trip plus two barriers for 256 points: 64 such rounds cost ~100 us)
+        float4 q[kSplatPer];
+#pragma unroll
+        for (int i = 0; i < kSplatPer; i++) {
+            const int j = j0 + i * kSplatBlock + threadIdx.x;
+            q[i] = j < n ? uvr[j] : make_float4(0.0f, 0.0f, -1.0f, 0.0f);
+        }
+#pragma unroll
+        for (int i = 0; i < kSplatPer; i++) {
+            // the disc's pixel box against the tile (the exact clipping follows)
+            if (q[i].z > 0.0f && q[i].x + q[i].z - 0.5f >= (float)tx0 - 1.0f && q[i].x - q[i].z - 0.5f <= (float)tx1 + 1.0f &&
+                q[i].y + q[i].z - 0.5f >= (float)ty0 - 1.0f && q[i].y - q[i].z - 0.5f <= (float)ty1 + 1.0f)
+                list[atomicAdd(&s_cnt, 1)] = q[i];
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        for (int k = wave; k < cnt; k += kSplatBlock / kWave) {
+            const float4 q = list[k];
+            // box of the disc (as the oracle draws it), clipped to the tile, walked in 8 x 8 patches
+            const int c0 = max((int)floorf(q.x - q.z - 0.5f), tx0), c1 = min((int)ceilf(q.x + q.z - 0.5f), tx1);
+            const int r0 = max((int)floorf(q.y - q.z - 0.5f), ty0), r1 = min((int)ceilf(q.y + q.z - 0.5f), ty1);
+            const float ir2 = 1.0f / (q.z * q.z);
+            for (int rb = r0; rb <= r1; rb += 8) {
+                for (int cb = c0; cb <= c1; cb += 8) {
+                    const int r = rb + ly, cc = cb + lx;
+                    const float dx = (float)cc + 0.5f - q.x, dy = (float)r + 0.5f - q.y;
+                    float a = 1.0f - (dx * dx + dy * dy) * ir2;
+                    if (r <= r1 && cc <= c1 && a > 0.0f) {
+                        a = fminf(a, kMaskAmax);
+                        // native LDS float add (the sum's order, hence its last bits, vary from run to run)
+                        unsafeAtomicAdd(&acc[(r - ty0) * kMaskTile + (cc - tx0)], __logf(1.0f - a));
+                    }
+                }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kMaskTile * kMaskTile; i += kQBlock) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < kMaskTile * kMaskTile; i += kSplatBlock) {
         const int r = ty0 + i / kMaskTile, cc = tx0 + i % kMaskTile;
-        if (r < S && cc < S) L[(size_t)r * S + cc] = tl[i];
+        if (r < S && cc < S) {
+            const float l = acc[i];
+            L[(size_t)r * S + cc] = l;
+            const float I = 1.0f - expf(l);
+            s1 += (double)I;
+            s2 += (double)I * (double)I;
+        }
+    }
+    if (accum) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, kWave); s2 += __shfl_xor(s2, off, kWave); }
+        if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w2 = 1; w2 < kSplatBlock / kWave; w2++) { s1 += red[0][w2]; s2 += red[1][w2]; }
+            atomicAdd(&accum[16], s1);
+            atomicAdd(&accum[17], s2);
+        }
     }
 }
 
@@ -472,81 +539,128 @@ __global__ __launch_bounds__(kMLThreads) void mask_ref_kernel(int S, float *__re
     }
 }
 
-// Per scan: loss and W = mask_weight * d mask_loss / d I * T  (T = exp(L): what the backward splat
-// multiplies by 1 / (1 - a_i)); accum[15] += mask_weight * mask_loss.
-__global__ __launch_bounds__(kMLThreads) void mask_loss_kernel(int S, const float *__restrict__ L,
-                                                               const float *__restrict__ mref,
-                                                               const float *__restrict__ stats, float mask_weight,
-                                                               float *__restrict__ W, double *__restrict__ accum)
+// image statistics of the posed cloud from the sums the splat left in accum[16,17]
+__device__ __forceinline__ void mask_image_stats(const double *accum, int P, double sdr, float &muf, float &k, double &sd,
+                                                 double &mu)
 {
-    __shared__ double red[4][kMLThreads / kWave];
-    const int e = blockIdx.x, P = S * S;
+    mu = accum[16] / P;
+    double var = (accum[17] - (double)P * mu * mu) / (P - 1);
+    var = var > 0.0 ? var : 0.0;
+    sd = sqrt(var);
+    k = (float)((sdr + 1e-6) / (sd + 1e-6));
+    muf = (float)mu;
+}
+
+// the per-pixel quantities every pass needs
+struct MaskPx {
+    float I, m, mr, sp;      // sp = d m / d x_normalised (0 where the clamp or the saturated sigmoid cuts the gradient)
+    float lm, l1m, dmb;      // clamped logs; d (30 MSE + BCE) / d m * P
+};
+
+__device__ __forceinline__ MaskPx mask_pixel(float l, float mr, float muf, float k, float murf)
+{
+    MaskPx o;
+    o.I = 1.0f - expf(l);
+    const float x0 = (o.I - muf) * k + murf;
+    const float xn = fminf(fmaxf(x0, 0.0f), 1.0f);
+    o.m = sigmoidf((xn - 0.1f) * 20.0f);
+    o.mr = mr;
+    const float lm = logf(o.m), l1m = logf(1.0f - o.m);
+    o.lm = fmaxf(lm, -100.0f);
+    o.l1m = fmaxf(l1m, -100.0f);
+    o.sp = (x0 > 0.0f && x0 < 1.0f) ? o.m * (1.0f - o.m) * 20.0f : 0.0f;
+    float db = 0.0f;
+    if (lm > -100.0f) db -= mr / o.m;
+    if (l1m > -100.0f) db += (1.0f - mr) / (1.0f - o.m);
+    o.dmb = 60.0f * (o.m - mr) + db;
+    return o;
+}
+
+// grid (blocks, b).  accum[18..27] += mse, bce, intersection, sum m,  and with g1 = dmb sp / P, g2 = mr sp,
+// g3 = sp:  sum g1, sum g2, sum g3, sum g1 (I - mu), sum g2 (I - mu), sum g3 (I - mu)  -- the Dice
+// term's share of G is (dice_a g2 + dice_b g3) with coefficients only known after this pass.
+__global__ __launch_bounds__(kQBlock) void mask_sums_kernel(int S, const float *__restrict__ L,
+                                                            const float *__restrict__ mref,
+                                                            const float *__restrict__ stats, double *__restrict__ accum)
+{
+    __shared__ double red[10][kQBlock / kWave];
+    const int e = blockIdx.y, P = S * S;
+    L += (size_t)e * P;
+    mref += (size_t)e * P;
+    stats += (size_t)e * 4;
+    accum += (size_t)e * kAcc;
+    float muf, k;
+    double sd, mu;
+    mask_image_stats(accum, P, (double)stats[1], muf, k, sd, mu);
+    const float murf = stats[0];
+    const float invP = 1.0f / (float)P;
+    double a[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) a[i] = 0.0;
+    for (int q = blockIdx.x * kQBlock + threadIdx.x; q < P; q += gridDim.x * kQBlock) {
+        const MaskPx px = mask_pixel(L[q], mref[q], muf, k, murf);
+        a[0] += (double)((px.m - px.mr) * (px.m - px.mr));
+        a[1] += (double)(-(px.mr * px.lm + (1.0f - px.mr) * px.l1m));
+        a[2] += (double)(px.m * px.mr);
+        a[3] += (double)px.m;
+        const double g1 = (double)(px.dmb * px.sp * invP), g2 = (double)(px.mr * px.sp), g3 = (double)px.sp;
+        const double dI = (double)px.I - mu;
+        a[4] += g1; a[5] += g2; a[6] += g3;
+        a[7] += g1 * dI; a[8] += g2 * dI; a[9] += g3 * dI;
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        double x = a[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+        if (lane == 0) red[i][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        double x = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kQBlock / kWave; w2++) x += red[threadIdx.x][w2];
+        atomicAdd(&accum[18 + threadIdx.x], x);
+    }
+}
+
+// grid (blocks, b): W = mask_weight * d mask_loss / d I * T (T = exp(L): what the backward splat
+// multiplies by 1 / (1 - a_i)); block 0 adds mask_weight * mask_loss to accum[15].
+__global__ __launch_bounds__(kQBlock) void mask_w_kernel(int S, const float *__restrict__ L,
+                                                         const float *__restrict__ mref,
+                                                         const float *__restrict__ stats, float mask_weight,
+                                                         float *__restrict__ W, double *__restrict__ accum)
+{
+    const int e = blockIdx.y, P = S * S;
     L += (size_t)e * P;
     mref += (size_t)e * P;
     W += (size_t)e * P;
     stats += (size_t)e * 4;
-    accum += (size_t)e * 16;
-    const double mur = stats[0], sdr = stats[1], s_r = stats[2];
-    double a[4] = {0, 0, 0, 0};
-    for (int q = threadIdx.x; q < P; q += kMLThreads) a[0] += (double)(1.0f - expf(L[q]));
-    block_sum4(a, red);
-    const double mu = a[0] / P;
-    double b[4] = {0, 0, 0, 0};
-    for (int q = threadIdx.x; q < P; q += kMLThreads) {
-        const double dd = (double)(1.0f - expf(L[q])) - mu;
-        b[0] += dd * dd;
-    }
-    block_sum4(b, red);
-    const double sd = sqrt(b[0] / (P - 1));
-    const float k = (float)((sdr + 1e-6) / (sd + 1e-6));
-    const float muf = (float)mu, murf = (float)mur;
-    // loss terms
-    double c[4] = {0, 0, 0, 0};      // mse, bce, intersection, sum m
-    for (int q = threadIdx.x; q < P; q += kMLThreads) {
-        const float I = 1.0f - expf(L[q]);
-        float xn = (I - muf) * k + murf;
-        xn = fminf(fmaxf(xn, 0.0f), 1.0f);
-        const float m = sigmoidf((xn - 0.1f) * 20.0f), mr = mref[q];
-        const float lm = fmaxf(logf(m), -100.0f), l1m = fmaxf(logf(1.0f - m), -100.0f);
-        c[0] += (double)((m - mr) * (m - mr));
-        c[1] += (double)(-(mr * lm + (1.0f - mr) * l1m));
-        c[2] += (double)(m * mr);
-        c[3] += (double)m;
-    }
-    block_sum4(c, red);
-    const double den = c[3] + s_r + 1e-6, num = 2.0 * c[2] + 1e-6;
-    const double loss = 30.0 * c[0] / P + c[1] / P + 10.0 * (1.0 - num / den);
-    // G = d loss / d xn; sums for the statistics' share of the gradient
-    const float dice_a = (float)(-10.0 * 2.0 / den), dice_b = (float)(10.0 * num / (den * den));
+    accum += (size_t)e * kAcc;
+    float muf, k;
+    double sd, mu;
+    const double sdr = stats[1];
+    mask_image_stats(accum, P, sdr, muf, k, sd, mu);
+    const float murf = stats[0];
+    const double den = accum[21] + (double)stats[2] + 1e-6, num = 2.0 * accum[20] + 1e-6;
+    const float dice_a = (float)(-20.0 / den), dice_b = (float)(10.0 * num / (den * den));
+    const double sG = accum[22] + (double)dice_a * accum[23] + (double)dice_b * accum[24];
+    const double sGd = accum[25] + (double)dice_a * accum[26] + (double)dice_b * accum[27];
+    const float meanG = (float)(sG / P);
+    const float kk = sd > 0.0 ? (float)((sdr + 1e-6) / ((sd + 1e-6) * (sd + 1e-6)) / ((P - 1) * sd) * sGd) : 0.0f;
     const float invP = 1.0f / (float)P;
-    double g[4] = {0, 0, 0, 0};
-    for (int q = threadIdx.x; q < P; q += kMLThreads) {
-        const float I = 1.0f - expf(L[q]);
-        const float x0 = (I - muf) * k + murf;
-        float G = 0.0f;
-        if (x0 > 0.0f && x0 < 1.0f) {
-            const float m = sigmoidf((x0 - 0.1f) * 20.0f), mr = mref[q];
-            float dm = 60.0f * (m - mr) * invP;
-            float db = 0.0f;
-            if (logf(m) > -100.0f) db -= mr / m;
-            if (logf(1.0f - m) > -100.0f) db += (1.0f - mr) / (1.0f - m);
-            dm += db * invP + dice_a * mr + dice_b;
-            G = dm * m * (1.0f - m) * 20.0f;
-        }
-        g[0] += (double)G;
-        g[1] += (double)G * ((double)I - mu);
-        W[q] = G;                                  // finished below
+    for (int q = blockIdx.x * kQBlock + threadIdx.x; q < P; q += gridDim.x * kQBlock) {
+        const float l = L[q];
+        const MaskPx px = mask_pixel(l, mref[q], muf, k, murf);
+        const float G = (px.dmb * invP + dice_a * px.mr + dice_b) * px.sp;
+        const float dI = k * (G - meanG) - kk * (px.I - muf);
+        W[q] = mask_weight * dI * expf(l);
     }
-    block_sum4(g, red);
-    const float meanG = (float)(g[0] / P);
-    const float kk = sd > 0.0 ? (float)((sdr + 1e-6) / ((sd + 1e-6) * (sd + 1e-6)) / ((P - 1) * sd) * g[1]) : 0.0f;
-    for (int q = threadIdx.x; q < P; q += kMLThreads) {
-        const float T = expf(L[q]);
-        const float I = 1.0f - T;
-        const float dI = k * (W[q] - meanG) - kk * (I - muf);
-        W[q] = mask_weight * dI * T;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double loss = 30.0 * accum[18] / P + accum[19] / P + 10.0 * (1.0 - num / den);
+        accum[15] += (double)mask_weight * loss;
     }
-    if (threadIdx.x == 0) accum[15] += (double)mask_weight * loss;
 }
 
 // grid (blocks, b): gradient of the mask term with respect to (R, s, t), into accum[0..12].
@@ -562,7 +676,7 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
     W += (size_t)e * S * S;
     center += (size_t)e * cstride;
     params += (size_t)e * pstride;
-    accum += (size_t)e * 16;
+    accum += (size_t)e * kAcc;
     float R[9];
     rot6d_to_matrix(params, R);
     const float s = expf(params[9]);
@@ -658,25 +772,29 @@ namespace genpc {
 static int mask_tiles(int S) { const int t = ceil_div(S, kMaskTile); return t * t; }
 
 // splat of the partial clouds + reference soft masks / statistics (once per call)
-static int mask_prepare_ref(int b, int np, const float *partial, float radius, int S, float *mref, float *stats,
+static int mask_prepare_ref(int b, int np, const float *partial, float radius, int S, float4 *uvr, float *mref, float *stats,
                             hipStream_t st)
 {
-    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kQBlock), 0, st, np, partial, (const float *)nullptr,
-                       0, (const float *)nullptr, 0, 0, radius, S, mref);
+    hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(np), b), dim3(kQBlock), 0, st, np, partial, (const float *)nullptr, 0,
+                       (const float *)nullptr, 0, 0, radius, S, uvr);
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, np, (const float4 *)uvr, S, mref,
+                       (double *)nullptr);
     hipLaunchKernelGGL(mask_ref_kernel, dim3(b), dim3(kMLThreads), 0, st, S, mref, stats);
     return check(hipGetLastError(), "mask reference launch") ? 1 : 0;
 }
 
-// the three launches of the mask term for the current parameters: accum += gradient, accum[15] += loss
+// the launches of the mask term for the current parameters: accum[0..12] += gradient, accum[15] += loss
 static int mask_step(int b, int nc, const float *complete, const float *center, int cstride, const float *params,
                      int pstride, float radius, int S, float mask_weight, const float *mref, const float *stats,
-                     float *L, float *W, double *accum, hipStream_t st)
+                     float4 *uvr, float *L, float *W, double *accum, hipStream_t st)
 {
     const float rad = 1.1f * radius;      // diff_obj_pose.py:385: the posed cloud is drawn with 1.1 x the radius
-    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kQBlock), 0, st, nc, complete, center, cstride,
-                       params, pstride, 1, rad, S, L);
-    hipLaunchKernelGGL(mask_loss_kernel, dim3(b), dim3(kMLThreads), 0, st, S, (const float *)L, mref, stats, mask_weight,
-                       W, accum);
+    const int gp = lin_grid((long long)S * S);
+    hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride, params,
+                       pstride, 1, rad, S, uvr);
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, nc, (const float4 *)uvr, S, L, accum);
+    hipLaunchKernelGGL(mask_sums_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)L, mref, stats, accum);
+    hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)L, mref, stats, mask_weight, W, accum);
     hipLaunchKernelGGL(mask_grad_kernel, dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride,
                        params, pstride, rad, S, (const float *)W, accum);
     return check(hipGetLastError(), "mask step launch") ? 1 : 0;
@@ -689,10 +807,14 @@ GENPC_API int genpc_splat_image(int n, const float *pts, float radius, int size,
     using namespace genpc;
     if (n < 0 || size <= 0 || !(radius > 0.0f)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    float *L = (float *)workspace(14, (size_t)size * size * sizeof(float), st);
-    if (!L) return 0;
-    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(size), 1), dim3(kQBlock), 0, st, n, pts, (const float *)nullptr, 0,
-                       (const float *)nullptr, 0, 0, radius, size, L);
+    char *ws = (char *)workspace(14, (size_t)size * size * sizeof(float) + 256 + (size_t)(n > 0 ? n : 1) * sizeof(float4), st);
+    if (!ws) return 0;
+    float *L = (float *)ws;
+    float4 *uvr = (float4 *)(ws + (((size_t)size * size * sizeof(float) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(n > 0 ? n : 1), 1), dim3(kQBlock), 0, st, n, pts, (const float *)nullptr, 0,
+                       (const float *)nullptr, 0, 0, radius, size, uvr);
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(size), 1), dim3(kSplatBlock), 0, st, n, (const float4 *)uvr, size, L,
+                       (double *)nullptr);
     hipLaunchKernelGGL(mask_image_kernel, dim3(ceil_div(size * size, 256)), dim3(256), 0, st, size * size, (const float *)L, img);
     return check(hipGetLastError(), "splat_image launch") ? 1 : 0;
 }
@@ -708,20 +830,22 @@ GENPC_API int genpc_pose_loss_grad(int nc, const float *v, const float *center, 
     if (mask && (render_size <= 0 || !(radius > 0.0f))) return -1;
     hipStream_t st = (hipStream_t)stream;
     const size_t P = mask ? (size_t)render_size * render_size : 0;
-    char *ws = (char *)workspace(3, 512 + sizeof(PoseState) + 3 * P * sizeof(float) + 256, st);
+    const size_t nmax = (size_t)(nc > np ? nc : np);
+    char *ws = (char *)workspace(3, 1024 + sizeof(PoseState) + 3 * P * sizeof(float) + 256 + nmax * sizeof(float4) + 256, st);
     if (!ws) return 0;
     double *accum = (double *)ws;
     PoseState *S = (PoseState *)(ws + 256);
     float *stats = (float *)(ws + 256 + ((sizeof(PoseState) + 255) & ~(size_t)255));
     float *mref = stats + 64, *L = mref + P, *W = L + P;
-    if (!check(hipMemsetAsync(accum, 0, 16 * sizeof(double), st), "hipMemsetAsync(accum)")) return 0;
+    float4 *uvr = (float4 *)(((uintptr_t)(W + P) + 255) & ~(uintptr_t)255);
+    if (!check(hipMemsetAsync(accum, 0, kAcc * sizeof(double), st), "hipMemsetAsync(accum)")) return 0;
     if (!check(hipMemcpyAsync(S->params, params, 10 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy params"))
         return 0;
     hipLaunchKernelGGL(pose_grad_kernel, dim3(lin_grid((long long)nc + np), 1), dim3(kQBlock), 0, st, nc, v, center, 0,
                        params, 0, np, partial, d1, i1, d2, i2, cd_weight, accum);
     if (mask) {
-        if (!mask_prepare_ref(1, np, partial, radius, render_size, mref, stats, st)) return 0;
-        if (!mask_step(1, nc, v, center, 0, params, 0, radius, render_size, mask_weight, mref, stats, L, W, accum, st)) return 0;
+        if (!mask_prepare_ref(1, np, partial, radius, render_size, uvr, mref, stats, st)) return 0;
+        if (!mask_step(1, nc, v, center, 0, params, 0, radius, render_size, mask_weight, mref, stats, uvr, L, W, accum, st)) return 0;
     }
     hipLaunchKernelGGL(pose_update_kernel, dim3(1), dim3(64), 0, st, 1, S, accum, nc, np, cd_weight, reg_weight, 0.0f, 0,
                        (float *)nullptr, 0);
@@ -759,7 +883,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, in
     // scratch: accum[b,16] | state[b] | center[b,4] | pts[b,nc,3] | d1 | d2 | i1 | i2 | mask: stats, m_ref, L, W
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     size_t off = 0;
-    const size_t o_acc = off; off += up((size_t)b * 16 * sizeof(double));
+    const size_t o_acc = off; off += up((size_t)b * kAcc * sizeof(double));
     const size_t o_state = off; off += up((size_t)b * sizeof(PoseState));
     const size_t o_center = off; off += up((size_t)b * 4 * sizeof(float));
     const size_t o_pts = off; off += up((size_t)b * nc * 12);
@@ -771,6 +895,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, in
     const size_t o_mref = off; off += up((size_t)b * P * sizeof(float));
     const size_t o_L = off; off += up((size_t)b * P * sizeof(float));
     const size_t o_W = off; off += up((size_t)b * P * sizeof(float));
+    const size_t o_uvr = off; off += up(mask ? (size_t)b * (size_t)(nc > np ? nc : np) * sizeof(float4) : 0);
     char *ws = (char *)workspace(4, off, st);
     if (!ws) return 0;
     double *accum = (double *)(ws + o_acc);
@@ -780,13 +905,14 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, in
     float *d1 = (float *)(ws + o_d1), *d2 = (float *)(ws + o_d2);
     int *i1 = (int *)(ws + o_i1), *i2 = (int *)(ws + o_i2);
     float *stats = (float *)(ws + o_stats), *mref = (float *)(ws + o_mref), *L = (float *)(ws + o_L), *W = (float *)(ws + o_W);
+    float4 *uvr = (float4 *)(ws + o_uvr);
     constexpr int kStateFloats = (int)(sizeof(PoseState) / sizeof(float));
     static_assert(sizeof(PoseState) % sizeof(float) == 0, "PoseState must be float-addressable");
 
     // center = mean(vert_pos) per scan (diff_obj_pose.py:362)
     if (!genpc_mean3(b, nc, complete, center, accum, st)) return 0;
     // reference image of the partial cloud (render_reference_image, diff_obj_pose.py:108-134)
-    if (mask && !mask_prepare_ref(b, np, partial, radius, render_size, mref, stats, st)) return 0;
+    if (mask && !mask_prepare_ref(b, np, partial, radius, render_size, uvr, mref, stats, st)) return 0;
 
     const int gb = ceil_div(b, 64);
     hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, -1);
@@ -802,7 +928,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, in
                                4, (const float *)S->params, kStateFloats, np, partial, (const float *)d1,
                                (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, accum);
             if (mask && !mask_step(b, nc, complete, center, 4, S->params, kStateFloats, radius, render_size, mask_weight, mref,
-                                   stats, L, W, accum, st))
+                                   stats, uvr, L, W, accum, st))
                 return 0;
             hipLaunchKernelGGL(pose_update_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, nc, np, 3.0f, 0.001f, lr, 1,
                                history ? history + (size_t)s * (iters + 1) + it : (float *)nullptr, hstride);
@@ -831,14 +957,14 @@ GENPC_API int genpc_pose_optimize_cd(int nc, const float *complete, int np, cons
 
 namespace genpc {
 
-// accum[e*16 + 0..2] += sum of v[e, :, 0..2]
+// accum[e*kAcc + 0..2] += sum of v[e, :, 0..2]
 __global__ __launch_bounds__(kQBlock) void mean3_accum_kernel(int n, const float *__restrict__ v,
                                                               double *__restrict__ accum)
 {
     __shared__ double red[3][kQBlock / kWave];
     const int e = blockIdx.y;
     v += (size_t)e * n * 3;
-    accum += (size_t)e * 16;
+    accum += (size_t)e * kAcc;
     double a[3] = {0.0, 0.0, 0.0};
     for (int j = blockIdx.x * kQBlock + threadIdx.x; j < n; j += gridDim.x * kQBlock) {
         a[0] += (double)v[(size_t)j * 3 + 0];
@@ -866,13 +992,13 @@ __global__ void mean3_finish_kernel(int b, int n, double *__restrict__ accum, fl
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= b * 3) return;
     const int e = t / 3, k = t % 3;
-    out[e * 4 + k] = (float)(accum[(size_t)e * 16 + k] / n);
-    accum[(size_t)e * 16 + k] = 0.0;
+    out[e * 4 + k] = (float)(accum[(size_t)e * kAcc + k] / n);
+    accum[(size_t)e * kAcc + k] = 0.0;
 }
 
 int genpc_mean3(int b, int n, const float *v, float *out, double *accum, hipStream_t st)
 {
-    if (!check(hipMemsetAsync(accum, 0, (size_t)b * 16 * sizeof(double), st), "hipMemsetAsync(mean)")) return 0;
+    if (!check(hipMemsetAsync(accum, 0, (size_t)b * kAcc * sizeof(double), st), "hipMemsetAsync(mean)")) return 0;
     hipLaunchKernelGGL(mean3_accum_kernel, dim3(lin_grid(n), b), dim3(kQBlock), 0, st, n, v, accum);
     hipLaunchKernelGGL(mean3_finish_kernel, dim3(ceil_div(b * 3, 64)), dim3(64), 0, st, b, n, accum, out);
     return check(hipGetLastError(), "mean3 launch") ? 1 : 0;

@@ -141,6 +141,16 @@ def test_full_size_properties(gp):
         assert torch.equal(torch.where(take_r, ri + h, li), i1)
 
 
+def test_more_query_blocks_than_the_resident_counter_area(gp, oracle):
+    """300 batch elements x 8192 queries: > 16384 (batch, query block) units, i.e. more arrival
+    counters than the 64 KiB that stay zero between calls (the scale search's 1000 candidates
+    on dense clouds hit this); then a small call again."""
+    a, b = gen_pair(5, (300, 8192, 3), (300, 64, 3))
+    assert_same(run_hip(gp, a, b, 1), oracle.chamfer_forward(a, b, 1))
+    a2, b2 = gen_pair(6, (2, 3000, 3), (2, 2500, 3))
+    assert_same(run_hip(gp, a2, b2, 1), oracle.chamfer_forward(a2, b2, 1))
+
+
 def test_degenerate_and_extreme_shapes(gp, oracle):
     """All points identical (every distance ties: index 0 must win everywhere), one
     query against a long cloud and vice versa, sizes around the tiling constants."""

@@ -123,3 +123,30 @@ def test_gather_rejects_wrong_row_count():
     from genpc_amd.sharding import gather_scan_metrics
     with pytest.raises(ValueError):
         gather_scan_metrics(torch.zeros(5, 3), 13, 0, 1)
+
+
+def test_bench_spawns_the_torchrun_form(monkeypatch):
+    """`python bench.py --gpus 4` outside torchrun must start `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 ... bench.py --gpus 4 ...` as a child
+    and exit with its code -- before touching a GPU; inside torchrun (WORLD_SIZE set) or with
+    --gpus 1 it must not."""
+    import subprocess
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 7)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.maybe_spawn(types.SimpleNamespace(gpus=4))
+    assert e.value.code == 7 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node" in cmd and "4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    bench.maybe_spawn(types.SimpleNamespace(gpus=4))          # returns: already under a launcher
+    monkeypatch.delenv("WORLD_SIZE")
+    bench.maybe_spawn(types.SimpleNamespace(gpus=1))
+    assert len(calls) == 1
