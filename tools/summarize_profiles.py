@@ -1,15 +1,17 @@
-"""Turns the rocprofv3 CSVs that tools/collect_profiles.sh wrote under
-gpurun_out/prof_<tag>/ into the small summaries committed under profiles/.
+"""Turns the rocprofv3 CSVs that tools/collect_profiles.sh wrote under gpurun_out/prof_<tag>/ into the
+small summaries committed under profiles/.
 
-    python tools/summarize_profiles.py r01
+    python tools/summarize_profiles.py r02
 
-HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (section HBM): FETCH_SIZE
-and WRITE_SIZE come from separate passes, are in KiB, and FETCH_SIZE counts wide
-coalesced reads at half their size on gfx950, so
-    hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024     (per launch).
+Per family one JSON: for every library kernel its calls and average duration from the kernel trace
+and the per-launch averages of the PMC passes.  HBM bytes follow
+/opt/skills/guides/MI355X_MICROARCH.md (section HBM): FETCH_SIZE and WRITE_SIZE come from separate
+passes, are in KiB, and FETCH_SIZE counts wide coalesced reads at half their size on gfx950, so
+    hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024     (per launch; WRITE_SIZE uncalibrated).
 """
 import collections
 import csv
+import glob
 import json
 import os
 import shutil
@@ -18,68 +20,76 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def counters(path, kernel_substr):
-    per = collections.defaultdict(dict)
-    with open(path) as f:
-        for r in csv.DictReader(f):
-            if kernel_substr in r["Kernel_Name"]:
-                d = per[r["Dispatch_Id"]]
-                d[r["Counter_Name"]] = float(r["Counter_Value"])
-                d["_dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-                d["_grid"] = int(r["Grid_Size"])
-                d["_lds"] = int(r["LDS_Block_Size"])
-                d["_kernel"] = r["Kernel_Name"]
-    rows = list(per.values())
-    if not rows:
-        return {}
-    keys = [k for k in rows[-1] if not k.startswith("_")]
-    out = {k: sum(r[k] for r in rows) / len(rows) for k in keys}
-    out["launches"] = len(rows)
-    out["avg_duration_us_under_pmc"] = round(sum(r["_dur_us"] for r in rows) / len(rows), 2)
-    out["grid_threads"] = rows[-1]["_grid"]
-    out["lds_bytes_per_block"] = rows[-1]["_lds"]
-    out["kernel_name"] = rows[-1]["_kernel"]
+def short(name):
+    n = name.replace("void ", "").replace("genpc::", "")
+    return n.split("(")[0]
+
+
+def trace_stats(d):
+    out = {}
+    for f in glob.glob(os.path.join(d, "trace", "*kernel_stats.csv")):
+        for r in csv.DictReader(open(f)):
+            if "genpc::" in r["Name"]:
+                out[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
+                                         "min_us": round(float(r["MinNs"]) / 1e3, 2), "max_us": round(float(r["MaxNs"]) / 1e3, 2),
+                                         "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3)}
+    return out
+
+
+def counters(d, sub):
+    per = collections.defaultdict(lambda: collections.defaultdict(dict))
+    for f in glob.glob(os.path.join(d, sub, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "genpc::" not in r["Kernel_Name"]:
+                continue
+            per[short(r["Kernel_Name"])][r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+    out = {}
+    for k, disp in per.items():
+        rows = list(disp.values())
+        keys = set().union(*[set(r) for r in rows])
+        out[k] = {c: sum(r.get(c, 0.0) for r in rows) / len(rows) for c in sorted(keys)}
+        out[k]["launches"] = len(rows)
     return out
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     ks = os.path.join(src, "bench", "bench_kernel_stats.csv")
     if os.path.exists(ks):
         shutil.copy(ks, os.path.join(dst, tag + "_bench_kernel_stats.csv"))
-    for name, b, n, fetch, write, sq in (("chamfer_B1_16384", 1, 16384, "fetch", "write", "sq"),
-                                         ("chamfer_B13_16384", 13, 16384, "fetch13", None, "sq13")):
-        # dominant kernel: the f16 MFMA filter; the finish kernel's counters are kept beside it
-        d = {"kernel": "nn_f16_kernel", "batch": b, "points": n, "tag": tag,
-             "command": "rocprofv3 --pmc <counters> -- python3 tools/prof_chamfer.py %d %d" % (b, n)}
-        f = counters(os.path.join(src, fetch, "c_counter_collection.csv"), "nn_f16_kernel") if fetch else {}
-        w = counters(os.path.join(src, write, "c_counter_collection.csv"), "nn_f16_kernel") if write else {}
-        s = counters(os.path.join(src, sq, "c_counter_collection.csv"), "nn_f16_kernel") if sq else {}
-        ff = counters(os.path.join(src, fetch, "c_counter_collection.csv"), "nn_finish_kernel") if fetch else {}
-        fw = counters(os.path.join(src, write, "c_counter_collection.csv"), "nn_finish_kernel") if write else {}
-        fs = counters(os.path.join(src, sq, "c_counter_collection.csv"), "nn_finish_kernel") if sq else {}
-        d["finish_kernel"] = {"FETCH_SIZE_KiB": ff.get("FETCH_SIZE"), "WRITE_SIZE_KiB": fw.get("WRITE_SIZE"), "sq": fs}
-        if ff and fw:
-            d["finish_kernel"]["hbm_bytes_per_launch"] = (2 * ff["FETCH_SIZE"] + fw["WRITE_SIZE"]) * 1024
-        if f:
-            d["FETCH_SIZE_KiB"] = f.get("FETCH_SIZE")
-        if w:
-            d["WRITE_SIZE_KiB"] = w.get("WRITE_SIZE")
-        if f and w:
-            d["hbm_bytes_per_launch"] = (2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024
-        alg = 20.0 * 2 * n * b
-        d["algorithmic_bytes_per_launch"] = alg
-        if "hbm_bytes_per_launch" in d:
-            d["traffic_over_algorithmic"] = round(d["hbm_bytes_per_launch"] / alg, 2)
-        d["sq"] = s
-        if s:
-            d["kernel_name"] = s.get("kernel_name")
-        with open(os.path.join(dst, "%s_%s_pmc.json" % (tag, name)), "w") as fh:
-            json.dump(d, fh, indent=1)
-        print(name, json.dumps(d)[:600])
+    for fam in sorted(os.listdir(src)):
+        d = os.path.join(src, fam)
+        if not os.path.isdir(os.path.join(d, "trace")):
+            continue
+        tr, fe, wr, sq = trace_stats(d), counters(d, "fetch"), counters(d, "write"), counters(d, "sq")
+        kernels = {}
+        for k in sorted(set(tr) | set(fe) | set(wr) | set(sq)):
+            e = dict(tr.get(k, {}))
+            if k in fe:
+                e["FETCH_SIZE_KiB"] = round(fe[k].get("FETCH_SIZE", 0.0), 2)
+            if k in wr:
+                e["WRITE_SIZE_KiB"] = round(wr[k].get("WRITE_SIZE", 0.0), 2)
+            if k in fe and k in wr:
+                e["hbm_bytes_per_launch"] = (2 * fe[k].get("FETCH_SIZE", 0.0) + wr[k].get("WRITE_SIZE", 0.0)) * 1024
+                if e.get("avg_us"):
+                    e["hbm_GB_s_at_trace_duration"] = round(e["hbm_bytes_per_launch"] / (e["avg_us"] * 1e-6) / 1e9, 1)
+            if k in sq:
+                e["sq"] = {c: v for c, v in sq[k].items() if c != "launches"}
+                w = sq[k].get("SQ_WAVE_CYCLES")
+                if w:
+                    e["sq_fractions_of_wave_cycles"] = {c: round(sq[k][c] / w, 3) for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU")
+                                                       if c in sq[k]}
+            kernels[k] = e
+        out = {"family": fam, "tag": tag, "command": "tools/collect_profiles.sh %s (rocprofv3 --kernel-trace --stats / --pmc ... -- python3 <driver>)" % tag,
+               "kernels": kernels}
+        with open(os.path.join(dst, "%s_%s.json" % (tag, fam)), "w") as fh:
+            json.dump(out, fh, indent=1)
+        tot = sum(v.get("total_ms", 0.0) for v in kernels.values())
+        print("%-28s %2d kernels, %.2f ms traced; top: %s" % (fam, len(kernels), tot, ", ".join(
+            "%s %.1fus" % (k, v["avg_us"]) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1].get("total_ms", 0))[:3] if "avg_us" in v)))
 
 
 if __name__ == "__main__":
