@@ -95,12 +95,23 @@ class DepthPrompting:
         return uv, depth, tr
 
     # DepthPrompting.py:273-290 -- with a z-buffer definition instead of open3d's HPR
-    def getVisiblePoints(self, points, cams=None, tol=1e-4, res=None, uvs=None, depths=None, point_size=2):
+    def getVisiblePoints(self, points, viewpoints=None, radius=None, cams=None, tol=1e-4, res=None, uvs=None,
+                         depths=None, point_size=2):
         """Visibility of every point from every camera: [C,N] bool and the per-camera
-        counts [C].  The reference uses open3d.hidden_point_removal (Katz' operator, CPU,
-        third-party); this is a z-buffer test at `res` x `res` (cfg.cam_res by default):
-        visible = no point whose (2*point_size-1)^2 stamp covers the pixel is nearer by more
-        than `tol` (NDC depth)."""
+        counts [C].  Signature as in the reference (points, viewpoints, radius); `viewpoints`
+        are eye positions [C,3] looking at the origin (None: the cameras of this object, or
+        `cams` [C,12] view matrices).  The reference uses open3d.hidden_point_removal (Katz'
+        operator with `radius`, CPU, qhull); this is a z-buffer test at `res` x `res`
+        (cfg.cam_res by default): visible = no point whose (2*point_size-1)^2 stamp covers the
+        pixel is nearer by more than `tol` (NDC depth); `radius` has no counterpart and is ignored.
+        How differently the two operators choose a view is measured in
+        tests/test_gpu_scans.py::test_viewpoint_selection_against_katz_hpr
+        (profiles/r02_hpr_agreement.json: count correlation 0.8-0.88, the z-buffer's view ranks
+        0-6 of 64 by Katz counts)."""
+        if viewpoints is not None and cams is None and uvs is None:
+            eyes = np.asarray(viewpoints.cpu() if torch.is_tensor(viewpoints) else viewpoints, np.float64).reshape(-1, 3)
+            cams = torch.from_numpy(np.stack([look_at(e, np.zeros(3), calculate_up_vector(e, np.zeros(3))) for e in eyes])
+                                    ).to(points.device)
         if uvs is None:
             uvs, depths, _ = self.getUvs(self.cameras if cams is None else cams, points,
                                          rescale=self.cfg.rescale, padding=self.cfg.padding, want_transformed=False)
@@ -121,7 +132,7 @@ class DepthPrompting:
         from .fps import fps_sampling
         k = min(int(getattr(self.cfg, "downsample_num", 10000)), xyz.shape[0])
         xyz_fps = xyz[fps_sampling(xyz.contiguous().float(), k).long()]
-        _, counts = self.getVisiblePoints(xyz_fps, self.cameras, tol=tol)
+        _, counts = self.getVisiblePoints(xyz_fps, cams=self.cameras, tol=tol)
         return int(torch.argmax(counts))
 
     def uvToPixels(self, uvs, res):

@@ -281,5 +281,5 @@ def test_zbuffer_visibility_and_viewpoint_select(gp, oracle):
     gp["cfg"].cam_res = 128
     best = dp.viewpoint_select(cap)
     sub = cap[fps_sampling(cap, 3000).long()]
-    _, counts = dp.getVisiblePoints(sub, dp.cameras, tol=1e-4)
+    _, counts = dp.getVisiblePoints(sub, cams=dp.cameras, tol=1e-4)
     assert best == int(torch.argmax(counts)) and int(counts.max()) > 1500

@@ -86,3 +86,49 @@ def test_config4_waymo_cars_4096(tg, golden, mode):
     np.testing.assert_array_equal(d1.cpu().numpy(), g[f"dist1_m{mode}"])
     np.testing.assert_array_equal(ass.cpu().numpy(), g[f"assignment_m{mode}"])
     np.testing.assert_array_equal(de.cpu().numpy(), g[f"emd_dist_m{mode}"])
+
+
+def test_viewpoint_selection_against_katz_hpr(tg, golden):
+    """f3: the library selects the viewpoint with a z-buffer visibility test; the reference with Katz'
+    hidden-point removal through open3d/qhull (DepthPrompting.py:87-98,273-290).  The two operators are
+    different definitions; this measures how differently they choose, on the bundled scans, against a
+    qhull restatement of the reference's operator (oracle/hpr.py) at the reference's radius and at a
+    geometric one.  Asserted: the statistics are produced and the z-buffer's view is never among the
+    worst quarter by the geometric HPR count.  The numbers go to gpurun_out/hpr_agreement.json
+    (copied to profiles/)."""
+    import json
+    import os
+    from types import SimpleNamespace
+    torch = tg["torch"]
+    from conftest import ROOT
+    from genpc_amd.DepthPrompting import DepthPrompting
+    from genpc_amd.fps import fps_sampling
+    from oracle import hpr
+    g = golden("scans13_fps16384.npz")
+    cfg = SimpleNamespace(device="cuda", fovy=49.1, res=256, cam_res=256, padding=0.15, rescale=True, point_size=1,
+                          mask_pixel_rate=3, view_num=64, distance=1.6, downsample_num=3000)
+    dp = DepthPrompting(cfg)
+    eyes = np.asarray(dp.viewpoints, np.float64)
+    rows = []
+    for s in range(0, 13, 2):
+        pts = torch.from_numpy(g["partial"][s]).cuda()
+        sub = pts[fps_sampling(pts, cfg.downsample_num).long()]
+        _, cnt = dp.getVisiblePoints(sub, viewpoints=eyes, radius=10000)      # the reference's call shape
+        zb = cnt.cpu().numpy().astype(np.int64)
+        subn = sub.cpu().numpy()
+        geo = hpr.visible_counts(subn, eyes, 100.0)
+        ref = hpr.visible_counts(subn, eyes, 10000.0)
+
+        def rank_of(choice, counts):          # 0 = best view by `counts`
+            return int((counts > counts[choice]).sum())
+        zc = int(np.argmax(zb))
+        rows.append(dict(scan=str(g["ids"][s]), zbuffer_view=zc, hpr100_view=int(np.argmax(geo)), hpr10000_view=int(np.argmax(ref)),
+                         zbuffer_rank_in_hpr100=rank_of(zc, geo), zbuffer_rank_in_hpr10000=rank_of(zc, ref),
+                         corr_zbuffer_hpr100=float(np.corrcoef(zb, geo)[0, 1]), corr_zbuffer_hpr10000=float(np.corrcoef(zb, ref)[0, 1]),
+                         visible_fraction_hpr100=float(geo.mean() / len(subn)), visible_fraction_hpr10000=float(ref.mean() / len(subn)),
+                         visible_fraction_zbuffer=float(zb.mean() / len(subn))))
+        assert rows[-1]["zbuffer_rank_in_hpr100"] < 48, rows[-1]
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "hpr_agreement.json"), "w") as f:
+        json.dump(dict(views=64, points=cfg.downsample_num, scans=rows), f, indent=1)

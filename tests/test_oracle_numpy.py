@@ -237,3 +237,28 @@ def test_chamfer_non_finite_follows_the_tile_structure(oracle):
     b0[0, 0, 2] = np.nan               # tile 0 head: every query ends with (NaN, 0)
     d1, _, i1, _ = oracle.chamfer_forward(a, b0, 1)
     assert np.isnan(d1).all() and (i1 == 0).all()
+
+
+def test_hpr_oracle_on_a_sphere_and_a_shell():
+    """Katz' operator through qhull.  With a moderate radius it is geometric visibility: ~40 % of a
+    sampled sphere, 95 % of them on the camera's side, an inner sphere invisible.  With the
+    reference's radius (configs/config.yaml: removal_radius 10000, 10000 points, camera at 1.6) the
+    flipped cloud is so flat that a point is only removed when another one sits at almost the same
+    direction: most of the cloud counts as visible from every side -- the regime viewpoint_select
+    really runs in."""
+    from oracle import hpr
+    rng = np.random.default_rng(0)
+    u = rng.standard_normal((3000, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    sphere = u * 0.4
+    cam = np.array([0.0, 0.0, 1.6])
+    vis = hpr.hidden_point_removal(sphere, cam, 100)
+    assert 0.3 < len(vis) / 3000.0 < 0.55
+    facing = sphere[:, 2] > 0.4 * 0.4 / 1.6              # beyond the tangent cone: geometrically hidden
+    assert facing[vis].mean() > 0.9
+    both = np.vstack([sphere, sphere * 0.5])
+    assert (hpr.hidden_point_removal(both, cam, 100) >= 3000).mean() < 0.02
+    big = hpr.hidden_point_removal(sphere, cam, 10000)
+    assert len(big) / 3000.0 > 0.7 and facing[big].mean() < 0.7
+    counts = hpr.visible_counts(sphere, [cam, -cam, [1.6, 0, 0]], 10000)
+    assert counts.shape == (3,) and counts.min() > 1000
