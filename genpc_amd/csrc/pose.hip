@@ -334,13 +334,13 @@ __global__ void pose_end_kernel(int b, PoseState *__restrict__ S, int final, flo
 // normalisation, sigmoid soft masks, 30 MSE + BCE + 10 Dice (:204-217,261-278,238-259,304-311).
 //   mask_project_kernel  every point posed (the transform is fused) and projected once: (u, v, rho)
 //   mask_splat_kernel    one block per 16 x 16 image tile and scan: the points whose disc touches
-//                        the tile are compacted into LDS 256 at a time, then one WAVE per point, one
-//                        lane per pixel of an 8 x 8 patch of its box, adds log(1 - a) to the tile in
-//                        LDS (native ds_add_f32); writes L = sum log(1 - a) and adds the tile's sums
-//                        of I and I^2 to the scan's accumulators.  (Measured: one thread per point
-//                        walking its own box 634 us per call at 16384 points -- every wave pays a
-//                        full box for its one in-tile lane; 64-bit fixed-point accumulation with
-//                        accurate logf on 32 x 32 tiles 234 us.)
+//                        the tile are compacted into LDS, then every pixel (four threads each)
+//                        walks the list and sums log(1 - a) of the discs covering it, in list order:
+//                        no atomics on the image.  Writes L = sum log(1 - a) and adds the
+//                        tile's sums of I and I^2 to the scan's accumulators.  (Measured at 16384
+//                        points: one thread per point walking its own box 634 us per call -- every
+//                        wave pays a full box for its one in-tile lane; a wave per point with LDS
+//                        float atomics 36 us, 26 of them in the atomics.)
 //   mask_sums_kernel     pixels over many blocks: the ten sums the loss and its gradient need
 //   mask_w_kernel        W = d loss / d I * T per pixel; the loss itself
 //   mask_grad_kernel     one thread per point: gathers W over the pixels it covers, chains through
@@ -348,7 +348,8 @@ __global__ void pose_end_kernel(int b, PoseState *__restrict__ S, int final, flo
 //                        Chamfer gradient
 constexpr int kMaskTile = 16;
 constexpr int kSplatBlock = 1024;  // 16 waves per tile: a wave per point leaves long dependent chains, four waves per SIMD hide them
-constexpr int kSplatPer = 2;       // points per thread and compaction round of the splat
+constexpr int kSplatPer = 16;      // points per thread and round of the splat (16384 points per round)
+constexpr int kSplatList = 2048;   // in-tile points drawn per fill of the LDS list
 constexpr float kMaskAmax = 0.999f;
 constexpr float kMaskFocal = 4.0f, kMaskEyeZ = 3.0f, kMaskZnear = 1e-4f, kMaskZfar = 5.0f;
 
@@ -369,7 +370,7 @@ __device__ __forceinline__ SplatPt splat_project(const float *p, float radius, f
     return o;
 }
 
-// grid (blocks, b): uvr[e, j] = (u, v, rho, 0), rho = -1 for points the camera does not see.
+// grid (blocks, b): uvr[e, j] = (u, v, rho, 1 / rho^2), rho = -1 for points the camera does not see.
 // posed != 0: v is the complete cloud and is posed with params first.
 __global__ __launch_bounds__(kQBlock) void mask_project_kernel(int n, const float *__restrict__ v,
                                                                const float *__restrict__ center, int cstride,
@@ -397,16 +398,17 @@ __global__ __launch_bounds__(kQBlock) void mask_project_kernel(int n, const floa
             p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
         }
         const SplatPt q = splat_project(p, radius, hs);
-        uvr[j] = make_float4(q.u, q.v, q.ok ? q.rho : -1.0f, 0.0f);
+        uvr[j] = make_float4(q.u, q.v, q.ok ? q.rho : -1.0f, q.ok ? 1.0f / (q.rho * q.rho) : 0.0f);
     }
 }
 
 // grid (tiles, b)
 __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const float4 *__restrict__ uvr, int S,
-                                                             float *__restrict__ L, double *__restrict__ accum)
+                                                                 float *__restrict__ L, double *__restrict__ accum)
 {
-    __shared__ float acc[kMaskTile * kMaskTile];
-    __shared__ float4 list[kSplatBlock * kSplatPer];
+    static_assert(kSplatBlock == 4 * kMaskTile * kMaskTile, "four threads per pixel of the tile");
+    __shared__ float part[4][kMaskTile * kMaskTile];
+    __shared__ float4 list[kSplatList];
     __shared__ int s_cnt;
     __shared__ double red[2][kSplatBlock / kWave];
     const int e = blockIdx.y;
@@ -417,58 +419,74 @@ __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const fl
     L += (size_t)e * S * S;
     if (accum) accum += (size_t)e * kAcc;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int lx = lane & 7, ly = lane >> 3;          // a wave covers an 8 x 8 pixel patch of a point's box
-    for (int i = threadIdx.x; i < kMaskTile * kMaskTile; i += kSplatBlock) acc[i] = 0.0f;
+    // thread = (pixel of the tile, one of four interleaved shares of the point list)
+    const int pix = threadIdx.x & (kMaskTile * kMaskTile - 1), share = threadIdx.x / (kMaskTile * kMaskTile);
+    const float pxc = (float)(tx0 + (pix & (kMaskTile - 1))) + 0.5f, pyc = (float)(ty0 + pix / kMaskTile) + 0.5f;
+    float sum = 0.0f;
+    // Every block reads every point of its scan (16 x 16 tiles: 196 blocks per scan), kSplatPer per thread
+    // loaded together; the points whose disc touches the tile are compacted into LDS (one LDS atomic per wave
+    // and step), then GATHERED: every pixel walks the list (broadcast reads) and adds log(1 - a) of the discs
+    // that cover it, in list order -- no atomics on the image.  (Scattering with LDS float atomics ran at
+    // ~0.6 adds per clock per CU: 26 us of the kernel's 36 for 758 points in the busiest tile.)
     for (int j0 = 0; j0 < n; j0 += kSplatBlock * kSplatPer) {
-        if (threadIdx.x == 0) s_cnt = 0;
-        __syncthreads();
-        // kSplatPer points per thread and round: their loads are in flight together (a round is
-        // otherwise one L2 round trip plus two barriers for 256 points: 64 such rounds cost ~100 us)
         float4 q[kSplatPer];
 #pragma unroll
         for (int i = 0; i < kSplatPer; i++) {
             const int j = j0 + i * kSplatBlock + threadIdx.x;
             q[i] = j < n ? uvr[j] : make_float4(0.0f, 0.0f, -1.0f, 0.0f);
         }
+        unsigned hit = 0;
 #pragma unroll
         for (int i = 0; i < kSplatPer; i++) {
-            // the disc's pixel box against the tile (the exact clipping follows)
-            if (q[i].z > 0.0f && q[i].x + q[i].z - 0.5f >= (float)tx0 - 1.0f && q[i].x - q[i].z - 0.5f <= (float)tx1 + 1.0f &&
-                q[i].y + q[i].z - 0.5f >= (float)ty0 - 1.0f && q[i].y - q[i].z - 0.5f <= (float)ty1 + 1.0f)
-                list[atomicAdd(&s_cnt, 1)] = q[i];
+            // the disc's bounding box against the tile
+            if (q[i].z > 0.0f && q[i].x + q[i].z >= (float)tx0 && q[i].x - q[i].z <= (float)(tx1 + 1) &&
+                q[i].y + q[i].z >= (float)ty0 && q[i].y - q[i].z <= (float)(ty1 + 1))
+                hit |= 1u << i;
         }
-        __syncthreads();
-        const int cnt = s_cnt;
-        for (int k = wave; k < cnt; k += kSplatBlock / kWave) {
-            const float4 q = list[k];
-            // box of the disc (as the oracle draws it), clipped to the tile, walked in 8 x 8 patches
-            const int c0 = max((int)floorf(q.x - q.z - 0.5f), tx0), c1 = min((int)ceilf(q.x + q.z - 0.5f), tx1);
-            const int r0 = max((int)floorf(q.y - q.z - 0.5f), ty0), r1 = min((int)ceilf(q.y + q.z - 0.5f), ty1);
-            const float ir2 = 1.0f / (q.z * q.z);
-            for (int rb = r0; rb <= r1; rb += 8) {
-                for (int cb = c0; cb <= c1; cb += 8) {
-                    const int r = rb + ly, cc = cb + lx;
-                    const float dx = (float)cc + 0.5f - q.x, dy = (float)r + 0.5f - q.y;
-                    float a = 1.0f - (dx * dx + dy * dy) * ir2;
-                    if (r <= r1 && cc <= c1 && a > 0.0f) {
-                        a = fminf(a, kMaskAmax);
-                        // native LDS float add (the sum's order, hence its last bits, vary from run to run)
-                        unsafeAtomicAdd(&acc[(r - ty0) * kMaskTile + (cc - tx0)], __logf(1.0f - a));
+        // the list holds kSplatList entries: a crowded tile is drawn in several fills
+        unsigned done = 0;                   // bits of `hit` already listed
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_cnt = 0;
+            __syncthreads();
+            bool left = false;
+#pragma unroll
+            for (int i = 0; i < kSplatPer; i++) {
+                const bool want = ((hit >> i) & 1u) && !((done >> i) & 1u);
+                const unsigned long long m = __ballot(want);
+                if (m) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_cnt, __popcll(m));
+                    base = __shfl(base, 0, kWave);
+                    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (want) {
+                        if (slot < kSplatList) { list[slot] = q[i]; done |= 1u << i; }
+                        else left = true;
                     }
                 }
             }
+            const int more = __syncthreads_or(left ? 1 : 0);
+            const int cnt = min(s_cnt, kSplatList);
+            for (int k = share; k < cnt; k += 4) {
+                const float4 p = list[k];
+                const float dx = pxc - p.x, dy = pyc - p.y;
+                const float a = 1.0f - (dx * dx + dy * dy) * p.w;
+                if (a > 0.0f) sum += __logf(1.0f - fminf(a, kMaskAmax));
+            }
+            if (!more) break;
         }
-        __syncthreads();
     }
+    part[share][pix] = sum;
+    __syncthreads();
     double s1 = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < kMaskTile * kMaskTile; i += kSplatBlock) {
-        const int r = ty0 + i / kMaskTile, cc = tx0 + i % kMaskTile;
+    if (threadIdx.x < kMaskTile * kMaskTile) {
+        const int r = ty0 + pix / kMaskTile, cc = tx0 + (pix & (kMaskTile - 1));
         if (r < S && cc < S) {
-            const float l = acc[i];
+            const float l = (part[0][pix] + part[1][pix]) + (part[2][pix] + part[3][pix]);
             L[(size_t)r * S + cc] = l;
             const float I = 1.0f - expf(l);
-            s1 += (double)I;
-            s2 += (double)I * (double)I;
+            s1 = (double)I;
+            s2 = (double)I * (double)I;
         }
     }
     if (accum) {

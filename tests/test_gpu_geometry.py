@@ -235,8 +235,10 @@ def test_pose_loop_full_size_property(gp):
 
 
 def test_pose_loop_batched_equals_singles(gp):
-    """B scans in lock-step (one batched NN launch per Adam step) give the same
-    transforms as B separate runs (fp64 reductions are atomics: last-bit noise only)."""
+    """B scans in lock-step (one batched NN launch per Adam step) give the same transforms as B
+    separate runs.  Chamfer-only objective: fp64 reductions are atomics, last-bit noise only.  Full
+    objective: the splat sums its list in an order that varies from run to run and the loss jumps
+    by 100 / P when a soft-mask pixel saturates, so only the first steps are comparable."""
     torch = gp["torch"]
     cs, ps = [], []
     for seed in (9, 10, 11):
@@ -245,12 +247,15 @@ def test_pose_loop_batched_equals_singles(gp):
         ps.append(p[:700])
     C = torch.from_numpy(np.stack(cs)).cuda()
     P = torch.from_numpy(np.stack(ps)).cuda()
-    Tb, hb, _ = gp["POSE"].object_pose_optimization(C, P, lr=0.01, iters=60, return_history=True)
+    Tb, hb, _ = gp["POSE"].object_pose_optimization(C, P, lr=0.01, iters=60, return_history=True, cd_only=True)
     assert Tb.shape == (3, 4, 4) and hb.shape == (3, 4, 61)
+    Tf, hf, _ = gp["POSE"].object_pose_optimization(C, P, radius=0.02, lr=0.01, iters=20, return_history=True)
     for i in range(3):
-        Ti, hi, _ = gp["POSE"].object_pose_optimization(C[i], P[i], lr=0.01, iters=60, return_history=True)
-        np.testing.assert_allclose(hb[i][:, :10], hi[:, :10], rtol=1e-3)      # float atomics in the splat: noise per run, amplified by the saturating soft masks
-        np.testing.assert_allclose(Tb[i], Ti, atol=6e-3)
+        Ti, hi, _ = gp["POSE"].object_pose_optimization(C[i], P[i], lr=0.01, iters=60, return_history=True, cd_only=True)
+        np.testing.assert_allclose(hb[i][:, :10], hi[:, :10], rtol=1e-5)
+        np.testing.assert_allclose(Tb[i], Ti, atol=2e-3)
+        _, hfi, _ = gp["POSE"].object_pose_optimization(C[i], P[i], radius=0.02, lr=0.01, iters=20, return_history=True)
+        np.testing.assert_allclose(hf[i][:, :5], hfi[:, :5], rtol=2e-3)
 
 
 def test_zbuffer_visibility_and_viewpoint_select(gp, oracle):
