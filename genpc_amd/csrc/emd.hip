@@ -449,6 +449,63 @@ __global__ __launch_bounds__(kEBlock) void emd_assign_kernel(int n, const int *_
     }
 }
 
+// GetMax and Assign of one round in ONE launch, one 1024-thread block per batch element: used from
+// the round on in which few bidders are left (the two list-walking launches are then pure latency:
+// 4.7 + 5.1 us plus a launch boundary per round at 1 x 16384).  Phase 1 elects (atomicMax, performed in
+// L2), the block barrier separates it from phase 2, which reads the elections with L1-bypassing loads.
+constexpr int kResolveBlock = 1024;
+__global__ __launch_bounds__(kResolveBlock) void emd_resolve_kernel(int n, const int *__restrict__ list,
+                                                                    const int *__restrict__ cnt, int *__restrict__ list_next,
+                                                                    int *__restrict__ cnt_next, int *__restrict__ assignment,
+                                                                    int *__restrict__ assignment_inv, float *__restrict__ price,
+                                                                    const int *__restrict__ bid,
+                                                                    const float *__restrict__ bid_increments,
+                                                                    float *__restrict__ max_increments,
+                                                                    int *__restrict__ max_idx, int last)
+{
+    const int batch = blockIdx.x;
+    const int U = cnt[batch];
+    const size_t base = (size_t)batch * n;
+    for (int u = threadIdx.x; u < U; u += kResolveBlock) {
+        const int j = list[base + u];
+        const int bid_id = bid[base + j];
+        const double bid_inc = (double)bid_increments[base + j];
+        const double max_inc = (double)max_increments[base + bid_id];
+        if (last || (bid_inc - 1e-6 <= max_inc && max_inc <= bid_inc + 1e-6)) atomicMax(&max_idx[base + bid_id], j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int u = threadIdx.x; u < U; u += kResolveBlock) {
+        const int j = list[base + u];
+        const int bid_id = bid[base + j];
+        const bool elected = __hip_atomic_load(&max_idx[base + bid_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == j;
+        if (last) {
+            assignment[base + j] = bid_id;
+            atomicAdd(&price[base + bid_id], bid_increments[base + j]);
+            if (elected) {
+                assignment_inv[base + bid_id] = j;
+                max_increments[base + bid_id] = -1e9f;
+                max_idx[base + bid_id] = -1;
+            }
+        } else if (elected) {
+            const int prev = assignment_inv[base + bid_id];
+            if (prev != -1) {
+                assignment[base + prev] = -1;
+                const int pos = atomicAdd(&cnt_next[batch], 1);
+                list_next[base + pos] = prev;
+            }
+            assignment_inv[base + bid_id] = j;
+            assignment[base + j] = bid_id;
+            price[base + bid_id] = __fadd_rn(price[base + bid_id], bid_increments[base + j]);
+            max_increments[base + bid_id] = -1e9f;
+            max_idx[base + bid_id] = -1;
+        } else {
+            const int pos = atomicAdd(&cnt_next[batch], 1);
+            list_next[base + pos] = j;
+        }
+    }
+}
+
 // emd_cuda.cu:217-226
 template <int FMA>
 __global__ __launch_bounds__(kEBlock) void emd_calc_dist_kernel(long long total, int n, const float *__restrict__ xyz1,
@@ -552,7 +609,15 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     const int g_max = ceil_div(n * 64, kEBlock);
     if (G > g_max) G = g_max;
     if (G < 1) G = 1;
-    if (getenv("GENPC_EMD_G")) G = atoi(getenv("GENPC_EMD_G"));
+    static const int env_g = getenv("GENPC_EMD_G") ? atoi(getenv("GENPC_EMD_G")) : 0;
+    if (env_g > 0) G = env_g;
+    // rounds from which GetMax + Assign run as one single-block launch per cloud (few bidders left:
+    // ~n/7 after four rounds); a forced last round with all points bidding keeps the two launches
+    // (measured, 50 rounds: 1 x 2048 0.75 -> 0.68 ms, 64 x 2048 2.18 -> 1.98, 13 x 16384 8.45 -> 8.19; but
+    // 1 x 16384 1.61 -> 1.80: with ~1000-2000 bidders left per round one block walking the list is
+    // slower than 64 -- so only for small clouds or many of them)
+    static const int env_rf = getenv("GENPC_EMD_RESOLVE_FROM") ? atoi(getenv("GENPC_EMD_RESOLVE_FROM")) : -1;
+    const int resolve_from = env_rf >= 0 ? env_rf : ((n <= 4096 || b >= 8) ? 4 : 0x7fffffff);
     int GL = ceil_div(n, kEBlock);          // list-walking kernels
     if (GL > 64) GL = 64;
 
@@ -580,12 +645,18 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
                                (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
                                max_increments, force_p, parts, arrive, second, zmax);
         }
-        hipLaunchKernelGGL(emd_getmax_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
-                           (const int *)cnts[cur], (const int *)bid, (const float *)bid_increments,
-                           (const float *)max_increments, max_idx, last);
-        hipLaunchKernelGGL(emd_assign_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
-                           (const int *)cnts[cur], lists[nxt], cnts[nxt], assignment, assignment_inv, price,
-                           (const int *)bid, (const float *)bid_increments, max_increments, max_idx, last);
+        if (it >= resolve_from) {
+            hipLaunchKernelGGL(emd_resolve_kernel, dim3(b), dim3(kResolveBlock), 0, st, n, (const int *)lists[cur],
+                               (const int *)cnts[cur], lists[nxt], cnts[nxt], assignment, assignment_inv, price,
+                               (const int *)bid, (const float *)bid_increments, max_increments, max_idx, last);
+        } else {
+            hipLaunchKernelGGL(emd_getmax_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
+                               (const int *)cnts[cur], (const int *)bid, (const float *)bid_increments,
+                               (const float *)max_increments, max_idx, last);
+            hipLaunchKernelGGL(emd_assign_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
+                               (const int *)cnts[cur], lists[nxt], cnts[nxt], assignment, assignment_inv, price,
+                               (const int *)bid, (const float *)bid_increments, max_increments, max_idx, last);
+        }
     }
     if (fma)
         hipLaunchKernelGGL((emd_calc_dist_kernel<1>), dim3(lin_blocks), dim3(kEBlock), 0, st, total, n, xyz1, xyz2, dist,

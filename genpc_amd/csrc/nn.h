@@ -230,8 +230,182 @@ __device__ __forceinline__ float nn_tau(float a_best, float qq, float tmax2, dou
     return tf;
 }
 
+
+constexpr int kMaxLists = 16;          // slices x lists per lane, when sliced (planner: chamfer.hip)
+
+// Exact (reference arithmetic) minimum and first index over the 16 targets base + 16h ..
+// base + 16h + 15 of a 32-target tile: the rows whose approximate values lane half h of the
+// filter held (tile_row()).  Positions past the end are clamped to the last target.
+template <int FMA>
+__device__ __forceinline__ void rescan_half(const float *__restrict__ T, int nt, int base, int h, float qx, float qy,
+                                            float qz, float &bd, int &bi)
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int first = base + 16 * h;
+    bd = __builtin_inff();
+    bi = first < nt ? first : nt - 1;
+    if (first + 16 <= nt) {
+        const f4u *tp = (const f4u *)(T + (size_t)first * 3);
+        f4u v[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) v[k] = tp[k];
+#pragma unroll
+        for (int g = 3; g >= 0; g--) {
+            const float f[12] = {v[g * 3].x, v[g * 3].y, v[g * 3].z, v[g * 3].w, v[g * 3 + 1].x, v[g * 3 + 1].y,
+                                 v[g * 3 + 1].z, v[g * 3 + 1].w, v[g * 3 + 2].x, v[g * 3 + 2].y, v[g * 3 + 2].z, v[g * 3 + 2].w};
+#pragma unroll
+            for (int c = 3; c >= 0; c--) {
+                const float dd = sqdist<FMA>(f[c * 3 + 0] - qx, f[c * 3 + 1] - qy, f[c * 3 + 2] - qz);
+                const bool le = dd <= bd;
+                bd = le ? dd : bd;
+                bi = le ? first + 4 * g + c : bi;
+            }
+        }
+    } else {
+        for (int c = 15; c >= 0; c--) {
+            int kk = first + c;
+            kk = kk < nt ? kk : nt - 1;
+            const float *tp = T + (size_t)kk * 3;
+            const float dd = sqdist<FMA>(tp[0] - qx, tp[1] - qy, tp[2] - qz);
+            const bool le = dd <= bd;
+            bd = le ? dd : bd;
+            bi = le ? kk : bi;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// The finish step for the NQ queries [qfirst, qfirst + NQ) of one (direction, batch element), run by
+// the LAST slice block of nn_f16_kernel<..., FUSE = 1> to arrive for that query block instead of by a
+// second launch (nn_finish_kernel, nn_bf16.hip, whose logic this restates for NQ > 64): gather the
+// query's lists (agent-scope loads: the other slices' blocks published them with agent-scope stores),
+// derive the acceptance threshold tau, turn listed units that are not provably out into work items of
+// 16 targets, evaluate them exactly, write (distance, first index); queries whose proof fails go
+// through nn_exhaustive.  The slice maxima of |t'|^2 travel in the low half of each list's third word.
+// lds: >= nn_finish_block_lds<NQ>() bytes, 16-byte aligned; s_red / s_fi: kWavesPerBlock entries.
+constexpr int kFusedWork = 4096;       // work-item capacity of the fused finish (512 queries x 8 pieces)
+template <int NQ>
+__host__ __device__ constexpr int nn_finish_block_lds() { return NQ * (8 + 4 + 4 + 4 + 4) + kFusedWork * 4 + 64; }
+
+template <int FMA, int NQ>
+__device__ __forceinline__ void nn_finish_block(const NNArgs &a, const NNDir &D, int batch, int qfirst, int nl, int upieces,
+                                                float kqt, float ktt, float t2min, char *lds, float *s_red, int *s_fi)
+{
+    unsigned long long *s_best = (unsigned long long *)lds;              // (distance bits << 32 | index)
+    float *s_tau = (float *)(lds + NQ * 8);
+    float *s_qq = s_tau + NQ;
+    int *s_qflag = (int *)(s_qq + NQ);
+    int *s_flagged = s_qflag + NQ;
+    unsigned *s_work = (unsigned *)(s_flagged + NQ);
+    int *s_misc = (int *)(s_work + kFusedWork);                          // [0] work items, [1] flagged queries
+    const int nq = D.nq, nt = D.nt;
+    const float *__restrict__ Qp = D.q + (size_t)batch * nq * 3;
+    const float *__restrict__ T = D.t + (size_t)batch * nt * 3;
+    float *__restrict__ od = D.out_d + (size_t)batch * nq;
+    int *__restrict__ oi = D.out_i + (size_t)batch * nq;
+    const size_t bnq = (size_t)a.b * nq;
+    const unsigned long long *P = D.part + (size_t)batch * nq;
+    const int nlists = D.slices * nl;
+    const float *cptr = a.dir[0].t + (size_t)batch * a.dir[0].nt * 3;      // common centre of the filter
+    const float ccx = cptr[0], ccy = cptr[1], ccz = cptr[2];
+    if (threadIdx.x == 0) { s_misc[0] = 0; s_misc[1] = 0; }
+    // pass 1 over the lists: smallest approximate value, largest |t'|^2; then tau (fp64, once per query)
+    for (int ql = threadIdx.x; ql < NQ; ql += kBlock) {
+        int j = qfirst + ql;
+        j = j < nq ? j : nq - 1;
+        float amin = __builtin_inff(), tmax2 = 0.0f;
+        for (int li = 0; li < nlists; li++) {
+            const unsigned long long *p = P + (size_t)li * 3 * bnq + j;
+            const unsigned long long w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long w2 = __hip_atomic_load(p + 2 * bnq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            amin = fminf(amin, __uint_as_float((unsigned)(w0 >> 32)));
+            tmax2 = fmaxf(tmax2, __uint_as_float((unsigned)w2));
+        }
+        const float x = Qp[(size_t)j * 3 + 0] - ccx, y = Qp[(size_t)j * 3 + 1] - ccy, z = Qp[(size_t)j * 3 + 2] - ccz;
+        const float qq = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
+        float t = nn_tau(amin, qq, tmax2, (double)kqt, (double)ktt);
+        if (!(tmax2 >= t2min)) t = __builtin_nanf("");
+        if (!(tmax2 < __builtin_inff()) || !(qq < __builtin_inff())) t = __builtin_nanf("");      // non-finite input
+        if (a.debug & 16) t = __builtin_inff();          // test hook: every listed tile is evaluated
+        s_tau[ql] = t;
+        s_qq[ql] = qq;
+        s_best[ql] = ~0ull;
+        s_qflag[ql] = 0;
+    }
+    __syncthreads();
+    // pass 2: listed units that are not provably out become work items of 16 targets
+    for (int ql = threadIdx.x; ql < NQ; ql += kBlock) {
+        const int j0 = qfirst + ql;
+        const bool live = j0 < nq;
+        const int j = live ? j0 : nq - 1;
+        const float tau = s_tau[ql];
+        bool flag = (a.debug & 8) != 0 || !(tau == tau);
+        for (int li = 0; li < nlists; li++) {
+            const unsigned long long *p = P + (size_t)li * 3 * bnq + j;
+            const unsigned long long w[2] = {__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                             __hip_atomic_load(p + bnq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+            const unsigned long long w2 = __hip_atomic_load(p + 2 * bnq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(__uint_as_float((unsigned)(w2 >> 32)) > tau)) flag = true;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float av = __uint_as_float((unsigned)(w[k] >> 32));
+                const int c = (int)(unsigned)w[k];
+                if (av <= tau) {
+                    if (c < 0) {
+                        flag = true;
+                    } else if (live) {
+                        const int h = c & 1, c0 = c & ~1;
+                        const int left = (nt - c0 + 31) >> 5;
+                        const int n2 = left < upieces ? left : upieces;
+                        const int wpos = atomicAdd(&s_misc[0], n2);
+                        if (wpos + n2 <= kFusedWork) {
+                            for (int q2 = 0; q2 < n2; q2++) s_work[wpos + q2] = ((unsigned)ql << 22) | (unsigned)((((c0 >> 5) + q2) << 1) | h);
+                        } else {
+                            flag = true;
+                        }
+                    }
+                }
+            }
+        }
+        if (flag && live) s_qflag[ql] = 1;
+    }
+    __syncthreads();
+    const int nwork = min(s_misc[0], kFusedWork);
+    for (int w = threadIdx.x; w < nwork; w += kBlock) {
+        const unsigned it = s_work[w];
+        const int slot = (int)(it >> 22);
+        const int j = qfirst + slot;
+        const float qx = Qp[(size_t)j * 3 + 0], qy = Qp[(size_t)j * 3 + 1], qz = Qp[(size_t)j * 3 + 2];
+        float dd;
+        int ii;
+        rescan_half<FMA>(T, nt, (int)((it & 0x3fffffu) >> 1) << 5, (int)(it & 1u), qx, qy, qz, dd, ii);
+        atomicMin(&s_best[slot], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii);
+    }
+    __syncthreads();
+    for (int ql = threadIdx.x; ql < NQ; ql += kBlock) {
+        const int j = qfirst + ql;
+        if (j >= nq) continue;
+        if (s_qflag[ql]) {
+            s_flagged[atomicAdd(&s_misc[1], 1)] = j;
+        } else {
+            const unsigned long long v = s_best[ql];
+            od[j] = __uint_as_float((unsigned)(v >> 32));
+            oi[j] = (int)(unsigned)v;
+        }
+    }
+    __syncthreads();
+    const int nflag = s_misc[1];
+    if (a.stats && threadIdx.x == 0) {
+        atomicAdd(&a.stats[0], (unsigned long long)min(NQ, nq - qfirst));
+        atomicAdd(&a.stats[1], (unsigned long long)nflag);
+        atomicAdd(&a.stats[2], (unsigned long long)nwork);
+    }
+    for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Qp, T, nt, s_flagged[fidx], od, oi, s_red, s_fi);
+}
+
 int launch_nn_bf16(NNArgs &a, int q, int pre, int nl, long long total_blocks, hipStream_t st);
-int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, long long total_blocks, hipStream_t st);
+int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, int fuse, long long total_blocks, hipStream_t st);
 int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float t2min, hipStream_t st);
 int launch_nn_grid(const NNArgs &a, hipStream_t st);
 

@@ -43,7 +43,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 constexpr int kBTile = GENPC_BTILE;    // targets per LDS tile: 4 planes x 16 B = 32 KiB at 512
 constexpr double kQT16 = 27.0, kTT16 = 17.0;
-constexpr int kMaxLists = 16;          // slices x lists per lane, when sliced (planner: chamfer.hip)
 
 __device__ __forceinline__ unsigned bf16_rn(float v)      // v_cvt_pk_bf16_f32 (round to nearest even)
 {
@@ -388,47 +387,6 @@ __global__ __launch_bounds__(kBlock) void nn_bf16_kernel(NNArgs a)
                 p[bnq] = ((unsigned long long)__float_as_uint(f.a2) << 32) | (unsigned)f.c2;
                 p[2 * bnq] = (unsigned long long)__float_as_uint(f.a3) << 32;
             }
-        }
-    }
-}
-
-// Exact (reference arithmetic) minimum and first index over the 16 targets base + 16h ..
-// base + 16h + 15 of a 32-target tile: the rows whose approximate values lane half h of the
-// filter held (tile_row()).  Positions past the end are clamped to the last target.
-template <int FMA>
-__device__ __forceinline__ void rescan_half(const float *__restrict__ T, int nt, int base, int h, float qx, float qy,
-                                            float qz, float &bd, int &bi)
-{
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    const int first = base + 16 * h;
-    bd = __builtin_inff();
-    bi = first < nt ? first : nt - 1;
-    if (first + 16 <= nt) {
-        const f4u *tp = (const f4u *)(T + (size_t)first * 3);
-        f4u v[12];
-#pragma unroll
-        for (int k = 0; k < 12; k++) v[k] = tp[k];
-#pragma unroll
-        for (int g = 3; g >= 0; g--) {
-            const float f[12] = {v[g * 3].x, v[g * 3].y, v[g * 3].z, v[g * 3].w, v[g * 3 + 1].x, v[g * 3 + 1].y,
-                                 v[g * 3 + 1].z, v[g * 3 + 1].w, v[g * 3 + 2].x, v[g * 3 + 2].y, v[g * 3 + 2].z, v[g * 3 + 2].w};
-#pragma unroll
-            for (int c = 3; c >= 0; c--) {
-                const float dd = sqdist<FMA>(f[c * 3 + 0] - qx, f[c * 3 + 1] - qy, f[c * 3 + 2] - qz);
-                const bool le = dd <= bd;
-                bd = le ? dd : bd;
-                bi = le ? first + 4 * g + c : bi;
-            }
-        }
-    } else {
-        for (int c = 15; c >= 0; c--) {
-            int kk = first + c;
-            kk = kk < nt ? kk : nt - 1;
-            const float *tp = T + (size_t)kk * 3;
-            const float dd = sqdist<FMA>(tp[0] - qx, tp[1] - qy, tp[2] - qz);
-            const bool le = dd <= bd;
-            bd = le ? dd : bd;
-            bi = le ? kk : bi;
         }
     }
 }

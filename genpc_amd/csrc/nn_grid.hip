@@ -86,6 +86,7 @@ struct GridArgs {
     int block_begin[2];
     int fma;
     float radius2;          // search limit (squared distance), +inf = none
+    int near_only;          // experiment: stop after the 27 cells, count the unresolved queries in stats[1]
     int sort_cloud[2];      // cloud c is sorted (it is a target cloud, or its queries are wanted in cell order)
     unsigned long long *stats;
 };
@@ -479,7 +480,9 @@ __global__ __launch_bounds__(kBlock) void grid_query_kernel(GridArgs a)
         // everything outside the 27 cells differs by >= 2 cells on some axis: distance >= h - 2 slack
         float reach = fmaxf(0.0f, h - 2.0f * smax);
         bool done = __fmul_rn(__fmul_rn(reach, reach), kShrink) > __uint_as_float((unsigned)(best >> 32));
-        if (!done) {
+        if (!done && a.near_only) {
+            if (a.stats && sub == 0 && live) atomicAdd(&a.stats[1], 1ull);
+        } else if (!done) {
             // Far phase.  Coarse cells (4 x 4 x 4 fine cells, one contiguous run of the sorted cloud
             // each) are tested against the best so far, the lanes of the group taking LPQ of them at
             // a time; inside a surviving coarse cell the 64 fine cells are tested the same way and
@@ -579,6 +582,8 @@ int launch_nn_grid(const NNArgs &na, hipStream_t st)
     a.fma = na.fma;
     a.stats = na.stats;
     a.radius2 = na.radius2;
+    static const int near_env = getenv("GENPC_GRID_NEARONLY") ? 1 : 0;
+    a.near_only = near_env;
     // one direction: only the target cloud is sorted (the queries lose some locality, a whole cloud less to sort)
     a.sort_cloud[0] = na.ndir > 1 ? 1 : 0;
     a.sort_cloud[1] = 1;

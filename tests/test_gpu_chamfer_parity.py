@@ -261,3 +261,37 @@ def test_radius_limited_search(gp, oracle, golden, mode):
     finally:
         lib.genpc_set_arith(prev)
     assert lib.genpc_nm_distance_within(1, 4, None, 4, None, -1.0, None, None, None) == -1
+
+
+HOOK_FUSE = 1024
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fused_finish_elementwise(gp, oracle, golden, mode):
+    """The f16 filter with the finish step run by the last slice block to arrive (hook 1024; the
+    512-query-block variant, i.e. problems of >= 2e8 pairs): bench input, a ragged unequal pair, the
+    13 real scans, with the test hooks that force the exhaustive pass / evaluate every listed unit,
+    and a non-finite case -- every distance and index against the oracle."""
+    a, b = gen_pair(20250101, (1, 16384, 3), (1, 16384, 3))
+    exp = oracle.chamfer_forward(a, b, mode)
+    read_stats(gp)
+    assert_bits(run_hip(gp, a, b, mode, PATHS["f16"], HOOK_FUSE | HOOK_COUNT), exp, "fused")
+    q, ex, pieces = read_stats(gp)
+    assert q == 32768 and ex == 0 and 0 < pieces < 6 * q
+    assert_bits(run_hip(gp, a, b, mode, PATHS["f16"], HOOK_FUSE | 16), exp, "fused, every listed unit")
+    a2, b2 = gen_pair(5, (1, 20001, 3), (1, 11003, 3))
+    assert_bits(run_hip(gp, a2, b2, mode, PATHS["f16"], HOOK_FUSE), oracle.chamfer_forward(a2, b2, mode), "fused ragged")
+    a2[0, 17] = np.nan
+    b2[0, 1024, 1] = np.nan
+    got, e2 = run_hip(gp, a2, b2, mode, PATHS["f16"], HOOK_FUSE), oracle.chamfer_forward(a2, b2, mode)
+    for gg, e in zip(got[2:], e2[2:]):
+        np.testing.assert_array_equal(gg, e)
+    for gg, e in zip(got[:2], e2[:2]):
+        assert np.array_equal(gg, e, equal_nan=True)
+    if mode == 1:
+        g = golden("scans13_fps16384.npz")
+        assert_bits(run_hip(gp, g["partial"][:5], g["gt"][:5], 1, PATHS["f16"], HOOK_FUSE),
+                    oracle.chamfer_forward(g["partial"][:5], g["gt"][:5], 1), "fused scans")
+        grid = np.random.default_rng(3).integers(0, 24, size=(1, 30000, 3)).astype(np.float32)      # exact ties: exhaustive pass
+        assert_bits(run_hip(gp, grid[:, :15000].copy(), grid[:, 15000:].copy(), 1, PATHS["f16"], HOOK_FUSE),
+                    oracle.chamfer_forward(grid[:, :15000].copy(), grid[:, 15000:].copy(), 1), "fused ties")
