@@ -8,6 +8,7 @@ Cameras are [C,12] tensors of 3x4 world->camera matrices instead of kaolin
 ``Camera`` objects (kaolin is not a dependency): ``create_cameras`` restates
 utils/camera_utils.py:84-160 (fibonacci sphere, ``calculate_up_vector``, look-at).
 """
+import ctypes
 import math
 
 import numpy as np
@@ -72,6 +73,7 @@ class DepthPrompting:
     def __init__(self, cfg, cameras=None, focal=None):
         self.cfg = cfg
         self.device = torch.device(cfg.device)
+        self.viewpoints = None
         if cameras is None:
             cameras, self.viewpoints, focal = create_cameras(
                 num_views=cfg.view_num, distance=cfg.distance, fovy=cfg.fovy, device=self.device)
@@ -94,24 +96,46 @@ class DepthPrompting:
             raise RuntimeError("genpc_get_uvs failed: " + _lib.last_error())
         return uv, depth, tr
 
-    # DepthPrompting.py:273-290 -- with a z-buffer definition instead of open3d's HPR
-    def getVisiblePoints(self, points, viewpoints=None, radius=None, cams=None, tol=1e-4, res=None, uvs=None,
-                         depths=None, point_size=2):
-        """Visibility of every point from every camera: [C,N] bool and the per-camera
-        counts [C].  Signature as in the reference (points, viewpoints, radius); `viewpoints`
-        are eye positions [C,3] looking at the origin (None: the cameras of this object, or
-        `cams` [C,12] view matrices).  The reference uses open3d.hidden_point_removal (Katz'
-        operator with `radius`, CPU, qhull); this is a z-buffer test at `res` x `res`
-        (cfg.cam_res by default): visible = no point whose (2*point_size-1)^2 stamp covers the
-        pixel is nearer by more than `tol` (NDC depth); `radius` has no counterpart and is ignored.
-        How differently the two operators choose a view is measured in
-        tests/test_gpu_scans.py::test_viewpoint_selection_against_katz_hpr
-        (profiles/r02_hpr_agreement.json: count correlation 0.8-0.88, the z-buffer's view ranks
-        0-6 of 64 by Katz counts)."""
-        if viewpoints is not None and cams is None and uvs is None:
-            eyes = np.asarray(viewpoints.cpu() if torch.is_tensor(viewpoints) else viewpoints, np.float64).reshape(-1, 3)
-            cams = torch.from_numpy(np.stack([look_at(e, np.zeros(3), calculate_up_vector(e, np.zeros(3))) for e in eyes])
-                                    ).to(points.device)
+    # DepthPrompting.py:273-290
+    def getVisiblePoints(self, points, viewpoints=None, radius=None):
+        """[C,N] bool: point n is visible from viewpoints[c] -- the reference's call
+        (points, viewpoints, radius) and result.  The reference loops over the viewpoints calling
+        open3d's hidden_point_removal (Katz: spherical flipping + qhull, CPU); here all viewpoints go
+        through one exact evaluation of the same operator on the GPU (csrc/hpr.hip: the hull-vertex test
+        as a normal-cone polygon per point, double arithmetic).  viewpoints: eye positions [C,3]
+        (default: this object's), radius: cfg.removal_radius by default."""
+        return self.hidden_point_removal(points, viewpoints, radius)[0]
+
+    def hidden_point_removal(self, points, viewpoints=None, radius=None):
+        """-> (visible [C,N] bool, counts [C] int32, points that needed the large-polygon pass)."""
+        if viewpoints is None:
+            viewpoints = self.viewpoints
+        if viewpoints is None:          # cameras were handed in: eye = -R^T t of each 3x4 world->camera matrix
+            m = self.cameras.reshape(-1, 3, 4).double().cpu().numpy()
+            viewpoints = -np.einsum("cji,cj->ci", m[:, :, :3], m[:, :, 3])
+        if radius is None:
+            radius = self.cfg.removal_radius
+        points = points.contiguous().float()
+        _lib.check_tensors((("points", points),))
+        eyes = torch.as_tensor(np.asarray(viewpoints.cpu() if torch.is_tensor(viewpoints) else viewpoints, np.float64)
+                               ).reshape(-1, 3).contiguous().to(points.device)
+        c, n = eyes.shape[0], points.shape[0]
+        vis = torch.zeros(c, n, device=points.device, dtype=torch.uint8)
+        cnt = torch.empty(c, device=points.device, dtype=torch.int32)
+        second = ctypes.c_int(0)
+        rc = _lib.on_device_of(points, _L.genpc_hpr_visibility, c, n, _p(points), _p(eyes), float(radius), _p(vis), _p(cnt),
+                               ctypes.addressof(second))
+        if rc != 1:
+            raise RuntimeError("genpc_hpr_visibility failed (rc=%d): %s" % (rc, _lib.last_error()))
+        return vis.bool(), cnt, int(second.value)
+
+    def getVisiblePointsZBuffer(self, points, cams=None, tol=1e-4, res=None, uvs=None, depths=None, point_size=2):
+        """A cheaper visibility for ranking viewpoints (NOT the reference's operator, which is
+        getVisiblePoints above): [C,N] bool and the per-camera counts [C] from a z-buffer test at
+        `res` x `res` (cfg.cam_res by default): visible = no point whose (2*point_size-1)^2 stamp covers
+        the pixel is nearer by more than `tol` (NDC depth).  `cams` [C,12] view matrices (default: this
+        object's).  How differently the two operators rank views is measured in
+        tests/test_gpu_scans.py::test_viewpoint_selection_against_katz_hpr."""
         if uvs is None:
             uvs, depths, _ = self.getUvs(self.cameras if cams is None else cams, points,
                                          rescale=self.cfg.rescale, padding=self.cfg.padding, want_transformed=False)
@@ -126,14 +150,56 @@ class DepthPrompting:
         return vis.bool(), cnt
 
     # DepthPrompting.py:87-98
-    def viewpoint_select(self, xyz, tol=1e-4):
-        """FPS to cfg.downsample_num points, visibility from all cameras, the camera that
-        sees the most points."""
+    def viewpoint_select(self, xyz, tol=1e-4, zbuffer=False):
+        """FPS to cfg.downsample_num points, hidden-point removal from every viewpoint with
+        cfg.removal_radius, the viewpoint that sees the most points (zbuffer=True: rank with the
+        z-buffer test instead)."""
         from .fps import fps_sampling
         k = min(int(getattr(self.cfg, "downsample_num", 10000)), xyz.shape[0])
         xyz_fps = xyz[fps_sampling(xyz.contiguous().float(), k).long()]
-        _, counts = self.getVisiblePoints(xyz_fps, cams=self.cameras, tol=tol)
+        if zbuffer:
+            _, counts = self.getVisiblePointsZBuffer(xyz_fps, cams=self.cameras, tol=tol)
+        else:
+            _, counts, _ = self.hidden_point_removal(xyz_fps, self.viewpoints, getattr(self.cfg, "removal_radius", 10000))
         return int(torch.argmax(counts))
+
+    # DepthPrompting.py:100-187 (getDepth up to the raw depth image; the inpainting that follows is stock
+    # diffusion / cv2 code and stays with the reference)
+    def getDepth(self, xyz, flag=None, rgb=None):
+        """The geometric half of the reference's getDepth: projection from every camera, viewpoint
+        selection by hidden-point removal (view_num == 6: view 1), the opposite viewpoint's camera,
+        hidden-point removal of the WHOLE cloud from both, the depth-sum heuristic that picks one of
+        the two (:154-175), pixels, and getRawDepth on the visible points.  Sets self.point_uv /
+        self.view / self.cam like the reference and returns a dict with sparse_img, raw_depth,
+        hole_mask1, hole_mask2, view_index, used_opposite, visible (bool [N]), depth_sums."""
+        xyz = xyz.contiguous().float()
+        n = xyz.shape[0]
+        rgb = torch.ones(n, 3, device=xyz.device) if rgb is None else rgb
+        point_uvs, point_depths, _ = self.getUvs(self.cameras, xyz, rescale=self.cfg.rescale, padding=self.cfg.padding,
+                                                 want_transformed=False)
+        best = 1 if getattr(self.cfg, "view_num", 0) == 6 else self.viewpoint_select(xyz)
+        original = np.asarray(self.viewpoints[best], np.float64)
+        opposite = -original
+        opp_cam = torch.from_numpy(look_at(opposite, np.zeros(3), calculate_up_vector(opposite, np.zeros(3)))).to(xyz.device)
+        opp_uvs, opp_depths, _ = self.getUvs(opp_cam[None], xyz, rescale=self.cfg.rescale, padding=self.cfg.padding,
+                                             want_transformed=False)
+        radius = getattr(self.cfg, "removal_radius", 10000)
+        vis, _, _ = self.hidden_point_removal(xyz, np.stack([original, opposite]), radius)      # both viewpoints, one call
+        sum1 = float(point_depths[best][vis[0]].sum())
+        sum2 = float(opp_depths[0][vis[1]].sum())
+        if sum1 >= sum2:
+            used_opposite, visible, uvs, depths = False, vis[0], point_uvs[best], point_depths[best]
+            self.view, self.cam = original, self.cameras[best]
+        else:
+            used_opposite, visible, uvs, depths = True, vis[1], opp_uvs[0], opp_depths[0]
+            self.view, self.cam = opposite, opp_cam
+        pix = self.uvToPixels(uvs, self.cfg.res).long()
+        sparse_img, raw_depth, hole1, hole2 = self.getRawDepth(
+            pix[visible], depths[visible], colors=rgb[visible].contiguous(), dataset=getattr(self.cfg, "dataset", None),
+            res=self.cfg.res, point_size=self.cfg.point_size, mask_pixel_rate=self.cfg.mask_pixel_rate)
+        self.point_uv = uvs
+        return dict(sparse_img=sparse_img, raw_depth=raw_depth, hole_mask1=hole1, hole_mask2=hole2, view_index=best,
+                    used_opposite=used_opposite, visible=visible, depth_sums=(sum1, sum2), uv=uvs, depth=depths, pixels=pix)
 
     def uvToPixels(self, uvs, res):
         """DepthPrompting.py:179-184: (uv*res).long(), swap to (row, col), clip."""

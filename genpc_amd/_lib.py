@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GENPC_LIB: an alternative build of the same library (kernel experiments only)
 LIB_PATH = os.environ.get("GENPC_LIB") or os.path.join(_HERE, "lib", "libgenpc_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -40,6 +40,7 @@ SIGNATURES = {
     "genpc_uv_to_pixels": (_i, [_i, _vp, _f, _i, _vp, _vp]),
     "genpc_paint_pixels": (_i, [_i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "genpc_gather_colors": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "genpc_hpr_visibility": (_i, [_i, _i, _vp, _vp, _d, _vp, _vp, _vp, _vp]),
     "genpc_zbuffer_visibility": (_i, [_i, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "genpc_pose_transform": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_pose_cd_grad": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),

@@ -1,0 +1,696 @@
+// hpr.hip -- exact hidden-point removal: the operator the reference applies per
+// viewpoint through open3d's PointCloud.hidden_point_removal(camera, radius) (DepthPrompting.py:273-290;
+// Katz, Tal, Basri 2007): spherical flipping p' = v + 2 (radius - |v|) v / |v| with v = p - camera, then
+// the convex hull of the flipped points and the origin; visible = the hull's vertices.
+//
+// No hull is built here.  A flipped point p'_i is a hull vertex iff some plane through it has every other
+// flipped point and the origin strictly on one side, i.e. iff there is a normal n with n.p'_i > 0 and
+// n.p'_j < n.p'_i for all j.  n.p'_i > 0 lets n be scaled to n = u + a e1 + b e2 (u = p'_i / |p'_i|;
+// e1, e2 an orthonormal basis of u's normal plane); then n.p'_i = |p'_i| and every other point is ONE
+// LINEAR constraint on (a, b):
+//       a (e1.p'_j) + b (e2.p'_j) <= |p'_i| - u.p'_j
+// The feasible (a, b) are a convex polygon -- the cross-section of the vertex's normal cone; for the
+// reference's large radii it is the power cell of point i among the cloud's directions, weighted by depth --
+// and the point is visible iff the polygon survives clipping by every other point.  One thread owns one
+// (view, point): the polygon lives in LDS ([vertex][thread], <= kHprMaxV vertices), the candidates stream
+// through LDS tiles that the whole block reads at the same address (broadcast), and a candidate that cannot
+// reach the polygon (Cauchy-Schwarz against the polygon's largest vertex norm, with a 1e-9 margin: it never
+// rejects a candidate that would clip) costs 3 dot products.  Polygons that outgrow kHprMaxV (regular
+// lattices: many cospherical neighbours) are redone by a second kernel, one wave per point, with room for 1024 vertices.
+//
+// All arithmetic is double with contraction OFF and the operation order of oracle/genpc_oracle_hpr.c, which
+// processes the candidates in the same (input) order: the two produce the same polygons bit for bit, hence
+// the same mask.  That restatement is pinned against qhull (scipy) on random clouds, real scans and lattices.
+// Deviations from the hull definition: normals tilted from u by more than atan(1e4) are not considered;
+// exact duplicates clip nothing (every copy is reported; qhull keeps one).
+//
+// Points are put in 3-D Morton order (one hipcub sort per call).  A block owns 128 consecutive points and
+// takes the candidates tile by tile (128 consecutive points), outward from its own tile: own, +1, -1, +2, ...
+// The polygon is tight after the first tiles, and a tile whose cone of directions (axis, half-angle, largest
+// |p'|: hpr_tile_kernel) cannot reach any vertex of it is skipped whole -- a conservative test, so the result
+// is that of examining every candidate.  oracle/genpc_oracle_hpr.c takes the candidates in the same order.
+//
+// Cost: c * n^2 candidate tests (64 views x 10000 points: 6.4e9); see DESIGN.md.
+#include "common.h"
+#include "../../include/genpc_hip.h"
+
+#include <limits.h>
+#include <stdlib.h>
+
+#include <hipcub/hipcub.hpp>
+
+#pragma clang fp contract(off)
+
+namespace genpc {
+
+constexpr int kHprThreads = 128;
+constexpr int kHprMaxV = 24;            // polygon vertices per thread in LDS (48 KB per block)
+constexpr int kHprOverCap = 1024;       // vertices per polygon in the second pass (2 x 16 KB of LDS per wave)
+constexpr double kHprBox = 1.0e4;
+
+// p' for every (view, point), stored in Morton order (row pos = point perm[pos]); open3d: |v| = 0 -> 1e-4
+__global__ __launch_bounds__(256) void hpr_flip_kernel(int n, const float *__restrict__ pts, const int *__restrict__ perm,
+                                                      const double *__restrict__ eyes, double radius, double *__restrict__ fl)
+{
+    const int pos = blockIdx.x * 256 + threadIdx.x, view = blockIdx.y;
+    if (pos >= n) return;
+    const int i = perm[pos];
+    const double vx = (double)pts[(size_t)i * 3 + 0] - eyes[view * 3 + 0];
+    const double vy = (double)pts[(size_t)i * 3 + 1] - eyes[view * 3 + 1];
+    const double vz = (double)pts[(size_t)i * 3 + 2] - eyes[view * 3 + 2];
+    double r = sqrt(vx * vx + vy * vy + vz * vz);
+    if (r == 0.0) r = 0.0001;
+    const double k = 2.0 * (radius - r) / r;
+    double *o = fl + ((size_t)view * n + pos) * 3;
+    o[0] = vx + k * vx;
+    o[1] = vy + k * vy;
+    o[2] = vz + k * vz;
+}
+
+__device__ __forceinline__ unsigned hpr_ord(float f)      // order-preserving float -> uint
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float hpr_unord(unsigned o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// bounds[0..2] = min, [3..5] = max of the finite coordinates, as ordered uints (0xffffffff / 0 initially)
+__global__ __launch_bounds__(256) void hpr_bounds_kernel(int n, const float *__restrict__ pts, unsigned *bounds)
+{
+    unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float v = pts[(size_t)i * 3 + k];
+            if (!(fabsf(v) < __builtin_inff())) continue;
+            const unsigned o = hpr_ord(v);
+            mn[k] = o < mn[k] ? o : mn[k];
+            mx[k] = o > mx[k] ? o : mx[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned a = (unsigned)__shfl_xor((int)mn[k], off, kWave), b = (unsigned)__shfl_xor((int)mx[k], off, kWave);
+            mn[k] = a < mn[k] ? a : mn[k];
+            mx[k] = b > mx[k] ? b : mx[k];
+        }
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            atomicMin(&bounds[k], mn[k]);
+            atomicMax(&bounds[3 + k], mx[k]);
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned hpr_spread10(unsigned v)      // 10 bits -> every third bit
+{
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// 30-bit Morton key of every point in the cloud's bounding box (non-finite points last).  The key only decides
+// which points share a wave -- it has no influence on the result.
+__global__ __launch_bounds__(256) void hpr_key_kernel(int n, const float *__restrict__ pts, const unsigned *__restrict__ bounds,
+                                                     unsigned *__restrict__ keys, int *__restrict__ idx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned key = 0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float v = pts[(size_t)i * 3 + k];
+        const float lo = hpr_unord(bounds[k]), hi = hpr_unord(bounds[3 + k]);
+        if (!(fabsf(v) < __builtin_inff())) { ok = false; continue; }
+        const float w = hi - lo;
+        float q = w > 0.0f ? (v - lo) / w * 1023.0f : 0.0f;
+        q = q < 0.0f ? 0.0f : (q > 1023.0f ? 1023.0f : q);
+        key |= hpr_spread10((unsigned)q) << k;
+    }
+    keys[i] = ok ? key : 0xffffffffu;
+    idx[i] = i;
+}
+
+__device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
+
+struct HprFrame {
+    double px, py, pz, rho, ux, uy, uz, e1x, e1y, e1z, e2x, e2y, e2z;
+};
+
+// u, e1, e2 of a flipped point; false when it coincides with the origin or is not finite
+__device__ __forceinline__ bool hpr_frame(const double *p, HprFrame &f)
+{
+    f.px = p[0]; f.py = p[1]; f.pz = p[2];
+    f.rho = sqrt(f.px * f.px + f.py * f.py + f.pz * f.pz);
+    if (!(f.rho > 0.0) || !(f.rho < __builtin_inf())) return false;
+    f.ux = f.px / f.rho; f.uy = f.py / f.rho; f.uz = f.pz / f.rho;
+    const double ax = fabs(f.ux), ay = fabs(f.uy), az = fabs(f.uz);
+    double x, y, z;
+    if (ax <= ay && ax <= az) { x = 0.0; y = f.uz; z = -f.uy; }
+    else if (ay <= az)        { x = -f.uz; y = 0.0; z = f.ux; }
+    else                      { x = f.uy; y = -f.ux; z = 0.0; }
+    const double l = sqrt(x * x + y * y + z * z);
+    f.e1x = x / l; f.e1y = y / l; f.e1z = z / l;
+    f.e2x = f.uy * f.e1z - f.uz * f.e1y;
+    f.e2y = f.uz * f.e1x - f.ux * f.e1z;
+    f.e2z = f.ux * f.e1y - f.uy * f.e1x;
+    return true;
+}
+
+// What a thread needs to know about a tile of kHprThreads consecutive (Morton-neighbour) candidates to skip
+// it whole: their directions lie within angle phi of the axis w, their lengths are <= rho_max.
+struct HprTile {
+    double wx, wy, wz, cos_phi, sin_phi, cos2_phi, sin2_phi, inv_rho_max;
+};
+
+__global__ __launch_bounds__(kHprThreads) void hpr_tile_kernel(int n, const double *__restrict__ fl_all, HprTile *__restrict__ tiles)
+{
+    __shared__ double red[4][kHprThreads];
+    const int view = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int pos = tile * kHprThreads + tid;
+    double ux = 0.0, uy = 0.0, uz = 0.0, rho = 0.0;
+    bool ok = false;
+    if (pos < n) {
+        const double *p = fl_all + ((size_t)view * n + pos) * 3;
+        rho = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        ok = rho > 0.0 && rho < __builtin_inf();
+        if (ok) { ux = p[0] / rho; uy = p[1] / rho; uz = p[2] / rho; }
+        else rho = 0.0;
+    }
+    red[0][tid] = ux; red[1][tid] = uy; red[2][tid] = uz; red[3][tid] = rho;
+    __syncthreads();
+    for (int h = kHprThreads / 2; h > 0; h >>= 1) {
+        if (tid < h) {
+            red[0][tid] += red[0][tid + h];
+            red[1][tid] += red[1][tid + h];
+            red[2][tid] += red[2][tid + h];
+            red[3][tid] = red[3][tid] > red[3][tid + h] ? red[3][tid] : red[3][tid + h];
+        }
+        __syncthreads();
+    }
+    const double sx = red[0][0], sy = red[1][0], sz = red[2][0], rho_max = red[3][0];
+    const double l = sqrt(sx * sx + sy * sy + sz * sz);
+    __syncthreads();
+    const bool axis = l > 0.0 && rho_max > 0.0;
+    const double wx = axis ? sx / l : 0.0, wy = axis ? sy / l : 0.0, wz = axis ? sz / l : 0.0;
+    red[0][tid] = ok ? ux * wx + uy * wy + uz * wz : 1.0;
+    __syncthreads();
+    for (int h = kHprThreads / 2; h > 0; h >>= 1) {
+        if (tid < h) red[0][tid] = red[0][tid] < red[0][tid + h] ? red[0][tid] : red[0][tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        HprTile t;
+        double c = red[0][0] - 1e-12;          // widen the cone past roundoff
+        if (!axis) c = -1.0;                   // no usable axis: never skipped
+        t.wx = wx; t.wy = wy; t.wz = wz;
+        t.cos_phi = c;
+        t.cos2_phi = c * c;
+        t.sin2_phi = 1.0 - c * c + 1e-15;
+        t.sin_phi = sqrt(t.sin2_phi) * (1.0 + 1e-15);
+        t.inv_rho_max = rho_max > 0.0 ? 1.0 / (rho_max * (1.0 + 1e-12)) : 0.0;
+        tiles[(size_t)view * gridDim.x + tile] = t;
+    }
+}
+
+// Sutherland-Hodgman against a A + b B <= C: src (nv vertices, element k at src[k * ss]) -> dst (stride ds);
+// returns the new count.  A vertex exactly on the line is kept and spawns no intersection point.
+__device__ __forceinline__ int hpr_clip(const double2 *src, int ss, int nv, double A, double B, double C, double2 *dst, int ds)
+{
+    int m = 0;
+    double2 cur = src[0];
+    double s0 = cur.x * A + cur.y * B - C;
+    for (int k = 0; k < nv; k++) {
+        const int k2 = k + 1 < nv ? k + 1 : 0;
+        const double2 nxt = src[(size_t)k2 * ss];
+        const double s1 = nxt.x * A + nxt.y * B - C;
+        if (!(s0 > 0.0)) dst[(size_t)(m++) * ds] = cur;
+        if ((s0 > 0.0) != (s1 > 0.0) && s0 != 0.0 && s1 != 0.0) {
+            const double t = s0 / (s0 - s1);
+            double2 x;
+            x.x = cur.x + t * (nxt.x - cur.x);
+            x.y = cur.y + t * (nxt.y - cur.y);
+            dst[(size_t)(m++) * ds] = x;
+        }
+        cur = nxt;
+        s0 = s1;
+    }
+    return m;
+}
+
+// The same clip IN PLACE (no scratch): the outside vertices of a convex polygon are one cyclic run [f, f+L);
+// it is replaced by the two edge crossings.  Each crossing is computed exactly as hpr_clip does (from the
+// edge's first vertex, in the polygon's orientation), so the new polygon is hpr_clip's up to a rotation of the
+// array -- which changes nothing downstream.  `out` = number of outside vertices (0 < out < nv), f = the first
+// of them (the one whose predecessor is inside).
+__device__ __forceinline__ int hpr_clip_inplace(double2 *p, int ss, int nv, int out, int f, double A, double B, double C)
+{
+    const int ia = f ? f - 1 : nv - 1, ib = f;
+    int ic = f + out - 1, id = f + out;
+    ic -= ic >= nv ? nv : 0;
+    id -= id >= nv ? nv : 0;
+    const double2 va = p[(size_t)ia * ss], vb = p[(size_t)ib * ss], vc = p[(size_t)ic * ss], vd = p[(size_t)id * ss];
+    const double sa = va.x * A + va.y * B - C, sb = vb.x * A + vb.y * B - C;
+    const double sc = vc.x * A + vc.y * B - C, sd = vd.x * A + vd.y * B - C;
+    double2 x1, x2;
+    const bool h1 = sa != 0.0, h2 = sd != 0.0;          // (sb > 0 and sc > 0 always)
+    {
+        const double t = sa / (sa - sb);
+        x1.x = va.x + t * (vb.x - va.x);
+        x1.y = va.y + t * (vb.y - va.y);
+    }
+    {
+        const double t = sc / (sc - sd);
+        x2.x = vc.x + t * (vd.x - vc.x);
+        x2.y = vc.y + t * (vd.y - vc.y);
+    }
+    const int e = (h1 ? 1 : 0) + (h2 ? 1 : 0);
+    const double2 y0 = h1 ? x1 : x2;          // the crossings in order: y0 [, x2]
+    const int m = nv - out + e;
+    if (f + out <= nv) {
+        // no wrap: [0, f) stays, the crossings, then the tail [f + out, nv) moved to f + e
+        const int from = f + out, to = f + e, cnt = nv - from;
+        if (to < from) {
+            for (int k = 0; k < cnt; k++) p[(size_t)(to + k) * ss] = p[(size_t)(from + k) * ss];
+        } else if (to > from) {
+            for (int k = cnt - 1; k >= 0; k--) p[(size_t)(to + k) * ss] = p[(size_t)(from + k) * ss];
+        }
+        if (e > 0) p[(size_t)f * ss] = y0;
+        if (e > 1) p[(size_t)(f + 1) * ss] = x2;
+    } else {
+        // the run wraps: the inside vertices [id, f) move to the front, the crossings follow
+        const int cnt = f - id;
+        if (id > 0)
+            for (int k = 0; k < cnt; k++) p[(size_t)k * ss] = p[(size_t)(id + k) * ss];
+        if (e > 0) p[(size_t)cnt * ss] = y0;
+        if (e > 1) p[(size_t)(cnt + 1) * ss] = x2;
+    }
+    return m;
+}
+
+// What a polygon can reach: its largest squared vertex norm D^2 and its support max_v (v . d) in the eight
+// directions d = (+-1, 0), (0, +-1), (+-1, +-1).  UPPER bounds suffice (they only feed conservative rejections),
+// and a clip only shrinks the polygon, so these are refreshed now and then, not after every clip.
+struct HprReach {
+    double d2, xp, xn, yp, yn, pp, pn, np, nn;
+};
+
+__device__ __forceinline__ HprReach hpr_reach(const double2 *p, int ss, int nv)
+{
+    HprReach r;
+    double d2 = 0.0, xp = -__builtin_inf(), xn = xp, yp = xp, yn = xp, pp = xp, pn = xp, np = xp, nn = xp;
+    for (int k = 0; k < nv; k++) {
+        const double2 v = p[(size_t)k * ss];
+        const double r2 = v.x * v.x + v.y * v.y, s = v.x + v.y, t = v.x - v.y;
+        d2 = r2 > d2 ? r2 : d2;
+        xp = v.x > xp ? v.x : xp;   xn = -v.x > xn ? -v.x : xn;
+        yp = v.y > yp ? v.y : yp;   yn = -v.y > yn ? -v.y : yn;
+        pp = s > pp ? s : pp;       nn = -s > nn ? -s : nn;
+        pn = t > pn ? t : pn;       np = -t > np ? -t : np;
+    }
+    r.d2 = d2;
+    r.xp = xp; r.xn = xn; r.yp = yp; r.yn = yn; r.pp = pp; r.pn = pn; r.np = np; r.nn = nn;
+    return r;
+}
+
+// True when the candidate's line a A + b B = C provably misses the polygon (then every vertex has
+// a A + b B - C < 0 in floating point as well: the margins are 1e-9, the roundoff 1e-15).  Two bounds on
+// max_v (a A + b B): Cauchy-Schwarz with the largest vertex norm, and -- for polygons that run out to the
+// box in some directions (points on the silhouette) -- (A, B) split into its two neighbouring support
+// directions: with a = |A| >= b = |B|, (A, B) = (a - b)(sx, 0) + b (sx, sy), so v.(A, B) <= (a-b) h(sx,0) + b h(sx,sy).
+__device__ __forceinline__ bool hpr_far(const HprReach r, double A, double B, double C)
+{
+    if (C > 0.0 && r.d2 * (A * A + B * B) * 1.000000001 < C * C) return true;
+    const double a = fabs(A), b = fabs(B);
+    const double hx = A >= 0.0 ? r.xp : r.xn, hy = B >= 0.0 ? r.yp : r.yn;
+    const double hd = A >= 0.0 ? (B >= 0.0 ? r.pp : r.pn) : (B >= 0.0 ? r.np : r.nn);
+    const double t1 = a >= b ? (a - b) * hx : (b - a) * hy;
+    const double t2 = (a >= b ? b : a) * hd;
+    return t1 + t2 + 1e-9 * (fabs(t1) + fabs(t2) + fabs(C)) < C;
+}
+
+// Can any candidate of tile T cut the polygon?  Every candidate q = rho_q u_q of the tile has u_q within phi of
+// the axis w and rho_q <= rho_max, so for a normal n:  n.q <= rho_max |n| cos(max(0, angle(n, w) - phi)).
+// First for all n = u + d with |d| <= D at once (|n| <= L, angle(n, u) <= psi), then vertex by vertex.  The
+// tile is skipped when the bound stays below |p'_i| (margins 1e-9 >> roundoff; squares instead of sqrt).
+__device__ __forceinline__ bool hpr_tile_needed(const HprFrame &f, double cpsi, double spsi, const double2 *p, int ss, int nv,
+                                                const HprTile &T)
+{
+    if (!(T.cos_phi > 0.0)) return true;
+    const double uw = f.ux * T.wx + f.uy * T.wy + f.uz * T.wz;
+    const double rr = f.rho * (1.0 - 1e-9) * T.inv_rho_max;
+    {
+        const double cc = T.cos_phi * cpsi - T.sin_phi * spsi;       // cos(phi + psi), psi = atan D
+        const double sc = T.sin_phi * cpsi + T.cos_phi * spsi;       // sin(phi + psi)
+        if (cc > 0.0 && uw < cc * (1.0 - 1e-9)) {                        // angle(u, w) > phi + psi
+            const double rhs = rr * cpsi - 1e-9 - cc * uw;                 // cpsi = 1 / L, L = sqrt(1 + D^2) >= |n|
+            const double s2 = sc * sc * ((1.0 - uw * uw) * (1.0 + 1e-9) + 1e-12);
+            if (rhs > 0.0 && s2 < rhs * rhs) return false;
+        }
+    }
+    const double e1w = f.e1x * T.wx + f.e1y * T.wy + f.e1z * T.wz;
+    const double e2w = f.e2x * T.wx + f.e2y * T.wy + f.e2z * T.wz;
+    for (int k = 0; k < nv; k++) {
+        const double2 v = p[(size_t)k * ss];
+        const double nn = 1.0 + v.x * v.x + v.y * v.y;
+        const double dw = uw + v.x * e1w + v.y * e2w;
+        if (dw > 0.0 && dw * dw >= T.cos2_phi * nn * (1.0 - 1e-9)) {
+            if (!(nn < rr * rr)) return true;                            // n inside the cone: bound rho_max |n|
+        } else {
+            const double rhs = rr - 1e-9 * nn - T.cos_phi * dw;
+            const double s2 = T.sin2_phi * ((nn - dw * dw) * (1.0 + 1e-9) + 1e-12 * nn);
+            if (!(rhs > 0.0 && s2 < rhs * rhs)) return true;
+        }
+    }
+    return false;
+}
+
+// tiles outward from the own one: step 0 = own, 1 = own + 1, 2 = own - 1, 3 = own + 2, ...
+__device__ __forceinline__ int hpr_tile_of(int step, int own) { return (step & 1) ? own + (step + 1) / 2 : own - step / 2; }
+
+constexpr int kHprBatch = 64;      // tiles tested per round (one bit each)
+constexpr int kHprRimStep = 8;     // after this many tiles ...
+constexpr double kHprRimD2 = 1.0e6; // ... a polygon with a vertex farther than 1000 from the origin is a silhouette point's
+constexpr int kHprRimTiles = 256;  // ... and is handed to the second pass if the cloud has at least this many tiles
+
+// status[0] = points handed to the second pass, status[1] = error (2: a polygon outgrew kHprOverCap)
+__global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *__restrict__ fl_all, const int *__restrict__ perm,
+                                                         const HprTile *__restrict__ tiles_all, unsigned char *__restrict__ vis,
+                                                         int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull)
+{
+    __shared__ double2 s_poly[kHprMaxV * kHprThreads];
+    __shared__ double4 s_stage[kHprThreads];      // 64 tile records while testing, then one tile's candidates
+    __shared__ unsigned long long s_mask;
+    static_assert(sizeof(HprTile) * kHprBatch <= sizeof(double4) * kHprThreads, "the tile records share the staging area");
+    const int view = blockIdx.y, tid = threadIdx.x;
+    const double *fl = fl_all + (size_t)view * n * 3;
+    const int pos = blockIdx.x * kHprThreads + tid;
+    const int i = pos < n ? perm[pos] : -1;
+    const int ntiles = ceil_div_dev(n, kHprThreads), own = blockIdx.x;
+    const HprTile *tiles = tiles_all + (size_t)view * ntiles;
+    HprFrame f;
+    bool active = false;
+    int nv = 0;            // > 0 visible so far, 0 hidden, -1 handed to the second pass
+    if (i >= 0) active = hpr_frame(fl + (size_t)pos * 3, f);
+    double2 *poly = s_poly + tid;
+    HprReach R = {};
+    if (active) {
+        nv = 4;
+        poly[0 * kHprThreads] = make_double2(-kHprBox, -kHprBox);
+        poly[1 * kHprThreads] = make_double2(kHprBox, -kHprBox);
+        poly[2 * kHprThreads] = make_double2(kHprBox, kHprBox);
+        poly[3 * kHprThreads] = make_double2(-kHprBox, kHprBox);
+        R = hpr_reach(poly, kHprThreads, nv);
+    }
+    constexpr int kU = 4;      // candidates examined together (their loads and dot products overlap)
+    HprTile *s_rec = (HprTile *)s_stage;
+    // batches of 1, 1, 2, 4, ... 64 tiles: the polygon is the whole box at first (every tile "needed") and
+    // tight after the own tile and its neighbours, so the early batches are short
+    for (int step0 = 0, bsz = 1; step0 < 2 * ntiles; step0 += bsz, bsz = step0 < kHprBatch ? step0 : kHprBatch) {
+        // A polygon that still runs out to the box after the eight nearest tiles belongs to a point on the
+        // silhouette: it is cut by points all along the rim and holds its whole wave up for as many tiles as
+        // the cloud has -- in a large cloud such points go to the second pass, which puts a wave on each
+        // (measured: 2 x 165546 points 77 -> 51 ms; 64 x 10000 points 29 -> 32 ms, hence the size rule).
+        if (step0 == kHprRimStep && ntiles >= kHprRimTiles && active && R.d2 > kHprRimD2 && !(no_cull & 8)) {
+            over_list[atomicAdd(&status[0], 1)] = view * n + pos;
+            nv = -1;
+            active = false;
+        }
+        if (__syncthreads_count(active) == 0) break;
+        // which of the next tiles can still cut somebody's polygon (tested against the polygon as it is now:
+        // it only shrinks, so a tile found out of reach stays out of reach)
+        if (tid < bsz) {
+            const int tile = hpr_tile_of(step0 + tid, own);
+            if (tile >= 0 && tile < ntiles) s_rec[tid] = tiles[tile];
+        }
+        if (tid == 0) s_mask = 0ull;
+        __syncthreads();
+        unsigned long long mine = 0ull;
+        if (active) {
+            R = hpr_reach(poly, kHprThreads, nv);
+            const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15), cpsi = 1.0 / l, spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
+            for (int b = 0; b < bsz; b++) {
+                const int tile = hpr_tile_of(step0 + b, own);
+                if (tile < 0 || tile >= ntiles) continue;
+                if ((no_cull & 1) || hpr_tile_needed(f, cpsi, spsi, poly, kHprThreads, nv, s_rec[b])) mine |= 1ull << b;
+            }
+        }
+        {
+            unsigned long long w = mine;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) w |= (unsigned long long)__shfl_xor((long long)w, o, kWave);
+            if ((tid & (kWave - 1)) == 0 && w) atomicOr(&s_mask, w);
+        }
+        __syncthreads();
+        unsigned long long todo = s_mask;
+        while (todo) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int tile0 = hpr_tile_of(step0 + b, own) * kHprThreads;
+            const int tn = min(kHprThreads, n - tile0);
+            {
+                // rows past the end are NaN: they cut nothing
+                double4 q = make_double4(__builtin_nan(""), 0.0, 0.0, 0.0);
+                if (tid < tn) {
+                    const double *g = fl + (size_t)(tile0 + tid) * 3;
+                    q = make_double4(g[0], g[1], g[2], 0.0);
+                }
+                s_stage[tid] = q;
+            }
+            __syncthreads();
+            if (active && ((mine >> b) & 1ull)) {
+                bool stale = false;
+                for (int t = 0; t < tn && active; t += kU) {
+                    if ((t & 31) == 0 && stale) {          // a few times per tile, not per clip
+                        R = hpr_reach(poly, kHprThreads, nv);
+                        stale = false;
+                    }
+                    unsigned pass = 0;
+#pragma unroll
+                    for (int u = 0; u < kU; u++) {
+                        const double4 q = s_stage[t + u];      // t + u < kHprThreads: padded with NaN rows
+                        const double A = f.e1x * q.x + f.e1y * q.y + f.e1z * q.z;
+                        const double B = f.e2x * q.x + f.e2y * q.y + f.e2z * q.z;
+                        const double C = f.rho - (f.ux * q.x + f.uy * q.y + f.uz * q.z);
+                        const bool self = q.x == f.px && q.y == f.py && q.z == f.pz;      // the point itself, or an exact duplicate
+                        pass |= (!self && q.x == q.x && !hpr_far(R, A, B, C)) ? (1u << u) : 0u;
+                    }
+                    while (pass && active) {
+                        const int u = __ffs((int)pass) - 1;
+                        pass &= pass - 1;
+                        const double4 q = s_stage[t + u];      // (recomputed: the same values)
+                        const double A = f.e1x * q.x + f.e1y * q.y + f.e1z * q.z;
+                        const double B = f.e2x * q.x + f.e2y * q.y + f.e2z * q.z;
+                        const double C = f.rho - (f.ux * q.x + f.uy * q.y + f.uz * q.z);
+                        // outside vertices: how many, and where their (cyclic) run starts
+                        int out = 0, first = 0;
+                        bool prev_out;
+                        {
+                            const double2 v = poly[(nv - 1) * kHprThreads];
+                            prev_out = v.x * A + v.y * B - C > 0.0;
+                        }
+                        for (int k = 0; k < nv; k++) {
+                            const double2 v = poly[k * kHprThreads];
+                            const bool o = v.x * A + v.y * B - C > 0.0;
+                            out += o ? 1 : 0;
+                            first = (o && !prev_out) ? k : first;
+                            prev_out = o;
+                        }
+                        if (!out) continue;
+                        if (out == nv) { nv = 0; active = false; break; }
+                        if (nv - out + 2 > kHprMaxV) {
+                            over_list[atomicAdd(&status[0], 1)] = view * n + pos;
+                            nv = -1;
+                            active = false;
+                            break;
+                        }
+                        const int m = hpr_clip_inplace(poly, kHprThreads, nv, out, first, A, B, C);
+                        if (m < 3) { nv = 0; active = false; break; }      // no interior left: not strictly extreme
+                        nv = m;
+                        stale = true;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const bool seen = i >= 0 && nv > 0;
+    if (i >= 0 && nv >= 0) vis[(size_t)view * n + i] = seen ? 1 : 0;
+    const int c = __syncthreads_count(seen);
+    if (tid == 0 && c) atomicAdd(&cnt[view], c);
+}
+
+// second pass: one WAVE per listed point, polygon in LDS (two buffers of kHprOverCap vertices).  Lane b tests
+// tile b of a batch of 64; in a tile that can reach the polygon the 64 lanes test 64 candidates at once, and
+// the few that are not provably out of reach are taken one by one, in order, the vertex test spread over the
+// lanes and the clip itself done by lane 0.  Same candidates, same order, same arithmetic as the first pass
+// (and the oracle).
+__global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double *__restrict__ fl_all,
+                                                             const HprTile *__restrict__ tiles_all, unsigned char *__restrict__ vis,
+                                                             int *__restrict__ cnt, int *status, const int *__restrict__ list,
+                                                             const int *__restrict__ perm, int no_cull)
+{
+    __shared__ double2 s_buf[2][kHprOverCap];
+    const int lane = threadIdx.x;
+    const int id = list[blockIdx.x], view = id / n, pos = id - view * n, i = perm[pos];
+    const double *fl = fl_all + (size_t)view * n * 3;
+    const int ntiles = ceil_div_dev(n, kHprThreads), own = pos / kHprThreads;
+    const HprTile *tiles = tiles_all + (size_t)view * ntiles;
+    HprFrame f;
+    if (!hpr_frame(fl + (size_t)pos * 3, f)) return;      // (cannot happen: the first pass listed it)
+    int cur = 0, nv = 4;
+    if (lane == 0) {
+        s_buf[0][0] = make_double2(-kHprBox, -kHprBox);
+        s_buf[0][1] = make_double2(kHprBox, -kHprBox);
+        s_buf[0][2] = make_double2(kHprBox, kHprBox);
+        s_buf[0][3] = make_double2(-kHprBox, kHprBox);
+    }
+    __syncthreads();
+    HprReach R = hpr_reach(s_buf[0], 1, nv);
+    for (int step0 = 0, bsz = 1; step0 < 2 * ntiles && nv > 0; step0 += bsz, bsz = step0 < kWave ? step0 : kWave) {
+        bool need = false;
+        if (lane < bsz) {
+            const int tile = hpr_tile_of(step0 + lane, own);
+            const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15), cpsi = 1.0 / l, spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
+            if (tile >= 0 && tile < ntiles) need = (no_cull & 1) || hpr_tile_needed(f, cpsi, spsi, s_buf[cur], 1, nv, tiles[tile]);
+        }
+        unsigned long long todo = __ballot(need);
+        while (todo && nv > 0) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int tile0 = hpr_tile_of(step0 + b, own) * kHprThreads;
+            for (int base = tile0; base < tile0 + kHprThreads && base < n && nv > 0; base += kWave) {
+                const int j = base + lane;
+                double A = 0.0, B = 0.0, C = 0.0;
+                bool pass = false;
+                if (j < n) {
+                    const double qx = fl[(size_t)j * 3 + 0], qy = fl[(size_t)j * 3 + 1], qz = fl[(size_t)j * 3 + 2];
+                    A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
+                    B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
+                    C = f.rho - (f.ux * qx + f.uy * qy + f.uz * qz);
+                    const bool self = qx == f.px && qy == f.py && qz == f.pz;
+                    pass = !self && qx == qx && !hpr_far(R, A, B, C);
+                }
+                unsigned long long mask = __ballot(pass);
+                while (mask && nv > 0) {
+                    const int from = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const double Aj = __shfl(A, from, kWave), Bj = __shfl(B, from, kWave), Cj = __shfl(C, from, kWave);
+                    const double2 *src = s_buf[cur];
+                    int out = 0;
+                    for (int k = lane; k < nv; k += kWave) out += (src[k].x * Aj + src[k].y * Bj - Cj > 0.0) ? 1 : 0;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) out += __shfl_xor(out, o, kWave);
+                    if (!out) continue;
+                    if (out == nv) { nv = 0; break; }
+                    if (nv - out + 2 > kHprOverCap) {
+                        if (lane == 0) atomicExch(&status[1], 2);
+                        return;
+                    }
+                    int m = 0;
+                    if (lane == 0) m = hpr_clip(src, 1, nv, Aj, Bj, Cj, s_buf[cur ^ 1], 1);
+                    __syncthreads();
+                    m = __shfl(m, 0, kWave);
+                    if (m < 3) { nv = 0; break; }
+                    nv = m;
+                    cur ^= 1;
+                    R = hpr_reach(s_buf[cur], 1, nv);      // (every lane the same loop: broadcast reads)
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        vis[(size_t)view * n + i] = nv > 0 ? 1 : 0;
+        if (nv > 0) atomicAdd(&cnt[view], 1);
+    }
+}
+
+}  // namespace genpc
+
+using namespace genpc;
+
+GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const double *eyes, double radius, unsigned char *visible,
+                                   int *counts, int *second_pass_points, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (c < 0 || n < 0 || !(radius > 0.0)) {
+        set_error("genpc_hpr_visibility: bad size or radius");
+        return -1;
+    }
+    if (second_pass_points) *second_pass_points = 0;
+    if (c == 0) return 1;
+    if (!counts || (n > 0 && (!points || !eyes || !visible))) {
+        set_error("genpc_hpr_visibility: null pointer");
+        return -1;
+    }
+    if ((long long)c * n > (long long)INT_MAX || c > 65535) {
+        set_error("genpc_hpr_visibility: views x points too large");
+        return -1;
+    }
+    if (!check(hipMemsetAsync(counts, 0, sizeof(int) * (size_t)c, stream), "hipMemsetAsync(hpr counts)")) return 0;
+    if (n == 0) return 1;
+    const size_t total = (size_t)c * n;
+    size_t sort_bytes = 0;
+    if (!check(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
+                                                  (const int *)nullptr, (int *)nullptr, n, 0, 32, stream),
+               "hpr sort size"))
+        return 0;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 256;
+    const size_t o_fl = off; off += up(total * 3 * sizeof(double));
+    const size_t o_list = off; off += up(total * sizeof(int));
+    const size_t o_k0 = off; off += up((size_t)n * 4);
+    const size_t o_k1 = off; off += up((size_t)n * 4);
+    const size_t o_i0 = off; off += up((size_t)n * 4);
+    const size_t o_i1 = off; off += up((size_t)n * 4);
+    const size_t o_tmp = off; off += up(sort_bytes);
+    const int ntiles = ceil_div(n, kHprThreads);
+    const size_t o_tiles = off; off += up((size_t)c * ntiles * sizeof(HprTile));
+    char *ws = (char *)workspace(17, off, stream);
+    if (!ws) return 0;
+    int *status = (int *)ws;
+    unsigned *bounds = (unsigned *)(ws + 64);
+    double *fl = (double *)(ws + o_fl);
+    int *list = (int *)(ws + o_list);
+    unsigned *k0 = (unsigned *)(ws + o_k0), *k1 = (unsigned *)(ws + o_k1);
+    int *i0 = (int *)(ws + o_i0), *i1 = (int *)(ws + o_i1);
+    if (!check(hipMemsetAsync(status, 0, 256, stream), "hipMemsetAsync(hpr status)")) return 0;
+    if (!check(hipMemsetAsync(bounds, 0xff, 12, stream), "hipMemsetAsync(hpr bounds)")) return 0;
+    const int g256 = ceil_div(n, 256);
+    hipLaunchKernelGGL(hpr_bounds_kernel, dim3(g256 < 1024 ? g256 : 1024), dim3(256), 0, stream, n, points, bounds);
+    hipLaunchKernelGGL(hpr_key_kernel, dim3(g256), dim3(256), 0, stream, n, points, (const unsigned *)bounds, k0, i0);
+    if (!check(hipcub::DeviceRadixSort::SortPairs(ws + o_tmp, sort_bytes, (const unsigned *)k0, k1, (const int *)i0, i1, n, 0, 32, stream),
+               "hpr radix sort"))
+        return 0;
+    HprTile *tiles = (HprTile *)(ws + o_tiles);
+    static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // test knob: every tile examined
+    hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl);
+    hipLaunchKernelGGL(hpr_tile_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, tiles);
+    hipLaunchKernelGGL(hpr_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
+                       (const HprTile *)tiles, visible, counts, status, list, no_cull);
+    if (!check(hipGetLastError(), "hpr launch")) return 0;
+    // the second pass is sized from the first one's count: the one host round trip of this entry
+    int st[2] = {0, 0};
+    if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
+    if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
+    if (second_pass_points) *second_pass_points = st[0];
+    if (st[0] > 0) {
+        hipLaunchKernelGGL(hpr_overflow_kernel, dim3(st[0]), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
+                           visible, counts, status, (const int *)list, (const int *)i1, no_cull);
+        if (!check(hipGetLastError(), "hpr second pass launch")) return 0;
+        if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
+        if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
+        if (st[1]) {
+            set_error("genpc_hpr_visibility: a normal-cone polygon outgrew 1024 vertices");
+            return 0;
+        }
+    }
+    return 1;
+}

@@ -335,16 +335,16 @@ static void launch_main(const NNArgs &a, int blocks, int u, bool tight, hipStrea
     }
 }
 
-// fused finish: the 512-query blocks at two waves per SIMD (single-round launches)
-template <int NL>
+// fused finish: the 512-query blocks, two or three (tight) waves per SIMD
+template <int NL, int W>
 static void launch_fused(const NNArgs &a, int blocks, int u, hipStream_t st)
 {
     if (u == 2) {
-        if (a.fma) hipLaunchKernelGGL((nn_f16_kernel<4, 2, NL, 2, 1, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<4, 2, NL, 2, 1, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
+        if (a.fma) hipLaunchKernelGGL((nn_f16_kernel<4, 2, NL, W, 1, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((nn_f16_kernel<4, 2, NL, W, 1, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
     } else {
-        if (a.fma) hipLaunchKernelGGL((nn_f16_kernel<4, 4, NL, 2, 1, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<4, 4, NL, 2, 1, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
+        if (a.fma) hipLaunchKernelGGL((nn_f16_kernel<4, 4, NL, W, 1, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((nn_f16_kernel<4, 4, NL, W, 1, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
     }
 }
 
@@ -355,7 +355,7 @@ static hipEvent_t g_prof_e0 = nullptr, g_prof_e1 = nullptr;
 // Launches the filter and the finish kernel.  q / u / nl as chosen by the planner in chamfer.hip.
 int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, int fuse, long long total_blocks, hipStream_t st)
 {
-    fuse = fuse && q == 4 && !tight;      // instantiated for the 512-query blocks at two waves per SIMD
+    fuse = fuse && q == 4;      // instantiated for the 512-query blocks
     size_t bytes = 0;
     size_t off_t[2];
     for (int d = 0; d < a.ndir; d++) {
@@ -372,8 +372,8 @@ int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, int fuse, long lon
         (void)hipEventRecord(g_prof_e0, st);
     }
     if (fuse) {
-        if (nl == 2) launch_fused<2>(a, blocks, u, st);
-        else launch_fused<1>(a, blocks, u, st);
+        if (tight) { if (nl == 2) launch_fused<2, 3>(a, blocks, u, st); else launch_fused<1, 3>(a, blocks, u, st); }
+        else       { if (nl == 2) launch_fused<2, 2>(a, blocks, u, st); else launch_fused<1, 2>(a, blocks, u, st); }
     } else if (q == 4) {
         if (nl == 2) launch_main<4, 2>(a, blocks, u, tight != 0, st);
         else launch_main<4, 1>(a, blocks, u, tight != 0, st);

@@ -607,7 +607,8 @@ int launch_nn_grid(const NNArgs &na, hipStream_t st)
     }
     const int nmax = std::max(a.sort_cloud[0] ? a.n[0] : 0, a.n[1]);      // the grid follows the density of the sorted (target) clouds
     // about three points per cell of the denser cloud if it filled the box; surfaces fill ~ G^2 of G^3 cells
-    int target = nmax / 3;
+    static const int env_ppc = getenv("GENPC_GRID_PPC_X10") ? atoi(getenv("GENPC_GRID_PPC_X10")) : 30;      // points per cell x 10
+    int target = (int)((long long)nmax * 10 / (env_ppc > 0 ? env_ppc : 30));
     target = std::max(8, std::min(target, kGridMaxCells / 2));
     a.cells_target = target;
     a.cells_max = std::min(kGridMaxCells - 256, 2 * target + 512);      // coarse cells are padded to 4 x 4 x 4

@@ -30,7 +30,7 @@ from . import reg_xyz
 def default_cfg(device="cuda", view_num=1024):
     """configs/config.yaml values of the reference that the geometric stages read."""
     return SimpleNamespace(device=str(device), fovy=49.1, res=256, cam_res=256, padding=0.15, rescale=True, point_size=1,
-                           mask_pixel_rate=3, view_num=view_num, distance=1.6, downsample_num=10000,
+                           mask_pixel_rate=3, view_num=view_num, distance=1.6, downsample_num=10000, removal_radius=10000,
                            generative_model="trellis", dataset="redwood")
 
 
@@ -53,15 +53,10 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
     sa = ScaleAdapter(cfg)
     out = {}
     # ---- stage 1: DepthPrompting.getImage (:100-170) ----
-    view = dp.viewpoint_select(partial_xyz)
-    cam = dp.cameras[view:view + 1]
-    uv, depth, _ = dp.getUvs(cam, partial_xyz, rescale=cfg.rescale, padding=cfg.padding, want_transformed=False)
-    pix = dp.uvToPixels(uv[0], cfg.res)
-    colors = torch.ones(partial_xyz.shape[0], 3, device=partial_xyz.device)
-    sparse_img, sparse_depth, hole1, hole2 = dp.getRawDepth(pix, depth[0], colors=colors, res=cfg.res,
-                                                            point_size=cfg.point_size, mask_pixel_rate=cfg.mask_pixel_rate)
-    out.update(view=view, uv=uv[0], depth=depth[0], pixels=pix, sparse_img=sparse_img, sparse_depth=sparse_depth,
-               hole_mask1=hole1, hole_mask2=hole2)
+    g = dp.getDepth(partial_xyz)
+    view, uv, depth = g["view_index"], g["uv"][None], g["depth"][None]
+    out.update(view=view, used_opposite=g["used_opposite"], visible=g["visible"], uv=g["uv"], depth=g["depth"], pixels=g["pixels"],
+               sparse_img=g["sparse_img"], sparse_depth=g["raw_depth"], hole_mask1=g["hole_mask1"], hole_mask2=g["hole_mask2"])
     # ---- stage 2: ScaleAdapter.scaleAdapter (:15-86) ----
     out["point_colors"] = sa.colorPoint(uv[0], generated_img)
     res = reg_xyz.reg(partial_xyz, generated_xyz, generative_model=cfg.generative_model, dataset=cfg.dataset,

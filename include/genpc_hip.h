@@ -154,9 +154,24 @@ int genpc_paint_pixels(int res, int n, const int *pix, const float *colors, int 
 int genpc_gather_colors(int n, const int *pix, const float *img, int ch, int h,
                         int w, float *out, void *stream);
 
-/* Visibility (viewpoint selection, DepthPrompting.py:87-98,273-290).  NOT the
- * reference's operator: open3d's hidden_point_removal (Katz: spherical flipping +
- * convex hull) is replaced by a z-buffer test -- a point is visible from camera c
+/* Replaces DepthPrompting.getVisiblePoints (DepthPrompting.py:273-290): open3d's
+ * PointCloud.hidden_point_removal(camera, radius) for every viewpoint -- Katz' operator:
+ * spherical flipping p' = v + 2 (radius - |v|) v / |v|, v = p - eye, then the vertices of
+ * the convex hull of the flipped points and the origin.  Computed exactly, without a hull:
+ * a flipped point is a vertex iff the polygon of normals (tilts of its own direction) that
+ * keep every other flipped point below it is not empty (genpc_amd/csrc/hpr.hip; double
+ * arithmetic, the candidates in input order).  points[N,3] float, eyes[C,3] DOUBLE (both
+ * device), radius > 0; visible[C,N] bytes, counts[C].  second_pass_points (HOST int, may
+ * be NULL): how many points needed the large-polygon pass (lattice-like inputs).
+ * Synchronises the stream once (the second pass is sized from the first).  0 if a polygon
+ * outgrows 1024 vertices.  Differences from qhull: normals tilted more than atan(1e4) from
+ * the point's direction are not considered; exact duplicates are all reported.          */
+int genpc_hpr_visibility(int c, int n, const float *points, const double *eyes,
+                         double radius, unsigned char *visible, int *counts,
+                         int *second_pass_points, void *stream);
+
+/* A cheaper visibility for viewpoint ranking.  NOT the reference's operator (that is
+ * genpc_hpr_visibility above): a z-buffer test -- a point is visible from camera c
  * when no point whose (2*point_size-1)^2 pixel stamp covers its pixel of a res x res
  * image is nearer by more than tol (NDC depth).  uv[C,N,2] / depth[C,N] as produced
  * by genpc_get_uvs; visible[C,N] bytes, counts[C] = visible points per camera.   */

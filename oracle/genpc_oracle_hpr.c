@@ -1,0 +1,188 @@
+/*
+ * genpc_oracle_hpr.c -- CPU restatement of the EXACT hidden-point-removal operator in the form the
+ * gfx950 library computes it (genpc_amd/csrc/hpr.hip).  TEST INFRASTRUCTURE ONLY, same rules as
+ * genpc_oracle.c.
+ *
+ * The reference calls open3d's PointCloud.hidden_point_removal(camera, radius) (DepthPrompting.py:273-290):
+ * Katz' operator -- spherical flipping p' = v + 2 (radius - |v|) v / |v|, v = p - camera, then the convex
+ * hull of the flipped points and the origin (qhull); visible = hull vertices.  oracle/hpr.py restates that
+ * with qhull itself (scipy).  This file restates the same SET without a hull:
+ *
+ *   p'_i is a vertex of conv({p'_j} U {0})  <=>  some plane through p'_i has every other p'_j and the origin
+ *   strictly on one side  <=>  there is a normal n with n.p'_i > 0 and n.p'_j < n.p'_i for all j.
+ *   n.p'_i > 0 lets n be scaled to n = u_i + a e1 + b e2 with u_i = p'_i/|p'_i| and (e1, e2) an orthonormal
+ *   basis of the plane normal to u_i; then n.p'_i = |p'_i| and every other point is ONE LINEAR constraint on
+ *   (a, b):   a (e1.p'_j) + b (e2.p'_j) <= |p'_i| - u_i.p'_j .
+ *   The feasible (a, b) form a convex polygon (the cross-section of p'_i's normal cone; for a large radius
+ *   it is the power cell of point i among the directions of the cloud, weighted by depth): the point is
+ *   visible iff the polygon is not empty after clipping by every other point.
+ *
+ * The polygon starts as the square |a|, |b| <= HPR_BOX (normals tilted from u_i by more than atan(HPR_BOX) =
+ * 89.994 degrees are not considered: the one deviation from the hull definition, besides roundoff -- qhull
+ * merges facets within its own tolerance).  Exact duplicates clip nothing (both copies are reported).
+ * The points are put in 3-D Morton order of the cloud's bounding box (30-bit keys, ties by index) and cut into
+ * tiles of HPR_TILE; a point takes the candidates tile by tile outward from its own tile (own, +1, -1, +2, ...)
+ * -- the order the GPU streams them in.  The order has no influence beyond the last bits of the polygon vertices.
+ * Everything is double, operation order spelled out, -ffp-contract=off.
+ * Pinned against oracle/hpr.py (qhull) in tests/test_oracle_numpy.py.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+#define HPR_BOX 1.0e4
+#define HPR_MAXV 4096
+#define HPR_TILE 128
+
+typedef struct { uint32_t key; int idx; } mkey_t;
+
+static int cmp_mkey(const void *a, const void *b)
+{
+    const mkey_t *x = (const mkey_t *)a, *y = (const mkey_t *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+static uint32_t spread10(uint32_t v)
+{
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+/* perm[pos] = index of the pos-th point in Morton order (hpr.hip: hpr_bounds_kernel, hpr_key_kernel, stable sort) */
+static void morton_order(int n, const float *pts, int *perm)
+{
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            const float v = pts[3 * i + k];
+            if (!(fabsf(v) < INFINITY)) continue;
+            if (v < lo[k]) lo[k] = v;
+            if (v > hi[k]) hi[k] = v;
+        }
+    mkey_t *keys = (mkey_t *)malloc(sizeof(mkey_t) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        uint32_t key = 0;
+        int ok = 1;
+        for (int k = 0; k < 3; k++) {
+            const float v = pts[3 * i + k];
+            if (!(fabsf(v) < INFINITY)) { ok = 0; continue; }
+            const float w = hi[k] - lo[k];
+            float q = w > 0.0f ? (v - lo[k]) / w * 1023.0f : 0.0f;
+            q = q < 0.0f ? 0.0f : (q > 1023.0f ? 1023.0f : q);
+            key |= spread10((uint32_t)q) << k;
+        }
+        keys[i].key = ok ? key : 0xffffffffu;
+        keys[i].idx = i;
+    }
+    qsort(keys, (size_t)n, sizeof(mkey_t), cmp_mkey);
+    for (int i = 0; i < n; i++) perm[i] = keys[i].idx;
+    free(keys);
+}
+
+/* p' of every point for one camera, in the order of perm (open3d: |v| = 0 -> 1e-4) */
+static void flip_points(int n, const float *pts_in, const int *perm, const double *eye, double radius, double *fl)
+{
+    for (int i = 0; i < n; i++) {
+        const float *pts = pts_in + 3 * (size_t)perm[i] - 3 * (size_t)i;      /* so that pts[3 i + k] is point perm[i] */
+        const double vx = (double)pts[3 * i + 0] - eye[0];
+        const double vy = (double)pts[3 * i + 1] - eye[1];
+        const double vz = (double)pts[3 * i + 2] - eye[2];
+        double r = sqrt(vx * vx + vy * vy + vz * vz);
+        if (r == 0.0) r = 0.0001;
+        const double k = 2.0 * (radius - r) / r;
+        fl[3 * i + 0] = vx + k * vx;
+        fl[3 * i + 1] = vy + k * vy;
+        fl[3 * i + 2] = vz + k * vz;
+    }
+}
+
+/* clip the polygon (a[], b[], *nv vertices, counter-clockwise or clockwise, convex) by A a + B b <= C */
+static void clip(double *a, double *b, int *nv, double A, double B, double C, double *ta, double *tb)
+{
+    const int n = *nv;
+    int m = 0;
+    for (int k = 0; k < n; k++) {
+        const int k2 = k + 1 < n ? k + 1 : 0;
+        const double s0 = a[k] * A + b[k] * B - C;
+        const double s1 = a[k2] * A + b[k2] * B - C;
+        if (!(s0 > 0.0)) { ta[m] = a[k]; tb[m] = b[k]; m++; }
+        if ((s0 > 0.0) != (s1 > 0.0) && s0 != 0.0 && s1 != 0.0) {
+            const double t = s0 / (s0 - s1);
+            ta[m] = a[k] + t * (a[k2] - a[k]);
+            tb[m] = b[k] + t * (b[k2] - b[k]);
+            m++;
+        }
+    }
+    memcpy(a, ta, sizeof(double) * (size_t)m);
+    memcpy(b, tb, sizeof(double) * (size_t)m);
+    *nv = m;
+}
+
+/* vis[i] = 1 if point i is visible from `eye`; returns the number visible, -1 on bad input, -2 if a
+ * polygon outgrew HPR_MAXV vertices.  max_vertices (optional): the largest polygon met on the way. */
+ORACLE_API int oracle_hpr_visibility(int n, const float *pts, const double *eye, double radius, uint8_t *vis,
+                                     int *max_vertices)
+{
+    if (n < 0 || !pts || !eye || !vis || !(radius > 0.0)) return -1;
+    double *fl = (double *)malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
+    int *perm = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    if (!fl || !perm) { free(fl); free(perm); return -1; }
+    morton_order(n, pts, perm);
+    flip_points(n, pts, perm, eye, radius, fl);
+    int total = 0, bad = 0, mv = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : total) reduction(| : bad) reduction(max : mv)
+    for (int i = 0; i < n; i++) {
+        double pa[HPR_MAXV + 2], pb[HPR_MAXV + 2], ta[HPR_MAXV + 2], tb[HPR_MAXV + 2];
+        const double px = fl[3 * i], py = fl[3 * i + 1], pz = fl[3 * i + 2];
+        const double rho = sqrt(px * px + py * py + pz * pz);
+        vis[perm[i]] = 0;
+        if (!(rho > 0.0) || !(rho < INFINITY)) continue;        /* coincides with the origin / not finite */
+        const double ux = px / rho, uy = py / rho, uz = pz / rho;
+        /* e1 = normalise(u x axis of u's smallest component), e2 = u x e1 */
+        const double ax = fabs(ux), ay = fabs(uy), az = fabs(uz);
+        double e1x, e1y, e1z;
+        if (ax <= ay && ax <= az) { e1x = 0.0; e1y = uz; e1z = -uy; }
+        else if (ay <= az)        { e1x = -uz; e1y = 0.0; e1z = ux; }
+        else                      { e1x = uy; e1y = -ux; e1z = 0.0; }
+        const double l = sqrt(e1x * e1x + e1y * e1y + e1z * e1z);
+        e1x /= l; e1y /= l; e1z /= l;
+        const double e2x = uy * e1z - uz * e1y, e2y = uz * e1x - ux * e1z, e2z = ux * e1y - uy * e1x;
+        int nv = 4;
+        pa[0] = -HPR_BOX; pb[0] = -HPR_BOX;
+        pa[1] = HPR_BOX;  pb[1] = -HPR_BOX;
+        pa[2] = HPR_BOX;  pb[2] = HPR_BOX;
+        pa[3] = -HPR_BOX; pb[3] = HPR_BOX;
+        const int ntiles = (n + HPR_TILE - 1) / HPR_TILE, own = i / HPR_TILE;
+        for (int jj = 0; jj < 2 * ntiles * HPR_TILE && nv > 0; jj++) {
+            const int step = jj / HPR_TILE;
+            const int tile = (step & 1) ? own + (step + 1) / 2 : own - step / 2;
+            const int j = tile * HPR_TILE + (jj - step * HPR_TILE);
+            if (tile < 0 || tile >= ntiles || j >= n) continue;
+            const double qx = fl[3 * j], qy = fl[3 * j + 1], qz = fl[3 * j + 2];
+            if (qx == px && qy == py && qz == pz) continue;        /* the point itself, or an exact duplicate */
+            const double A = e1x * qx + e1y * qy + e1z * qz;
+            const double B = e2x * qx + e2y * qy + e2z * qz;
+            const double C = rho - (ux * qx + uy * qy + uz * qz);
+            int any = 0;
+            for (int k = 0; k < nv; k++) any |= (pa[k] * A + pb[k] * B - C > 0.0);
+            if (!any) continue;
+            if (nv + 2 > HPR_MAXV) { bad = 1; nv = 0; break; }
+            clip(pa, pb, &nv, A, B, C, ta, tb);
+            if (nv < 3) nv = 0;            /* no interior left: not strictly extreme */
+            if (nv > mv) mv = nv;
+        }
+        if (nv > 0) { vis[perm[i]] = 1; total++; }
+    }
+    free(fl);
+    free(perm);
+    if (max_vertices) *max_vertices = mv;
+    return bad ? -2 : total;
+}

@@ -457,3 +457,19 @@ def voxel_down_sample(xyz, voxel_size):
     if k < 0:
         raise ValueError("voxel_down_sample: bad input")
     return out[:k].copy()
+
+
+def hpr_visibility(points, eye, radius, want_max_vertices=False):
+    """Exact Katz visibility by normal-cone clipping (genpc_oracle_hpr.c) -> bool [N]."""
+    p, pp = _f(points)
+    e = np.ascontiguousarray(eye, dtype=np.float64).reshape(3)
+    vis = np.zeros(p.shape[0], np.uint8)
+    mv = ctypes.c_int(0)
+    k = int(lib().oracle_hpr_visibility(p.shape[0], pp, e.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                        ctypes.c_double(radius), vis.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                        ctypes.byref(mv)))
+    if k < 0:
+        raise ValueError("hpr_visibility failed (%d)" % k)
+    if want_max_vertices:
+        return vis.astype(bool), int(mv.value)
+    return vis.astype(bool)

@@ -259,7 +259,7 @@ def test_pose_loop_batched_equals_singles(gp):
 
 
 def test_zbuffer_visibility_and_viewpoint_select(gp, oracle):
-    """f3 with the z-buffer definition: bit-exact vs the oracle's restatement of the
+    """f3, the cheaper z-buffer ranking (the exact operator is tested in test_gpu_hpr.py): bit-exact vs the oracle's restatement of the
     same definition; on a closed surface about half the points face any camera; the
     selected view of a hemisphere shell looks at its open side's opposite."""
     torch = gp["torch"]
@@ -269,7 +269,7 @@ def test_zbuffer_visibility_and_viewpoint_select(gp, oracle):
     sphere = (u * 0.4).astype(np.float32)
     dp = gp["dp"]
     uv, depth, _ = dp.getUvs(dp.cameras, torch.from_numpy(sphere).cuda(), want_transformed=False)
-    vis, cnt = dp.getVisiblePoints(None, uvs=uv, depths=depth, tol=2e-4, res=256, point_size=3)
+    vis, cnt = dp.getVisiblePointsZBuffer(None, uvs=uv, depths=depth, tol=2e-4, res=256, point_size=3)
     ovis, ocnt = oracle.zbuffer_visibility(uv.cpu().numpy(), depth.cpu().numpy(), 256, 2e-4, 3)
     np.testing.assert_array_equal(vis.cpu().numpy(), ovis)
     np.testing.assert_array_equal(cnt.cpu().numpy(), ocnt)
@@ -284,7 +284,7 @@ def test_zbuffer_visibility_and_viewpoint_select(gp, oracle):
     cap = torch.from_numpy(sphere[sphere[:, 1] > 0.15]).cuda()
     gp["cfg"].downsample_num = 3000
     gp["cfg"].cam_res = 128
-    best = dp.viewpoint_select(cap)
+    best = dp.viewpoint_select(cap, zbuffer=True)
     sub = cap[fps_sampling(cap, 3000).long()]
-    _, counts = dp.getVisiblePoints(sub, cams=dp.cameras, tol=1e-4)
+    _, counts = dp.getVisiblePointsZBuffer(sub, cams=dp.cameras, tol=1e-4)
     assert best == int(torch.argmax(counts)) and int(counts.max()) > 1500

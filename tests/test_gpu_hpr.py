@@ -1,0 +1,141 @@
+"""f3: exact hidden-point removal on the GPU (genpc_hpr_visibility, csrc/hpr.hip) against
+  * oracle/genpc_oracle_hpr.c -- the same normal-cone clipping in C, same arithmetic and candidate order:
+    the masks must be IDENTICAL, and
+  * oracle/hpr.py -- the reference's operator through qhull itself (scipy), the library open3d calls:
+    identical on the clouds below (random balls / shells, real scans, a lattice full of cospherical ties).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    import torch
+    from genpc_amd import _lib
+    from oracle import oracle, hpr
+
+    def run(points, eyes, radius):
+        P = torch.from_numpy(np.ascontiguousarray(points, np.float32)).cuda()
+        E = torch.from_numpy(np.ascontiguousarray(eyes, np.float64).reshape(-1, 3)).cuda()
+        c, n = E.shape[0], P.shape[0]
+        vis = torch.zeros(c, n, device="cuda", dtype=torch.uint8)
+        cnt = torch.full((c,), -7, device="cuda", dtype=torch.int32)
+        second = ctypes.c_int(-1)
+        rc = _lib.lib.genpc_hpr_visibility(c, n, _lib.ptr(P), _lib.ptr(E), float(radius), _lib.ptr(vis), _lib.ptr(cnt),
+                                           ctypes.addressof(second), None)
+        torch.cuda.synchronize()
+        assert rc == 1, _lib.last_error()
+        return vis.cpu().numpy().astype(bool), cnt.cpu().numpy(), second.value
+
+    def qhull(points, eyes, radius):
+        out = np.zeros((len(eyes), len(points)), bool)
+        for k, e in enumerate(eyes):
+            out[k, hpr.hidden_point_removal(points, e, radius)] = True
+        return out
+
+    def clip(points, eyes, radius):
+        return np.stack([oracle.hpr_visibility(points, e, radius) for e in eyes])
+    return dict(run=run, qhull=qhull, clip=clip, lib=_lib)
+
+
+EYES = np.array([[0, 0, 3.0], [2.0, 1.0, -1.5], [-1.1, 0.3, 0.9], [0.2, -1.6, 0.1]])
+
+
+def clouds():
+    rng = np.random.default_rng(0)
+    out = {}
+    for n in (1, 2, 3, 50, 700, 3001):
+        out["ball%d" % n] = (rng.random((n, 3)) - 0.5).astype(np.float32)
+        v = rng.normal(size=(n, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        out["sphere%d" % n] = (v * 0.5).astype(np.float32)
+        out["shell%d" % n] = (v * (0.45 + 0.05 * rng.random((n, 1)))).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("radius", [3.0, 100.0, 800.0, 10000.0])
+def test_hpr_equals_qhull_and_the_clipping_oracle(hp, radius):
+    for name, P in clouds().items():
+        vis, cnt, second = hp["run"](P, EYES, radius)
+        np.testing.assert_array_equal(vis, hp["clip"](P, EYES, radius), err_msg=name)
+        if len(P) >= 4:          # qhull needs a full-dimensional input
+            np.testing.assert_array_equal(vis, hp["qhull"](P, EYES, radius), err_msg=name)
+        np.testing.assert_array_equal(cnt, vis.sum(1))
+
+
+def test_hpr_real_scans(hp, golden):
+    """16384-point scans, the reference's radius and a geometric one, four viewpoints each."""
+    g = golden("scans13_fps16384.npz")
+    eyes = np.array([[0, 0, 2.0], [1.2, 1.0, -1.0], [-1.6, 0.0, 0.0], [0.0, 1.6, 0.2]])
+    for k, name in ((0, "partial"), (5, "gt"), (9, "partial")):
+        P = g[name][k]
+        for radius in (100.0, 10000.0):
+            vis, cnt, second = hp["run"](P, eyes, radius)
+            np.testing.assert_array_equal(vis, hp["qhull"](P, eyes, radius), err_msg="%s %d %g" % (name, k, radius))
+            np.testing.assert_array_equal(vis[:2], hp["clip"](P, eyes[:2], radius))
+            np.testing.assert_array_equal(cnt, vis.sum(1))
+
+
+def test_hpr_lattice_takes_the_second_pass(hp):
+    """A regular lattice: dozens of cospherical neighbours per point, polygons of > 24 vertices ->
+    the second (wave-per-point) pass; still the oracle's mask, and qhull's."""
+    gr = np.stack(np.meshgrid(*[np.arange(12)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) / 12 - 0.5
+    for radius in (100.0, 10000.0):
+        vis, cnt, second = hp["run"](gr, EYES[:2], radius)
+        assert second > 0 or radius < 1000.0          # (at radius 100 this lattice's polygons stay under 24 vertices)
+        np.testing.assert_array_equal(vis, hp["clip"](gr, EYES[:2], radius))
+        np.testing.assert_array_equal(vis, hp["qhull"](gr, EYES[:2], radius))
+        np.testing.assert_array_equal(cnt, vis.sum(1))
+
+
+def test_hpr_edge_cases(hp):
+    import torch
+    lib = hp["lib"].lib
+    rng = np.random.default_rng(3)
+    P = (rng.random((500, 3)) - 0.5).astype(np.float32)
+    # duplicates: every copy of a visible point is reported (qhull keeps one: documented difference)
+    D = np.concatenate([P, P[:40]])
+    vis, cnt, _ = hp["run"](D, EYES[:1], 100.0)
+    base, _, _ = hp["run"](P, EYES[:1], 100.0)
+    np.testing.assert_array_equal(vis[0, :500], base[0])
+    np.testing.assert_array_equal(vis[0, 500:], base[0, :40])
+    # a NaN point is hidden and hides nothing; the eye on a point
+    N = P.copy()
+    N[7] = np.nan
+    vis, _, _ = hp["run"](N, EYES[:1], 100.0)
+    ref, _, _ = hp["run"](np.delete(P, 7, 0), EYES[:1], 100.0)
+    assert not vis[0, 7]
+    np.testing.assert_array_equal(np.delete(vis[0], 7), ref[0])
+    vis, _, _ = hp["run"](P, P[3:4].astype(np.float64), 100.0)
+    np.testing.assert_array_equal(vis, hp["clip"](P, P[3:4].astype(np.float64), 100.0))
+    # empty inputs, bad arguments
+    vis, cnt, _ = hp["run"](np.zeros((0, 3), np.float32), EYES, 10.0)
+    assert vis.shape == (4, 0) and (cnt == 0).all()
+    assert lib.genpc_hpr_visibility(0, 5, None, None, 1.0, None, None, None, None) == 1
+    assert lib.genpc_hpr_visibility(1, 5, None, None, 1.0, None, None, None, None) == -1
+    assert lib.genpc_hpr_visibility(1, 5, None, None, 0.0, None, None, None, None) == -1
+    assert lib.genpc_hpr_visibility(-1, 5, None, None, 1.0, None, None, None, None) == -1
+    torch.cuda.synchronize()
+
+
+def test_hpr_viewpoint_select_sizes(hp):
+    """viewpoint_select's shape: 64 viewpoints x 10000 FPS-ordered points at the reference's radius;
+    the mask equals the clipping oracle on a sample of views, the counts equal qhull's everywhere."""
+    import torch
+    from genpc_amd.DepthPrompting import fibonacci_sphere
+    from genpc_amd.fps import fps_sampling
+    from oracle import hpr
+    rng = np.random.default_rng(5)
+    v = rng.normal(size=(40000, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    cloud = (v * (0.3 + 0.2 * np.abs(np.sin(3 * v[:, :1])))).astype(np.float32)
+    pts = torch.from_numpy(cloud).cuda()
+    sub = pts[fps_sampling(pts, 10000).long()].cpu().numpy()
+    eyes = np.asarray(fibonacci_sphere(64, 1.6), np.float64)
+    vis, cnt, second = hp["run"](sub, eyes, 10000.0)
+    np.testing.assert_array_equal(cnt, hpr.visible_counts(sub, eyes, 10000.0))
+    np.testing.assert_array_equal(vis[[0, 31, 63]], hp["clip"](sub, eyes[[0, 31, 63]], 10000.0))

@@ -46,17 +46,25 @@ def test_config2_chain_8192(env, oracle, golden):
     Pt, Gt, It, GTt = (torch.from_numpy(x).cuda() for x in (partial, gen, img, gt))
     out = env["P"].complete_scan(Pt, Gt, It, GTt, cfg=env["cfg"], dp=env["dp"])
     cfg = env["cfg"]
-    # ---- stage 1: projection / pixels / splat against the oracle, on the chosen camera ----
-    view = out["view"]
-    cam = env["dp"].cameras[view:view + 1].cpu().numpy()
+    # ---- stage 1: the chosen viewpoint's visible set is Katz' (qhull), then projection / pixels / splat of the
+    # visible points against the oracle, on the chosen camera ----
+    from oracle import hpr
+    dp = env["dp"]
+    eye = np.asarray(dp.view, np.float64)
+    np.testing.assert_allclose(np.abs(eye), np.abs(np.asarray(dp.viewpoints[out["view"]], np.float64)))      # the view or its opposite
+    vis = np.zeros(len(partial), bool)
+    vis[hpr.hidden_point_removal(partial, eye, cfg.removal_radius)] = True
+    np.testing.assert_array_equal(out["visible"].cpu().numpy(), vis)
+    assert 0.2 < vis.mean() <= 1.0
+    cam = dp.cam.reshape(1, 12).cpu().numpy()
     ouv, odepth, _, _ = oracle.get_uvs(cam, env["dp"].focal, partial, rescale=True, padding=cfg.padding)
     np.testing.assert_array_equal(out["uv"].cpu().numpy(), ouv[0])
     np.testing.assert_array_equal(out["depth"].cpu().numpy(), odepth[0])
     opix = oracle.uv_to_pixels(ouv[0], cfg.res, cfg.res - 1)
     np.testing.assert_array_equal(out["pixels"].cpu().numpy(), opix)
-    d = odepth[0]
+    d = odepth[0][vis]
     grey = (np.float32(0.1) + np.float32(0.8) * (np.float32(1) - (d - d.min()) / (d.max() - d.min()))).astype(np.float32)
-    osparse, _ = oracle.paint_pixels(cfg.res, opix, np.repeat(grey[:, None], 3, 1), cfg.point_size)
+    osparse, _ = oracle.paint_pixels(cfg.res, opix[vis], np.repeat(grey[:, None], 3, 1), cfg.point_size)
     np.testing.assert_allclose(out["sparse_depth"].cpu().numpy(), osparse, atol=1e-6)
     assert float(out["hole_mask1"].sum()) > 0 and out["sparse_img"].shape == (3, cfg.res, cfg.res)
     # ---- stage 2a: colours of the partial points from the generated image ----

@@ -89,13 +89,12 @@ def test_config4_waymo_cars_4096(tg, golden, mode):
 
 
 def test_viewpoint_selection_against_katz_hpr(tg, golden):
-    """f3: the library selects the viewpoint with a z-buffer visibility test; the reference with Katz'
-    hidden-point removal through open3d/qhull (DepthPrompting.py:87-98,273-290).  The two operators are
-    different definitions; this measures how differently they choose, on the bundled scans, against a
-    qhull restatement of the reference's operator (oracle/hpr.py) at the reference's radius and at a
-    geometric one.  Asserted: the statistics are produced and the z-buffer's view is never among the
-    worst quarter by the geometric HPR count.  The numbers go to gpurun_out/hpr_agreement.json
-    (copied to profiles/)."""
+    """f3: viewpoint_select ranks the views with Katz' hidden-point removal like the reference
+    (DepthPrompting.py:87-98,273-290) -- asserted here: the library's per-view counts EQUAL qhull's
+    (oracle/hpr.py) on the bundled scans, at the reference's radius and at a geometric one, so the
+    selected view is the reference's.  The optional z-buffer ranking (viewpoint_select(zbuffer=True)) is
+    a different definition; how differently it chooses is measured and written to
+    gpurun_out/hpr_agreement.json (copied to profiles/)."""
     import json
     import os
     from types import SimpleNamespace
@@ -113,11 +112,17 @@ def test_viewpoint_selection_against_katz_hpr(tg, golden):
     for s in range(0, 13, 2):
         pts = torch.from_numpy(g["partial"][s]).cuda()
         sub = pts[fps_sampling(pts, cfg.downsample_num).long()]
-        _, cnt = dp.getVisiblePoints(sub, viewpoints=eyes, radius=10000)      # the reference's call shape
+        _, cnt = dp.getVisiblePointsZBuffer(sub, cams=dp.cameras)
         zb = cnt.cpu().numpy().astype(np.int64)
         subn = sub.cpu().numpy()
         geo = hpr.visible_counts(subn, eyes, 100.0)
         ref = hpr.visible_counts(subn, eyes, 10000.0)
+        for radius, expect in ((100.0, geo), (10000.0, ref)):
+            vis = dp.getVisiblePoints(sub, eyes, radius)          # the reference's call shape
+            assert vis.shape == (64, cfg.downsample_num) and vis.dtype == torch.bool
+            np.testing.assert_array_equal(vis.sum(1).cpu().numpy(), expect)
+        cfg.removal_radius = 10000
+        assert dp.viewpoint_select(pts) == int(np.argmax(ref))
 
         def rank_of(choice, counts):          # 0 = best view by `counts`
             return int((counts > counts[choice]).sum())

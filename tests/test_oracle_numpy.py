@@ -262,3 +262,43 @@ def test_hpr_oracle_on_a_sphere_and_a_shell():
     assert len(big) / 3000.0 > 0.7 and facing[big].mean() < 0.7
     counts = hpr.visible_counts(sphere, [cam, -cam, [1.6, 0, 0]], 10000)
     assert counts.shape == (3,) and counts.min() > 1000
+
+
+def test_hpr_clipping_oracle_equals_qhull(oracle, golden):
+    """oracle/genpc_oracle_hpr.c (the hull-vertex test as a normal-cone polygon per point -- the form the
+    GPU computes) against the reference's operator through qhull (oracle/hpr.py): IDENTICAL masks on
+    random balls / spheres / shells, at the reference's radii and a tiny one, on two real scans, and on a
+    lattice (cospherical ties, polygons of 100+ vertices)."""
+    from oracle import hpr
+    rng = np.random.default_rng(0)
+
+    def both(P, eye, radius):
+        a = oracle.hpr_visibility(P, eye, radius)
+        b = np.zeros(len(P), bool)
+        b[hpr.hidden_point_removal(P, eye, radius)] = True
+        np.testing.assert_array_equal(a, b)
+        return a
+    for n in (50, 500, 3000):
+        v = rng.normal(size=(n, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        for P in ((rng.random((n, 3)) - 0.5), v * 0.5, v * (0.45 + 0.05 * rng.random((n, 1)))):
+            for eye in ([0, 0, 3.0], [2.0, 1.0, -1.5]):
+                for radius in (3.0, 100.0, 800.0, 10000.0):
+                    both(P.astype(np.float32), eye, radius)
+    g = golden("scans13_fps16384.npz")
+    vis = both(g["partial"][0][:6000], [1.2, 1.0, -1.0], 10000.0)
+    assert 0.3 < vis.mean() < 1.0
+    both(g["gt"][5][:6000], [0, 0, 2.0], 100.0)
+    gr = np.stack(np.meshgrid(*[np.arange(10)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) / 10 - 0.5
+    a, mv = oracle.hpr_visibility(gr, [0, 0, 3.0], 10000.0, True)
+    b = np.zeros(len(gr), bool)
+    b[hpr.hidden_point_removal(gr, [0, 0, 3.0], 10000.0)] = True
+    np.testing.assert_array_equal(a, b)
+    assert mv > 24          # larger than the GPU kernel's LDS polygons: the case its second pass exists for
+    # duplicates are all reported; a NaN point is hidden and hides nothing
+    P = (rng.random((300, 3)) - 0.5).astype(np.float32)
+    base = oracle.hpr_visibility(P, [0, 0, 3.0], 100.0)
+    D = np.concatenate([P, P[:20]])
+    d = oracle.hpr_visibility(D, [0, 0, 3.0], 100.0)
+    np.testing.assert_array_equal(d[:300], base)
+    np.testing.assert_array_equal(d[300:], base[:20])

@@ -4,7 +4,7 @@ set -u
 OUT=gpurun_out/ktp
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -o t -- python3 tools/prof_pose.py > $OUT/t.log 2>&1
+timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -o t -- python3 tools/prof_pose.py ${POSE_ARGS:-} > $OUT/t.log 2>&1
 python3 - <<'PY'
 import csv, glob
 for f in glob.glob("gpurun_out/ktp/t/*kernel_stats.csv"):
