@@ -44,7 +44,7 @@
 namespace genpc {
 
 constexpr int kHprThreads = 128;
-constexpr int kHprMaxV = 24;            // polygon vertices per thread in LDS (48 KB per block)
+constexpr int kHprMaxV = 16;            // polygon vertices per thread in LDS (32 KB per block: four blocks per CU; measured 24 -> 16: 24.7 -> 20.9 ms at 64 x 10000, 12: 32 ms -- too many points fall to the second pass)
 constexpr int kHprOverCap = 1024;       // vertices per polygon in the second pass (2 x 16 KB of LDS per wave)
 constexpr double kHprBox = 1.0e4;
 
@@ -409,7 +409,6 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
         poly[3 * kHprThreads] = make_double2(-kHprBox, kHprBox);
         R = hpr_reach(poly, kHprThreads, nv);
     }
-    constexpr int kU = 4;      // candidates examined together (their loads and dot products overlap)
     HprTile *s_rec = (HprTile *)s_stage;
     // batches of 1, 1, 2, 4, ... 64 tiles: the polygon is the whole box at first (every tile "needed") and
     // tight after the own tile and its neighbours, so the early batches are short
@@ -466,42 +465,57 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
             }
             __syncthreads();
             if (active && ((mine >> b) & 1ull)) {
-                bool stale = false;
-                for (int t = 0; t < tn && active; t += kU) {
-                    if ((t & 31) == 0 && stale) {          // a few times per tile, not per clip
-                        R = hpr_reach(poly, kHprThreads, nv);
-                        stale = false;
-                    }
-                    unsigned pass = 0;
+                // Pass 1 over the tile, the same for every lane: which candidates are not provably out of reach
+                // (one bit each).  Pass 2: every lane takes ITS marked candidates in order -- the lanes of a
+                // wave run their k-th marked candidate together, so the wave pays for the longest list, not
+                // for the sum of all of them (clipping candidate by candidate as they come costs 10x more:
+                // the lanes meet their cuts at different candidates).
+                R = hpr_reach(poly, kHprThreads, nv);
+                unsigned long long bits[2] = {0ull, 0ull};
 #pragma unroll
-                    for (int u = 0; u < kU; u++) {
-                        const double4 q = s_stage[t + u];      // t + u < kHprThreads: padded with NaN rows
+                for (int h = 0; h < 2; h++) {
+                    unsigned long long m = 0ull;
+#pragma unroll 4
+                    for (int t = 0; t < 64; t++) {
+                        const double4 q = s_stage[h * 64 + t];      // rows past the end are NaN
                         const double A = f.e1x * q.x + f.e1y * q.y + f.e1z * q.z;
                         const double B = f.e2x * q.x + f.e2y * q.y + f.e2z * q.z;
                         const double C = f.rho - (f.ux * q.x + f.uy * q.y + f.uz * q.z);
                         const bool self = q.x == f.px && q.y == f.py && q.z == f.pz;      // the point itself, or an exact duplicate
-                        pass |= (!self && q.x == q.x && !hpr_far(R, A, B, C)) ? (1u << u) : 0u;
+                        m |= (!self && q.x == q.x && !hpr_far(R, A, B, C)) ? (1ull << t) : 0ull;
                     }
-                    while (pass && active) {
-                        const int u = __ffs((int)pass) - 1;
-                        pass &= pass - 1;
-                        const double4 q = s_stage[t + u];      // (recomputed: the same values)
+                    bits[h] = m;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    unsigned long long m = bits[h];
+                    while (m && active) {
+                        const int t = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const double4 q = s_stage[h * 64 + t];      // (recomputed: the same values)
                         const double A = f.e1x * q.x + f.e1y * q.y + f.e1z * q.z;
                         const double B = f.e2x * q.x + f.e2y * q.y + f.e2z * q.z;
                         const double C = f.rho - (f.ux * q.x + f.uy * q.y + f.uz * q.z);
                         // outside vertices: how many, and where their (cyclic) run starts
+                        // (eight vertices are fetched at a time: one LDS round trip instead of eight in a row;
+                        // slots past nv are read -- they belong to this thread -- and ignored)
                         int out = 0, first = 0;
                         bool prev_out;
                         {
                             const double2 v = poly[(nv - 1) * kHprThreads];
                             prev_out = v.x * A + v.y * B - C > 0.0;
                         }
-                        for (int k = 0; k < nv; k++) {
-                            const double2 v = poly[k * kHprThreads];
-                            const bool o = v.x * A + v.y * B - C > 0.0;
-                            out += o ? 1 : 0;
-                            first = (o && !prev_out) ? k : first;
-                            prev_out = o;
+                        for (int k0 = 0; k0 < nv; k0 += 8) {
+                            double2 v[8];
+#pragma unroll
+                            for (int j = 0; j < 8; j++) v[j] = poly[(k0 + j < kHprMaxV ? k0 + j : kHprMaxV - 1) * kHprThreads];
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                const bool o = k0 + j < nv && v[j].x * A + v[j].y * B - C > 0.0;
+                                out += o ? 1 : 0;
+                                first = (o && !prev_out) ? k0 + j : first;
+                                prev_out = k0 + j < nv ? o : prev_out;
+                            }
                         }
                         if (!out) continue;
                         if (out == nv) { nv = 0; active = false; break; }
@@ -511,10 +525,9 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                             active = false;
                             break;
                         }
-                        const int m = hpr_clip_inplace(poly, kHprThreads, nv, out, first, A, B, C);
-                        if (m < 3) { nv = 0; active = false; break; }      // no interior left: not strictly extreme
-                        nv = m;
-                        stale = true;
+                        const int mm = hpr_clip_inplace(poly, kHprThreads, nv, out, first, A, B, C);
+                        if (mm < 3) { nv = 0; active = false; break; }      // no interior left: not strictly extreme
+                        nv = mm;
                     }
                 }
             }
