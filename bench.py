@@ -243,6 +243,31 @@ def extras(A, B, n, dev, stream):
                                             "unit": "GB/s", "frac": round(alg / (t * 1e-3) / 8e12, 4),
                                             "frac_of_6.29TBs_achievable": round(alg / (t * 1e-3) / 6.29e12, 4),
                                             "ms_per_launch_pair": round(t, 4), "algorithmic_bytes": alg}
+    # f3: hidden-point removal (Katz' operator, exact) at viewpoint_select's shape -- the reference's 1024
+    # viewpoints x 10000 FPS-ordered points, removal_radius 10000 -- and at getDepth's (2 viewpoints x the
+    # whole scan); next to it qhull (what open3d calls) on one host core for ONE viewpoint
+    cfgh = SimpleNamespace(device=str(dev), fovy=49.1, res=256, cam_res=256, padding=0.15, rescale=True, point_size=1,
+                           mask_pixel_rate=3, view_num=1024, distance=1.6, downsample_num=10000, removal_radius=10000)
+    dph = DepthPrompting(cfgh)
+    rngh = np.random.default_rng(5)
+    vh = rngh.normal(size=(165546, 3))
+    vh /= np.linalg.norm(vh, axis=1, keepdims=True)
+    scan = torch.from_numpy((vh * (0.3 + 0.2 * np.abs(np.sin(3 * vh[:, :1])))).astype(np.float32)).to(dev)
+    sub = scan[fps_sampling(scan, 10000).long()].contiguous()
+    for name, p_, e_ in (("hpr_1024x10000", sub, dph.viewpoints), ("hpr_2x165546", scan, dph.viewpoints[:2])):
+        dph.hidden_point_removal(p_, e_, 10000.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, cnt_h, second_h = dph.hidden_point_removal(p_, e_, 10000.0)
+        torch.cuda.synchronize()
+        extra[name + "_R10000_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        extra[name + "_visible_fraction"] = round(float(cnt_h.float().mean()) / p_.shape[0], 4)
+    from oracle import hpr as ohpr
+    t0 = time.perf_counter()
+    ref_cnt = ohpr.visible_counts(sub.cpu().numpy(), np.asarray(dph.viewpoints)[:4], 10000.0)
+    extra["hpr_cpu_qhull_ms_per_viewpoint_10000pts_1core"] = round((time.perf_counter() - t0) / 4 * 1e3, 2)
+    _, cnt4, _ = dph.hidden_point_removal(sub, dph.viewpoints[:4], 10000.0)
+    extra["hpr_counts_equal_qhull"] = bool((cnt4.cpu().numpy() == ref_cnt).all())
     # BASELINE config 2: the chained geometric stages of one completed scan (8192-point partial scan,
     # 16384-point generated shape): DepthPrompting -> colorPoint -> reg -> fuse -> metric
     from genpc_amd import pipeline

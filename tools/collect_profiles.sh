@@ -28,4 +28,6 @@ family get_uvs_1024x71372 tools/prof_uvs.py 3
 family pose_loop_16384x8192 tools/prof_pose.py 16384 8192 20 1
 family scale_search_icp tools/prof_scale_search.py
 family fps_voxel tools/prof_fps_voxel.py
+family hpr_64x10000 tools/prof_hpr.py small
+family hpr_2x165546 tools/prof_hpr.py big
 ls $OUT | head -60
