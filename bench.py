@@ -287,7 +287,8 @@ def extras(A, B, n, dev, stream):
     C5 = torch.from_numpy(np.stack([x[0] for x in sc])).to(dev)
     P5 = torch.from_numpy(np.stack([x[1] for x in sc])).to(dev)
     G5 = torch.from_numpy(np.stack([x[2] for x in sc])).to(dev)
-    object_pose_optimization(C5, P5, radius=0.02, lr=0.01, iters=200, render_size=224)
+    object_pose_optimization(C5, P5, radius=0.02, lr=0.01, iters=20, render_size=224)
+    evaluate_scans(C5, G5)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     object_pose_optimization(C5, P5, radius=0.02, lr=0.01, iters=200, render_size=224)

@@ -859,13 +859,14 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
             // pair) take 64-target units (half the re-read, +10 % filter VALU), long ones 128
             const int fu = cfg.u == 2 || cfg.u == 4 ? cfg.u : (nt_max <= 8192 ? 2 : 4);
             // fused finish (the last-arriving filter block of a query block finishes it; no second
-            // launch): pays once the launch runs for several rounds, where other blocks' filter work
-            // hides the tail -- measured two launches vs fused: 13x16384^2 313 vs 296 us, 8x32768^2
-            // 636 vs 606, 64x4096^2 135 vs 120, 4x16384^2 101 vs 103; but 1x16384^2 36 vs 59 (the
-            // tail is exposed), so launches of fewer than three rounds keep the finish kernel.
-            // Hook 1024 / GENPC_NN_FUSE=1 force it on, hook 2048 / GENPC_NN_FUSE=0 off.
+            // launch), hook 1024 / GENPC_NN_FUSE=1.  Measured two launches vs fused on uniform clouds:
+            // 13x16384^2 313 vs 296 us, 8x32768^2 636 vs 606, 64x4096^2 135 vs 120, 4x16384^2 101 vs 103,
+            // 1x16384^2 36 vs 59 (the tail is exposed).  NOT a default: on scan-like clouds (partial vs
+            // complete shapes, many near-ties) a block's 512 queries list more than the 4096 work items its
+            // LDS holds and the overflow falls to the exhaustive pass -- the 8 x 32768 alignment loop went
+            // from 1.35 s to 3.86 s.  The finish kernel (64 queries per block) has no such cliff.
             static const int fuse_env = getenv("GENPC_NN_FUSE") ? atoi(getenv("GENPC_NN_FUSE")) : -1;
-            const int fuse = fuse_env >= 0 ? fuse_env : ((a.debug & 1024) ? 1 : ((a.debug & 2048) ? 0 : (tight && q == 4)));
+            const int fuse = fuse_env >= 0 ? fuse_env : ((a.debug & 1024) ? 1 : 0);
             return launch_nn_f16(a, q, fu, nl, tight ? 1 : 0, fuse, tb, st);
         }
         const int pre = cfg.pre >= 0 ? cfg.pre : ((a.debug & 256) ? 1 : 0);      // measured: 13x16384^2 401+8 us vs 410 us, 1x16384^2 35+5 vs 36 -- does not pay

@@ -295,8 +295,8 @@ def test_fused_finish_elementwise(gp, oracle, golden, mode):
         grid = np.random.default_rng(3).integers(0, 24, size=(1, 30000, 3)).astype(np.float32)      # exact ties: exhaustive pass
         assert_bits(run_hip(gp, grid[:, :15000].copy(), grid[:, 15000:].copy(), 1, PATHS["f16"], HOOK_FUSE),
                     oracle.chamfer_forward(grid[:, :15000].copy(), grid[:, 15000:].copy(), 1), "fused ties")
-        # launches of several rounds (three resident blocks per CU; the planner fuses these by default):
-        # fused, forced two-launch (hook 2048) and the planner's own choice agree with the oracle
+        # launches of several rounds (three resident blocks per CU): fused, two launches (hook 2048 is
+        # accepted and means the default) and the planner's own choice agree with the oracle
         e13 = oracle.chamfer_forward(g["partial"], g["gt"], 1)
         for hooks, what in ((HOOK_FUSE, "fused"), (2048, "two launches"), (0, "planner")):
             assert_bits(run_hip(gp, g["partial"], g["gt"], 1, PATHS["f16"], hooks), e13, "13 scans, " + what)
