@@ -5,14 +5,21 @@ the "complete" cloud that reg() aligns.  Host-side format code, numpy only.
 ``load_glb``   binary glTF 2.0: JSON chunk + BIN chunk, every triangle primitive of
                every mesh reachable from the default scene, node transforms applied
                (matrix or translation / rotation / scale), concatenated like
-               ``trimesh.Scene.dump(concatenate=True)``.  Vertex colours (COLOR_0)
-               are returned when present; textures are not baked.
+               ``trimesh.Scene.dump(concatenate=True)``.  Vertex colours: COLOR_0 when
+               present; otherwise the material's base-colour TEXTURE baked to the vertices
+               the way ``TextureVisuals.to_color()`` does it (utils/dataUtils.py:224-225;
+               trimesh's published ``uv_to_color``: nearest texel at x = u (W-1),
+               y = v_gltf (H-1), rounded, wrapped like GL_REPEAT -- trimesh is absent and
+               unpinned); otherwise the material's baseColorFactor.  The image (PNG / JPEG
+               in a bufferView or a data URI) is decoded with PIL.
 ``sample_surface``  area-weighted uniform sampling of a triangle mesh, the published
                algorithm of ``trimesh.sample.sample_surface``: faces drawn with
                probability proportional to area, points by the folded-parallelogram
                trick.  trimesh draws from numpy's unseeded global RNG, so the
                reference's samples are not reproducible; here a Generator is passed.
 """
+import base64
+import io
 import json
 import struct
 
@@ -63,6 +70,58 @@ def _node_matrix(node):
     return M
 
 
+def _texture_image(gltf, bin_chunk, tex_index, cache):
+    """RGBA uint8 array [H,W,4] of texture `tex_index` (None if it cannot be resolved)."""
+    if tex_index in cache:
+        return cache[tex_index]
+    img = None
+    try:
+        source = gltf["textures"][tex_index]["source"]
+        rec = gltf["images"][source]
+        if "bufferView" in rec:
+            view = gltf["bufferViews"][rec["bufferView"]]
+            raw = bytes(bin_chunk[view.get("byteOffset", 0): view.get("byteOffset", 0) + view["byteLength"]])
+        elif str(rec.get("uri", "")).startswith("data:"):
+            raw = base64.b64decode(rec["uri"].split(",", 1)[1])
+        else:
+            raw = None                                          # external file: not followed
+        if raw is not None:
+            from PIL import Image
+            img = np.asarray(Image.open(io.BytesIO(raw)).convert("RGBA"))
+    except (KeyError, IndexError, ValueError, OSError):
+        img = None
+    cache[tex_index] = img
+    return img
+
+
+def uv_to_color(uv, image):
+    """trimesh.visual.color.uv_to_color with the glTF loader's v-flip folded in: uv are the file's
+    TEXCOORD values, image an [H,W,4] uint8 array -> uint8 [N,4]."""
+    h, w = image.shape[:2]
+    x = np.round(uv[:, 0] * (w - 1)).astype(np.int64) % w
+    y = np.round(uv[:, 1] * (h - 1)).astype(np.int64) % h
+    return image[y, x]
+
+
+def _material_colors(gltf, bin_chunk, prim, nverts, cache):
+    """Per-vertex colours in [0,1] from the primitive's material, or None."""
+    if "material" not in prim:
+        return None
+    pbr = gltf["materials"][prim["material"]].get("pbrMetallicRoughness", {})
+    tex = pbr.get("baseColorTexture")
+    if tex is not None:
+        attr = "TEXCOORD_%d" % tex.get("texCoord", 0)
+        img = _texture_image(gltf, bin_chunk, tex["index"], cache)
+        if img is not None and attr in prim["attributes"]:
+            uv = np.asarray(_accessor(gltf, bin_chunk, prim["attributes"][attr]), np.float64)[:, :2]
+            return uv_to_color(uv, img)[:, :3].astype(np.float64) / 255.0
+    if "baseColorFactor" in pbr:
+        # (trimesh stores the factor as uint8 RGBA)
+        f8 = np.round(np.clip(np.asarray(pbr["baseColorFactor"], np.float64)[:3], 0, 1) * 255.0)
+        return np.tile(f8 / 255.0, (nverts, 1))
+    return None
+
+
 def load_glb(path):
     """-> (vertices float64 [N,3], faces int64 [M,3], colors float64 [N,3] in [0,1] or None)."""
     with open(path, "rb") as f:
@@ -83,6 +142,7 @@ def load_glb(path):
         raise ValueError("%s: no JSON chunk" % path)
     verts, faces, cols, base = [], [], [], 0
     any_color = False
+    tex_cache = {}
 
     def visit(ni, parent):
         nonlocal base, any_color
@@ -102,7 +162,11 @@ def load_glb(path):
                     c = _accessor(gltf, bin_chunk, prim["attributes"]["COLOR_0"])[:, :3].astype(np.float64)
                     any_color = True
                 else:
-                    c = np.full((len(v), 3), np.nan)
+                    c = _material_colors(gltf, bin_chunk, prim, len(v), tex_cache)
+                    if c is None:
+                        c = np.full((len(v), 3), np.nan)
+                    else:
+                        any_color = True
                 verts.append(v)
                 faces.append(fi + base)
                 cols.append(c)
@@ -139,7 +203,8 @@ def sample_surface(vertices, faces, count, rng=None):
 
 def glb2point(glb_path, num_points=16384, rng=None):
     """utils/dataUtils.py:217-250 without open3d/trimesh: (points [n,3], colours [n,3]);
-    colours are barycentric blends of the vertex colours, 0.5 grey when the file has none."""
+    colours are barycentric blends of the vertex colours (COLOR_0, or the baked base-colour texture
+    / factor), 0.5 grey when the file has none."""
     V, F, C = load_glb(glb_path)
     pts, fi = sample_surface(V, F, num_points, rng)
     if C is None:

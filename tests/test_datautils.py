@@ -112,6 +112,77 @@ def test_glb_loader_and_surface_sampling(tmp_path):
     np.testing.assert_allclose(Cc[on], np.stack([1 - P[on, 0] - P[on, 1], P[on, 0], P[on, 1]], 1), atol=1e-9)
 
 
+def _write_textured_glb(path, verts, faces, uv, png_bytes=None, data_uri=False, factor=None):
+    """One textured primitive: TEXCOORD_0 + a material whose base-colour texture is an embedded PNG
+    (bufferView or data URI), or a material with only a baseColorFactor."""
+    import base64
+    import json
+    import struct
+    v = np.asarray(verts, "<f4")
+    idx = np.asarray(faces, "<u2").reshape(-1)
+    t = np.asarray(uv, "<f4")
+    blobs, views = [], []
+
+    def add(b):
+        views.append({"buffer": 0, "byteOffset": sum(map(len, blobs)), "byteLength": len(b)})
+        blobs.append(b + b"\x00" * (-len(b) % 4))
+        return len(views) - 1
+    accs = [{"bufferView": add(v.tobytes()), "componentType": 5126, "count": len(v), "type": "VEC3"},
+            {"bufferView": add(idx.tobytes()), "componentType": 5123, "count": len(idx), "type": "SCALAR"},
+            {"bufferView": add(t.tobytes()), "componentType": 5126, "count": len(t), "type": "VEC2"}]
+    g = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+         "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 2}, "indices": 1, "material": 0}]}],
+         "accessors": accs}
+    if png_bytes is not None:
+        img = {"uri": "data:image/png;base64," + base64.b64encode(png_bytes).decode()} if data_uri else \
+              {"bufferView": add(png_bytes), "mimeType": "image/png"}
+        g.update(images=[img], textures=[{"source": 0}],
+                 materials=[{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "baseColorFactor": [0.1, 0.2, 0.3, 1.0]}}])
+    else:
+        g.update(materials=[{"pbrMetallicRoughness": {"baseColorFactor": list(factor)}}])
+    g["bufferViews"] = views
+    g["buffers"] = [{"byteLength": sum(map(len, blobs))}]
+    js = json.dumps(g).encode()
+    js += b" " * (-len(js) % 4)
+    binc = b"".join(blobs)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(binc)))
+        f.write(struct.pack("<I4s", len(js), b"JSON") + js)
+        f.write(struct.pack("<I4s", len(binc), b"BIN\x00") + binc)
+
+
+def test_glb_texture_is_baked_to_vertex_colours(tmp_path):
+    """TextureVisuals.to_color() of glb2point (utils/dataUtils.py:224-225): nearest texel at
+    x = u (W-1), y = v (H-1) of the file's TEXCOORD, GL_REPEAT wrap; the texture wins over the factor."""
+    import io
+    from PIL import Image
+    from genpc_amd.utils import mesh_io as M
+    rng = np.random.default_rng(0)
+    tex = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)               # H = 5, W = 7
+    buf = io.BytesIO()
+    Image.fromarray(tex, "RGB").save(buf, format="PNG")
+    verts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], float)
+    faces = np.array([[0, 1, 2], [1, 3, 2]])
+    uv = np.array([[0.0, 0.0], [1.0, 0.0], [2.0 / 6.0, 1.0], [1.0 + 3.0 / 6.0, 0.5]])     # last one wraps in u
+    expect = np.stack([tex[0, 0], tex[0, 6], tex[4, 2], tex[2, (6 + 3) % 7]]) / 255.0
+    for data_uri in (False, True):
+        p = str(tmp_path / ("tex%d.glb" % data_uri))
+        _write_textured_glb(p, verts, faces, uv, buf.getvalue(), data_uri=data_uri)
+        V, F, C = M.load_glb(p)
+        np.testing.assert_allclose(C, expect, atol=1e-12)
+    np.testing.assert_array_equal(M.uv_to_color(np.array([[0.49 / 6, 0.51 / 4], [0.5 / 6, 1.5 / 4]]), np.dstack([tex, tex[:, :, :1]]))[:, :3],
+                                  np.stack([tex[1, 0], tex[2, 0]]))             # rounding: 0.49 -> 0, 0.51 -> 1; halves to even
+    # sampled colours are barycentric blends of the baked vertex colours
+    P, Cc = M.glb2point(str(tmp_path / "tex0.glb"), 2000, np.random.default_rng(1))
+    lower = P[:, 0] + P[:, 1] <= 1.0
+    b = np.stack([1 - P[lower, 0] - P[lower, 1], P[lower, 0], P[lower, 1]], 1)
+    np.testing.assert_allclose(Cc[lower], b @ expect[:3], atol=1e-9)
+    # a material with only a factor
+    p = str(tmp_path / "factor.glb")
+    _write_textured_glb(p, verts, faces, uv, None, factor=[0.25, 0.5, 1.0, 1.0])
+    np.testing.assert_allclose(M.load_glb(p)[2], np.tile(np.round(np.array([0.25, 0.5, 1.0]) * 255) / 255, (4, 1)))
+
+
 def np_voxel_down_sample(xyz, voxel):
     """open3d's published definition in numpy: double index arithmetic, per-voxel mean summed in
     point order (np.add.at is sequential), ascending (i, j, k)."""
