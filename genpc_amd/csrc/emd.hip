@@ -30,8 +30,6 @@
 // object with the smallest (reference-thread, index) key, so assignments agree
 // with the oracle even on clouds with duplicated points.
 #include "common.h"
-#include <mutex>
-#include <string.h>
 #include "../../include/genpc_hip.h"
 
 #include <stdlib.h>
@@ -546,33 +544,6 @@ __global__ __launch_bounds__(kEBlock) void emd_grad_kernel(long long total, int 
     o[2] = __fadd_rn(o[2], __fmul_rn(g, p1[2] - p2[2]));
 }
 
-// ---- replay cache -------------------------------------------------------------------------------------
-// A forward call is 1 + 3 x iters + 1 small dependent launches whose arguments depend only on the call's
-// arguments and the workspace block.  Back-to-back stream launches of a dependent chain cost ~3.5 us each
-// on this runtime, the same chain replayed from a hipGraph ~1.8 us (tools/ubench_graph.hip) -- for EMPTY
-// kernels; with the real ones the host runs ahead of the GPU anyway and the replay gains 3-4 % (measured on
-// fixed buffers, tools/time_emd_graph.py: 1 x 2048 0.636 -> 0.612 ms, 1 x 16384 1.539 -> 1.492, 13 x 16384 and
-// 64 x 2048 unchanged): the dependent-kernel gap on the GPU side is what a round costs, not the submission.  A call whose
-// complete argument set has been seen before (evaluation loops reuse their buffers: torch's caching
-// allocator hands the same blocks back) is captured once on the caller's stream and replayed from then on.
-// GENPC_EMD_GRAPH=0 turns it off.
-struct EmdKey {
-    const void *p[14];
-    int b, n, iters, fma, dev;
-    float eps;
-    hipStream_t st;
-    bool operator==(const EmdKey &o) const { return memcmp(this, &o, sizeof(EmdKey)) == 0; }
-};
-struct EmdEntry {
-    EmdKey key;
-    int seen = 0;
-    hipGraphExec_t exec = nullptr;
-    unsigned long long stamp = 0;
-};
-static std::mutex g_emd_mu;
-static EmdEntry g_emd_cache[8];
-static unsigned long long g_emd_clock = 0;
-
 }  // namespace genpc
 
 GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist,
@@ -616,8 +587,8 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     int *list_b = (int *)(ws + arrive_bytes);
     int *second = (int *)(ws + arrive_bytes + list_bytes);
     float4 *parts = (float4 *)(ws + arrive_bytes + list_bytes + second_bytes);
-    // second-best object of each point's last bid (-1: has not bid yet; cleared below, inside the recorded part)
-    int *second_all = second;
+    // second-best object of each point's last bid (-1: has not bid yet)
+    if (!check(hipMemsetAsync(second, 0xff, (size_t)total * sizeof(int), st), "hipMemsetAsync(second)")) return 0;
     static const bool noseed = getenv("GENPC_EMD_NOSEED") != nullptr;
     if (noseed) second = nullptr;
     static const bool nosplit = getenv("GENPC_EMD_NOSPLIT") != nullptr;
@@ -625,62 +596,6 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     int *lists[2] = {unass_idx, list_b};
     int *cnts[2] = {unass_cnt, cnt_tmp};
     const bool fma = arith_mode() != 0;
-
-    // replay / capture decision (see EmdKey)
-    static const bool graph_on = !(getenv("GENPC_EMD_GRAPH") && atoi(getenv("GENPC_EMD_GRAPH")) == 0);
-    EmdEntry *entry = nullptr;
-    bool capturing = false;
-    const hipStream_t user_st = st;
-    std::unique_lock<std::mutex> glock(g_emd_mu, std::defer_lock);
-    if (graph_on) {
-        EmdKey key;
-        memset(&key, 0, sizeof key);
-        const void *ptrs[14] = {xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_increments, max_increments,
-                                unass_idx, unass_cnt, cnt_tmp, max_idx, ws};
-        memcpy(key.p, ptrs, sizeof ptrs);
-        key.b = b; key.n = n; key.iters = iters; key.fma = fma ? 1 : 0; key.eps = eps; key.st = st;
-        (void)hipGetDevice(&key.dev);
-        glock.lock();
-        EmdEntry *oldest = &g_emd_cache[0];
-        for (EmdEntry &e : g_emd_cache) {
-            if (e.seen && e.key == key) entry = &e;
-            if (e.stamp < oldest->stamp) oldest = &e;
-        }
-        if (!entry) {
-            if (oldest->exec) (void)hipGraphExecDestroy(oldest->exec);
-            *oldest = EmdEntry();
-            oldest->key = key;
-            entry = oldest;
-        }
-        entry->stamp = ++g_emd_clock;
-        entry->seen++;
-        if (entry->exec) {
-            const bool ok = check(hipGraphLaunch(entry->exec, st), "hipGraphLaunch(emd forward)");
-            return ok ? 1 : 0;
-        }
-        if (entry->seen >= 2) {
-            // second sighting: record the launches below instead of running them, then replay
-            // (on a private stream: the caller's is usually the legacy default stream, which cannot capture)
-            static hipStream_t caps[64] = {};          // one per device (guarded by g_emd_mu)
-            hipStream_t &cap = caps[key.dev & 63];
-            if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) cap = nullptr;
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (cap && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone &&
-                hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                capturing = true;
-                st = cap;
-            }
-            else {
-                (void)hipGetLastError();
-                if (getenv("GENPC_EMD_GRAPH_DEBUG")) fprintf(stderr, "emd: capture refused\n");
-            }
-        }
-        if (!capturing) glock.unlock();
-    }
-    if (!check(hipMemsetAsync(second_all, 0xff, (size_t)total * sizeof(int), st), "hipMemsetAsync(second)")) {
-        if (capturing) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); }
-        return 0;
-    }
 
     const int lin_blocks = ceil_div((int)total, kEBlock);
     hipLaunchKernelGGL(emd_init_kernel, dim3(lin_blocks), dim3(kEBlock), 0, st, b, n, lists[0], cnts[0], cnts[1]);
@@ -749,22 +664,6 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     else
         hipLaunchKernelGGL((emd_calc_dist_kernel<0>), dim3(lin_blocks), dim3(kEBlock), 0, st, total, n, xyz1, xyz2, dist,
                            (const int *)assignment);
-    if (capturing) {
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        const bool ok = hipStreamEndCapture(st, &g) == hipSuccess && g &&
-                        hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
-        if (g) (void)hipGraphDestroy(g);
-        if (!ok) {
-            (void)hipGetLastError();
-            set_error("emd forward: graph capture failed");
-            entry->seen = -1000000;          // never try again for this argument set
-            return 0;
-        }
-        entry->exec = ge;
-        if (getenv("GENPC_EMD_GRAPH_DEBUG")) fprintf(stderr, "emd: captured graph for b=%d n=%d\n", b, n);
-        return check(hipGraphLaunch(ge, user_st), "hipGraphLaunch(emd forward)") ? 1 : 0;
-    }
     return check(hipGetLastError(), "emd forward launch") ? 1 : 0;
 }
 

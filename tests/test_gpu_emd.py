@@ -178,8 +178,8 @@ def test_unnormalised_clouds(gp, oracle, scale, offset):
         np.testing.assert_array_equal(s["bid_increments"], st["bid_increments"])
 
 
-def test_emd_replay_cache_follows_the_data(gp, oracle):
-    """The forward call is replayed from a hipGraph once the same buffers have been seen twice: five calls
+def test_emd_repeated_calls_on_the_same_buffers(gp, oracle):
+    """Five calls
     on the SAME tensors with the inputs overwritten in place and the state re-initialised each time --
     every call's assignment and distances equal the oracle's for the data of that call."""
     torch = gp["torch"]
