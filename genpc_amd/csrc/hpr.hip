@@ -683,7 +683,7 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
                "hpr radix sort"))
         return 0;
     HprTile *tiles = (HprTile *)(ws + o_tiles);
-    static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // test knob: every tile examined
+    static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off (results unchanged)
     hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl);
     hipLaunchKernelGGL(hpr_tile_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, tiles);
     hipLaunchKernelGGL(hpr_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
