@@ -298,6 +298,8 @@ __device__ __forceinline__ int hpr_clip_inplace(double2 *p, int ss, int nv, int 
 // What a polygon can reach: its largest squared vertex norm D^2 and its support max_v (v . d) in the eight
 // directions d = (+-1, 0), (0, +-1), (+-1, +-1).  UPPER bounds suffice (they only feed conservative rejections),
 // and a clip only shrinks the polygon, so these are refreshed now and then, not after every clip.
+constexpr int kHprBatchA = 64;     // tiles per round of the accept pass
+
 struct HprReach {
     double d2, xp, xn, yp, yn, pp, pn, np, nn;
 };
@@ -375,6 +377,147 @@ __device__ __forceinline__ bool hpr_tile_needed(const HprFrame &f, double cpsi, 
 // tiles outward from the own one: step 0 = own, 1 = own + 1, 2 = own - 1, 3 = own + 2, ...
 __device__ __forceinline__ int hpr_tile_of(int step, int own) { return (step & 1) ? own + (step + 1) / 2 : own - step / 2; }
 
+// the tile a group of 128 consecutive listed points starts from: that of its middle point
+__device__ __forceinline__ int hpr_base_tile(const int *hl, int nhard, int rank)
+{
+    int mid = (rank / kHprThreads) * kHprThreads + kHprThreads / 2;
+    mid = mid < nhard ? mid : nhard - 1;
+    return hl[mid] / kHprThreads;
+}
+
+// Early accept.  If the point's own direction is already a separating normal -- u.p'_j < |p'_i| for every other
+// point, i.e. the origin of the (a, b) plane satisfies every constraint strictly -- the polygon contains a disc
+// around the origin and the point is visible; no polygon has to be built.  That is the case for most visible
+// points (on a smooth patch nothing projects farther along the point's own ray direction).  The test is one dot
+// product per candidate, tiles are skipped with the cone bound for the single normal n = u (D = 0), and the
+// margin (1e-8 of the larger |p'|) is far above anything roundoff does to the clipped polygon, so the answer
+// agrees with the full computation.  Points that fail go through hpr_kernel as before.
+__global__ __launch_bounds__(kHprThreads) void hpr_accept_kernel(int n, const double *__restrict__ fl_all, const int *__restrict__ perm,
+                                                                const HprTile *__restrict__ tiles_all, unsigned char *__restrict__ hard,
+                                                                unsigned char *__restrict__ vis, int *__restrict__ cnt, int accept_none)
+{
+    __shared__ double4 s_stage[kHprThreads];
+    __shared__ unsigned long long s_mask;
+    const int view = blockIdx.y, tid = threadIdx.x;
+    const double *fl = fl_all + (size_t)view * n * 3;
+    const int pos = blockIdx.x * kHprThreads + tid;
+    const int ntiles = ceil_div_dev(n, kHprThreads), own = blockIdx.x;
+    const HprTile *tiles = tiles_all + (size_t)view * ntiles;
+    HprFrame f;
+    bool active = false;
+    if (pos < n) active = hpr_frame(fl + (size_t)pos * 3, f);
+    const bool valid = active;
+    if (accept_none) active = false;           // measurement knob: every point goes through the polygon kernel
+    bool ok = active;
+    HprTile *s_rec = (HprTile *)s_stage;
+    for (int step0 = 0; step0 < 2 * ntiles; step0 += kHprBatchA) {
+        if (__syncthreads_count(active) == 0) break;
+        if (tid < kHprBatchA) {
+            const int tile = hpr_tile_of(step0 + tid, own);
+            if (tile >= 0 && tile < ntiles) s_rec[tid] = tiles[tile];
+        }
+        if (tid == 0) s_mask = 0ull;
+        __syncthreads();
+        unsigned long long mine = 0ull;
+        if (active) {
+            for (int b = 0; b < kHprBatchA; b++) {
+                const int tile = hpr_tile_of(step0 + b, own);
+                if (tile < 0 || tile >= ntiles) continue;
+                const HprTile &T = s_rec[b];
+                bool need = !(T.cos_phi > 0.0);
+                if (!need) {
+                    // max over the tile of u.q <= rho_max cos(max(0, angle(u, w) - phi)); needed unless that is
+                    // below |p'_i| minus the margin of the candidate test
+                    const double uw = f.ux * T.wx + f.uy * T.wy + f.uz * T.wz;
+                    const double rr = f.rho * (1.0 - 1e-7) * T.inv_rho_max;
+                    if (uw >= T.cos_phi * (1.0 - 1e-9)) {
+                        need = !(rr > 1.0);
+                    } else {
+                        const double rhs = rr - 1e-9 - T.cos_phi * uw;
+                        const double s2 = T.sin2_phi * ((1.0 - uw * uw) * (1.0 + 1e-9) + 1e-12);
+                        need = !(rhs > 0.0 && s2 < rhs * rhs);
+                    }
+                }
+                if (need) mine |= 1ull << b;
+            }
+        }
+        {
+            unsigned long long w = mine;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) w |= (unsigned long long)__shfl_xor((long long)w, o, kWave);
+            if ((tid & (kWave - 1)) == 0 && w) atomicOr(&s_mask, w);
+        }
+        __syncthreads();
+        unsigned long long todo = s_mask;
+        while (todo) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int tile = hpr_tile_of(step0 + b, own);
+            const int tile0 = tile * kHprThreads;
+            const int tn = min(kHprThreads, n - tile0);
+            {
+                double4 q = make_double4(__builtin_nan(""), 0.0, 0.0, 0.0);
+                if (tid < tn) {
+                    const double *g = fl + (size_t)(tile0 + tid) * 3;
+                    q = make_double4(g[0], g[1], g[2], 0.0);
+                }
+                s_stage[tid] = q;
+            }
+            __syncthreads();
+            if (active && ((mine >> b) & 1ull)) {
+                const double thr = 1e-8 * f.rho;
+                bool bad = false;
+#pragma unroll 8
+                for (int t = 0; t < kHprThreads; t++) {
+                    const double4 q = s_stage[t];          // rows past the end are NaN: the comparison below is false
+                    const double C = f.rho - (f.ux * q.x + f.uy * q.y + f.uz * q.z);
+                    const bool self = q.x == f.px && q.y == f.py && q.z == f.pz;
+                    bad |= !self && C < thr;
+                }
+                if (bad) { ok = false; active = false; }
+            }
+            __syncthreads();
+        }
+    }
+    if (pos < n) {
+        hard[(size_t)view * n + pos] = (valid && !ok) ? 1 : 0;
+        vis[(size_t)view * n + perm[pos]] = ok ? 1 : 0;          // (the polygon kernel overwrites its own points)
+    }
+    const int c = __syncthreads_count(ok);
+    if (tid == 0 && c) atomicAdd(&cnt[view], c);
+}
+
+// The points the accept pass left over, per view in Morton order: hardlist[view][rank] = position, hardcnt[view].
+// One block per view; an order-preserving scan (the order defines who shares a block of hpr_kernel).
+__global__ __launch_bounds__(1024) void hpr_compact_kernel(int n, const unsigned char *__restrict__ hard, int *__restrict__ hardlist,
+                                                          int *__restrict__ hardcnt)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_base;
+    const int view = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < n; p0 += 1024) {
+        const int pos = p0 + tid;
+        const bool h = pos < n && hard[(size_t)view * n + pos];
+        const unsigned long long bal = __ballot(h);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[wave] = __popcll(bal);
+        __syncthreads();
+        int wbase = 0, total = 0;
+        for (int w = 0; w < 16; w++) {
+            wbase += w < wave ? s_w[w] : 0;
+            total += s_w[w];
+        }
+        const int base = s_base;
+        if (h) hardlist[(size_t)view * n + base + wbase + before] = pos;
+        __syncthreads();
+        if (tid == 0) s_base = base + total;
+        __syncthreads();
+    }
+    if (tid == 0) hardcnt[view] = s_base;
+}
+
 constexpr int kHprBatch = 64;      // tiles tested per round (one bit each)
 constexpr int kHprRimStep = 8;     // after this many tiles ...
 constexpr double kHprRimD2 = 1.0e6; // ... a polygon with a vertex farther than 1000 from the origin is a silhouette point's
@@ -382,7 +525,8 @@ constexpr int kHprRimTiles = 256;  // ... and is handed to the second pass if th
 
 // status[0] = points handed to the second pass, status[1] = error (2: a polygon outgrew kHprOverCap)
 __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *__restrict__ fl_all, const int *__restrict__ perm,
-                                                         const HprTile *__restrict__ tiles_all, unsigned char *__restrict__ vis,
+                                                         const HprTile *__restrict__ tiles_all, const int *__restrict__ hardlist,
+                                                         const int *__restrict__ hardcnt, unsigned char *__restrict__ vis,
                                                          int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull)
 {
     __shared__ double2 s_poly[kHprMaxV * kHprThreads];
@@ -391,9 +535,15 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     static_assert(sizeof(HprTile) * kHprBatch <= sizeof(double4) * kHprThreads, "the tile records share the staging area");
     const int view = blockIdx.y, tid = threadIdx.x;
     const double *fl = fl_all + (size_t)view * n * 3;
-    const int pos = blockIdx.x * kHprThreads + tid;
-    const int i = pos < n ? perm[pos] : -1;
-    const int ntiles = ceil_div_dev(n, kHprThreads), own = blockIdx.x;
+    // block g of a view owns the points of rank 128 g .. 128 g + 127 in the view's list of points the accept pass
+    // left over; its tile order starts at the tile of its middle point (hpr_base_tile: the oracle's rule too)
+    const int nhard = hardcnt[view];
+    if ((int)blockIdx.x * kHprThreads >= nhard) return;
+    const int *hl = hardlist + (size_t)view * n;
+    const int rank = blockIdx.x * kHprThreads + tid;
+    const int pos = rank < nhard ? hl[rank] : -1;
+    const int i = pos >= 0 ? perm[pos] : -1;
+    const int ntiles = ceil_div_dev(n, kHprThreads), own = hpr_base_tile(hl, nhard, rank);
     const HprTile *tiles = tiles_all + (size_t)view * ntiles;
     HprFrame f;
     bool active = false;
@@ -410,49 +560,14 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
         R = hpr_reach(poly, kHprThreads, nv);
     }
     HprTile *s_rec = (HprTile *)s_stage;
-    // batches of 1, 1, 2, 4, ... 64 tiles: the polygon is the whole box at first (every tile "needed") and
-    // tight after the own tile and its neighbours, so the early batches are short
-    for (int step0 = 0, bsz = 1; step0 < 2 * ntiles; step0 += bsz, bsz = step0 < kHprBatch ? step0 : kHprBatch) {
-        // A polygon that still runs out to the box after the eight nearest tiles belongs to a point on the
-        // silhouette: it is cut by points all along the rim and holds its whole wave up for as many tiles as
-        // the cloud has -- in a large cloud such points go to the second pass, which puts a wave on each
-        // (measured: 2 x 165546 points 77 -> 51 ms; 64 x 10000 points 29 -> 32 ms, hence the size rule).
-        if (step0 == kHprRimStep && ntiles >= kHprRimTiles && active && R.d2 > kHprRimD2 && !(no_cull & 8)) {
-            over_list[atomicAdd(&status[0], 1)] = view * n + pos;
-            nv = -1;
-            active = false;
-        }
-        if (__syncthreads_count(active) == 0) break;
-        // which of the next tiles can still cut somebody's polygon (tested against the polygon as it is now:
-        // it only shrinks, so a tile found out of reach stays out of reach)
-        if (tid < bsz) {
-            const int tile = hpr_tile_of(step0 + tid, own);
-            if (tile >= 0 && tile < ntiles) s_rec[tid] = tiles[tile];
-        }
-        if (tid == 0) s_mask = 0ull;
-        __syncthreads();
-        unsigned long long mine = 0ull;
-        if (active) {
-            R = hpr_reach(poly, kHprThreads, nv);
-            const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15), cpsi = 1.0 / l, spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
-            for (int b = 0; b < bsz; b++) {
-                const int tile = hpr_tile_of(step0 + b, own);
-                if (tile < 0 || tile >= ntiles) continue;
-                if ((no_cull & 1) || hpr_tile_needed(f, cpsi, spsi, poly, kHprThreads, nv, s_rec[b])) mine |= 1ull << b;
-            }
-        }
-        {
-            unsigned long long w = mine;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) w |= (unsigned long long)__shfl_xor((long long)w, o, kWave);
-            if ((tid & (kWave - 1)) == 0 && w) atomicOr(&s_mask, w);
-        }
-        __syncthreads();
-        unsigned long long todo = s_mask;
-        while (todo) {
-            const int b = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int tile0 = hpr_tile_of(step0 + b, own) * kHprThreads;
+    const int home = pos >= 0 ? pos / kHprThreads : -0x40000000;      // the tile this point lies in
+    // Stage one tile of candidates and let the lanes that want it clip against it.  Pass 1 over the tile, the
+    // same for every lane: which candidates are not provably out of reach (one bit each).  Pass 2: every lane
+    // takes ITS marked candidates in order -- the lanes of a wave run their k-th marked candidate together, so
+    // the wave pays for the longest list, not for the sum of all of them (clipping candidate by candidate as
+    // they come costs 10x more: the lanes meet their cuts at different candidates).
+    auto take_tile = [&](int tile, bool wanted) {
+        const int tile0 = tile * kHprThreads;
             const int tn = min(kHprThreads, n - tile0);
             {
                 // rows past the end are NaN: they cut nothing
@@ -464,12 +579,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                 s_stage[tid] = q;
             }
             __syncthreads();
-            if (active && ((mine >> b) & 1ull)) {
-                // Pass 1 over the tile, the same for every lane: which candidates are not provably out of reach
-                // (one bit each).  Pass 2: every lane takes ITS marked candidates in order -- the lanes of a
-                // wave run their k-th marked candidate together, so the wave pays for the longest list, not
-                // for the sum of all of them (clipping candidate by candidate as they come costs 10x more:
-                // the lanes meet their cuts at different candidates).
+            if (active && wanted) {
                 R = hpr_reach(poly, kHprThreads, nv);
                 unsigned long long bits[2] = {0ull, 0ull};
 #pragma unroll
@@ -520,7 +630,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                         if (!out) continue;
                         if (out == nv) { nv = 0; active = false; break; }
                         if (nv - out + 2 > kHprMaxV) {
-                            over_list[atomicAdd(&status[0], 1)] = view * n + pos;
+                            over_list[atomicAdd(&status[0], 1)] = view * n + rank;
                             nv = -1;
                             active = false;
                             break;
@@ -532,6 +642,67 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                 }
             }
             __syncthreads();
+    };
+    // Phase 1: every point's home tile and its two neighbours, whatever the group's starting tile is (when few
+    // points are left over, the 128 of a block lie many tiles apart; a polygon that has not met its nearest
+    // neighbours first stays large for a long time).
+    {
+        const int first_home = hl[blockIdx.x * kHprThreads] / kHprThreads;
+        const int last_rank = min(nhard, (int)(blockIdx.x + 1) * kHprThreads) - 1;
+        const int last_home = hl[last_rank] / kHprThreads;
+        for (int rel = 0; rel < 3; rel++) {            // home, home + 1, home - 1: nearest first
+            const int d = rel == 0 ? 0 : (rel == 1 ? 1 : -1);
+            for (int tile = max(first_home + d, 0); tile <= min(last_home + d, ntiles - 1); tile++) {
+                const bool wanted = active && tile == home + d;
+                if (__syncthreads_count(wanted) == 0) continue;
+                take_tile(tile, wanted);
+            }
+        }
+    }
+    // Phase 2: all other tiles, outward from the group's starting tile, in batches of 1, 1, 2, 4, ... 64 whose
+    // records are tested first (the polygon is tight by now, most tiles are out of its reach)
+    for (int step0 = 0, bsz = 1; step0 < 2 * ntiles; step0 += bsz, bsz = step0 < kHprBatch ? step0 : kHprBatch) {
+        // A polygon that still runs out to the box after the eight nearest tiles belongs to a point on the
+        // silhouette: it is cut by points all along the rim and holds its whole wave up for as many tiles as
+        // the cloud has -- in a large cloud such points go to the second pass, which puts a wave on each
+        // (measured: 2 x 165546 points 77 -> 51 ms; 64 x 10000 points 29 -> 32 ms, hence the size rule).
+        if (step0 == kHprRimStep && ntiles >= kHprRimTiles && active && R.d2 > kHprRimD2 && !(no_cull & 8)) {
+            over_list[atomicAdd(&status[0], 1)] = view * n + rank;
+            nv = -1;
+            active = false;
+        }
+        if (__syncthreads_count(active) == 0) break;
+        // which of the next tiles can still cut somebody's polygon (tested against the polygon as it is now:
+        // it only shrinks, so a tile found out of reach stays out of reach)
+        if (tid < bsz) {
+            const int tile = hpr_tile_of(step0 + tid, own);
+            if (tile >= 0 && tile < ntiles) s_rec[tid] = tiles[tile];
+        }
+        if (tid == 0) s_mask = 0ull;
+        __syncthreads();
+        unsigned long long mine = 0ull;
+        if (active) {
+            R = hpr_reach(poly, kHprThreads, nv);
+            const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15), cpsi = 1.0 / l, spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
+            for (int b = 0; b < bsz; b++) {
+                const int tile = hpr_tile_of(step0 + b, own);
+                if (tile < 0 || tile >= ntiles) continue;
+                if (tile >= home - 1 && tile <= home + 1) continue;          // taken in phase 1
+                if ((no_cull & 1) || hpr_tile_needed(f, cpsi, spsi, poly, kHprThreads, nv, s_rec[b])) mine |= 1ull << b;
+            }
+        }
+        {
+            unsigned long long w = mine;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) w |= (unsigned long long)__shfl_xor((long long)w, o, kWave);
+            if ((tid & (kWave - 1)) == 0 && w) atomicOr(&s_mask, w);
+        }
+        __syncthreads();
+        unsigned long long todo = s_mask;
+        while (todo) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            take_tile(hpr_tile_of(step0 + b, own), ((mine >> b) & 1ull) != 0ull);
         }
     }
     const bool seen = i >= 0 && nv > 0;
@@ -548,13 +719,16 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
 __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double *__restrict__ fl_all,
                                                              const HprTile *__restrict__ tiles_all, unsigned char *__restrict__ vis,
                                                              int *__restrict__ cnt, int *status, const int *__restrict__ list,
-                                                             const int *__restrict__ perm, int no_cull)
+                                                             const int *__restrict__ perm, const int *__restrict__ hardlist,
+                                                             const int *__restrict__ hardcnt, int no_cull)
 {
     __shared__ double2 s_buf[2][kHprOverCap];
     const int lane = threadIdx.x;
-    const int id = list[blockIdx.x], view = id / n, pos = id - view * n, i = perm[pos];
+    const int id = list[blockIdx.x], view = id / n, rank = id - view * n;
+    const int *hl = hardlist + (size_t)view * n;
+    const int pos = hl[rank], i = perm[pos];
     const double *fl = fl_all + (size_t)view * n * 3;
-    const int ntiles = ceil_div_dev(n, kHprThreads), own = pos / kHprThreads;
+    const int ntiles = ceil_div_dev(n, kHprThreads), own = hpr_base_tile(hl, hardcnt[view], rank);
     const HprTile *tiles = tiles_all + (size_t)view * ntiles;
     HprFrame f;
     if (!hpr_frame(fl + (size_t)pos * 3, f)) return;      // (cannot happen: the first pass listed it)
@@ -567,18 +741,10 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     }
     __syncthreads();
     HprReach R = hpr_reach(s_buf[0], 1, nv);
-    for (int step0 = 0, bsz = 1; step0 < 2 * ntiles && nv > 0; step0 += bsz, bsz = step0 < kWave ? step0 : kWave) {
-        bool need = false;
-        if (lane < bsz) {
-            const int tile = hpr_tile_of(step0 + lane, own);
-            const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15), cpsi = 1.0 / l, spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
-            if (tile >= 0 && tile < ntiles) need = (no_cull & 1) || hpr_tile_needed(f, cpsi, spsi, s_buf[cur], 1, nv, tiles[tile]);
-        }
-        unsigned long long todo = __ballot(need);
-        while (todo && nv > 0) {
-            const int b = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int tile0 = hpr_tile_of(step0 + b, own) * kHprThreads;
+    bool failed = false;
+    // one tile of candidates against the polygon (64 lanes = 64 candidates at a time)
+    auto take_tile = [&](int tile) {
+        const int tile0 = tile * kHprThreads;
             for (int base = tile0; base < tile0 + kHprThreads && base < n && nv > 0; base += kWave) {
                 const int j = base + lane;
                 double A = 0.0, B = 0.0, C = 0.0;
@@ -605,7 +771,9 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                     if (out == nv) { nv = 0; break; }
                     if (nv - out + 2 > kHprOverCap) {
                         if (lane == 0) atomicExch(&status[1], 2);
-                        return;
+                        failed = true;
+                        nv = 0;
+                        break;
                     }
                     int m = 0;
                     if (lane == 0) m = hpr_clip(src, 1, nv, Aj, Bj, Cj, s_buf[cur ^ 1], 1);
@@ -617,8 +785,29 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                     R = hpr_reach(s_buf[cur], 1, nv);      // (every lane the same loop: broadcast reads)
                 }
             }
+    };
+    // the same order as the first pass: the home tile and its neighbours, then outward from the group's tile
+    const int home = pos / kHprThreads;
+    for (int rel = 0; rel < 3 && nv > 0; rel++) {
+        const int tile = home + (rel == 0 ? 0 : (rel == 1 ? 1 : -1));
+        if (tile >= 0 && tile < ntiles) take_tile(tile);
+    }
+    for (int step0 = 0, bsz = 1; step0 < 2 * ntiles && nv > 0; step0 += bsz, bsz = step0 < kWave ? step0 : kWave) {
+        bool need = false;
+        if (lane < bsz) {
+            const int tile = hpr_tile_of(step0 + lane, own);
+            const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15), cpsi = 1.0 / l, spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
+            if (tile >= 0 && tile < ntiles && !(tile >= home - 1 && tile <= home + 1))
+                need = (no_cull & 1) || hpr_tile_needed(f, cpsi, spsi, s_buf[cur], 1, nv, tiles[tile]);
+        }
+        unsigned long long todo = __ballot(need);
+        while (todo && nv > 0) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            take_tile(hpr_tile_of(step0 + b, own));
         }
     }
+    if (failed) return;
     if (lane == 0) {
         vis[(size_t)view * n + i] = nv > 0 ? 1 : 0;
         if (nv > 0) atomicAdd(&cnt[view], 1);
@@ -666,6 +855,9 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     const size_t o_tmp = off; off += up(sort_bytes);
     const int ntiles = ceil_div(n, kHprThreads);
     const size_t o_tiles = off; off += up((size_t)c * ntiles * sizeof(HprTile));
+    const size_t o_hard = off; off += up(total);
+    const size_t o_hl = off; off += up(total * sizeof(int));
+    const size_t o_hc = off; off += up((size_t)c * sizeof(int));
     char *ws = (char *)workspace(17, off, stream);
     if (!ws) return 0;
     int *status = (int *)ws;
@@ -683,11 +875,16 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
                "hpr radix sort"))
         return 0;
     HprTile *tiles = (HprTile *)(ws + o_tiles);
-    static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off (results unchanged)
+    static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept (results unchanged)
     hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl);
     hipLaunchKernelGGL(hpr_tile_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, tiles);
+    unsigned char *hard = (unsigned char *)(ws + o_hard);
+    int *hardlist = (int *)(ws + o_hl), *hardcnt = (int *)(ws + o_hc);
+    hipLaunchKernelGGL(hpr_accept_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
+                       (const HprTile *)tiles, hard, visible, counts, (no_cull & 16) ? 1 : 0);
+    hipLaunchKernelGGL(hpr_compact_kernel, dim3(c), dim3(1024), 0, stream, n, (const unsigned char *)hard, hardlist, hardcnt);
     hipLaunchKernelGGL(hpr_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
-                       (const HprTile *)tiles, visible, counts, status, list, no_cull);
+                       (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull);
     if (!check(hipGetLastError(), "hpr launch")) return 0;
     // the second pass is sized from the first one's count: the one host round trip of this entry
     int st[2] = {0, 0};
@@ -696,7 +893,7 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     if (second_pass_points) *second_pass_points = st[0];
     if (st[0] > 0) {
         hipLaunchKernelGGL(hpr_overflow_kernel, dim3(st[0]), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
-                           visible, counts, status, (const int *)list, (const int *)i1, no_cull);
+                           visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist, (const int *)hardcnt, no_cull);
         if (!check(hipGetLastError(), "hpr second pass launch")) return 0;
         if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
         if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;

@@ -21,8 +21,10 @@
  * 89.994 degrees are not considered: the one deviation from the hull definition, besides roundoff -- qhull
  * merges facets within its own tolerance).  Exact duplicates clip nothing (both copies are reported).
  * The points are put in 3-D Morton order of the cloud's bounding box (30-bit keys, ties by index) and cut into
- * tiles of HPR_TILE; a point takes the candidates tile by tile outward from its own tile (own, +1, -1, +2, ...)
- * -- the order the GPU streams them in.  The order has no influence beyond the last bits of the polygon vertices.
+ * tiles of HPR_TILE; points whose own direction already separates them are accepted at once (see below); the
+ * others are taken, in Morton order, in groups of HPR_TILE, and a point takes the candidates tile by tile: its
+ * home tile and the two next to it, then outward from its group's starting tile (s, s+1, s-1, s+2, ...) -- the
+ * order the GPU streams them in.  The order has no influence beyond the last bits of the polygon vertices.
  * Everything is double, operation order spelled out, -ffp-contract=off.
  * Pinned against oracle/hpr.py (qhull) in tests/test_oracle_numpy.py.
  */
@@ -137,14 +139,42 @@ ORACLE_API int oracle_hpr_visibility(int n, const float *pts, const double *eye,
     if (!fl || !perm) { free(fl); free(perm); return -1; }
     morton_order(n, pts, perm);
     flip_points(n, pts, perm, eye, radius, fl);
+    /* Early accept (hpr.hip: hpr_accept_kernel): the point's own direction u is already a separating normal
+     * when u.p'_j < |p'_i| for every other point (margin 1e-8 |p'_i|): the origin of the (a, b) plane is
+     * strictly feasible, the point is visible and no polygon is built. */
+    uint8_t *hard = (uint8_t *)calloc((size_t)(n > 0 ? n : 1), 1);
+    int *hl = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    if (!hard || !hl) { free(fl); free(perm); free(hard); free(hl); return -1; }
     int total = 0, bad = 0, mv = 0;
-#pragma omp parallel for schedule(dynamic, 16) reduction(+ : total) reduction(| : bad) reduction(max : mv)
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : total)
     for (int i = 0; i < n; i++) {
-        double pa[HPR_MAXV + 2], pb[HPR_MAXV + 2], ta[HPR_MAXV + 2], tb[HPR_MAXV + 2];
         const double px = fl[3 * i], py = fl[3 * i + 1], pz = fl[3 * i + 2];
         const double rho = sqrt(px * px + py * py + pz * pz);
         vis[perm[i]] = 0;
         if (!(rho > 0.0) || !(rho < INFINITY)) continue;        /* coincides with the origin / not finite */
+        const double ux = px / rho, uy = py / rho, uz = pz / rho;
+        const double thr = 1e-8 * rho;
+        int ok = 1;
+        for (int j = 0; j < n && ok; j++) {
+            const double qx = fl[3 * j], qy = fl[3 * j + 1], qz = fl[3 * j + 2];
+            if (qx == px && qy == py && qz == pz) continue;
+            const double C = rho - (ux * qx + uy * qy + uz * qz);
+            if (C < thr) ok = 0;
+        }
+        if (ok) { vis[perm[i]] = 1; total++; }
+        else hard[i] = 1;
+    }
+    /* the rest, in Morton order, in groups of HPR_TILE that share a starting tile (that of the group's middle
+     * point): the blocks of hpr_kernel */
+    int nhard = 0;
+    for (int i = 0; i < n; i++)
+        if (hard[i]) hl[nhard++] = i;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : total) reduction(| : bad) reduction(max : mv)
+    for (int r = 0; r < nhard; r++) {
+        const int i = hl[r];
+        double pa[HPR_MAXV + 2], pb[HPR_MAXV + 2], ta[HPR_MAXV + 2], tb[HPR_MAXV + 2];
+        const double px = fl[3 * i], py = fl[3 * i + 1], pz = fl[3 * i + 2];
+        const double rho = sqrt(px * px + py * py + pz * pz);
         const double ux = px / rho, uy = py / rho, uz = pz / rho;
         /* e1 = normalise(u x axis of u's smallest component), e2 = u x e1 */
         const double ax = fabs(ux), ay = fabs(uy), az = fabs(uz);
@@ -160,27 +190,40 @@ ORACLE_API int oracle_hpr_visibility(int n, const float *pts, const double *eye,
         pa[1] = HPR_BOX;  pb[1] = -HPR_BOX;
         pa[2] = HPR_BOX;  pb[2] = HPR_BOX;
         pa[3] = -HPR_BOX; pb[3] = HPR_BOX;
-        const int ntiles = (n + HPR_TILE - 1) / HPR_TILE, own = i / HPR_TILE;
-        for (int jj = 0; jj < 2 * ntiles * HPR_TILE && nv > 0; jj++) {
-            const int step = jj / HPR_TILE;
-            const int tile = (step & 1) ? own + (step + 1) / 2 : own - step / 2;
-            const int j = tile * HPR_TILE + (jj - step * HPR_TILE);
-            if (tile < 0 || tile >= ntiles || j >= n) continue;
-            const double qx = fl[3 * j], qy = fl[3 * j + 1], qz = fl[3 * j + 2];
-            if (qx == px && qy == py && qz == pz) continue;        /* the point itself, or an exact duplicate */
-            const double A = e1x * qx + e1y * qy + e1z * qz;
-            const double B = e2x * qx + e2y * qy + e2z * qz;
-            const double C = rho - (ux * qx + uy * qy + uz * qz);
-            int any = 0;
-            for (int k = 0; k < nv; k++) any |= (pa[k] * A + pb[k] * B - C > 0.0);
-            if (!any) continue;
-            if (nv + 2 > HPR_MAXV) { bad = 1; nv = 0; break; }
-            clip(pa, pb, &nv, A, B, C, ta, tb);
-            if (nv < 3) nv = 0;            /* no interior left: not strictly extreme */
-            if (nv > mv) mv = nv;
+        int mid = (r / HPR_TILE) * HPR_TILE + HPR_TILE / 2;
+        if (mid > nhard - 1) mid = nhard - 1;
+        const int ntiles = (n + HPR_TILE - 1) / HPR_TILE, own = hl[mid] / HPR_TILE, home = i / HPR_TILE;
+        /* candidate order: the point's home tile, the next, the previous, then every other tile
+         * outward from the group's starting tile */
+        for (int seq = 0; seq < 3 + 2 * ntiles && nv > 0; seq++) {
+            int tile;
+            if (seq < 3) {
+                tile = home + (seq == 0 ? 0 : (seq == 1 ? 1 : -1));
+            } else {
+                const int step = seq - 3;
+                tile = (step & 1) ? own + (step + 1) / 2 : own - step / 2;
+                if (tile >= home - 1 && tile <= home + 1) continue;
+            }
+            if (tile < 0 || tile >= ntiles) continue;
+            for (int j = tile * HPR_TILE; j < (tile + 1) * HPR_TILE && j < n && nv > 0; j++) {
+                const double qx = fl[3 * j], qy = fl[3 * j + 1], qz = fl[3 * j + 2];
+                if (qx == px && qy == py && qz == pz) continue;        /* the point itself, or an exact duplicate */
+                const double A = e1x * qx + e1y * qy + e1z * qz;
+                const double B = e2x * qx + e2y * qy + e2z * qz;
+                const double C = rho - (ux * qx + uy * qy + uz * qz);
+                int any = 0;
+                for (int k = 0; k < nv; k++) any |= (pa[k] * A + pb[k] * B - C > 0.0);
+                if (!any) continue;
+                if (nv + 2 > HPR_MAXV) { bad = 1; nv = 0; break; }
+                clip(pa, pb, &nv, A, B, C, ta, tb);
+                if (nv < 3) nv = 0;            /* no interior left: not strictly extreme */
+                if (nv > mv) mv = nv;
+            }
         }
         if (nv > 0) { vis[perm[i]] = 1; total++; }
     }
+    free(hard);
+    free(hl);
     free(fl);
     free(perm);
     if (max_vertices) *max_vertices = mv;
