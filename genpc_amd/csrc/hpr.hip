@@ -11,26 +11,33 @@
 //       a (e1.p'_j) + b (e2.p'_j) <= |p'_i| - u.p'_j
 // The feasible (a, b) are a convex polygon -- the cross-section of the vertex's normal cone; for the
 // reference's large radii it is the power cell of point i among the cloud's directions, weighted by depth --
-// and the point is visible iff the polygon survives clipping by every other point.  One thread owns one
-// (view, point): the polygon lives in LDS ([vertex][thread], <= kHprMaxV vertices), the candidates stream
-// through LDS tiles that the whole block reads at the same address (broadcast), and a candidate that cannot
-// reach the polygon (Cauchy-Schwarz against the polygon's largest vertex norm, with a 1e-9 margin: it never
-// rejects a candidate that would clip) costs 3 dot products.  Polygons that outgrow kHprMaxV (regular
-// lattices: many cospherical neighbours) are redone by a second kernel, one wave per point, with room for 1024 vertices.
+// and the point is visible iff the polygon survives clipping by every other point.
+//
+// Pipeline (one call = all viewpoints):
+//   hpr_bounds / hpr_key / hipcub sort   per view, the points in 2-D Morton order of their DIRECTION from the
+//                         eye: a surface and what it hides become neighbours, so a hidden point meets its
+//                         occluders at once.  The order never changes a result, only when it is reached.
+//   hpr_flip_kernel       p' per (view, position), fp64
+//   hpr_tile_kernel       per tile of 128 consecutive positions: axis, half-angle, largest |p'| of its directions
+//   hpr_accept_kernel     u itself separates (u.p'_j < |p'_i| for all j: the origin of the (a, b) plane strictly
+//                         feasible): visible, no polygon -- one dot product per candidate
+//   hpr_compact_kernel    the left-over positions per view, in order
+//   hpr_kernel            one thread per left-over (view, point), polygon in LDS ([vertex][thread], <= kHprMaxV):
+//                         (1) the point's home tile, the next, the previous; (2) one interior point of the
+//                         polygon tried as THE normal against everything (strictly feasible: visible);
+//                         (3) all other tiles outward from the group's tile, tiles whose cone cannot reach
+//                         the polygon skipped whole, candidates filtered by two reach bounds, then clipped
+//   hpr_overflow_kernel   polygons that outgrow kHprMaxV, and in large clouds silhouette points: one wave each
+// Every skip and every early decision is conservative (margins 1e-7 .. 1e-10 against fp64 roundoff of 1e-16),
+// so the mask is that of clipping every polygon by every point.
 //
 // All arithmetic is double with contraction OFF and the operation order of oracle/genpc_oracle_hpr.c, which
-// processes the candidates in the same (input) order: the two produce the same polygons bit for bit, hence
-// the same mask.  That restatement is pinned against qhull (scipy) on random clouds, real scans and lattices.
-// Deviations from the hull definition: normals tilted from u by more than atan(1e4) are not considered;
-// exact duplicates clip nothing (every copy is reported; qhull keeps one).
+// restates the ordering, the accept test, the grouping and the candidate order: the two produce the same
+// polygons bit for bit, hence the same mask.  That restatement is pinned against qhull (scipy) on random clouds,
+// real scans and lattices.  Deviations from the hull definition: normals tilted from u by more than atan(1e4)
+// are not considered; exact duplicates clip nothing (every copy is reported; qhull keeps one).
 //
-// Points are put in 3-D Morton order (one hipcub sort per call).  A block owns 128 consecutive points and
-// takes the candidates tile by tile (128 consecutive points), outward from its own tile: own, +1, -1, +2, ...
-// The polygon is tight after the first tiles, and a tile whose cone of directions (axis, half-angle, largest
-// |p'|: hpr_tile_kernel) cannot reach any vertex of it is skipped whole -- a conservative test, so the result
-// is that of examining every candidate.  oracle/genpc_oracle_hpr.c takes the candidates in the same order.
-//
-// Cost: c * n^2 candidate tests (64 views x 10000 points: 6.4e9); see DESIGN.md.
+// Measured numbers and the steps that led here: DESIGN.md section 4.6.
 #include "common.h"
 #include "../../include/genpc_hip.h"
 
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(256) void hpr_flip_kernel(int n, const float *__res
 {
     const int pos = blockIdx.x * 256 + threadIdx.x, view = blockIdx.y;
     if (pos >= n) return;
-    const int i = perm[pos];
+    const int i = perm[(size_t)view * n + pos];
     const double vx = (double)pts[(size_t)i * 3 + 0] - eyes[view * 3 + 0];
     const double vy = (double)pts[(size_t)i * 3 + 1] - eyes[view * 3 + 1];
     const double vz = (double)pts[(size_t)i * 3 + 2] - eyes[view * 3 + 2];
@@ -106,36 +113,76 @@ __global__ __launch_bounds__(256) void hpr_bounds_kernel(int n, const float *__r
     }
 }
 
-__device__ __forceinline__ unsigned hpr_spread10(unsigned v)      // 10 bits -> every third bit
+__device__ __forceinline__ unsigned hpr_spread10(unsigned v)      // 10 bits -> every second bit
 {
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
     return v;
 }
 
-// 30-bit Morton key of every point in the cloud's bounding box (non-finite points last).  The key only decides
-// which points share a wave -- it has no influence on the result.
-__global__ __launch_bounds__(256) void hpr_key_kernel(int n, const float *__restrict__ pts, const unsigned *__restrict__ bounds,
-                                                     unsigned *__restrict__ keys, int *__restrict__ idx)
+// The frame in which a view's directions are ordered: w = towards the centre of the cloud's bounding box,
+// (E1, E2) the completion hpr_frame uses, s = the largest |x|, |y| a direction to a point of the box can have
+// (sine of the bounding sphere's angular radius, 5 % slack; 1 when the eye is inside that sphere).
+struct HprViewFrame {
+    double e1x, e1y, e1z, e2x, e2y, e2z, s;
+};
+
+__device__ __forceinline__ HprViewFrame hpr_view_frame(const unsigned *bounds, const double *eye)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    unsigned key = 0;
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float v = pts[(size_t)i * 3 + k];
-        const float lo = hpr_unord(bounds[k]), hi = hpr_unord(bounds[3 + k]);
-        if (!(fabsf(v) < __builtin_inff())) { ok = false; continue; }
-        const float w = hi - lo;
-        float q = w > 0.0f ? (v - lo) / w * 1023.0f : 0.0f;
-        q = q < 0.0f ? 0.0f : (q > 1023.0f ? 1023.0f : q);
-        key |= hpr_spread10((unsigned)q) << k;
+    const double lx = (double)hpr_unord(bounds[0]), ly = (double)hpr_unord(bounds[1]), lz = (double)hpr_unord(bounds[2]);
+    const double hx = (double)hpr_unord(bounds[3]), hy = (double)hpr_unord(bounds[4]), hz = (double)hpr_unord(bounds[5]);
+    double wx = (lx + hx) * 0.5 - eye[0], wy = (ly + hy) * 0.5 - eye[1], wz = (lz + hz) * 0.5 - eye[2];
+    const double dist = sqrt(wx * wx + wy * wy + wz * wz);
+    const double hd = 0.5 * sqrt((hx - lx) * (hx - lx) + (hy - ly) * (hy - ly) + (hz - lz) * (hz - lz));
+    HprViewFrame v;
+    if (dist > 0.0 && dist < __builtin_inf()) { wx /= dist; wy /= dist; wz /= dist; }
+    else { wx = 0.0; wy = 0.0; wz = 1.0; }
+    const double ax = fabs(wx), ay = fabs(wy), az = fabs(wz);
+    double x, y, z;
+    if (ax <= ay && ax <= az) { x = 0.0; y = wz; z = -wy; }
+    else if (ay <= az)        { x = -wz; y = 0.0; z = wx; }
+    else                      { x = wy; y = -wx; z = 0.0; }
+    const double l = sqrt(x * x + y * y + z * z);
+    v.e1x = x / l; v.e1y = y / l; v.e1z = z / l;
+    v.e2x = wy * v.e1z - wz * v.e1y;
+    v.e2y = wz * v.e1x - wx * v.e1z;
+    v.e2z = wx * v.e1y - wy * v.e1x;
+    double s = 1.0;
+    if (dist > hd) {
+        s = 1.05 * hd / dist;
+        s = s < 1.0 ? s : 1.0;
     }
-    keys[i] = ok ? key : 0xffffffffu;
-    idx[i] = i;
+    v.s = s > 0.0 ? s : 1.0;
+    return v;
+}
+
+// Sort key of (view, point): view << 20 | 2-D Morton code of the point's DIRECTION from the eye, 10 bits per
+// axis over [-s, s]^2 (non-finite points last within their view).  Points that lie in the same direction --
+// a front surface and what it hides -- become neighbours; the order has no influence on the result.
+__global__ __launch_bounds__(256) void hpr_key_kernel(int n, const float *__restrict__ pts, const unsigned *__restrict__ bounds,
+                                                     const double *__restrict__ eyes, unsigned *__restrict__ keys, int *__restrict__ idx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, view = blockIdx.y;
+    if (i >= n) return;
+    const HprViewFrame V = hpr_view_frame(bounds, eyes + view * 3);
+    const double vx = (double)pts[(size_t)i * 3 + 0] - eyes[view * 3 + 0];
+    const double vy = (double)pts[(size_t)i * 3 + 1] - eyes[view * 3 + 1];
+    const double vz = (double)pts[(size_t)i * 3 + 2] - eyes[view * 3 + 2];
+    const double r = sqrt(vx * vx + vy * vy + vz * vz);
+    unsigned key = 0xfffffu;
+    if (r > 0.0 && r < __builtin_inf()) {
+        const double dx = vx / r, dy = vy / r, dz = vz / r;
+        const double x = dx * V.e1x + dy * V.e1y + dz * V.e1z;
+        const double y = dx * V.e2x + dy * V.e2y + dz * V.e2z;
+        double qx = floor((x / V.s + 1.0) * 512.0), qy = floor((y / V.s + 1.0) * 512.0);
+        qx = qx < 0.0 ? 0.0 : (qx > 1023.0 ? 1023.0 : qx);
+        qy = qy < 0.0 ? 0.0 : (qy > 1023.0 ? 1023.0 : qy);
+        key = hpr_spread10((unsigned)qx) | (hpr_spread10((unsigned)qy) << 1);
+    }
+    keys[(size_t)view * n + i] = ((unsigned)view << 20) | key;
+    idx[(size_t)view * n + i] = i;
 }
 
 __device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
@@ -481,7 +528,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_accept_kernel(int n, const do
     }
     if (pos < n) {
         hard[(size_t)view * n + pos] = (valid && !ok) ? 1 : 0;
-        vis[(size_t)view * n + perm[pos]] = ok ? 1 : 0;          // (the polygon kernel overwrites its own points)
+        vis[(size_t)view * n + perm[(size_t)view * n + pos]] = ok ? 1 : 0;          // (the polygon kernel overwrites its own points)
     }
     const int c = __syncthreads_count(ok);
     if (tid == 0 && c) atomicAdd(&cnt[view], c);
@@ -542,7 +589,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     const int *hl = hardlist + (size_t)view * n;
     const int rank = blockIdx.x * kHprThreads + tid;
     const int pos = rank < nhard ? hl[rank] : -1;
-    const int i = pos >= 0 ? perm[pos] : -1;
+    const int i = pos >= 0 ? perm[(size_t)view * n + pos] : -1;
     const int ntiles = ceil_div_dev(n, kHprThreads), own = hpr_base_tile(hl, nhard, rank);
     const HprTile *tiles = tiles_all + (size_t)view * ntiles;
     HprFrame f;
@@ -580,29 +627,25 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
             }
             __syncthreads();
             if (active && wanted) {
-                R = hpr_reach(poly, kHprThreads, nv);
-                unsigned long long bits[2] = {0ull, 0ull};
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    unsigned long long m = 0ull;
+                // 32 candidates at a time: the marks are taken against the polygon as the previous 32 left it (while
+                // the polygon is still the box every candidate is marked; after the nearest few it is tight and
+                // almost none are)
+                for (int c0 = 0; c0 < kHprThreads && active; c0 += 32) {
+                    R = hpr_reach(poly, kHprThreads, nv);
+                    unsigned m = 0u;
 #pragma unroll 4
-                    for (int t = 0; t < 64; t++) {
-                        const double4 q = s_stage[h * 64 + t];      // rows past the end are NaN
+                    for (int t = 0; t < 32; t++) {
+                        const double4 q = s_stage[c0 + t];      // rows past the end are NaN
                         const double A = f.e1x * q.x + f.e1y * q.y + f.e1z * q.z;
                         const double B = f.e2x * q.x + f.e2y * q.y + f.e2z * q.z;
                         const double C = f.rho - (f.ux * q.x + f.uy * q.y + f.uz * q.z);
                         const bool self = q.x == f.px && q.y == f.py && q.z == f.pz;      // the point itself, or an exact duplicate
-                        m |= (!self && q.x == q.x && !hpr_far(R, A, B, C)) ? (1ull << t) : 0ull;
+                        m |= (!self && q.x == q.x && !hpr_far(R, A, B, C)) ? (1u << t) : 0u;
                     }
-                    bits[h] = m;
-                }
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    unsigned long long m = bits[h];
                     while (m && active) {
-                        const int t = __ffsll((long long)m) - 1;
+                        const int t = __ffs((int)m) - 1;
                         m &= m - 1;
-                        const double4 q = s_stage[h * 64 + t];      // (recomputed: the same values)
+                        const double4 q = s_stage[c0 + t];      // (recomputed: the same values)
                         const double A = f.e1x * q.x + f.e1y * q.y + f.e1z * q.z;
                         const double B = f.e2x * q.x + f.e2y * q.y + f.e2z * q.z;
                         const double C = f.rho - (f.ux * q.x + f.uy * q.y + f.uz * q.z);
@@ -657,6 +700,109 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                 if (__syncthreads_count(wanted) == 0) continue;
                 take_tile(tile, wanted);
             }
+        }
+    }
+    // Verify phase.  The polygon now reflects the nearest neighbours; later candidates mostly shave its corners.
+    // Take its centroid (a*, b*) -- an interior point -- and test that ONE normal n = u + a* e1 + b* e2 against
+    // every other point: if a* A + b* B - C < 0 with room to spare for all of them, (a*, b*) is strictly feasible,
+    // the final polygon is not empty and the point is visible -- one dot product per candidate instead of the
+    // polygon machinery, and tiles skipped with the same cone bound (for a one-vertex polygon).  A lane that
+    // meets a counter-example goes on to phase 2 with its polygon untouched (the decision there is the same
+    // computation as without this phase).  This is the early accept of hpr_accept_kernel with a better normal.
+    // (Interior point: the centroid; for a polygon that runs out to the box, a point near its bounded end.)
+    if (!(no_cull & 32)) {
+        bool trying = active && nv >= 3;
+        double2 ctr = make_double2(0.0, 0.0);
+        if (trying) {
+            // the two vertices nearest the origin (v0, v1) and the centroid
+            double2 v0 = make_double2(0.0, 0.0), v1 = v0;
+            double r0 = __builtin_inf(), r1 = __builtin_inf();
+            for (int k = 0; k < nv; k++) {
+                const double2 v = poly[k * kHprThreads];
+                const double r2 = v.x * v.x + v.y * v.y;
+                ctr.x += v.x;
+                ctr.y += v.y;
+                if (r2 < r0) { r1 = r0; v1 = v0; r0 = r2; v0 = v; }
+                else if (r2 < r1) { r1 = r2; v1 = v; }
+            }
+            ctr.x /= (double)nv;
+            ctr.y /= (double)nv;
+            if (!(ctr.x * ctr.x + ctr.y * ctr.y < 1.0e6)) {
+                // The polygon runs out to the box (a point on the silhouette): its centroid is somewhere near
+                // the box.  Any point of the segment from a vertex to the centroid is interior: step from the
+                // vertex nearest the origin towards the centroid by the length of the polygon's near part.
+                const double dx = ctr.x - v0.x, dy = ctr.y - v0.y;
+                const double len = sqrt(dx * dx + dy * dy);
+                double h = sqrt((v1.x - v0.x) * (v1.x - v0.x) + (v1.y - v0.y) * (v1.y - v0.y));
+                h = h < 0.5 * len ? h : 0.5 * len;
+                trying = len > 0.0 && h > 0.0;
+                if (trying) {
+                    ctr.x = v0.x + h * (dx / len);
+                    ctr.y = v0.y + h * (dy / len);
+                }
+            }
+        }
+        const double nx = f.ux + ctr.x * f.e1x + ctr.y * f.e2x, ny = f.uy + ctr.x * f.e1y + ctr.y * f.e2y,
+                     nz = f.uz + ctr.x * f.e1z + ctr.y * f.e2z;
+        const double nn = 1.0 + ctr.x * ctr.x + ctr.y * ctr.y;
+        const double thr = 1e-10 * f.rho * nn;
+        // a one-vertex "polygon" in LDS slot kHprMaxV - 1?  No: hpr_tile_needed reads through a pointer -- give it
+        // a private copy (stride 0 is fine: one element)
+        const double cl = sqrt(nn) * (1.0 + 1e-15), cpsi1 = 1.0 / cl, spsi1 = sqrt(nn - 1.0) / cl * (1.0 + 1e-15);
+        for (int step0 = 0; step0 < 2 * ntiles; step0 += kHprBatch) {
+            if (__syncthreads_count(trying) == 0) break;
+            if (tid < kHprBatch) {
+                const int tile = hpr_tile_of(step0 + tid, own);
+                if (tile >= 0 && tile < ntiles) s_rec[tid] = tiles[tile];
+            }
+            if (tid == 0) s_mask = 0ull;
+            __syncthreads();
+            unsigned long long mine = 0ull;
+            if (trying) {
+                for (int b = 0; b < kHprBatch; b++) {
+                    const int tile = hpr_tile_of(step0 + b, own);
+                    if (tile < 0 || tile >= ntiles) continue;
+                    if ((no_cull & 1) || hpr_tile_needed(f, cpsi1, spsi1, &ctr, 0, 1, s_rec[b])) mine |= 1ull << b;
+                }
+            }
+            {
+                unsigned long long w = mine;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) w |= (unsigned long long)__shfl_xor((long long)w, o, kWave);
+                if ((tid & (kWave - 1)) == 0 && w) atomicOr(&s_mask, w);
+            }
+            __syncthreads();
+            unsigned long long todo = s_mask;
+            while (todo) {
+                const int b = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int tile0 = hpr_tile_of(step0 + b, own) * kHprThreads;
+                const int tn = min(kHprThreads, n - tile0);
+                {
+                    double4 q = make_double4(__builtin_nan(""), 0.0, 0.0, 0.0);
+                    if (tid < tn) {
+                        const double *g = fl + (size_t)(tile0 + tid) * 3;
+                        q = make_double4(g[0], g[1], g[2], 0.0);
+                    }
+                    s_stage[tid] = q;
+                }
+                __syncthreads();
+                if (trying && ((mine >> b) & 1ull)) {
+                    bool bad = false;
+#pragma unroll 8
+                    for (int t = 0; t < kHprThreads; t++) {
+                        const double4 q = s_stage[t];          // NaN rows: the comparison is false
+                        const double sv = (nx * q.x + ny * q.y + nz * q.z) - f.rho;
+                        const bool self = q.x == f.px && q.y == f.py && q.z == f.pz;
+                        bad |= !self && sv > -thr;
+                    }
+                    if (bad) trying = false;
+                }
+                __syncthreads();
+            }
+        }
+        if (trying) {              // no counter-example anywhere: visible
+            active = false;        // (nv >= 3 stays: reported as visible below)
         }
     }
     // Phase 2: all other tiles, outward from the group's starting tile, in batches of 1, 1, 2, 4, ... 64 whose
@@ -726,7 +872,7 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     const int lane = threadIdx.x;
     const int id = list[blockIdx.x], view = id / n, rank = id - view * n;
     const int *hl = hardlist + (size_t)view * n;
-    const int pos = hl[rank], i = perm[pos];
+    const int pos = hl[rank], i = perm[(size_t)view * n + pos];
     const double *fl = fl_all + (size_t)view * n * 3;
     const int ntiles = ceil_div_dev(n, kHprThreads), own = hpr_base_tile(hl, hardcnt[view], rank);
     const HprTile *tiles = tiles_all + (size_t)view * ntiles;
@@ -832,8 +978,8 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
         set_error("genpc_hpr_visibility: null pointer");
         return -1;
     }
-    if ((long long)c * n > (long long)INT_MAX || c > 65535) {
-        set_error("genpc_hpr_visibility: views x points too large");
+    if ((long long)c * n > (long long)INT_MAX || c > 4096) {
+        set_error("genpc_hpr_visibility: views x points too large (at most 4096 views per call)");
         return -1;
     }
     if (!check(hipMemsetAsync(counts, 0, sizeof(int) * (size_t)c, stream), "hipMemsetAsync(hpr counts)")) return 0;
@@ -841,17 +987,17 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     const size_t total = (size_t)c * n;
     size_t sort_bytes = 0;
     if (!check(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
-                                                  (const int *)nullptr, (int *)nullptr, n, 0, 32, stream),
+                                                  (const int *)nullptr, (int *)nullptr, (int)((size_t)c * n), 0, 32, stream),
                "hpr sort size"))
         return 0;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t off = 256;
     const size_t o_fl = off; off += up(total * 3 * sizeof(double));
     const size_t o_list = off; off += up(total * sizeof(int));
-    const size_t o_k0 = off; off += up((size_t)n * 4);
-    const size_t o_k1 = off; off += up((size_t)n * 4);
-    const size_t o_i0 = off; off += up((size_t)n * 4);
-    const size_t o_i1 = off; off += up((size_t)n * 4);
+    const size_t o_k0 = off; off += up(total * 4);
+    const size_t o_k1 = off; off += up(total * 4);
+    const size_t o_i0 = off; off += up(total * 4);
+    const size_t o_i1 = off; off += up(total * 4);
     const size_t o_tmp = off; off += up(sort_bytes);
     const int ntiles = ceil_div(n, kHprThreads);
     const size_t o_tiles = off; off += up((size_t)c * ntiles * sizeof(HprTile));
@@ -870,12 +1016,15 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     if (!check(hipMemsetAsync(bounds, 0xff, 12, stream), "hipMemsetAsync(hpr bounds)")) return 0;
     const int g256 = ceil_div(n, 256);
     hipLaunchKernelGGL(hpr_bounds_kernel, dim3(g256 < 1024 ? g256 : 1024), dim3(256), 0, stream, n, points, bounds);
-    hipLaunchKernelGGL(hpr_key_kernel, dim3(g256), dim3(256), 0, stream, n, points, (const unsigned *)bounds, k0, i0);
-    if (!check(hipcub::DeviceRadixSort::SortPairs(ws + o_tmp, sort_bytes, (const unsigned *)k0, k1, (const int *)i0, i1, n, 0, 32, stream),
+    hipLaunchKernelGGL(hpr_key_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const unsigned *)bounds, eyes, k0, i0);
+    int key_bits = 20;
+    while ((1 << (key_bits - 20)) < c) key_bits++;
+    if (!check(hipcub::DeviceRadixSort::SortPairs(ws + o_tmp, sort_bytes, (const unsigned *)k0, k1, (const int *)i0, i1, (int)total, 0, key_bits,
+                                                  stream),
                "hpr radix sort"))
         return 0;
     HprTile *tiles = (HprTile *)(ws + o_tiles);
-    static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept (results unchanged)
+    static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept, 32 = no verify phase (results unchanged)
     hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl);
     hipLaunchKernelGGL(hpr_tile_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, tiles);
     unsigned char *hard = (unsigned char *)(ws + o_hard);

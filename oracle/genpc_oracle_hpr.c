@@ -20,8 +20,8 @@
  * The polygon starts as the square |a|, |b| <= HPR_BOX (normals tilted from u_i by more than atan(HPR_BOX) =
  * 89.994 degrees are not considered: the one deviation from the hull definition, besides roundoff -- qhull
  * merges facets within its own tolerance).  Exact duplicates clip nothing (both copies are reported).
- * The points are put in 3-D Morton order of the cloud's bounding box (30-bit keys, ties by index) and cut into
- * tiles of HPR_TILE; points whose own direction already separates them are accepted at once (see below); the
+ * The points are ordered by the 2-D Morton code of their DIRECTION from the eye (20-bit keys, ties by index:
+ * points in the same direction -- a surface and what it hides -- are neighbours) and cut into tiles of HPR_TILE; points whose own direction already separates them are accepted at once (see below); the
  * others are taken, in Morton order, in groups of HPR_TILE, and a point takes the candidates tile by tile: its
  * home tile and the two next to it, then outward from its group's starting tile (s, s+1, s-1, s+2, ...) -- the
  * order the GPU streams them in.  The order has no influence beyond the last bits of the polygon vertices.
@@ -49,17 +49,19 @@ static int cmp_mkey(const void *a, const void *b)
     return x->idx < y->idx ? -1 : (x->idx > y->idx);
 }
 
-static uint32_t spread10(uint32_t v)
+static uint32_t spread10(uint32_t v)          /* 10 bits -> every second bit */
 {
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
     return v;
 }
 
-/* perm[pos] = index of the pos-th point in Morton order (hpr.hip: hpr_bounds_kernel, hpr_key_kernel, stable sort) */
-static void morton_order(int n, const float *pts, int *perm)
+/* perm[pos] = index of the pos-th point in the view's order: 2-D Morton code of the point's DIRECTION from the
+ * eye, in a frame whose axis points at the centre of the cloud's bounding box (hpr.hip: hpr_bounds_kernel,
+ * hpr_view_frame, hpr_key_kernel, stable sort).  The order only decides which candidates a point meets first. */
+static void view_order(int n, const float *pts, const double *eye, int *perm)
 {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = 0; i < n; i++)
@@ -69,19 +71,44 @@ static void morton_order(int n, const float *pts, int *perm)
             if (v < lo[k]) lo[k] = v;
             if (v > hi[k]) hi[k] = v;
         }
+    const double lx = (double)lo[0], ly = (double)lo[1], lz = (double)lo[2];
+    const double hx = (double)hi[0], hy = (double)hi[1], hz = (double)hi[2];
+    double wx = (lx + hx) * 0.5 - eye[0], wy = (ly + hy) * 0.5 - eye[1], wz = (lz + hz) * 0.5 - eye[2];
+    const double dist = sqrt(wx * wx + wy * wy + wz * wz);
+    const double hd = 0.5 * sqrt((hx - lx) * (hx - lx) + (hy - ly) * (hy - ly) + (hz - lz) * (hz - lz));
+    if (dist > 0.0 && dist < INFINITY) { wx /= dist; wy /= dist; wz /= dist; }
+    else { wx = 0.0; wy = 0.0; wz = 1.0; }
+    const double ax = fabs(wx), ay = fabs(wy), az = fabs(wz);
+    double x, y, z;
+    if (ax <= ay && ax <= az) { x = 0.0; y = wz; z = -wy; }
+    else if (ay <= az)        { x = -wz; y = 0.0; z = wx; }
+    else                      { x = wy; y = -wx; z = 0.0; }
+    const double l = sqrt(x * x + y * y + z * z);
+    const double e1x = x / l, e1y = y / l, e1z = z / l;
+    const double e2x = wy * e1z - wz * e1y, e2y = wz * e1x - wx * e1z, e2z = wx * e1y - wy * e1x;
+    double s = 1.0;
+    if (dist > hd) {
+        s = 1.05 * hd / dist;
+        s = s < 1.0 ? s : 1.0;
+    }
+    s = s > 0.0 ? s : 1.0;
     mkey_t *keys = (mkey_t *)malloc(sizeof(mkey_t) * (size_t)(n > 0 ? n : 1));
     for (int i = 0; i < n; i++) {
-        uint32_t key = 0;
-        int ok = 1;
-        for (int k = 0; k < 3; k++) {
-            const float v = pts[3 * i + k];
-            if (!(fabsf(v) < INFINITY)) { ok = 0; continue; }
-            const float w = hi[k] - lo[k];
-            float q = w > 0.0f ? (v - lo[k]) / w * 1023.0f : 0.0f;
-            q = q < 0.0f ? 0.0f : (q > 1023.0f ? 1023.0f : q);
-            key |= spread10((uint32_t)q) << k;
+        const double vx = (double)pts[3 * i + 0] - eye[0];
+        const double vy = (double)pts[3 * i + 1] - eye[1];
+        const double vz = (double)pts[3 * i + 2] - eye[2];
+        const double r = sqrt(vx * vx + vy * vy + vz * vz);
+        uint32_t key = 0xfffffu;
+        if (r > 0.0 && r < INFINITY) {
+            const double dx = vx / r, dy = vy / r, dz = vz / r;
+            const double px = dx * e1x + dy * e1y + dz * e1z;
+            const double py = dx * e2x + dy * e2y + dz * e2z;
+            double qx = floor((px / s + 1.0) * 512.0), qy = floor((py / s + 1.0) * 512.0);
+            qx = qx < 0.0 ? 0.0 : (qx > 1023.0 ? 1023.0 : qx);
+            qy = qy < 0.0 ? 0.0 : (qy > 1023.0 ? 1023.0 : qy);
+            key = spread10((uint32_t)qx) | (spread10((uint32_t)qy) << 1);
         }
-        keys[i].key = ok ? key : 0xffffffffu;
+        keys[i].key = key;
         keys[i].idx = i;
     }
     qsort(keys, (size_t)n, sizeof(mkey_t), cmp_mkey);
@@ -137,7 +164,7 @@ ORACLE_API int oracle_hpr_visibility(int n, const float *pts, const double *eye,
     double *fl = (double *)malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
     int *perm = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
     if (!fl || !perm) { free(fl); free(perm); return -1; }
-    morton_order(n, pts, perm);
+    view_order(n, pts, eye, perm);
     flip_points(n, pts, perm, eye, radius, fl);
     /* Early accept (hpr.hip: hpr_accept_kernel): the point's own direction u is already a separating normal
      * when u.p'_j < |p'_i| for every other point (margin 1e-8 |p'_i|): the origin of the (a, b) plane is
