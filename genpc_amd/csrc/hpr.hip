@@ -630,7 +630,10 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                 // 32 candidates at a time: the marks are taken against the polygon as the previous 32 left it (while
                 // the polygon is still the box every candidate is marked; after the nearest few it is tight and
                 // almost none are)
-                for (int c0 = 0; c0 < kHprThreads && active; c0 += 32) {
+                // (in the point's HOME tile the chunks start with its own: nearest neighbours first)
+                const int rot = tile == home ? ((pos - home * kHprThreads) >> 5) : 0;
+                for (int cc = 0; cc < kHprThreads / 32 && active; cc++) {
+                    const int c0 = ((cc + rot) & (kHprThreads / 32 - 1)) * 32;
                     R = hpr_reach(poly, kHprThreads, nv);
                     unsigned m = 0u;
 #pragma unroll 4
@@ -888,14 +891,17 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     __syncthreads();
     HprReach R = hpr_reach(s_buf[0], 1, nv);
     bool failed = false;
-    // one tile of candidates against the polygon (64 lanes = 64 candidates at a time)
+    const int home = pos / kHprThreads;
+    // one tile of candidates against the polygon (32 candidates at a time)
     auto take_tile = [&](int tile) {
         const int tile0 = tile * kHprThreads;
-            for (int base = tile0; base < tile0 + kHprThreads && base < n && nv > 0; base += kWave) {
-                const int j = base + lane;
+            // the first pass's order: 32-candidate chunks, in the home tile starting with the point's own
+            const int rot = tile == home ? ((pos - home * kHprThreads) >> 5) : 0;
+            for (int cc = 0; cc < kHprThreads / 32 && nv > 0; cc++) {
+                const int j = tile0 + ((cc + rot) & (kHprThreads / 32 - 1)) * 32 + lane;
                 double A = 0.0, B = 0.0, C = 0.0;
                 bool pass = false;
-                if (j < n) {
+                if (lane < 32 && j < n) {
                     const double qx = fl[(size_t)j * 3 + 0], qy = fl[(size_t)j * 3 + 1], qz = fl[(size_t)j * 3 + 2];
                     A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
                     B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
@@ -933,7 +939,6 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
             }
     };
     // the same order as the first pass: the home tile and its neighbours, then outward from the group's tile
-    const int home = pos / kHprThreads;
     for (int rel = 0; rel < 3 && nv > 0; rel++) {
         const int tile = home + (rel == 0 ? 0 : (rel == 1 ? 1 : -1));
         if (tile >= 0 && tile < ntiles) take_tile(tile);

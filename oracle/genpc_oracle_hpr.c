@@ -232,7 +232,11 @@ ORACLE_API int oracle_hpr_visibility(int n, const float *pts, const double *eye,
                 if (tile >= home - 1 && tile <= home + 1) continue;
             }
             if (tile < 0 || tile >= ntiles) continue;
-            for (int j = tile * HPR_TILE; j < (tile + 1) * HPR_TILE && j < n && nv > 0; j++) {
+            /* 32-candidate chunks; in the home tile they start with the point's own chunk (nearest first) */
+            const int rot = tile == home ? ((i - home * HPR_TILE) >> 5) : 0;
+            for (int jj = 0; jj < HPR_TILE && nv > 0; jj++) {
+                const int j = tile * HPR_TILE + (((jj >> 5) + rot) & (HPR_TILE / 32 - 1)) * 32 + (jj & 31);
+                if (j >= n) continue;
                 const double qx = fl[3 * j], qy = fl[3 * j + 1], qz = fl[3 * j + 2];
                 if (qx == px && qy == py && qz == pz) continue;        /* the point itself, or an exact duplicate */
                 const double A = e1x * qx + e1y * qy + e1z * qz;
