@@ -943,6 +943,59 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
         const int tile = home + (rel == 0 ? 0 : (rel == 1 ? 1 : -1));
         if (tile >= 0 && tile < ntiles) take_tile(tile);
     }
+    // verify, as in hpr_kernel: one interior point of the polygon as THE normal against every other point (the 64
+    // lanes take 64 candidates at a time); strictly feasible everywhere: visible, nothing left to clip
+    if (nv >= 3 && !(no_cull & 32)) {
+        const double2 *src = s_buf[cur];
+        double2 ctr = make_double2(0.0, 0.0), v0 = ctr, v1 = ctr;
+        double r0 = __builtin_inf(), r1 = __builtin_inf();
+        for (int k = 0; k < nv; k++) {
+            const double2 v = src[k];
+            const double r2 = v.x * v.x + v.y * v.y;
+            ctr.x += v.x;
+            ctr.y += v.y;
+            if (r2 < r0) { r1 = r0; v1 = v0; r0 = r2; v0 = v; }
+            else if (r2 < r1) { r1 = r2; v1 = v; }
+        }
+        ctr.x /= (double)nv;
+        ctr.y /= (double)nv;
+        bool trying = true;
+        if (!(ctr.x * ctr.x + ctr.y * ctr.y < 1.0e6)) {
+            const double dx = ctr.x - v0.x, dy = ctr.y - v0.y;
+            const double len = sqrt(dx * dx + dy * dy);
+            double h = sqrt((v1.x - v0.x) * (v1.x - v0.x) + (v1.y - v0.y) * (v1.y - v0.y));
+            h = h < 0.5 * len ? h : 0.5 * len;
+            trying = len > 0.0 && h > 0.0;
+            if (trying) {
+                ctr.x = v0.x + h * (dx / len);
+                ctr.y = v0.y + h * (dy / len);
+            }
+        }
+        if (trying) {
+            const double nx = f.ux + ctr.x * f.e1x + ctr.y * f.e2x, ny = f.uy + ctr.x * f.e1y + ctr.y * f.e2y,
+                         nz = f.uz + ctr.x * f.e1z + ctr.y * f.e2z;
+            const double thr = 1e-10 * f.rho * (1.0 + ctr.x * ctr.x + ctr.y * ctr.y);
+            bool bad = false;
+            for (int j0 = 0; j0 < n && !bad; j0 += kWave) {
+                const int j = j0 + lane;
+                bool b1 = false;
+                if (j < n) {
+                    const double qx = fl[(size_t)j * 3 + 0], qy = fl[(size_t)j * 3 + 1], qz = fl[(size_t)j * 3 + 2];
+                    const double sv = (nx * qx + ny * qy + nz * qz) - f.rho;
+                    const bool self = qx == f.px && qy == f.py && qz == f.pz;
+                    b1 = !self && sv > -thr;
+                }
+                bad = __ballot(b1) != 0ull;
+            }
+            if (!bad) {
+                if (lane == 0) {
+                    vis[(size_t)view * n + i] = 1;
+                    atomicAdd(&cnt[view], 1);
+                }
+                return;
+            }
+        }
+    }
     for (int step0 = 0, bsz = 1; step0 < 2 * ntiles && nv > 0; step0 += bsz, bsz = step0 < kWave ? step0 : kWave) {
         bool need = false;
         if (lane < bsz) {
