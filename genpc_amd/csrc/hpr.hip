@@ -896,12 +896,15 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     auto take_tile = [&](int tile) {
         const int tile0 = tile * kHprThreads;
             // the first pass's order: 32-candidate chunks, in the home tile starting with the point's own
-            const int rot = tile == home ? ((pos - home * kHprThreads) >> 5) : 0;
-            for (int cc = 0; cc < kHprThreads / 32 && nv > 0; cc++) {
-                const int j = tile0 + ((cc + rot) & (kHprThreads / 32 - 1)) * 32 + lane;
+            // (any other tile is taken in ascending order: 64 candidates at a time there)
+            const bool is_home = tile == home;
+            const int rot = is_home ? ((pos - home * kHprThreads) >> 5) : 0;
+            const int width = is_home ? 32 : kWave;
+            for (int cc = 0; cc < kHprThreads / width && nv > 0; cc++) {
+                const int j = tile0 + (is_home ? ((cc + rot) & (kHprThreads / 32 - 1)) * 32 : cc * kWave) + lane;
                 double A = 0.0, B = 0.0, C = 0.0;
                 bool pass = false;
-                if (lane < 32 && j < n) {
+                if (lane < width && j < n) {
                     const double qx = fl[(size_t)j * 3 + 0], qy = fl[(size_t)j * 3 + 1], qz = fl[(size_t)j * 3 + 2];
                     A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
                     B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
@@ -943,8 +946,10 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
         const int tile = home + (rel == 0 ? 0 : (rel == 1 ? 1 : -1));
         if (tile >= 0 && tile < ntiles) take_tile(tile);
     }
-    // verify, as in hpr_kernel: one interior point of the polygon as THE normal against every other point (the 64
-    // lanes take 64 candidates at a time); strictly feasible everywhere: visible, nothing left to clip
+    // verify, as in hpr_kernel: an interior point of the polygon as THE normal against every other point (the 64
+    // lanes take 64 candidates at a time); strictly feasible everywhere: visible, nothing left to clip.  A wave
+    // per point makes a trial cheap (n / 64 steps), so several interior points are tried: the centroid, or -- for
+    // a polygon that runs out to the box -- points at decreasing distance from its vertex nearest the origin.
     if (nv >= 3 && !(no_cull & 32)) {
         const double2 *src = s_buf[cur];
         double2 ctr = make_double2(0.0, 0.0), v0 = ctr, v1 = ctr;
@@ -959,22 +964,22 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
         }
         ctr.x /= (double)nv;
         ctr.y /= (double)nv;
-        bool trying = true;
-        if (!(ctr.x * ctr.x + ctr.y * ctr.y < 1.0e6)) {
-            const double dx = ctr.x - v0.x, dy = ctr.y - v0.y;
-            const double len = sqrt(dx * dx + dy * dy);
-            double h = sqrt((v1.x - v0.x) * (v1.x - v0.x) + (v1.y - v0.y) * (v1.y - v0.y));
-            h = h < 0.5 * len ? h : 0.5 * len;
-            trying = len > 0.0 && h > 0.0;
-            if (trying) {
-                ctr.x = v0.x + h * (dx / len);
-                ctr.y = v0.y + h * (dy / len);
+        const bool open = !(ctr.x * ctr.x + ctr.y * ctr.y < 1.0e6);
+        const double dx = ctr.x - v0.x, dy = ctr.y - v0.y;
+        const double len = sqrt(dx * dx + dy * dy);
+        double h = sqrt((v1.x - v0.x) * (v1.x - v0.x) + (v1.y - v0.y) * (v1.y - v0.y));
+        h = h < 0.5 * len ? h : 0.5 * len;
+        for (int trial = 0; trial < (open ? 4 : 1); trial++) {
+            double2 c = ctr;
+            if (open) {
+                if (!(len > 0.0 && h > 0.0)) break;
+                c.x = v0.x + h * (dx / len);
+                c.y = v0.y + h * (dy / len);
+                h *= 0.125;
             }
-        }
-        if (trying) {
-            const double nx = f.ux + ctr.x * f.e1x + ctr.y * f.e2x, ny = f.uy + ctr.x * f.e1y + ctr.y * f.e2y,
-                         nz = f.uz + ctr.x * f.e1z + ctr.y * f.e2z;
-            const double thr = 1e-10 * f.rho * (1.0 + ctr.x * ctr.x + ctr.y * ctr.y);
+            const double nx = f.ux + c.x * f.e1x + c.y * f.e2x, ny = f.uy + c.x * f.e1y + c.y * f.e2y,
+                         nz = f.uz + c.x * f.e1z + c.y * f.e2z;
+            const double thr = 1e-10 * f.rho * (1.0 + c.x * c.x + c.y * c.y);
             bool bad = false;
             for (int j0 = 0; j0 < n && !bad; j0 += kWave) {
                 const int j = j0 + lane;
