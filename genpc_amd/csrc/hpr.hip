@@ -912,6 +912,16 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                     const bool self = qx == f.px && qy == f.py && qz == f.pz;
                     pass = !self && qx == qx && !hpr_far(R, A, B, C);
                 }
+                // every lane tests ITS candidate against the whole polygon (broadcast reads); only the ones
+                // that cut anything are then taken one by one (a candidate that does not cut the polygon now
+                // cannot cut what is left of it later) -- the tail of this kernel is a point with 20000
+                // candidates in reach of its polygon of which 1400 cut: 29 ms when each was taken serially
+                if (pass) {
+                    const double2 *pv = s_buf[cur];
+                    bool cuts = false;
+                    for (int k = 0; k < nv; k++) cuts |= pv[k].x * A + pv[k].y * B - C > 0.0;
+                    pass = cuts;
+                }
                 unsigned long long mask = __ballot(pass);
                 while (mask && nv > 0) {
                     const int from = __ffsll((long long)mask) - 1;
