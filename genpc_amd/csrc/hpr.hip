@@ -568,6 +568,7 @@ __global__ __launch_bounds__(1024) void hpr_compact_kernel(int n, const unsigned
 constexpr int kHprBatch = 64;      // tiles tested per round (one bit each)
 constexpr int kHprRimStep = 8;     // after this many tiles ...
 constexpr double kHprRimD2 = 1.0e6; // ... a polygon with a vertex farther than 1000 from the origin is a silhouette point's
+constexpr int kHprMaxClips = 128;    // cuts after which a point is handed to the second pass (measured 48 / 96 / 160: 64 x 10000 20.8 / 16.4 / 15.5 ms, 2 x 165546 39.8 / 40.5 / 44.6)
 constexpr int kHprRimTiles = 256;  // ... and is handed to the second pass if the cloud has at least this many tiles
 
 // status[0] = points handed to the second pass, status[1] = error (2: a polygon outgrew kHprOverCap)
@@ -606,6 +607,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
         poly[3 * kHprThreads] = make_double2(-kHprBox, kHprBox);
         R = hpr_reach(poly, kHprThreads, nv);
     }
+    int nclips = 0;
     HprTile *s_rec = (HprTile *)s_stage;
     const int home = pos >= 0 ? pos / kHprThreads : -0x40000000;      // the tile this point lies in
     // Stage one tile of candidates and let the lanes that want it clip against it.  Pass 1 over the tile, the
@@ -684,6 +686,16 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                         const int mm = hpr_clip_inplace(poly, kHprThreads, nv, out, first, A, B, C);
                         if (mm < 3) { nv = 0; active = false; break; }      // no interior left: not strictly extreme
                         nv = mm;
+                        // a polygon that has been cut this often is a sliver far from the origin that thousands
+                        // of candidates shave a little more (seen: 1400 cuts): such a point holds its whole block
+                        // up -- the second pass, a wave per point with the candidates tested in parallel, is the
+                        // place for it
+                        if (++nclips > kHprMaxClips && !(no_cull & 64)) {
+                            over_list[atomicAdd(&status[0], 1)] = view * n + rank;
+                            nv = -1;
+                            active = false;
+                            break;
+                        }
                     }
                 }
             }
@@ -1097,7 +1109,7 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
                "hpr radix sort"))
         return 0;
     HprTile *tiles = (HprTile *)(ws + o_tiles);
-    static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept, 32 = no verify phase (results unchanged)
+    static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept, 32 = no verify phase, 64 = no hand-off of much-cut polygons (results unchanged)
     hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl);
     hipLaunchKernelGGL(hpr_tile_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, tiles);
     unsigned char *hard = (unsigned char *)(ws + o_hard);
