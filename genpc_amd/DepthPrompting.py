@@ -122,12 +122,18 @@ class DepthPrompting:
         c, n = eyes.shape[0], points.shape[0]
         vis = torch.zeros(c, n, device=points.device, dtype=torch.uint8)
         cnt = torch.empty(c, device=points.device, dtype=torch.int32)
-        second = ctypes.c_int(0)
-        rc = _lib.on_device_of(points, _L.genpc_hpr_visibility, c, n, _p(points), _p(eyes), float(radius), _p(vis), _p(cnt),
-                               ctypes.addressof(second))
-        if rc != 1:
-            raise RuntimeError("genpc_hpr_visibility failed (rc=%d): %s" % (rc, _lib.last_error()))
-        return vis.bool(), cnt, int(second.value)
+        total_second = 0
+        # the library takes at most 4096 viewpoints and 2^31 - 1 (viewpoint, point) pairs per call
+        step = max(1, min(4096, (2 ** 31 - 1) // max(n, 1)))
+        for v0 in range(0, c, step):
+            v1 = min(c, v0 + step)
+            second = ctypes.c_int(0)
+            rc = _lib.on_device_of(points, _L.genpc_hpr_visibility, v1 - v0, n, _p(points), _p(eyes[v0:v1]), float(radius),
+                                   _p(vis[v0:v1]), _p(cnt[v0:v1]), ctypes.addressof(second))
+            if rc != 1:
+                raise RuntimeError("genpc_hpr_visibility failed (rc=%d): %s" % (rc, _lib.last_error()))
+            total_second += int(second.value)
+        return vis.bool(), cnt, total_second
 
     def getVisiblePointsZBuffer(self, points, cams=None, tol=1e-4, res=None, uvs=None, depths=None, point_size=2):
         """A cheaper visibility for ranking viewpoints (NOT the reference's operator, which is

@@ -160,7 +160,7 @@ int genpc_gather_colors(int n, const int *pix, const float *img, int ch, int h,
  * the convex hull of the flipped points and the origin.  Computed exactly, without a hull:
  * a flipped point is a vertex iff the polygon of normals (tilts of its own direction) that
  * keep every other flipped point below it is not empty (genpc_amd/csrc/hpr.hip; double
- * arithmetic, the candidates in input order).  points[N,3] float, eyes[C,3] DOUBLE (both
+ * arithmetic; at most 4096 viewpoints and 2^31 - 1 (viewpoint, point) pairs per call).  points[N,3] float, eyes[C,3] DOUBLE (both
  * device), radius > 0; visible[C,N] bytes, counts[C].  second_pass_points (HOST int, may
  * be NULL): how many points needed the large-polygon pass (lattice-like inputs).
  * Synchronises the stream once (the second pass is sized from the first).  0 if a polygon
