@@ -568,14 +568,13 @@ __global__ __launch_bounds__(1024) void hpr_compact_kernel(int n, const unsigned
 constexpr int kHprBatch = 64;      // tiles tested per round (one bit each)
 constexpr int kHprRimStep = 8;     // after this many tiles ...
 constexpr double kHprRimD2 = 1.0e6; // ... a polygon with a vertex farther than 1000 from the origin is a silhouette point's
-constexpr int kHprMaxClips = 128;    // cuts after which a point is handed to the second pass (measured 48 / 96 / 160: 64 x 10000 20.8 / 16.4 / 15.5 ms, 2 x 165546 39.8 / 40.5 / 44.6)
 constexpr int kHprRimTiles = 256;  // ... and is handed to the second pass if the cloud has at least this many tiles
 
 // status[0] = points handed to the second pass, status[1] = error (2: a polygon outgrew kHprOverCap)
 __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *__restrict__ fl_all, const int *__restrict__ perm,
                                                          const HprTile *__restrict__ tiles_all, const int *__restrict__ hardlist,
                                                          const int *__restrict__ hardcnt, unsigned char *__restrict__ vis,
-                                                         int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull)
+                                                         int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull, int max_clips)
 {
     __shared__ double2 s_poly[kHprMaxV * kHprThreads];
     __shared__ double4 s_stage[kHprThreads];      // 64 tile records while testing, then one tile's candidates
@@ -690,7 +689,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                         // of candidates shave a little more (seen: 1400 cuts): such a point holds its whole block
                         // up -- the second pass, a wave per point with the candidates tested in parallel, is the
                         // place for it
-                        if (++nclips > kHprMaxClips && !(no_cull & 64)) {
+                        if (++nclips > max_clips) {
                             over_list[atomicAdd(&status[0], 1)] = view * n + rank;
                             nv = -1;
                             active = false;
@@ -1112,13 +1111,18 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept, 32 = no verify phase, 64 = no hand-off of much-cut polygons (results unchanged)
     hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl);
     hipLaunchKernelGGL(hpr_tile_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, tiles);
+    static const int env_clips = getenv("GENPC_HPR_MAXCLIPS") ? atoi(getenv("GENPC_HPR_MAXCLIPS")) : 0;
+    // (large clouds: 96 -- 2 x 165546 points 46 -> 40 ms; many views of a small cloud: the second pass fills up
+    //  instead -- 1024 x 10000 points 154 ms with 256, 168 with 128, 180 with 96)
+    const int max_clips = (no_cull & 64) ? 0x7fffffff : (env_clips > 0 ? env_clips : (ntiles >= kHprRimTiles ? 96 : 256));
     unsigned char *hard = (unsigned char *)(ws + o_hard);
     int *hardlist = (int *)(ws + o_hl), *hardcnt = (int *)(ws + o_hc);
     hipLaunchKernelGGL(hpr_accept_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
                        (const HprTile *)tiles, hard, visible, counts, (no_cull & 16) ? 1 : 0);
     hipLaunchKernelGGL(hpr_compact_kernel, dim3(c), dim3(1024), 0, stream, n, (const unsigned char *)hard, hardlist, hardcnt);
     hipLaunchKernelGGL(hpr_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
-                       (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull);
+                       (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull,
+                       max_clips);
     if (!check(hipGetLastError(), "hpr launch")) return 0;
     // the second pass is sized from the first one's count: the one host round trip of this entry
     int st[2] = {0, 0};
