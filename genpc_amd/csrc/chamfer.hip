@@ -659,7 +659,7 @@ static void launch_r(const NNArgs &a, int blocks, hipStream_t st)
 
 static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0, float *d0, int *i0,
                       const float *q1, int n1, const float *t1, int m1, float *d1, int *i1, hipStream_t st,
-                      float radius2 = __builtin_inff())
+                      float radius2 = __builtin_inff(), const NNSorted *srt = nullptr)
 {
     // A direction with no queries or no targets does nothing (the reference's
     // loops do not execute, outputs keep the caller's zeros).
@@ -696,6 +696,19 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // measured on MI355X (tools/nn_sweep.py): below ~6M pairs the single-launch fp32-MFMA
     // kernel wins (1x1024^2 11.0 vs 13.5 us), from 2048^2 on the two-launch f16 filter
     if (path == 3 && pairs < 6e6 && t_tune_path < 0 && !cfg.env_path) path = 1;
+    // Sorted mode (nn_sort.hip; hook 4096 / GENPC_NN_SORT=1): Morton-sort both clouds, then run this very function
+    // on the sorted copies with whole (query block, target slice) pairs culled.  Needs the 512-query blocks of the
+    // f16 filter (>= 2e8 pairs), <= 32 batch elements, both directions on the same two clouds.
+    static const int sort_env = getenv("GENPC_NN_SORT") ? atoi(getenv("GENPC_NN_SORT")) : -1;
+    const bool sort_on = sort_env >= 0 ? sort_env != 0 : (a.debug & 4096) != 0;
+    if (!srt && sort_on && path == 3 && pairs >= 2e8 && b <= 32 && radius2 == __builtin_inff() && !cfg.q &&
+        (nd == 1 || (nd == 2 && q1 == t0 && t1 == q0)) && n0 >= 4096 && m0 >= 4096 && m0 <= (1 << 19) && n0 <= (1 << 19)) {
+        NNSorted S{};
+        if (!nn_sort_prepare(b, q0, n0, t0, m0, st, S)) return 0;
+        S.orig[0] = q0;
+        S.orig[1] = t0;
+        return nn_forward(b, nd, S.s[0], n0, S.s[1], m0, d0, i0, S.s[1], n1, S.s[0], m1, d1, i1, st, radius2, &S);
+    }
     if (radius2 < __builtin_inff()) path = 4;      // only the cell search knows how to stop at a distance
     if (path == 4) {
         // three launches, O(N + M) work (nn_grid.hip); needs both directions to be each other's swap
@@ -803,6 +816,13 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         }
         tight = best_res == 3;
         len = best_len;
+        if (srt) {
+            // the slices are the culling granularity: 1024 sorted targets (a compact piece of the cloud), more only
+            // to keep a query's lists within 16 and the need masks within 32 bits
+            len = 1024;
+            while (ceil_div64(nt_max, len) > 16) len += 512;
+            tight = blocks_at(len) >= 3LL * kNumCU * 3;
+        }
         (void)lists_of(len, nl);
         a.slice_len = (int)len;
         pwords = 3 * nl;
@@ -851,6 +871,18 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
             }
         }
     }
+    if (srt) {
+        if (!(path == 2 && f16 && q == 4)) {
+            set_error("nn sort: planner did not choose the 512-query f16 filter");
+            return 0;
+        }
+        const int cloud_of_q[2] = {0, 1};
+        for (int d = 0; d < nd; d++) {
+            a.dir[d].q_orig = srt->orig[cloud_of_q[d]];
+            a.dir[d].t_orig = srt->orig[1 - cloud_of_q[d]];
+        }
+        if (!nn_sort_plan(a, *srt, cloud_of_q, qper, st)) return 0;
+    }
     if (path == 2) {
         // pre-split targets + LDS-DMA (one more launch) once every target is staged by many blocks
         if (f16) {
@@ -866,7 +898,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
             // LDS holds and the overflow falls to the exhaustive pass -- the 8 x 32768 alignment loop went
             // from 1.35 s to 3.86 s.  The finish kernel (64 queries per block) has no such cliff.
             static const int fuse_env = getenv("GENPC_NN_FUSE") ? atoi(getenv("GENPC_NN_FUSE")) : -1;
-            const int fuse = fuse_env >= 0 ? fuse_env : ((a.debug & 1024) ? 1 : 0);
+            const int fuse = srt ? 0 : (fuse_env >= 0 ? fuse_env : ((a.debug & 1024) ? 1 : 0));
             return launch_nn_f16(a, q, fu, nl, tight ? 1 : 0, fuse, tb, st);
         }
         const int pre = cfg.pre >= 0 ? cfg.pre : ((a.debug & 256) ? 1 : 0);      // measured: 13x16384^2 401+8 us vs 410 us, 1x16384^2 35+5 vs 36 -- does not pay

@@ -41,6 +41,12 @@ struct NNDir {
     int slices;        // S for this direction: ceil(nt / slice_len)
     int block_begin;   // first block id of this direction
     int unit_begin;    // first arrival counter of this direction
+    // sorted mode (nn_sort.hip): q / t above are Morton-sorted copies; results go back through the permutations
+    const int *perm_q;      // [B, nq] sorted position -> original index (null: not sorted)
+    const int *perm_t;      // [B, nt]
+    const float *q_orig;    // the caller's arrays (exhaustive pass: the reference's order matters there)
+    const float *t_orig;
+    const unsigned *need;   // [B, qblocks] bit s: slice s can hold a neighbour of this query block
 };
 
 struct NNArgs {
@@ -53,6 +59,9 @@ struct NNArgs {
     int fma;           // arithmetic mode of this call (read once at the entry point; host side only)
     unsigned long long *stats;   // hook 512: [0] queries, [1] exhaustive re-dos, [2] exact pieces; else null
     float radius2;     // grid path only: search limit (squared); +inf = none.  Queries with no target within it get (+inf, -1)
+    // sorted mode: the filter runs only the listed blocks (work[0 .. *work_count)), ids in the planner's numbering
+    const int *work;
+    const int *work_count;
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -274,6 +283,25 @@ __device__ __forceinline__ void rescan_half(const float *__restrict__ T, int nt,
     }
 }
 
+// The same 16 targets of a SORTED cloud: the reference's tie rule is the lowest ORIGINAL index, so the minimum is
+// taken over (distance bits, perm[target]) keys.  Distances are >= 0 or NaN; a NaN key is larger than any real one.
+template <int FMA>
+__device__ __forceinline__ unsigned long long rescan_half_perm(const float *__restrict__ T, const int *__restrict__ perm, int nt,
+                                                               int base, int h, float qx, float qy, float qz)
+{
+    const int first = base + 16 * h;
+    unsigned long long best = ~0ull;
+    for (int c = 0; c < 16; c++) {
+        int kk = first + c;
+        kk = kk < nt ? kk : nt - 1;
+        const float *tp = T + (size_t)kk * 3;
+        const float dd = sqdist<FMA>(tp[0] - qx, tp[1] - qy, tp[2] - qz);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)perm[kk];
+        best = key < best ? key : best;
+    }
+    return best;
+}
+
 
 // ---------------------------------------------------------------------------
 // The finish step for the NQ queries [qfirst, qfirst + NQ) of one (direction, batch element), run by
@@ -429,5 +457,19 @@ int launch_nn_bf16(NNArgs &a, int q, int pre, int nl, long long total_blocks, hi
 int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, int fuse, long long total_blocks, hipStream_t st);
 int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float t2min, hipStream_t st);
 int launch_nn_grid(const NNArgs &a, hipStream_t st);
+
+// sorted mode (nn_sort.hip)
+struct NNSorted {
+    const float *s[2];        // Morton-sorted copies of the two clouds [B, n, 3]
+    const int *perm[2];       // [B, n] sorted position -> original index
+    const unsigned *keys[2];  // [B * n] sorted keys (batch << 27 | 27-bit Morton code)
+    const float *box[2];      // [B, ceil(n / 512), 6] min xyz, max xyz of every 512 sorted points
+    const float *orig[2];     // the caller's arrays
+    int n[2];
+    int b;
+};
+int nn_sort_prepare(int b, const float *c0, int n0, const float *c1, int n1, hipStream_t st, NNSorted &out);
+// per (direction, batch, query block): which target slices can hold a neighbour -> need masks + the work list
+int nn_sort_plan(NNArgs &a, const NNSorted &srt, const int cloud_of_q[2], int qper, hipStream_t st);
 
 }  // namespace genpc

@@ -430,6 +430,9 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     const unsigned long long *P = D.part + (size_t)batch * nq;
     const int nlists = D.slices * nl;
 
+    // (a finish block's 64 queries lie in one 512-query filter block)
+    const unsigned needmask = D.need ? D.need[(size_t)batch * D.qblocks + (fb * kFQ) / 512] : 0xffffffffu;
+    const int *__restrict__ permT = D.perm_t ? D.perm_t + (size_t)batch * nt : nullptr;
     const int ql = threadIdx.x & (kFQ - 1), part = threadIdx.x >> 6;     // part == wave
     int j = fb * kFQ + ql;
     const bool live = j < nq;
@@ -444,7 +447,8 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     for (int k = 0; k < kMaxLists / 4; k++) {
         const int li = part + 4 * k;
         w0[k] = w1[k] = w2[k] = 0x7f800000ull << 32;      // (+inf, 0)
-        if (li < nlists) {
+        // sorted mode: a slice whose filter block never ran has no lists (its targets are provably too far)
+        if (li < nlists && ((needmask >> (li / nl)) & 1u)) {
             const unsigned long long *p = P + (size_t)li * 3 * bnq + j;
             w0[k] = p[0];
             w1[k] = p[bnq];
@@ -534,19 +538,25 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         const unsigned it = s_work[w];
         const int slot = (int)(it >> 22);
         const float4 qv = s_q[slot];
-        float dd;
-        int ii;
-        rescan_half<FMA>(T, nt, (int)((it & 0x3fffffu) >> 1) << 5, (int)(it & 1u), qv.x, qv.y, qv.z, dd, ii);
-        atomicMin(&s_best[slot], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii);
+        if (permT) {
+            atomicMin(&s_best[slot], rescan_half_perm<FMA>(T, permT, nt, (int)((it & 0x3fffffu) >> 1) << 5, (int)(it & 1u), qv.x, qv.y, qv.z));
+        } else {
+            float dd;
+            int ii;
+            rescan_half<FMA>(T, nt, (int)((it & 0x3fffffu) >> 1) << 5, (int)(it & 1u), qv.x, qv.y, qv.z, dd, ii);
+            atomicMin(&s_best[slot], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii);
+        }
     }
     __syncthreads();
     if (part == 0 && live) {
+        // sorted mode: the result belongs to the query's original position
+        const int jo = D.perm_q ? D.perm_q[(size_t)batch * nq + j] : j;
         if (s_qflag[ql]) {
-            s_flagged[atomicAdd(&s_misc[1], 1)] = j;
+            s_flagged[atomicAdd(&s_misc[1], 1)] = jo;
         } else {
             const unsigned long long v = s_best[ql];
-            od[j] = __uint_as_float((unsigned)(v >> 32));
-            oi[j] = (int)(unsigned)v;
+            od[jo] = __uint_as_float((unsigned)(v >> 32));
+            oi[jo] = (int)(unsigned)v;
         }
     }
     __syncthreads();
@@ -556,7 +566,10 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         atomicAdd(&a.stats[1], (unsigned long long)nflag);
         atomicAdd(&a.stats[2], (unsigned long long)nwork);
     }
-    for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Qp, T, nt, s_flagged[fidx], od, oi, s_red, s_fi);
+    // (sorted mode: the exhaustive pass runs on the caller's arrays -- the reference's tile order matters there)
+    const float *Qx = D.q_orig ? D.q_orig + (size_t)batch * nq * 3 : Qp;
+    const float *Tx = D.t_orig ? D.t_orig + (size_t)batch * nt * 3 : T;
+    for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Qx, Tx, nt, s_flagged[fidx], od, oi, s_red, s_fi);
 }
 
 template <int Q, int U, int NL, int PRE>
