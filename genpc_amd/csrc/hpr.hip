@@ -614,20 +614,9 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     // takes ITS marked candidates in order -- the lanes of a wave run their k-th marked candidate together, so
     // the wave pays for the longest list, not for the sum of all of them (clipping candidate by candidate as
     // they come costs 10x more: the lanes meet their cuts at different candidates).
-    auto take_tile = [&](int tile, bool wanted) {
-        const int tile0 = tile * kHprThreads;
-            const int tn = min(kHprThreads, n - tile0);
-            {
-                // rows past the end are NaN: they cut nothing
-                double4 q = make_double4(__builtin_nan(""), 0.0, 0.0, 0.0);
-                if (tid < tn) {
-                    const double *g = fl + (size_t)(tile0 + tid) * 3;
-                    q = make_double4(g[0], g[1], g[2], 0.0);
-                }
-                s_stage[tid] = q;
-            }
-            __syncthreads();
-            if (active && wanted) {
+    // Clip the polygon of this lane by the 128 candidates of one tile; `load(k)` returns candidate k of the tile
+    // (rows past the end of the cloud: NaN).
+    auto clip_by_tile = [&](int tile, auto load) {
                 // 32 candidates at a time: the marks are taken against the polygon as the previous 32 left it (while
                 // the polygon is still the box every candidate is marked; after the nearest few it is tight and
                 // almost none are)
@@ -639,7 +628,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                     unsigned m = 0u;
 #pragma unroll 4
                     for (int t = 0; t < 32; t++) {
-                        const double4 q = s_stage[c0 + t];      // rows past the end are NaN
+                        const double4 q = load(c0 + t);      // rows past the end are NaN
                         const double A = f.e1x * q.x + f.e1y * q.y + f.e1z * q.z;
                         const double B = f.e2x * q.x + f.e2y * q.y + f.e2z * q.z;
                         const double C = f.rho - (f.ux * q.x + f.uy * q.y + f.uz * q.z);
@@ -649,7 +638,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                     while (m && active) {
                         const int t = __ffs((int)m) - 1;
                         m &= m - 1;
-                        const double4 q = s_stage[c0 + t];      // (recomputed: the same values)
+                        const double4 q = load(c0 + t);      // (recomputed: the same values)
                         const double A = f.e1x * q.x + f.e1y * q.y + f.e1z * q.z;
                         const double B = f.e2x * q.x + f.e2y * q.y + f.e2z * q.z;
                         const double C = f.rho - (f.ux * q.x + f.uy * q.y + f.uz * q.z);
@@ -697,24 +686,40 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                         }
                     }
                 }
+                };
+    // Stage one tile of candidates in LDS and let the lanes that want it clip against it.
+    auto take_tile = [&](int tile, bool wanted) {
+        const int tile0 = tile * kHprThreads;
+        const int tn = min(kHprThreads, n - tile0);
+        {
+            // rows past the end are NaN: they cut nothing
+            double4 q = make_double4(__builtin_nan(""), 0.0, 0.0, 0.0);
+            if (tid < tn) {
+                const double *g = fl + (size_t)(tile0 + tid) * 3;
+                q = make_double4(g[0], g[1], g[2], 0.0);
             }
-            __syncthreads();
+            s_stage[tid] = q;
+        }
+        __syncthreads();
+        if (active && wanted) clip_by_tile(tile, [&](int k) { return s_stage[k]; });
+        __syncthreads();
     };
     // Phase 1: every point's home tile and its two neighbours, whatever the group's starting tile is (when few
     // points are left over, the 128 of a block lie many tiles apart; a polygon that has not met its nearest
     // neighbours first stays large for a long time).
-    {
-        const int first_home = hl[blockIdx.x * kHprThreads] / kHprThreads;
-        const int last_rank = min(nhard, (int)(blockIdx.x + 1) * kHprThreads) - 1;
-        const int last_home = hl[last_rank] / kHprThreads;
-        for (int rel = 0; rel < 3; rel++) {            // home, home + 1, home - 1: nearest first
-            const int d = rel == 0 ? 0 : (rel == 1 ? 1 : -1);
-            for (int tile = max(first_home + d, 0); tile <= min(last_home + d, ntiles - 1); tile++) {
-                const bool wanted = active && tile == home + d;
-                if (__syncthreads_count(wanted) == 0) continue;
-                take_tile(tile, wanted);
-            }
-        }
+    // Each lane reads ITS tiles straight from memory (its neighbours in the wave read the same or the next tile:
+    // the lines are shared in L1/L2): staging them through LDS would take the block's tiles one after the other
+    // with a few lanes busy on each -- measured 1.0 of a block's 2.7 ms.
+    for (int rel = 0; rel < 3 && active; rel++) {            // home, home + 1, home - 1: nearest first
+        const int tile = home + (rel == 0 ? 0 : (rel == 1 ? 1 : -1));
+        if (tile < 0 || tile >= ntiles) continue;
+        const int tile0 = tile * kHprThreads;
+        clip_by_tile(tile, [&](int k) {
+            const int j = tile0 + k;
+            if (j >= n) return make_double4(__builtin_nan(""), 0.0, 0.0, 0.0);
+            const double *g = fl + (size_t)j * 3;
+            return make_double4(g[0], g[1], g[2], 0.0);
+        });
     }
     // Verify phase.  The polygon now reflects the nearest neighbours; later candidates mostly shave its corners.
     // Take its centroid (a*, b*) -- an interior point -- and test that ONE normal n = u + a* e1 + b* e2 against
