@@ -877,10 +877,6 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
             return 0;
         }
         const int cloud_of_q[2] = {0, 1};
-        for (int d = 0; d < nd; d++) {
-            a.dir[d].q_orig = srt->orig[cloud_of_q[d]];
-            a.dir[d].t_orig = srt->orig[1 - cloud_of_q[d]];
-        }
         if (!nn_sort_plan(a, *srt, cloud_of_q, qper, st)) return 0;
     }
     if (path == 2) {

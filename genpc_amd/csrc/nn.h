@@ -41,12 +41,19 @@ struct NNDir {
     int slices;        // S for this direction: ceil(nt / slice_len)
     int block_begin;   // first block id of this direction
     int unit_begin;    // first arrival counter of this direction
-    // sorted mode (nn_sort.hip): q / t above are Morton-sorted copies; results go back through the permutations
-    const int *perm_q;      // [B, nq] sorted position -> original index (null: not sorted)
-    const int *perm_t;      // [B, nt]
-    const float *q_orig;    // the caller's arrays (exhaustive pass: the reference's order matters there)
-    const float *t_orig;
-    const unsigned *need;   // [B, qblocks] bit s: slice s can hold a neighbour of this query block
+};
+
+// sorted mode (nn_sort.hip): the q / t of NNDir are Morton-sorted copies; results go back through the
+// permutations.  Kept out of NNArgs (one pointer there): the kernel argument block is read at the start of every
+// launch, and growing it by these 96 bytes cost the default path 0.5 us of its 36 (measured on one box).
+struct NNSortDev {
+    const int *perm_q[2];      // [B, nq] sorted position -> original index, per direction
+    const int *perm_t[2];      // [B, nt]
+    const float *q_orig[2];    // the caller's arrays (exhaustive pass: the reference's order matters there)
+    const float *t_orig[2];
+    const unsigned *need[2];   // [B, qblocks] bit s: slice s can hold a neighbour of this query block
+    const int *work;           // the filter runs only the listed blocks (ids in the planner's numbering)
+    const int *work_count;
 };
 
 struct NNArgs {
@@ -59,9 +66,7 @@ struct NNArgs {
     int fma;           // arithmetic mode of this call (read once at the entry point; host side only)
     unsigned long long *stats;   // hook 512: [0] queries, [1] exhaustive re-dos, [2] exact pieces; else null
     float radius2;     // grid path only: search limit (squared); +inf = none.  Queries with no target within it get (+inf, -1)
-    // sorted mode: the filter runs only the listed blocks (work[0 .. *work_count)), ids in the planner's numbering
-    const int *work;
-    const int *work_count;
+    const NNSortDev *srt;   // sorted mode (device memory), null otherwise
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

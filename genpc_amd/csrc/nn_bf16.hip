@@ -431,8 +431,9 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     const int nlists = D.slices * nl;
 
     // (a finish block's 64 queries lie in one 512-query filter block)
-    const unsigned needmask = D.need ? D.need[(size_t)batch * D.qblocks + (fb * kFQ) / 512] : 0xffffffffu;
-    const int *__restrict__ permT = D.perm_t ? D.perm_t + (size_t)batch * nt : nullptr;
+    const NNSortDev *S = a.srt;
+    const unsigned needmask = S ? S->need[d][(size_t)batch * D.qblocks + (fb * kFQ) / 512] : 0xffffffffu;
+    const int *__restrict__ permT = S ? S->perm_t[d] + (size_t)batch * nt : nullptr;
     const int ql = threadIdx.x & (kFQ - 1), part = threadIdx.x >> 6;     // part == wave
     int j = fb * kFQ + ql;
     const bool live = j < nq;
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     __syncthreads();
     if (part == 0 && live) {
         // sorted mode: the result belongs to the query's original position
-        const int jo = D.perm_q ? D.perm_q[(size_t)batch * nq + j] : j;
+        const int jo = S ? S->perm_q[d][(size_t)batch * nq + j] : j;
         if (s_qflag[ql]) {
             s_flagged[atomicAdd(&s_misc[1], 1)] = jo;
         } else {
@@ -567,8 +568,8 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         atomicAdd(&a.stats[2], (unsigned long long)nwork);
     }
     // (sorted mode: the exhaustive pass runs on the caller's arrays -- the reference's tile order matters there)
-    const float *Qx = D.q_orig ? D.q_orig + (size_t)batch * nq * 3 : Qp;
-    const float *Tx = D.t_orig ? D.t_orig + (size_t)batch * nt * 3 : T;
+    const float *Qx = S ? S->q_orig[d] + (size_t)batch * nq * 3 : Qp;
+    const float *Tx = S ? S->t_orig[d] + (size_t)batch * nt * 3 : T;
     for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Qx, Tx, nt, s_flagged[fidx], od, oi, s_red, s_fi);
 }
 

@@ -79,9 +79,9 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
     const int wave = threadIdx.x >> 6;
     const int half = lane >> 5, col = lane & 31;
     int bid = blockIdx.x;
-    if (a.work) {                                  // sorted mode: only the (query block, slice) pairs that can matter
-        if (bid >= *a.work_count) return;
-        bid = a.work[bid];
+    if (a.srt) {                                   // sorted mode: only the (query block, slice) pairs that can matter
+        if (bid >= *a.srt->work_count) return;
+        bid = a.srt->work[bid];
     }
     const int d = (a.ndir > 1 && bid >= a.dir[1].block_begin) ? 1 : 0;
     const NNDir &D = a.dir[d];

@@ -212,6 +212,8 @@ struct SrtPlanArgs {
     int *work, *work_count;
 };
 
+__global__ void srt_store_kernel(NNSortDev v, NNSortDev *dst) { *dst = v; }
+
 __global__ __launch_bounds__(256) void srt_need_kernel(SrtPlanArgs p)
 {
     const int d = blockIdx.z;
@@ -308,7 +310,7 @@ int nn_sort_plan(NNArgs &a, const NNSorted &srt, const int cloud_of_q[2], int qp
         return 0;
     }
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    size_t off = 256;
+    size_t off = 512;
     size_t o_D[2] = {0, 0}, o_need[2] = {0, 0};
     long long total_blocks = 0;
     for (int d = 0; d < a.ndir; d++) {
@@ -326,6 +328,7 @@ int nn_sort_plan(NNArgs &a, const NNSorted &srt, const int cloud_of_q[2], int qp
     // zero: the count, the D maxima (0.0f) and the need masks
     if (!check(hipMemsetAsync(ws, 0, o_work, st), "hipMemsetAsync(nn sort plan)")) return 0;
     SrtPlanArgs p{};
+    NNSortDev dev{};
     p.ndir = a.ndir;
     p.b = a.b;
     p.boxes_per_slice = a.slice_len / kSortBox;
@@ -351,14 +354,19 @@ int nn_sort_plan(NNArgs &a, const NNSorted &srt, const int cloud_of_q[2], int qp
         p.block_begin[d] = D.block_begin;
         p.nqbox[d] = ceil_div(D.nq, kSortBox);
         p.ntbox[d] = ceil_div(D.nt, kSortBox);
-        D.need = p.need[d];
-        D.perm_q = srt.perm[cq];
-        D.perm_t = srt.perm[ct];
+        dev.need[d] = p.need[d];
+        dev.perm_q[d] = srt.perm[cq];
+        dev.perm_t[d] = srt.perm[ct];
+        dev.q_orig[d] = srt.orig[cq];
+        dev.t_orig[d] = srt.orig[ct];
         if (D.qblocks * D.slices > maxid) maxid = D.qblocks * D.slices;
     }
+    dev.work = p.work;
+    dev.work_count = p.work_count;
+    NNSortDev *dev_mem = (NNSortDev *)(ws + 256);          // (after the count word; zeroed area ends at o_work)
+    hipLaunchKernelGGL(srt_store_kernel, dim3(1), dim3(1), 0, st, dev, dev_mem);
     hipLaunchKernelGGL(srt_need_kernel, dim3(ceil_div(maxid, 256), a.b, a.ndir), dim3(256), 0, st, p);
-    a.work = p.work;
-    a.work_count = p.work_count;
+    a.srt = dev_mem;
     return check(hipGetLastError(), "nn sort plan launch") ? 1 : 0;
 }
 
