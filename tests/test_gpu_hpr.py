@@ -57,7 +57,7 @@ def clouds():
     return out
 
 
-@pytest.mark.parametrize("radius", [3.0, 100.0, 800.0, 10000.0])
+@pytest.mark.parametrize("radius", [0.3, 1.6, 3.0, 100.0, 800.0, 10000.0])      # (below ~1.5 the flipped points lie BEHIND the eye)
 def test_hpr_equals_qhull_and_the_clipping_oracle(hp, radius):
     for name, P in clouds().items():
         vis, cnt, second = hp["run"](P, EYES, radius)
