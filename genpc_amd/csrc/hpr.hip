@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                         // outside vertices: how many, and where their (cyclic) run starts
                         // (eight vertices are fetched at a time: one LDS round trip instead of eight in a row;
                         // slots past nv are read -- they belong to this thread -- and ignored)
-                        int out = 0, first = 0;
+                        int out = 0, first = 0, runs = 0;
                         bool prev_out;
                         {
                             const double2 v = poly[(nv - 1) * kHprThreads];
@@ -660,12 +660,15 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                                 const bool o = k0 + j < nv && v[j].x * A + v[j].y * B - C > 0.0;
                                 out += o ? 1 : 0;
                                 first = (o && !prev_out) ? k0 + j : first;
+                                runs += (o && !prev_out) ? 1 : 0;
                                 prev_out = k0 + j < nv ? o : prev_out;
                             }
                         }
                         if (!out) continue;
                         if (out == nv) { nv = 0; active = false; break; }
-                        if (nv - out + 2 > kHprMaxV) {
+                        // (runs > 1: on a sliver, roundoff can put the outside vertices in two runs; the in-place clip
+                        // assumes one -- the second pass clips like the oracle does, vertex by vertex)
+                        if (nv - out + 2 > kHprMaxV || runs > 1) {
                             over_list[atomicAdd(&status[0], 1)] = view * n + rank;
                             nv = -1;
                             active = false;
