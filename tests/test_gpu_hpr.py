@@ -146,3 +146,47 @@ def test_hpr_viewpoint_select_sizes(hp):
     vis, cnt, second = hp["run"](sub, eyes, 10000.0)
     np.testing.assert_array_equal(cnt, hpr.visible_counts(sub, eyes, 10000.0))
     np.testing.assert_array_equal(vis[[0, 31, 63]], hp["clip"](sub, eyes[[0, 31, 63]], 10000.0))
+
+
+def test_hpr_differential_fuzz(hp):
+    """120 random configurations -- sizes 1 .. 4000, radii 0.2 .. 1e5, eyes outside, near and inside the cloud,
+    balls / spheres / shells / planes / lines / clusters / duplicated points / a lattice, three eyes each: the GPU
+    mask equals the clipping oracle's in EVERY case (the two run the same arithmetic; every shortcut the kernel
+    takes -- tile culling, early accept, verify phase, hand-offs -- must leave no trace)."""
+    rng = np.random.default_rng(2024)
+    kinds = ["ball", "sphere", "shell", "plane", "line", "clusters", "dups", "lattice"]
+    total = second_total = 0
+    for case in range(120):
+        kind = kinds[case % len(kinds)]
+        n = int(rng.integers(1, 4001)) if case % 5 else int(rng.integers(1, 140))
+        scale = 10.0 ** rng.uniform(-2, 2)
+        if kind == "ball":
+            P = rng.random((n, 3)) - 0.5
+        elif kind in ("sphere", "shell"):
+            v = rng.normal(size=(n, 3))
+            v /= np.linalg.norm(v, axis=1, keepdims=True)
+            P = v * (0.5 if kind == "sphere" else (0.4 + 0.1 * rng.random((n, 1))))
+        elif kind == "plane":
+            P = np.concatenate([rng.random((n, 2)) - 0.5, 1e-3 * rng.normal(size=(n, 1))], 1)
+        elif kind == "line":
+            P = np.outer(rng.random(n) - 0.5, [1.0, 0.3, -0.2]) + 1e-4 * rng.normal(size=(n, 3))
+        elif kind == "clusters":
+            c = rng.random((8, 3)) - 0.5
+            P = c[rng.integers(0, 8, n)] + 0.01 * rng.normal(size=(n, 3))
+        elif kind == "dups":
+            base = rng.random((max(1, n // 3), 3)) - 0.5
+            P = base[rng.integers(0, len(base), n)]
+        else:
+            g = int(max(2, round(n ** (1 / 3))))
+            P = np.stack(np.meshgrid(*[np.arange(g)] * 3, indexing="ij"), -1).reshape(-1, 3) / g - 0.5
+        P = (P * scale + rng.normal(size=3) * scale * 0.1).astype(np.float32)
+        ext = float(np.abs(P - P.mean(0)).max()) + 1e-6
+        eyes = np.stack([P.mean(0) + rng.normal(size=3) * ext * f for f in (4.0, 1.2, 0.3)]).astype(np.float64)
+        radius = ext * 10.0 ** rng.uniform(-0.7, 5)
+        vis, cnt, second = hp["run"](P, eyes, radius)
+        exp = hp["clip"](P, eyes, radius)
+        assert np.array_equal(vis, exp), (case, kind, len(P), radius, int((vis != exp).sum()))
+        np.testing.assert_array_equal(cnt, vis.sum(1))
+        total += vis.size
+        second_total += second
+    assert total > 100000
