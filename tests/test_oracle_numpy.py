@@ -302,3 +302,35 @@ def test_hpr_clipping_oracle_equals_qhull(oracle, golden):
     d = oracle.hpr_visibility(D, [0, 0, 3.0], 100.0)
     np.testing.assert_array_equal(d[:300], base)
     np.testing.assert_array_equal(d[300:], base[:20])
+
+
+def test_hpr_clipping_oracle_equals_qhull_fuzz(oracle):
+    """60 random generic configurations (balls, shells, clusters; 5 .. 3000 points; scale 1e-2 .. 1e2; the eye far
+    from, near and inside the cloud; radius 0.2 .. 1e5 of the extent): the clipping oracle's mask equals qhull's
+    point for point (79 000 points)."""
+    from oracle import hpr
+    rng = np.random.default_rng(77)
+    total = 0
+    for case in range(60):
+        n = int(rng.integers(5, 3000))
+        kind = case % 3
+        if kind == 0:
+            P = rng.random((n, 3)) - 0.5
+        elif kind == 1:
+            v = rng.normal(size=(n, 3))
+            v /= np.linalg.norm(v, axis=1, keepdims=True)
+            P = v * (0.4 + 0.1 * rng.random((n, 1)))
+        else:
+            c = rng.random((6, 3)) - 0.5
+            P = c[rng.integers(0, 6, n)] + 0.05 * rng.normal(size=(n, 3))
+        scale = 10.0 ** rng.uniform(-2, 2)
+        P = (P * scale).astype(np.float32)
+        ext = float(np.abs(P - P.mean(0)).max())
+        eye = (P.mean(0) + rng.normal(size=3) * ext * float(rng.choice([4.0, 1.2, 0.3]))).astype(np.float64)
+        radius = ext * 10.0 ** rng.uniform(-0.7, 5)
+        a = oracle.hpr_visibility(P, eye, radius)
+        b = np.zeros(n, bool)
+        b[hpr.hidden_point_removal(P, eye, radius)] = True
+        np.testing.assert_array_equal(a, b, err_msg="case %d" % case)
+        total += n
+    assert total > 70000
