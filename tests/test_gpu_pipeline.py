@@ -165,3 +165,27 @@ def test_config5_rank_shape_8x32768(env):
         aligned = (C[i] - c) @ Tt[:3, :3].T + c + Tt[:3, 3]
         d = cl.chamfer_partial_l1(P[i][None].contiguous(), aligned[None].contiguous()).item()
         assert d < 0.05, (i, d)          # 5 % of the object's extent after 201 steps (reg() refines from here)
+
+
+def test_voxel_down_sample_fuzz(env, oracle):
+    """30 random clouds (1 .. 60000 points, scales 1e-3 .. 1e3, offsets, clusters with many points per voxel,
+    exact duplicates) x random voxel sizes: the GPU grid equals the oracle's, bit for bit and in the same order."""
+    torch = env["torch"]
+    rng = np.random.default_rng(31)
+    for case in range(30):
+        n = int(rng.integers(1, 60001)) if case % 4 else int(rng.integers(1, 50))
+        scale = 10.0 ** rng.uniform(-3, 3)
+        kind = case % 3
+        if kind == 0:
+            P = rng.random((n, 3)) - 0.5
+        elif kind == 1:
+            c = rng.random((5, 3)) - 0.5
+            P = c[rng.integers(0, 5, n)] + 0.02 * rng.normal(size=(n, 3))
+        else:
+            base = rng.random((max(1, n // 4), 3)) - 0.5
+            P = base[rng.integers(0, len(base), n)]
+        P = (P * scale + rng.normal(size=3) * scale * rng.choice([0.0, 3.0])).astype(np.float32)
+        ext = float(np.ptp(P, axis=0).max()) + 1e-6 * scale
+        voxel = ext * 10.0 ** rng.uniform(-2.2, 0.3)
+        got = env["R"].voxel_down_sample(torch.from_numpy(P).cuda(), voxel).cpu().numpy()
+        np.testing.assert_array_equal(got, oracle.voxel_down_sample(P, voxel), err_msg="case %d n %d voxel %g" % (case, n, voxel))
