@@ -713,6 +713,7 @@ __global__ __launch_bounds__(kQBlock) void mask_w_kernel(int S, const float *__r
 }
 
 // grid (blocks, b): gradient of the mask term with respect to (R, s, t), into accum[0..12].
+template <int kGradSub>
 __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *__restrict__ v,
                                                             const float *__restrict__ center, int cstride,
                                                             const float *__restrict__ params, int pstride, float radius,
@@ -735,29 +736,47 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
     double a[13];
 #pragma unroll
     for (int k = 0; k < 13; k++) a[k] = 0.0;
-    for (int j = blockIdx.x * kQBlock + threadIdx.x; j < n; j += gridDim.x * kQBlock) {
-        const float vx = v[(size_t)j * 3 + 0], vy = v[(size_t)j * 3 + 1], vz = v[(size_t)j * 3 + 2];
+    // kGradSub lanes share a point: each takes every kGradSub-th row of the point's pixel box, the partial sums meet
+    // by shuffles and the first lane does the chain rule.  One scan: 8 lanes (one thread per point leaves 64 blocks
+    // for 16384 points and a 64-pixel serial loop per thread: 21 us of a 109 us step -> 102); several scans in
+    // lock-step fill the chip with one thread per point, and the idle lanes of the 8-lane form cost 7 % there.
+    const int sub = threadIdx.x & (kGradSub - 1);
+    const int per_block = kQBlock / kGradSub;
+    for (int j0 = blockIdx.x * per_block; j0 < n; j0 += gridDim.x * per_block) {
+        const int j = j0 + threadIdx.x / kGradSub;
+        const bool live = j < n;
+        const int jj = live ? j : n - 1;
+        const float vx = v[(size_t)jj * 3 + 0], vy = v[(size_t)jj * 3 + 1], vz = v[(size_t)jj * 3 + 2];
         float p[3];
         pose_point(R, s, c, t, vx, vy, vz, p);
         const SplatPt q = splat_project(p, radius, hs);
-        if (!q.ok) continue;
+        const bool ok = live && q.ok;
         const int c0 = max((int)floorf(q.u - q.rho - 0.5f), 0), c1 = min((int)ceilf(q.u + q.rho - 0.5f), S - 1);
         const int r0 = max((int)floorf(q.v - q.rho - 0.5f), 0), r1 = min((int)ceilf(q.v + q.rho - 0.5f), S - 1);
         const float ir2 = 1.0f / (q.rho * q.rho);
         float gu = 0.0f, gv = 0.0f, gr = 0.0f;
-        for (int r = r0; r <= r1; r++) {
-            const float dy = (float)r + 0.5f - q.v;
-            for (int cc = c0; cc <= c1; cc++) {
-                const float dx = (float)cc + 0.5f - q.u;
-                const float d2 = dx * dx + dy * dy;
-                const float av = 1.0f - d2 * ir2;
-                if (av <= 0.0f || av >= kMaskAmax) continue;      // outside the disc / clamped: no gradient
-                const float w = W[(size_t)r * S + cc] / (1.0f - av);
-                gu += w * dx;
-                gv += w * dy;
-                gr += w * d2;
+        if (ok) {
+            for (int r = r0 + sub; r <= r1; r += kGradSub) {
+                const float dy = (float)r + 0.5f - q.v;
+                for (int cc = c0; cc <= c1; cc++) {
+                    const float dx = (float)cc + 0.5f - q.u;
+                    const float d2 = dx * dx + dy * dy;
+                    const float av = 1.0f - d2 * ir2;
+                    if (av <= 0.0f || av >= kMaskAmax) continue;      // outside the disc / clamped: no gradient
+                    const float w = W[(size_t)r * S + cc] / (1.0f - av);
+                    gu += w * dx;
+                    gv += w * dy;
+                    gr += w * d2;
+                }
             }
         }
+#pragma unroll
+        for (int off = kGradSub / 2; off > 0; off >>= 1) {
+            gu += __shfl_xor(gu, off, kWave);
+            gv += __shfl_xor(gv, off, kWave);
+            gr += __shfl_xor(gr, off, kWave);
+        }
+        if (!ok || sub != 0) continue;
         gu *= 2.0f * ir2; gv *= 2.0f * ir2; gr *= 2.0f * ir2 / q.rho;
         const double iz = 1.0 / (double)q.zv;
         const double f4 = (double)hs * kMaskFocal;
@@ -845,7 +864,11 @@ static int mask_step(int b, int nc, const float *complete, const float *center, 
     hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, nc, (const float4 *)uvr, S, L, accum);
     hipLaunchKernelGGL(mask_sums_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)L, mref, stats, accum);
     hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)L, mref, stats, mask_weight, W, accum);
-    hipLaunchKernelGGL(mask_grad_kernel, dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride,
+    if (b <= 2)
+        hipLaunchKernelGGL((mask_grad_kernel<8>), dim3(lin_grid((long long)nc * 8), b), dim3(kQBlock), 0, st, nc, complete, center, cstride,
+                       params, pstride, rad, S, (const float *)W, accum);
+    else
+        hipLaunchKernelGGL((mask_grad_kernel<1>), dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride,
                        params, pstride, rad, S, (const float *)W, accum);
     return check(hipGetLastError(), "mask step launch") ? 1 : 0;
 }
