@@ -288,3 +288,48 @@ def test_zbuffer_visibility_and_viewpoint_select(gp, oracle):
     sub = cap[fps_sampling(cap, 3000).long()]
     _, counts = dp.getVisiblePointsZBuffer(sub, cams=dp.cameras, tol=1e-4)
     assert best == int(torch.argmax(counts)) and int(counts.max()) > 1500
+
+
+def test_get_uvs_fuzz(gp, oracle):
+    """40 random shapes: 1 .. 70000 points, 1 .. 200 cameras at random eyes (incl. points behind a camera and far
+    off-axis), scales 1e-2 .. 1e2, rescale on and off, paddings 0 .. 0.3 -- uv / depth / transformed points are
+    the oracle's, bit for bit (NaN where the oracle has NaN)."""
+    torch = gp["torch"]
+    DP = gp["DP"]
+    rng = np.random.default_rng(99)
+    for case in range(40):
+        n = int(rng.integers(2, 70001)) if case % 4 else int(rng.integers(2, 70))
+        c = int(rng.integers(1, 201)) if case % 3 else int(rng.integers(1, 4))
+        scale = 10.0 ** rng.uniform(-2, 2)
+        xyz = ((rng.random((n, 3)) - 0.5) * scale).astype(np.float32)
+        eyes = rng.normal(size=(c, 3))
+        eyes *= (scale * rng.uniform(0.3, 4.0, size=(c, 1))) / np.linalg.norm(eyes, axis=1, keepdims=True)
+        views = np.stack([DP.look_at(e, np.zeros(3), DP.calculate_up_vector(e, np.zeros(3))) for e in eyes]).astype(np.float32)
+        rescale = bool(case & 1)
+        padding = float(rng.choice([0.0, 0.15, 0.3]))
+        uv, depth, tr = gp["dp"].getUvs(torch.from_numpy(views).cuda(), torch.from_numpy(xyz).cuda(), rescale=rescale, padding=padding)
+        ouv, od, otr, _ = oracle.get_uvs(views, gp["dp"].focal, xyz, rescale=rescale, padding=padding)
+        assert np.array_equal(uv.cpu().numpy(), ouv, equal_nan=True), (case, n, c)
+        assert np.array_equal(depth.cpu().numpy(), od, equal_nan=True), (case, n, c)
+        assert np.array_equal(tr.cpu().numpy(), otr, equal_nan=True), (case, n, c)
+
+
+def test_paint_and_gather_fuzz(gp, oracle):
+    """30 random cases of uvToPixels -> paintPixels (collisions: the highest point index wins) -> gather_colors:
+    1 .. 50000 points, resolutions 8 .. 512, point sizes 1 .. 4, uv partly out of range."""
+    torch = gp["torch"]
+    rng = np.random.default_rng(123)
+    for case in range(30):
+        n = int(rng.integers(1, 50001)) if case % 3 else int(rng.integers(1, 40))
+        res = int(rng.choice([8, 31, 64, 256, 512]))
+        ps = int(rng.integers(1, 5))
+        uv = (rng.random((n, 2), dtype=np.float32) * 1.2 - 0.1).astype(np.float32)
+        pix = gp["dp"].uvToPixels(torch.from_numpy(uv).cuda(), res)
+        opix = oracle.uv_to_pixels(uv, res)
+        np.testing.assert_array_equal(pix.cpu().numpy(), opix)
+        col = rng.random((n, 3), dtype=np.float32)
+        img = torch.zeros(3, res, res, device="cuda")
+        out = gp["dp"].paintPixels(img, pix, torch.from_numpy(col).cuda(), ps)
+        oout, oimg = oracle.paint_pixels(res, opix, col, ps)
+        np.testing.assert_array_equal(out.cpu().numpy(), oout, err_msg="case %d" % case)
+        np.testing.assert_array_equal(img.cpu().numpy(), oimg, err_msg="case %d" % case)
