@@ -61,3 +61,32 @@ def test_fps_bad_args(fg):
     torch = fg["torch"]
     with pytest.raises(ValueError):
         fg["fps"](torch.rand(10, 3).cuda(), 11)
+
+
+def test_fps_fuzz(fg, oracle):
+    """24 random cases: 1 .. 90000 points (one to eleven workgroups per cloud), k from 1 to n, 1 .. 5 clouds,
+    lattices and repeated points (arg-max ties: the first index wins), scales 1e-3 .. 1e3, both arithmetic modes."""
+    torch = fg["torch"]
+    rng = np.random.default_rng(808)
+    for case in range(24):
+        n = int(rng.integers(1, 90001)) if case % 3 else int(rng.integers(1, 300))
+        k = int(rng.integers(1, min(n, 3000) + 1))
+        c = int(rng.integers(1, 6)) if n < 30000 else 1
+        kind = case % 3
+        if kind == 0:
+            x = rng.random((c, n, 3)) - 0.5
+        elif kind == 1:
+            g = rng.integers(0, 12, size=(c, n, 3)).astype(np.float64) / 12           # lattice: many exact ties
+            x = g - 0.5
+        else:
+            base = rng.random((c, max(1, n // 5), 3)) - 0.5
+            x = np.stack([base[i][rng.integers(0, base.shape[1], n)] for i in range(c)])
+        x = (x * 10.0 ** rng.uniform(-3, 3)).astype(np.float32)
+        mode = case & 1
+        prev = fg["lib"].lib.genpc_set_arith(mode)
+        try:
+            idx = fg["fps"](torch.from_numpy(x).cuda(), k).cpu().numpy()
+        finally:
+            fg["lib"].lib.genpc_set_arith(prev)
+        for i in range(c):
+            np.testing.assert_array_equal(idx[i], oracle.fps(x[i], k, mode), err_msg="case %d n %d k %d" % (case, n, k))
