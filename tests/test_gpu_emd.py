@@ -203,3 +203,35 @@ def test_emd_repeated_calls_on_the_same_buffers(gp, oracle):
         od, oa = oracle.emd_forward(xn, yn, 0.005, 30)[:2]
         np.testing.assert_array_equal(s["assignment"].cpu().numpy(), oa, err_msg="call %d" % call)
         np.testing.assert_array_equal(s["dist"].cpu().numpy(), od, err_msg="call %d" % call)
+
+
+def test_emd_fuzz(gp, oracle):
+    """16 random cases: B 1 .. 6, n 256 .. 3072, iters 1 .. 40, eps 1e-3 .. 2e-2, uniform / clustered / lattice /
+    duplicated clouds at scales 0.1 .. 3, both arithmetic modes: assignment, assignment_inv and dist bit-exact."""
+    rng = np.random.default_rng(4242)
+    for case in range(16):
+        b = int(rng.integers(1, 7))
+        n = 256 * int(rng.integers(1, 13))
+        iters = int(rng.integers(1, 41))
+        eps = float(10.0 ** rng.uniform(-3, -1.7))
+        kind = case % 4
+
+        def cloud():
+            if kind == 0:
+                x = rng.random((b, n, 3))
+            elif kind == 1:
+                c = rng.random((b, 6, 3))
+                x = np.stack([c[i][rng.integers(0, 6, n)] for i in range(b)]) + 0.03 * rng.normal(size=(b, n, 3))
+            elif kind == 2:
+                x = rng.integers(0, 9, size=(b, n, 3)) / 9.0
+            else:
+                base = rng.random((b, n // 4, 3))
+                x = np.stack([base[i][rng.integers(0, n // 4, n)] for i in range(b)])
+            return (x * rng.uniform(0.1, 3.0)).astype(np.float32)
+        x, y = cloud(), cloud()
+        mode = case & 1
+        s = run_hip(gp, x, y, eps, iters, mode)
+        d, ass, st = oracle.emd_forward(x, y, eps, iters, mode, return_state=True)
+        np.testing.assert_array_equal(s["assignment"], ass, err_msg="case %d" % case)
+        np.testing.assert_array_equal(s["dist"], d, err_msg="case %d" % case)
+        np.testing.assert_array_equal(s["assignment_inv"], st["assignment_inv"], err_msg="case %d" % case)
