@@ -170,3 +170,31 @@ def test_statistical_outlier_filter(rg, oracle, mode):
     tiny = torch.from_numpy(pts[:5]).cuda()            # fewer points than k: mean over what exists
     mt = rg["R"].knn_mean_distance(tiny, 8).cpu().numpy()
     np.testing.assert_array_equal(mt, oracle.knn_mean_distance(pts[:5], 8, 1))
+
+
+def test_knn_mean_distance_fuzz(rg, oracle):
+    """12 random clouds (2 .. 20000 points; uniform, clustered, repeated points; scales 1e-2 .. 1e2; k in
+    {8, 16, 20, 32}; both arithmetic modes): the k-NN mean distances are the oracle's, bit for bit."""
+    torch = rg["torch"]
+    from genpc_amd import _lib
+    rng = np.random.default_rng(515)
+    for case in range(12):
+        n = int(rng.integers(2, 20001)) if case % 3 else int(rng.integers(2, 60))
+        kind = case % 3
+        if kind == 0:
+            P = rng.random((n, 3)) - 0.5
+        elif kind == 1:
+            c = rng.random((5, 3)) - 0.5
+            P = c[rng.integers(0, 5, n)] + 0.02 * rng.normal(size=(n, 3))
+        else:
+            base = rng.random((max(1, n // 3), 3)) - 0.5
+            P = base[rng.integers(0, len(base), n)]
+        P = (P * 10.0 ** rng.uniform(-2, 2)).astype(np.float32)
+        k = int(rng.choice([8, 16, 20, 32]))
+        mode = case & 1
+        prev = _lib.lib.genpc_set_arith(mode)
+        try:
+            m = rg["R"].knn_mean_distance(torch.from_numpy(P).cuda(), k).cpu().numpy()
+        finally:
+            _lib.lib.genpc_set_arith(prev)
+        np.testing.assert_array_equal(m, oracle.knn_mean_distance(P, k, mode), err_msg="case %d n %d k %d" % (case, n, k))
