@@ -28,29 +28,54 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "include", "genpc_hip.h"))
+    hs.append(os.path.abspath(__file__))
+    return hs
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(HERE, "..", "include", "genpc_hip.h"))
-    deps.append(os.path.abspath(__file__))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in sources() + _headers())
 
 
-def build(force=False, save_temps=False, verbose=True):
+def build(force=False, save_temps=False, verbose=True, jobs=None):
+    """One object per .hip file (stale ones only, compiled side by side), then one link."""
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + sources() + ["-o", LIB]
-    cwd = LIBDIR
-    if save_temps:
-        cwd = os.path.join(LIBDIR, "temps")
-        os.makedirs(cwd, exist_ok=True)
-        cmd.insert(1, "-save-temps")
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    cflags = [f for f in FLAGS if f != "-shared"]
+    todo, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            cmd = [HIPCC] + cflags + ["-c", src, "-o", obj]
+            cwd = objdir
+            if save_temps:
+                cwd = os.path.join(LIBDIR, "temps")
+                os.makedirs(cwd, exist_ok=True)
+                cmd.insert(1, "-save-temps")
+            todo.append((cmd, cwd))
+
+    def run(job):
+        if verbose:
+            print("[genpc_amd.build]", " ".join(job[0]), flush=True)
+        subprocess.check_call(job[0], cwd=job[1])
+
+    jobs = jobs or int(os.environ.get("GENPC_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+        list(ex.map(run, todo))
+    link = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", LIB]
     if verbose:
-        print("[genpc_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=cwd)
+        print("[genpc_amd.build]", " ".join(link), flush=True)
+    subprocess.check_call(link, cwd=LIBDIR)
     return LIB
 
 
