@@ -101,6 +101,45 @@ static inline void project_one(const float *V, float focal, float zn, float zf, 
     o[2] = fmaf(A, zc, B) / w;
 }
 
+/* The part of DepthPrompting.getUvs that is the reference's own torch code (DepthPrompting.py:246-268),
+ * for ONE camera: t[n,3] = cam.transform(points) -> uv[n,2], depth[n].  Pinned to that code itself
+ * by tests/golden/ref_py_uvs.npz.  bbox (optional) receives min_x, min_y, max_x, max_y. */
+static void rescale_row(int n, const float *t, int rescale, float padmul, float *uv, float *depth, float *bbox)
+{
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int j = 0; j < n; j++) {
+        const float *o = t + (size_t)j * 3;
+        mnx = o[0] < mnx ? o[0] : mnx;
+        mny = o[1] < mny ? o[1] : mny;
+        mxx = o[0] > mxx ? o[0] : mxx;
+        mxy = o[1] > mxy ? o[1] : mxy;
+    }
+    if (bbox) { bbox[0] = mnx; bbox[1] = mny; bbox[2] = mxx; bbox[3] = mxy; }
+    float cx = (mnx + mxx) / 2.0f, cy = (mny + mxy) / 2.0f;
+    float sx = mxx - mnx, sy = mxy - mny;
+    float sc = sx > sy ? sx : sy;
+    for (int j = 0; j < n; j++) {
+        const float *o = t + (size_t)j * 3;
+        if (rescale) {
+            uv[j * 2 + 0] = ((o[0] - cx) / sc) * padmul + 0.5f;
+            uv[j * 2 + 1] = ((o[1] - cy) / sc) * padmul + 0.5f;
+        } else {
+            uv[j * 2 + 0] = (o[0] + 1.0f) * 0.5f;
+            uv[j * 2 + 1] = (o[1] + 1.0f) * 0.5f;
+        }
+        depth[j] = o[2];
+    }
+}
+
+/* getUvs on given transformed points [C,N,3] (what kaolin's Camera.transform returned) */
+ORACLE_API void oracle_rescale_uvs(int c, int n, const float *transformed, int rescale, float padmul, float *uv,
+                                   float *depth)
+{
+    for (int i = 0; i < c; i++)
+        rescale_row(n, transformed + (size_t)i * n * 3, rescale, padmul, uv + (size_t)i * n * 2, depth + (size_t)i * n,
+                    NULL);
+}
+
 /* DepthPrompting.getUvs, DepthPrompting.py:239-271.  transformed may be NULL.
  * padmul = float(1 - 2*padding).  bbox (optional) receives [C,4] = min_x, min_y,
  * max_x, max_y of the NDC xy. */
@@ -111,36 +150,9 @@ ORACLE_API void oracle_get_uvs(int c, int n, const float *view, float focal, flo
     float *tmp = (float *)malloc(sizeof(float) * (size_t)n * 3);
     for (int i = 0; i < c; i++) {
         const float *V = view + (size_t)i * 12;
-        float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
-        for (int j = 0; j < n; j++) {
-            float *o = tmp + (size_t)j * 3;
-            project_one(V, focal, zn, zf, xyz + (size_t)j * 3, o);
-            mnx = o[0] < mnx ? o[0] : mnx;
-            mny = o[1] < mny ? o[1] : mny;
-            mxx = o[0] > mxx ? o[0] : mxx;
-            mxy = o[1] > mxy ? o[1] : mxy;
-        }
-        if (bbox) {
-            bbox[i * 4 + 0] = mnx; bbox[i * 4 + 1] = mny; bbox[i * 4 + 2] = mxx; bbox[i * 4 + 3] = mxy;
-        }
-        float cx = (mnx + mxx) / 2.0f, cy = (mny + mxy) / 2.0f;
-        float sx = mxx - mnx, sy = mxy - mny;
-        float sc = sx > sy ? sx : sy;
-        for (int j = 0; j < n; j++) {
-            const float *o = tmp + (size_t)j * 3;
-            size_t q = (size_t)i * n + j;
-            if (transformed) {
-                transformed[q * 3 + 0] = o[0]; transformed[q * 3 + 1] = o[1]; transformed[q * 3 + 2] = o[2];
-            }
-            if (rescale) {
-                uv[q * 2 + 0] = ((o[0] - cx) / sc) * padmul + 0.5f;
-                uv[q * 2 + 1] = ((o[1] - cy) / sc) * padmul + 0.5f;
-            } else {
-                uv[q * 2 + 0] = (o[0] + 1.0f) * 0.5f;
-                uv[q * 2 + 1] = (o[1] + 1.0f) * 0.5f;
-            }
-            depth[q] = o[2];
-        }
+        for (int j = 0; j < n; j++) project_one(V, focal, zn, zf, xyz + (size_t)j * 3, tmp + (size_t)j * 3);
+        if (transformed) memcpy(transformed + (size_t)i * n * 3, tmp, sizeof(float) * (size_t)n * 3);
+        rescale_row(n, tmp, rescale, padmul, uv + (size_t)i * n * 2, depth + (size_t)i * n, bbox ? bbox + i * 4 : NULL);
     }
     free(tmp);
 }
@@ -421,38 +433,46 @@ ORACLE_API void oracle_pose_optimize_cd(int nc, const float *complete, int np_, 
 
 /* ------------------------------------------------------------------------
  * Silhouette ("mask") half of compute_loss_function, diff_obj_pose.py:286-336, and the
- * renders it compares (:108-134 reference image of the partial cloud, :426-433 image of the
- * posed complete cloud).
+ * renders it compares (:108-134 reference image of the partial cloud with ITS colours, :426-433
+ * image of the posed complete cloud with its colours; load_point_cloud always returns colours for the
+ * reference's inputs, :136-164 with utils/dataUtils.py:182-187,229-246 -- ones only for a colourless
+ * PLY).
  *
- * WHAT IS RESTATED FROM THE REFERENCE (its own torch code):
- *   normalize_images 'statistical' (:204-217): result' = clamp((result - mean) / (std + 1e-6)
+ * WHAT IS RESTATED FROM THE REFERENCE (its own torch code; pinned to that code itself, executed in the
+ * build container, by tests/golden/ref_py_mask_loss.npz -- see tests/golden/make_reference_vectors.py):
+ *   normalize_images 'statistical' (:204-217): per CHANNEL, result' = clamp((result - mean) / (std + 1e-6)
  *     * (std_ref + 1e-6) + mean_ref, 0, 1), torch.std = unbiased;
- *   compute_soft_mask (:261-278): m = sigmoid((luminance - 0.1) / 0.05);
+ *   compute_soft_mask (:261-278): m = sigmoid((0.299 R + 0.587 G + 0.114 B - 0.1) / 0.05);
  *   mask_loss = 30 MSE(m, m_ref) + BCE(m, m_ref) + 10 Dice(m, m_ref)   (:304-311,238-259),
  *     F.binary_cross_entropy clamps its logs at -100; Dice smooth 1e-6;
  *   total = mask_loss * 1 + cd * 3 (+ 1e-3 |RR^T - I|_F)   (:329-333,543-546).
  * WHAT IS NOT: the renderer.  The reference renders with pytorch3d's PulsarPointsRenderer
- * (CUDA only, absent here, unpinned): sphere splatting with a softmax in depth.  Its point clouds
- * carry no colours on this path (load_point_cloud gives ones, :157-158), so the image is a soft
- * occupancy map.  This build defines its OWN differentiable occupancy splat with the same
- * camera and radii (PARITY UNPINNED against Pulsar):
+ * (CUDA only, absent here, unpinned): sphere splatting blended by a softmax in depth (gamma 1e-2).
+ * This build defines its OWN differentiable colour splat with the same camera and radii (PARITY
+ * UNPINNED against Pulsar -- wherever a mask_loss value is quoted it is this splat's):
  *   camera (pytorch3d look_at_view_transform(eye=(0,0,3)) + PerspectiveCameras(focal 4, NDC),
  *     from memory):  Zv = 3 - z;  u = S/2 (1 + 4 x / Zv);  v = S/2 (1 - 4 y / Zv);
  *     rho = S/2 * 4 * radius / Zv (radius_world=True); points with Zv outside (1e-4, 5) are skipped;
- *   coverage of pixel (r, c) by point i:  a = min(0.999, max(0, 1 - ((c + .5 - u)^2 + (r + .5 - v)^2) / rho^2));
- *   image  I = 1 - prod_i (1 - a_i)   (all three channels equal: luminance = I).
+ *   coverage of pixel (r, c) by point i:  a_i = min(0.999, max(0, 1 - ((c + .5 - u)^2 + (r + .5 - v)^2) / rho^2));
+ *   occupancy  O = 1 - prod_i (1 - a_i);  colour  A_ch = sum_i a_i c_i,ch / sum_i a_i  (coverage-weighted mean,
+ *   order-independent: NO depth ordering, unlike Pulsar);  image  I_ch = O * A_ch  (background 0, as bg_col).
  * The posed cloud is splatted with 1.1 * radius (:385), the reference cloud with radius (:118).
+ * Images are [S, S, 3] (H, W, C like the reference's).
  * ---------------------------------------------------------------------- */
 #define MASK_AMAX 0.999
-static void splat_logt(int n, const float *pts, double radius, int S, double *logt)
+/* logt[P] = sum log(1 - a), den[P] = sum a, num[P*3] = sum a c  (col NULL: white) */
+static void splat_accumulate(int n, const float *pts, const float *col, double radius, int S, double *logt, double *den,
+                             double *num)
 {
-    for (int q = 0; q < S * S; q++) logt[q] = 0.0;
+    for (int q = 0; q < S * S; q++) { logt[q] = 0.0; den[q] = 0.0; num[3 * q] = num[3 * q + 1] = num[3 * q + 2] = 0.0; }
     const double hs = 0.5 * S;
     for (int i = 0; i < n; i++) {
         const double x = pts[(size_t)i * 3 + 0], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
         const double zv = 3.0 - z;
         if (!(zv > 1e-4) || !(zv < 5.0)) continue;
         const double u = hs * (1.0 + 4.0 * x / zv), v = hs * (1.0 - 4.0 * y / zv), rho = hs * 4.0 * radius / zv;
+        const double cr = col ? col[(size_t)i * 3 + 0] : 1.0, cg = col ? col[(size_t)i * 3 + 1] : 1.0,
+                     cb = col ? col[(size_t)i * 3 + 2] : 1.0;
         int c0 = (int)floor(u - rho - 0.5), c1 = (int)ceil(u + rho - 0.5);
         int r0 = (int)floor(v - rho - 0.5), r1 = (int)ceil(v + rho - 0.5);
         if (c0 < 0) c0 = 0;
@@ -465,44 +485,76 @@ static void splat_logt(int n, const float *pts, double radius, int S, double *lo
                 double a = 1.0 - (dx * dx + dy * dy) / (rho * rho);
                 if (a <= 0.0) continue;
                 if (a > MASK_AMAX) a = MASK_AMAX;
-                logt[(size_t)r * S + c] += log(1.0 - a);
+                const size_t q = (size_t)r * S + c;
+                logt[q] += log(1.0 - a);
+                den[q] += a;
+                num[3 * q + 0] += a * cr;
+                num[3 * q + 1] += a * cg;
+                num[3 * q + 2] += a * cb;
             }
     }
 }
 
-/* image of a cloud: I[S*S] */
-ORACLE_API void oracle_splat_image(int n, const float *pts, float radius, int S, float *img)
+static void splat_compose(int P, const double *logt, const double *den, const double *num, double *I)
 {
-    double *logt = (double *)malloc(sizeof(double) * (size_t)S * S);
-    splat_logt(n, pts, radius, S, logt);
-    for (int q = 0; q < S * S; q++) img[q] = (float)(1.0 - exp(logt[q]));
-    free(logt);
+    for (int q = 0; q < P; q++) {
+        const double O = 1.0 - exp(logt[q]);
+        for (int ch = 0; ch < 3; ch++) I[3 * q + ch] = den[q] > 0.0 ? O * num[3 * q + ch] / den[q] : 0.0;
+    }
+}
+
+/* image of a coloured cloud: img[S, S, 3]; col NULL = white */
+ORACLE_API void oracle_splat_image(int n, const float *pts, const float *col, float radius, int S, float *img)
+{
+    const int P = S * S;
+    double *w = (double *)malloc(sizeof(double) * (size_t)P * 8);
+    splat_accumulate(n, pts, col, radius, S, w, w + P, w + 2 * (size_t)P);
+    splat_compose(P, w, w + P, w + 2 * (size_t)P, w + 5 * (size_t)P);
+    for (int q = 0; q < 3 * P; q++) img[q] = (float)w[5 * (size_t)P + q];
+    free(w);
 }
 
 /* torch.sigmoid on a float32 tensor: the soft masks are fp32 in the reference, and that shows:
  * for (x - 0.1) / 0.05 > ~16.6 the result is exactly 1.0f, log(1 - m) is -inf and
  * F.binary_cross_entropy's clamp at -100 decides the loss of that pixel (a pixel the posed cloud
  * covers and the reference image does not costs 100 (1 - m_ref) / P, not 18 / P), while its
- * gradient m (1 - m) is exactly 0.  The restatement keeps m and its logs in fp32 for that reason;
- * everything around them accumulates in double. */
+ * gradient m (1 - m) is exactly 0.  The restatement keeps the sigmoid's argument, m and its logs in fp32
+ * for that reason; everything around them accumulates in double. */
 static double sigm(double x) { return (double)(1.0f / (1.0f + expf(-(float)x))); }
 static double log_as_f32(double m) { return (double)logf((float)m); }
+static const double kLum[3] = {0.299, 0.587, 0.114};
+static double soft_mask(const double *rgb)
+{
+    const float lum = (float)(kLum[0] * rgb[0] + kLum[1] * rgb[1] + kLum[2] * rgb[2]);
+    return sigm((double)((lum - 0.1f) / 0.05f));
+}
 
-/* mask_loss(result image I, reference image Iref) and d mask_loss / d I (NULL to skip). */
+/* mask_loss(result image I[P*3], reference image Iref[P*3]) and d mask_loss / d I (NULL to skip). */
 static double mask_loss_images(int P, const double *I, const double *Iref, double *dLdI)
 {
-    double mu = 0, mur = 0;
-    for (int q = 0; q < P; q++) { mu += I[q]; mur += Iref[q]; }
-    mu /= P; mur /= P;
-    double var = 0, varr = 0;
-    for (int q = 0; q < P; q++) { var += (I[q] - mu) * (I[q] - mu); varr += (Iref[q] - mur) * (Iref[q] - mur); }
-    const double sd = sqrt(var / (P - 1)), sdr = sqrt(varr / (P - 1));
-    const double k = (sdr + 1e-6) / (sd + 1e-6);
+    double mu[3] = {0, 0, 0}, mur[3] = {0, 0, 0}, sd[3], sdr[3], k[3];
+    for (int q = 0; q < P; q++)
+        for (int ch = 0; ch < 3; ch++) { mu[ch] += I[3 * q + ch]; mur[ch] += Iref[3 * q + ch]; }
+    for (int ch = 0; ch < 3; ch++) { mu[ch] /= P; mur[ch] /= P; }
+    double var[3] = {0, 0, 0}, varr[3] = {0, 0, 0};
+    for (int q = 0; q < P; q++)
+        for (int ch = 0; ch < 3; ch++) {
+            var[ch] += (I[3 * q + ch] - mu[ch]) * (I[3 * q + ch] - mu[ch]);
+            varr[ch] += (Iref[3 * q + ch] - mur[ch]) * (Iref[3 * q + ch] - mur[ch]);
+        }
+    for (int ch = 0; ch < 3; ch++) {
+        sd[ch] = sqrt(var[ch] / (P - 1));
+        sdr[ch] = sqrt(varr[ch] / (P - 1));
+        k[ch] = (sdr[ch] + 1e-6) / (sd[ch] + 1e-6);
+    }
     double s_mse = 0, s_bce = 0, s_int = 0, s_m = 0, s_r = 0;
     for (int q = 0; q < P; q++) {
-        double xn = (I[q] - mu) * k + mur;
-        xn = xn < 0 ? 0 : (xn > 1 ? 1 : xn);
-        const double m = sigm((xn - 0.1) / 0.05), mr = sigm((Iref[q] - 0.1) / 0.05);
+        double xn[3];
+        for (int ch = 0; ch < 3; ch++) {
+            const double x0 = (I[3 * q + ch] - mu[ch]) * k[ch] + mur[ch];
+            xn[ch] = x0 < 0 ? 0 : (x0 > 1 ? 1 : x0);
+        }
+        const double m = soft_mask(xn), mr = soft_mask(Iref + 3 * q);
         double lm = log_as_f32(m), l1m = log_as_f32(1.0 - m);
         if (lm < -100) lm = -100;
         if (l1m < -100) l1m = -100;
@@ -515,14 +567,18 @@ static double mask_loss_images(int P, const double *I, const double *Iref, doubl
     const double den = s_m + s_r + 1e-6, num = 2.0 * s_int + 1e-6;
     const double loss = 30.0 * s_mse / P + s_bce / P + 10.0 * (1.0 - num / den);
     if (!dLdI) return loss;
-    /* G = d loss / d xn (through sigmoid and clamp), then through the statistics */
+    /* G_ch = d loss / d xn_ch (through the sigmoid, the luminance and the clamp), then through the statistics */
     double *G = dLdI;
-    double sG = 0, sGd = 0;
+    double sG[3] = {0, 0, 0}, sGd[3] = {0, 0, 0};
     for (int q = 0; q < P; q++) {
-        double xn = (I[q] - mu) * k + mur;
-        const int inside = xn > 0 && xn < 1;
-        xn = xn < 0 ? 0 : (xn > 1 ? 1 : xn);
-        const double m = sigm((xn - 0.1) / 0.05), mr = sigm((Iref[q] - 0.1) / 0.05);
+        double xn[3];
+        int inside[3];
+        for (int ch = 0; ch < 3; ch++) {
+            const double x0 = (I[3 * q + ch] - mu[ch]) * k[ch] + mur[ch];
+            inside[ch] = x0 > 0 && x0 < 1;
+            xn[ch] = x0 < 0 ? 0 : (x0 > 1 ? 1 : x0);
+        }
+        const double m = soft_mask(xn), mr = soft_mask(Iref + 3 * q);
         double dm = 30.0 * 2.0 * (m - mr) / P;
         /* BCE: -(mr/m - (1-mr)/(1-m)) / P where the logs are not clamped (torch's backward divides
          * (m - mr) by max(m (1 - m), 1e-12): the same wherever m (1 - m) > 0, and where it is 0 the
@@ -532,51 +588,59 @@ static double mask_loss_images(int P, const double *I, const double *Iref, doubl
         if (log_as_f32(1.0 - m) > -100) db += (1.0 - mr) / (1.0 - m);
         dm += db / P;
         dm += 10.0 * (-(2.0 * mr * den - num) / (den * den));
-        const double g = inside ? dm * m * (1.0 - m) / 0.05 : 0.0;
-        G[q] = g;
-        sG += g;
-        sGd += g * (I[q] - mu);
+        for (int ch = 0; ch < 3; ch++) {
+            const double g = inside[ch] ? dm * m * (1.0 - m) / 0.05 * kLum[ch] : 0.0;
+            G[3 * q + ch] = g;
+            sG[ch] += g;
+            sGd[ch] += g * (I[3 * q + ch] - mu[ch]);
+        }
     }
-    for (int q = 0; q < P; q++) {
-        double v = k * (G[q] - sG / P);
-        if (sd > 0) v -= (sdr + 1e-6) / ((sd + 1e-6) * (sd + 1e-6)) * (I[q] - mu) / ((P - 1) * sd) * sGd;
-        dLdI[q] = v;
-    }
+    for (int q = 0; q < P; q++)
+        for (int ch = 0; ch < 3; ch++) {
+            double v = k[ch] * (G[3 * q + ch] - sG[ch] / P);
+            if (sd[ch] > 0)
+                v -= (sdr[ch] + 1e-6) / ((sd[ch] + 1e-6) * (sd[ch] + 1e-6)) * (I[3 * q + ch] - mu[ch]) / ((P - 1) * sd[ch]) * sGd[ch];
+            dLdI[3 * q + ch] = v;
+        }
     return loss;
 }
 
-ORACLE_API float oracle_mask_loss(int S, const float *img, const float *ref)
+/* img, ref: [S, S, 3]; grad (NULL to skip): d mask_loss / d img, [S, S, 3] */
+ORACLE_API float oracle_mask_loss(int S, const float *img, const float *ref, float *grad)
 {
     const int P = S * S;
-    double *a = (double *)malloc(sizeof(double) * 2 * (size_t)P);
-    for (int q = 0; q < P; q++) { a[q] = img[q]; a[P + q] = ref[q]; }
-    const double l = mask_loss_images(P, a, a + P, NULL);
+    double *a = (double *)calloc(9 * (size_t)P, sizeof(double));
+    for (int q = 0; q < 3 * P; q++) { a[q] = img[q]; a[3 * (size_t)P + q] = ref[q]; }
+    const double l = mask_loss_images(P, a, a + 3 * (size_t)P, grad ? a + 6 * (size_t)P : NULL);
+    if (grad)
+        for (int q = 0; q < 3 * P; q++) grad[q] = (float)a[6 * (size_t)P + q];
     free(a);
     return (float)l;
 }
 
 /* Full loss and gradient: mask_weight * mask_loss + cd_weight * cd + reg_weight * |RR^T - I|_F.
- * ref_img[S*S]: oracle_splat_image(partial, radius).  loss_out[4] = total, cd, ortho, mask. */
-ORACLE_API void oracle_pose_full_loss_grad(int nc, const float *v, const float *center, const float *params,
-                                           int np_, const float *partial, const float *d1, const int *i1,
-                                           const float *d2, const int *i2, float cd_weight, float reg_weight,
-                                           float mask_weight, float radius, int S, const float *ref_img,
-                                           float *loss_out, float *grad)
+ * vert_col[nc,3] (NULL = white): the complete cloud's colours; ref_img[S*S*3]: oracle_splat_image(partial,
+ * partial_col, radius).  loss_out[4] = total, cd, ortho, mask. */
+ORACLE_API void oracle_pose_full_loss_grad(int nc, const float *v, const float *vert_col, const float *center,
+                                           const float *params, int np_, const float *partial, const float *d1,
+                                           const int *i1, const float *d2, const int *i2, float cd_weight,
+                                           float reg_weight, float mask_weight, float radius, int S,
+                                           const float *ref_img, float *loss_out, float *grad)
 {
     float lo3[3], g_cd[10];
     oracle_pose_loss_grad(nc, v, center, params, np_, partial, d1, i1, d2, i2, cd_weight, reg_weight, lo3, g_cd);
     const int P = S * S;
     float *pts = (float *)malloc(sizeof(float) * (size_t)nc * 3);
     oracle_pose_transform(nc, v, center, params, pts);
-    double *logt = (double *)malloc(sizeof(double) * (size_t)P);
-    double *I = (double *)malloc(sizeof(double) * (size_t)P);
-    double *Ir = (double *)malloc(sizeof(double) * (size_t)P);
-    double *dLdI = (double *)malloc(sizeof(double) * (size_t)P);
+    double *logt = (double *)malloc(sizeof(double) * (size_t)P * 14);
+    double *den = logt + P, *num = den + P, *I = num + 3 * (size_t)P, *Ir = I + 3 * (size_t)P, *dLdI = Ir + 3 * (size_t)P;
     const double rad = 1.1 * (double)radius;
-    splat_logt(nc, pts, rad, S, logt);
-    for (int q = 0; q < P; q++) { I[q] = 1.0 - exp(logt[q]); Ir[q] = ref_img[q]; }
+    splat_accumulate(nc, pts, vert_col, rad, S, logt, den, num);
+    splat_compose(P, logt, den, num, I);
+    for (int q = 0; q < 3 * P; q++) Ir[q] = ref_img[q];
     const double ml = mask_loss_images(P, I, Ir, dLdI);
-    /* back through the splat to the points, then to (R, s, t) like the CD term */
+    /* back through the splat to the points, then to (R, s, t) like the CD term.
+     * I_ch = O A_ch:  d I_ch / d a_i = T / (1 - a_i) A_ch + O (c_i,ch - A_ch) / D   (T = exp(logt), D = den) */
     float R[9];
     oracle_rot6d_to_matrix(params, R);
     const float s = expf(params[9]);
@@ -587,6 +651,8 @@ ORACLE_API void oracle_pose_full_loss_grad(int nc, const float *v, const float *
         const double zv = 3.0 - z;
         if (!(zv > 1e-4) || !(zv < 5.0)) continue;
         const double u = hs * (1.0 + 4.0 * x / zv), vv = hs * (1.0 - 4.0 * y / zv), rho = hs * 4.0 * rad / zv;
+        const double ci[3] = {vert_col ? vert_col[(size_t)i * 3 + 0] : 1.0, vert_col ? vert_col[(size_t)i * 3 + 1] : 1.0,
+                              vert_col ? vert_col[(size_t)i * 3 + 2] : 1.0};
         int c0 = (int)floor(u - rho - 0.5), c1 = (int)ceil(u + rho - 0.5);
         int r0 = (int)floor(vv - rho - 0.5), r1 = (int)ceil(vv + rho - 0.5);
         if (c0 < 0) c0 = 0;
@@ -599,8 +665,13 @@ ORACLE_API void oracle_pose_full_loss_grad(int nc, const float *v, const float *
                 const double dx = c + 0.5 - u, dy = r + 0.5 - vv;
                 const double a = 1.0 - (dx * dx + dy * dy) / (rho * rho);
                 if (a <= 0.0 || a >= MASK_AMAX) continue;        /* clamped: no gradient */
-                const int q = r * S + c;
-                const double w = dLdI[q] * exp(logt[q]) / (1.0 - a);    /* dL/da_i */
+                const size_t q = (size_t)r * S + c;
+                const double T = exp(logt[q]), O = 1.0 - T;
+                double w = 0.0;                                   /* dL/da_i */
+                for (int ch = 0; ch < 3; ch++) {
+                    const double A = num[3 * q + ch] / den[q];
+                    w += dLdI[3 * q + ch] * (T / (1.0 - a) * A + O * (ci[ch] - A) / den[q]);
+                }
                 gu += w * 2.0 * dx / (rho * rho);
                 gv += w * 2.0 * dy / (rho * rho);
                 grho += w * 2.0 * (dx * dx + dy * dy) / (rho * rho * rho);
@@ -625,15 +696,16 @@ ORACLE_API void oracle_pose_full_loss_grad(int nc, const float *v, const float *
     loss_out[1] = lo3[1];
     loss_out[2] = lo3[2];
     loss_out[3] = (float)ml;
-    free(pts); free(logt); free(I); free(Ir); free(dLdI);
+    free(pts); free(logt);
 }
 
 /* object_pose_optimization with the full objective (diff_obj_pose.py:496-594):
  * loss = mask_loss + 3 cd + 1e-3 |RR^T - I|_F, multi-start, best-of-starts as in
  * oracle_pose_optimize_cd. */
-ORACLE_API void oracle_pose_optimize(int nc, const float *complete, int np_, const float *partial, float lr,
-                                     int iters, int starts, int fma_mode, float radius, int S, float mask_weight,
-                                     float *transform, float *history, float *best_params)
+ORACLE_API void oracle_pose_optimize(int nc, const float *complete, const float *complete_col, int np_,
+                                     const float *partial, const float *partial_col, float lr, int iters, int starts,
+                                     int fma_mode, float radius, int S, float mask_weight, float *transform,
+                                     float *history, float *best_params)
 {
     float center[3] = {0, 0, 0};
     {
@@ -647,8 +719,8 @@ ORACLE_API void oracle_pose_optimize(int nc, const float *complete, int np_, con
     int *i1 = (int *)malloc(sizeof(int) * (size_t)nc);
     float *d2 = (float *)malloc(sizeof(float) * (size_t)np_);
     int *i2 = (int *)malloc(sizeof(int) * (size_t)np_);
-    float *ref = (float *)malloc(sizeof(float) * (size_t)S * S);
-    oracle_splat_image(np_, partial, radius, S, ref);
+    float *ref = (float *)malloc(sizeof(float) * (size_t)S * S * 3);
+    oracle_splat_image(np_, partial, partial_col, radius, S, ref);
     float best_loss = INFINITY;
     for (int st = 0; st < starts; st++) {
         double th = st * 90.0 * M_PI / 180.0;
@@ -660,7 +732,7 @@ ORACLE_API void oracle_pose_optimize(int nc, const float *complete, int np_, con
             oracle_nm_distance(1, nc, pts, np_, partial, d1, i1, fma_mode);
             oracle_nm_distance(1, np_, partial, nc, pts, d2, i2, fma_mode);
             float lo[4], grad[10];
-            oracle_pose_full_loss_grad(nc, complete, center, params, np_, partial, d1, i1, d2, i2, 3.0f, 0.001f,
+            oracle_pose_full_loss_grad(nc, complete, complete_col, center, params, np_, partial, d1, i1, d2, i2, 3.0f, 0.001f,
                                        mask_weight, radius, S, ref, lo, grad);
             if (history) history[(size_t)st * (iters + 1) + it] = lo[0];
             if (lo[0] < local_best) local_best = lo[0];

@@ -268,6 +268,17 @@ def get_uvs(views, focal, xyz, rescale=True, padding=0.15, near=1e-2, far=1e2):
     return uv, dp, tr, bb
 
 
+def rescale_uvs(transformed, rescale=True, padding=0.15):
+    """getUvs' own arithmetic (DepthPrompting.py:246-268) on given transformed points [C,N,3] -> uv, depth."""
+    t, pt = _f(transformed)
+    c, n = t.shape[0], t.shape[1]
+    uv = np.zeros((c, n, 2), np.float32)
+    dp = np.zeros((c, n), np.float32)
+    lib().oracle_rescale_uvs(c, n, pt, int(bool(rescale)), ctypes.c_float(np.float32(1 - 2 * padding)),
+                             uv.ctypes.data_as(_f32p), dp.ctypes.data_as(_f32p))
+    return uv, dp
+
+
 def uv_to_pixels(uv, res, clip_max=None):
     uv, pu = _f(uv)
     n = uv.shape[0]
@@ -288,6 +299,23 @@ def paint_pixels(res, pix, colors, point_size, img=None):
     out = np.zeros_like(img)
     lib().oracle_paint_pixels(int(res), pix.shape[0], pp, pc, ch, int(point_size), pi, out.ctypes.data_as(_f32p))
     return out, img
+
+
+def get_raw_depth(pix, depth, colors, res, point_size=1, mask_pixel_rate=3):
+    """DepthPrompting.getRawDepth (:341-391) composed from paint_pixels: -> sparse_img, sparse_depth,
+    hole_mask1, hole_mask2, each [3,res,res] float32.  Grey level (:362-366) in float32 like torch."""
+    d = np.ascontiguousarray(depth, np.float32)
+    one, p1, p8 = np.float32(1.0), np.float32(0.1), np.float32(0.8)
+    grey = p1 + p8 * (one - (d - d.min()) / (d.max() - d.min()))
+    sparse_img, _ = paint_pixels(res, pix, colors, point_size)
+    sparse_depth, _ = paint_pixels(res, pix, np.repeat(grey[:, None], 3, 1), point_size)
+    all_front, _ = paint_pixels(res, pix, colors, point_size * mask_pixel_rate)
+    all_front = (all_front != 0).astype(np.float32)
+    all_back = 1 - all_front
+    back = 1 - (sparse_img != 0).astype(np.float32)
+    h1 = ((all_back * 255).astype(np.int32) ^ (back * 255).astype(np.int32)).astype(np.float32) / 255
+    h2 = ((all_front * 255).astype(np.int32) ^ (back * 255).astype(np.int32)).astype(np.float32) / 255
+    return sparse_img, sparse_depth, h1, h2
 
 
 def gather_colors(pix, img):
@@ -351,25 +379,41 @@ def pose_optimize_cd(complete, partial, lr=0.01, iters=200, starts=4, fma_mode=1
     return T.reshape(4, 4), hist, bp
 
 
-def splat_image(pts, radius, size):
-    """Own soft-occupancy splat (genpc_oracle_geom.c, PARITY UNPINNED against Pulsar) -> [size, size]."""
+def _fopt(x):
+    """optional float array -> (array or None, pointer or NULL)"""
+    if x is None:
+        return None, None
+    return _f(x)
+
+
+def splat_image(pts, radius, size, colors=None):
+    """Own differentiable colour splat (genpc_oracle_geom.c, PARITY UNPINNED against Pulsar)
+    -> [size, size, 3]; colors None = white."""
     p, pp = _f(pts)
-    img = np.zeros((size, size), np.float32)
-    lib().oracle_splat_image(p.shape[0], pp, ctypes.c_float(radius), int(size), img.ctypes.data_as(_f32p))
+    c, pc = _fopt(colors)
+    img = np.zeros((size, size, 3), np.float32)
+    lib().oracle_splat_image(p.shape[0], pp, pc, ctypes.c_float(radius), int(size), img.ctypes.data_as(_f32p))
     return img
 
 
-def mask_loss(img, ref):
+def mask_loss(img, ref, with_grad=False):
+    """compute_loss_function's mask_loss on [S,S,3] images (diff_obj_pose.py:286-311); with_grad: also d/d img."""
     a, pa = _f(img)
     r, pr = _f(ref)
+    assert a.shape == r.shape and a.ndim == 3 and a.shape[2] == 3 and a.shape[0] == a.shape[1]
     lib().oracle_mask_loss.restype = ctypes.c_float
-    return float(lib().oracle_mask_loss(int(a.shape[0]), pa, pr))
+    if not with_grad:
+        return float(lib().oracle_mask_loss(int(a.shape[0]), pa, pr, None))
+    g = np.zeros_like(a)
+    l = float(lib().oracle_mask_loss(int(a.shape[0]), pa, pr, g.ctypes.data_as(_f32p)))
+    return l, g
 
 
 def pose_full_loss_grad(v, center, params, partial, d1, i1, d2, i2, radius, size, ref_img, cd_weight=3.0,
-                        reg_weight=0.001, mask_weight=1.0):
-    """-> (loss[4] = total, cd, ortho, mask ; grad[10])."""
+                        reg_weight=0.001, mask_weight=1.0, vert_col=None):
+    """-> (loss[4] = total, cd, ortho, mask ; grad[10]).  ref_img [size,size,3]."""
     v, pv = _f(v)
+    vc, pvc = _fopt(vert_col)
     c, pc = _f(center)
     p, pp = _f(params)
     q, pq = _f(partial)
@@ -378,23 +422,27 @@ def pose_full_loss_grad(v, center, params, partial, d1, i1, d2, i2, radius, size
     i1, pi1 = _i(i1)
     i2, pi2 = _i(i2)
     ref, pref = _f(ref_img)
+    assert ref.shape == (size, size, 3)
     lo = np.zeros(4, np.float32)
     g = np.zeros(10, np.float32)
-    lib().oracle_pose_full_loss_grad(v.shape[0], pv, pc, pp, q.shape[0], pq, pd1, pi1, pd2, pi2,
+    lib().oracle_pose_full_loss_grad(v.shape[0], pv, pvc, pc, pp, q.shape[0], pq, pd1, pi1, pd2, pi2,
                                      ctypes.c_float(cd_weight), ctypes.c_float(reg_weight), ctypes.c_float(mask_weight),
                                      ctypes.c_float(radius), int(size), pref, lo.ctypes.data_as(_f32p),
                                      g.ctypes.data_as(_f32p))
     return lo, g
 
 
-def pose_optimize(complete, partial, lr=0.01, iters=200, starts=4, radius=0.02, size=224, mask_weight=1.0, fma_mode=1):
+def pose_optimize(complete, partial, lr=0.01, iters=200, starts=4, radius=0.02, size=224, mask_weight=1.0, fma_mode=1,
+                  complete_col=None, partial_col=None):
     """Full objective (mask + 3 cd + ortho) -> (T[4,4], history[starts, iters+1], best_params[10])."""
     c, pc = _f(complete)
     q, pq = _f(partial)
+    cc, pcc = _fopt(complete_col)
+    qc, pqc = _fopt(partial_col)
     T = np.zeros(16, np.float32)
     hist = np.zeros((starts, iters + 1), np.float32)
     bp = np.zeros(10, np.float32)
-    lib().oracle_pose_optimize(c.shape[0], pc, q.shape[0], pq, ctypes.c_float(lr), int(iters), int(starts),
+    lib().oracle_pose_optimize(c.shape[0], pc, pcc, q.shape[0], pq, pqc, ctypes.c_float(lr), int(iters), int(starts),
                                int(fma_mode), ctypes.c_float(radius), int(size), ctypes.c_float(mask_weight),
                                T.ctypes.data_as(_f32p), hist.ctypes.data_as(_f32p), bp.ctypes.data_as(_f32p))
     return T.reshape(4, 4), hist, bp

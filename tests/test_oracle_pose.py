@@ -185,8 +185,9 @@ def test_paint_and_gather(oracle):
 
 # ---------------------------------------------------------------------------
 # silhouette ("mask") half of the loss
-def t_splat(pts, radius, S):
-    """The build's own soft-occupancy splat, written densely in torch ([P pixels] x [N points])."""
+def t_splat(pts, radius, S, col=None):
+    """The build's own colour splat, written densely in torch ([P pixels] x [N points]) -> [S,S,3]:
+    occupancy O = 1 - prod(1 - a), colour = coverage-weighted mean of the point colours, I = O * colour."""
     zv = 3.0 - pts[:, 2]
     ok = (zv > 1e-4) & (zv < 5.0)
     hs = 0.5 * S
@@ -198,28 +199,42 @@ def t_splat(pts, radius, S):
     dy = rr.reshape(-1, 1) - v[None]
     a = 1.0 - (dx * dx + dy * dy) / (rho * rho)[None]
     a = torch.clamp(a, min=0.0, max=0.999) * ok[None]
-    return (1.0 - torch.prod(1.0 - a, dim=1)).reshape(S, S)
+    occ = 1.0 - torch.prod(1.0 - a, dim=1)
+    if col is None:
+        col = torch.ones(pts.shape[0], 3, dtype=pts.dtype)
+    den = a.sum(1)
+    num = a @ col
+    colour = torch.where(den[:, None] > 0, num / torch.clamp(den, min=1e-300)[:, None], torch.zeros_like(num))
+    return (occ[:, None] * colour).reshape(S, S, 3)
 
 
 def t_mask_loss(img, ref):
     """compute_loss_function's mask terms as the reference writes them (diff_obj_pose.py:204-217,
-    261-278,238-259,304-311) on single-channel images (the clouds carry no colour: R = G = B)."""
+    261-278,238-259,304-311) on [S,S,3] images.  (tests/test_reference_vectors.py pins the oracle to the
+    reference's code itself; this torch version exists so that autograd can run through splat + loss.)"""
     F = torch.nn.functional
-    ref3, img3 = ref[..., None].expand(-1, -1, 3), img[..., None].expand(-1, -1, 3)
-    ref_mean = torch.mean(ref3, dim=(0, 1), keepdim=True)
-    ref_std = torch.std(ref3, dim=(0, 1), keepdim=True) + 1e-6
-    res_mean = torch.mean(img3, dim=(0, 1), keepdim=True)
-    res_std = torch.std(img3, dim=(0, 1), keepdim=True) + 1e-6
-    norm = torch.clamp((img3 - res_mean) / res_std * ref_std + ref_mean, 0.0, 1.0)
+    ref_mean = torch.mean(ref, dim=(0, 1), keepdim=True)
+    ref_std = torch.std(ref, dim=(0, 1), keepdim=True) + 1e-6
+    res_mean = torch.mean(img, dim=(0, 1), keepdim=True)
+    res_std = torch.std(img, dim=(0, 1), keepdim=True) + 1e-6
+    norm = torch.clamp((img - res_mean) / res_std * ref_std + ref_mean, 0.0, 1.0)
 
     def soft(x):
         lum = 0.299 * x[:, :, 0] + 0.587 * x[:, :, 1] + 0.114 * x[:, :, 2]
         return torch.sigmoid((lum - 0.1) / 0.05)
-    m, mr = soft(norm), soft(ref3)
+    m, mr = soft(norm), soft(ref)
     loss = F.mse_loss(m, mr) * 30 + F.binary_cross_entropy(m, mr)
     inter = (m.reshape(-1) * mr.reshape(-1)).sum()
     dice = 1 - (2.0 * inter + 1e-6) / (m.sum() + mr.sum() + 1e-6)
     return loss * 1 + dice * 10
+
+
+def _colours(rng, n, dark=0.0):
+    col = (0.25 + 0.75 * rng.random((n, 3))).astype(np.float32)
+    k = int(n * dark)
+    if k:
+        col[:k] *= np.float32(0.08)
+    return col
 
 
 def test_splat_and_mask_loss_match_torch(oracle):
@@ -227,40 +242,49 @@ def test_splat_and_mask_loss_match_torch(oracle):
     S = 40
     pts = ((rng.random((60, 3)) - 0.5) * 0.9).astype(np.float32)
     ref_pts = ((rng.random((400, 3)) - 0.5) * 0.9).astype(np.float32)
-    img = oracle.splat_image(pts, 0.025, S)
-    ref = oracle.splat_image(ref_pts, 0.04, S)
-    ti = t_splat(torch.from_numpy(pts).double(), 0.025, S)
-    tr = t_splat(torch.from_numpy(ref_pts).double(), 0.04, S)
-    np.testing.assert_allclose(img, ti.numpy(), atol=2e-6)
-    assert 0.02 < float(img.mean()) < 0.9 and float(ref.max()) > 0.9
-    # the loss on float32 images, as the reference computes it: sigmoid saturates to exactly 1.0f
-    # and binary_cross_entropy's -100 clamp decides those pixels (a float64 evaluation differs by
-    # tens of percent here -- checked below so that the test input really exercises the clamp)
-    l32 = float(t_mask_loss(ti.float(), tr.float()))
-    l64 = float(t_mask_loss(ti, tr))
-    assert abs(l32 - l64) > 0.01 * l64
-    np.testing.assert_allclose(oracle.mask_loss(img, ref), l32, rtol=2e-4)
+    col, ref_col = _colours(rng, 60, 0.3), _colours(rng, 400)
+    for c, rc in ((None, None), (col, ref_col)):
+        img = oracle.splat_image(pts, 0.025, S, c)
+        ref = oracle.splat_image(ref_pts, 0.04, S, rc)
+        ti = t_splat(torch.from_numpy(pts).double(), 0.025, S, None if c is None else torch.from_numpy(c).double())
+        tr = t_splat(torch.from_numpy(ref_pts).double(), 0.04, S, None if rc is None else torch.from_numpy(rc).double())
+        assert img.shape == (S, S, 3)
+        np.testing.assert_allclose(img, ti.numpy(), atol=2e-6)
+        assert 0.005 < float(img.mean()) < 0.9 and float(ref.max()) > 0.9
+        if c is None:
+            assert np.array_equal(img[..., 0], img[..., 1]) and np.array_equal(img[..., 0], img[..., 2])
+        # the loss on float32 images, as the reference computes it: sigmoid saturates to exactly 1.0f
+        # and binary_cross_entropy's -100 clamp decides those pixels (a float64 evaluation differs by
+        # tens of percent here -- checked below so that the test input really exercises the clamp)
+        l32 = float(t_mask_loss(ti.float(), tr.float()))
+        l64 = float(t_mask_loss(ti, tr))
+        assert abs(l32 - l64) > 0.01 * l64
+        np.testing.assert_allclose(oracle.mask_loss(img, ref), l32, rtol=2e-4)
 
 
-def test_full_loss_gradient_matches_torch_autograd(oracle):
+@pytest.mark.parametrize("coloured", [False, True])
+def test_full_loss_gradient_matches_torch_autograd(oracle, coloured):
     """mask_loss + 3 cd + 1e-3 ortho: the oracle's analytic gradient against autograd through the
-    dense torch splat, the reference's own normalisation / soft-mask / MSE+BCE+Dice code and the CD
+    dense torch splat, the reference's normalisation / soft-mask / MSE+BCE+Dice code and the CD
     term.  The pose, the splat and the CD term run in float64; the image is cast to float32 before
     the reference's loss code, as the reference's images are (saturated soft masks carry no
-    gradient there)."""
+    gradient there).  coloured: both clouds carry colours, a third of the complete cloud dark."""
     S = 36
     radius = 0.04
     v, partial, params = make_case(5, nc=260, npart=170)
+    rng = np.random.default_rng(50)
+    vcol = _colours(rng, len(v), 0.33) if coloured else None
+    pcol = _colours(rng, len(partial)) if coloured else None
     center = v.astype(np.float64).mean(0).astype(np.float32)
     pts = oracle.pose_transform(v, center, params)
     d1, d2, i1, i2 = oracle.chamfer_forward(pts[None], partial[None], 0)
-    ref = oracle.splat_image(partial, radius, S)
-    lo, g = oracle.pose_full_loss_grad(v, center, params, partial, d1[0], i1[0], d2[0], i2[0], radius, S, ref)
+    ref = oracle.splat_image(partial, radius, S, pcol)
+    lo, g = oracle.pose_full_loss_grad(v, center, params, partial, d1[0], i1[0], d2[0], i2[0], radius, S, ref, vert_col=vcol)
     P = torch.tensor(params.astype(np.float64), requires_grad=True)
     tv, tc, tp = (torch.from_numpy(x.astype(np.float64)) for x in (v, center, partial))
     cd_total, cd, ortho, tpts = t_loss(P, tv, tc, tp, torch.from_numpy(i1[0].astype(np.int64)),
                                        torch.from_numpy(i2[0].astype(np.int64)))
-    timg = t_splat(tpts, 1.1 * radius, S)
+    timg = t_splat(tpts, 1.1 * radius, S, None if vcol is None else torch.from_numpy(vcol).double())
     ml = t_mask_loss(timg.float(), torch.from_numpy(ref)).double()
     total = cd_total + ml
     total.backward()
@@ -272,23 +296,34 @@ def test_full_loss_gradient_matches_torch_autograd(oracle):
     t_loss(P2, tv, tc, tp, torch.from_numpy(i1[0].astype(np.int64)), torch.from_numpy(i2[0].astype(np.int64)))[0].backward()
     assert np.abs(tg - P2.grad.numpy()).max() > 0.05 * np.abs(tg).max()
     np.testing.assert_allclose(g, tg, rtol=2e-3, atol=2e-3 * np.abs(tg).max())
+    if coloured:
+        # and the colours must matter: the same geometry drawn white gives another loss and gradient
+        lo_w, g_w = oracle.pose_full_loss_grad(v, center, params, partial, d1[0], i1[0], d2[0], i2[0], radius, S,
+                                               oracle.splat_image(partial, radius, S), vert_col=None)
+        assert abs(lo_w[3] - lo[3]) > 1e-2 and np.abs(g_w - g).max() > 1e-2 * np.abs(g).max()
 
 
 def test_full_objective_loop_recovers_pose(oracle):
     """The multi-start loop with the mask term on a small asymmetric shape: finite, decreasing
     history; the mask term changes the trajectory; the scale stays in a sane range (the silhouette of
     a PARTIAL view pulls the scale below the Chamfer-only optimum: a property of the reference's
-    objective, not of this restatement)."""
+    objective, not of this restatement); colours change the trajectory."""
     rng = np.random.default_rng(4)
     n = 500
     complete = (rng.random((n, 3), dtype=np.float32) - np.float32(0.5)) * np.float32([0.9, 0.5, 0.3])
     complete[: n // 4, 0] += np.float32(0.25)
     c = complete.mean(0)
     full = ((complete - c) * 0.9) + c + np.array([0.02, -0.01, 0.015], np.float32)
-    partial = full[full[:, 2] > -0.05][: n // 2].astype(np.float32)
+    sel = full[:, 2] > -0.05
+    partial = full[sel][: n // 2].astype(np.float32)
     T, hist, bp = oracle.pose_optimize(complete, partial, lr=0.01, iters=120, starts=2, radius=0.03, size=64)
     T0, hist0, _ = oracle.pose_optimize_cd(complete, partial, lr=0.01, iters=120, starts=2)
     assert np.isfinite(hist).all() and hist[0, -1] < hist[0, 0]
     assert np.abs(hist[0, :50] - hist0[0, :50]).max() > 1e-3
     s = np.cbrt(np.linalg.det(T[:3, :3].astype(np.float64)))
     assert 0.6 < s < 1.1
+    ccol = _colours(rng, n, 0.4)
+    pcol = ccol[sel][: n // 2]
+    Tc, histc, _ = oracle.pose_optimize(complete, partial, lr=0.01, iters=40, starts=1, radius=0.03, size=64,
+                                        complete_col=ccol, partial_col=pcol)
+    assert np.isfinite(histc).all() and np.abs(histc[0, :40] - hist[0, :40]).max() > 1e-3
