@@ -73,10 +73,14 @@ class DepthPrompting:
     def __init__(self, cfg, cameras=None, focal=None):
         self.cfg = cfg
         self.device = torch.device(cfg.device)
-        self.viewpoints = None
         if cameras is None:
             cameras, self.viewpoints, focal = create_cameras(
                 num_views=cfg.view_num, distance=cfg.distance, fovy=cfg.fovy, device=self.device)
+        else:
+            # cameras were handed in: eye = -R^T t of each 3x4 world->camera matrix (viewpoint_select, getDepth and
+            # hidden_point_removal all index self.viewpoints)
+            m = torch.as_tensor(cameras).reshape(-1, 3, 4).double().cpu().numpy()
+            self.viewpoints = -np.einsum("cji,cj->ci", m[:, :, :3], m[:, :, 3])
         self.cameras = cameras
         self.focal = focal if focal is not None else 1.0 / math.tan(math.pi * cfg.fovy / 180 / 2)
 
@@ -110,9 +114,6 @@ class DepthPrompting:
         """-> (visible [C,N] bool, counts [C] int32, points that needed the large-polygon pass)."""
         if viewpoints is None:
             viewpoints = self.viewpoints
-        if viewpoints is None:          # cameras were handed in: eye = -R^T t of each 3x4 world->camera matrix
-            m = self.cameras.reshape(-1, 3, 4).double().cpu().numpy()
-            viewpoints = -np.einsum("cji,cj->ci", m[:, :, :3], m[:, :, 3])
         if radius is None:
             radius = self.cfg.removal_radius
         points = points.contiguous().float()
@@ -123,8 +124,11 @@ class DepthPrompting:
         vis = torch.zeros(c, n, device=points.device, dtype=torch.uint8)
         cnt = torch.empty(c, device=points.device, dtype=torch.int32)
         total_second = 0
-        # the library takes at most 4096 viewpoints and 2^31 - 1 (viewpoint, point) pairs per call
-        step = max(1, min(4096, (2 ** 31 - 1) // max(n, 1)))
+        # the library takes at most 4096 viewpoints and 2^31 - 1 (viewpoint, point) pairs per call, and its
+        # per-stream workspace holds ~49 bytes per pair and is never released: views are chunked so that one call
+        # stays within cfg.hpr_workspace_bytes (default 2 GiB; 1024 x 10000 pairs = 0.5 GB is one call)
+        budget = int(getattr(self.cfg, "hpr_workspace_bytes", 2 << 30))
+        step = max(1, min(4096, (2 ** 31 - 1) // max(n, 1), budget // (49 * max(n, 1))))
         for v0 in range(0, c, step):
             v1 = min(c, v0 + step)
             second = ctypes.c_int(0)

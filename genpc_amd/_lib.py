@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GENPC_LIB: an alternative build of the same library (kernel experiments only)
 LIB_PATH = os.environ.get("GENPC_LIB") or os.path.join(_HERE, "lib", "libgenpc_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -44,14 +44,15 @@ SIGNATURES = {
     "genpc_zbuffer_visibility": (_i, [_i, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "genpc_pose_transform": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_pose_cd_grad": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
-    "genpc_splat_image": (_i, [_i, _vp, _f, _i, _vp, _vp]),
-    "genpc_pose_loss_grad": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
-    "genpc_pose_optimize_batch": (_i, [_i, _i, _vp, _i, _vp, _f, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp]),
+    "genpc_splat_image": (_i, [_i, _vp, _vp, _f, _i, _vp, _vp]),
+    "genpc_mask_loss": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "genpc_pose_loss_grad": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "genpc_pose_optimize_batch": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _f, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp]),
     "genpc_pose_optimize_cd": (_i, [_i, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "genpc_pose_optimize_cd_batch": (_i, [_i, _i, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "genpc_icp_batch": (_i, [_i, _i, _vp, _i, _vp, _d, _vp, _i, _d, _d, _vp, _vp, _vp]),
     "genpc_scale_search_scores": (_i, [_i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp]),
-    "genpc_voxel_down_sample": (_i, [_i, _vp, _f, _vp, _vp, _vp]),
+    "genpc_voxel_down_sample": (_i, [_i, _vp, _vp, _d, _vp, _vp, _vp, _vp]),
     "genpc_fps": (_i, [_i, _i, _vp, _i, _vp, _vp]),
     "genpc_knn_mean_distance": (_i, [_i, _vp, _i, _vp, _vp]),
 }

@@ -35,7 +35,9 @@ namespace genpc {
 int genpc_mean3(int b, int n, const float *v, float *out, double *accum, hipStream_t st);
 
 constexpr int kQBlock = 256;
-constexpr int kAcc = 32;      // doubles per scan: [0..12] gradient sums, [13,14] Chamfer sums, [15] mask loss, [16,17] image sums, [18..27] mask sums
+// doubles per scan: [0..12] gradient sums, [13,14] Chamfer sums, [15] mask loss, [16..18] sum I_ch, [19..21] sum I_ch^2,
+// [22..25] mse / bce / intersection / sum m, [26 + 6 ch + k] the six gradient sums of channel ch (mask_sums_kernel)
+constexpr int kAcc = 48;
 
 // pytorch3d.transforms.rotation_6d_to_matrix (rows b1, b2, b1 x b2); F.normalize eps 1e-12
 __device__ __forceinline__ void rot6d_to_matrix(const float *d6, float *R)
@@ -324,34 +326,40 @@ __global__ void pose_end_kernel(int b, PoseState *__restrict__ S, int final, flo
 // ---------------------------------------------------------------------------
 // Silhouette ("mask") half of compute_loss_function (diff_obj_pose.py:286-336).
 // The reference compares Pulsar renders (pytorch3d, CUDA only, absent, unpinned) of the partial
-// cloud (:108-134) and of the posed complete cloud (:426-433); its clouds carry no colour on this
-// path, so the images are soft occupancy maps.  This build defines its OWN differentiable splat
-// with the reference's camera and radii -- restated with the loss in oracle/genpc_oracle_geom.c,
-// whose gradient is pinned to torch autograd (tests/test_oracle_pose.py):
+// cloud WITH ITS COLOURS (:108-134; load_point_cloud returns vert_col for every input the pipeline
+// produces, :136-164) and of the posed complete cloud with its colours (:426-433).  This build defines
+// its OWN differentiable colour splat with the reference's camera and radii -- restated with the loss
+// in oracle/genpc_oracle_geom.c, whose loss is pinned to the reference's own code
+// (tests/golden/ref_py_mask_loss.npz) and whose gradient is pinned to torch autograd:
 //   Zv = 3 - z;  u = S/2 (1 + 4 x / Zv);  v = S/2 (1 - 4 y / Zv);  rho = S/2 * 4 * radius / Zv
-//   a_i(pixel) = min(0.999, max(0, 1 - |pixel centre - (u, v)|^2 / rho^2));  I = 1 - prod_i (1 - a_i)
-// and keeps the reference's own torch code for what follows the render: statistical
-// normalisation, sigmoid soft masks, 30 MSE + BCE + 10 Dice (:204-217,261-278,238-259,304-311).
+//   a_i(pixel) = min(0.999, max(0, 1 - |pixel centre - (u, v)|^2 / rho^2))
+//   O = 1 - prod_i (1 - a_i);  A_ch = sum_i a_i c_i,ch / sum_i a_i;  I_ch = O A_ch      (background 0)
+// (coverage-weighted colour, order-independent: Pulsar's softmax in depth is NOT reproduced) and keeps
+// the reference's own torch code for what follows the render: per-channel statistical normalisation,
+// luminance, sigmoid soft masks, 30 MSE + BCE + 10 Dice (:204-217,261-278,238-259,304-311).
 //   mask_project_kernel  every point posed (the transform is fused) and projected once: (u, v, rho)
 //   mask_splat_kernel    one block per 16 x 16 image tile and scan: the points whose disc touches
-//                        the tile are compacted into LDS, then every pixel (four threads each)
-//                        walks the list and sums log(1 - a) of the discs covering it, in list order:
-//                        no atomics on the image.  Writes L = sum log(1 - a) and adds the
-//                        tile's sums of I and I^2 to the scan's accumulators.  (Measured at 16384
-//                        points: one thread per point walking its own box 634 us per call -- every
+//                        the tile are compacted into LDS with their colours, then every pixel (four
+//                        threads each) walks the list and accumulates log(1 - a), a and a c of the discs
+//                        covering it, in list order: no atomics on the image.  Writes the five planes
+//                        L = sum log(1 - a), D = sum a, N_ch = sum a c_ch and adds the tile's sums of
+//                        I_ch and I_ch^2 to the scan's accumulators.  (Measured at 16384 points, single
+//                        channel: one thread per point walking its own box 634 us per call -- every
 //                        wave pays a full box for its one in-tile lane; a wave per point with LDS
 //                        float atomics 36 us, 26 of them in the atomics.)
-//   mask_sums_kernel     pixels over many blocks: the ten sums the loss and its gradient need
-//   mask_w_kernel        W = d loss / d I * T per pixel; the loss itself
-//   mask_grad_kernel     one thread per point: gathers W over the pixels it covers, chains through
-//                        (u, v, rho) to the point and on to (R, s, t): same 13 accumulators as the
-//                        Chamfer gradient
+//   mask_sums_kernel     pixels over many blocks: the 22 sums the loss and its gradient need
+//   mask_w_kernel        d loss / d I_ch per pixel folded with the splat's own derivative into the five
+//                        per-pixel weights the backward gather needs; the loss itself
+//   mask_grad_kernel     one thread per point: gathers the weights over the pixels it covers, chains
+//                        through (u, v, rho) to the point and on to (R, s, t): same 13 accumulators as
+//                        the Chamfer gradient
 constexpr int kMaskTile = 16;
 constexpr int kSplatBlock = 1024;  // 16 waves per tile: a wave per point leaves long dependent chains, four waves per SIMD hide them
 constexpr int kSplatPer = 16;      // points per thread and round of the splat (16384 points per round)
 constexpr int kSplatList = 2048;   // in-tile points drawn per fill of the LDS list
 constexpr float kMaskAmax = 0.999f;
 constexpr float kMaskFocal = 4.0f, kMaskEyeZ = 3.0f, kMaskZnear = 1e-4f, kMaskZfar = 5.0f;
+constexpr float kLumR = 0.299f, kLumG = 0.587f, kLumB = 0.114f;      // compute_soft_mask, diff_obj_pose.py:273
 
 struct SplatPt {
     float u, v, rho, zv;
@@ -433,30 +441,63 @@ __global__ __launch_bounds__(kQBlock) void pose_transform_project_kernel(int n, 
     }
 }
 
-// grid (tiles, b)
-__global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const float4 *__restrict__ uvr, int S,
-                                                                 float *__restrict__ L, double *__restrict__ accum)
+// The image of a scan is kept as five planes of P = S * S floats: L, D, N_r, N_g, N_b (header comment).
+// `direct` images (genpc_mask_loss: the caller supplies I itself) hold I_r, I_g, I_b in planes 0..2.
+struct PxImg {
+    float I[3];
+    float T, O, iD;        // exp(L), 1 - exp(L), 1 / D (0 where no disc covers the pixel)
+    float A[3];            // N_ch / D
+};
+
+__device__ __forceinline__ PxImg load_pixel(const float *__restrict__ pl, int P, int q, int direct)
+{
+    PxImg o;
+    if (direct) {
+        o.I[0] = pl[q]; o.I[1] = pl[P + q]; o.I[2] = pl[2 * P + q];
+        o.T = 0.0f; o.O = 1.0f; o.iD = 0.0f;
+        o.A[0] = o.A[1] = o.A[2] = 0.0f;
+        return o;
+    }
+    const float l = pl[q], d = pl[P + q];
+    o.T = expf(l);
+    o.O = 1.0f - o.T;
+    o.iD = d > 0.0f ? 1.0f / d : 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        o.A[ch] = pl[(2 + ch) * P + q] * o.iD;
+        o.I[ch] = o.O * o.A[ch];
+    }
+    return o;
+}
+
+// grid (tiles, b).  col: [b, n, 3] colours or nullptr (white).
+__global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const float4 *__restrict__ uvr,
+                                                                 const float *__restrict__ col, int S,
+                                                                 float *__restrict__ planes, double *__restrict__ accum)
 {
     static_assert(kSplatBlock == 4 * kMaskTile * kMaskTile, "four threads per pixel of the tile");
-    __shared__ float part[4][kMaskTile * kMaskTile];
-    __shared__ float4 list[kSplatList];
+    __shared__ float part[5][4][kMaskTile * kMaskTile];
+    __shared__ float4 list[kSplatList];       // u, v, 1 / rho^2, red
+    __shared__ float2 list_gb[kSplatList];    // green, blue
     __shared__ int s_cnt;
-    __shared__ double red[2][kSplatBlock / kWave];
+    __shared__ double red[6][kSplatBlock / kWave];
     const int e = blockIdx.y;
+    const int P = S * S;
     const int tiles_x = (S + kMaskTile - 1) / kMaskTile;
     const int tx0 = (blockIdx.x % tiles_x) * kMaskTile, ty0 = (blockIdx.x / tiles_x) * kMaskTile;
     const int tx1 = min(S, tx0 + kMaskTile) - 1, ty1 = min(S, ty0 + kMaskTile) - 1;
     uvr += (size_t)e * n;
-    L += (size_t)e * S * S;
+    if (col) col += (size_t)e * n * 3;
+    planes += (size_t)e * 5 * P;
     if (accum) accum += (size_t)e * kAcc;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     // thread = (pixel of the tile, one of four interleaved shares of the point list)
     const int pix = threadIdx.x & (kMaskTile * kMaskTile - 1), share = threadIdx.x / (kMaskTile * kMaskTile);
     const float pxc = (float)(tx0 + (pix & (kMaskTile - 1))) + 0.5f, pyc = (float)(ty0 + pix / kMaskTile) + 0.5f;
-    float sum = 0.0f;
+    float sum = 0.0f, sd = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
     // Every block reads every point of its scan (16 x 16 tiles: 196 blocks per scan), kSplatPer per thread
     // loaded together; the points whose disc touches the tile are compacted into LDS (one LDS atomic per wave
-    // and step), then GATHERED: every pixel walks the list (broadcast reads) and adds log(1 - a) of the discs
+    // and step), then GATHERED: every pixel walks the list (broadcast reads) and accumulates the discs
     // that cover it, in list order -- no atomics on the image.  (Scattering with LDS float atomics ran at
     // ~0.6 adds per clock per CU: 26 us of the kernel's 36 for 758 points in the busiest tile.)
     for (int j0 = 0; j0 < n; j0 += kSplatBlock * kSplatPer) {
@@ -491,8 +532,15 @@ __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const fl
                     base = __shfl(base, 0, kWave);
                     const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
                     if (want) {
-                        if (slot < kSplatList) { list[slot] = q[i]; done |= 1u << i; }
-                        else left = true;
+                        if (slot < kSplatList) {
+                            const int j = j0 + i * kSplatBlock + threadIdx.x;
+                            float cr = 1.0f, cg = 1.0f, cb = 1.0f;
+                            if (col) { cr = col[(size_t)j * 3 + 0]; cg = col[(size_t)j * 3 + 1]; cb = col[(size_t)j * 3 + 2]; }
+                            list[slot] = make_float4(q[i].x, q[i].y, q[i].w, cr);
+                            list_gb[slot] = make_float2(cg, cb);
+                            done |= 1u << i;
+                        } else
+                            left = true;
                     }
                 }
             }
@@ -501,34 +549,58 @@ __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const fl
             for (int k = share; k < cnt; k += 4) {
                 const float4 p = list[k];
                 const float dx = pxc - p.x, dy = pyc - p.y;
-                const float a = 1.0f - (dx * dx + dy * dy) * p.w;
-                if (a > 0.0f) sum += __logf(1.0f - fminf(a, kMaskAmax));
+                const float a = 1.0f - (dx * dx + dy * dy) * p.z;
+                if (a > 0.0f) {
+                    const float2 gb = list_gb[k];
+                    const float ac = fminf(a, kMaskAmax);
+                    sum += __logf(1.0f - ac);
+                    sd += ac;
+                    sr += ac * p.w;
+                    sg += ac * gb.x;
+                    sb += ac * gb.y;
+                }
             }
             if (!more) break;
         }
     }
-    part[share][pix] = sum;
+    part[0][share][pix] = sum;
+    part[1][share][pix] = sd;
+    part[2][share][pix] = sr;
+    part[3][share][pix] = sg;
+    part[4][share][pix] = sb;
     __syncthreads();
-    double s1 = 0.0, s2 = 0.0;
+    double s1[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0};
     if (threadIdx.x < kMaskTile * kMaskTile) {
         const int r = ty0 + pix / kMaskTile, cc = tx0 + (pix & (kMaskTile - 1));
         if (r < S && cc < S) {
-            const float l = (part[0][pix] + part[1][pix]) + (part[2][pix] + part[3][pix]);
-            L[(size_t)r * S + cc] = l;
-            const float I = 1.0f - expf(l);
-            s1 = (double)I;
-            s2 = (double)I * (double)I;
+            float w[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                w[k] = (part[k][0][pix] + part[k][1][pix]) + (part[k][2][pix] + part[k][3][pix]);
+                planes[(size_t)k * P + (size_t)r * S + cc] = w[k];
+            }
+            const float O = 1.0f - expf(w[0]);
+            const float iD = w[1] > 0.0f ? 1.0f / w[1] : 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float I = O * (w[2 + ch] * iD);
+                s1[ch] = (double)I;
+                s2[ch] = (double)I * (double)I;
+            }
         }
     }
     if (accum) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, kWave); s2 += __shfl_xor(s2, off, kWave); }
-        if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+        for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { s1[ch] += __shfl_xor(s1[ch], off, kWave); s2[ch] += __shfl_xor(s2[ch], off, kWave); }
+            if (lane == 0) { red[ch][wave] = s1[ch]; red[3 + ch][wave] = s2[ch]; }
+        }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w2 = 1; w2 < kSplatBlock / kWave; w2++) { s1 += red[0][w2]; s2 += red[1][w2]; }
-            atomicAdd(&accum[16], s1);
-            atomicAdd(&accum[17], s2);
+        if (threadIdx.x < 6) {
+            double x = 0.0;
+            for (int w2 = 0; w2 < kMaskTile * kMaskTile / kWave; w2++) x += red[threadIdx.x][w2];   // only the first 256 threads held pixels
+            atomicAdd(&accum[16 + threadIdx.x], x);
         }
     }
 }
@@ -558,66 +630,106 @@ __device__ __forceinline__ void block_sum4(double (&x)[4], double (*red)[kMLThre
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// Reference image of a scan (once per call): I_ref = 1 - exp(L); writes the soft mask
-// m_ref = sigmoid((I_ref - 0.1) / 0.05) over L and stats = (mean, unbiased std, sum m_ref).
-__global__ __launch_bounds__(kMLThreads) void mask_ref_kernel(int S, float *__restrict__ Lref, float *__restrict__ stats)
+// compute_soft_mask (diff_obj_pose.py:261-278): sigmoid((luminance - 0.1) / 0.05), float32 like the reference
+__device__ __forceinline__ float soft_mask(float r, float g, float b)
+{
+    const float lum = kLumR * r + kLumG * g + kLumB * b;
+    return sigmoidf((lum - 0.1f) / 0.05f);
+}
+
+// Reference image of a scan (once per call; one block per scan): per-channel mean and unbiased std of the
+// image (normalize_images, :208-209), the soft mask m_ref = soft_mask(I_ref) into mref[P] and
+// stats[8] = mean[3], std[3], sum m_ref, 0.
+__global__ __launch_bounds__(kMLThreads) void mask_ref_kernel(int S, const float *__restrict__ planes, int direct,
+                                                              float *__restrict__ mref, float *__restrict__ stats)
 {
     __shared__ double red[4][kMLThreads / kWave];
     const int e = blockIdx.x, P = S * S;
-    Lref += (size_t)e * P;
-    stats += (size_t)e * 4;
+    planes += (size_t)e * 5 * P;
+    mref += (size_t)e * P;
+    stats += (size_t)e * 8;
     double a[4] = {0, 0, 0, 0};
-    for (int q = threadIdx.x; q < P; q += kMLThreads) a[0] += (double)(1.0f - expf(Lref[q]));
+    for (int q = threadIdx.x; q < P; q += kMLThreads) {
+        const PxImg px = load_pixel(planes, P, q, direct);
+        a[0] += (double)px.I[0]; a[1] += (double)px.I[1]; a[2] += (double)px.I[2];
+    }
     block_sum4(a, red);
-    const double mu = a[0] / P;
+    const double mu[3] = {a[0] / P, a[1] / P, a[2] / P};
     double b[4] = {0, 0, 0, 0};
     for (int q = threadIdx.x; q < P; q += kMLThreads) {
-        const float I = 1.0f - expf(Lref[q]);
-        const double dd = (double)I - mu;
-        b[0] += dd * dd;
-        const float m = sigmoidf((I - 0.1f) * 20.0f);
-        b[1] += (double)m;
-        Lref[q] = m;
+        const PxImg px = load_pixel(planes, P, q, direct);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const double dd = (double)px.I[ch] - mu[ch];
+            b[ch] += dd * dd;
+        }
+        const float m = soft_mask(px.I[0], px.I[1], px.I[2]);
+        b[3] += (double)m;
+        mref[q] = m;
     }
     block_sum4(b, red);
     if (threadIdx.x == 0) {
-        stats[0] = (float)mu;
-        stats[1] = (float)sqrt(b[0] / (P - 1));
-        stats[2] = (float)b[1];
-        stats[3] = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            stats[ch] = (float)mu[ch];
+            stats[3 + ch] = (float)sqrt(b[ch] / (P - 1));
+        }
+        stats[6] = (float)b[3];
+        stats[7] = 0.0f;
     }
 }
 
-// image statistics of the posed cloud from the sums the splat left in accum[16,17]
-__device__ __forceinline__ void mask_image_stats(const double *accum, int P, double sdr, float &muf, float &k, double &sd,
-                                                 double &mu)
+// per-channel statistics of the posed cloud's image from the sums in accum[16..21], and the reference's
+struct MaskStats {
+    float muf[3], k[3], murf[3];
+    double sd[3], mu[3], sdr[3];
+};
+
+__device__ __forceinline__ MaskStats mask_image_stats(const double *accum, const float *stats, int P)
 {
-    mu = accum[16] / P;
-    double var = (accum[17] - (double)P * mu * mu) / (P - 1);
-    var = var > 0.0 ? var : 0.0;
-    sd = sqrt(var);
-    k = (float)((sdr + 1e-6) / (sd + 1e-6));
-    muf = (float)mu;
+    MaskStats o;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const double mu = accum[16 + ch] / P;
+        double var = (accum[19 + ch] - (double)P * mu * mu) / (P - 1);
+        var = var > 0.0 ? var : 0.0;
+        o.mu[ch] = mu;
+        o.sd[ch] = sqrt(var);
+        o.sdr[ch] = (double)stats[3 + ch];
+        o.k[ch] = (float)((o.sdr[ch] + 1e-6) / (o.sd[ch] + 1e-6));
+        o.muf[ch] = (float)mu;
+        o.murf[ch] = stats[ch];
+    }
+    return o;
 }
 
 // the per-pixel quantities every pass needs
 struct MaskPx {
-    float I, m, mr, sp;      // sp = d m / d x_normalised (0 where the clamp or the saturated sigmoid cuts the gradient)
+    float m, mr;
+    float spc[3];            // d m / d I'_ch (normalised image): 0 where the clamp or the saturated sigmoid cuts the gradient
     float lm, l1m, dmb;      // clamped logs; d (30 MSE + BCE) / d m * P
 };
 
-__device__ __forceinline__ MaskPx mask_pixel(float l, float mr, float muf, float k, float murf)
+__device__ __forceinline__ MaskPx mask_pixel(const float *I, float mr, const MaskStats &st)
 {
     MaskPx o;
-    o.I = 1.0f - expf(l);
-    const float x0 = (o.I - muf) * k + murf;
-    const float xn = fminf(fmaxf(x0, 0.0f), 1.0f);
-    o.m = sigmoidf((xn - 0.1f) * 20.0f);
+    float xn[3];
+    bool inside[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const float x0 = (I[ch] - st.muf[ch]) * st.k[ch] + st.murf[ch];
+        inside[ch] = x0 > 0.0f && x0 < 1.0f;
+        xn[ch] = fminf(fmaxf(x0, 0.0f), 1.0f);
+    }
+    o.m = soft_mask(xn[0], xn[1], xn[2]);
     o.mr = mr;
     const float lm = logf(o.m), l1m = logf(1.0f - o.m);
     o.lm = fmaxf(lm, -100.0f);
     o.l1m = fmaxf(l1m, -100.0f);
-    o.sp = (x0 > 0.0f && x0 < 1.0f) ? o.m * (1.0f - o.m) * 20.0f : 0.0f;
+    const float sp = o.m * (1.0f - o.m) * 20.0f;
+    o.spc[0] = inside[0] ? sp * kLumR : 0.0f;
+    o.spc[1] = inside[1] ? sp * kLumG : 0.0f;
+    o.spc[2] = inside[2] ? sp * kLumB : 0.0f;
     float db = 0.0f;
     if (lm > -100.0f) db -= mr / o.m;
     if (l1m > -100.0f) db += (1.0f - mr) / (1.0f - o.m);
@@ -625,89 +737,144 @@ __device__ __forceinline__ MaskPx mask_pixel(float l, float mr, float muf, float
     return o;
 }
 
-// grid (blocks, b).  accum[18..27] += mse, bce, intersection, sum m,  and with g1 = dmb sp / P, g2 = mr sp,
-// g3 = sp:  sum g1, sum g2, sum g3, sum g1 (I - mu), sum g2 (I - mu), sum g3 (I - mu)  -- the Dice
-// term's share of G is (dice_a g2 + dice_b g3) with coefficients only known after this pass.
-__global__ __launch_bounds__(kQBlock) void mask_sums_kernel(int S, const float *__restrict__ L,
-                                                            const float *__restrict__ mref,
-                                                            const float *__restrict__ stats, double *__restrict__ accum)
+// grid (blocks, b): accum[16..21] += sum I_ch, sum I_ch^2 of a direct image (the splat does this for its own)
+__global__ __launch_bounds__(kQBlock) void mask_image_sums_kernel(int P, const float *__restrict__ planes,
+                                                                  double *__restrict__ accum)
 {
-    __shared__ double red[10][kQBlock / kWave];
-    const int e = blockIdx.y, P = S * S;
-    L += (size_t)e * P;
-    mref += (size_t)e * P;
-    stats += (size_t)e * 4;
+    __shared__ double red[6][kQBlock / kWave];
+    const int e = blockIdx.y;
+    planes += (size_t)e * 5 * P;
     accum += (size_t)e * kAcc;
-    float muf, k;
-    double sd, mu;
-    mask_image_stats(accum, P, (double)stats[1], muf, k, sd, mu);
-    const float murf = stats[0];
-    const float invP = 1.0f / (float)P;
-    double a[10];
-#pragma unroll
-    for (int i = 0; i < 10; i++) a[i] = 0.0;
+    double a[6] = {0, 0, 0, 0, 0, 0};
     for (int q = blockIdx.x * kQBlock + threadIdx.x; q < P; q += gridDim.x * kQBlock) {
-        const MaskPx px = mask_pixel(L[q], mref[q], muf, k, murf);
-        a[0] += (double)((px.m - px.mr) * (px.m - px.mr));
-        a[1] += (double)(-(px.mr * px.lm + (1.0f - px.mr) * px.l1m));
-        a[2] += (double)(px.m * px.mr);
-        a[3] += (double)px.m;
-        const double g1 = (double)(px.dmb * px.sp * invP), g2 = (double)(px.mr * px.sp), g3 = (double)px.sp;
-        const double dI = (double)px.I - mu;
-        a[4] += g1; a[5] += g2; a[6] += g3;
-        a[7] += g1 * dI; a[8] += g2 * dI; a[9] += g3 * dI;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const double I = (double)planes[(size_t)ch * P + q];
+            a[ch] += I;
+            a[3 + ch] += I * I;
+        }
     }
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 10; i++) {
+    for (int i = 0; i < 6; i++) {
         double x = a[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
         if (lane == 0) red[i][wave] = x;
     }
     __syncthreads();
-    if (threadIdx.x < 10) {
+    if (threadIdx.x < 6) {
         double x = 0.0;
 #pragma unroll
         for (int w2 = 0; w2 < kQBlock / kWave; w2++) x += red[threadIdx.x][w2];
-        atomicAdd(&accum[18 + threadIdx.x], x);
+        atomicAdd(&accum[16 + threadIdx.x], x);
     }
 }
 
-// grid (blocks, b): W = mask_weight * d mask_loss / d I * T (T = exp(L): what the backward splat
-// multiplies by 1 / (1 - a_i)); block 0 adds mask_weight * mask_loss to accum[15].
-__global__ __launch_bounds__(kQBlock) void mask_w_kernel(int S, const float *__restrict__ L,
+// grid (blocks, b).  accum[22..25] += mse, bce, intersection, sum m, and per channel, with g1 = dmb spc / P,
+// g2 = mr spc, g3 = spc:  accum[26 + 6 ch ..] += sum g1, sum g2, sum g3, sum g1 (I - mu), sum g2 (I - mu),
+// sum g3 (I - mu)  -- the Dice term's share of G is (dice_a g2 + dice_b g3) with coefficients only known
+// after this pass.
+constexpr int kMaskSums = 22;
+__global__ __launch_bounds__(kQBlock) void mask_sums_kernel(int S, const float *__restrict__ planes, int direct,
+                                                            const float *__restrict__ mref,
+                                                            const float *__restrict__ stats, double *__restrict__ accum)
+{
+    __shared__ double red[kMaskSums][kQBlock / kWave];
+    const int e = blockIdx.y, P = S * S;
+    planes += (size_t)e * 5 * P;
+    mref += (size_t)e * P;
+    stats += (size_t)e * 8;
+    accum += (size_t)e * kAcc;
+    const MaskStats st = mask_image_stats(accum, stats, P);
+    const float invP = 1.0f / (float)P;
+    double a[kMaskSums];
+#pragma unroll
+    for (int i = 0; i < kMaskSums; i++) a[i] = 0.0;
+    for (int q = blockIdx.x * kQBlock + threadIdx.x; q < P; q += gridDim.x * kQBlock) {
+        const PxImg im = load_pixel(planes, P, q, direct);
+        const MaskPx px = mask_pixel(im.I, mref[q], st);
+        a[0] += (double)((px.m - px.mr) * (px.m - px.mr));
+        a[1] += (double)(-(px.mr * px.lm + (1.0f - px.mr) * px.l1m));
+        a[2] += (double)(px.m * px.mr);
+        a[3] += (double)px.m;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const double g1 = (double)(px.dmb * px.spc[ch] * invP), g2 = (double)(px.mr * px.spc[ch]), g3 = (double)px.spc[ch];
+            const double dI = (double)im.I[ch] - st.mu[ch];
+            a[4 + 6 * ch + 0] += g1; a[4 + 6 * ch + 1] += g2; a[4 + 6 * ch + 2] += g3;
+            a[4 + 6 * ch + 3] += g1 * dI; a[4 + 6 * ch + 4] += g2 * dI; a[4 + 6 * ch + 5] += g3 * dI;
+        }
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kMaskSums; i++) {
+        double x = a[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+        if (lane == 0) red[i][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMaskSums) {
+        double x = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kQBlock / kWave; w2++) x += red[threadIdx.x][w2];
+        atomicAdd(&accum[22 + threadIdx.x], x);
+    }
+}
+
+// grid (blocks, b): with dI_ch = mask_weight * d mask_loss / d I_ch, the five weights of the backward gather
+//   W1 = T sum_ch dI_ch A_ch     (d O / d a_i = T / (1 - a_i))
+//   W4 = (O / D) (dI_r, dI_g, dI_b, sum_ch dI_ch A_ch)     (d A_ch / d a_i = (c_i,ch - A_ch) / D)
+// so that d loss / d a_i = W1 / (1 - a_i) + W4.xyz . c_i - W4.w.  direct: W4.xyz = dI itself.
+// Block 0 adds mask_weight * mask_loss to accum[15].
+__global__ __launch_bounds__(kQBlock) void mask_w_kernel(int S, const float *__restrict__ planes, int direct,
                                                          const float *__restrict__ mref,
                                                          const float *__restrict__ stats, float mask_weight,
-                                                         float *__restrict__ W, double *__restrict__ accum)
+                                                         float *__restrict__ W1, float4 *__restrict__ W4,
+                                                         double *__restrict__ accum)
 {
     const int e = blockIdx.y, P = S * S;
-    L += (size_t)e * P;
+    planes += (size_t)e * 5 * P;
     mref += (size_t)e * P;
-    W += (size_t)e * P;
-    stats += (size_t)e * 4;
+    W1 += (size_t)e * P;
+    W4 += (size_t)e * P;
+    stats += (size_t)e * 8;
     accum += (size_t)e * kAcc;
-    float muf, k;
-    double sd, mu;
-    const double sdr = stats[1];
-    mask_image_stats(accum, P, sdr, muf, k, sd, mu);
-    const float murf = stats[0];
-    const double den = accum[21] + (double)stats[2] + 1e-6, num = 2.0 * accum[20] + 1e-6;
+    const MaskStats st = mask_image_stats(accum, stats, P);
+    const double den = accum[25] + (double)stats[6] + 1e-6, num = 2.0 * accum[24] + 1e-6;
     const float dice_a = (float)(-20.0 / den), dice_b = (float)(10.0 * num / (den * den));
-    const double sG = accum[22] + (double)dice_a * accum[23] + (double)dice_b * accum[24];
-    const double sGd = accum[25] + (double)dice_a * accum[26] + (double)dice_b * accum[27];
-    const float meanG = (float)(sG / P);
-    const float kk = sd > 0.0 ? (float)((sdr + 1e-6) / ((sd + 1e-6) * (sd + 1e-6)) / ((P - 1) * sd) * sGd) : 0.0f;
+    float meanG[3], kk[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const double *s = accum + 26 + 6 * ch;
+        const double sG = s[0] + (double)dice_a * s[1] + (double)dice_b * s[2];
+        const double sGd = s[3] + (double)dice_a * s[4] + (double)dice_b * s[5];
+        meanG[ch] = (float)(sG / P);
+        const double sd = st.sd[ch];
+        kk[ch] = sd > 0.0 ? (float)((st.sdr[ch] + 1e-6) / ((sd + 1e-6) * (sd + 1e-6)) / ((P - 1) * sd) * sGd) : 0.0f;
+    }
     const float invP = 1.0f / (float)P;
     for (int q = blockIdx.x * kQBlock + threadIdx.x; q < P; q += gridDim.x * kQBlock) {
-        const float l = L[q];
-        const MaskPx px = mask_pixel(l, mref[q], muf, k, murf);
-        const float G = (px.dmb * invP + dice_a * px.mr + dice_b) * px.sp;
-        const float dI = k * (G - meanG) - kk * (px.I - muf);
-        W[q] = mask_weight * dI * expf(l);
+        const PxImg im = load_pixel(planes, P, q, direct);
+        const MaskPx px = mask_pixel(im.I, mref[q], st);
+        const float Gm = px.dmb * invP + dice_a * px.mr + dice_b;
+        float dI[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            dI[ch] = mask_weight * (st.k[ch] * (Gm * px.spc[ch] - meanG[ch]) - kk[ch] * (im.I[ch] - st.muf[ch]));
+        if (direct) {
+            W4[q] = make_float4(dI[0], dI[1], dI[2], 0.0f);
+            W1[q] = 0.0f;
+        } else {
+            const float sA = dI[0] * im.A[0] + dI[1] * im.A[1] + dI[2] * im.A[2];
+            const float od = im.O * im.iD;
+            W1[q] = im.T * sA;
+            W4[q] = make_float4(od * dI[0], od * dI[1], od * dI[2], od * sA);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const double loss = 30.0 * accum[18] / P + accum[19] / P + 10.0 * (1.0 - num / den);
+        const double loss = 30.0 * accum[22] / P + accum[23] / P + 10.0 * (1.0 - num / den);
         accum[15] += (double)mask_weight * loss;
     }
 }
@@ -715,15 +882,18 @@ __global__ __launch_bounds__(kQBlock) void mask_w_kernel(int S, const float *__r
 // grid (blocks, b): gradient of the mask term with respect to (R, s, t), into accum[0..12].
 template <int kGradSub>
 __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *__restrict__ v,
+                                                            const float *__restrict__ col,
                                                             const float *__restrict__ center, int cstride,
                                                             const float *__restrict__ params, int pstride, float radius,
-                                                            int S, const float *__restrict__ W,
-                                                            double *__restrict__ accum)
+                                                            int S, const float *__restrict__ W1,
+                                                            const float4 *__restrict__ W4, double *__restrict__ accum)
 {
     __shared__ double red[13][kQBlock / kWave];
     const int e = blockIdx.y;
     v += (size_t)e * n * 3;
-    W += (size_t)e * S * S;
+    if (col) col += (size_t)e * n * 3;
+    W1 += (size_t)e * S * S;
+    W4 += (size_t)e * S * S;
     center += (size_t)e * cstride;
     params += (size_t)e * pstride;
     accum += (size_t)e * kAcc;
@@ -747,6 +917,8 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
         const bool live = j < n;
         const int jj = live ? j : n - 1;
         const float vx = v[(size_t)jj * 3 + 0], vy = v[(size_t)jj * 3 + 1], vz = v[(size_t)jj * 3 + 2];
+        float cr = 1.0f, cg = 1.0f, cb = 1.0f;
+        if (col) { cr = col[(size_t)jj * 3 + 0]; cg = col[(size_t)jj * 3 + 1]; cb = col[(size_t)jj * 3 + 2]; }
         float p[3];
         pose_point(R, s, c, t, vx, vy, vz, p);
         const SplatPt q = splat_project(p, radius, hs);
@@ -763,7 +935,8 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
                     const float d2 = dx * dx + dy * dy;
                     const float av = 1.0f - d2 * ir2;
                     if (av <= 0.0f || av >= kMaskAmax) continue;      // outside the disc / clamped: no gradient
-                    const float w = W[(size_t)r * S + cc] / (1.0f - av);
+                    const float4 w4 = W4[(size_t)r * S + cc];
+                    const float w = W1[(size_t)r * S + cc] / (1.0f - av) + ((cr * w4.x + cg * w4.y) + (cb * w4.z - w4.w));
                     gu += w * dx;
                     gv += w * dy;
                     gr += w * d2;
@@ -808,11 +981,39 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
     }
 }
 
-// image = 1 - exp(L)
-__global__ void mask_image_kernel(int P, const float *__restrict__ L, float *__restrict__ img)
+// img[P, 3] (H, W, C like the reference's renders) from the five planes
+__global__ void mask_image_kernel(int P, const float *__restrict__ planes, float *__restrict__ img)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < P) img[q] = 1.0f - expf(L[q]);
+    if (q >= P) return;
+    const PxImg px = load_pixel(planes, P, q, 0);
+    img[(size_t)q * 3 + 0] = px.I[0];
+    img[(size_t)q * 3 + 1] = px.I[1];
+    img[(size_t)q * 3 + 2] = px.I[2];
+}
+
+// [P, 3] -> planes 0..2 (genpc_mask_loss's inputs)
+__global__ void mask_to_planes_kernel(int P, const float *__restrict__ img, float *__restrict__ planes)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= P) return;
+    planes[q] = img[(size_t)q * 3 + 0];
+    planes[(size_t)P + q] = img[(size_t)q * 3 + 1];
+    planes[2 * (size_t)P + q] = img[(size_t)q * 3 + 2];
+}
+
+// genpc_mask_loss's outputs: loss from accum[15], grad[P, 3] from W4.xyz; clears the accumulators
+__global__ void mask_loss_out_kernel(int P, const float4 *__restrict__ W4, double *__restrict__ accum,
+                                     float *__restrict__ loss_out, float *__restrict__ grad)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (grad && q < P) {
+        const float4 w = W4[q];
+        grad[(size_t)q * 3 + 0] = w.x;
+        grad[(size_t)q * 3 + 1] = w.y;
+        grad[(size_t)q * 3 + 2] = w.z;
+    }
+    if (q == 0) *loss_out = (float)accum[15];
 }
 
 static int lin_grid(long long n)
@@ -839,86 +1040,143 @@ namespace genpc {
 
 static int mask_tiles(int S) { const int t = ceil_div(S, kMaskTile); return t * t; }
 
-// splat of the partial clouds + reference soft masks / statistics (once per call)
-static int mask_prepare_ref(int b, int np, const float *partial, float radius, int S, float4 *uvr, float *mref, float *stats,
-                            hipStream_t st)
+// scratch of the mask term for b scans of P pixels and up to nmax points (bytes, 256-aligned pieces)
+struct MaskScratch {
+    float *stats;      // [b, 8]
+    float *mref;       // [b, P]
+    float *planes;     // [b, 5, P]
+    float *W1;         // [b, P]
+    float4 *W4;        // [b, P]
+    float4 *uvr;       // [b, nmax]
+    static size_t up(size_t x) { return (x + 255) / 256 * 256; }
+    static size_t bytes(int b, size_t P, size_t nmax)
+    {
+        return up((size_t)b * 8 * 4) + up((size_t)b * P * 4) + up((size_t)b * 5 * P * 4) + up((size_t)b * P * 4) +
+               up((size_t)b * P * 16) + up((size_t)b * nmax * 16);
+    }
+    void carve(char *base, int b, size_t P, size_t nmax)
+    {
+        size_t off = 0;
+        stats = (float *)(base + off); off += up((size_t)b * 8 * 4);
+        mref = (float *)(base + off); off += up((size_t)b * P * 4);
+        planes = (float *)(base + off); off += up((size_t)b * 5 * P * 4);
+        W1 = (float *)(base + off); off += up((size_t)b * P * 4);
+        W4 = (float4 *)(base + off); off += up((size_t)b * P * 16);
+        uvr = (float4 *)(base + off);
+        (void)nmax;
+    }
+};
+
+// splat of the partial clouds (with their colours) + reference soft masks / statistics (once per call)
+static int mask_prepare_ref(int b, int np, const float *partial, const float *partial_col, float radius, int S,
+                            const MaskScratch &m, hipStream_t st)
 {
     hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(np), b), dim3(kQBlock), 0, st, np, partial, (const float *)nullptr, 0,
-                       (const float *)nullptr, 0, 0, radius, S, uvr);
-    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, np, (const float4 *)uvr, S, mref,
-                       (double *)nullptr);
-    hipLaunchKernelGGL(mask_ref_kernel, dim3(b), dim3(kMLThreads), 0, st, S, mref, stats);
+                       (const float *)nullptr, 0, 0, radius, S, m.uvr);
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, np, (const float4 *)m.uvr, partial_col,
+                       S, m.planes, (double *)nullptr);
+    hipLaunchKernelGGL(mask_ref_kernel, dim3(b), dim3(kMLThreads), 0, st, S, (const float *)m.planes, 0, m.mref, m.stats);
     return check(hipGetLastError(), "mask reference launch") ? 1 : 0;
 }
 
 // the launches of the mask term for the current parameters: accum[0..12] += gradient, accum[15] += loss
-static int mask_step(int b, int nc, const float *complete, const float *center, int cstride, const float *params,
-                     int pstride, float radius, int S, float mask_weight, const float *mref, const float *stats,
-                     float4 *uvr, float *L, float *W, double *accum, hipStream_t st, bool projected = false)
+static int mask_step(int b, int nc, const float *complete, const float *complete_col, const float *center, int cstride,
+                     const float *params, int pstride, float radius, int S, float mask_weight, const MaskScratch &m,
+                     double *accum, hipStream_t st, bool projected = false)
 {
     const float rad = 1.1f * radius;      // diff_obj_pose.py:385: the posed cloud is drawn with 1.1 x the radius
     const int gp = lin_grid((long long)S * S);
     if (!projected)      // (the alignment loop projects in its transform launch)
         hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride, params,
-                           pstride, 1, rad, S, uvr);
-    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, nc, (const float4 *)uvr, S, L, accum);
-    hipLaunchKernelGGL(mask_sums_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)L, mref, stats, accum);
-    hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)L, mref, stats, mask_weight, W, accum);
+                           pstride, 1, rad, S, m.uvr);
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, nc, (const float4 *)m.uvr, complete_col,
+                       S, m.planes, accum);
+    hipLaunchKernelGGL(mask_sums_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, 0, (const float *)m.mref,
+                       (const float *)m.stats, accum);
+    hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, 0, (const float *)m.mref,
+                       (const float *)m.stats, mask_weight, m.W1, m.W4, accum);
     if (b <= 2)
-        hipLaunchKernelGGL((mask_grad_kernel<8>), dim3(lin_grid((long long)nc * 8), b), dim3(kQBlock), 0, st, nc, complete, center, cstride,
-                       params, pstride, rad, S, (const float *)W, accum);
+        hipLaunchKernelGGL((mask_grad_kernel<8>), dim3(lin_grid((long long)nc * 8), b), dim3(kQBlock), 0, st, nc, complete,
+                           complete_col, center, cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum);
     else
-        hipLaunchKernelGGL((mask_grad_kernel<1>), dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride,
-                       params, pstride, rad, S, (const float *)W, accum);
+        hipLaunchKernelGGL((mask_grad_kernel<1>), dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, complete_col, center,
+                           cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum);
     return check(hipGetLastError(), "mask step launch") ? 1 : 0;
 }
 
 }  // namespace genpc
 
-GENPC_API int genpc_splat_image(int n, const float *pts, float radius, int size, float *img, void *stream)
+GENPC_API int genpc_splat_image(int n, const float *pts, const float *col, float radius, int size, float *img, void *stream)
 {
     using namespace genpc;
     if (n < 0 || size <= 0 || !(radius > 0.0f)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    char *ws = (char *)workspace(14, (size_t)size * size * sizeof(float) + 256 + (size_t)(n > 0 ? n : 1) * sizeof(float4), st);
+    const size_t P = (size_t)size * size;
+    char *ws = (char *)workspace(14, MaskScratch::bytes(1, P, n > 0 ? n : 1), st);
     if (!ws) return 0;
-    float *L = (float *)ws;
-    float4 *uvr = (float4 *)(ws + (((size_t)size * size * sizeof(float) + 255) & ~(size_t)255));
+    MaskScratch m;
+    m.carve(ws, 1, P, n > 0 ? n : 1);
     hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(n > 0 ? n : 1), 1), dim3(kQBlock), 0, st, n, pts, (const float *)nullptr, 0,
-                       (const float *)nullptr, 0, 0, radius, size, uvr);
-    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(size), 1), dim3(kSplatBlock), 0, st, n, (const float4 *)uvr, size, L,
-                       (double *)nullptr);
-    hipLaunchKernelGGL(mask_image_kernel, dim3(ceil_div(size * size, 256)), dim3(256), 0, st, size * size, (const float *)L, img);
+                       (const float *)nullptr, 0, 0, radius, size, m.uvr);
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(size), 1), dim3(kSplatBlock), 0, st, n, (const float4 *)m.uvr, col, size,
+                       m.planes, (double *)nullptr);
+    hipLaunchKernelGGL(mask_image_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, (int)P, (const float *)m.planes, img);
     return check(hipGetLastError(), "splat_image launch") ? 1 : 0;
 }
 
-GENPC_API int genpc_pose_loss_grad(int nc, const float *v, const float *center, const float *params, int np,
-                                   const float *partial, const float *d1, const int *i1, const float *d2, const int *i2,
-                                   float cd_weight, float reg_weight, float mask_weight, float radius, int render_size,
-                                   float *loss_out, float *grad, void *stream)
+GENPC_API int genpc_mask_loss(int size, const float *img, const float *ref, float *loss_out, float *grad, void *stream)
+{
+    using namespace genpc;
+    if (size <= 1) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const int P = size * size;
+    char *ws = (char *)workspace(18, 512 + MaskScratch::bytes(2, (size_t)P, 1), st);
+    if (!ws) return 0;
+    double *accum = (double *)ws;
+    MaskScratch m;
+    m.carve(ws + 512, 2, (size_t)P, 1);
+    float *pl_img = m.planes, *pl_ref = m.planes + (size_t)5 * P;
+    if (!check(hipMemsetAsync(accum, 0, kAcc * sizeof(double), st), "hipMemsetAsync(accum)")) return 0;
+    const int g256 = ceil_div(P, 256), gp = lin_grid(P);
+    hipLaunchKernelGGL(mask_to_planes_kernel, dim3(g256), dim3(256), 0, st, P, img, pl_img);
+    hipLaunchKernelGGL(mask_to_planes_kernel, dim3(g256), dim3(256), 0, st, P, ref, pl_ref);
+    hipLaunchKernelGGL(mask_ref_kernel, dim3(1), dim3(kMLThreads), 0, st, size, (const float *)pl_ref, 1, m.mref, m.stats);
+    hipLaunchKernelGGL(mask_image_sums_kernel, dim3(gp, 1), dim3(kQBlock), 0, st, P, (const float *)pl_img, accum);
+    hipLaunchKernelGGL(mask_sums_kernel, dim3(gp, 1), dim3(kQBlock), 0, st, size, (const float *)pl_img, 1, (const float *)m.mref,
+                       (const float *)m.stats, accum);
+    hipLaunchKernelGGL(mask_w_kernel, dim3(gp, 1), dim3(kQBlock), 0, st, size, (const float *)pl_img, 1, (const float *)m.mref,
+                       (const float *)m.stats, 1.0f, m.W1, m.W4, accum);
+    hipLaunchKernelGGL(mask_loss_out_kernel, dim3(g256), dim3(256), 0, st, P, (const float4 *)m.W4, accum, loss_out, grad);
+    return check(hipGetLastError(), "mask_loss launch") ? 1 : 0;
+}
+
+GENPC_API int genpc_pose_loss_grad(int nc, const float *v, const float *vert_col, const float *center, const float *params,
+                                   int np, const float *partial, const float *partial_col, const float *d1, const int *i1,
+                                   const float *d2, const int *i2, float cd_weight, float reg_weight, float mask_weight,
+                                   float radius, int render_size, float *loss_out, float *grad, void *stream)
 {
     using namespace genpc;
     if (nc <= 0 || np <= 0) return -1;
     const bool mask = mask_weight != 0.0f;
-    if (mask && (render_size <= 0 || !(radius > 0.0f))) return -1;
+    if (mask && (render_size <= 1 || !(radius > 0.0f))) return -1;
     hipStream_t st = (hipStream_t)stream;
     const size_t P = mask ? (size_t)render_size * render_size : 0;
     const size_t nmax = (size_t)(nc > np ? nc : np);
-    char *ws = (char *)workspace(3, 1024 + sizeof(PoseState) + 3 * P * sizeof(float) + 256 + nmax * sizeof(float4) + 256, st);
+    const size_t o_state = 512, o_mask = o_state + MaskScratch::up(sizeof(PoseState));
+    char *ws = (char *)workspace(3, o_mask + MaskScratch::bytes(1, P, nmax), st);
     if (!ws) return 0;
     double *accum = (double *)ws;
-    PoseState *S = (PoseState *)(ws + 256);
-    float *stats = (float *)(ws + 256 + ((sizeof(PoseState) + 255) & ~(size_t)255));
-    float *mref = stats + 64, *L = mref + P, *W = L + P;
-    float4 *uvr = (float4 *)(((uintptr_t)(W + P) + 255) & ~(uintptr_t)255);
+    PoseState *S = (PoseState *)(ws + o_state);
+    MaskScratch m;
+    m.carve(ws + o_mask, 1, P, nmax);
     if (!check(hipMemsetAsync(accum, 0, kAcc * sizeof(double), st), "hipMemsetAsync(accum)")) return 0;
     if (!check(hipMemcpyAsync(S->params, params, 10 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy params"))
         return 0;
     hipLaunchKernelGGL(pose_grad_kernel, dim3(lin_grid((long long)nc + np), 1), dim3(kQBlock), 0, st, nc, v, center, 0,
                        params, 0, np, partial, d1, i1, d2, i2, cd_weight, accum);
     if (mask) {
-        if (!mask_prepare_ref(1, np, partial, radius, render_size, uvr, mref, stats, st)) return 0;
-        if (!mask_step(1, nc, v, center, 0, params, 0, radius, render_size, mask_weight, mref, stats, uvr, L, W, accum, st)) return 0;
+        if (!mask_prepare_ref(1, np, partial, partial_col, radius, render_size, m, st)) return 0;
+        if (!mask_step(1, nc, v, vert_col, center, 0, params, 0, radius, render_size, mask_weight, m, accum, st)) return 0;
     }
     hipLaunchKernelGGL(pose_update_kernel, dim3(1), dim3(64), 0, st, 1, S, accum, nc, np, cd_weight, reg_weight, 0.0f, 0,
                        (float *)nullptr, 0);
@@ -936,24 +1194,24 @@ GENPC_API int genpc_pose_cd_grad(int nc, const float *v, const float *center, co
     hipStream_t st = (hipStream_t)stream;
     float *tmp = (float *)workspace(15, 256, st);
     if (!tmp) return 0;
-    const int rc = genpc_pose_loss_grad(nc, v, center, params, np, partial, d1, i1, d2, i2, cd_weight, reg_weight, 0.0f,
-                                        0.0f, 0, tmp, grad, stream);
+    const int rc = genpc_pose_loss_grad(nc, v, nullptr, center, params, np, partial, nullptr, d1, i1, d2, i2, cd_weight,
+                                        reg_weight, 0.0f, 0.0f, 0, tmp, grad, stream);
     if (rc != 1) return rc;
     return check(hipMemcpyAsync(loss_out, tmp, 3 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy loss") ? 1 : 0;
 }
 
-GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, int np, const float *partial,
-                                        float lr, int iters, int starts, float radius, int render_size,
-                                        float mask_weight, float *transform, float *history, float *best_params,
-                                        void *stream)
+GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, const float *complete_col, int np,
+                                        const float *partial, const float *partial_col, float lr, int iters, int starts,
+                                        float radius, int render_size, float mask_weight, float *transform,
+                                        float *history, float *best_params, void *stream)
 {
     using namespace genpc;
     if (b <= 0 || nc <= 0 || np <= 0 || iters < 0 || starts < 1) return -1;
     const bool mask = mask_weight != 0.0f;
-    if (mask && (render_size <= 0 || !(radius > 0.0f))) return -1;
+    if (mask && (render_size <= 1 || !(radius > 0.0f))) return -1;
     hipStream_t st = (hipStream_t)stream;
     const size_t P = mask ? (size_t)render_size * render_size : 0;
-    // scratch: accum[b,16] | state[b] | center[b,4] | pts[b,nc,3] | d1 | d2 | i1 | i2 | mask: stats, m_ref, L, W
+    // scratch: accum[b,kAcc] | state[b] | center[b,4] | pts[b,nc,3] | d1 | d2 | i1 | i2 | mask scratch
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     size_t off = 0;
     const size_t o_acc = off; off += up((size_t)b * kAcc * sizeof(double));
@@ -964,11 +1222,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, in
     const size_t o_d2 = off; off += up((size_t)b * np * 4);
     const size_t o_i1 = off; off += up((size_t)b * nc * 4);
     const size_t o_i2 = off; off += up((size_t)b * np * 4);
-    const size_t o_stats = off; off += up((size_t)b * 4 * sizeof(float));
-    const size_t o_mref = off; off += up((size_t)b * P * sizeof(float));
-    const size_t o_L = off; off += up((size_t)b * P * sizeof(float));
-    const size_t o_W = off; off += up((size_t)b * P * sizeof(float));
-    const size_t o_uvr = off; off += up(mask ? (size_t)b * (size_t)(nc > np ? nc : np) * sizeof(float4) : 0);
+    const size_t o_mask = off; off += mask ? MaskScratch::bytes(b, P, (size_t)(nc > np ? nc : np)) : 0;
     char *ws = (char *)workspace(4, off, st);
     if (!ws) return 0;
     double *accum = (double *)(ws + o_acc);
@@ -977,15 +1231,15 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, in
     float *pts = (float *)(ws + o_pts);
     float *d1 = (float *)(ws + o_d1), *d2 = (float *)(ws + o_d2);
     int *i1 = (int *)(ws + o_i1), *i2 = (int *)(ws + o_i2);
-    float *stats = (float *)(ws + o_stats), *mref = (float *)(ws + o_mref), *L = (float *)(ws + o_L), *W = (float *)(ws + o_W);
-    float4 *uvr = (float4 *)(ws + o_uvr);
+    MaskScratch m = {};
+    if (mask) m.carve(ws + o_mask, b, P, (size_t)(nc > np ? nc : np));
     constexpr int kStateFloats = (int)(sizeof(PoseState) / sizeof(float));
     static_assert(sizeof(PoseState) % sizeof(float) == 0, "PoseState must be float-addressable");
 
     // center = mean(vert_pos) per scan (diff_obj_pose.py:362)
     if (!genpc_mean3(b, nc, complete, center, accum, st)) return 0;
     // reference image of the partial cloud (render_reference_image, diff_obj_pose.py:108-134)
-    if (mask && !mask_prepare_ref(b, np, partial, radius, render_size, uvr, mref, stats, st)) return 0;
+    if (mask && !mask_prepare_ref(b, np, partial, partial_col, radius, render_size, m, st)) return 0;
 
     const int gb = ceil_div(b, 64);
     hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, -1);
@@ -997,7 +1251,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, in
             if (mask)
                 hipLaunchKernelGGL(pose_transform_project_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
                                    (const float *)center, 4, (const float *)S->params, kStateFloats, pts, 1.1f * radius, render_size,
-                                   uvr);
+                                   m.uvr);
             else
                 hipLaunchKernelGGL(pose_transform_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
                                    (const float *)center, 4, (const float *)S->params, kStateFloats, pts);
@@ -1005,8 +1259,8 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, in
             hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, st, nc, complete, (const float *)center,
                                4, (const float *)S->params, kStateFloats, np, partial, (const float *)d1,
                                (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, accum);
-            if (mask && !mask_step(b, nc, complete, center, 4, S->params, kStateFloats, radius, render_size, mask_weight, mref,
-                                   stats, uvr, L, W, accum, st, true))
+            if (mask && !mask_step(b, nc, complete, complete_col, center, 4, S->params, kStateFloats, radius, render_size,
+                                   mask_weight, m, accum, st, true))
                 return 0;
             hipLaunchKernelGGL(pose_update_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, nc, np, 3.0f, 0.001f, lr, 1,
                                history ? history + (size_t)s * (iters + 1) + it : (float *)nullptr, hstride);
@@ -1021,8 +1275,8 @@ GENPC_API int genpc_pose_optimize_cd_batch(int b, int nc, const float *complete,
                                            float lr, int iters, int starts, float *transform, float *history,
                                            float *best_params, void *stream)
 {
-    return genpc_pose_optimize_batch(b, nc, complete, np, partial, lr, iters, starts, 0.0f, 0, 0.0f, transform, history,
-                                     best_params, stream);
+    return genpc_pose_optimize_batch(b, nc, complete, nullptr, np, partial, nullptr, lr, iters, starts, 0.0f, 0, 0.0f,
+                                     transform, history, best_params, stream);
 }
 
 GENPC_API int genpc_pose_optimize_cd(int nc, const float *complete, int np, const float *partial, float lr,

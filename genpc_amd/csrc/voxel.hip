@@ -3,7 +3,8 @@
 // (reg_xyz.py:154-155,178-183).  open3d is absent and unpinned; its published definition:
 //   voxel_min_bound = min_bound - voxel_size / 2;  index = floor((p - voxel_min_bound) / voxel_size)
 //   (double arithmetic on Eigen::Vector3d points);  one output point per occupied voxel = the mean
-//   of its points, accumulated in point order.
+//   of its points, accumulated in point order; colours, when the cloud has them, are averaged the same way
+//   (load_xyz / glb2point down-sample COLOURED clouds: utils/dataUtils.py:174-189,217-250).
 // Output order here: ascending (i, j, k) (open3d's is its hash-map iteration order, unspecified).
 //
 //   voxel_bounds_kernel   min / max of the cloud (order-independent: bitwise reproducible)
@@ -99,28 +100,40 @@ __global__ __launch_bounds__(kVBlock) void voxel_head_kernel(int n, const unsign
 // rank[i] = inclusive scan of head: the run starting at a head i is output slot rank[i] - 1
 __global__ __launch_bounds__(kVBlock) void voxel_mean_kernel(int n, const float *__restrict__ xyz,
                                                              const unsigned long long *__restrict__ keys,
+                                                             const float *__restrict__ attr,
                                                              const int *__restrict__ idx, const int *__restrict__ head,
                                                              const int *__restrict__ rank, float *__restrict__ out,
-                                                             int *__restrict__ out_count)
+                                                             float *__restrict__ out_attr, int *__restrict__ out_count)
 {
     const int i = blockIdx.x * kVBlock + threadIdx.x;
     if (i >= n) return;
     if (i == n - 1) *out_count = rank[i];
     if (!head[i]) return;
     const unsigned long long key = keys[i];
-    double s[3] = {0.0, 0.0, 0.0};
+    double s[3] = {0.0, 0.0, 0.0}, c[3] = {0.0, 0.0, 0.0};
     int cnt = 0;
     for (int j = i; j < n && keys[j] == key; j++) {
         const int p = idx[j];
         s[0] += (double)xyz[(size_t)p * 3 + 0];
         s[1] += (double)xyz[(size_t)p * 3 + 1];
         s[2] += (double)xyz[(size_t)p * 3 + 2];
+        if (attr) {
+            c[0] += (double)attr[(size_t)p * 3 + 0];
+            c[1] += (double)attr[(size_t)p * 3 + 1];
+            c[2] += (double)attr[(size_t)p * 3 + 2];
+        }
         cnt++;
     }
     float *o = out + (size_t)(rank[i] - 1) * 3;
     o[0] = (float)(s[0] / cnt);
     o[1] = (float)(s[1] / cnt);
     o[2] = (float)(s[2] / cnt);
+    if (attr && out_attr) {
+        float *oc = out_attr + (size_t)(rank[i] - 1) * 3;
+        oc[0] = (float)(c[0] / cnt);
+        oc[1] = (float)(c[1] / cnt);
+        oc[2] = (float)(c[2] / cnt);
+    }
 }
 
 __global__ void voxel_error_kernel(const int *__restrict__ err, int *__restrict__ out_count)
@@ -130,10 +143,11 @@ __global__ void voxel_error_kernel(const int *__restrict__ err, int *__restrict_
 
 }  // namespace genpc
 
-GENPC_API int genpc_voxel_down_sample(int n, const float *xyz, float voxel_size, float *out, int *out_count, void *stream)
+GENPC_API int genpc_voxel_down_sample(int n, const float *xyz, const float *colors, double voxel_size, float *out,
+                                      float *out_colors, int *out_count, void *stream)
 {
     using namespace genpc;
-    if (n < 0 || !(voxel_size > 0.0f)) return -1;
+    if (n < 0 || !(voxel_size > 0.0)) return -1;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return check(hipMemsetAsync(out_count, 0, sizeof(int), st), "hipMemsetAsync(voxel count)") ? 1 : 0;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -162,7 +176,7 @@ GENPC_API int genpc_voxel_down_sample(int n, const float *xyz, float voxel_size,
     if (!check(hipMemsetAsync(bounds + 3, 0, 256 - 12, st), "hipMemsetAsync(voxel)")) return 0;
     const int grid = ceil_div(n, kVBlock);
     hipLaunchKernelGGL(voxel_bounds_kernel, dim3(grid < 1024 ? grid : 1024), dim3(kVBlock), 0, st, n, xyz, bounds);
-    hipLaunchKernelGGL(voxel_key_kernel, dim3(grid), dim3(kVBlock), 0, st, n, xyz, (double)voxel_size, (const unsigned *)bounds, k0,
+    hipLaunchKernelGGL(voxel_key_kernel, dim3(grid), dim3(kVBlock), 0, st, n, xyz, voxel_size, (const unsigned *)bounds, k0,
                        i0, err);
     size_t sb = tmp_bytes;
     if (!check(hipcub::DeviceRadixSort::SortPairs(ws + o_tmp, sb, (const unsigned long long *)k0, k1, (const int *)i0, i1, n, 0, 63, st),
@@ -171,8 +185,8 @@ GENPC_API int genpc_voxel_down_sample(int n, const float *xyz, float voxel_size,
     hipLaunchKernelGGL(voxel_head_kernel, dim3(grid), dim3(kVBlock), 0, st, n, (const unsigned long long *)k1, head);
     sb = tmp_bytes;
     if (!check(hipcub::DeviceScan::InclusiveSum(ws + o_tmp, sb, (const int *)head, rank, n, st), "voxel scan")) return 0;
-    hipLaunchKernelGGL(voxel_mean_kernel, dim3(grid), dim3(kVBlock), 0, st, n, xyz, (const unsigned long long *)k1, (const int *)i1,
-                       (const int *)head, (const int *)rank, out, out_count);
+    hipLaunchKernelGGL(voxel_mean_kernel, dim3(grid), dim3(kVBlock), 0, st, n, xyz, (const unsigned long long *)k1, colors,
+                       (const int *)i1, (const int *)head, (const int *)rank, out, out_colors, out_count);
     if (!check(hipGetLastError(), "voxel_down_sample launch")) return 0;
     // out_count = -1 when a coordinate was not finite or the grid exceeded 2^21 cells per axis
     hipLaunchKernelGGL(voxel_error_kernel, dim3(1), dim3(1), 0, st, (const int *)err, out_count);

@@ -1,16 +1,17 @@
 """The SE(3)+scale alignment loop of the reference's
 optim_registration/diff_obj_pose.py on the gfx950 library.
 
-``object_pose_optimization`` keeps the reference's name, hyper-parameters and
-return value (4x4 numpy ``[[sR, t],[0,1]]``, :464-468,:496-594) but takes the two
-clouds as tensors (the reference loads a GLB and a PLY through trimesh/open3d,
-which is I/O outside the hot path) and optimises the reference's objective
+``object_pose_optimization`` keeps the reference's name, signature, hyper-parameters and
+return value (4x4 numpy ``[[sR, t],[0,1]]``, :464-468,:496-594): called with the GLB and PLY
+paths it loads both clouds WITH THEIR COLOURS like the reference's load_point_cloud (:136-164);
+called with tensors it skips the file layer.  It optimises the reference's objective
 ``mask_loss + 3 * (partial_l1(pts, partial) + 0.5 partial_l1(partial, pts)) + 1e-3 |RR^T - I|_F``
 (:329-333,543-546).  ``mask_loss`` (30 MSE + BCE + 10 Dice on sigmoid soft masks of the
 statistically normalised images, :204-217,261-311) is the reference's own torch code
-restated; the IMAGES are not the reference's: it draws them with pytorch3d's CUDA-only
-Pulsar renderer (absent, unpinned), this build with its own differentiable occupancy
-splat, same camera and radii (include/genpc_hip.h).  The whole multi-start loop
+restated (and pinned to it: tests/golden/ref_py_mask_loss.npz); the IMAGES are not the
+reference's: it draws them with pytorch3d's CUDA-only Pulsar renderer (absent, unpinned), this build
+with its own differentiable colour splat -- occupancy times the coverage-weighted mean colour of the
+points over a pixel --, same camera and radii (include/genpc_hip.h).  The whole multi-start loop
 runs on the device without host synchronisation (7 launches per Adam step; 4 with
 ``cd_only=True``).
 """
@@ -60,25 +61,66 @@ def pose_cd_loss_grad(vert_pos, center, params, partial, cd_weight=3.0, reg_weig
     return loss, grad
 
 
-def splat_image(points, radius, render_size=224):
-    """The library's occupancy splat of a cloud [N,3] -> [render_size, render_size] in [0,1]
-    (what stands in for render_reference_image, diff_obj_pose.py:108-134)."""
+def _col(colors, like, name):
+    """optional [..,N,3] colours in [0,1] -> contiguous float32 on like's device (None stays None = white)."""
+    if colors is None:
+        return None
+    c = torch.as_tensor(colors, device=like.device).contiguous().float()
+    if c.shape != like.shape:
+        raise ValueError("%s must have the shape of its cloud %s, got %s" % (name, tuple(like.shape), tuple(c.shape)))
+    return c
+
+
+def splat_image(points, radius, render_size=224, colors=None):
+    """The library's colour splat of a cloud [N,3] (colours [N,3] in [0,1], None = white)
+    -> [render_size, render_size, 3] in [0,1] (what stands in for render_reference_image,
+    diff_obj_pose.py:108-134; NOT Pulsar's blend, see include/genpc_hip.h)."""
     pts = points.contiguous().float()
     _lib.check_tensors((("points", pts),))
-    img = torch.empty(render_size, render_size, device=pts.device)
-    rc = _lib.on_device_of(pts, _L.genpc_splat_image, pts.shape[0], _p(pts), float(radius), int(render_size), _p(img))
+    col = _col(colors, pts, "colors")
+    img = torch.empty(render_size, render_size, 3, device=pts.device)
+    rc = _lib.on_device_of(pts, _L.genpc_splat_image, pts.shape[0], _p(pts), _p(col), float(radius), int(render_size), _p(img))
     if rc != 1:
         raise RuntimeError("genpc_splat_image failed (rc=%d): %s" % (rc, _lib.last_error()))
     return img
 
 
+def compute_mask_from_rendering(rendered_img, threshold=0.1, method="luminance"):
+    """diff_obj_pose.py:166-178: hard mask of a render (the second output of render_reference_image)."""
+    if rendered_img.shape[-1] == 4:
+        return (rendered_img[..., 3] > 0).float()
+    if method == "occupancy":
+        return (rendered_img.sum(-1) > threshold).float()
+    luminance = 0.299 * rendered_img[:, :, 0] + 0.587 * rendered_img[:, :, 1] + 0.114 * rendered_img[:, :, 2]
+    return (luminance > threshold).float()
+
+
+def mask_loss(result, ref_img, with_grad=False):
+    """compute_loss_function's mask_loss (diff_obj_pose.py:286-311: per-channel statistical
+    normalisation of `result` towards `ref_img`, luminance soft masks, 30 MSE + BCE + 10 Dice) for
+    [S,S,3] float32 GPU images, on the library's kernels -> loss (0-dim tensor), and d loss / d result."""
+    a = result.contiguous().float()
+    r = ref_img.contiguous().float()
+    _lib.check_tensors((("result", a), ("ref_img", r)))
+    if a.shape != r.shape or a.dim() != 3 or a.shape[2] != 3 or a.shape[0] != a.shape[1]:
+        raise ValueError("mask_loss: images must be [S,S,3] and alike, got %s and %s" % (tuple(a.shape), tuple(r.shape)))
+    loss = torch.empty(1, device=a.device)
+    grad = torch.empty_like(a) if with_grad else None
+    rc = _lib.on_device_of(a, _L.genpc_mask_loss, a.shape[0], _p(a), _p(r), _p(loss), _p(grad))
+    if rc != 1:
+        raise RuntimeError("genpc_mask_loss failed (rc=%d): %s" % (rc, _lib.last_error()))
+    return (loss[0], grad) if with_grad else loss[0]
+
+
 def pose_loss_grad(vert_pos, center, params, partial, radius, render_size=224, cd_weight=3.0, reg_weight=0.001,
-                   mask_weight=1.0):
+                   mask_weight=1.0, vert_col=None, partial_col=None):
     """compute_loss_function + rot_reg for the current parameters
-    -> (loss[4] = total, cd, |RR^T-I|_F, mask_loss ; grad[10])."""
+    -> (loss[4] = total, cd, |RR^T-I|_F, mask_loss ; grad[10]).  vert_col / partial_col: the clouds'
+    colours ([N,3] in [0,1]; None = white)."""
     from .. import chamfer_3D
     vert_pos = vert_pos.contiguous().float()
     partial = partial.contiguous().float()
+    vc, pc = _col(vert_col, vert_pos, "vert_col"), _col(partial_col, partial, "partial_col")
     pts = pose_transform(vert_pos, center, params)
     nc, np_ = vert_pos.shape[0], partial.shape[0]
     dev = vert_pos.device
@@ -90,8 +132,8 @@ def pose_loss_grad(vert_pos, center, params, partial, radius, render_size=224, c
         raise RuntimeError("chamfer forward failed: " + _lib.last_error())
     loss = torch.empty(4, device=dev)
     grad = torch.empty(10, device=dev)
-    rc = _lib.on_device_of(vert_pos, _L.genpc_pose_loss_grad, nc, _p(vert_pos), _p(center.contiguous().float()),
-                           _p(params.contiguous().float()), np_, _p(partial), _p(d1), _p(i1), _p(d2), _p(i2),
+    rc = _lib.on_device_of(vert_pos, _L.genpc_pose_loss_grad, nc, _p(vert_pos), _p(vc), _p(center.contiguous().float()),
+                           _p(params.contiguous().float()), np_, _p(partial), _p(pc), _p(d1), _p(i1), _p(d2), _p(i2),
                            float(cd_weight), float(reg_weight), float(mask_weight), float(radius), int(render_size),
                            _p(loss), _p(grad))
     if rc != 1:
@@ -99,27 +141,72 @@ def pose_loss_grad(vert_pos, center, params, partial, radius, render_size=224, c
     return loss, grad
 
 
-def object_pose_optimization(complete_xyz, partial_xyz, radius=0.005, lr=0.005, iters=300, render_size=224,
+def load_point_cloud(point_path, device, radius=0.05, num_points=5000):
+    """diff_obj_pose.py:136-164: a .ply through load_xyz, a .glb through glb2point, both voxel
+    down-sampled at `radius` WITH their colours -> (vert_pos [N,3], vert_col [N,3] in [0,1]) on
+    `device`.  (load_xyz substitutes position-derived colours for a colourless PLY, glb2point grey
+    for a colourless mesh, so vert_col is never None -- as in the reference.)"""
+    from ..utils.dataUtils import load_xyz
+    from ..utils.mesh_io import glb2point
+    if point_path.endswith(".ply"):
+        xyz, color = load_xyz(point_path, down_sample=radius, device=device)
+    elif point_path.endswith(".glb"):
+        xyz, color = glb2point(point_path, down_sample=radius, num_points=num_points, device=device)
+    else:
+        raise ValueError("Unsupported point cloud format")
+    vert_pos = torch.as_tensor(xyz, dtype=torch.float32, device=device)
+    if color is None:
+        vert_col = torch.ones(vert_pos.shape[0], 3, dtype=torch.float32, device=device)
+    else:
+        vert_col = torch.as_tensor(color, dtype=torch.float32, device=device)
+        if vert_col.max() > 1.0:
+            vert_col = vert_col / 255.0
+    return vert_pos, vert_col
+
+
+def object_pose_optimization(glb_path, point_path, radius=0.005, lr=0.005, iters=300, render_size=224,
                              vis=False, save_path=None, device=None, cam_bias_num=4, return_history=False,
-                             cd_only=False):
-    """diff_obj_pose.py:496-594.  complete_xyz [Nc,3], partial_xyz [Np,3] GPU tensors -- or
-    [B,Nc,3] / [B,Np,3]: B scans optimised in lock-step, one batched NN launch per Adam step
-    (returns [B,4,4]).  radius / render_size parameterise the silhouette term (splat radius in
-    world units, image side); cd_only=True drops that term (Chamfer + orthogonality only).
-    vis / save_path (the reference's debug GIF) are accepted and unused."""
+                             cd_only=False, complete_col=None, partial_col=None):
+    """diff_obj_pose.py:496-594, same positional arguments and hyper-parameters, returns the 4x4 numpy
+    ``[[sR, t],[0,1]]`` (:464-468).
+
+    File form (the reference's): ``glb_path`` / ``point_path`` are paths; the complete cloud is
+    sampled from the GLB (120 000 points) and the partial cloud read from the PLY (both voxel
+    down-sampled at ``radius`` with their colours, load_point_cloud).
+    Tensor form: ``glb_path`` = complete_xyz [Nc,3] and ``point_path`` = partial_xyz [Np,3] GPU
+    tensors -- or [B,Nc,3] / [B,Np,3]: B scans optimised in lock-step, one batched NN launch per Adam
+    step (returns [B,4,4]) -- with their colours in ``complete_col`` / ``partial_col`` (None = white).
+
+    radius / render_size parameterise the silhouette term (splat radius in world units, image side);
+    cd_only=True drops that term (Chamfer + orthogonality only).  vis / save_path (the reference's
+    debug GIF) are accepted and unused."""
+    if isinstance(glb_path, str) or isinstance(point_path, str):
+        if not (isinstance(glb_path, str) and isinstance(point_path, str)):
+            raise TypeError("object_pose_optimization: pass two paths or two tensors")
+        if device is None:
+            device = torch.device("cuda:0")
+        partial_xyz, partial_col = load_point_cloud(point_path, device, radius=radius, num_points=8000)      # :502
+        complete_xyz, complete_col = load_point_cloud(glb_path, device, radius=radius, num_points=120000)   # :504
+    else:
+        complete_xyz, partial_xyz = glb_path, point_path
     batched = complete_xyz.dim() == 3
     complete_xyz = (complete_xyz if batched else complete_xyz[None]).contiguous().float()
     partial_xyz = (partial_xyz if batched else partial_xyz[None]).contiguous().float()
     _lib.check_tensors((("complete_xyz", complete_xyz), ("partial_xyz", partial_xyz)))
     if complete_xyz.shape[0] != partial_xyz.shape[0]:
         raise ValueError("object_pose_optimization: batch sizes differ")
+    if complete_col is not None and not batched:
+        complete_col = torch.as_tensor(complete_col)[None]
+    if partial_col is not None and not batched:
+        partial_col = torch.as_tensor(partial_col)[None]
+    cc, pc = _col(complete_col, complete_xyz, "complete_col"), _col(partial_col, partial_xyz, "partial_col")
     dev = complete_xyz.device
     b = complete_xyz.shape[0]
     T = torch.empty(b, 16, device=dev)
     hist = torch.empty(b, cam_bias_num * (iters + 1), device=dev)
     bp = torch.empty(b, 10, device=dev)
-    rc = _lib.on_device_of(complete_xyz, _L.genpc_pose_optimize_batch, b, complete_xyz.shape[1], _p(complete_xyz),
-                           partial_xyz.shape[1], _p(partial_xyz), float(lr), int(iters), int(cam_bias_num),
+    rc = _lib.on_device_of(complete_xyz, _L.genpc_pose_optimize_batch, b, complete_xyz.shape[1], _p(complete_xyz), _p(cc),
+                           partial_xyz.shape[1], _p(partial_xyz), _p(pc), float(lr), int(iters), int(cam_bias_num),
                            float(radius), int(render_size), 0.0 if cd_only else 1.0, _p(T), _p(hist), _p(bp))
     if rc != 1:
         raise RuntimeError("genpc_pose_optimize_batch failed (rc=%d): %s" % (rc, _lib.last_error()))

@@ -151,18 +151,26 @@ def normalize_numpy(xyz, range=1.0):
     return (xyz - center) / scale_factor * (range / 0.5), center, scale_factor
 
 
-def voxel_down_sample(xyz, voxel_size):
+def voxel_down_sample(xyz, voxel_size, colors=None):
     """Counterpart of open3d's PointCloud.voxel_down_sample (reg_xyz.py:154-155; open3d
     absent and unpinned): grid anchored at min_bound - voxel/2, one output point per
-    occupied voxel = mean of its points (double, point order).  Output order: ascending
+    occupied voxel = mean of its points (double, point order); `colors` [N,3], when given, are
+    averaged per voxel the same way and returned as a second tensor.  Output order: ascending
     voxel index (open3d's is its hash-map order).  One call into the HIP library
-    (csrc/voxel.hip: keys, radix sort, segmented mean)."""
+    (csrc/voxel.hip: keys, radix sort, segmented mean).  voxel_size goes down as a double."""
     pts = xyz.contiguous().float()
     _lib.check_tensors((("xyz", pts),))
     n = pts.shape[0]
+    col = None
+    if colors is not None:
+        col = colors.contiguous().float()
+        _lib.check_tensors((("colors", col),))
+        if col.shape != pts.shape:
+            raise ValueError("voxel_down_sample: colors must be [N,3] like xyz")
     out = torch.empty(n, 3, device=pts.device)
+    outc = torch.empty(n, 3, device=pts.device) if col is not None else None
     cnt = torch.empty(1, device=pts.device, dtype=torch.int32)
-    rc = _lib.on_device_of(pts, _L.genpc_voxel_down_sample, n, _p(pts), float(voxel_size), _p(out), _p(cnt))
+    rc = _lib.on_device_of(pts, _L.genpc_voxel_down_sample, n, _p(pts), _p(col), float(voxel_size), _p(out), _p(outc), _p(cnt))
     if rc == -1:
         raise ValueError("voxel_down_sample: voxel_size must be positive")
     if rc != 1:
@@ -170,7 +178,9 @@ def voxel_down_sample(xyz, voxel_size):
     k = int(cnt.item())
     if k < 0:
         raise ValueError("voxel_down_sample: non-finite coordinate, or more than 2^21 voxels along an axis")
-    return out[:k].to(xyz.dtype)
+    if col is None:
+        return out[:k].to(xyz.dtype)
+    return out[:k].to(xyz.dtype), outc[:k].to(colors.dtype)
 
 
 def _apply(T, xyz):
@@ -179,27 +189,94 @@ def _apply(T, xyz):
     return (xyz.double() @ Tt[:3, :3].T + Tt[:3, 3]).to(xyz.dtype)
 
 
-def reg(partial_xyz, complete_xyz, generative_model="trellis", dataset="redwood", cd_inv_weight=0.5,
-        diff_init=True, reg_fine_xyz=False, pose_points=(8000, 120000), pose_voxel=0.02, cd_only_pose=False):
-    """reg_xyz.py:99-205 without file I/O and without the fusion tail.
+def _is_cfg(x):
+    return hasattr(x, "output_path") and not torch.is_tensor(x)
+
+
+def reg(cfg, flag, cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=False, **kwargs):
+    """reg_xyz.py:99-223, same signature.
+
+    File form (the reference's): ``reg(cfg, flag, cd_inv_weight, diff_init, reg_fine_xyz)`` reads
+    ``{cfg.output_path}/{flag}/color_point.ply`` (the partial cloud with the colours colorPoint gave
+    it) and ``{flag}_{cfg.generative_model}.glb`` (the generated mesh; 163 840 surface samples with
+    their colours), aligns them and writes ``{flag}_fused.ply`` WITH COLOURS (:207-219); returns the
+    dict of `reg_tensors` plus ``fused`` / ``fused_col`` / ``fused_path``.  Raises FileNotFoundError
+    like the reference when an input is missing.
+    Tensor form: ``reg(partial_xyz, complete_xyz, ...)`` = `reg_tensors` (no files)."""
+    if not _is_cfg(cfg):
+        return reg_tensors(cfg, flag, cd_inv_weight=cd_inv_weight, diff_init=diff_init, reg_fine_xyz=reg_fine_xyz, **kwargs)
+    import os
+    from .optim_registration.diff_obj_pose import object_pose_optimization
+    from .utils.dataUtils import read_ply, save_ply_xyzrgb
+    from .utils.mesh_io import glb2point
+    path = cfg.output_path
+    ply = f"{path}/{flag}/color_point.ply"
+    glb = f"{path}/{flag}/{flag}_{cfg.generative_model}.glb"
+    for f in (ply, glb):                                                # :103-108
+        if not os.path.exists(f):
+            print(f"Path {f} does not exist.")
+            raise FileNotFoundError(f"Path {f} does not exist.")
+    dev = torch.device(getattr(cfg, "device", "cuda"))
+    diff_transform = None
+    if diff_init:                                                       # :109-122
+        diff_transform = np.linalg.inv(object_pose_optimization(
+            glb_path=glb, point_path=ply, radius=0.02, lr=0.01, iters=200, render_size=224, vis=True, device=dev,
+            cd_only=kwargs.get("cd_only_pose", False)).astype(np.float64))
+    sxyz, scol = read_ply(ply)                                          # :124 o3d.io.read_point_cloud
+    txyz, tcol = glb2point(glb, num_points=163840, rng=kwargs.get("rng"))                      # :125
+    if scol is None:
+        scol = np.zeros_like(sxyz)                                      # an open3d cloud without colours: fused file stays valid
+    out = reg_tensors(torch.as_tensor(sxyz, dtype=torch.float32, device=dev), torch.as_tensor(txyz, dtype=torch.float32, device=dev),
+                      generative_model=cfg.generative_model, dataset=getattr(cfg, "dataset", "redwood"),
+                      cd_inv_weight=cd_inv_weight, diff_init=diff_init, reg_fine_xyz=reg_fine_xyz,
+                      partial_col=torch.as_tensor(scol, dtype=torch.float32, device=dev),
+                      complete_col=torch.as_tensor(tcol, dtype=torch.float32, device=dev), diff_transform=diff_transform)
+    fused, fused_col = fuse(out["source"], out["target"], num_points=20000, distance_threshold=0.0001, std_ratio=2.5,
+                            source_col=out["source_col"], target_col=out["target_col"])       # :207-217
+    out.update(fused=fused, fused_col=fused_col, fused_path=f"{path}/{flag}/{flag}_fused.ply")
+    save_ply_xyzrgb(fused.double().cpu().numpy(), fused_col.double().cpu().numpy(), out["fused_path"])     # :221
+    return out
+
+
+def reg_tensors(partial_xyz, complete_xyz, generative_model="trellis", dataset="redwood", cd_inv_weight=0.5,
+                diff_init=True, reg_fine_xyz=False, pose_voxel=0.02, cd_only_pose=False, partial_col=None,
+                complete_col=None, diff_transform=None):
+    """reg_xyz.py:99-205 on tensors, without file I/O and without the fusion tail.
     partial_xyz: the observed cloud (color_point.ply), complete_xyz: points sampled from
-    the generated mesh (glb2point).  Returns a dict with the aligned clouds
-    (`source`, `target`: both back in the partial cloud's original frame, as at
-    :200-205) and every intermediate transform."""
+    the generated mesh (glb2point); partial_col / complete_col: their colours ([N,3] in [0,1], None =
+    white in the pose loss) -- they feed the silhouette term of the pose initialisation and are carried
+    to the outputs.  diff_transform: a precomputed inverse pose (the file form computes it from its own
+    120 000-point sampling like the reference); None runs object_pose_optimization on both clouds
+    voxel-down-sampled at `pose_voxel` (load_point_cloud's radius).  Returns a dict with the aligned
+    clouds (`source`, `target`: both back in the partial cloud's original frame, as at :200-205;
+    `source_col`, `target_col`) and every intermediate transform."""
     from .optim_registration.diff_obj_pose import object_pose_optimization
     source = partial_xyz.contiguous().float()
     target = complete_xyz.contiguous().float()
+    scol = None if partial_col is None else partial_col.contiguous().float()
+    tcol = None if complete_col is None else complete_col.contiguous().float()
     out = {}
-    diff_transform = np.eye(4)
-    if diff_init:                                                       # :109-122
-        T = object_pose_optimization(voxel_down_sample(target, pose_voxel), voxel_down_sample(source, pose_voxel),
-                                     radius=0.02, lr=0.01, iters=200, render_size=224, cd_only=cd_only_pose)
+    if not diff_init:
+        diff_transform = np.eye(4)
+    elif diff_transform is None:                                        # :109-122
+        if tcol is not None:
+            tv, tvc = voxel_down_sample(target, pose_voxel, colors=tcol)
+        else:
+            tv, tvc = voxel_down_sample(target, pose_voxel), None
+        if scol is not None:
+            sv, svc = voxel_down_sample(source, pose_voxel, colors=scol)
+        else:
+            sv, svc = voxel_down_sample(source, pose_voxel), None
+        T = object_pose_optimization(tv, sv, radius=0.02, lr=0.01, iters=200, render_size=224, cd_only=cd_only_pose,
+                                     complete_col=tvc, partial_col=svc)
         diff_transform = np.linalg.inv(T.astype(np.float64))
     out["diff_transform"] = diff_transform
     source = _apply(diff_transform, source)                             # :126
     target, _, _ = normalize_numpy(target, range=0.5)                   # :130
     if generative_model in ("instantmesh",):                            # :132-137
-        source, _ = remove_noise_from_point_cloud(source)
+        source, keep = remove_noise_from_point_cloud(source)
+        if scol is not None:
+            scol = scol[keep]
         target = (target.double() @ torch.as_tensor(get_rotate_matrix("x", 90).T, device=target.device)
                   @ torch.as_tensor(get_rotate_matrix("y", 90).T, device=target.device)).float()
     best_scale, best_loss, coarse = coarse_scale_sweep(voxel_down_sample(source, 0.03), voxel_down_sample(target, 0.03),
@@ -218,7 +295,7 @@ def reg(partial_xyz, complete_xyz, generative_model="trellis", dataset="redwood"
     target = _apply(np.linalg.inv(coarse), target)                      # :201-205
     target = _apply(np.linalg.inv(diff_transform), target)
     source = _apply(np.linalg.inv(diff_transform), source)
-    out.update(source=source, target=target)
+    out.update(source=source, target=target, source_col=scol, target_col=tcol)
     return out
 
 
@@ -231,7 +308,7 @@ def remove_close_points(source_xyz, target_xyz, distance_threshold=0.0001):
     reference's 1e-4 is 0.01 units).  One NN launch instead of a Python loop of KD-tree
     queries (measured at 163840 x 16384: 147 us on the default MFMA filter; the radius-limited
     cell search, chamfer_3D.nm_distance_within, gives the same mask in 156 us -- no gain yet).
-    Returns (filtered target [K,3], keep mask [M])."""
+    Returns (filtered target [K,3], keep mask [M]) -- index colours with the mask (:56)."""
     from . import chamfer_3D
     src = source_xyz.contiguous().float()
     tgt = target_xyz.contiguous().float()
@@ -245,18 +322,25 @@ def remove_close_points(source_xyz, target_xyz, distance_threshold=0.0001):
     return tgt[keep], keep
 
 
-def fuse(source_xyz, target_xyz, num_points=20000, distance_threshold=0.0001, std_ratio=2.5):
+def fuse(source_xyz, target_xyz, num_points=20000, distance_threshold=0.0001, std_ratio=2.5, source_col=None,
+         target_col=None):
     """reg_xyz.py:207-217: partial + (complete minus what the partial already covers),
     farthest-point-sampled to `num_points`, then the statistical outlier filter
-    (std_ratio 2.5 as at :217; None skips it)."""
+    (std_ratio 2.5 as at :217; None skips it).  With source_col / target_col the colours follow their
+    points through all three steps (:56,:212-216) and (fused, fused_col) is returned."""
     from .fps import fps_sampling
-    filtered, _ = remove_close_points(source_xyz, target_xyz, distance_threshold)
+    with_col = source_col is not None and target_col is not None
+    filtered, keep = remove_close_points(source_xyz, target_xyz, distance_threshold)
     fused = torch.cat([source_xyz.float(), filtered], dim=0).contiguous()
+    col = torch.cat([source_col.float(), target_col.float()[keep]], dim=0) if with_col else None
     if fused.shape[0] > num_points:
-        fused = fused[fps_sampling(fused, num_points).long()]
+        idx = fps_sampling(fused, num_points).long()
+        fused = fused[idx]
+        col = col[idx] if with_col else None
     if std_ratio is not None:                                            # :217
-        fused, _ = remove_noise_from_point_cloud(fused, std_ratio=std_ratio)
-    return fused
+        fused, ok = remove_noise_from_point_cloud(fused, std_ratio=std_ratio)
+        col = col[ok] if with_col else None
+    return (fused, col) if with_col else fused
 
 
 def knn_mean_distance(xyz, k=20):

@@ -9,9 +9,9 @@ _PLY_TYPES = {"double": "<f8", "float": "<f4", "float32": "<f4", "float64": "<f8
               "int": "<i4", "int32": "<i4", "uint": "<u4", "short": "<i2", "ushort": "<u2", "char": "i1"}
 
 
-def load_xyz(path, want_color=True):
-    """utils/dataUtils.py:174-189 (`load_xyz`) for binary little-endian and ASCII
-    PLY: returns (xyz float64 [N,3], rgb float64 [N,3] in [0,1] or None)."""
+def read_ply(path, want_color=True):
+    """Binary little-endian and ASCII PLY vertex reader (what open3d's read_point_cloud does for the
+    reference's files): returns (xyz float64 [N,3], rgb float64 [N,3] in [0,1] or None)."""
     with open(path, "rb") as f:
         header = []
         while True:
@@ -53,6 +53,38 @@ def load_xyz(path, want_color=True):
         if rgb.max() > 1.0:
             rgb = rgb / 255.0
     return xyz, rgb
+
+
+def voxel_down_sample_colored(xyz, colors, voxel_size, device=None):
+    """open3d's PointCloud.voxel_down_sample of a coloured cloud (points AND colours are averaged per
+    voxel) on the HIP library (csrc/voxel.hip).  numpy in, numpy float32 out.  GPU only: there is no
+    CPU fallback."""
+    import torch
+    from .. import reg_xyz
+    dev = torch.device("cuda" if device is None else device)
+    x = torch.as_tensor(np.ascontiguousarray(xyz, np.float32), device=dev)
+    if colors is None:
+        return reg_xyz.voxel_down_sample(x, voxel_size).cpu().numpy(), None
+    c = torch.as_tensor(np.ascontiguousarray(colors, np.float32), device=dev)
+    ox, oc = reg_xyz.voxel_down_sample(x, voxel_size, colors=c)
+    return ox.cpu().numpy(), oc.cpu().numpy()
+
+
+def load_xyz(path, down_sample=None, device=None):
+    """utils/dataUtils.py:174-189, same signature and returns: (points float32 [N,3], colours float32
+    [N,3]).  down_sample: voxel size of an open3d-style voxel_down_sample applied to points and
+    colours (runs on the GPU).  A PLY without colours -- or with all-zero ones -- gets colours derived
+    from the position inside the bounding box (:185-187), so the colours are never None."""
+    xyz, rgb = read_ply(path)
+    points = xyz.astype(np.float32)
+    colors = None if rgb is None else rgb.astype(np.float32)
+    if down_sample:
+        points, colors = voxel_down_sample_colored(xyz, rgb, down_sample, device)
+    has_valid_color = colors is not None and not np.allclose(colors, 0)
+    if not has_valid_color:
+        colors = (points - points.min(axis=0)) / (points.max(axis=0) - points.min(axis=0) + 1e-8)
+        colors = np.clip(colors, 0, 1)
+    return points, colors
 
 
 def save_ply_xyzrgb(xyz, rgb, path):

@@ -201,10 +201,20 @@ def sample_surface(vertices, faces, count, rng=None):
     return pts, face_index
 
 
-def glb2point(glb_path, num_points=16384, rng=None):
-    """utils/dataUtils.py:217-250 without open3d/trimesh: (points [n,3], colours [n,3]);
-    colours are barycentric blends of the vertex colours (COLOR_0, or the baked base-colour texture
-    / factor), 0.5 grey when the file has none."""
+def glb2point(glb_path, down_sample=None, num_points=16384, rng=None, device=None):
+    """utils/dataUtils.py:217-250 without open3d/trimesh, same leading arguments: (points [n,3],
+    colours [n,3]); colours are barycentric blends of the vertex colours (COLOR_0, or the baked
+    base-colour texture / factor), 0.5 grey when the file has none.  down_sample: voxel size of the
+    open3d-style voxel_down_sample applied to points and colours afterwards (:248-249; on the GPU).
+    The reference samples from trimesh's unseeded global RNG; pass `rng` for a reproducible cloud."""
+    pts, col = _glb2point_full(glb_path, num_points, rng)
+    if down_sample:
+        from .dataUtils import voxel_down_sample_colored
+        pts, col = voxel_down_sample_colored(pts, col, down_sample, device)
+    return pts, col
+
+
+def _glb2point_full(glb_path, num_points, rng):
     V, F, C = load_glb(glb_path)
     pts, fi = sample_surface(V, F, num_points, rng)
     if C is None:

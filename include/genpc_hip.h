@@ -219,37 +219,56 @@ int genpc_pose_optimize_cd_batch(int b, int nc, const float *complete, int np,
 
 /* Silhouette ("mask") half of the pose loss -------------------------------------- *
  * The reference compares PulsarPointsRenderer images (pytorch3d, CUDA only -- absent here and
- * unpinned) of the partial cloud (diff_obj_pose.py:108-134) and of the posed complete cloud
- * (:426-433).  This library draws both with its OWN differentiable occupancy splat, same camera
- * (eye (0,0,3) looking at the origin, focal 4 NDC) and radii (world units):
+ * unpinned) of the partial cloud with its colours (diff_obj_pose.py:108-134; load_point_cloud
+ * returns vert_col for every input the pipeline produces, :136-164) and of the posed complete cloud
+ * with its colours (:426-433).  This library draws both with its OWN differentiable colour splat, same
+ * camera (eye (0,0,3) looking at the origin, focal 4 NDC) and radii (world units):
  *   Zv = 3 - z;  u = S/2 (1 + 4 x / Zv);  v = S/2 (1 - 4 y / Zv);  rho = S/2 * 4 * radius / Zv
- *   a_i = min(0.999, max(0, 1 - |pixel centre - (u, v)|^2 / rho^2));  img = 1 - prod_i (1 - a_i)
- * genpc_splat_image writes img[size*size] (row-major, row 0 at the top) for pts[n,3].          */
-int genpc_splat_image(int n, const float *pts, float radius, int size, float *img, void *stream);
+ *   a_i = min(0.999, max(0, 1 - |pixel centre - (u, v)|^2 / rho^2))
+ *   O = 1 - prod_i (1 - a_i);  A_ch = sum_i a_i c_i,ch / sum_i a_i;  img_ch = O * A_ch
+ * (coverage-weighted colour, order-independent; Pulsar's softmax in depth is NOT reproduced).
+ * genpc_splat_image writes img[size, size, 3] (H, W, C like the reference's renders, row 0 at the
+ * top) for pts[n,3] with colours col[n,3] in [0,1]; col == NULL draws white (what load_point_cloud
+ * substitutes when a PLY has no colours, :157-158).                                              */
+int genpc_splat_image(int n, const float *pts, const float *col, float radius, int size,
+                      float *img, void *stream);
+
+/* compute_loss_function's mask terms on given images (diff_obj_pose.py:286-311 with
+ * normalize_images :204-217, compute_soft_mask :261-278, dice_loss :238-259): img, ref [size,size,3]
+ * device float32 -> loss_out[1] = 30 MSE + BCE + 10 Dice of the luminance soft masks after the
+ * per-channel statistical normalisation of img towards ref; grad (NULL to skip) [size,size,3] =
+ * d loss / d img.  The same device code as the alignment loop's; pinned to the reference's own
+ * Python through tests/golden/ref_py_mask_loss.npz.  Returns 1 / 0 / -1 (size < 2).               */
+int genpc_mask_loss(int size, const float *img, const float *ref, float *loss_out, float *grad,
+                    void *stream);
 
 /* compute_loss_function as a whole (diff_obj_pose.py:286-336) + the orthogonality term, and its
  * analytic gradient:
  *   loss = mask_weight * mask_loss + cd_weight * cd + reg_weight * |RR^T - I|_F
  *   mask_loss = 30 MSE(m, m_ref) + BCE(m, m_ref) + 10 Dice(m, m_ref)  on the soft masks
- *   m = sigmoid((normalised image - 0.1) / 0.05) of the posed cloud (splat radius 1.1 * radius,
- *   :385) and of `partial` (radius, :118), statistical normalisation as at :204-217.
- * d1/i1/d2/i2 as in genpc_pose_cd_grad.  mask_weight = 0 skips the mask term (render_size and
- * radius are then ignored).  loss_out[4] = loss, cd, |RR^T-I|_F, mask_loss; grad[10].           */
-int genpc_pose_loss_grad(int nc, const float *v, const float *center, const float *params,
-                         int np, const float *partial, const float *d1, const int *i1,
+ *   m = sigmoid((luminance of the normalised image - 0.1) / 0.05) of the posed cloud (colours
+ *   vert_col[nc,3], splat radius 1.1 * radius, :385) and of `partial` (colours partial_col[np,3],
+ *   radius, :118); per-channel statistical normalisation as at :204-217.  NULL colours = white.
+ * d1/i1/d2/i2 as in genpc_pose_cd_grad.  mask_weight = 0 skips the mask term (render_size, radius
+ * and the colours are then ignored).  loss_out[4] = loss, cd, |RR^T-I|_F, mask_loss; grad[10].   */
+int genpc_pose_loss_grad(int nc, const float *v, const float *vert_col, const float *center,
+                         const float *params, int np, const float *partial,
+                         const float *partial_col, const float *d1, const int *i1,
                          const float *d2, const int *i2, float cd_weight, float reg_weight,
                          float mask_weight, float radius, int render_size, float *loss_out,
                          float *grad, void *stream);
 
 /* object_pose_optimization's loop with the FULL objective for B scans in lock-step: as
  * genpc_pose_optimize_cd_batch plus, per Adam step, the splat of the posed cloud, the mask loss
- * and its gradient (three more launches; the reference image of `partial` is drawn once).
- * radius / render_size: diff_obj_pose.py:496; mask_weight 1 is the reference's weight (:331).   */
-int genpc_pose_optimize_batch(int b, int nc, const float *complete, int np,
-                              const float *partial, float lr, int iters, int starts,
-                              float radius, int render_size, float mask_weight,
-                              float *transform, float *history, float *best_params,
-                              void *stream);
+ * and its gradient (four more launches; the reference image of `partial` is drawn once).
+ * complete_col[B,nc,3] / partial_col[B,np,3]: the clouds' colours in [0,1] (vert_col of
+ * load_point_cloud, :136-164), NULL = white.  radius / render_size: diff_obj_pose.py:496;
+ * mask_weight 1 is the reference's weight (:331).                                                 */
+int genpc_pose_optimize_batch(int b, int nc, const float *complete, const float *complete_col,
+                              int np, const float *partial, const float *partial_col, float lr,
+                              int iters, int starts, float radius, int render_size,
+                              float mask_weight, float *transform, float *history,
+                              float *best_params, void *stream);
 
 /* Voxel-grid down-sampling ---------------------------------------------------- *
  * Counterpart of open3d's PointCloud.voxel_down_sample, which reg() applies to both clouds
@@ -257,11 +276,14 @@ int genpc_pose_optimize_batch(int b, int nc, const float *complete, int np,
  * published definition): grid anchored at min_bound - voxel_size / 2, index =
  * floor((p - anchor) / voxel_size) in double, one output point per occupied voxel = the mean
  * of its points accumulated in point order (double).  Output order: ascending (i, j, k).
+ * colors[n,3] (NULL = none): per-point colours, averaged per voxel into out_colors[n,3] the same
+ * way (what open3d does for the coloured clouds of load_xyz / glb2point, utils/dataUtils.py:174-189,
+ * 217-250).  voxel_size is a double, as in open3d (0.03 != 0.03f moves points near a cell face).
  * out[n,3] must hold up to n points; *out_count (device int) receives the number written, or
  * -1 when a coordinate is not finite or the grid would exceed 2^21 cells along an axis.
  * Returns -1 for voxel_size <= 0.                                                        */
-int genpc_voxel_down_sample(int n, const float *xyz, float voxel_size, float *out,
-                            int *out_count, void *stream);
+int genpc_voxel_down_sample(int n, const float *xyz, const float *colors, double voxel_size,
+                            float *out, float *out_colors, int *out_count, void *stream);
 
 /* ICP + scale search --------------------------------------------------------- *
  * Batched point-to-point ICP with the semantics of open3d's registration_icp as

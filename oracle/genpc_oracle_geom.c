@@ -1011,7 +1011,10 @@ static int vox_cmp(const void *a, const void *b)
     return x->idx < y->idx ? -1 : (x->idx > y->idx);
 }
 
-ORACLE_API int oracle_voxel_down_sample(int n, const float *xyz, float voxel_size, float *out)
+/* colors / out_colors: optional [n,3] attributes averaged per voxel like the points (open3d averages the
+ * colours of a coloured cloud); voxel_size is a DOUBLE like open3d's (0.03 is not 0.03f). */
+ORACLE_API int oracle_voxel_down_sample(int n, const float *xyz, const float *colors, double voxel_size, float *out,
+                                        float *out_colors)
 {
     if (n <= 0) return 0;
     const double voxel = voxel_size;
@@ -1033,11 +1036,16 @@ ORACLE_API int oracle_voxel_down_sample(int n, const float *xyz, float voxel_siz
     qsort(v, (size_t)n, sizeof(vox_t), vox_cmp);
     int m = 0;
     for (int i = 0; i < n;) {
-        double s[3] = {0, 0, 0};
+        double s[3] = {0, 0, 0}, c[3] = {0, 0, 0};
         int j = i;
         for (; j < n && v[j].key == v[i].key; j++)
-            for (int k = 0; k < 3; k++) s[k] += (double)xyz[(size_t)v[j].idx * 3 + k];
+            for (int k = 0; k < 3; k++) {
+                s[k] += (double)xyz[(size_t)v[j].idx * 3 + k];
+                if (colors) c[k] += (double)colors[(size_t)v[j].idx * 3 + k];
+            }
         for (int k = 0; k < 3; k++) out[(size_t)m * 3 + k] = (float)(s[k] / (j - i));
+        if (colors && out_colors)
+            for (int k = 0; k < 3; k++) out_colors[(size_t)m * 3 + k] = (float)(c[k] / (j - i));
         m++;
         i = j;
     }

@@ -497,14 +497,20 @@ def zbuffer_visibility(uv, depth, res, tol, point_size=2):
     return vis.astype(bool), cnt
 
 
-def voxel_down_sample(xyz, voxel_size):
-    """open3d-style voxel grid mean (published definition; unpinned) -> [K,3]."""
+def voxel_down_sample(xyz, voxel_size, colors=None):
+    """open3d-style voxel grid mean (published definition; unpinned) -> [K,3] (and the voxel-mean colours
+    [K,3] when `colors` is given)."""
     p, pp = _f(xyz)
+    c, pc = _fopt(colors)
     out = np.zeros_like(p)
-    k = int(lib().oracle_voxel_down_sample(p.shape[0], pp, ctypes.c_float(voxel_size), out.ctypes.data_as(_f32p)))
+    outc = np.zeros_like(p) if c is not None else None
+    k = int(lib().oracle_voxel_down_sample(p.shape[0], pp, pc, ctypes.c_double(voxel_size), out.ctypes.data_as(_f32p),
+                                           outc.ctypes.data_as(_f32p) if outc is not None else None))
     if k < 0:
         raise ValueError("voxel_down_sample: bad input")
-    return out[:k].copy()
+    if colors is None:
+        return out[:k].copy()
+    return out[:k].copy(), outc[:k].copy()
 
 
 def hpr_visibility(points, eye, radius, want_max_vertices=False):

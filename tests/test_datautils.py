@@ -1,6 +1,8 @@
 """Host-side format helpers (no GPU): PLY round trip in the layout of the
 reference's data/*.ply, normalisation and rotation helpers."""
 import numpy as np
+
+from conftest import write_glb as _write_glb
 import pytest
 
 from genpc_amd.utils import dataUtils as D
@@ -12,12 +14,12 @@ def test_ply_roundtrip(tmp_path, oracle):
     rgb = rng.random((1234, 3))
     p = str(tmp_path / "a.ply")
     D.save_ply_xyzrgb(xyz, rgb, p)
-    x2, c2 = D.load_xyz(p)
+    x2, c2 = D.read_ply(p)
     np.testing.assert_array_equal(x2, xyz)
     np.testing.assert_allclose(c2, np.rint(rgb * 255) / 255, atol=1e-12)
     np.testing.assert_array_equal(oracle.read_ply_xyz(p), xyz)          # the oracle's reader agrees
     D.save_ply_xyzrgb(xyz, None, p)
-    x3, c3 = D.load_xyz(p)
+    x3, c3 = D.read_ply(p)
     assert c3 is None
     np.testing.assert_array_equal(x3, xyz)
     header = open(p, "rb").read(200)
@@ -28,7 +30,7 @@ def test_ascii_ply(tmp_path):
     p = tmp_path / "b.ply"
     p.write_text("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\n"
                  "end_header\n1 2 3\n4 5 6.5\n")
-    x, c = D.load_xyz(str(p))
+    x, c = D.read_ply(str(p))
     np.testing.assert_array_equal(x, [[1, 2, 3], [4, 5, 6.5]])
     assert c is None
 
@@ -44,39 +46,6 @@ def test_normalize_and_rotate():
         np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-12)
         assert abs(np.linalg.det(R) - 1) < 1e-12
     np.testing.assert_allclose(D.get_rotate_matrix("y", 90) @ np.array([0, 0, 1.0]), [1, 0, 0], atol=1e-12)
-
-
-def _write_glb(path, verts, faces, colors=None, node=None, indices_u16=True):
-    """Minimal binary glTF writer for the tests (one mesh, one primitive, one node)."""
-    import json
-    import struct
-    v = np.asarray(verts, "<f4")
-    idx = np.asarray(faces, "<u2" if indices_u16 else "<u4").reshape(-1)
-    blobs = [v.tobytes(), idx.tobytes() + b"\x00" * (-len(idx.tobytes()) % 4)]
-    views = [{"buffer": 0, "byteOffset": 0, "byteLength": len(blobs[0])},
-             {"buffer": 0, "byteOffset": len(blobs[0]), "byteLength": len(idx.tobytes())}]
-    accs = [{"bufferView": 0, "componentType": 5126, "count": len(v), "type": "VEC3"},
-            {"bufferView": 1, "componentType": 5123 if indices_u16 else 5125, "count": len(idx), "type": "SCALAR"}]
-    attrs = {"POSITION": 0}
-    if colors is not None:
-        c = np.asarray(colors, "<f4")
-        views.append({"buffer": 0, "byteOffset": sum(map(len, blobs)), "byteLength": c.nbytes})
-        blobs.append(c.tobytes())
-        accs.append({"bufferView": 2, "componentType": 5126, "count": len(c), "type": "VEC3"})
-        attrs["COLOR_0"] = 2
-    n = dict(node or {})
-    n["mesh"] = 0
-    g = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [n],
-         "meshes": [{"primitives": [{"attributes": attrs, "indices": 1}]}], "accessors": accs, "bufferViews": views,
-         "buffers": [{"byteLength": sum(map(len, blobs))}]}
-    js = json.dumps(g).encode()
-    js += b" " * (-len(js) % 4)
-    binc = b"".join(blobs)
-    total = 12 + 8 + len(js) + 8 + len(binc)
-    with open(path, "wb") as f:
-        f.write(struct.pack("<4sII", b"glTF", 2, total))
-        f.write(struct.pack("<I4s", len(js), b"JSON") + js)
-        f.write(struct.pack("<I4s", len(binc), b"BIN\x00") + binc)
 
 
 def test_glb_loader_and_surface_sampling(tmp_path):
@@ -105,7 +74,7 @@ def test_glb_loader_and_surface_sampling(tmp_path):
     area = 0.5 * np.linalg.norm(np.cross(verts[faces][:, 1] - verts[faces][:, 0], verts[faces][:, 2] - verts[faces][:, 0]), axis=1)
     np.testing.assert_allclose(np.bincount(fi, minlength=4) / 40000, area / area.sum(), atol=0.01)
     _write_glb(p, verts, faces, cols, None)
-    P, Cc = M.glb2point(p, 5000, np.random.default_rng(1))
+    P, Cc = M.glb2point(p, num_points=5000, rng=np.random.default_rng(1))
     assert P.shape == (5000, 3) and Cc.shape == (5000, 3) and Cc.min() >= 0 and Cc.max() <= 1
     # on face (0,1,2) (z = 0) the colour is the barycentric blend of red / green / blue
     on = np.abs(P[:, 2]) < 1e-12
@@ -173,7 +142,7 @@ def test_glb_texture_is_baked_to_vertex_colours(tmp_path):
     np.testing.assert_array_equal(M.uv_to_color(np.array([[0.49 / 6, 0.51 / 4], [0.5 / 6, 1.5 / 4]]), np.dstack([tex, tex[:, :, :1]]))[:, :3],
                                   np.stack([tex[1, 0], tex[2, 0]]))             # rounding: 0.49 -> 0, 0.51 -> 1; halves to even
     # sampled colours are barycentric blends of the baked vertex colours
-    P, Cc = M.glb2point(str(tmp_path / "tex0.glb"), 2000, np.random.default_rng(1))
+    P, Cc = M.glb2point(str(tmp_path / "tex0.glb"), num_points=2000, rng=np.random.default_rng(1))
     lower = P[:, 0] + P[:, 1] <= 1.0
     b = np.stack([1 - P[lower, 0] - P[lower, 1], P[lower, 0], P[lower, 1]], 1)
     np.testing.assert_allclose(Cc[lower], b @ expect[:3], atol=1e-9)

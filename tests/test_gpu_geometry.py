@@ -131,32 +131,55 @@ def test_pose_transform_and_gradient(gp, oracle):
         assert np.abs(gg[sl] - go[sl]).max() <= 1e-4 * np.abs(go[sl]).max(), (sl, gg[sl], go[sl])
 
 
+def _colours(rng, n, dark=0.0):
+    col = (0.25 + 0.75 * rng.random((n, 3))).astype(np.float32)
+    k = int(n * dark)
+    if k:
+        col[:k] *= np.float32(0.08)
+    return col
+
+
 def test_splat_image_vs_oracle(gp, oracle):
-    """The occupancy splat (the build's stand-in for the reference's Pulsar renders): image of a
-    cloud against the oracle's fp64 restatement, several radii and image sizes."""
+    """The colour splat (the build's stand-in for the reference's Pulsar renders): [S,S,3] image of a
+    cloud against the oracle's fp64 restatement, several radii and image sizes, white and coloured."""
     torch = gp["torch"]
     complete, partial, _ = _shape(5, 4000)
+    col = _colours(np.random.default_rng(1), len(partial), 0.3)
     for radius, size in ((0.02, 224), (0.022, 224), (0.05, 96), (0.005, 224), (0.02, 57)):
-        img = gp["POSE"].splat_image(torch.from_numpy(partial).cuda(), radius, size).cpu().numpy()
-        ref = oracle.splat_image(partial, radius, size)
-        np.testing.assert_allclose(img, ref, atol=2e-4)      # fp32 (u, v, rho) against fp64: pixels on a disc's rim
-        assert img.shape == (size, size) and 0.005 < img.mean() < 0.9
+        for c in (None, col):
+            img = gp["POSE"].splat_image(torch.from_numpy(partial).cuda(), radius, size,
+                                         None if c is None else torch.from_numpy(c).cuda()).cpu().numpy()
+            ref = oracle.splat_image(partial, radius, size, c)
+            assert img.shape == (size, size, 3)
+            np.testing.assert_allclose(img, ref, atol=2e-4)      # fp32 (u, v, rho) against fp64: pixels on a disc's rim
+            assert 0.002 < img.mean() < 0.9
+            if c is None:
+                assert np.array_equal(img[..., 0], img[..., 1]) and np.array_equal(img[..., 0], img[..., 2])
+    # a cloud the camera does not see, and an empty one
+    far = torch.tensor([[0.0, 0.0, 4.0], [0.0, 0.0, -2.5]]).cuda()
+    assert float(gp["POSE"].splat_image(far, 0.05, 32).abs().max()) == 0.0
+    assert float(gp["POSE"].splat_image(torch.zeros(0, 3).cuda(), 0.05, 32).abs().max()) == 0.0
 
 
 def test_full_loss_and_gradient_vs_oracle(gp, oracle):
     """compute_loss_function as a whole (mask + 3 cd + ortho): loss terms and the 10-vector
-    gradient against the oracle (whose gradient is pinned to torch autograd)."""
+    gradient against the oracle (whose loss is pinned to the reference's own code and whose gradient
+    to torch autograd), white clouds and coloured clouds with a dark third."""
     torch = gp["torch"]
     complete, partial, _ = _shape(3, 3000)
     params = np.array([0.9, 0.1, -0.3, 0.05, 1.1, 0.2, 0.02, -0.01, 0.03, math.log(0.8)], np.float32)
     c = complete.astype(np.float64).mean(0).astype(np.float32)
     C, P, PR, CT = (torch.from_numpy(x).cuda() for x in (complete, partial, params, c))
-    for radius, size in ((0.02, 224), (0.03, 128)):
-        loss, grad = gp["POSE"].pose_loss_grad(C, CT, PR, P, radius, size)
+    rng = np.random.default_rng(8)
+    ccol, pcol = _colours(rng, len(complete), 0.33), _colours(rng, len(partial))
+    seen = []
+    for radius, size, vc, pc in ((0.02, 224, None, None), (0.03, 128, None, None), (0.02, 224, ccol, pcol), (0.03, 96, ccol, pcol)):
+        loss, grad = gp["POSE"].pose_loss_grad(C, CT, PR, P, radius, size, vert_col=None if vc is None else torch.from_numpy(vc).cuda(),
+                                               partial_col=None if pc is None else torch.from_numpy(pc).cuda())
         opts = oracle.pose_transform(complete, c, params)
         d1, d2, i1, i2 = oracle.chamfer_forward(opts[None], partial[None], 1)
-        ref = oracle.splat_image(partial, radius, size)
-        lo, g = oracle.pose_full_loss_grad(complete, c, params, partial, d1[0], i1[0], d2[0], i2[0], radius, size, ref)
+        ref = oracle.splat_image(partial, radius, size, pc)
+        lo, g = oracle.pose_full_loss_grad(complete, c, params, partial, d1[0], i1[0], d2[0], i2[0], radius, size, ref, vert_col=vc)
         np.testing.assert_allclose(loss.cpu().numpy(), lo, rtol=2e-4, atol=1e-5)
         lo_cd, g_cd = oracle.pose_loss_grad(complete, c, params, partial, d1[0], i1[0], d2[0], i2[0])
         gg, go = grad.cpu().numpy().astype(np.float64), g.astype(np.float64)
@@ -164,29 +187,62 @@ def test_full_loss_and_gradient_vs_oracle(gp, oracle):
         assert np.abs(go - g_cd).max() > 0.05 * np.abs(go).max()
         for sl in (slice(0, 6), slice(6, 9), slice(9, 10)):
             assert np.abs(gg[sl] - go[sl]).max() <= 2e-3 * np.abs(go[sl]).max(), (sl, gg[sl], go[sl])
+        seen.append((float(loss[3]), gg))
+    # colours change the loss and its gradient (same geometry, same radius and size: cases 0 and 2)
+    assert abs(seen[0][0] - seen[2][0]) > 1e-2 and np.abs(seen[0][1] - seen[2][1]).max() > 1e-2 * np.abs(seen[0][1]).max()
+
+
+def test_dark_points_drop_out_of_the_mask(gp, oracle):
+    """the reference's soft mask is a LUMINANCE threshold (diff_obj_pose.py:273-277), so
+    points darker than 0.1 leave it.  Same posed geometry, once bright, once with its x > 0 half at 5 %
+    brightness: the loss against a bright reference must rise, and exactly as the oracle says."""
+    torch = gp["torch"]
+    complete, partial, _ = _shape(6, 3000)
+    params = np.array([1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, math.log(0.9)], np.float32)
+    c = complete.astype(np.float64).mean(0).astype(np.float32)
+    bright = np.full((len(complete), 3), 0.9, np.float32)
+    half = bright.copy()
+    half[complete[:, 0] > c[0]] = 0.045
+    pcol = np.full((len(partial), 3), 0.9, np.float32)
+    C, P, PR, CT = (torch.from_numpy(x).cuda() for x in (complete, partial, params, c))
+    out = {}
+    for name, col in (("bright", bright), ("half", half)):
+        loss, grad = gp["POSE"].pose_loss_grad(C, CT, PR, P, 0.02, 224, vert_col=torch.from_numpy(col).cuda(),
+                                               partial_col=torch.from_numpy(pcol).cuda())
+        opts = oracle.pose_transform(complete, c, params)
+        d1, d2, i1, i2 = oracle.chamfer_forward(opts[None], partial[None], 1)
+        lo, g = oracle.pose_full_loss_grad(complete, c, params, partial, d1[0], i1[0], d2[0], i2[0], 0.02, 224,
+                                           oracle.splat_image(partial, 0.02, 224, pcol), vert_col=col)
+        np.testing.assert_allclose(loss.cpu().numpy(), lo, rtol=2e-4, atol=1e-5)
+        out[name] = float(loss[3])
+    assert out["half"] > out["bright"] + 0.2, out
 
 
 def test_pose_loop_full_objective(gp, oracle):
     """object_pose_optimization with radius / render_size live (the reference's call: radius 0.02,
-    224 x 224): the early loss history tracks the oracle's loop, the same start wins, and the
-    result differs from the Chamfer-only run."""
+    224 x 224), white and coloured clouds: the early loss history tracks the oracle's loop, the same start
+    wins, and the result differs from the Chamfer-only run."""
     torch = gp["torch"]
     complete, partial, Rt = _shape(9, 1200)
     C, P = torch.from_numpy(complete).cuda(), torch.from_numpy(partial).cuda()
-    T, hist, bp = gp["POSE"].object_pose_optimization(C, P, radius=0.02, lr=0.01, iters=60, render_size=224,
-                                                      return_history=True)
-    oT, ohist, obp = oracle.pose_optimize(complete, partial, lr=0.01, iters=60, starts=4, radius=0.02, size=224)
-    assert hist.shape == (4, 61) and np.isfinite(hist).all()
-    np.testing.assert_allclose(hist[:, :10], ohist[:, :10], rtol=5e-3)
-    best = int(np.argmin(ohist.min(1)))
-    assert int(np.argmin(hist.min(1))) == best
-    # the winning start ends where the oracle's does; the losing starts (rotated by 90 / 180 / 270
-    # degrees) wander: the loss jumps by 100 / P whenever a pixel's soft mask saturates (fp32
-    # sigmoid + BCE clamp, as in the reference), so late trajectories are not comparable
-    np.testing.assert_allclose(hist.min(1)[best], ohist.min(1)[best], rtol=0.02)
+    rng = np.random.default_rng(12)
+    for ccol, pcol in ((None, None), (_colours(rng, len(complete), 0.25), _colours(rng, len(partial)))):
+        kw = {} if ccol is None else dict(complete_col=torch.from_numpy(ccol).cuda(), partial_col=torch.from_numpy(pcol).cuda())
+        T, hist, bp = gp["POSE"].object_pose_optimization(C, P, radius=0.02, lr=0.01, iters=60, render_size=224,
+                                                          return_history=True, **kw)
+        oT, ohist, obp = oracle.pose_optimize(complete, partial, lr=0.01, iters=60, starts=4, radius=0.02, size=224,
+                                              complete_col=ccol, partial_col=pcol)
+        assert hist.shape == (4, 61) and np.isfinite(hist).all()
+        np.testing.assert_allclose(hist[:, :10], ohist[:, :10], rtol=5e-3)
+        best = int(np.argmin(ohist.min(1)))
+        assert int(np.argmin(hist.min(1))) == best
+        # the winning start ends where the oracle's does; the losing starts (rotated by 90 / 180 / 270
+        # degrees) wander: the loss jumps by 100 / P whenever a pixel's soft mask saturates (fp32
+        # sigmoid + BCE clamp, as in the reference), so late trajectories are not comparable
+        np.testing.assert_allclose(hist.min(1)[best], ohist.min(1)[best], rtol=0.02)
+        assert T[3].tolist() == [0, 0, 0, 1]
     Tc, hc, _ = gp["POSE"].object_pose_optimization(C, P, radius=0.02, lr=0.01, iters=60, return_history=True, cd_only=True)
     assert np.abs(hist[:, 0] - hc[:, 0]).min() > 1e-3        # the mask term is in the loss
-    assert T[3].tolist() == [0, 0, 0, 1]
 
 
 def test_pose_optimisation_loop(gp, oracle):

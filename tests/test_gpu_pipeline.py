@@ -189,3 +189,14 @@ def test_voxel_down_sample_fuzz(env, oracle):
         voxel = ext * 10.0 ** rng.uniform(-2.2, 0.3)
         got = env["R"].voxel_down_sample(torch.from_numpy(P).cuda(), voxel).cpu().numpy()
         np.testing.assert_array_equal(got, oracle.voxel_down_sample(P, voxel), err_msg="case %d n %d voxel %g" % (case, n, voxel))
+        if case % 2 == 0:         # coloured clouds (load_xyz / glb2point): the colours are averaged per voxel like the points
+            col = rng.random((n, 3)).astype(np.float32)
+            gx, gc = env["R"].voxel_down_sample(torch.from_numpy(P).cuda(), voxel, colors=torch.from_numpy(col).cuda())
+            ox, oc = oracle.voxel_down_sample(P, voxel, colors=col)
+            np.testing.assert_array_equal(gx.cpu().numpy(), ox, err_msg="case %d" % case)
+            np.testing.assert_array_equal(gc.cpu().numpy(), oc, err_msg="case %d colours" % case)
+    # the voxel size travels as a double (open3d's 0.03, not 0.03f): a point a hair inside a cell face of the
+    # double grid stays there
+    P = np.array([[0.0, 0.0, 0.0], [0.045 * (1 - 2e-8), 0.0, 0.0], [0.1, 0.1, 0.1]], np.float32)
+    got = env["R"].voxel_down_sample(torch.from_numpy(P).cuda(), 0.03).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.voxel_down_sample(P, 0.03))

@@ -1,0 +1,96 @@
+"""Stage-2 entry points keep the reference's call shapes, so that main.py / ScaleAdapter.py /
+reg_xyz.py call sites run unchanged (north_star).  CPU part: signatures, the
+file layer (PLY colours, 'obj' colour source, missing-input errors).  The values behind the file
+forms are GPU work: tests/test_gpu_stage2_files.py."""
+import inspect
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import write_glb
+
+
+def _names(fn):
+    return [p for p in inspect.signature(fn).parameters if p != "self"]
+
+
+def test_signatures_match_the_reference():
+    from genpc_amd.ScaleAdapter import ScaleAdapter
+    from genpc_amd import reg_xyz
+    from genpc_amd.optim_registration import diff_obj_pose as P
+    from genpc_amd.utils import dataUtils as D, mesh_io as M
+    # ScaleAdapter.py:38,46,70,74,78
+    assert _names(ScaleAdapter.remove_bg) == ["flag", "img_resource"]
+    assert _names(ScaleAdapter.colorPoint)[:5] == ["flag", "xyz", "gt", "rgb", "img_resource"]
+    assert _names(ScaleAdapter.img2shape) == ["flag"]
+    assert _names(ScaleAdapter.scaleReg)[:1] == ["flag"]
+    assert _names(ScaleAdapter.scaleAdapter) == ["xyz", "flag", "rgb"]
+    assert inspect.signature(ScaleAdapter.scaleAdapter).parameters["rgb"].default is None
+    # reg_xyz.py:99
+    sig = inspect.signature(reg_xyz.reg)
+    assert _names(reg_xyz.reg)[:5] == ["cfg", "flag", "cd_inv_weight", "diff_init", "reg_fine_xyz"]
+    assert (sig.parameters["cd_inv_weight"].default, sig.parameters["diff_init"].default,
+            sig.parameters["reg_fine_xyz"].default) == (0.5, True, False)
+    # diff_obj_pose.py:496
+    sig = inspect.signature(P.object_pose_optimization)
+    assert _names(P.object_pose_optimization)[:10] == ["glb_path", "point_path", "radius", "lr", "iters", "render_size",
+                                                       "vis", "save_path", "device", "cam_bias_num"]
+    assert [sig.parameters[k].default for k in ("radius", "lr", "iters", "render_size", "cam_bias_num")] == [0.005, 0.005, 300, 224, 4]
+    # diff_obj_pose.py:136, utils/dataUtils.py:174,217
+    assert _names(P.load_point_cloud) == ["point_path", "device", "radius", "num_points"]
+    assert _names(D.load_xyz)[:2] == ["path", "down_sample"]
+    assert _names(M.glb2point)[:3] == ["glb_path", "down_sample", "num_points"]
+    assert inspect.signature(M.glb2point).parameters["num_points"].default == 16384
+
+
+def test_load_xyz_colours_like_the_reference(tmp_path):
+    """utils/dataUtils.py:174-189: colours of the file when it has valid ones; position-derived
+    colours for a colourless PLY and for all-zero colours; float32 outputs."""
+    from genpc_amd.utils import dataUtils as D
+    rng = np.random.default_rng(0)
+    xyz = rng.random((200, 3)) * [1.0, 2.0, 0.5] - 0.3
+    rgb = rng.integers(1, 255, (200, 3)) / 255.0
+    p = str(tmp_path / "c.ply")
+    D.save_ply_xyzrgb(xyz, rgb, p)
+    pts, col = D.load_xyz(p)
+    assert pts.dtype == np.float32 and col.dtype == np.float32
+    np.testing.assert_allclose(pts, xyz.astype(np.float32))
+    np.testing.assert_allclose(col, rgb, atol=0.5 / 255)
+    for colours in (None, np.zeros((200, 3))):
+        D.save_ply_xyzrgb(xyz, colours, p)
+        pts, col = D.load_xyz(p)
+        want = (pts - pts.min(0)) / (pts.max(0) - pts.min(0) + 1e-8)
+        np.testing.assert_array_equal(col, np.clip(want, 0, 1))
+        assert col.max() > 0.99 and col.min() == 0.0
+
+
+def test_color_point_obj_source_and_missing_inputs(tmp_path):
+    """ScaleAdapter.colorPoint(flag, xyz, gt, rgb, 'obj') writes the cloud's own colours (:49-51, no GPU
+    work); reg(cfg, flag) raises FileNotFoundError for a missing color_point.ply / GLB like the
+    reference (:103-108); the generator stages ask for their stock modules."""
+    from genpc_amd.ScaleAdapter import ScaleAdapter
+    from genpc_amd import reg_xyz
+    from genpc_amd.utils import dataUtils as D
+    flag = "00001"
+    os.makedirs(tmp_path / flag)
+    cfg = SimpleNamespace(output_path=str(tmp_path), device="cpu", generative_model="trellis", dataset="redwood")
+    rng = np.random.default_rng(1)
+    xyz = torch.from_numpy(rng.random((300, 3)).astype(np.float32))
+    rgb = torch.from_numpy((rng.integers(0, 256, (300, 3)) / 255.0).astype(np.float32))
+    np.save(tmp_path / flag / "point_uv.npy", rng.random((300, 2)).astype(np.float32))
+    sa = ScaleAdapter(cfg)
+    sa.colorPoint(flag, xyz, xyz, rgb, img_resource="obj")
+    x2, c2 = D.read_ply(str(tmp_path / flag / "color_point.ply"))
+    np.testing.assert_allclose(x2, xyz.numpy().astype(np.float64))
+    np.testing.assert_allclose(c2, rgb.numpy(), atol=1e-6)
+    with pytest.raises(FileNotFoundError):                       # the GLB is missing
+        reg_xyz.reg(cfg, flag, cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=True)
+    os.remove(tmp_path / flag / "color_point.ply")
+    write_glb(str(tmp_path / flag / (flag + "_trellis.glb")), np.eye(3), [[0, 1, 2]])
+    with pytest.raises(FileNotFoundError):                       # now the PLY is
+        sa.scaleReg(flag)
+    with pytest.raises(RuntimeError, match="stock module"):
+        sa.scaleAdapter(xyz, flag, rgb)
