@@ -74,21 +74,30 @@ def time_events(fn, reps, stream):
     return e0.elapsed_time(e1) / reps
 
 
-def pmc_traffic(n):
-    """HBM bytes per launch of nn_forward_kernel from the committed rocprofv3 PMC
-    passes (profiles/*_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate runs,
-    FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM).  None when no profile of
-    this size is committed."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
-        try:
-            d = json.load(open(f))
-        except Exception:
-            continue
-        if d.get("kernel") in ("nn_forward_kernel", "nn_f16_kernel") and d.get("points") == n and d.get("batch") == 1:
-            best = d.get("hbm_bytes_per_launch")
-    return best
+ROUND_TAG = "r03"          # the profiles/ tag this bench's PMC-derived numbers must come from
+
+
+def pmc_traffic(n, kernel_prefix="nn_f16_kernel"):
+    """HBM bytes per launch of the dominant kernel from THIS round's committed rocprofv3 PMC passes
+    (profiles/<ROUND_TAG>_chamfer_B1_<n>.json, written by tools/collect_profiles.sh +
+    tools/summarize_profiles.py: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE
+    doubled per MI355X_MICROARCH.md section HBM).  Returns (bytes or None, source): a missing or
+    older-tagged profile is reported on stderr and yields None -- never a stale number."""
+    f = os.path.join(ROOT, "profiles", "%s_chamfer_B1_%d.json" % (ROUND_TAG, n))
+    try:
+        d = json.load(open(f))
+    except Exception as e:
+        print("bench.py: roofline.traffic unavailable: %s (%s); run tools/collect_profiles.sh %s on the GPU box"
+              % (os.path.relpath(f, ROOT), type(e).__name__, ROUND_TAG), file=sys.stderr)
+        return None, None
+    if d.get("tag") != ROUND_TAG:
+        print("bench.py: %s carries tag %r, not %r: refusing a stale traffic figure" % (f, d.get("tag"), ROUND_TAG), file=sys.stderr)
+        return None, None
+    for name, k in d.get("kernels", {}).items():
+        if name.startswith(kernel_prefix) and k.get("hbm_bytes_per_launch") is not None:
+            return k["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    print("bench.py: no %s* kernel with PMC counters in %s" % (kernel_prefix, f), file=sys.stderr)
+    return None, None
 
 
 def extras(A, B, n, dev, stream):
@@ -134,7 +143,6 @@ def extras(A, B, n, dev, stream):
     t = time_events(f, 10, stream)
     g13 = 13 * 2.0 * n * n / (t * 1e-3) / 1e9
     extra["chamfer_fwd_B13_n%d_gpair_s" % n] = round(g13, 2)
-    extra["chamfer_fwd_B13_n%d_frac_of_fp32_peak" % n] = round(FLOP_PER_PAIR * g13 * 1e9 / 1e12 / PEAK_FP32_TFLOPS, 4)
     em = emdModule()
     X = A + 0.5
     Y = B + 0.5
@@ -230,7 +238,15 @@ def extras(A, B, n, dev, stream):
     t0 = time.perf_counter()
     fps_sampling(big, 16384)
     torch.cuda.synchronize()
-    extra["fps_4x165546_to_16384_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    t_fps = time.perf_counter() - t0
+    extra["fps_4x165546_to_16384_ms"] = round(t_fps * 1e3, 2)
+    # roofline-shaped: FPS is k SEQUENTIAL steps (each needs the previous winner); the floor of a step is one
+    # cross-workgroup hand-off = an L2 round trip pair (~1 us measured for store -> visible -> load on this chip,
+    # tools/ubench_dispatch.hip) -- not bandwidth: a step touches 165546 x 16 B of REGISTER-resident state
+    extra["fps_4x165546_to_16384_roofline"] = {
+        "bound": "latency (sequential steps)", "unit": "us/step", "steps": 16384, "clouds_side_by_side": 4,
+        "achieved": round(t_fps * 1e6 / 16384, 3), "floor": 1.0, "frac": round(1.0 / (t_fps * 1e6 / 16384), 4),
+        "point_updates_per_s": round(4 * 165546 * 16384 / t_fps / 1e9, 1), "point_updates_unit": "G/s"}
     # HBM-bound streaming kernel: getUvs for the reference's 1024 cameras x 71372 points
     cfg = SimpleNamespace(device=str(dev), fovy=49.1, res=256, padding=0.15, rescale=True, point_size=1,
                           mask_pixel_rate=3, view_num=1024, distance=1.6)
@@ -238,11 +254,14 @@ def extras(A, B, n, dev, stream):
     pts = (torch.rand(71372, 3, device=dev, generator=gen) - 0.5) * 0.8
     dp.getUvs(dp.cameras, pts, want_transformed=False)
     t = time_events(lambda: dp.getUvs(dp.cameras, pts, want_transformed=False), 5, stream)
-    alg = 1024 * 71372 * (12 + 12)             # per (camera, point): read xyz, write uv + depth
+    # algorithmic bytes: the cloud is read once (12 B per POINT, not per (camera, point)), uv + depth are written
+    # per (camera, point): 12 N + 12 C N
+    alg = 12 * 71372 + 1024 * 71372 * 12
     extra["get_uvs_1024x71372_roofline"] = {"bound": "hbm", "achieved": round(alg / (t * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                                             "unit": "GB/s", "frac": round(alg / (t * 1e-3) / 8e12, 4),
                                             "frac_of_6.29TBs_achievable": round(alg / (t * 1e-3) / 6.29e12, 4),
-                                            "ms_per_launch_pair": round(t, 4), "algorithmic_bytes": alg}
+                                            "ms_per_call": round(t, 4), "algorithmic_bytes": alg,
+                                            "bytes_model": "12 N read + 12 C N written (uv 8 + depth 4)"}
     # f3: hidden-point removal (Katz' operator, exact) at viewpoint_select's shape -- the reference's 1024
     # viewpoints x 10000 FPS-ordered points, removal_radius 10000 -- and at getDepth's (2 viewpoints x the
     # whole scan); next to it qhull (what open3d calls) on one host core for ONE viewpoint
@@ -260,8 +279,18 @@ def extras(A, B, n, dev, stream):
         t0 = time.perf_counter()
         _, cnt_h, second_h = dph.hidden_point_removal(p_, e_, 10000.0)
         torch.cuda.synchronize()
-        extra[name + "_R10000_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        t_h = time.perf_counter() - t0
+        extra[name + "_R10000_ms"] = round(t_h * 1e3, 2)
         extra[name + "_visible_fraction"] = round(float(cnt_h.float().mean()) / p_.shape[0], 4)
+        # roofline-shaped: the brute-force operator tests every (view, point, other point) triple once (one fp64
+        # dot product + compare = 6 flop); the culled kernels are priced against that algorithmic count
+        v_, n_ = (len(e_), p_.shape[0])
+        tests = float(v_) * n_ * (n_ - 1)
+        extra[name + "_roofline"] = {"bound": "valu-fp64", "unit": "Gtest/s (algorithmic candidate tests: views x n x (n-1))",
+                                     "achieved": round(tests / t_h / 1e9, 1), "peak": round(78.6e12 / 6 / 1e9, 1),
+                                     "frac": round(tests / t_h / (78.6e12 / 6), 4),
+                                     "note": "peak = 78.6 TFLOP/s fp64 vector / 6 flop per test; culling skips most tests, "
+                                             "so frac is an equivalent rate, not a utilisation"}
     from oracle import hpr as ohpr
     t0 = time.perf_counter()
     ref_cnt = ohpr.visible_counts(sub.cpu().numpy(), np.asarray(dph.viewpoints)[:4], 10000.0)

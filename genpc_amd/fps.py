@@ -32,6 +32,36 @@ def fps_sampling(points, k):
     return out[0] if single else out
 
 
+def fps_sampling_multi(clouds, ks):
+    """Several clouds of different sizes / sample counts in ONE pass (FPS is latency-bound: k sequential
+    steps per cloud, so independent clouds side by side cost the longest one, not the sum).
+    clouds: list of [N_j,3] GPU tensors, ks: list of ints -> list of int32 index tensors [k_j]."""
+    import ctypes
+    pts = [c.contiguous().float() for c in clouds]
+    _lib.check_tensors(tuple(("clouds[%d]" % j, p) for j, p in enumerate(pts)))
+    c = len(pts)
+    if c == 0:
+        return []
+    if len(ks) != c or any(p.dim() != 2 or p.shape[1] != 3 for p in pts):
+        raise ValueError("fps_sampling_multi: need one k per [N,3] cloud")
+    dev = pts[0].device
+    outs = [torch.empty(int(k), device=dev, dtype=torch.int32) for k in ks]
+    n_arr = (ctypes.c_int * c)(*[int(p.shape[0]) for p in pts])
+    k_arr = (ctypes.c_int * c)(*[int(k) for k in ks])
+    x_arr = (ctypes.c_void_p * c)(*[p.data_ptr() for p in pts])
+    o_arr = (ctypes.c_void_p * c)(*[o.data_ptr() for o in outs])
+    rc = _lib.on_device_of(pts[0], _L.genpc_fps_multi, c, ctypes.addressof(n_arr), ctypes.addressof(k_arr),
+                           ctypes.addressof(x_arr), ctypes.addressof(o_arr))
+    if rc == -1:
+        raise ValueError("fps_sampling_multi: need 0 < k <= N <= 262144 for every cloud")
+    if rc != 1:
+        raise RuntimeError("genpc_fps_multi failed: " + _lib.last_error())
+    if bool(torch.stack([o[0] for o in outs]).ne(0).any()):
+        raise RuntimeError("genpc_fps: inter-workgroup hand-off timed out (workgroups of a cloud were not "
+                           "co-resident); no samples returned")
+    return outs
+
+
 def fps_subsample(points, k):
     """The helper metric.py calls but never defines: [B,N,3] -> [B,k,3]."""
     idx = fps_sampling(points, k).long()

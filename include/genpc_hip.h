@@ -314,6 +314,12 @@ int genpc_scale_search_scores(int k, int ns, const float *source, int nt,
  * unless 0 < k <= n <= 262144.                                                  */
 int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, void *stream);
 
+/* The same for C clouds of DIFFERENT sizes in one pass (the metric's two subsamplings and the fused
+ * cloud's run side by side: a step costs its latency, not its work): host arrays n[C], k[C],
+ * xyz[C] (device pointers to [n_j,3]), out_idx[C] (device pointers to [k_j]).                    */
+int genpc_fps_multi(int c, const int *n, const int *k, const float *const *xyz,
+                    int *const *out_idx, void *stream);
+
 /* Statistical outlier filter ------------------------------------------------ *
  * mean_out[N] = mean Euclidean distance of every point to its k nearest points of
  * the same cloud, itself included (the per-point statistic of open3d's

@@ -90,3 +90,36 @@ def test_fps_fuzz(fg, oracle):
             fg["lib"].lib.genpc_set_arith(prev)
         for i in range(c):
             np.testing.assert_array_equal(idx[i], oracle.fps(x[i], k, mode), err_msg="case %d n %d k %d" % (case, n, k))
+
+
+def test_fps_multi_ragged(fg, oracle):
+    """genpc_fps_multi: clouds of different sizes and sample counts in one launch (1 .. 64 workgroups per
+    cloud, k == n included) give the oracle's sequences; same result as one call per cloud."""
+    torch = fg["torch"]
+    from genpc_amd.fps import fps_sampling_multi
+    rng = np.random.default_rng(77)
+    shapes = [(172000, 1500), (16384, 16384), (19000, 3000), (300, 300), (2049, 100), (1, 1)]
+    clouds = [(rng.random((n, 3), dtype=np.float32) - 0.5).astype(np.float32) for n, _ in shapes]
+    clouds[2][100:200] = clouds[2][0:100]                    # duplicates: ties
+    got = fps_sampling_multi([torch.from_numpy(c).cuda() for c in clouds], [k for _, k in shapes])
+    for (n, k), c, g in zip(shapes, clouds, got):
+        np.testing.assert_array_equal(g.cpu().numpy(), oracle.fps(c, k, 1), err_msg="n %d k %d" % (n, k))
+        np.testing.assert_array_equal(fg["fps"](torch.from_numpy(c).cuda(), k).cpu().numpy(), g.cpu().numpy())
+    assert sorted(got[1].cpu().numpy().tolist()) == list(range(16384))      # k == n: a permutation
+
+
+def test_fps_step_time(fg):
+    """Recorded, not asserted tightly: microseconds per sequential step (round 2: 2.8 at 4 x 165546)."""
+    torch = fg["torch"]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    for c, n, k in ((4, 165546, 16384), (1, 172000, 20000), (1, 16384, 16384), (1, 8192, 8192)):
+        x = torch.rand(c, n, 3, device="cuda", generator=g)
+        fg["fps"](x, 64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fg["fps"](x, k)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) * 1e6 / k
+        print("fps %d x %d -> %d: %.3f us/step" % (c, n, k, us))
+        assert us < 5.0
