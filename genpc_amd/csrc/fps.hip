@@ -43,6 +43,7 @@ struct FpsJobs {
     int *out[kFMaxJobs];
     int n[kFMaxJobs], k[kFMaxJobs], W[kFMaxJobs];
     int slot0[kFMaxJobs];        // first slot of the job in the slot array (slots are per (job, parity, workgroup))
+    int stat0;                   // index of the launch's first cloud in the call (statistics)
 };
 
 template <int FMA>
@@ -126,162 +127,313 @@ __device__ __forceinline__ void store_sc_b64(void *p, uint2 v)
     const u32x2 w = {v.x, v.y};
     asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
 }
-__device__ __forceinline__ void load_slot(const void *pa, const void *pb, uint4 &a, uint2 &b)
-{
-    u32x4 wa;
-    u32x2 wb;
-    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\t"
-                 "global_load_dwordx2 %1, %3, off sc0 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(wa), "=&v"(wb)
-                 : "v"(pa), "v"(pb)
-                 : "memory");
-    a = make_uint4(wa.x, wa.y, wa.z, wa.w);
-    b = make_uint2(wb.x, wb.y);
-}
 
-struct FpsSlot {          // 32 bytes per (job, parity, workgroup)
+constexpr int kFT = 4;          // candidates a workgroup publishes per exchange
+constexpr int kFBatch = 64;     // most samples drawn from one exchange
+constexpr int kFBlock = kFThreads + kWave;     // four waves own the points, a fifth coordinates
+
+struct FpsCand {          // 32 bytes
     uint4 a;              // dist bits, gen << 20 | idx, x bits, y bits
     uint2 b;              // z bits, gen
     uint2 pad;
 };
+struct FpsSlot {          // one 128-byte line per (job, parity, workgroup)
+    FpsCand c[kFT];
+};
+
+// the eight loads of one slot in flight together, one wait
+__device__ __forceinline__ void load_slot(const FpsSlot *p, u32x4 (&a)[kFT], u32x2 (&b)[kFT])
+{
+    static_assert(kFT == 4 && sizeof(FpsCand) == 32, "offsets below");
+    asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+                 "global_load_dwordx2 %4, %8, off offset:16 sc0 sc1\n\t"
+                 "global_load_dwordx4 %1, %8, off offset:32 sc0 sc1\n\t"
+                 "global_load_dwordx2 %5, %8, off offset:48 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:64 sc0 sc1\n\t"
+                 "global_load_dwordx2 %6, %8, off offset:80 sc0 sc1\n\t"
+                 "global_load_dwordx4 %3, %8, off offset:96 sc0 sc1\n\t"
+                 "global_load_dwordx2 %7, %8, off offset:112 sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                 : "v"(p)
+                 : "memory");
+}
+
+// One exchange among a cloud's workgroups yields SEVERAL samples, exactly:
+//   every workgroup lists its kFT best points in the order (distance desc, index asc) with their coordinates;
+//   every workgroup reads all lists and replays the sequential algorithm on the listed points alone -- pick the
+//   best, lower the listed distances by the pick, pick again ...  A pick is the true next sample as long as its
+//   key is not below tau = the best of the workgroups' LAST listed keys (as listed): every unlisted point of a
+//   workgroup ranks below that workgroup's last listed point, and distances only fall.  The first pick of an
+//   exchange always qualifies, so a round never stalls; with points dealt to workgroups round-robin the top of
+//   the global order is spread over many lists and a round draws tens of samples (measured: 30 at 172000
+//   points, 13 at 16384, 8.5 at 8192).
+// Inside a workgroup: waves 0..3 own the points (registers); wave 4, the coordinator, owns none.  It merges the
+// waves' lists, publishes, polls, replays -- and hands every pick to the workers through LDS (s_piv + a progress
+// word) the moment it is made, so the workers lower their running minima WHILE the replay goes on (the replay is a
+// chain of dependent cross-lane steps, ~400 cycles per pick, and would otherwise leave three SIMDs idle).  One
+// barrier per round: workers' lists ready -> coordinator.
+constexpr unsigned kProgDone = 0x8000u, kProgFinal = 0x4000u, kProgAbort = 0x2000u, kProgCount = 0x0fffu;
+
+__device__ __forceinline__ void prog_store(unsigned *p, unsigned v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned prog_load(unsigned *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    v = max(v, dpp_i32<0x128>(v));
+    v = max(v, dpp_i32<0x124>(v));
+    v = max(v, dpp_i32<0x122>(v));
+    v = max(v, dpp_i32<0x121>(v));
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// The lane with the wave's best key.  Distances are >= 0 or one of the negative sentinels (-1 padding, -2 dead),
+// never NaN: the signed-integer order of their bit patterns ranks every live value above every sentinel and agrees
+// with the float order among live values, so the maximum is ONE integer reduction (fmaxf would canonicalise every
+// operand first).  Ties (equal distances) take the index reduction.
+__device__ __forceinline__ int wave_argbest(float v, int idx, float &m)
+{
+    const int vb = __float_as_int(v);
+    const int mb = wave_max_i32(vb);
+    m = __int_as_float(mb);
+    const unsigned long long mask = __ballot(vb == mb);
+    if (__popcll(mask) == 1) return __ffsll((long long)mask) - 1;
+    const int cand = vb == mb ? idx : 0x7fffffff;
+    const int best = wave_min_i32(cand);
+    return __ffsll((long long)__ballot(cand == best)) - 1;
+}
 
 template <int FMA, int R>
-__global__ __launch_bounds__(kFThreads) void fps_kernel(FpsJobs jobs, FpsSlot *slots, int *__restrict__ err)
+__global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slots, int *__restrict__ err)
 {
-    __shared__ float s_w[kFWaves][5];      // per wave: dist, idx (bits), x, y, z of its best
-    __shared__ float s_piv[4];             // pivot x, y, z and index (bits; -1: abort)
+    __shared__ float s_c[kFWaves][kFT][5];     // per worker wave: dist, idx (bits), x, y, z of its kFT best
+    __shared__ float s_piv[kFBatch][4];        // the round's pivots: x, y, z, idx (bits)
+    __shared__ unsigned s_prog;                // round << 16 | flags | pivots of that round published so far
     const int job = blockIdx.y, wg = blockIdx.x, t = threadIdx.x;
     const int W = jobs.W[job];
     if (wg >= W) return;
     const int n = jobs.n[job], k = jobs.k[job];
     const int lane = t & (kWave - 1), wave = t >> 6;
     const float *__restrict__ X = jobs.xyz[job];
-    int *__restrict__ out = jobs.out[job];
-    FpsSlot *S = slots + jobs.slot0[job];
-    const int per = (n + W - 1) / W;
-    const int lo = wg * per;
-    const int hi = min(n, lo + per);
-    float px[R], py[R], pz[R], d[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int i = lo + t + r * kFThreads;
-        const bool ok = i < hi;
-        const int ii = ok ? i : (n - 1);
-        px[r] = X[(size_t)ii * 3 + 0];
-        py[r] = X[(size_t)ii * 3 + 1];
-        pz[r] = X[(size_t)ii * 3 + 2];
-        d[r] = ok ? __builtin_inff() : -1.0f;          // -1: never selected, never updated upward
-    }
-    float cx = X[0], cy = X[1], cz = X[2];
-    int cur = 0;
-    for (int s = 0; s < k; s++) {
-        if (wg == 0 && t == 0) out[s] = cur;
-        if (s == k - 1) break;                          // the last sample needs no successor
-        float bv = -1.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
-        int bi = 0x7fffffff;
+    if (t == 0) s_prog = 0xffff0000u;          // no round carries this tag
+    __syncthreads();
+
+    if (wave < kFWaves) {
+        // ------------------------------------------------------------------ workers
+        // points are dealt round-robin: point i belongs to workgroup i % W (a file's scan order would otherwise
+        // give every workgroup one compact patch, and a patch's best points fall together)
+        float px[R], py[R], pz[R], d[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const float dd = sqdist_f<FMA>(px[r] - cx, py[r] - cy, pz[r] - cz);
-            const float v = d[r] < dd ? d[r] : dd;      // padding slots stay at -1
-            d[r] = v;
-            const bool gt = v > bv;                     // ascending index within a thread: first max
-            bv = gt ? v : bv;
-            bi = gt ? lo + t + r * kFThreads : bi;
-            bx = gt ? px[r] : bx;
-            by = gt ? py[r] : by;
-            bz = gt ? pz[r] : bz;
+            const long long i = ((long long)r * kFThreads + t) * W + wg;
+            const bool ok = i < n;
+            const size_t ii = ok ? (size_t)i : (size_t)(n - 1);
+            px[r] = X[ii * 3 + 0];
+            py[r] = X[ii * 3 + 1];
+            pz[r] = X[ii * 3 + 2];
+            d[r] = ok ? __builtin_inff() : -1.0f;          // -1: never selected, never updated upward
         }
-        // wave's best -> LDS
-        {
-            const float m = wave_max_f32(bv);
-            const int src = wave_best_lane(bv, bi, m);
-            if (lane == 0) {
-                s_w[wave][0] = m;
-                s_w[wave][1] = __int_as_float(__builtin_amdgcn_readlane(bi, src));
-                s_w[wave][2] = lane_f32(bx, src);
-                s_w[wave][3] = lane_f32(by, src);
-                s_w[wave][4] = lane_f32(bz, src);
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            // workgroup's best (every lane computes it: four LDS broadcast reads)
-            float m = s_w[0][0];
-            int mi = __float_as_int(s_w[0][1]), mw = 0;
+        for (unsigned round = 0;; round++) {
+            // ---- lower the running minima by the round's pivots as the coordinator hands them over
+            unsigned applied = 0, pr;
+            for (;;) {
+                pr = prog_load(&s_prog);
+                if ((pr >> 16) != (round & 0xffffu)) { __builtin_amdgcn_s_sleep(1); continue; }
+                const unsigned avail = pr & kProgCount;
+                for (; applied < avail; applied++) {
+                    const float cx = s_piv[applied][0], cy = s_piv[applied][1], cz = s_piv[applied][2];
 #pragma unroll
-            for (int w = 1; w < kFWaves; w++) {
-                const float v = s_w[w][0];
-                const int i = __float_as_int(s_w[w][1]);
-                const bool better = v > m || (v == m && i < mi);
-                m = better ? v : m;
-                mi = better ? i : mi;
-                mw = better ? w : mw;
+                    for (int r = 0; r < R; r++) {
+                        const float dd = sqdist_f<FMA>(px[r] - cx, py[r] - cy, pz[r] - cz);
+                        d[r] = d[r] < dd ? d[r] : dd;       // padding slots stay at -1
+                    }
+                }
+                if (pr & kProgDone) break;
             }
-            float wx = s_w[mw][2], wy = s_w[mw][3], wz = s_w[mw][4];
-            bool timed_out = false;
-            if (W > 1) {
-                const unsigned gen = (unsigned)(s % 4095) + 1u;
-                FpsSlot *slot = S + (size_t)(s & 1) * W;
+            if (pr & (kProgFinal | kProgAbort)) break;
+            // ---- the wave's kFT best, best first
+            unsigned taken = 0;
+#pragma unroll
+            for (int c = 0; c < kFT; c++) {
+                float bv = -2.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
+                int br = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const bool gt = !((taken >> r) & 1u) && d[r] > bv;    // ascending index within a thread: first max
+                    bv = gt ? d[r] : bv;
+                    br = gt ? r : br;
+                    bx = gt ? px[r] : bx;
+                    by = gt ? py[r] : by;
+                    bz = gt ? pz[r] : bz;
+                }
+                const int bi = bv > -2.0f ? (int)((((long long)br * kFThreads + t) * W + wg)) : 0x7fffffff;
+                float mx;
+                const int src = wave_argbest(bv, bi, mx);
+                // (cross-lane reads in wave-uniform code: inside a lane-0 branch the compiler may copy a value with
+                // an exec-masked move, and v_readlane would then fetch another lane's stale register)
+                const float wi = __int_as_float(__builtin_amdgcn_readlane(bi, src));
+                const float w0 = lane_f32(bx, src), w1 = lane_f32(by, src), w2 = lane_f32(bz, src);
                 if (lane == 0) {
-                    // a workgroup with no live point (m = -1) publishes index 0xFFFFF: it never wins
-                    const unsigned pidx = m >= 0.0f ? (unsigned)mi : 0xFFFFFu;
-                    store_sc_b128(&slot[wg].a, make_uint4(__float_as_uint(m), (gen << 20) | pidx, __float_as_uint(wx), __float_as_uint(wy)));
-                    store_sc_b64(&slot[wg].b, make_uint2(__float_as_uint(wz), gen));
+                    s_c[wave][c][0] = mx;
+                    s_c[wave][c][1] = wi;
+                    s_c[wave][c][2] = w0;
+                    s_c[wave][c][3] = w1;
+                    s_c[wave][c][4] = w2;
                 }
-                // poll the W slots of this step (a lane per slot), bounded
-                uint4 a = make_uint4(0, 0, 0, 0);
-                uint2 b = make_uint2(0, 0);
-                int spins = 0;
-                for (;;) {
-                    bool ready = true;
-                    if (lane < W) {
-                        load_slot(&slot[lane].a, &slot[lane].b, a, b);
-                        ready = (a.y >> 20) == gen && b.y == gen;
-                    }
-                    if (__all(ready)) break;
-                    if (++spins > (1 << 21)) {
-                        if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        timed_out = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                const float v = lane < W ? __uint_as_float(a.x) : -2.0f;
-                const int vi = lane < W ? (int)(a.y & 0xFFFFFu) : 0x7fffffff;
-                m = wave_max_f32(v);
-                const int src = wave_best_lane(v, vi, m);
-                mi = __builtin_amdgcn_readlane(vi, src);
-                wx = lane_f32(__uint_as_float(a.z), src);
-                wy = lane_f32(__uint_as_float(a.w), src);
-                wz = lane_f32(__uint_as_float(b.x), src);
+                if (lane == src) taken |= 1u << br;
             }
+            __syncthreads();                   // lists ready -> coordinator
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- coordinator (wave 4)
+    int *__restrict__ out = jobs.out[job];
+    FpsSlot *S = slots + jobs.slot0[job];
+    int s = 1;                                 // samples drawn so far
+    if (lane == 0) {
+        s_piv[0][0] = X[0]; s_piv[0][1] = X[1]; s_piv[0][2] = X[2];
+        s_piv[0][3] = __int_as_float(0);
+        if (wg == 0) out[0] = 0;
+        prog_store(&s_prog, (0u << 16) | kProgDone | (k <= 1 ? kProgFinal : 0u) | 1u);
+    }
+    bool timed_out = false;
+    unsigned round = 0;
+    while (s < k) {
+        __syncthreads();                       // the workers' lists of this round
+        round++;
+        // ---- the workgroup's kFT best of the waves' lists (lanes 0..15 hold one entry each)
+        float ev = -2.0f, ex = 0.0f, ey = 0.0f, ez = 0.0f;
+        int ei = 0x7fffffff;
+        if (lane < kFWaves * kFT) {
+            const float *e = &s_c[lane / kFT][lane % kFT][0];
+            ev = e[0]; ei = __float_as_int(e[1]); ex = e[2]; ey = e[3]; ez = e[4];
+        }
+        float cd[kFT], cxs[kFT], cys[kFT], czs[kFT];
+        int ci[kFT];
+#pragma unroll
+        for (int c = 0; c < kFT; c++) {
+            float mx;
+            const int src = wave_argbest(ev, ei, mx);
+            cd[c] = mx;
+            ci[c] = __builtin_amdgcn_readlane(ei, src);
+            cxs[c] = lane_f32(ex, src); cys[c] = lane_f32(ey, src); czs[c] = lane_f32(ez, src);
+            if (lane == src) ev = -2.0f;
+        }
+        if (W > 1) {
+            const unsigned gen = (round % 4095u) + 1u;
+            FpsSlot *slot = S + (size_t)(round & 1u) * W;
+            if (lane < kFT) {
+                // lane c publishes candidate c; an entry without a live point (dist < 0) carries index 0xFFFFF
+                float pd = cd[0], pxx = cxs[0], pyy = cys[0], pzz = czs[0];
+                int pi = ci[0];
+#pragma unroll
+                for (int c = 1; c < kFT; c++)
+                    if (lane == c) { pd = cd[c]; pi = ci[c]; pxx = cxs[c]; pyy = cys[c]; pzz = czs[c]; }
+                const unsigned pidx = pd >= 0.0f ? (unsigned)pi : 0xFFFFFu;
+                store_sc_b128(&slot[wg].c[lane].a, make_uint4(__float_as_uint(pd), (gen << 20) | pidx, __float_as_uint(pxx), __float_as_uint(pyy)));
+                store_sc_b64(&slot[wg].c[lane].b, make_uint2(__float_as_uint(pzz), gen));
+            }
+            // every lane < W reads workgroup `lane`'s list, bounded
+            u32x4 a[kFT];
+            u32x2 b[kFT];
+#pragma unroll
+            for (int c = 0; c < kFT; c++) { a[c] = (u32x4){0, 0, 0, 0}; b[c] = (u32x2){0, 0}; }
+            int spins = 0;
+            for (;;) {
+                bool ready = true;
+                if (lane < W) {
+                    load_slot(&slot[lane], a, b);
+#pragma unroll
+                    for (int c = 0; c < kFT; c++) ready = ready && (a[c].y >> 20) == gen && b[c].y == gen;
+                }
+                if (__all(ready)) break;
+                if (++spins > (1 << 21)) {
+                    if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    timed_out = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (timed_out) break;
+#pragma unroll
+            for (int c = 0; c < kFT; c++) {
+                const bool live = lane < W && (a[c].y & 0xFFFFFu) != 0xFFFFFu;
+                cd[c] = live ? __uint_as_float(a[c].x) : -2.0f;
+                ci[c] = live ? (int)(a[c].y & 0xFFFFFu) : 0x7fffffff;
+                cxs[c] = __uint_as_float(a[c].z);
+                cys[c] = __uint_as_float(a[c].w);
+                czs[c] = __uint_as_float(b[c].x);
+            }
+        } else if (lane != 0) {
+#pragma unroll
+            for (int c = 0; c < kFT; c++) { cd[c] = -2.0f; ci[c] = 0x7fffffff; }
+        }
+        // ---- replay the sequential algorithm on the listed points (a lane per workgroup's list)
+        // tau: the best of the lists' last entries, as listed (a list that is not full bounds nothing)
+        float td;
+        const int ti = __builtin_amdgcn_readlane(ci[kFT - 1], wave_argbest(cd[kFT - 1], ci[kFT - 1], td));
+        int mm = 0;
+        for (;;) {
+            float ld = cd[0], lx = cxs[0], ly = cys[0], lz = czs[0];
+            int li = ci[0];
+#pragma unroll
+            for (int c = 1; c < kFT; c++) {
+                const bool better = (cd[c] > ld) | ((cd[c] == ld) & (ci[c] < li));
+                ld = better ? cd[c] : ld;
+                li = better ? ci[c] : li;
+                lx = better ? cxs[c] : lx;
+                ly = better ? cys[c] : ly;
+                lz = better ? czs[c] : lz;
+            }
+            float md;
+            const int src = wave_argbest(ld, li, md);
+            const int mi = __builtin_amdgcn_readlane(li, src);
+            const float qx = lane_f32(lx, src), qy = lane_f32(ly, src), qz = lane_f32(lz, src);
+            if ((mm > 0) & !((md > td) | ((md == td) & (mi <= ti)))) break;
             if (lane == 0) {
-                s_piv[0] = wx; s_piv[1] = wy; s_piv[2] = wz;
-                s_piv[3] = __int_as_float(timed_out ? -1 : mi);
+                s_piv[mm][0] = qx; s_piv[mm][1] = qy; s_piv[mm][2] = qz;
+                s_piv[mm][3] = __int_as_float(mi);
+                if (wg == 0) out[s + mm] = mi;
+            }
+            mm++;
+            if (s + mm >= k || mm == kFBatch) break;
+            if (lane == 0) prog_store(&s_prog, (round << 16) | (unsigned)mm);       // the workers may take it
+#pragma unroll
+            for (int c = 0; c < kFT; c++) {
+                const float dd = sqdist_f<FMA>(cxs[c] - qx, cys[c] - qy, czs[c] - qz);
+                cd[c] = cd[c] < dd ? cd[c] : dd;        // dead entries stay at -2
             }
         }
-        __syncthreads();
-        cx = s_piv[0]; cy = s_piv[1]; cz = s_piv[2];
-        cur = __float_as_int(s_piv[3]);
-        // aborted: this workgroup stops publishing, so its peers time out once and leave as well
-        // (one bounded spin per workgroup, not one per remaining step)
-        if (cur < 0) break;
+        s += mm;
+        if (lane == 0) prog_store(&s_prog, (round << 16) | kProgDone | (s >= k ? kProgFinal : 0u) | (unsigned)mm);
     }
-    // a hand-off that timed out (workgroups of a cloud not co-resident) poisons the
-    // result visibly: index 0 is always 0 in a good run
-    if (wg == 0 && t == 0 && (cur < 0 || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) out[0] = -1;
+    if (timed_out && lane == 0) prog_store(&s_prog, (round << 16) | kProgDone | kProgAbort);
+    // a hand-off that timed out (workgroups of a cloud not co-resident) poisons the result visibly: index 0 is
+    // always 0 in a good run.  The other workgroups' coordinators time out once on the missing list and leave too.
+    if (wg == 0 && lane == 0) {
+        if (timed_out || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) out[0] = -1;
+        err[1 + jobs.stat0 + job] = (int)round;          // exchanges this cloud took (genpc_fps_stats)
+    }
 }
 
 template <int FMA>
 static void launch_fps(int R, dim3 grid, hipStream_t st, const FpsJobs &jobs, FpsSlot *slots, int *err)
 {
     switch (R) {
-    case 1: case 2: hipLaunchKernelGGL((fps_kernel<FMA, 2>), grid, dim3(kFThreads), 0, st, jobs, slots, err); break;
-    case 3: case 4: hipLaunchKernelGGL((fps_kernel<FMA, 4>), grid, dim3(kFThreads), 0, st, jobs, slots, err); break;
-    case 5: case 6: case 7: case 8: hipLaunchKernelGGL((fps_kernel<FMA, 8>), grid, dim3(kFThreads), 0, st, jobs, slots, err); break;
-    case 9: case 10: case 11: case 12: hipLaunchKernelGGL((fps_kernel<FMA, 12>), grid, dim3(kFThreads), 0, st, jobs, slots, err); break;
-    default: hipLaunchKernelGGL((fps_kernel<FMA, 16>), grid, dim3(kFThreads), 0, st, jobs, slots, err); break;
+    case 1: case 2: hipLaunchKernelGGL((fps_kernel<FMA, 2>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+    case 3: case 4: hipLaunchKernelGGL((fps_kernel<FMA, 4>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+    case 5: case 6: case 7: case 8: hipLaunchKernelGGL((fps_kernel<FMA, 8>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+    case 9: case 10: case 11: case 12: hipLaunchKernelGGL((fps_kernel<FMA, 12>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+    default: hipLaunchKernelGGL((fps_kernel<FMA, 16>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
     }
 }
 
@@ -324,6 +476,7 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
     for (int j0 = 0; j0 < c;) {
         // a launch takes up to kFMaxJobs clouds whose workgroups fit the budget together
         FpsJobs jobs = {};
+        jobs.stat0 = j0 < 32 ? j0 : 32;
         int nj = 0, wsum = 0, wmax = 0, rmax = 1;
         while (j0 + nj < c && nj < kFMaxJobs) {
             const int j = j0 + nj, W = fps_workgroups(n[j]);
@@ -351,6 +504,19 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
     }
     if (!check(hipGetLastError(), "fps launch")) return 0;
     return 1;
+}
+
+GENPC_API int genpc_fps_stats(int c, int *rounds, void *stream)
+{
+    // exchanges (hand-off rounds) each of the first c <= 32 clouds of the last genpc_fps_multi call on this
+    // stream took; synchronises the stream
+    using namespace genpc;
+    if (c < 0 || c > 32) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace(7, 256, st);
+    if (!ws) return 0;
+    if (!check(hipMemcpyAsync(rounds, ws + 4, (size_t)c * sizeof(int), hipMemcpyDeviceToHost, st), "fps stats copy")) return 0;
+    return check(hipStreamSynchronize(st), "fps stats sync") ? 1 : 0;
 }
 
 GENPC_API int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, void *stream)

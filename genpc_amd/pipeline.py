@@ -62,12 +62,18 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
     res = reg_xyz.reg(partial_xyz, generated_xyz, generative_model=cfg.generative_model, dataset=cfg.dataset,
                       cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=True, cd_only_pose=cd_only_pose)
     out["reg"] = res
-    fused = reg_xyz.fuse(res["source"], res["target"], num_points=fused_points)
+    # the ground truth's metric subsampling (main.py:21) depends on nothing above: it rides along in the fused
+    # cloud's FPS launch
+    side = [(gt_xyz, metric_points)] if gt_xyz is not None and gt_xyz.shape[0] >= metric_points else None
+    fused = reg_xyz.fuse(res["source"], res["target"], num_points=fused_points, side_fps=side)
+    gt_idx = None
+    if side:
+        fused, (gt_idx,) = fused
     out["fused"] = fused
     # ---- metric: main.metric (main.py:11-36) ----
     if gt_xyz is not None:
         pred = fps_to(fused, metric_points)
-        gt = fps_to(gt_xyz, metric_points)
+        gt = gt_xyz[gt_idx.long()] if gt_idx is not None else fps_to(gt_xyz, metric_points)
         out["pred_metric_points"] = pred
         out["gt_metric_points"] = gt
         out["metric"] = evaluate_scans(pred[None].contiguous(), gt[None].contiguous())[0]

@@ -323,24 +323,41 @@ def remove_close_points(source_xyz, target_xyz, distance_threshold=0.0001):
 
 
 def fuse(source_xyz, target_xyz, num_points=20000, distance_threshold=0.0001, std_ratio=2.5, source_col=None,
-         target_col=None):
+         target_col=None, side_fps=None):
     """reg_xyz.py:207-217: partial + (complete minus what the partial already covers),
     farthest-point-sampled to `num_points`, then the statistical outlier filter
     (std_ratio 2.5 as at :217; None skips it).  With source_col / target_col the colours follow their
-    points through all three steps (:56,:212-216) and (fused, fused_col) is returned."""
-    from .fps import fps_sampling
+    points through all three steps (:56,:212-216) and (fused, fused_col) is returned.
+    side_fps: [(cloud [N,3], k), ...] -- independent subsamplings the caller needs anyway (the metric's
+    ground-truth cloud, main.py:21) ride along in the fused cloud's FPS launch (a pass costs its longest
+    chain of sequential steps, not the sum); their index tensors are appended to the return value."""
+    from .fps import fps_sampling, fps_sampling_multi
     with_col = source_col is not None and target_col is not None
     filtered, keep = remove_close_points(source_xyz, target_xyz, distance_threshold)
     fused = torch.cat([source_xyz.float(), filtered], dim=0).contiguous()
     col = torch.cat([source_col.float(), target_col.float()[keep]], dim=0) if with_col else None
-    if fused.shape[0] > num_points:
+    side = []
+    if side_fps:
+        need = fused.shape[0] > num_points
+        clouds = ([fused] if need else []) + [c.contiguous().float() for c, _ in side_fps]
+        ks = ([num_points] if need else []) + [k for _, k in side_fps]
+        got = fps_sampling_multi(clouds, ks)
+        if need:
+            idx = got[0].long()
+            fused = fused[idx]
+            col = col[idx] if with_col else None
+        side = got[1:] if need else got
+    elif fused.shape[0] > num_points:
         idx = fps_sampling(fused, num_points).long()
         fused = fused[idx]
         col = col[idx] if with_col else None
     if std_ratio is not None:                                            # :217
         fused, ok = remove_noise_from_point_cloud(fused, std_ratio=std_ratio)
         col = col[ok] if with_col else None
-    return (fused, col) if with_col else fused
+    out = (fused, col) if with_col else fused
+    if side_fps:
+        return out, side
+    return out
 
 
 def knn_mean_distance(xyz, k=20):

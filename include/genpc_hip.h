@@ -319,6 +319,9 @@ int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, void *stream)
  * xyz[C] (device pointers to [n_j,3]), out_idx[C] (device pointers to [k_j]).                    */
 int genpc_fps_multi(int c, const int *n, const int *k, const float *const *xyz,
                     int *const *out_idx, void *stream);
+/* Diagnostics: rounds[j] (host, c <= 32) = inter-workgroup exchanges cloud j of the last
+ * genpc_fps_multi call on this stream took (one exchange yields several samples).  Synchronises.  */
+int genpc_fps_stats(int c, int *rounds, void *stream);
 
 /* Statistical outlier filter ------------------------------------------------ *
  * mean_out[N] = mean Euclidean distance of every point to its k nearest points of

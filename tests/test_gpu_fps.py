@@ -121,5 +121,8 @@ def test_fps_step_time(fg):
         fg["fps"](x, k)
         torch.cuda.synchronize()
         us = (time.perf_counter() - t0) * 1e6 / k
-        print("fps %d x %d -> %d: %.3f us/step" % (c, n, k, us))
+        import ctypes
+        rounds = (ctypes.c_int * 1)()
+        fg["lib"].on_device_of(x, fg["lib"].lib.genpc_fps_stats, 1, ctypes.addressof(rounds))
+        print("fps %d x %d -> %d: %.3f us/step, %.1f samples per exchange" % (c, n, k, us, k / max(1, rounds[0])))
         assert us < 5.0
