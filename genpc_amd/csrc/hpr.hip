@@ -570,11 +570,13 @@ constexpr int kHprRimStep = 8;     // after this many tiles ...
 constexpr double kHprRimD2 = 1.0e6; // ... a polygon with a vertex farther than 1000 from the origin is a silhouette point's
 constexpr int kHprRimTiles = 256;  // ... and is handed to the second pass if the cloud has at least this many tiles
 
-// status[0] = points handed to the second pass, status[1] = error (2: a polygon outgrew kHprOverCap)
+// status[0] = points handed to the wave-per-point pass, status[1] = error (2: a polygon outgrew kHprOverCap),
+// status[2] = points left undecided for hpr_phase2_kernel
 __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *__restrict__ fl_all, const int *__restrict__ perm,
                                                          const HprTile *__restrict__ tiles_all, const int *__restrict__ hardlist,
                                                          const int *__restrict__ hardcnt, unsigned char *__restrict__ vis,
-                                                         int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull, int max_clips)
+                                                         int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull, int max_clips,
+                                                         int split, int4 *__restrict__ surv, double2 *__restrict__ surv_poly)
 {
     __shared__ double2 s_poly[kHprMaxV * kHprThreads];
     __shared__ double4 s_stage[kHprThreads];      // 64 tile records while testing, then one tile's candidates
@@ -827,6 +829,25 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
             active = false;        // (nv >= 3 stays: reported as visible below)
         }
     }
+    // Phase 2 (every other tile, outward from the group's starting tile) is hpr_phase2_kernel's: only about one
+    // listed point in eight is still undecided here, and a block that carried them on waited for its slowest
+    // lane with the other seven eighths idle (1.5 of a block's 2.7 ms).  The undecided lanes
+    // park their polygons in memory; the second kernel packs them densely, 128 to a block.
+    if (split && active) {
+        const unsigned long long bal = __ballot(true);
+        const int lane = tid & (kWave - 1);
+        int base = 0;
+        if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(&status[2], __popcll(bal));
+        base = __shfl(base, __ffsll((long long)bal) - 1, kWave);
+        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+        surv[slot] = make_int4(view * n + rank, nv, nclips, 0);
+        double2 *sp = surv_poly + (size_t)slot * kHprMaxV;
+        for (int k = 0; k < nv; k++) sp[k] = poly[k * kHprThreads];
+        nv = -1;               // decided later
+        active = false;
+    }
+    // split == 0 (large clouds: few views, thousands of tiles -- there the lanes of a block want the same tiles and
+    // staging them once per block through LDS beats per-lane reads: 2 x 165546 points 40 ms against 49):
     // Phase 2: all other tiles, outward from the group's starting tile, in batches of 1, 1, 2, 4, ... 64 whose
     // records are tested first (the polygon is tight by now, most tiles are out of its reach)
     for (int step0 = 0, bsz = 1; step0 < 2 * ntiles; step0 += bsz, bsz = step0 < kHprBatch ? step0 : kHprBatch) {
@@ -877,6 +898,140 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     if (i >= 0 && nv >= 0) vis[(size_t)view * n + i] = seen ? 1 : 0;
     const int c = __syncthreads_count(seen);
     if (tid == 0 && c) atomicAdd(&cnt[view], c);
+}
+
+// Phase 2 of the polygon pass for the points hpr_kernel left undecided, packed densely: one thread per survivor,
+// polygon back in LDS.  Every lane walks ITS OWN tile sequence -- outward from the starting tile of the group it
+// was listed in (hpr_base_tile of its rank: the order the oracle restates), skipping its three home tiles -- and
+// reads tile records and candidates straight from memory (the lanes of a wave want different tiles; the view's
+// flipped cloud and tile records stay in L2).  Same candidates, same order, same arithmetic as before the split:
+// the skips (tile cone test, reach bounds) are conservative, so when they are evaluated changes no polygon.
+// No block-wide synchronisation: a wave retires as soon as its 64 lanes are decided.
+__global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsurv, const double *__restrict__ fl_all,
+                                                                const int *__restrict__ perm, const HprTile *__restrict__ tiles_all,
+                                                                const int *__restrict__ hardlist, const int *__restrict__ hardcnt,
+                                                                const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
+                                                                unsigned char *__restrict__ vis, int *__restrict__ cnt, int *status,
+                                                                int *__restrict__ over_list, int no_cull, int max_clips)
+{
+    __shared__ double2 s_poly[kHprMaxV * kHprThreads];
+    const int tid = threadIdx.x, slot = blockIdx.x * kHprThreads + tid;
+    bool active = slot < nsurv;
+    int view = 0, rank = 0, nv = 0, nclips = 0, pos = 0, i = -1;
+    if (active) {
+        const int4 e = surv[slot];
+        view = e.x / n;
+        rank = e.x - view * n;
+        nv = e.y;
+        nclips = e.z;
+    }
+    const double *fl = fl_all + (size_t)view * n * 3;
+    const int *hl = hardlist + (size_t)view * n;
+    const int ntiles = ceil_div_dev(n, kHprThreads);
+    const HprTile *tiles = tiles_all + (size_t)view * ntiles;
+    HprFrame f = {};
+    int own = 0, home = 0;
+    double2 *poly = s_poly + tid;
+    if (active) {
+        pos = hl[rank];
+        i = perm[(size_t)view * n + pos];
+        own = hpr_base_tile(hl, hardcnt[view], rank);
+        home = pos / kHprThreads;
+        hpr_frame(fl + (size_t)pos * 3, f);         // (true: hpr_kernel listed it)
+        const double2 *sp = surv_poly + (size_t)slot * kHprMaxV;
+        for (int k = 0; k < nv; k++) poly[k * kHprThreads] = sp[k];
+    }
+    HprReach R = {};
+    if (active) R = hpr_reach(poly, kHprThreads, nv);
+    // one tile of candidates against this lane's polygon: hpr_kernel's clip_by_tile for a tile that is not the
+    // point's home tile (chunks of 32 in ascending order), candidates read from memory
+    auto clip_by_tile = [&](int tile) {
+        const int tile0 = tile * kHprThreads;
+        for (int cc = 0; cc < kHprThreads / 32 && active; cc++) {
+            const int c0 = cc * 32;
+            R = hpr_reach(poly, kHprThreads, nv);
+            unsigned m = 0u;
+#pragma unroll 4
+            for (int t = 0; t < 32; t++) {
+                const int j = tile0 + c0 + t;
+                if (j >= n) break;
+                const double *g = fl + (size_t)j * 3;
+                const double qx = g[0], qy = g[1], qz = g[2];
+                const double A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
+                const double B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
+                const double C = f.rho - (f.ux * qx + f.uy * qy + f.uz * qz);
+                const bool self = qx == f.px && qy == f.py && qz == f.pz;      // the point itself, or an exact duplicate
+                m |= (!self && qx == qx && !hpr_far(R, A, B, C)) ? (1u << t) : 0u;
+            }
+            while (m && active) {
+                const int t = __ffs((int)m) - 1;
+                m &= m - 1;
+                const double *g = fl + (size_t)(tile0 + c0 + t) * 3;
+                const double qx = g[0], qy = g[1], qz = g[2];
+                const double A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
+                const double B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
+                const double C = f.rho - (f.ux * qx + f.uy * qy + f.uz * qz);
+                int out = 0, first = 0, runs = 0;
+                bool prev_out;
+                {
+                    const double2 v = poly[(nv - 1) * kHprThreads];
+                    prev_out = v.x * A + v.y * B - C > 0.0;
+                }
+                for (int k0 = 0; k0 < nv; k0 += 8) {
+                    double2 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = poly[(k0 + j < kHprMaxV ? k0 + j : kHprMaxV - 1) * kHprThreads];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const bool o = k0 + j < nv && v[j].x * A + v[j].y * B - C > 0.0;
+                        out += o ? 1 : 0;
+                        first = (o && !prev_out) ? k0 + j : first;
+                        runs += (o && !prev_out) ? 1 : 0;
+                        prev_out = k0 + j < nv ? o : prev_out;
+                    }
+                }
+                if (!out) continue;
+                if (out == nv) { nv = 0; active = false; break; }
+                if (nv - out + 2 > kHprMaxV || runs > 1) {
+                    over_list[atomicAdd(&status[0], 1)] = view * n + rank;
+                    nv = -1;
+                    active = false;
+                    break;
+                }
+                const int mm = hpr_clip_inplace(poly, kHprThreads, nv, out, first, A, B, C);
+                if (mm < 3) { nv = 0; active = false; break; }
+                nv = mm;
+                if (++nclips > max_clips) {
+                    over_list[atomicAdd(&status[0], 1)] = view * n + rank;
+                    nv = -1;
+                    active = false;
+                    break;
+                }
+            }
+        }
+    };
+    for (int step = 0; step < 2 * ntiles; step++) {
+        // a polygon that still runs out to the box after the eight nearest tiles belongs to a point on the
+        // silhouette: in a large cloud it goes to the wave-per-point pass (as before the split)
+        if (step == kHprRimStep && ntiles >= kHprRimTiles && active && R.d2 > kHprRimD2 && !(no_cull & 8)) {
+            over_list[atomicAdd(&status[0], 1)] = view * n + rank;
+            nv = -1;
+            active = false;
+        }
+        if (!__any(active)) break;
+        if (!active) continue;
+        const int tile = hpr_tile_of(step, own);
+        if (tile < 0 || tile >= ntiles) continue;
+        if (tile >= home - 1 && tile <= home + 1) continue;          // taken in phase 1
+        if (!(no_cull & 1)) {
+            const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15), cpsi = 1.0 / l, spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
+            if (!hpr_tile_needed(f, cpsi, spsi, poly, kHprThreads, nv, tiles[tile])) continue;
+        }
+        clip_by_tile(tile);
+    }
+    const bool seen = i >= 0 && nv > 0;
+    if (i >= 0 && nv >= 0) vis[(size_t)view * n + i] = seen ? 1 : 0;
+    if (seen) atomicAdd(&cnt[view], 1);
 }
 
 // second pass: one WAVE per listed point, polygon in LDS (two buffers of kHprOverCap vertices).  Lane b tests
@@ -1096,6 +1251,8 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     const size_t o_hard = off; off += up(total);
     const size_t o_hl = off; off += up(total * sizeof(int));
     const size_t o_hc = off; off += up((size_t)c * sizeof(int));
+    const size_t o_surv = off; off += up(total * sizeof(int4));
+    // (the survivors' polygons are sized after hpr_kernel has counted them: a second, smaller workspace)
     char *ws = (char *)workspace(17, off, stream);
     if (!ws) return 0;
     int *status = (int *)ws;
@@ -1128,14 +1285,47 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     hipLaunchKernelGGL(hpr_accept_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
                        (const HprTile *)tiles, hard, visible, counts, (no_cull & 16) ? 1 : 0);
     hipLaunchKernelGGL(hpr_compact_kernel, dim3(c), dim3(1024), 0, stream, n, (const unsigned char *)hard, hardlist, hardcnt);
+    // the undecided points' polygons: at most one per listed point; the listed points are counted by now only on the
+    // device, so the buffer is sized for the worst case the accept pass leaves in practice (every point) lazily:
+    // total * kHprMaxV * 16 bytes would be 2.6 GB at 1024 x 10000 -- instead the count is fetched (the first of
+    // this entry's host round trips) and the buffer sized from it
+    int4 *surv = (int4 *)(ws + o_surv);
+    int hc_total = 0;
+    // the split pays when many views share a small cloud (viewpoint_select: 1024 x 10000, 128 -> 88 ms; 64 x 10000: 14.3 -> 16.6, so not there); a few views
+    // of a large cloud keep the one-kernel form (GENPC_HPR_SPLIT=0/1 overrides)
+    static const int env_split = getenv("GENPC_HPR_SPLIT") ? atoi(getenv("GENPC_HPR_SPLIT")) : -1;
+    const int split = env_split >= 0 ? env_split : (ntiles < kHprRimTiles && (long long)c * n >= 4000000ll ? 1 : 0);
+    if (split) {
+        // sum of hardcnt over the views = an upper bound on the survivors
+        int *hc_host = (int *)malloc(sizeof(int) * (size_t)c);
+        if (!hc_host) { set_error("genpc_hpr_visibility: out of host memory"); return 0; }
+        if (!check(hipMemcpyAsync(hc_host, hardcnt, sizeof(int) * (size_t)c, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr hardcnt)") ||
+            !check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) { free(hc_host); return 0; }
+        long long sum = 0;
+        for (int v = 0; v < c; v++) sum += hc_host[v];
+        free(hc_host);
+        hc_total = (int)(sum < INT_MAX ? sum : INT_MAX);
+    }
+    double2 *surv_poly = nullptr;
+    if (split) {
+        surv_poly = (double2 *)workspace(20, (size_t)(hc_total > 0 ? hc_total : 1) * kHprMaxV * sizeof(double2), stream);
+        if (!surv_poly) return 0;
+    }
     hipLaunchKernelGGL(hpr_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
                        (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull,
-                       max_clips);
+                       max_clips, split, surv, surv_poly);
     if (!check(hipGetLastError(), "hpr launch")) return 0;
-    // the second pass is sized from the first one's count: the one host round trip of this entry
-    int st[2] = {0, 0};
+    int st[3] = {0, 0, 0};
     if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
     if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
+    if (st[2] > 0) {
+        hipLaunchKernelGGL(hpr_phase2_kernel, dim3(ceil_div(st[2], kHprThreads)), dim3(kHprThreads), 0, stream, n, st[2],
+                           (const double *)fl, (const int *)i1, (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt,
+                           (const int4 *)surv, (const double2 *)surv_poly, visible, counts, status, list, no_cull, max_clips);
+        if (!check(hipGetLastError(), "hpr phase 2 launch")) return 0;
+        if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
+        if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
+    }
     if (second_pass_points) *second_pass_points = st[0];
     if (st[0] > 0) {
         hipLaunchKernelGGL(hpr_overflow_kernel, dim3(st[0]), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
