@@ -25,6 +25,7 @@
 #include "../../include/genpc_hip.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 // chamfer.hip
 extern "C" int genpc_chamfer_forward(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1,
@@ -270,10 +271,12 @@ __global__ void pose_update_kernel(int b, PoseState *__restrict__ S, double *__r
 
 // start < 0: global init.  Otherwise begin start `start` (get_init_rot('y', 90*start),
 // trans 0, log_scale log(0.75): diff_obj_pose.py:367,519).
-__global__ void pose_begin_kernel(int b, PoseState *__restrict__ S, double *__restrict__ accum, int start)
+// start_mod > 0: the starts of a scan run side by side (element e = scan * start_mod + start): start = e % start_mod.
+__global__ void pose_begin_kernel(int b, PoseState *__restrict__ S, double *__restrict__ accum, int start, int start_mod)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= b) return;
+    if (start >= 0 && start_mod > 0) start = e % start_mod;
     S += e;
     accum += (size_t)e * kAcc;
     if (start < 0) {
@@ -321,6 +324,46 @@ __global__ void pose_end_kernel(int b, PoseState *__restrict__ S, int final, flo
     transform[15] = 1.0f;
     if (best_params)
         for (int k = 0; k < 10; k++) best_params[k] = S->best_params[k];
+}
+
+// Lock-step starts: the `starts` elements of scan g have finished side by side; apply the sequential rule of
+// diff_obj_pose.py:570-576 in start order (strict <: the first of equal lowest losses wins) and emit that start's
+// FINAL parameters and T = [[sR, t],[0,1]].
+__global__ void pose_pick_kernel(int scans, int starts, const PoseState *__restrict__ S, float *__restrict__ transform,
+                                 float *__restrict__ best_params)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= scans) return;
+    float best_loss = __builtin_inff();
+    int best = 0;
+    for (int s = 0; s < starts; s++) {
+        const float l = S[g * starts + s].local_best;
+        if (l < best_loss) { best_loss = l; best = s; }
+    }
+    const float *bp = S[g * starts + best].params;
+    float R[9];
+    rot6d_to_matrix(bp, R);
+    const float sc = expf(bp[9]);
+    float *T = transform + (size_t)g * 16;
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) T[a * 4 + b] = R[a * 3 + b] * sc;
+        T[a * 4 + 3] = bp[6 + a];
+    }
+    T[12] = T[13] = T[14] = 0.0f;
+    T[15] = 1.0f;
+    if (best_params)
+        for (int k = 0; k < 10; k++) best_params[(size_t)g * 10 + k] = bp[k];
+}
+
+// dst[g, r, :] = src[g, :] for r < rep (count floats per row)
+__global__ __launch_bounds__(kQBlock) void pose_replicate_kernel(size_t count, int rep, const float *__restrict__ src,
+                                                                 float *__restrict__ dst)
+{
+    const int g = blockIdx.y;
+    for (size_t j = (size_t)blockIdx.x * kQBlock + threadIdx.x; j < count; j += (size_t)gridDim.x * kQBlock) {
+        const float v = src[(size_t)g * count + j];
+        for (int r = 0; r < rep; r++) dst[((size_t)g * rep + r) * count + j] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1210,6 +1253,36 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     const bool mask = mask_weight != 0.0f;
     if (mask && (render_size <= 1 || !(radius > 0.0f))) return -1;
     hipStream_t st = (hipStream_t)stream;
+    // The multi-starts of a scan are independent optimisations of the same clouds (diff_obj_pose.py:516-576): they run
+    // SIDE BY SIDE as batch elements (element = scan * starts + start) -- one pass of iters + 1 Adam steps with
+    // `starts` times the work per launch instead of `starts` passes.  At the reference's sizes every kernel of a
+    // step is latency-bound (15403 x 7855 points: 118 us of kernels per step, 804 steps = 95 ms of reg()'s 110),
+    // so the wider launches are nearly free.  Same arithmetic per element, same selection rule at the end.
+    static const int env_lock = getenv("GENPC_POSE_LOCKSTEP") ? atoi(getenv("GENPC_POSE_LOCKSTEP")) : 1;
+    const int lock = (starts > 1 && env_lock && (long long)b * starts <= 256) ? starts : 0;
+    const int scans = b, starts_in = starts;
+    float *x_complete = nullptr, *x_partial = nullptr, *x_ccol = nullptr, *x_pcol = nullptr;
+    if (lock) {
+        auto up0 = [](size_t x) { return (x + 255) / 256 * 256; };
+        const size_t bc = (size_t)b * lock * nc * 12, bp = (size_t)b * lock * np * 12;
+        char *xs = (char *)workspace(22, 2 * up0(bc) + 2 * up0(bp), st);
+        if (!xs) return 0;
+        x_complete = (float *)xs;
+        x_partial = (float *)(xs + up0(bc));
+        hipLaunchKernelGGL(pose_replicate_kernel, dim3(lin_grid((long long)nc * 3), b), dim3(kQBlock), 0, st, (size_t)nc * 3, lock, complete, x_complete);
+        hipLaunchKernelGGL(pose_replicate_kernel, dim3(lin_grid((long long)np * 3), b), dim3(kQBlock), 0, st, (size_t)np * 3, lock, partial, x_partial);
+        if (complete_col) {
+            x_ccol = (float *)(xs + up0(bc) + up0(bp));
+            hipLaunchKernelGGL(pose_replicate_kernel, dim3(lin_grid((long long)nc * 3), b), dim3(kQBlock), 0, st, (size_t)nc * 3, lock, complete_col, x_ccol);
+        }
+        if (partial_col) {
+            x_pcol = (float *)(xs + 2 * up0(bc) + up0(bp));
+            hipLaunchKernelGGL(pose_replicate_kernel, dim3(lin_grid((long long)np * 3), b), dim3(kQBlock), 0, st, (size_t)np * 3, lock, partial_col, x_pcol);
+        }
+        complete = x_complete; partial = x_partial; complete_col = x_ccol; partial_col = x_pcol;
+        b *= lock;
+        starts = 1;
+    }
     const size_t P = mask ? (size_t)render_size * render_size : 0;
     // scratch: accum[b,kAcc] | state[b] | center[b,4] | pts[b,nc,3] | d1 | d2 | i1 | i2 | mask scratch
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -1242,11 +1315,11 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     if (mask && !mask_prepare_ref(b, np, partial, partial_col, radius, render_size, m, st)) return 0;
 
     const int gb = ceil_div(b, 64);
-    hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, -1);
+    hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, -1, 0);
     const int g_t = lin_grid(nc), g_g = lin_grid((long long)nc + np);
     const int hstride = starts * (iters + 1);
     for (int s = 0; s < starts; s++) {
-        hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, s);
+        hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, s, lock);
         for (int it = 0; it <= iters; it++) {
             if (mask)
                 hipLaunchKernelGGL(pose_transform_project_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
@@ -1267,7 +1340,11 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
         }
         hipLaunchKernelGGL(pose_end_kernel, dim3(gb), dim3(64), 0, st, b, S, 0, (float *)nullptr, (float *)nullptr);
     }
-    hipLaunchKernelGGL(pose_end_kernel, dim3(gb), dim3(64), 0, st, b, S, 1, transform, best_params);
+    if (lock)
+        hipLaunchKernelGGL(pose_pick_kernel, dim3(ceil_div(scans, 64)), dim3(64), 0, st, scans, starts_in, (const PoseState *)S, transform,
+                           best_params);
+    else
+        hipLaunchKernelGGL(pose_end_kernel, dim3(gb), dim3(64), 0, st, b, S, 1, transform, best_params);
     return check(hipGetLastError(), "pose_optimize launch") ? 1 : 0;
 }
 
