@@ -150,3 +150,33 @@ def test_bench_spawns_the_torchrun_form(monkeypatch):
     monkeypatch.delenv("WORLD_SIZE")
     bench.maybe_spawn(types.SimpleNamespace(gpus=1))
     assert len(calls) == 1
+
+
+def test_bench_scan_workload_two_ranks_gloo():
+    """`bench.py --gpus 2 --workload c4` end to end on two CPU ranks over gloo: the self-spawned
+    torchrun form, 59 scans dealt unevenly over 2 ranks (30 + 29), barriers, MAX-over-ranks timing,
+    gather_scan_metrics and ranks_seen all execute; registration + metric are replaced by a stub of the same shapes
+    (GENPC_BENCH_STUB=1 -- no kernel runs on CPU, nothing is measured).  The gathered table must equal the
+    one-process run's."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env["GENPC_BENCH_STUB"] = "1"
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    bench = os.path.join(ROOT, "bench.py")
+
+    def run(gpus):
+        p = subprocess.run([sys.executable, bench, "--gpus", str(gpus), "--workload", "c4", "--steps", "2", "--warmup", "1",
+                            "--no-extra"], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout
+        return json.loads(lines[0])
+
+    two, one = run(2), run(1)
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == [0, 1] and two["scaling"] == "strong"
+    assert two["config"]["scans"] == 59 and two["steps"] == 2 and two["value"] > 0 and two["extra"]["stub"] is True
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == [0]
+    assert two["extra"]["scan_table_checksum"] == one["extra"]["scan_table_checksum"]
+    assert two["extra"]["mean_cd_l1_vs_true_pose"] == one["extra"]["mean_cd_l1_vs_true_pose"]
