@@ -53,6 +53,7 @@ SIGNATURES = {
     "genpc_icp_batch": (_i, [_i, _i, _vp, _i, _vp, _d, _vp, _i, _d, _d, _vp, _vp, _vp]),
     "genpc_scale_search_scores": (_i, [_i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp]),
     "genpc_voxel_down_sample": (_i, [_i, _vp, _vp, _d, _vp, _vp, _vp, _vp]),
+    "genpc_mfma_f16_probe": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_fps_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_fps_stats": (_i, [_i, _vp, _vp]),
     "genpc_fps": (_i, [_i, _i, _vp, _i, _vp, _vp]),

@@ -306,6 +306,15 @@ int genpc_scale_search_scores(int k, int ns, const float *source, int nt,
                               const float *target, const float *scales,
                               float cd_inv_weight, float *scores, void *stream);
 
+/* Hardware-premise probe ------------------------------------------------------ *
+ * D[p] = A[p] B[p] + C[p] for `problems` independent 32x16 * 16x32 + 32x32 products computed by ONE
+ * v_mfma_f32_32x32x16_f16 each (A, B: f16 bit patterns, row-major; C, D float32; device memory).
+ * The default nearest-neighbour filter's proof leans on this instruction's internal summation error
+ * being <= 6.5 * 2^-24 * sum|terms| (csrc/nn_f16.hip); tests/test_gpu_mfma_premise.py measures it
+ * with this entry on the box the suite runs on.                                                  */
+int genpc_mfma_f16_probe(int problems, const unsigned short *a, const unsigned short *b,
+                         const float *c, float *d, void *stream);
+
 /* Farthest point sampling --------------------------------------------------- *
  * Deterministic counterpart of fpsample.fps_sampling as the reference uses it
  * (main.py:21-24, reg_xyz.py:215, DepthPrompting.py:88; third-party, random start):

@@ -1,0 +1,94 @@
+"""Same input twice => identical output, for every entry point whose results the parity tests hold bit-exact
+(SURVEY section 5's determinism checks) -- and a stated, tested bound for the one path that is
+not run-to-run deterministic: the alignment loop (fp64 atomics in its reductions)."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+def _twice(fn):
+    a = fn()
+    b = fn()
+    a = a if isinstance(a, (tuple, list)) else (a,)
+    b = b if isinstance(b, (tuple, list)) else (b,)
+    return a, b
+
+
+def _same(a, b):
+    for x, y in zip(a, b):
+        assert x.dtype == y.dtype and x.shape == y.shape
+        assert bool((x.view(-1).view(dtype=x.dtype) == y.view(-1)).all()) or (
+            x.dtype.is_floating_point and bool(((x == y) | (x.isnan() & y.isnan())).all()))
+
+
+def test_bit_exact_entry_points_repeat(env):
+    torch = env
+    from genpc_amd.loss_functions import chamfer_3DDist, emdModule
+    from genpc_amd.fps import fps_sampling
+    from genpc_amd import reg_xyz
+    from genpc_amd.DepthPrompting import DepthPrompting
+    from genpc_amd.ScaleAdapter import ScaleAdapter
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    A = torch.rand(2, 6000, 3, device="cuda", generator=g) - 0.5
+    B = torch.rand(2, 5000, 3, device="cuda", generator=g) - 0.5
+    _same(*_twice(lambda: chamfer_3DDist()(A, B)))
+    X = torch.rand(2, 2048, 3, device="cuda", generator=g)
+    Y = torch.rand(2, 2048, 3, device="cuda", generator=g)
+    _same(*_twice(lambda: emdModule()(X, Y, 0.005, 50)))
+    big = torch.rand(40000, 3, device="cuda", generator=g)
+    _same(*_twice(lambda: fps_sampling(big, 3000)))
+    col = torch.rand(40000, 3, device="cuda", generator=g)
+    _same(*_twice(lambda: reg_xyz.voxel_down_sample(big, 0.03, colors=col)))
+    _same(*_twice(lambda: reg_xyz.knn_mean_distance(big[:20000].contiguous(), 20)))
+    cfg = SimpleNamespace(device="cuda", fovy=49.1, res=256, cam_res=256, padding=0.15, rescale=True, point_size=2,
+                          mask_pixel_rate=3, view_num=32, distance=1.6, downsample_num=4000, removal_radius=10000)
+    dp = DepthPrompting(cfg)
+    pts = (big[:6000] - 0.5).contiguous()
+    _same(*_twice(lambda: dp.getUvs(dp.cameras, pts)))
+    _same(*_twice(lambda: dp.hidden_point_removal(pts, dp.viewpoints, 10000.0)[:2]))
+    uv, depth, _ = dp.getUvs(dp.cameras[:1], pts)
+    pix = dp.uvToPixels(uv[0], 256)
+    _same(*_twice(lambda: dp.getRawDepth(pix, depth[0], colors=col[:6000].contiguous(), res=256, point_size=2, mask_pixel_rate=3)))
+    img = torch.rand(3, 1024, 1024, device="cuda", generator=g)
+    _same(*_twice(lambda: ScaleAdapter(cfg).colorPoint(uv[0], img)))
+    # ICP / scale search: fp64 sums through atomics -> transforms agree to rounding, scores are bit-exact NN outputs
+    S1, l1, T1 = reg_xyz.iterative_scale_search(pts[:3000].contiguous() * 0.9, pts[:4000].contiguous(), [(0.8, 1.2)] * 3, 6, cd_inv_weight=0.5)
+    S2, l2, T2 = reg_xyz.iterative_scale_search(pts[:3000].contiguous() * 0.9, pts[:4000].contiguous(), [(0.8, 1.2)] * 3, 6, cd_inv_weight=0.5)
+    assert l1 == l2 and np.array_equal(S1, S2)
+    np.testing.assert_allclose(T1, T2, atol=1e-12)
+
+
+def test_alignment_loop_run_to_run_bound(env):
+    """The alignment loop is NOT bit-reproducible: its gradient and image sums are fp64 atomics (order varies) and
+    the splat sums a pixel's discs in list order (varies).  Documented bound, asserted here: the first 50 losses
+    of every start agree to 1e-6 relative between two runs, Chamfer-only and full objective (white and coloured)."""
+    torch = env
+    from genpc_amd.optim_registration.diff_obj_pose import object_pose_optimization
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal((4000, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    complete = (u * np.array([0.5, 0.3, 0.2])).astype(np.float32)
+    complete[:600] += np.float32([0.15, 0.1, 0.0]) * np.abs(u[:600, :1]).astype(np.float32)
+    th = math.radians(10.0)
+    Rt = np.array([[math.cos(th), 0, math.sin(th)], [0, 1, 0], [-math.sin(th), 0, math.cos(th)]])
+    c = complete.mean(0)
+    full = ((complete - c) * 0.9) @ Rt.T + c + np.array([0.02, -0.01, 0.015])
+    partial = full[full[:, 2] > -0.05][:2000].astype(np.float32)
+    C, P = torch.from_numpy(complete).cuda(), torch.from_numpy(partial).cuda()
+    col = torch.from_numpy((0.2 + 0.8 * rng.random((4000, 3))).astype(np.float32)).cuda()
+    pcol = torch.from_numpy((0.2 + 0.8 * rng.random((len(partial), 3))).astype(np.float32)).cuda()
+    for kw in (dict(cd_only=True), dict(radius=0.02), dict(radius=0.02, complete_col=col, partial_col=pcol)):
+        runs = [object_pose_optimization(C, P, lr=0.01, iters=60, return_history=True, **kw)[1] for _ in range(2)]
+        np.testing.assert_allclose(runs[0][:, :50], runs[1][:, :50], rtol=1e-6, err_msg=str(kw))

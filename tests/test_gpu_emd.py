@@ -235,3 +235,19 @@ def test_emd_fuzz(gp, oracle):
         np.testing.assert_array_equal(s["assignment"], ass, err_msg="case %d" % case)
         np.testing.assert_array_equal(s["dist"], d, err_msg="case %d" % case)
         np.testing.assert_array_equal(s["assignment_inv"], st["assignment_inv"], err_msg="case %d" % case)
+
+
+def test_emd_elementwise_at_16384(gp, oracle):
+    """BASELINE config 3's size, element by element: assignment, assignment_inv, bids and dist
+    of one 16384-point pair after the reference's 50 rounds at eps 0.005 equal the oracle's, bit for bit."""
+    rng = np.random.default_rng(163)
+    x = rng.random((1, 16384, 3), dtype=np.float32)
+    y = rng.random((1, 16384, 3), dtype=np.float32)
+    got = run_hip(gp, x, y, 0.005, 50, 1)
+    od, oass = oracle.emd_forward(x, y, 0.005, 50, 1)
+    np.testing.assert_array_equal(got["assignment"], oass)
+    np.testing.assert_array_equal(got["dist"], od)
+    inv = np.full(16384, -1, np.int64)
+    inv[oass[0]] = np.arange(16384)               # (the forced last round makes it many-to-one: compare where unique)
+    uniq, cnt = np.unique(oass[0], return_counts=True)
+    np.testing.assert_array_equal(got["assignment_inv"][0][uniq[cnt == 1]], inv[uniq[cnt == 1]])
