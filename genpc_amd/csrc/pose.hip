@@ -523,6 +523,7 @@ __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const fl
     __shared__ float4 list[kSplatList];       // u, v, 1 / rho^2, red
     __shared__ float2 list_gb[kSplatList];    // green, blue
     __shared__ int s_cnt;
+    __shared__ int s_tab[kSplatPer * (kSplatBlock / kWave)];      // per (i, wave): hits, then their exclusive prefix
     __shared__ double red[6][kSplatBlock / kWave];
     const int e = blockIdx.y;
     const int P = S * S;
@@ -558,37 +559,54 @@ __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const fl
                 q[i].y + q[i].z >= (float)ty0 && q[i].y - q[i].z <= (float)(ty1 + 1))
                 hit |= 1u << i;
         }
+        // The list is filled in ascending point order -- rank = number of hits before this one in (i, wave, lane)
+        // order, which is the order of the point indices j = j0 + i * kSplatBlock + tid -- so that a pixel sums its
+        // discs in the same order in every run (an arrival-order list made the whole alignment loop irreproducible:
+        // last-bit differences in the image flip a soft-mask pixel in or out of fp32 sigmoid saturation a few steps
+        // later).  One table of per-(i, wave) counts, one scan by wave 0, two barriers per round of 16384 points.
+        unsigned long long bal[kSplatPer];
+#pragma unroll
+        for (int i = 0; i < kSplatPer; i++) {
+            bal[i] = __ballot((hit >> i) & 1u);
+            if (lane == 0) s_tab[i * (kSplatBlock / kWave) + wave] = __popcll(bal[i]);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // exclusive scan of the 256 counts (four per lane, in table order)
+            static_assert(kSplatPer * (kSplatBlock / kWave) == 4 * kWave, "four table entries per lane");
+            int c4[4], tot = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { c4[q] = s_tab[lane * 4 + q]; tot += c4[q]; }
+            int incl = tot;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const int o = __shfl_up(incl, off, kWave);
+                incl += lane >= off ? o : 0;
+            }
+            int run = incl - tot;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { s_tab[lane * 4 + q] = run; run += c4[q]; }
+            if (lane == kWave - 1) s_cnt = incl;
+        }
+        __syncthreads();
+        const int total = s_cnt;
         // the list holds kSplatList entries: a crowded tile is drawn in several fills
-        unsigned done = 0;                   // bits of `hit` already listed
-        for (;;) {
-            __syncthreads();
-            if (threadIdx.x == 0) s_cnt = 0;
-            __syncthreads();
-            bool left = false;
+        for (int f0 = 0; f0 < total; f0 += kSplatList) {
 #pragma unroll
             for (int i = 0; i < kSplatPer; i++) {
-                const bool want = ((hit >> i) & 1u) && !((done >> i) & 1u);
-                const unsigned long long m = __ballot(want);
-                if (m) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&s_cnt, __popcll(m));
-                    base = __shfl(base, 0, kWave);
-                    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                    if (want) {
-                        if (slot < kSplatList) {
-                            const int j = j0 + i * kSplatBlock + threadIdx.x;
-                            float cr = 1.0f, cg = 1.0f, cb = 1.0f;
-                            if (col) { cr = col[(size_t)j * 3 + 0]; cg = col[(size_t)j * 3 + 1]; cb = col[(size_t)j * 3 + 2]; }
-                            list[slot] = make_float4(q[i].x, q[i].y, q[i].w, cr);
-                            list_gb[slot] = make_float2(cg, cb);
-                            done |= 1u << i;
-                        } else
-                            left = true;
+                if ((hit >> i) & 1u) {
+                    const int slot = s_tab[i * (kSplatBlock / kWave) + wave] + __popcll(bal[i] & ((1ull << lane) - 1ull)) - f0;
+                    if (slot >= 0 && slot < kSplatList) {
+                        const int j = j0 + i * kSplatBlock + threadIdx.x;
+                        float cr = 1.0f, cg = 1.0f, cb = 1.0f;
+                        if (col) { cr = col[(size_t)j * 3 + 0]; cg = col[(size_t)j * 3 + 1]; cb = col[(size_t)j * 3 + 2]; }
+                        list[slot] = make_float4(q[i].x, q[i].y, q[i].w, cr);
+                        list_gb[slot] = make_float2(cg, cb);
                     }
                 }
             }
-            const int more = __syncthreads_or(left ? 1 : 0);
-            const int cnt = min(s_cnt, kSplatList);
+            __syncthreads();
+            const int cnt = min(total - f0, kSplatList);
             for (int k = share; k < cnt; k += 4) {
                 const float4 p = list[k];
                 const float dx = pxc - p.x, dy = pyc - p.y;
@@ -603,7 +621,7 @@ __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const fl
                     sb += ac * gb.y;
                 }
             }
-            if (!more) break;
+            __syncthreads();
         }
     }
     part[0][share][pix] = sum;

@@ -70,10 +70,13 @@ def test_bit_exact_entry_points_repeat(env):
     np.testing.assert_allclose(T1, T2, atol=1e-12)
 
 
-def test_alignment_loop_run_to_run_bound(env):
-    """The alignment loop is NOT bit-reproducible: its gradient and image sums are fp64 atomics (order varies) and
-    the splat sums a pixel's discs in list order (varies).  Documented bound, asserted here: the first 50 losses
-    of every start agree to 1e-6 relative between two runs, Chamfer-only and full objective (white and coloured)."""
+def test_alignment_loop_repeats(env):
+    """The alignment loop, same input twice: identical loss histories and transforms, Chamfer-only and full
+    objective (white and coloured).  Its reductions are fp64 atomics over float-derived terms (their order varies,
+    the float results do not: no difference seen in any run), and the splat fills its per-tile lists in ascending
+    point order, so a pixel sums its discs in the same order every time.  (Round 2's arrival-order lists made the
+    full objective drift run to run: 3e-5 after 5 steps, 3 % after 50 -- a last-bit difference in the image flips
+    a soft-mask pixel in or out of fp32 sigmoid saturation and the loss jumps by 100 / P.)"""
     torch = env
     from genpc_amd.optim_registration.diff_obj_pose import object_pose_optimization
     rng = np.random.default_rng(5)
@@ -90,5 +93,7 @@ def test_alignment_loop_run_to_run_bound(env):
     col = torch.from_numpy((0.2 + 0.8 * rng.random((4000, 3))).astype(np.float32)).cuda()
     pcol = torch.from_numpy((0.2 + 0.8 * rng.random((len(partial), 3))).astype(np.float32)).cuda()
     for kw in (dict(cd_only=True), dict(radius=0.02), dict(radius=0.02, complete_col=col, partial_col=pcol)):
-        runs = [object_pose_optimization(C, P, lr=0.01, iters=60, return_history=True, **kw)[1] for _ in range(2)]
-        np.testing.assert_allclose(runs[0][:, :50], runs[1][:, :50], rtol=1e-6, err_msg=str(kw))
+        runs = [object_pose_optimization(C, P, lr=0.01, iters=60, return_history=True, **kw) for _ in range(3)]
+        for T, h, bp in runs[1:]:
+            np.testing.assert_array_equal(h, runs[0][1], err_msg=str(list(kw)))
+            np.testing.assert_array_equal(T, runs[0][0], err_msg=str(list(kw)))
