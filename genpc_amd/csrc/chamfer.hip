@@ -602,12 +602,11 @@ __global__ __launch_bounds__(kBlock) void chamfer_grad_kernel(int b, int n, cons
 struct NNConfig {
     int r;                // VALU path, queries per lane: 0 = pick, else 2 or 4
     int blocks_per_cu;    // occupancy target used to pick the slice count
-    int mfma;             // 4: cell-sorted pruned search (opt-in: wins when most queries have a near target), 3: two-piece f16 MFMA filter (default), 2: three-piece bf16, 1: fp32 MFMA filter, 0: VALU path
+    int mfma;             // 4: cell-sorted pruned search (opt-in: wins when most queries have a near target), 3: two-piece f16 MFMA filter (default), 1: fp32 MFMA filter (small problems), 0: VALU path (cross-check).  (2 was the bf16 filter, removed in round 3.)
     int q;                // MFMA path, 32-query tiles per wave: 0 = pick, else 1 or 2
     int u;                // MFMA path, tiles per bookkeeping unit: 0 = pick, else 1 or 2
     bool env_path, env_wps;   // GENPC_NN_PATH / GENPC_NN_WPS were given
     int dbg;              // GENPC_NN_DEBUG
-    int pre;              // GENPC_NN_PRE (-1: not given)
 };
 
 // genpc_nn_tune() overrides (-1: use the environment / default).  Thread-local: a test that
@@ -619,10 +618,10 @@ static thread_local int t_tune_path = -1, t_tune_hooks = -1;
 static const NNConfig &nn_config()
 {
     static const NNConfig c = [] {
-        NNConfig k{0, 4, 3, 0, 0, false, false, 0, -1};
+        NNConfig k{0, 4, 3, 0, 0, false, false, 0};
         if (const char *e = getenv("GENPC_NN_R")) k.r = atoi(e);
         if (const char *e = getenv("GENPC_NN_PATH")) {
-            k.mfma = (e[0] == 'v') ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'b' ? 2 : (e[0] == 'f' ? 3 : 4)));
+            k.mfma = (e[0] == 'v') ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'f' ? 3 : 4));
             k.env_path = true;
         }
         if (const char *e = getenv("GENPC_NN_Q")) k.q = atoi(e);
@@ -631,7 +630,6 @@ static const NNConfig &nn_config()
         if (k.u != 1 && k.u != 2 && k.u != 4) k.u = 0;
         if (const char *e = getenv("GENPC_NN_WPS")) { k.blocks_per_cu = atoi(e); k.env_wps = true; }
         if (const char *e = getenv("GENPC_NN_DEBUG")) k.dbg = atoi(e);
-        if (const char *e = getenv("GENPC_NN_PRE")) k.pre = atoi(e);
         if (k.r != 2 && k.r != 4) k.r = 0;
         if (k.blocks_per_cu < 1) k.blocks_per_cu = 1;
         return k;
@@ -659,7 +657,7 @@ static void launch_r(const NNArgs &a, int blocks, hipStream_t st)
 
 static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0, float *d0, int *i0,
                       const float *q1, int n1, const float *t1, int m1, float *d1, int *i1, hipStream_t st,
-                      float radius2 = __builtin_inff(), const NNSorted *srt = nullptr)
+                      float radius2 = __builtin_inff())
 {
     // A direction with no queries or no targets does nothing (the reference's
     // loops do not execute, outputs keep the caller's zeros).
@@ -696,27 +694,15 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // measured on MI355X (tools/nn_sweep.py): below ~6M pairs the single-launch fp32-MFMA
     // kernel wins (1x1024^2 11.0 vs 13.5 us), from 2048^2 on the two-launch f16 filter
     if (path == 3 && pairs < 6e6 && t_tune_path < 0 && !cfg.env_path) path = 1;
-    // Sorted mode (nn_sort.hip; hook 4096 / GENPC_NN_SORT=1): Morton-sort both clouds, then run this very function
-    // on the sorted copies with whole (query block, target slice) pairs culled.  Needs the 512-query blocks of the
-    // f16 filter (>= 2e8 pairs), <= 32 batch elements, both directions on the same two clouds.
-    static const int sort_env = getenv("GENPC_NN_SORT") ? atoi(getenv("GENPC_NN_SORT")) : -1;
-    const bool sort_on = sort_env >= 0 ? sort_env != 0 : (a.debug & 4096) != 0;
-    if (!srt && sort_on && path == 3 && pairs >= 2e8 && b <= 32 && radius2 == __builtin_inff() && !cfg.q &&
-        (nd == 1 || (nd == 2 && q1 == t0 && t1 == q0)) && n0 >= 4096 && m0 >= 4096 && m0 <= (1 << 19) && n0 <= (1 << 19)) {
-        NNSorted S{};
-        if (!nn_sort_prepare(b, q0, n0, t0, m0, st, S)) return 0;
-        S.orig[0] = q0;
-        S.orig[1] = t0;
-        return nn_forward(b, nd, S.s[0], n0, S.s[1], m0, d0, i0, S.s[1], n1, S.s[0], m1, d1, i1, st, radius2, &S);
-    }
     if (radius2 < __builtin_inff()) path = 4;      // only the cell search knows how to stop at a distance
     if (path == 4) {
         // three launches, O(N + M) work (nn_grid.hip); needs both directions to be each other's swap
         if (nd == 1 || (a.dir[1].q == a.dir[0].t && a.dir[1].t == a.dir[0].q)) return launch_nn_grid(a, st);
         path = 3;
     }
-    const bool f16 = path == 3;      // same planning as the bf16 path, other kernel
-    if (f16) path = 2;
+    if (path == 2) path = 3;                             // (the bf16 filter's number: gone)
+    const bool f16 = path == 3;
+    if (f16) path = 2;                                   // below, 2 = "filter + finish kernel" planning
     if (path == 2 && nt_max >= (1 << 25)) path = 1;      // finish kernel packs tile indices in 21 bits
     // R = 4 (fewer LDS reads per pair, more independent chains per lane) when the query
     // blocks alone fill the chip; R = 2 otherwise: twice the blocks, half the per-wave
@@ -734,12 +720,12 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         long long unsplit2 = 0;
         for (int d = 0; d < nd; d++) unsplit2 += (long long)b * ceil_div(a.dir[d].nq, 256);
         // fp32 MFMA: Q = 2 measured slower at every size from 1x2048^2 to 13x16384^2
-        // f16 / bf16 filters: 512-query blocks (Q = 4) once there is enough work to fill the chip with
+        // f16 filter: 512-query blocks (Q = 4) once there is enough work to fill the chip with
         // them (1x16384^2 37.8 vs 49.7 us), 256-query blocks below (1x8192^2 20.4 vs 21.6 us)
         q = path == 2 ? (pairs >= 2e8 ? 4 : 2) : 1;
         (void)unsplit2;
     }
-    // bf16 / f16 filters: at least two accumulator chains per wave (see the hazard note in nn_f16.hip)
+    // f16 filter: at least two accumulator chains per wave (see the hazard note in nn_f16.hip)
     if (path == 2 && q < 2) q = 2;
     if (path == 2 && !cfg.env_wps) want_blocks = (long long)kNumCU * (q == 4 ? 2 : (q == 2 ? 3 : 4));   // resident blocks per CU (VGPRs)
     const int qper = path ? 128 * q : kBlock * r;       // queries per block
@@ -770,7 +756,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // bookkeeping per 64 targets once a block has enough of them to amortise the coarser
     // re-scan (measured: 1x2048^2 14.5 vs 16.0 us, 1x16384^2 63.6 vs 61.2, 13x16384^2 644 vs 590)
     const int u = (cfg.u == 1 || cfg.u == 2) ? cfg.u : (len >= 2048 ? 2 : 1);
-    // split-bf16 path: the launch runs in rounds of `want_blocks` resident blocks, so the
+    // filter path: the launch runs in rounds of `want_blocks` resident blocks, so the
     // slice count is chosen to minimise rounds x (targets per block + a fixed per-block
     // cost worth ~192 targets), over the slice counts that keep a query's candidate lists
     // (slices x NL; NL = 2 lists per lane below three slices: a query is flagged only when THREE
@@ -816,13 +802,6 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         }
         tight = best_res == 3;
         len = best_len;
-        if (srt) {
-            // the slices are the culling granularity: 1024 sorted targets (a compact piece of the cloud), more only
-            // to keep a query's lists within 16 and the need masks within 32 bits
-            len = 1024;
-            while (ceil_div64(nt_max, len) > 16) len += 512;
-            tight = blocks_at(len) >= 3LL * kNumCU * 3;
-        }
         (void)lists_of(len, nl);
         a.slice_len = (int)len;
         pwords = 3 * nl;
@@ -838,7 +817,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         D.unit_begin = units;
         tb += (long long)D.slices * b * D.qblocks;
         units += b * D.qblocks;
-        if (D.slices > 1 || path == 2) {      // the bf16 path always hands its lists to a second launch
+        if (D.slices > 1 || path == 2) {      // the filter always hands its lists to a second launch
             part += (size_t)D.slices * b * D.nq * pwords;
             any_split = true;
         }
@@ -871,34 +850,12 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
             }
         }
     }
-    if (srt) {
-        if (!(path == 2 && f16 && q == 4)) {
-            set_error("nn sort: planner did not choose the 512-query f16 filter");
-            return 0;
-        }
-        const int cloud_of_q[2] = {0, 1};
-        if (!nn_sort_plan(a, *srt, cloud_of_q, qper, st)) return 0;
-    }
     if (path == 2) {
-        // pre-split targets + LDS-DMA (one more launch) once every target is staged by many blocks
-        if (f16) {
-            // bookkeeping unit: the finish kernel re-reads 16 targets per tile of every candidate unit --
-            // per QUERY, while the filter's work is per PAIR: short target clouds (many queries per
-            // pair) take 64-target units (half the re-read, +10 % filter VALU), long ones 128
-            const int fu = cfg.u == 2 || cfg.u == 4 ? cfg.u : (nt_max <= 8192 ? 2 : 4);
-            // fused finish (the last-arriving filter block of a query block finishes it; no second
-            // launch), hook 1024 / GENPC_NN_FUSE=1.  Measured two launches vs fused on uniform clouds:
-            // 13x16384^2 313 vs 296 us, 8x32768^2 636 vs 606, 64x4096^2 135 vs 120, 4x16384^2 101 vs 103,
-            // 1x16384^2 36 vs 59 (the tail is exposed).  NOT a default: on scan-like clouds (partial vs
-            // complete shapes, many near-ties) a block's 512 queries list more than the 4096 work items its
-            // LDS holds and the overflow falls to the exhaustive pass -- the 8 x 32768 alignment loop went
-            // from 1.35 s to 3.86 s.  The finish kernel (64 queries per block) has no such cliff.
-            static const int fuse_env = getenv("GENPC_NN_FUSE") ? atoi(getenv("GENPC_NN_FUSE")) : -1;
-            const int fuse = srt ? 0 : (fuse_env >= 0 ? fuse_env : ((a.debug & 1024) ? 1 : 0));
-            return launch_nn_f16(a, q, fu, nl, tight ? 1 : 0, fuse, tb, st);
-        }
-        const int pre = cfg.pre >= 0 ? cfg.pre : ((a.debug & 256) ? 1 : 0);      // measured: 13x16384^2 401+8 us vs 410 us, 1x16384^2 35+5 vs 36 -- does not pay
-        return launch_nn_bf16(a, q, pre, nl, tb, st);
+        // bookkeeping unit: the finish kernel re-reads 16 targets per tile of every candidate unit --
+        // per QUERY, while the filter's work is per PAIR: short target clouds (many queries per
+        // pair) take 64-target units (half the re-read, +10 % filter VALU), long ones 128
+        const int fu = cfg.u == 2 || cfg.u == 4 ? cfg.u : (nt_max <= 8192 ? 2 : 4);
+        return launch_nn_f16(a, q, fu, nl, tight ? 1 : 0, tb, st);
     } else if (path) {
         if (q == 2) { if (u == 2) launch_mfma<2, 2>(a, (int)tb, st); else launch_mfma<2, 1>(a, (int)tb, st); }
         else        { if (u == 2) launch_mfma<1, 2>(a, (int)tb, st); else launch_mfma<1, 1>(a, (int)tb, st); }
@@ -915,7 +872,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
 GENPC_API int genpc_nn_tune(int path, int hooks)
 {
     const int prev = genpc::t_tune_path >= 0 ? genpc::t_tune_path : genpc::nn_config().mfma;
-    if (path >= 0 && path <= 4) genpc::t_tune_path = path;
+    if (path >= 0 && path <= 4 && path != 2) genpc::t_tune_path = path;
     if (hooks >= 0) genpc::t_tune_hooks = hooks;
     return prev;
 }

@@ -43,19 +43,6 @@ struct NNDir {
     int unit_begin;    // first arrival counter of this direction
 };
 
-// sorted mode (nn_sort.hip): the q / t of NNDir are Morton-sorted copies; results go back through the
-// permutations.  Kept out of NNArgs (one pointer there): the kernel argument block is read at the start of every
-// launch, and growing it by these 96 bytes cost the default path 0.5 us of its 36 (measured on one box).
-struct NNSortDev {
-    const int *perm_q[2];      // [B, nq] sorted position -> original index, per direction
-    const int *perm_t[2];      // [B, nt]
-    const float *q_orig[2];    // the caller's arrays (exhaustive pass: the reference's order matters there)
-    const float *t_orig[2];
-    const unsigned *need[2];   // [B, qblocks] bit s: slice s can hold a neighbour of this query block
-    const int *work;           // the filter runs only the listed blocks (ids in the planner's numbering)
-    const int *work_count;
-};
-
 struct NNArgs {
     NNDir dir[2];
     int ndir;
@@ -66,7 +53,6 @@ struct NNArgs {
     int fma;           // arithmetic mode of this call (read once at the entry point; host side only)
     unsigned long long *stats;   // hook 512: [0] queries, [1] exhaustive re-dos, [2] exact pieces; else null
     float radius2;     // grid path only: search limit (squared); +inf = none.  Queries with no target within it get (+inf, -1)
-    const NNSortDev *srt;   // sorted mode (device memory), null otherwise
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -288,193 +274,8 @@ __device__ __forceinline__ void rescan_half(const float *__restrict__ T, int nt,
     }
 }
 
-// The same 16 targets of a SORTED cloud: the reference's tie rule is the lowest ORIGINAL index, so the minimum is
-// taken over (distance bits, perm[target]) keys.  Distances are >= 0 or NaN; a NaN key is larger than any real one.
-template <int FMA>
-__device__ __forceinline__ unsigned long long rescan_half_perm(const float *__restrict__ T, const int *__restrict__ perm, int nt,
-                                                               int base, int h, float qx, float qy, float qz)
-{
-    const int first = base + 16 * h;
-    unsigned long long best = ~0ull;
-    for (int c = 0; c < 16; c++) {
-        int kk = first + c;
-        kk = kk < nt ? kk : nt - 1;
-        const float *tp = T + (size_t)kk * 3;
-        const float dd = sqdist<FMA>(tp[0] - qx, tp[1] - qy, tp[2] - qz);
-        const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)perm[kk];
-        best = key < best ? key : best;
-    }
-    return best;
-}
-
-
-// ---------------------------------------------------------------------------
-// The finish step for the NQ queries [qfirst, qfirst + NQ) of one (direction, batch element), run by
-// the LAST slice block of nn_f16_kernel<..., FUSE = 1> to arrive for that query block instead of by a
-// second launch (nn_finish_kernel, nn_bf16.hip, whose logic this restates for NQ > 64): gather the
-// query's lists (agent-scope loads: the other slices' blocks published them with agent-scope stores),
-// derive the acceptance threshold tau, turn listed units that are not provably out into work items of
-// 16 targets, evaluate them exactly, write (distance, first index); queries whose proof fails go
-// through nn_exhaustive.  The slice maxima of |t'|^2 travel in the low half of each list's third word.
-// lds: >= nn_finish_block_lds<NQ>() bytes, 16-byte aligned; s_red / s_fi: kWavesPerBlock entries.
-constexpr int kFusedWork = 4096;       // work-item capacity of the fused finish (512 queries x 8 pieces)
-template <int NQ>
-__host__ __device__ constexpr int nn_finish_block_lds() { return NQ * (8 + 4 + 4 + 4 + 4) + kFusedWork * 4 + 64; }
-
-template <int FMA, int NQ>
-__device__ __forceinline__ void nn_finish_block(const NNArgs &a, const NNDir &D, int batch, int qfirst, int nl, int upieces,
-                                                float kqt, float ktt, float t2min, char *lds, float *s_red, int *s_fi)
-{
-    unsigned long long *s_best = (unsigned long long *)lds;              // (distance bits << 32 | index)
-    float *s_tau = (float *)(lds + NQ * 8);
-    float *s_qq = s_tau + NQ;
-    int *s_qflag = (int *)(s_qq + NQ);
-    int *s_flagged = s_qflag + NQ;
-    unsigned *s_work = (unsigned *)(s_flagged + NQ);
-    int *s_misc = (int *)(s_work + kFusedWork);                          // [0] work items, [1] flagged queries
-    const int nq = D.nq, nt = D.nt;
-    const float *__restrict__ Qp = D.q + (size_t)batch * nq * 3;
-    const float *__restrict__ T = D.t + (size_t)batch * nt * 3;
-    float *__restrict__ od = D.out_d + (size_t)batch * nq;
-    int *__restrict__ oi = D.out_i + (size_t)batch * nq;
-    const size_t bnq = (size_t)a.b * nq;
-    const unsigned long long *P = D.part + (size_t)batch * nq;
-    const int nlists = D.slices * nl;
-    const float *cptr = a.dir[0].t + (size_t)batch * a.dir[0].nt * 3;      // common centre of the filter
-    const float ccx = cptr[0], ccy = cptr[1], ccz = cptr[2];
-    if (threadIdx.x == 0) { s_misc[0] = 0; s_misc[1] = 0; }
-    // pass 1 over the lists: smallest approximate value, largest |t'|^2; then tau (fp64, once per query).
-    // Lists are read eight at a time into registers: the loads of a batch are in flight together (read one
-    // by one, each is a round trip to L2 -- measured: the fused step's tail went from ~30 us to a few).
-    constexpr int kLB = 8;
-    for (int ql = threadIdx.x; ql < NQ; ql += kBlock) {
-        int j = qfirst + ql;
-        j = j < nq ? j : nq - 1;
-        float amin = __builtin_inff(), tmax2 = 0.0f;
-        const float qx0 = Qp[(size_t)j * 3 + 0], qy0 = Qp[(size_t)j * 3 + 1], qz0 = Qp[(size_t)j * 3 + 2];
-        for (int l0 = 0; l0 < nlists; l0 += kLB) {
-            unsigned long long w0[kLB], w2[kLB];
-#pragma unroll
-            for (int k = 0; k < kLB; k++) {
-                const int li = l0 + k < nlists ? l0 + k : nlists - 1;
-                const unsigned long long *p = P + (size_t)li * 3 * bnq + j;
-                w0[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w2[k] = __hip_atomic_load(p + 2 * bnq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int k = 0; k < kLB; k++) {
-                amin = fminf(amin, __uint_as_float((unsigned)(w0[k] >> 32)));
-                tmax2 = fmaxf(tmax2, __uint_as_float((unsigned)w2[k]));
-            }
-        }
-        const float x = qx0 - ccx, y = qy0 - ccy, z = qz0 - ccz;
-        const float qq = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
-        float t = nn_tau(amin, qq, tmax2, (double)kqt, (double)ktt);
-        if (!(tmax2 >= t2min)) t = __builtin_nanf("");
-        if (!(tmax2 < __builtin_inff()) || !(qq < __builtin_inff())) t = __builtin_nanf("");      // non-finite input
-        if (a.debug & 16) t = __builtin_inff();          // test hook: every listed tile is evaluated
-        s_tau[ql] = t;
-        s_qq[ql] = qq;
-        s_best[ql] = ~0ull;
-        s_qflag[ql] = 0;
-    }
-    __syncthreads();
-    // pass 2: listed units that are not provably out become work items of 16 targets
-    for (int ql = threadIdx.x; ql < NQ; ql += kBlock) {
-        const int j0 = qfirst + ql;
-        const bool live = j0 < nq;
-        const int j = live ? j0 : nq - 1;
-        const float tau = s_tau[ql];
-        bool flag = (a.debug & 8) != 0 || !(tau == tau);
-        for (int l0 = 0; l0 < nlists; l0 += kLB) {
-            unsigned long long w[kLB][3];
-#pragma unroll
-            for (int k = 0; k < kLB; k++) {
-                const int li = l0 + k < nlists ? l0 + k : nlists - 1;
-                const unsigned long long *p = P + (size_t)li * 3 * bnq + j;
-                w[k][0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w[k][1] = __hip_atomic_load(p + bnq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w[k][2] = __hip_atomic_load(p + 2 * bnq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int k = 0; k < kLB; k++) {
-                if (l0 + k >= nlists) continue;
-                if (!(__uint_as_float((unsigned)(w[k][2] >> 32)) > tau)) flag = true;
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float av = __uint_as_float((unsigned)(w[k][e] >> 32));
-                    const int c = (int)(unsigned)w[k][e];
-                    if (av <= tau) {
-                        if (c < 0) {
-                            flag = true;
-                        } else if (live) {
-                            const int h = c & 1, c0 = c & ~1;
-                            const int left = (nt - c0 + 31) >> 5;
-                            const int n2 = left < upieces ? left : upieces;
-                            const int wpos = atomicAdd(&s_misc[0], n2);
-                            if (wpos + n2 <= kFusedWork) {
-                                for (int q2 = 0; q2 < n2; q2++) s_work[wpos + q2] = ((unsigned)ql << 22) | (unsigned)((((c0 >> 5) + q2) << 1) | h);
-                            } else {
-                                flag = true;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (flag && live) s_qflag[ql] = 1;
-    }
-    __syncthreads();
-    const int nwork = min(s_misc[0], kFusedWork);
-    for (int w = threadIdx.x; w < nwork; w += kBlock) {
-        const unsigned it = s_work[w];
-        const int slot = (int)(it >> 22);
-        const int j = qfirst + slot;
-        const float qx = Qp[(size_t)j * 3 + 0], qy = Qp[(size_t)j * 3 + 1], qz = Qp[(size_t)j * 3 + 2];
-        float dd;
-        int ii;
-        rescan_half<FMA>(T, nt, (int)((it & 0x3fffffu) >> 1) << 5, (int)(it & 1u), qx, qy, qz, dd, ii);
-        atomicMin(&s_best[slot], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii);
-    }
-    __syncthreads();
-    for (int ql = threadIdx.x; ql < NQ; ql += kBlock) {
-        const int j = qfirst + ql;
-        if (j >= nq) continue;
-        if (s_qflag[ql]) {
-            s_flagged[atomicAdd(&s_misc[1], 1)] = j;
-        } else {
-            const unsigned long long v = s_best[ql];
-            od[j] = __uint_as_float((unsigned)(v >> 32));
-            oi[j] = (int)(unsigned)v;
-        }
-    }
-    __syncthreads();
-    const int nflag = s_misc[1];
-    if (a.stats && threadIdx.x == 0) {
-        atomicAdd(&a.stats[0], (unsigned long long)min(NQ, nq - qfirst));
-        atomicAdd(&a.stats[1], (unsigned long long)nflag);
-        atomicAdd(&a.stats[2], (unsigned long long)nwork);
-    }
-    for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Qp, T, nt, s_flagged[fidx], od, oi, s_red, s_fi);
-}
-
-int launch_nn_bf16(NNArgs &a, int q, int pre, int nl, long long total_blocks, hipStream_t st);
-int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, int fuse, long long total_blocks, hipStream_t st);
+int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, long long total_blocks, hipStream_t st);
 int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float t2min, hipStream_t st);
 int launch_nn_grid(const NNArgs &a, hipStream_t st);
-
-// sorted mode (nn_sort.hip)
-struct NNSorted {
-    const float *s[2];        // Morton-sorted copies of the two clouds [B, n, 3]
-    const int *perm[2];       // [B, n] sorted position -> original index
-    const unsigned *keys[2];  // [B * n] sorted keys (batch << 27 | 27-bit Morton code)
-    const float *box[2];      // [B, ceil(n / 512), 6] min xyz, max xyz of every 512 sorted points
-    const float *orig[2];     // the caller's arrays
-    int n[2];
-    int b;
-};
-int nn_sort_prepare(int b, const float *c0, int n0, const float *c1, int n1, hipStream_t st, NNSorted &out);
-// per (direction, batch, query block): which target slices can hold a neighbour -> need masks + the work list
-int nn_sort_plan(NNArgs &a, const NNSorted &srt, const int cloud_of_q[2], int qper, hipStream_t st);
 
 }  // namespace genpc

@@ -56,10 +56,12 @@ __device__ __forceinline__ float scale_for(float m)
 // tiles of 32 queries.  U = target tiles per bookkeeping unit, NL = candidate lists per lane.
 // W = waves per SIMD the register budget is held to (Q = 4: 182-202 VGPRs natural -> 2 waves; W = 3
 // caps at 168 with ~50-150 B of scratch: +1 us on a single-round launch, -4 % over many rounds)
-// FUSE = 1: the last slice block to arrive for a query block runs the finish step itself
-// (nn_finish_block, nn.h) instead of leaving it to a second launch; FMA: the arithmetic mode of that
-// step's exact evaluations (unused when FUSE = 0).
-template <int Q, int U, int NL, int W, int FUSE, int FMA>
+// The lists go to nn_finish_kernel (nn_finish.hip), a second launch.  (Round 2 also carried a fused form -- the last
+// slice block to arrive for a query block ran the finish step itself: 13x16384^2 313 -> 296 us but 1x16384^2
+// 36 -> 59, and a cliff on scan-like clouds whose 512-query blocks overflow the block's work list -- and a
+// Morton-sorted mode that culled whole (query block, slice) pairs: 336 -> 532 us on the 13 scans.  Both lost on
+// the inputs that matter and were removed in round 3; DESIGN.md section 4.1 keeps the measurements.)
+template <int Q, int U, int NL, int W>
 __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
 {
     // Hazard: the accumulators are consumed by inline-asm v_min3, which the compiler's hazard
@@ -72,17 +74,11 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
     constexpr int kC = 32 * U;
     constexpr int kRows = kHTile + 64;          // + two spare tiles: the pipeline fetches two tiles ahead
     __shared__ uint4 plane[2][kRows];
-    static_assert(!FUSE || (int)sizeof(uint4) * 2 * kRows >= nn_finish_block_lds<128 * Q>(), "the fused finish reuses the planes");
     __shared__ float s_red[kWavesPerBlock];
-    __shared__ int s_fi[kWavesPerBlock];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int half = lane >> 5, col = lane & 31;
     int bid = blockIdx.x;
-    if (a.srt) {                                   // sorted mode: only the (query block, slice) pairs that can matter
-        if (bid >= *a.srt->work_count) return;
-        bid = a.srt->work[bid];
-    }
     const int d = (a.ndir > 1 && bid >= a.dir[1].block_begin) ? 1 : 0;
     const NNDir &D = a.dir[d];
     bid -= D.block_begin;
@@ -255,11 +251,9 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
         }
     }
 
-    // max |t'|^2 of the slice, for the bound of the finish step.  Two-launch form: every query block
-    // sees the same targets, the first one publishes.  Fused form: every block needs it (it travels
-    // with the block's lists).
-    float tm = 0.0f;
-    if (FUSE || qb == 0) {
+    // max |t'|^2 of the slice, for the bound of the finish step: every query block sees the same targets, the
+    // first one publishes
+    if (qb == 0) {
         // non-finite targets: +inf tells the finish step to answer every query of this cloud
         // exhaustively (the reference's tile semantics for NaNs, nn_exhaustive in nn.h)
         if (nf != nf) tmax2 = __builtin_inff();
@@ -268,12 +262,12 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
         __syncthreads();
         if (lane == 0) s_red[wave] = tmax2;
         __syncthreads();
-        tm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        if (!FUSE && threadIdx.x == 0) D.tmaxp[(size_t)batch * D.slices + slice] = tm;
+        const float tm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        if (threadIdx.x == 0) D.tmaxp[(size_t)batch * D.slices + slice] = tm;
     }
 
     // Publish the lists: the two lane halves folded, NL lists of three 8-byte words
-    // (a1,c1) (a2,c2) (a3, slice max |t'|^2 when fused) per query and slice.
+    // (a1,c1) (a2,c2) (a3, -) per query and slice.
     const size_t bnq = (size_t)a.b * nq;
     unsigned long long *P = D.part + (size_t)batch * nq;
 #pragma unroll
@@ -296,33 +290,11 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
                 unsigned long long *p = P + (size_t)(slice * NL + n) * 3 * bnq + j;
                 const unsigned long long w0 = ((unsigned long long)__float_as_uint(f.a1) << 32) | (unsigned)f.c1;
                 const unsigned long long w1 = ((unsigned long long)__float_as_uint(f.a2) << 32) | (unsigned)f.c2;
-                if (FUSE) {
-                    // 8-byte agent-scope stores here, 8-byte agent-scope loads in the merging block: no fence
-                    // needed around the ticket (a release would write back the XCD's dirty L2 lines)
-                    __hip_atomic_store(p, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(p + bnq, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(p + 2 * bnq, ((unsigned long long)__float_as_uint(f.a3) << 32) | __float_as_uint(tm),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    p[0] = w0;
-                    p[bnq] = w1;
-                    p[2 * bnq] = (unsigned long long)__float_as_uint(f.a3) << 32;
-                }
+                p[0] = w0;
+                p[bnq] = w1;
+                p[2 * bnq] = (unsigned long long)__float_as_uint(f.a3) << 32;
             }
         }
-    }
-    if (FUSE) {
-        int *cnt = a.arrive + D.unit_begin + batch * D.qblocks + qb;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // also: every wave is done with the planes
-        int *s_ticket = (int *)&plane[0][0];
-        if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int ticket = *s_ticket;
-        __syncthreads();                       // the ticket word is plane memory: read before reuse
-        if (ticket != D.slices - 1) return;
-        if (threadIdx.x == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-        nn_finish_block<FMA, 128 * Q>(a, D, batch, qb * 128 * Q, NL, U, (float)kQTh, (float)kTTh, 0.0f, (char *)&plane[0][0], s_red, s_fi);
     }
 }
 
@@ -331,24 +303,11 @@ static void launch_main(const NNArgs &a, int blocks, int u, bool tight, hipStrea
 {
     // tight: three waves per SIMD for the 512-query blocks (planner: launches of several rounds)
     if (u == 2) {
-        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 3 : 4), 0, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 2 : 4), 0, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
+        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 3 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 2 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
     } else {
-        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 3 : 4), 0, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 2 : 4), 0, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
-    }
-}
-
-// fused finish: the 512-query blocks, two or three (tight) waves per SIMD
-template <int NL, int W>
-static void launch_fused(const NNArgs &a, int blocks, int u, hipStream_t st)
-{
-    if (u == 2) {
-        if (a.fma) hipLaunchKernelGGL((nn_f16_kernel<4, 2, NL, W, 1, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<4, 2, NL, W, 1, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
-    } else {
-        if (a.fma) hipLaunchKernelGGL((nn_f16_kernel<4, 4, NL, W, 1, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<4, 4, NL, W, 1, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
+        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 3 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 2 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
     }
 }
 
@@ -357,9 +316,8 @@ static bool g_prof_on = false;
 static hipEvent_t g_prof_e0 = nullptr, g_prof_e1 = nullptr;
 
 // Launches the filter and the finish kernel.  q / u / nl as chosen by the planner in chamfer.hip.
-int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, int fuse, long long total_blocks, hipStream_t st)
+int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, long long total_blocks, hipStream_t st)
 {
-    fuse = fuse && q == 4;      // instantiated for the 512-query blocks
     size_t bytes = 0;
     size_t off_t[2];
     for (int d = 0; d < a.ndir; d++) {
@@ -375,10 +333,7 @@ int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, int fuse, long lon
         if (!g_prof_e0) { (void)hipEventCreate(&g_prof_e0); (void)hipEventCreate(&g_prof_e1); }
         (void)hipEventRecord(g_prof_e0, st);
     }
-    if (fuse) {
-        if (tight) { if (nl == 2) launch_fused<2, 3>(a, blocks, u, st); else launch_fused<1, 3>(a, blocks, u, st); }
-        else       { if (nl == 2) launch_fused<2, 2>(a, blocks, u, st); else launch_fused<1, 2>(a, blocks, u, st); }
-    } else if (q == 4) {
+    if (q == 4) {
         if (nl == 2) launch_main<4, 2>(a, blocks, u, tight != 0, st);
         else launch_main<4, 1>(a, blocks, u, tight != 0, st);
     } else {
@@ -387,7 +342,6 @@ int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, int fuse, long lon
     }
     if (g_prof_on) (void)hipEventRecord(g_prof_e1, st);
     if (!check(hipGetLastError(), "nn_f16_kernel launch")) return 0;
-    if (fuse) return 1;
     return launch_nn_finish(a, nl, u, (float)kQTh, (float)kTTh, 0.0f, st);
 }
 

@@ -1,0 +1,197 @@
+// nn_finish.hip -- second launch of the filtered nearest-neighbour paths (the f16 MFMA filter of nn_f16.hip):
+// the exact step.  A block takes 64 queries of one (direction, batch element): it gathers each query's candidate
+// lists, derives the acceptance threshold tau from the smallest approximate value,
+// evaluates every listed tile that is not provably out with the reference's exact
+// arithmetic (work items of 16 targets, spread over the block), and writes
+// (distance, first index).  A query with a list whose THIRD minimum is not provably out
+// (or with non-finite values) is re-done exhaustively by the block (nn_exhaustive, nn.h: the reference's
+// 512-target tile semantics).  The proof obligation is spelled out in nn_f16.hip and DESIGN.md section 4.1.
+//
+// (Round 1-2 history: this kernel was written for a three-piece bf16 filter -- 27 products in two chained
+// v_mfma_f32_32x32x16_bf16 -- which the two-piece f16 filter superseded at half the matrix work; the bf16 kernel,
+// its pre-split / LDS-DMA staging variant and the Morton-sorted culling mode were removed in round 3.)
+#include "nn.h"
+
+namespace genpc {
+
+constexpr int kFQ = 64;                // queries per finish block
+constexpr int kFWork = 2048;           // work-item capacity (64 queries x 32 pieces)
+
+template <int FMA>
+__global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int upieces, float kqt, float ktt, float t2min)
+{
+    __shared__ unsigned long long s_best[kFQ];   // (distance bits << 32 | index): atomic min == (distance, first index)
+    __shared__ float4 s_q[kFQ];
+    __shared__ float s_a[4][kFQ];
+    __shared__ int s_qflag[kFQ];
+    __shared__ float s_tau[kFQ], s_qq[kFQ];
+    __shared__ int s_flagged[kFQ];
+    __shared__ unsigned s_work[kFWork];          // query slot << 22 | tile (first target / 32) << 1 | lane half
+    __shared__ float s_red[kWavesPerBlock];
+    __shared__ int s_fi[kWavesPerBlock];
+    __shared__ int s_misc[2];                    // work items, flagged queries
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    int bid = blockIdx.x;
+    const int d = (a.ndir > 1 && bid >= a.dir[1].fin_begin) ? 1 : 0;
+    const NNDir &D = a.dir[d];
+    bid -= D.fin_begin;
+    const int nq = D.nq, nt = D.nt;
+    const int fblocks = (nq + kFQ - 1) / kFQ;
+    const int batch = bid / fblocks, fb = bid % fblocks;
+    const float *__restrict__ Qp = D.q + (size_t)batch * nq * 3;
+    const float *__restrict__ T = D.t + (size_t)batch * nt * 3;
+    float *__restrict__ od = D.out_d + (size_t)batch * nq;
+    int *__restrict__ oi = D.out_i + (size_t)batch * nq;
+    const size_t bnq = (size_t)a.b * nq;
+    const unsigned long long *P = D.part + (size_t)batch * nq;
+    const int nlists = D.slices * nl;
+
+    const int ql = threadIdx.x & (kFQ - 1), part = threadIdx.x >> 6;     // part == wave
+    int j = fb * kFQ + ql;
+    const bool live = j < nq;
+    j = live ? j : nq - 1;
+
+    const float *cptr = a.dir[0].t + (size_t)batch * a.dir[0].nt * 3;      // common centre of the filter
+    const float ccx = cptr[0], ccy = cptr[1], ccz = cptr[2];
+    // this thread's lists: li = part + 4k
+    unsigned long long w0[kMaxLists / 4], w1[kMaxLists / 4], w2[kMaxLists / 4];
+    float amin = __builtin_inff();
+#pragma unroll
+    for (int k = 0; k < kMaxLists / 4; k++) {
+        const int li = part + 4 * k;
+        w0[k] = w1[k] = w2[k] = 0x7f800000ull << 32;      // (+inf, 0)
+        if (li < nlists) {
+            const unsigned long long *p = P + (size_t)li * 3 * bnq + j;
+            w0[k] = p[0];
+            w1[k] = p[bnq];
+            w2[k] = p[2 * bnq];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxLists / 4; k++) amin = fminf(amin, __uint_as_float((unsigned)(w0[k] >> 32)));
+    s_a[part][ql] = amin;
+    // max |t'|^2 over the whole target cloud (per-slice maxima of the filter kernel)
+    float tmax2 = 0.0f;
+    {
+        const float *tp = D.tmaxp + (size_t)batch * D.ntmax;
+        for (int i = threadIdx.x; i < D.ntmax; i += kBlock) tmax2 = fmaxf(tmax2, tp[i]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, o));
+        if (lane == 0) s_red[wave] = tmax2;
+    }
+    if (part == 0) {
+        s_q[ql] = make_float4(Qp[(size_t)j * 3 + 0], Qp[(size_t)j * 3 + 1], Qp[(size_t)j * 3 + 2], 0.0f);
+        s_best[ql] = ~0ull;
+        s_qflag[ql] = 0;
+    }
+    if (threadIdx.x == 0) { s_misc[0] = 0; s_misc[1] = 0; }
+    __syncthreads();
+    tmax2 = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const float abest = fminf(fminf(s_a[0][ql], s_a[1][ql]), fminf(s_a[2][ql], s_a[3][ql]));
+    // the threshold is fp64 arithmetic (three square roots): once per query, shared through LDS
+    float qq = 0.0f;
+    if (part == 0) {
+        const float4 qv = s_q[ql];
+        const float x = qv.x - ccx, y = qv.y - ccy, z = qv.z - ccz;
+        qq = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
+        float t = nn_tau(abest, qq, tmax2, (double)kqt, (double)ktt);
+        if (!(tmax2 >= t2min)) t = __builtin_nanf("");      // below the magnitudes the filter's bound covers: exhaustive
+        // non-finite targets anywhere in the cloud (the filter publishes +inf) or a non-finite query:
+        // the reference's result depends on its 512-target tiling, only nn_exhaustive reproduces it
+        if (!(tmax2 < __builtin_inff()) || !(qq < __builtin_inff())) t = __builtin_nanf("");
+        if (a.debug & 16) t = __builtin_inff();          // test hook: every listed tile is evaluated
+        s_tau[ql] = t;
+        s_qq[ql] = qq;
+    }
+    __syncthreads();
+    const float tau = s_tau[ql];
+    qq = s_qq[ql];
+    bool flag = (a.debug & 8) != 0 || !(tau == tau);   // test hook / non-finite input: exhaustive pass
+    int ncand = 0;
+    // a listed tile whose minimum is not provably out becomes work items of 32 targets
+    auto consider = [&](float av, int c) {
+        if (av <= tau) {
+            ncand++;
+            if (c < 0) {
+                flag = true;
+            } else if (live) {
+                // c = first target of the unit | lane half: rows 8i + 4h + (0..3) of each tile
+                const int h = c & 1, c0 = c & ~1;
+                const int left = (nt - c0 + 31) >> 5;
+                const int n2 = left < upieces ? left : upieces;
+                const int w = atomicAdd(&s_misc[0], n2);
+                if (w + n2 <= kFWork) {
+                    for (int k = 0; k < n2; k++) s_work[w + k] = ((unsigned)ql << 22) | (unsigned)((((c0 >> 5) + k) << 1) | h);
+                } else {
+                    flag = true;
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < kMaxLists / 4; k++) {
+        if (!(__uint_as_float((unsigned)(w2[k] >> 32)) > tau)) flag = true;
+        consider(__uint_as_float((unsigned)(w0[k] >> 32)), (int)(unsigned)w0[k]);
+        consider(__uint_as_float((unsigned)(w1[k] >> 32)), (int)(unsigned)w1[k]);
+    }
+    if (flag && live) s_qflag[ql] = 1;
+    if (a.debug & 32) {      // diagnostics: approximate minimum and candidate count instead of the result
+        __syncthreads();
+        if (part == 0) s_a[0][ql] = 0.0f;
+        __syncthreads();
+        atomicAdd(&s_a[0][ql], (float)ncand);
+        __syncthreads();
+        if (part == 0 && live) { od[j] = abest + qq; oi[j] = (int)s_a[0][ql] | (s_qflag[ql] ? 1 << 16 : 0); }
+        return;
+    }
+    __syncthreads();
+    const int nwork = min(s_misc[0], kFWork);
+    for (int w = threadIdx.x; w < nwork && !(a.debug & 1); w += kBlock) {
+        const unsigned it = s_work[w];
+        const int slot = (int)(it >> 22);
+        const float4 qv = s_q[slot];
+        float dd;
+        int ii;
+        rescan_half<FMA>(T, nt, (int)((it & 0x3fffffu) >> 1) << 5, (int)(it & 1u), qv.x, qv.y, qv.z, dd, ii);
+        atomicMin(&s_best[slot], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii);
+    }
+    __syncthreads();
+    if (part == 0 && live) {
+        if (s_qflag[ql]) {
+            s_flagged[atomicAdd(&s_misc[1], 1)] = j;
+        } else {
+            const unsigned long long v = s_best[ql];
+            od[j] = __uint_as_float((unsigned)(v >> 32));
+            oi[j] = (int)(unsigned)v;
+        }
+    }
+    __syncthreads();
+    const int nflag = s_misc[1];
+    if (a.stats && threadIdx.x == 0) {
+        atomicAdd(&a.stats[0], (unsigned long long)min(kFQ, nq - fb * kFQ));
+        atomicAdd(&a.stats[1], (unsigned long long)nflag);
+        atomicAdd(&a.stats[2], (unsigned long long)nwork);
+    }
+    for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Qp, T, nt, s_flagged[fidx], od, oi, s_red, s_fi);
+}
+
+// Second launch of the filtered paths.  kqt / ktt: coefficients of the filter's error bound.
+int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float t2min, hipStream_t st)
+{
+    long long fb = 0;
+    for (int d = 0; d < a.ndir; d++) {
+        a.dir[d].fin_begin = (int)fb;
+        fb += (long long)a.b * ceil_div(a.dir[d].nq, kFQ);
+    }
+    if (fb > 0x7fffffffLL) {
+        set_error("chamfer: problem too large for one launch");
+        return 0;
+    }
+    if (a.fma)
+        hipLaunchKernelGGL((nn_finish_kernel<1>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, upieces, kqt, ktt, t2min);
+    else
+        hipLaunchKernelGGL((nn_finish_kernel<0>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, upieces, kqt, ktt, t2min);
+    return check(hipGetLastError(), "nn_finish_kernel launch") ? 1 : 0;
+}
+
+}  // namespace genpc

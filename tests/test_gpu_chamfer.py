@@ -167,7 +167,7 @@ def test_degenerate_and_extreme_shapes(gp, oracle):
     assert_same(run_hip(gp, a, b, 0), oracle.chamfer_forward(a, b, 0))
 
 
-PATHS = {"valu": 0, "mfma32": 1, "bf16": 2, "f16": 3, "grid": 4}
+PATHS = {"valu": 0, "mfma32": 1, "f16": 3, "grid": 4}
 
 
 def run_path(gp, a, b, mode, path, hooks=0):
@@ -183,24 +183,23 @@ def run_path(gp, a, b, mode, path, hooks=0):
 @pytest.mark.parametrize("path", list(PATHS))
 @pytest.mark.parametrize("mode", [0, 1])
 def test_every_kernel_family_is_bit_exact(gp, oracle, path, mode):
-    """The VALU brute force and the three MFMA filters (fp32, split-bf16, two-piece f16)
+    """The VALU brute force, the two MFMA filters (fp32, two-piece f16) and the cell search
     must all return the oracle's bits: ragged sizes, several slices, unequal clouds."""
     for shape in (((2, 777, 3), (2, 4097, 3)), ((1, 5000, 3), (1, 130, 3)), ((3, 64, 3), (3, 64, 3))):
         a, b = gen_pair(77, *shape)
         assert_same(run_path(gp, a, b, mode, PATHS[path]), oracle.chamfer_forward(a, b, mode))
 
 
-@pytest.mark.parametrize("path", ["mfma32", "bf16", "f16"])
-@pytest.mark.parametrize("hooks", [8, 16, 256])
+@pytest.mark.parametrize("path", ["mfma32", "f16"])
+@pytest.mark.parametrize("hooks", [8, 16])
 def test_filter_fallback_paths(gp, oracle, path, hooks):
     """Test hooks of the filtered paths: 8 sends every query through the exhaustive
-    pass, 16 makes the finish step evaluate every listed tile, 256 (bf16) stages pre-split
-    targets with global_load_lds -- same bits every way."""
+    pass, 16 makes the finish step evaluate every listed tile -- same bits every way."""
     a, b = gen_pair(3, (2, 600, 3), (2, 1500, 3))
     assert_same(run_path(gp, a, b, 1, PATHS[path], hooks), oracle.chamfer_forward(a, b, 1))
 
 
-@pytest.mark.parametrize("path", ["mfma32", "bf16", "f16"])
+@pytest.mark.parametrize("path", ["mfma32", "f16"])
 def test_filter_adversarial_inputs(gp, oracle, path):
     """Inputs chosen against the filters' error bounds and the f16 path's scaling:
     exact ties on an integer grid (many tiles within the bound -> exhaustive pass, first

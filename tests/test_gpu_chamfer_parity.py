@@ -13,7 +13,7 @@ from conftest import ROOT, gen_pair
 
 pytestmark = pytest.mark.gpu
 
-PATHS = {"valu": 0, "mfma32": 1, "bf16": 2, "f16": 3, "grid": 4}
+PATHS = {"valu": 0, "mfma32": 1, "f16": 3, "grid": 4}
 HOOK_COUNT = 512
 
 
@@ -261,88 +261,3 @@ def test_radius_limited_search(gp, oracle, golden, mode):
     finally:
         lib.genpc_set_arith(prev)
     assert lib.genpc_nm_distance_within(1, 4, None, 4, None, -1.0, None, None, None) == -1
-
-
-HOOK_FUSE = 1024
-
-
-@pytest.mark.parametrize("mode", [0, 1])
-def test_fused_finish_elementwise(gp, oracle, golden, mode):
-    """The f16 filter with the finish step run by the last slice block to arrive (hook 1024; the
-    512-query-block variant, i.e. problems of >= 2e8 pairs): bench input, a ragged unequal pair, the
-    13 real scans, with the test hooks that force the exhaustive pass / evaluate every listed unit,
-    and a non-finite case -- every distance and index against the oracle."""
-    a, b = gen_pair(20250101, (1, 16384, 3), (1, 16384, 3))
-    exp = oracle.chamfer_forward(a, b, mode)
-    read_stats(gp)
-    assert_bits(run_hip(gp, a, b, mode, PATHS["f16"], HOOK_FUSE | HOOK_COUNT), exp, "fused")
-    q, ex, pieces = read_stats(gp)
-    assert q == 32768 and ex == 0 and 0 < pieces < 6 * q
-    assert_bits(run_hip(gp, a, b, mode, PATHS["f16"], HOOK_FUSE | 16), exp, "fused, every listed unit")
-    a2, b2 = gen_pair(5, (1, 20001, 3), (1, 11003, 3))
-    assert_bits(run_hip(gp, a2, b2, mode, PATHS["f16"], HOOK_FUSE), oracle.chamfer_forward(a2, b2, mode), "fused ragged")
-    a2[0, 17] = np.nan
-    b2[0, 1024, 1] = np.nan
-    got, e2 = run_hip(gp, a2, b2, mode, PATHS["f16"], HOOK_FUSE), oracle.chamfer_forward(a2, b2, mode)
-    for gg, e in zip(got[2:], e2[2:]):
-        np.testing.assert_array_equal(gg, e)
-    for gg, e in zip(got[:2], e2[:2]):
-        assert np.array_equal(gg, e, equal_nan=True)
-    if mode == 1:
-        g = golden("scans13_fps16384.npz")
-        assert_bits(run_hip(gp, g["partial"][:5], g["gt"][:5], 1, PATHS["f16"], HOOK_FUSE),
-                    oracle.chamfer_forward(g["partial"][:5], g["gt"][:5], 1), "fused scans")
-        grid = np.random.default_rng(3).integers(0, 24, size=(1, 30000, 3)).astype(np.float32)      # exact ties: exhaustive pass
-        assert_bits(run_hip(gp, grid[:, :15000].copy(), grid[:, 15000:].copy(), 1, PATHS["f16"], HOOK_FUSE),
-                    oracle.chamfer_forward(grid[:, :15000].copy(), grid[:, 15000:].copy(), 1), "fused ties")
-        # launches of several rounds (three resident blocks per CU): fused, two launches (hook 2048 is
-        # accepted and means the default) and the planner's own choice agree with the oracle
-        e13 = oracle.chamfer_forward(g["partial"], g["gt"], 1)
-        for hooks, what in ((HOOK_FUSE, "fused"), (2048, "two launches"), (0, "planner")):
-            assert_bits(run_hip(gp, g["partial"], g["gt"], 1, PATHS["f16"], hooks), e13, "13 scans, " + what)
-        a3, b3 = gen_pair(11, (64, 4096, 3), (64, 4096, 3))
-        e64 = oracle.chamfer_forward(a3, b3, 1)
-        for hooks in (HOOK_FUSE, 2048, 0, HOOK_FUSE | 8):
-            assert_bits(run_hip(gp, a3, b3, 1, PATHS["f16"], hooks), e64, "64x4096, hooks %d" % hooks)
-
-
-HOOK_SORT = 4096
-
-
-@pytest.mark.parametrize("mode", [0, 1])
-def test_sorted_mode_elementwise(gp, oracle, golden, mode):
-    """Sorted mode (hook 4096, csrc/nn_sort.hip): both clouds in Morton order, (query block, target slice) pairs
-    whose boxes are farther apart than the block's upper bound are never launched, results keyed on the ORIGINAL
-    indices -- every distance and index against the oracle: bench input, a ragged unequal pair, exact ties
-    (lattice points: the lowest original index must win although the sort moved it), duplicates, the 13 real
-    scans, a batch, non-finite points, with the hooks that force the exhaustive pass / every listed unit."""
-    a, b = gen_pair(20250101, (1, 16384, 3), (1, 16384, 3))
-    exp = oracle.chamfer_forward(a, b, mode)
-    assert_bits(run_hip(gp, a, b, mode, PATHS["f16"], HOOK_SORT), exp, "sorted")
-    assert_bits(run_hip(gp, a, b, mode, PATHS["f16"], HOOK_SORT | 16), exp, "sorted, every listed unit")
-    assert_bits(run_hip(gp, a, b, mode, PATHS["f16"], HOOK_SORT | 8), exp, "sorted, exhaustive")
-    a2, b2 = gen_pair(5, (1, 20001, 3), (1, 11003, 3))
-    assert_bits(run_hip(gp, a2, b2, mode, PATHS["f16"], HOOK_SORT), oracle.chamfer_forward(a2, b2, mode), "sorted ragged")
-    grid = np.random.default_rng(3).integers(0, 24, size=(1, 30000, 3)).astype(np.float32)      # exact ties
-    g1, g2 = grid[:, :15000].copy(), grid[:, 15000:].copy()
-    assert_bits(run_hip(gp, g1, g2, mode, PATHS["f16"], HOOK_SORT), oracle.chamfer_forward(g1, g2, mode), "sorted ties")
-    rng = np.random.default_rng(9)
-    base = (rng.random((6000, 3), dtype=np.float32) - 0.5)
-    dup = base[rng.integers(0, 6000, 16384)][None].copy()                                        # sampled with replacement
-    assert_bits(run_hip(gp, a, dup, mode, PATHS["f16"], HOOK_SORT), oracle.chamfer_forward(a, dup, mode), "sorted duplicates")
-    a3, b3 = gen_pair(11, (3, 12000, 3), (3, 9000, 3))
-    b3 = b3 * 0.3 + 0.2                                                                          # a small cloud inside a large one
-    assert_bits(run_hip(gp, a3, b3, mode, PATHS["f16"], HOOK_SORT), oracle.chamfer_forward(a3, b3, mode), "sorted batch")
-    a4, b4 = a2.copy(), b2.copy()
-    a4[0, 17] = np.nan
-    b4[0, 1024, 1] = np.nan
-    b4[0, 5000, 0] = np.inf
-    got, e4 = run_hip(gp, a4, b4, mode, PATHS["f16"], HOOK_SORT), oracle.chamfer_forward(a4, b4, mode)
-    for gg, e in zip(got[2:], e4[2:]):
-        np.testing.assert_array_equal(gg, e)
-    for gg, e in zip(got[:2], e4[:2]):
-        assert np.array_equal(gg, e, equal_nan=True)
-    if mode == 1:
-        g = golden("scans13_fps16384.npz")
-        assert_bits(run_hip(gp, g["partial"], g["gt"], 1, PATHS["f16"], HOOK_SORT),
-                    oracle.chamfer_forward(g["partial"], g["gt"], 1), "sorted 13 scans")
