@@ -166,8 +166,11 @@ class DepthPrompting:
         cfg.removal_radius, the viewpoint that sees the most points (zbuffer=True: rank with the
         z-buffer test instead)."""
         from .fps import fps_sampling
-        k = min(int(getattr(self.cfg, "downsample_num", 10000)), xyz.shape[0])
-        xyz_fps = xyz[fps_sampling(xyz.contiguous().float(), k).long()]
+        k = int(getattr(self.cfg, "downsample_num", 10000))
+        # (a cloud that is not larger than downsample_num is taken whole: sampling all of its points would only
+        # permute them -- fpsample starts from a random point, so the reference's own order is arbitrary -- and the
+        # visible COUNTS this method ranks by do not depend on the order)
+        xyz_fps = xyz[fps_sampling(xyz.contiguous().float(), k).long()] if xyz.shape[0] > k else xyz.contiguous().float()
         if zbuffer:
             _, counts = self.getVisiblePointsZBuffer(xyz_fps, cams=self.cameras, tol=tol)
         else:

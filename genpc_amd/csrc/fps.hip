@@ -8,10 +8,9 @@
 // FPS is k strictly sequential steps of (update N running minima, arg-max): what a step
 // costs is the LATENCY of its dependency chain, not bandwidth (a step touches no memory but
 // the hand-off).  Round 3 layout, built around that chain (round 2: 2.8 us per step):
-//   * a cloud is owned by W <= 64 workgroups of 256 threads; every thread keeps R <= 16 points and their
-//     running minima in REGISTERS for the whole run -- about 2-4 thousand points per workgroup, one wave per
-//     SIMD, so the update of a step is R x 14 instructions (round 2: 16 points on each of 16 waves of one CU,
-//     1.2 us of VALU issue per step);
+//   * a cloud is owned by W <= 64 workgroups of 192 worker threads; every thread keeps R <= 24 points and their
+//     running minima in REGISTERS for the whole run -- 192 to 4608 points per workgroup, one wave per
+//     SIMD (round 2: 16 points on each of 16 waves of one CU, 1.2 us of VALU issue per step);
 //   * a thread carries the coordinates of its best point along, the wave's best is found with DPP row
 //     rotations + v_readlane (no LDS round trips), the workgroup's best with one LDS exchange;
 //   * the hand-off carries the winner's COORDINATES: {dist, gen | idx, x, y} as one 16-byte write-through
@@ -31,12 +30,14 @@
 
 namespace genpc {
 
-constexpr int kFThreads = 256;
+constexpr int kFThreads = 192;           // worker threads of a workgroup: three waves, the fourth wave coordinates -- one wave per SIMD
 constexpr int kFWaves = kFThreads / kWave;
-constexpr int kFMaxR = 16;
+constexpr int kFMaxR = 24;
 constexpr int kFMaxW = 64;
 constexpr int kFMaxJobs = 8;
-constexpr int kFPointsPerWg = 2048;      // target; the cap of 64 workgroups raises it for clouds beyond 131072 points
+constexpr int kFPointsPerWg = 192;       // target: one point per worker thread.  What a round yields grows with the NUMBER of lists
+                                         // (64 lists x 4 candidates: ~45 samples per exchange; 8 lists: 13), so small clouds are spread
+                                         // over many workgroups too; the cap of 64 workgroups raises the share for clouds beyond 16384 points
 
 struct FpsJobs {
     const float *xyz[kFMaxJobs];
@@ -61,52 +62,31 @@ __device__ __forceinline__ float sqdist_f(float dx, float dy, float dz)
     }
 }
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
+// Wave-wide integer max / min, uniform result, in seven instructions: four row rotations (each one v_max_i32 with a
+// DPP operand -- written in assembly: the compiler emits v_mov_b32 + v_mov_b32_dpp + v_max_i32 per step) leave every
+// row's result in all of its lanes, row_bcast:15 / row_bcast:31 fold the rows into lane 63, one v_readlane fetches it.
+// (s_nop 1: a VGPR written by a VALU instruction needs two wait states before a DPP read.)
+#define GENPC_WAVE_REDUCE_I32(OP)                                                                         \
+    int r;                                                                                                \
+    asm volatile("s_nop 1\n\t"                                                                            \
+                 OP " %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                                 \
+                 "s_nop 1\n\t"                                                                            \
+                 OP " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                                 \
+                 "s_nop 1\n\t"                                                                            \
+                 OP " %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"                                 \
+                 "s_nop 1\n\t"                                                                            \
+                 OP " %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                                 \
+                 "s_nop 1\n\t"                                                                            \
+                 OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                              \
+                 "s_nop 1\n\t"                                                                            \
+                 OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                              \
+                 "s_nop 1"                                                                                \
+                 : "=&v"(r)                                                                               \
+                 : "v"(v));                                                                               \
+    return __builtin_amdgcn_readlane(r, 63);
 
-// maximum over the wave, uniform result: four row rotations leave every row's maximum in all of its
-// lanes, four v_readlane fold the rows (values are never NaN here)
-__device__ __forceinline__ float wave_max_f32(float v)
-{
-    v = fmaxf(v, dpp_f32<0x128>(v));      // row_ror:8
-    v = fmaxf(v, dpp_f32<0x124>(v));      // row_ror:4
-    v = fmaxf(v, dpp_f32<0x122>(v));      // row_ror:2
-    v = fmaxf(v, dpp_f32<0x121>(v));      // row_ror:1
-    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return fmaxf(fmaxf(a, b), fmaxf(c, d));
-}
-
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v)
-{
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
-}
-
-__device__ __forceinline__ int wave_min_i32(int v)
-{
-    v = min(v, dpp_i32<0x128>(v));
-    v = min(v, dpp_i32<0x124>(v));
-    v = min(v, dpp_i32<0x122>(v));
-    v = min(v, dpp_i32<0x121>(v));
-    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    return min(min(a, b), min(c, d));
-}
-
-// the lane holding the wave's best (largest v, then lowest index; indices are distinct): uniform lane number.
-// Branch-free: ties are the rule, not the exception, once most points are selected (distance 0 everywhere).
-__device__ __forceinline__ int wave_best_lane(float v, int idx, float m)
-{
-    const int cand = v == m ? idx : 0x7fffffff;
-    const int best = wave_min_i32(cand);
-    return __ffsll((long long)__ballot(cand == best)) - 1;
-}
+__device__ __forceinline__ int wave_min_i32(int v) { GENPC_WAVE_REDUCE_I32("v_min_i32_dpp") }
+__device__ __forceinline__ int wave_max_i32_dpp(int v) { GENPC_WAVE_REDUCE_I32("v_max_i32_dpp") }
 
 __device__ __forceinline__ float lane_f32(float v, int lane)
 {
@@ -130,7 +110,9 @@ __device__ __forceinline__ void store_sc_b64(void *p, uint2 v)
 
 constexpr int kFT = 4;          // candidates a workgroup publishes per exchange
 constexpr int kFBatch = 64;     // most samples drawn from one exchange
-constexpr int kFBlock = kFThreads + kWave;     // four waves own the points, a fifth coordinates
+constexpr int kFBlock = kFThreads + kWave;     // three waves own the points, a fourth coordinates: each has a SIMD to itself (a fifth
+                                               // wave shared its SIMD with a worker, and the replay -- a chain of dependent
+                                               // cross-lane steps -- got every other issue slot: 1200 cycles per pick)
 
 struct FpsCand {          // 32 bytes
     uint4 a;              // dist bits, gen << 20 | idx, x bits, y bits
@@ -168,31 +150,29 @@ __device__ __forceinline__ void load_slot(const FpsSlot *p, u32x4 (&a)[kFT], u32
 //   exchange always qualifies, so a round never stalls; with points dealt to workgroups round-robin the top of
 //   the global order is spread over many lists and a round draws tens of samples (measured: 30 at 172000
 //   points, 13 at 16384, 8.5 at 8192).
-// Inside a workgroup: waves 0..3 own the points (registers); wave 4, the coordinator, owns none.  It merges the
+// Inside a workgroup: waves 0..2 own the points (registers); wave 3, the coordinator, owns none.  It merges the
 // waves' lists, publishes, polls, replays -- and hands every pick to the workers through LDS (s_piv + a progress
 // word) the moment it is made, so the workers lower their running minima WHILE the replay goes on (the replay is a
 // chain of dependent cross-lane steps, ~400 cycles per pick, and would otherwise leave three SIMDs idle).  One
 // barrier per round: workers' lists ready -> coordinator.
 constexpr unsigned kProgDone = 0x8000u, kProgFinal = 0x4000u, kProgAbort = 0x2000u, kProgCount = 0x0fffu;
 
+// The progress word and the pivots it announces are both LDS, written by ONE wave and read by the others: the LDS unit
+// serves a wave's requests in issue order, so "pivot, then word" on the writer and "word, then pivot" on the readers
+// need no hardware fence -- only the compiler must keep the order (a release / acquire pair at workgroup scope also
+// waits for the wave's outstanding GLOBAL stores: ~500 cycles per pick next to the 16-byte publishes).
 __device__ __forceinline__ void prog_store(unsigned *p, unsigned v)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ unsigned prog_load(unsigned *p)
 {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-    v = max(v, dpp_i32<0x128>(v));
-    v = max(v, dpp_i32<0x124>(v));
-    v = max(v, dpp_i32<0x122>(v));
-    v = max(v, dpp_i32<0x121>(v));
-    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    return max(max(a, b), max(c, d));
+    asm volatile("" ::: "memory");
+    const unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    return v;
 }
 
 // The lane with the wave's best key.  Distances are >= 0 or one of the negative sentinels (-1 padding, -2 dead),
@@ -202,7 +182,7 @@ __device__ __forceinline__ int wave_max_i32(int v)
 __device__ __forceinline__ int wave_argbest(float v, int idx, float &m)
 {
     const int vb = __float_as_int(v);
-    const int mb = wave_max_i32(vb);
+    const int mb = wave_max_i32_dpp(vb);
     m = __int_as_float(mb);
     const unsigned long long mask = __ballot(vb == mb);
     if (__popcll(mask) == 1) return __ffsll((long long)mask) - 1;
@@ -295,7 +275,7 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
         return;
     }
 
-    // ---------------------------------------------------------------------- coordinator (wave 4)
+    // ---------------------------------------------------------------------- coordinator (the last wave)
     int *__restrict__ out = jobs.out[job];
     FpsSlot *S = slots + jobs.slot0[job];
     int s = 1;                                 // samples drawn so far
@@ -402,7 +382,6 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
             if (lane == 0) {
                 s_piv[mm][0] = qx; s_piv[mm][1] = qy; s_piv[mm][2] = qz;
                 s_piv[mm][3] = __int_as_float(mi);
-                if (wg == 0) out[s + mm] = mi;
             }
             mm++;
             if (s + mm >= k || mm == kFBatch) break;
@@ -413,8 +392,10 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
                 cd[c] = cd[c] < dd ? cd[c] : dd;        // dead entries stay at -2
             }
         }
+        if (lane == 0) prog_store(&s_prog, (round << 16) | kProgDone | (s + mm >= k ? kProgFinal : 0u) | (unsigned)mm);
+        // the samples of the round, after the workers have been released (no global store inside the pick loop)
+        if (wg == 0 && lane < mm) out[s + lane] = __float_as_int(s_piv[lane][3]);
         s += mm;
-        if (lane == 0) prog_store(&s_prog, (round << 16) | kProgDone | (s >= k ? kProgFinal : 0u) | (unsigned)mm);
     }
     if (timed_out && lane == 0) prog_store(&s_prog, (round << 16) | kProgDone | kProgAbort);
     // a hand-off that timed out (workgroups of a cloud not co-resident) poisons the result visibly: index 0 is
@@ -433,7 +414,8 @@ static void launch_fps(int R, dim3 grid, hipStream_t st, const FpsJobs &jobs, Fp
     case 3: case 4: hipLaunchKernelGGL((fps_kernel<FMA, 4>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
     case 5: case 6: case 7: case 8: hipLaunchKernelGGL((fps_kernel<FMA, 8>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
     case 9: case 10: case 11: case 12: hipLaunchKernelGGL((fps_kernel<FMA, 12>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
-    default: hipLaunchKernelGGL((fps_kernel<FMA, 16>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+    case 13: case 14: case 15: case 16: hipLaunchKernelGGL((fps_kernel<FMA, 16>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+    default: hipLaunchKernelGGL((fps_kernel<FMA, 24>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
     }
 }
 
@@ -451,8 +433,9 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
     using namespace genpc;
     if (c <= 0) return 1;
     for (int j = 0; j < c; j++) {
-        if (n[j] <= 0 || k[j] <= 0 || k[j] > n[j] || n[j] > (1 << 20) - 1 || n[j] > kFMaxW * kFMaxR * kFThreads) {
-            fprintf(stderr, "genpc_fps: need 0 < k <= n <= %d\n", kFMaxW * kFMaxR * kFThreads);
+        static_assert(kFMaxW * kFMaxR * kFThreads >= 262144, "the documented limit");
+        if (n[j] <= 0 || k[j] <= 0 || k[j] > n[j] || n[j] > 262144) {
+            fprintf(stderr, "genpc_fps: need 0 < k <= n <= 262144\n");
             return -1;
         }
     }
