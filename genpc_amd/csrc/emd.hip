@@ -612,7 +612,9 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     static const int env_g = getenv("GENPC_EMD_G") ? atoi(getenv("GENPC_EMD_G")) : 0;
     if (env_g > 0) G = env_g;
     // rounds from which GetMax + Assign run as one single-block launch per cloud (few bidders left:
-    // ~n/7 after four rounds); a forced last round with all points bidding keeps the two launches
+    // ~n/7 after four rounds).  The forced last round takes the same kernel: its bidders are that round's
+    // unassigned points like any other round's (every one of them is assigned, none evicted) -- the numbers below
+    // were measured that way
     // (measured, 50 rounds: 1 x 2048 0.75 -> 0.68 ms, 64 x 2048 2.18 -> 1.98, 13 x 16384 8.45 -> 8.19; but
     // 1 x 16384 1.61 -> 1.80: with ~1000-2000 bidders left per round one block walking the list is
     // slower than 64 -- so only for small clouds or many of them)

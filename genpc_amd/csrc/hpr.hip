@@ -1010,6 +1010,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsur
             }
         }
     };
+    double d2_cached = -1.0, cpsi = 1.0, spsi = 0.0;
     for (int step = 0; step < 2 * ntiles; step++) {
         // a polygon that still runs out to the box after the eight nearest tiles belongs to a point on the
         // silhouette: in a large cloud it goes to the wave-per-point pass (as before the split)
@@ -1024,7 +1025,14 @@ __global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsur
         if (tile < 0 || tile >= ntiles) continue;
         if (tile >= home - 1 && tile <= home + 1) continue;          // taken in phase 1
         if (!(no_cull & 1)) {
-            const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15), cpsi = 1.0 / l, spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
+            // (cos, sin) of the polygon's angular radius: two fp64 square roots and two divisions -- a hundred
+            // instructions -- recomputed only when a clip has changed the reach, not once per tile
+            if (R.d2 != d2_cached) {
+                const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15);
+                cpsi = 1.0 / l;
+                spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
+                d2_cached = R.d2;
+            }
             if (!hpr_tile_needed(f, cpsi, spsi, poly, kHprThreads, nv, tiles[tile])) continue;
         }
         clip_by_tile(tile);

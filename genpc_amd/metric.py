@@ -48,11 +48,15 @@ def evaluate_sharded(pred_np, gt_np, device=None, max_batch=16, metric_fn=None, 
         p = torch.from_numpy(np.ascontiguousarray(pred_np[sel])).to(device)
         g = torch.from_numpy(np.ascontiguousarray(gt_np[sel])).to(device)
         rows.append(metric_fn(p, g))
-    if rows:
-        local = torch.cat(rows)
-    else:      # more ranks than scans: this rank owns none; K from a zero-scan call is not available
-        local = torch.empty(0, 3 if metric_fn is evaluate_scans else int(os.environ.get("GENPC_METRIC_COLUMNS", "3")),
-                            device=device)
+    # K (columns per scan) is agreed on collectively: a rank that owns no scan (more ranks than scans) cannot know
+    # what a custom metric_fn returns, and ranks entering the all_gather with different shapes would hang
+    k_local = rows[0].shape[1] if rows else 0
+    k = int(sharding.max_over_ranks(float(k_local), device=device if (world > 1 and torch.device(device).type == "cuda") else "cpu"))
+    if k <= 0:
+        raise ValueError("evaluate_sharded: no rank owns a scan")
+    if rows and any(r.shape[1] != k for r in rows):
+        raise ValueError("evaluate_sharded: metric_fn returned %d columns here, %d elsewhere" % (k_local, k))
+    local = torch.cat(rows) if rows else torch.empty(0, k, device=device)
     return sharding.gather_scan_metrics(local, s_total, rank, world)
 
 

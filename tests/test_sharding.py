@@ -84,6 +84,11 @@ def _worker_eval(rank, world, port, q):
     # evaluate_sharded initialises the process group itself (gloo here, nccl = RCCL on GPUs)
     table = evaluate_sharded(pred, gt, device=torch.device("cpu"), max_batch=3, metric_fn=_stub_metric, backend="gloo")
     seen = sharding.all_ranks()
+    # more ranks than scans, custom metric with 5 columns: the rank that owns nothing learns K from the others
+    # (it used to guess 3 from an environment variable and hang the all_gather)
+    t1 = evaluate_sharded(pred[:1], gt[:1], device=torch.device("cpu"), metric_fn=lambda p, g: torch.cat(
+        [_stub_metric(p, g), _stub_metric(p, g)[:, :2] * 2], dim=1), backend="gloo")
+    assert tuple(t1.shape) == (1, 5) and float(t1[0, 3]) == 2 * float(t1[0, 0])
     # a caller that skips init() must be told, not handed a misaligned table
     sharding.shutdown()
     err = None
