@@ -267,6 +267,55 @@ __global__ __launch_bounds__(kHprThreads) void hpr_tile_kernel(int n, const doub
     }
 }
 
+// The same record for every CHUNK of 32 consecutive positions (four per tile): what lets a lane skip a quarter of a
+// tile it needs.  One wave per two chunks (a 32-lane half each; reductions by shuffles inside the half).
+__global__ __launch_bounds__(kWave) void hpr_subtile_kernel(int n, const double *__restrict__ fl_all, HprTile *__restrict__ subs)
+{
+    const int view = blockIdx.y, lane = threadIdx.x;
+    const int chunk = blockIdx.x * 2 + (lane >> 5);
+    const int nchunks = ceil_div_dev(n, kHprThreads) * (kHprThreads / 32);
+    const int pos = chunk * 32 + (lane & 31);
+    double ux = 0.0, uy = 0.0, uz = 0.0, rho = 0.0;
+    bool ok = false;
+    if (chunk < nchunks && pos < n) {
+        const double *p = fl_all + ((size_t)view * n + pos) * 3;
+        rho = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        ok = rho > 0.0 && rho < __builtin_inf();
+        if (ok) { ux = p[0] / rho; uy = p[1] / rho; uz = p[2] / rho; }
+        else rho = 0.0;
+    }
+    double sx = ux, sy = uy, sz = uz, rm = rho;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o, kWave);
+        sy += __shfl_xor(sy, o, kWave);
+        sz += __shfl_xor(sz, o, kWave);
+        const double r2 = __shfl_xor(rm, o, kWave);
+        rm = rm > r2 ? rm : r2;
+    }
+    const double l = sqrt(sx * sx + sy * sy + sz * sz);
+    const bool axis = l > 0.0 && rm > 0.0;
+    const double wx = axis ? sx / l : 0.0, wy = axis ? sy / l : 0.0, wz = axis ? sz / l : 0.0;
+    double cmin = ok ? ux * wx + uy * wy + uz * wz : 1.0;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        const double c2 = __shfl_xor(cmin, o, kWave);
+        cmin = cmin < c2 ? cmin : c2;
+    }
+    if ((lane & 31) == 0 && chunk < nchunks) {
+        HprTile t;
+        double c = cmin - 1e-12;          // widen the cone past roundoff
+        if (!axis) c = -1.0;              // no usable axis: never skipped
+        t.wx = wx; t.wy = wy; t.wz = wz;
+        t.cos_phi = c;
+        t.cos2_phi = c * c;
+        t.sin2_phi = 1.0 - c * c + 1e-15;
+        t.sin_phi = sqrt(t.sin2_phi) * (1.0 + 1e-15);
+        t.inv_rho_max = rm > 0.0 ? 1.0 / (rm * (1.0 + 1e-12)) : 0.0;
+        subs[(size_t)view * nchunks + chunk] = t;
+    }
+}
+
 // Sutherland-Hodgman against a A + b B <= C: src (nv vertices, element k at src[k * ss]) -> dst (stride ds);
 // returns the new count.  A vertex exactly on the line is kept and spawns no intersection point.
 __device__ __forceinline__ int hpr_clip(const double2 *src, int ss, int nv, double A, double B, double C, double2 *dst, int ds)
@@ -912,7 +961,8 @@ __global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsur
                                                                 const int *__restrict__ hardlist, const int *__restrict__ hardcnt,
                                                                 const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
                                                                 unsigned char *__restrict__ vis, int *__restrict__ cnt, int *status,
-                                                                int *__restrict__ over_list, int no_cull, int max_clips)
+                                                                int *__restrict__ over_list, int no_cull, int max_clips,
+                                                                const HprTile *__restrict__ subs_all)
 {
     __shared__ double2 s_poly[kHprMaxV * kHprThreads];
     const int tid = threadIdx.x, slot = blockIdx.x * kHprThreads + tid;
@@ -943,13 +993,30 @@ __global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsur
     }
     HprReach R = {};
     if (active) R = hpr_reach(poly, kHprThreads, nv);
+    const HprTile *subs = subs_all + (size_t)view * ntiles * (kHprThreads / 32);
+    double d2_cached = -1.0, cpsi = 1.0, spsi = 0.0;
+    // (cos, sin) of the polygon's angular radius: two fp64 square roots and two divisions -- a hundred
+    // instructions -- recomputed only when a clip has changed the reach
+    auto radius_of_reach = [&]() {
+        if (R.d2 != d2_cached) {
+            const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15);
+            cpsi = 1.0 / l;
+            spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
+            d2_cached = R.d2;
+        }
+    };
     // one tile of candidates against this lane's polygon: hpr_kernel's clip_by_tile for a tile that is not the
-    // point's home tile (chunks of 32 in ascending order), candidates read from memory
+    // point's home tile (chunks of 32 in ascending order), candidates read from memory.  A chunk whose own cone
+    // (hpr_subtile_kernel) cannot reach the polygon is skipped whole: 32 candidate tests for one cone test.
     auto clip_by_tile = [&](int tile) {
         const int tile0 = tile * kHprThreads;
         for (int cc = 0; cc < kHprThreads / 32 && active; cc++) {
             const int c0 = cc * 32;
             R = hpr_reach(poly, kHprThreads, nv);
+            if (!(no_cull & 1)) {
+                radius_of_reach();
+                if (!hpr_tile_needed(f, cpsi, spsi, poly, kHprThreads, nv, subs[tile * (kHprThreads / 32) + cc])) continue;
+            }
             unsigned m = 0u;
 #pragma unroll 4
             for (int t = 0; t < 32; t++) {
@@ -1010,7 +1077,6 @@ __global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsur
             }
         }
     };
-    double d2_cached = -1.0, cpsi = 1.0, spsi = 0.0;
     for (int step = 0; step < 2 * ntiles; step++) {
         // a polygon that still runs out to the box after the eight nearest tiles belongs to a point on the
         // silhouette: in a large cloud it goes to the wave-per-point pass (as before the split)
@@ -1025,14 +1091,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsur
         if (tile < 0 || tile >= ntiles) continue;
         if (tile >= home - 1 && tile <= home + 1) continue;          // taken in phase 1
         if (!(no_cull & 1)) {
-            // (cos, sin) of the polygon's angular radius: two fp64 square roots and two divisions -- a hundred
-            // instructions -- recomputed only when a clip has changed the reach, not once per tile
-            if (R.d2 != d2_cached) {
-                const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15);
-                cpsi = 1.0 / l;
-                spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
-                d2_cached = R.d2;
-            }
+            radius_of_reach();
             if (!hpr_tile_needed(f, cpsi, spsi, poly, kHprThreads, nv, tiles[tile])) continue;
         }
         clip_by_tile(tile);
@@ -1256,11 +1315,16 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     const size_t o_tmp = off; off += up(sort_bytes);
     const int ntiles = ceil_div(n, kHprThreads);
     const size_t o_tiles = off; off += up((size_t)c * ntiles * sizeof(HprTile));
+    const size_t o_subs = off; off += up((size_t)c * ntiles * (kHprThreads / 32) * sizeof(HprTile));
     const size_t o_hard = off; off += up(total);
     const size_t o_hl = off; off += up(total * sizeof(int));
     const size_t o_hc = off; off += up((size_t)c * sizeof(int));
-    const size_t o_surv = off; off += up(total * sizeof(int4));
-    // (the survivors' polygons are sized after hpr_kernel has counted them: a second, smaller workspace)
+    // the split pays when many views share a small cloud (viewpoint_select: 1024 x 10000, 128 -> 88 ms; 64 x 10000: 14.3 -> 16.6, so not there); a few views
+    // of a large cloud keep the one-kernel form (GENPC_HPR_SPLIT=0/1 overrides)
+    static const int env_split = getenv("GENPC_HPR_SPLIT") ? atoi(getenv("GENPC_HPR_SPLIT")) : -1;
+    const int split = env_split >= 0 ? env_split : (ntiles < kHprRimTiles && (long long)c * n >= 4000000ll ? 1 : 0);
+    const size_t o_surv = off; off += split ? up(total * sizeof(int4)) : 0;
+    // (the survivors' polygons are sized after the accept pass has counted the listed points: a second workspace)
     char *ws = (char *)workspace(17, off, stream);
     if (!ws) return 0;
     int *status = (int *)ws;
@@ -1284,6 +1348,7 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept, 32 = no verify phase, 64 = no hand-off of much-cut polygons (results unchanged)
     hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl);
     hipLaunchKernelGGL(hpr_tile_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, tiles);
+    HprTile *subs = (HprTile *)(ws + o_subs);
     static const int env_clips = getenv("GENPC_HPR_MAXCLIPS") ? atoi(getenv("GENPC_HPR_MAXCLIPS")) : 0;
     // (large clouds: 96 -- 2 x 165546 points 46 -> 40 ms; many views of a small cloud: the second pass fills up
     //  instead -- 1024 x 10000 points 154 ms with 256, 168 with 128, 180 with 96)
@@ -1299,10 +1364,6 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     // this entry's host round trips) and the buffer sized from it
     int4 *surv = (int4 *)(ws + o_surv);
     int hc_total = 0;
-    // the split pays when many views share a small cloud (viewpoint_select: 1024 x 10000, 128 -> 88 ms; 64 x 10000: 14.3 -> 16.6, so not there); a few views
-    // of a large cloud keep the one-kernel form (GENPC_HPR_SPLIT=0/1 overrides)
-    static const int env_split = getenv("GENPC_HPR_SPLIT") ? atoi(getenv("GENPC_HPR_SPLIT")) : -1;
-    const int split = env_split >= 0 ? env_split : (ntiles < kHprRimTiles && (long long)c * n >= 4000000ll ? 1 : 0);
     if (split) {
         // sum of hardcnt over the views = an upper bound on the survivors
         int *hc_host = (int *)malloc(sizeof(int) * (size_t)c);
@@ -1327,9 +1388,11 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
     if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
     if (st[2] > 0) {
+        hipLaunchKernelGGL(hpr_subtile_kernel, dim3(ntiles * (kHprThreads / 32) / 2, c), dim3(kWave), 0, stream, n, (const double *)fl, subs);
         hipLaunchKernelGGL(hpr_phase2_kernel, dim3(ceil_div(st[2], kHprThreads)), dim3(kHprThreads), 0, stream, n, st[2],
                            (const double *)fl, (const int *)i1, (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt,
-                           (const int4 *)surv, (const double2 *)surv_poly, visible, counts, status, list, no_cull, max_clips);
+                           (const int4 *)surv, (const double2 *)surv_poly, visible, counts, status, list, no_cull, max_clips,
+                           (const HprTile *)subs);
         if (!check(hipGetLastError(), "hpr phase 2 launch")) return 0;
         if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
         if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
