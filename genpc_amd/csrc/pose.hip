@@ -1156,7 +1156,7 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
                        (const float *)m.stats, accum);
     hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, 0, (const float *)m.mref,
                        (const float *)m.stats, mask_weight, m.W1, m.W4, accum);
-    if ((long long)b * nc <= 131072)      // (few points in flight: eight lanes per point; 4 x 15403 points 35 -> see DESIGN 4.5)
+    if (b <= 2)      // (measured at 4 x 16384 points, the four starts in lock-step: <1> 35 us, <8> 42)
         hipLaunchKernelGGL((mask_grad_kernel<8>), dim3(lin_grid((long long)nc * 8), b), dim3(kQBlock), 0, st, nc, complete,
                            complete_col, center, cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum);
     else

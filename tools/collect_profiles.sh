@@ -5,11 +5,11 @@
 # WRITE_SIZE / SQ counter passes (separate runs: TCC has 4 slots, FETCH_SIZE takes 3; never combined
 # with a trace).  Every profiled program is `python3 <script>` directly after `--` (no wrappers).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-K="timeout -s KILL 150"
+K="timeout -s KILL 240"
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES"
 $K rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 bench.py --steps 50 --warmup 5 --no-extra --no-cpu-baseline > $OUT/bench_trace.log 2>&1
 family() {   # family <name> <script> [args...]
@@ -30,4 +30,7 @@ family scale_search_icp tools/prof_scale_search.py
 family fps_voxel tools/prof_fps_voxel.py
 family hpr_64x10000 tools/prof_hpr.py small
 family hpr_2x165546 tools/prof_hpr.py big
+family hpr_1024x10000 tools/prof_hpr1024.py
+family reg_8192_vs_16384 tools/prof_reg.py
+family c2_chain_8192 tools/prof_c2.py
 ls $OUT | head -60
