@@ -242,13 +242,16 @@ def extras(A, B, n, dev, stream):
     torch.cuda.synchronize()
     t_fps = time.perf_counter() - t0
     extra["fps_4x165546_to_16384_ms"] = round(t_fps * 1e3, 2)
-    # roofline-shaped: FPS is k SEQUENTIAL steps (each needs the previous winner); the floor of a step is one
-    # cross-workgroup hand-off = an L2 round trip pair (~1 us measured for store -> visible -> load on this chip,
-    # tools/ubench_dispatch.hip) -- not bandwidth: a step touches 165546 x 16 B of REGISTER-resident state
+    # roofline-shaped: the O(n k) work of FPS is one distance update per (point, sample): 8 algorithmic flop (3 sub,
+    # 3 mul / fma, 1 min ... priced like a pair of SURVEY 8d) against the fp32 vector peak.  The path is NOT bound by
+    # that: the k samples are sequential, and what a step costs is the dependency chain that picks the next sample
+    # (csrc/fps.hip: one inter-workgroup exchange yields ~45 samples, replayed by one wave at ~900 cycles each)
+    upd = 4.0 * 165546 * 16384
     extra["fps_4x165546_to_16384_roofline"] = {
-        "bound": "latency (sequential steps)", "unit": "us/step", "steps": 16384, "clouds_side_by_side": 4,
-        "achieved": round(t_fps * 1e6 / 16384, 3), "floor": 1.0, "frac": round(1.0 / (t_fps * 1e6 / 16384), 4),
-        "point_updates_per_s": round(4 * 165546 * 16384 / t_fps / 1e9, 1), "point_updates_unit": "G/s"}
+        "bound": "valu-fp32", "unit": "TFLOP/s", "flop_per_point_update": 8, "point_updates": upd,
+        "achieved": round(8 * upd / t_fps / 1e12, 2), "peak": PEAK_FP32_TFLOPS, "frac": round(8 * upd / t_fps / 1e12 / PEAK_FP32_TFLOPS, 4),
+        "us_per_sequential_step": round(t_fps * 1e6 / 16384, 3), "clouds_side_by_side": 4,
+        "note": "latency-bound by construction (sequential argmax chain); round 2: 2.8 us per step"}
     # HBM-bound streaming kernel: getUvs for the reference's 1024 cameras x 71372 points
     cfg = SimpleNamespace(device=str(dev), fovy=49.1, res=256, padding=0.15, rescale=True, point_size=1,
                           mask_pixel_rate=3, view_num=1024, distance=1.6)
