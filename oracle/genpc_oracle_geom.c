@@ -3,7 +3,13 @@
  * / pose-optimisation half of GenPC's geometric hot path (SURVEY.md 8a rows
  * a13-a16).  TEST INFRASTRUCTURE ONLY, same rules as genpc_oracle.c.
  *
- * Parity status of these rows: "PARITY UNPINNED".  The reference implements them
+ * Parity status of these rows: "PARITY UNPINNED" for everything that lives in a
+ * third-party library (below); PINNED TO THE REFERENCE'S OWN PYTHON, executed in the
+ * build container, for the reference's own arithmetic around those calls
+ * (tests/golden/make_reference_vectors.py -> ref_py_*.npz, checked by
+ * tests/test_reference_vectors.py): compute_loss_function + normalize_images +
+ * compute_soft_mask + dice_loss and their autograd gradient, paintPixels / getRawDepth,
+ * getUvs' rescale, build_transform.  The reference implements the rest
  * on top of third-party libraries that are neither in /root/reference nor in
  * this image and for which the reference pins no version except kaolin 0.18.0
  * (README.md:27): kaolin cameras (DepthPrompting.py:245, utils/camera_utils.py:

@@ -2,7 +2,9 @@
 
 TEST INFRASTRUCTURE ONLY.  May be imported by tests/, by bench.py's
 ``cpu_baseline`` leg and by ``__graft_entry__.smoke()`` -- never by genpc_amd/.
-Parity status: see the header of genpc_oracle.c ("parity unpinned" by the
+Parity status: the reference's own pure-Python functions pin the rows they cover
+(tests/golden/ref_py_*.npz, see genpc_oracle_geom.c); for the CUDA kernels see the
+header of genpc_oracle.c ("parity unpinned" by the
 reference's own artefacts; pinned against BASELINE.md section 2 values).
 
 All arrays are numpy, C-contiguous, float32 / int32, shaped like the reference's
