@@ -13,8 +13,9 @@
 //     SIMD (round 2: 16 points on each of 16 waves of one CU, 1.2 us of VALU issue per step);
 //   * a thread carries the coordinates of its best point along, the wave's best is found with DPP row
 //     rotations + v_readlane (no LDS round trips), the workgroup's best with one LDS exchange;
-//   * the hand-off carries the winner's COORDINATES: {dist, gen | idx, x, y} as one 16-byte write-through
-//     store and {z, gen} as one 8-byte one, each self-tagged with the step's generation (round 2 published
+//   * the hand-off carries the candidates' COORDINATES: four 8-byte write-through stores per candidate,
+//     {dist, gen | idx} {x, gen} {y, gen} {z, gen}, each self-tagged with the exchange's generation (the
+//     8-byte granule written by one store is the unit whose atomicity the hardware documents; round 2 published
 //     the index alone and every workgroup then fetched the pivot from memory: one more dependent miss);
 //   * one wave per workgroup polls the cloud's W slots (a lane per slot), picks the global winner
 //     and hands the pivot to its workgroup through LDS.  Slots are double-buffered by step parity: no
@@ -93,15 +94,10 @@ __device__ __forceinline__ float lane_f32(float v, int lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// 16-byte / 8-byte write-through stores and L1-bypassing loads (sc0 sc1: what agent-scope relaxed atomics
-// lower to for 8 bytes; one instruction per granule, observed untorn on gfx950)
+// 8-byte write-through stores and L1-bypassing 16-byte loads (sc0 sc1: what agent-scope relaxed atomics lower to
+// for 8 bytes).  A 16-byte load may see its two granules at different times: each carries its own tag.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void store_sc_b128(void *p, uint4 v)
-{
-    const u32x4 w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
-}
 __device__ __forceinline__ void store_sc_b64(void *p, uint2 v)
 {
     const u32x2 w = {v.x, v.y};
@@ -114,27 +110,26 @@ constexpr int kFBlock = kFThreads + kWave;     // three waves own the points, a 
                                                // wave shared its SIMD with a worker, and the replay -- a chain of dependent
                                                // cross-lane steps -- got every other issue slot: 1200 cycles per pick)
 
-struct FpsCand {          // 32 bytes
-    uint4 a;              // dist bits, gen << 20 | idx, x bits, y bits
-    uint2 b;              // z bits, gen
-    uint2 pad;
+struct FpsCand {          // 32 bytes = four self-tagged 8-byte granules, each written by ONE write-through store (the
+    uint4 a;              //   documented single-copy-atomic unit): {dist bits, gen << 20 | idx} {x bits, gen}
+    uint4 b;              //   {y bits, gen} {z bits, gen}.  Read back as two 16-byte loads; every half carries its tag.
 };
 struct FpsSlot {          // one 128-byte line per (job, parity, workgroup)
     FpsCand c[kFT];
 };
 
 // the eight loads of one slot in flight together, one wait
-__device__ __forceinline__ void load_slot(const FpsSlot *p, u32x4 (&a)[kFT], u32x2 (&b)[kFT])
+__device__ __forceinline__ void load_slot(const FpsSlot *p, u32x4 (&a)[kFT], u32x4 (&b)[kFT])
 {
     static_assert(kFT == 4 && sizeof(FpsCand) == 32, "offsets below");
     asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
-                 "global_load_dwordx2 %4, %8, off offset:16 sc0 sc1\n\t"
+                 "global_load_dwordx4 %4, %8, off offset:16 sc0 sc1\n\t"
                  "global_load_dwordx4 %1, %8, off offset:32 sc0 sc1\n\t"
-                 "global_load_dwordx2 %5, %8, off offset:48 sc0 sc1\n\t"
+                 "global_load_dwordx4 %5, %8, off offset:48 sc0 sc1\n\t"
                  "global_load_dwordx4 %2, %8, off offset:64 sc0 sc1\n\t"
-                 "global_load_dwordx2 %6, %8, off offset:80 sc0 sc1\n\t"
+                 "global_load_dwordx4 %6, %8, off offset:80 sc0 sc1\n\t"
                  "global_load_dwordx4 %3, %8, off offset:96 sc0 sc1\n\t"
-                 "global_load_dwordx2 %7, %8, off offset:112 sc0 sc1\n\t"
+                 "global_load_dwordx4 %7, %8, off offset:112 sc0 sc1\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
                  : "v"(p)
@@ -319,21 +314,24 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
                 for (int c = 1; c < kFT; c++)
                     if (lane == c) { pd = cd[c]; pi = ci[c]; pxx = cxs[c]; pyy = cys[c]; pzz = czs[c]; }
                 const unsigned pidx = pd >= 0.0f ? (unsigned)pi : 0xFFFFFu;
-                store_sc_b128(&slot[wg].c[lane].a, make_uint4(__float_as_uint(pd), (gen << 20) | pidx, __float_as_uint(pxx), __float_as_uint(pyy)));
-                store_sc_b64(&slot[wg].c[lane].b, make_uint2(__float_as_uint(pzz), gen));
+                uint2 *g = (uint2 *)&slot[wg].c[lane];
+                store_sc_b64(g + 0, make_uint2(__float_as_uint(pd), (gen << 20) | pidx));
+                store_sc_b64(g + 1, make_uint2(__float_as_uint(pxx), gen));
+                store_sc_b64(g + 2, make_uint2(__float_as_uint(pyy), gen));
+                store_sc_b64(g + 3, make_uint2(__float_as_uint(pzz), gen));
             }
             // every lane < W reads workgroup `lane`'s list, bounded
             u32x4 a[kFT];
-            u32x2 b[kFT];
+            u32x4 b[kFT];
 #pragma unroll
-            for (int c = 0; c < kFT; c++) { a[c] = (u32x4){0, 0, 0, 0}; b[c] = (u32x2){0, 0}; }
+            for (int c = 0; c < kFT; c++) { a[c] = (u32x4){0, 0, 0, 0}; b[c] = (u32x4){0, 0, 0, 0}; }
             int spins = 0;
             for (;;) {
                 bool ready = true;
                 if (lane < W) {
                     load_slot(&slot[lane], a, b);
 #pragma unroll
-                    for (int c = 0; c < kFT; c++) ready = ready && (a[c].y >> 20) == gen && b[c].y == gen;
+                    for (int c = 0; c < kFT; c++) ready = ready && (a[c].y >> 20) == gen && a[c].w == gen && b[c].y == gen && b[c].w == gen;
                 }
                 if (__all(ready)) break;
                 if (++spins > (1 << 21)) {
@@ -350,8 +348,8 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
                 cd[c] = live ? __uint_as_float(a[c].x) : -2.0f;
                 ci[c] = live ? (int)(a[c].y & 0xFFFFFu) : 0x7fffffff;
                 cxs[c] = __uint_as_float(a[c].z);
-                cys[c] = __uint_as_float(a[c].w);
-                czs[c] = __uint_as_float(b[c].x);
+                cys[c] = __uint_as_float(b[c].x);
+                czs[c] = __uint_as_float(b[c].z);
             }
         } else if (lane != 0) {
 #pragma unroll
