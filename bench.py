@@ -296,6 +296,15 @@ def extras(A, B, n, dev, stream):
                                      "frac": round(tests / t_h / (78.6e12 / 6), 4),
                                      "note": "peak = 78.6 TFLOP/s fp64 vector / 6 flop per test; culling skips most tests, "
                                              "so frac is an equivalent rate, not a utilisation"}
+    # viewpoint_select's own pass: views that can no longer see the most points are dropped after the first polygon kernel
+    dph.hidden_point_removal(sub, dph.viewpoints, 10000.0, best_only=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, cnt_b, _ = dph.hidden_point_removal(sub, dph.viewpoints, 10000.0, best_only=True)
+    torch.cuda.synchronize()
+    extra["hpr_1024x10000_best_view_only_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    _, cnt_f, _ = dph.hidden_point_removal(sub, dph.viewpoints, 10000.0)
+    extra["hpr_best_view_equals_full_pass"] = bool(int(torch.argmax(cnt_b)) == int(torch.argmax(cnt_f)))
     from oracle import hpr as ohpr
     t0 = time.perf_counter()
     ref_cnt = ohpr.visible_counts(sub.cpu().numpy(), np.asarray(dph.viewpoints)[:4], 10000.0)

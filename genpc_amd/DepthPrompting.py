@@ -110,8 +110,11 @@ class DepthPrompting:
         (default: this object's), radius: cfg.removal_radius by default."""
         return self.hidden_point_removal(points, viewpoints, radius)[0]
 
-    def hidden_point_removal(self, points, viewpoints=None, radius=None):
-        """-> (visible [C,N] bool, counts [C] int32, points that needed the large-polygon pass)."""
+    def hidden_point_removal(self, points, viewpoints=None, radius=None, best_only=False):
+        """-> (visible [C,N] bool, counts [C] int32, points that needed the large-polygon pass).
+        best_only=True (viewpoint_select): the library stops working on views that can no longer see the most
+        points; counts are then exact for the views that could, lower bounds below the maximum for the rest
+        (argmax unchanged), and `visible` is complete only for the former."""
         if viewpoints is None:
             viewpoints = self.viewpoints
         if radius is None:
@@ -133,8 +136,12 @@ class DepthPrompting:
         for v0 in range(0, c, step):
             v1 = min(c, v0 + step)
             second = ctypes.c_int(0)
-            rc = _lib.on_device_of(points, _L.genpc_hpr_visibility, v1 - v0, n, _p(points), _p(eyes[v0:v1]), float(radius),
-                                   _p(vis[v0:v1]), _p(cnt[v0:v1]), ctypes.addressof(second))
+            if best_only and v0 == 0 and v1 == c:      # (pruning needs all views in one call)
+                rc = _lib.on_device_of(points, _L.genpc_hpr_best_view_counts, c, n, _p(points), _p(eyes), float(radius),
+                                       _p(vis), _p(cnt), None, ctypes.addressof(second))
+            else:
+                rc = _lib.on_device_of(points, _L.genpc_hpr_visibility, v1 - v0, n, _p(points), _p(eyes[v0:v1]), float(radius),
+                                       _p(vis[v0:v1]), _p(cnt[v0:v1]), ctypes.addressof(second))
             if rc != 1:
                 raise RuntimeError("genpc_hpr_visibility failed (rc=%d): %s" % (rc, _lib.last_error()))
             total_second += int(second.value)
@@ -174,7 +181,8 @@ class DepthPrompting:
         if zbuffer:
             _, counts = self.getVisiblePointsZBuffer(xyz_fps, cams=self.cameras, tol=tol)
         else:
-            _, counts, _ = self.hidden_point_removal(xyz_fps, self.viewpoints, getattr(self.cfg, "removal_radius", 10000))
+            _, counts, _ = self.hidden_point_removal(xyz_fps, self.viewpoints, getattr(self.cfg, "removal_radius", 10000),
+                                                     best_only=True)
         return int(torch.argmax(counts))
 
     # DepthPrompting.py:100-187 (getDepth up to the raw depth image; the inpainting that follows is stock

@@ -41,6 +41,7 @@ SIGNATURES = {
     "genpc_paint_pixels": (_i, [_i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "genpc_gather_colors": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "genpc_hpr_visibility": (_i, [_i, _i, _vp, _vp, _d, _vp, _vp, _vp, _vp]),
+    "genpc_hpr_best_view_counts": (_i, [_i, _i, _vp, _vp, _d, _vp, _vp, _vp, _vp, _vp]),
     "genpc_zbuffer_visibility": (_i, [_i, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "genpc_pose_transform": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_pose_cd_grad": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),

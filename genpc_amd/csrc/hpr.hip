@@ -625,7 +625,8 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                                                          const HprTile *__restrict__ tiles_all, const int *__restrict__ hardlist,
                                                          const int *__restrict__ hardcnt, unsigned char *__restrict__ vis,
                                                          int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull, int max_clips,
-                                                         int split, int4 *__restrict__ surv, double2 *__restrict__ surv_poly)
+                                                         int split, int4 *__restrict__ surv, double2 *__restrict__ surv_poly,
+                                                         int *__restrict__ und)
 {
     __shared__ double2 s_poly[kHprMaxV * kHprThreads];
     __shared__ double4 s_stage[kHprThreads];      // 64 tile records while testing, then one tile's candidates
@@ -721,6 +722,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                         // assumes one -- the second pass clips like the oracle does, vertex by vertex)
                         if (nv - out + 2 > kHprMaxV || runs > 1) {
                             over_list[atomicAdd(&status[0], 1)] = view * n + rank;
+                            if (und) atomicAdd(&und[view], 1);
                             nv = -1;
                             active = false;
                             break;
@@ -734,6 +736,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                         // place for it
                         if (++nclips > max_clips) {
                             over_list[atomicAdd(&status[0], 1)] = view * n + rank;
+                            if (und) atomicAdd(&und[view], 1);
                             nv = -1;
                             active = false;
                             break;
@@ -886,7 +889,10 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
         const unsigned long long bal = __ballot(true);
         const int lane = tid & (kWave - 1);
         int base = 0;
-        if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(&status[2], __popcll(bal));
+        if (lane == __ffsll((long long)bal) - 1) {
+            base = atomicAdd(&status[2], __popcll(bal));
+            if (und) atomicAdd(&und[view], __popcll(bal));      // (a wave's lanes share the view: one block = one view)
+        }
         base = __shfl(base, __ffsll((long long)bal) - 1, kWave);
         const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
         surv[slot] = make_int4(view * n + rank, nv, nclips, 0);
@@ -906,6 +912,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
         // (measured: 2 x 165546 points 77 -> 51 ms; 64 x 10000 points 29 -> 32 ms, hence the size rule).
         if (step0 == kHprRimStep && ntiles >= kHprRimTiles && active && R.d2 > kHprRimD2 && !(no_cull & 8)) {
             over_list[atomicAdd(&status[0], 1)] = view * n + rank;
+                            if (und) atomicAdd(&und[view], 1);
             nv = -1;
             active = false;
         }
@@ -949,6 +956,25 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     if (tid == 0 && c) atomicAdd(&cnt[view], c);
 }
 
+// viewpoint_select only needs the view that sees the MOST points.  After hpr_kernel a view's count is a lower bound
+// (accepted + verified + decided in phase 1) and `und` says how many of its points are still undecided: a view whose
+// upper bound stays below the best lower bound cannot win (nor tie), and the second kernel and the wave-per-point
+// pass skip its points.  alive[v] = 1: the view's final count is exact.
+__global__ __launch_bounds__(1024) void hpr_prune_kernel(int c, const int *__restrict__ cnt, const int *__restrict__ und,
+                                                        unsigned char *__restrict__ alive)
+{
+    __shared__ int s_max[16];
+    int m = 0;
+    for (int v = threadIdx.x; v < c; v += 1024) m = max(m, cnt[v]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, kWave));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = s_max[0];
+    for (int w = 1; w < 16; w++) m = max(m, s_max[w]);
+    for (int v = threadIdx.x; v < c; v += 1024) alive[v] = cnt[v] + und[v] >= m ? 1 : 0;
+}
+
 // Phase 2 of the polygon pass for the points hpr_kernel left undecided, packed densely: one thread per survivor,
 // polygon back in LDS.  Every lane walks ITS OWN tile sequence -- outward from the starting tile of the group it
 // was listed in (hpr_base_tile of its rank: the order the oracle restates), skipping its three home tiles -- and
@@ -962,7 +988,8 @@ __global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsur
                                                                 const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
                                                                 unsigned char *__restrict__ vis, int *__restrict__ cnt, int *status,
                                                                 int *__restrict__ over_list, int no_cull, int max_clips,
-                                                                const HprTile *__restrict__ subs_all)
+                                                                const HprTile *__restrict__ subs_all,
+                                                                const unsigned char *__restrict__ alive)
 {
     __shared__ double2 s_poly[kHprMaxV * kHprThreads];
     const int tid = threadIdx.x, slot = blockIdx.x * kHprThreads + tid;
@@ -974,6 +1001,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsur
         rank = e.x - view * n;
         nv = e.y;
         nclips = e.z;
+        if (alive && !alive[view]) { active = false; nv = -1; }      // a view that cannot be the best any more
     }
     const double *fl = fl_all + (size_t)view * n * 3;
     const int *hl = hardlist + (size_t)view * n;
@@ -1110,11 +1138,13 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                                                              const HprTile *__restrict__ tiles_all, unsigned char *__restrict__ vis,
                                                              int *__restrict__ cnt, int *status, const int *__restrict__ list,
                                                              const int *__restrict__ perm, const int *__restrict__ hardlist,
-                                                             const int *__restrict__ hardcnt, int no_cull)
+                                                             const int *__restrict__ hardcnt, int no_cull,
+                                                             const unsigned char *__restrict__ alive)
 {
     __shared__ double2 s_buf[2][kHprOverCap];
     const int lane = threadIdx.x;
     const int id = list[blockIdx.x], view = id / n, rank = id - view * n;
+    if (alive && !alive[view]) return;        // (wave-uniform) a view that cannot be the best any more
     const int *hl = hardlist + (size_t)view * n;
     const int pos = hl[rank], i = perm[(size_t)view * n + pos];
     const double *fl = fl_all + (size_t)view * n * 3;
@@ -1278,8 +1308,8 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
 
 using namespace genpc;
 
-GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const double *eyes, double radius, unsigned char *visible,
-                                   int *counts, int *second_pass_points, void *stream_)
+static int hpr_run(int c, int n, const float *points, const double *eyes, double radius, unsigned char *visible, int *counts,
+                   int *second_pass_points, void *stream_, int best_only, unsigned char *exact)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (c < 0 || n < 0 || !(radius > 0.0)) {
@@ -1319,6 +1349,8 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     const size_t o_hard = off; off += up(total);
     const size_t o_hl = off; off += up(total * sizeof(int));
     const size_t o_hc = off; off += up((size_t)c * sizeof(int));
+    const size_t o_und = off; off += up((size_t)c * sizeof(int));
+    const size_t o_alive = off; off += up((size_t)c);
     // the split pays when many views share a small cloud (viewpoint_select: 1024 x 10000, 128 -> 88 ms; 64 x 10000: 14.3 -> 16.6, so not there); a few views
     // of a large cloud keep the one-kernel form (GENPC_HPR_SPLIT=0/1 overrides)
     static const int env_split = getenv("GENPC_HPR_SPLIT") ? atoi(getenv("GENPC_HPR_SPLIT")) : -1;
@@ -1363,6 +1395,11 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     // total * kHprMaxV * 16 bytes would be 2.6 GB at 1024 x 10000 -- instead the count is fetched (the first of
     // this entry's host round trips) and the buffer sized from it
     int4 *surv = (int4 *)(ws + o_surv);
+    // best_only (viewpoint_select): views that cannot be the best any more are dropped after the first polygon kernel
+    const bool prune = best_only && split;
+    int *und = prune ? (int *)(ws + o_und) : nullptr;
+    unsigned char *alive = prune ? (unsigned char *)(ws + o_alive) : nullptr;
+    if (prune && !check(hipMemsetAsync(und, 0, sizeof(int) * (size_t)c, stream), "hipMemsetAsync(hpr und)")) return 0;
     int hc_total = 0;
     if (split) {
         // sum of hardcnt over the views = an upper bound on the survivors
@@ -1382,17 +1419,18 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     }
     hipLaunchKernelGGL(hpr_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
                        (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull,
-                       max_clips, split, surv, surv_poly);
+                       max_clips, split, surv, surv_poly, und);
     if (!check(hipGetLastError(), "hpr launch")) return 0;
     int st[3] = {0, 0, 0};
     if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
     if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
+    if (prune) hipLaunchKernelGGL(hpr_prune_kernel, dim3(1), dim3(1024), 0, stream, c, (const int *)counts, (const int *)und, alive);
     if (st[2] > 0) {
         hipLaunchKernelGGL(hpr_subtile_kernel, dim3(ntiles * (kHprThreads / 32) / 2, c), dim3(kWave), 0, stream, n, (const double *)fl, subs);
         hipLaunchKernelGGL(hpr_phase2_kernel, dim3(ceil_div(st[2], kHprThreads)), dim3(kHprThreads), 0, stream, n, st[2],
                            (const double *)fl, (const int *)i1, (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt,
                            (const int4 *)surv, (const double2 *)surv_poly, visible, counts, status, list, no_cull, max_clips,
-                           (const HprTile *)subs);
+                           (const HprTile *)subs, (const unsigned char *)alive);
         if (!check(hipGetLastError(), "hpr phase 2 launch")) return 0;
         if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
         if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
@@ -1400,7 +1438,8 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
     if (second_pass_points) *second_pass_points = st[0];
     if (st[0] > 0) {
         hipLaunchKernelGGL(hpr_overflow_kernel, dim3(st[0]), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
-                           visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist, (const int *)hardcnt, no_cull);
+                           visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist, (const int *)hardcnt, no_cull,
+                           (const unsigned char *)alive);
         if (!check(hipGetLastError(), "hpr second pass launch")) return 0;
         if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
         if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
@@ -1409,5 +1448,23 @@ GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const doub
             return 0;
         }
     }
+    if (exact) {
+        if (prune) {
+            if (!check(hipMemcpyAsync(exact, alive, (size_t)c, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(hpr exact)")) return 0;
+        } else if (!check(hipMemsetAsync(exact, 1, (size_t)c, stream), "hipMemsetAsync(hpr exact)")) return 0;
+    }
     return 1;
+}
+
+GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const double *eyes, double radius, unsigned char *visible,
+                                   int *counts, int *second_pass_points, void *stream_)
+{
+    return hpr_run(c, n, points, eyes, radius, visible, counts, second_pass_points, stream_, 0, nullptr);
+}
+
+GENPC_API int genpc_hpr_best_view_counts(int c, int n, const float *points, const double *eyes, double radius,
+                                         unsigned char *visible, int *counts, unsigned char *exact, int *second_pass_points,
+                                         void *stream_)
+{
+    return hpr_run(c, n, points, eyes, radius, visible, counts, second_pass_points, stream_, 1, exact);
 }

@@ -170,6 +170,17 @@ int genpc_hpr_visibility(int c, int n, const float *points, const double *eyes,
                          double radius, unsigned char *visible, int *counts,
                          int *second_pass_points, void *stream);
 
+/* The same pass for a caller that only needs THE BEST view (DepthPrompting.viewpoint_select,
+ * DepthPrompting.py:87-98: argmax over the viewpoints of the visible count): after the first polygon
+ * kernel a view's count is a lower bound and the number of its still undecided points is known, so a
+ * view whose upper bound stays below the best lower bound cannot win (nor tie) and its remaining
+ * points are skipped.  counts[c]: exact for the views with exact[v] = 1 (exact may be NULL), a lower
+ * bound below the maximum for the others -- argmax(counts) (first maximum) is the reference's choice.
+ * visible[c,n] is complete only for the exact views.  Other arguments as genpc_hpr_visibility.       */
+int genpc_hpr_best_view_counts(int c, int n, const float *points, const double *eyes, double radius,
+                               unsigned char *visible, int *counts, unsigned char *exact,
+                               int *second_pass_points, void *stream);
+
 /* A cheaper visibility for viewpoint ranking.  NOT the reference's operator (that is
  * genpc_hpr_visibility above): a z-buffer test -- a point is visible from camera c
  * when no point whose (2*point_size-1)^2 pixel stamp covers its pixel of a res x res

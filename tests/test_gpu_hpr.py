@@ -190,3 +190,45 @@ def test_hpr_differential_fuzz(hp):
         total += vis.size
         second_total += second
     assert total > 100000
+
+
+def test_best_view_counts_agree_with_full_pass(golden):
+    """genpc_hpr_best_view_counts (viewpoint_select's pass: views that can no longer see the most points are dropped
+    after the first polygon kernel): argmax and the exact views' counts and masks equal the full pass; the pruned
+    views' counts are lower bounds below the maximum.  Three scans x 1024 viewpoints, and a tie (two identical
+    viewpoints: the first must win)."""
+    import ctypes
+    import torch
+    from types import SimpleNamespace
+    from genpc_amd import _lib
+    from genpc_amd.DepthPrompting import DepthPrompting
+    cfg = SimpleNamespace(device="cuda", fovy=49.1, res=256, cam_res=256, padding=0.15, rescale=True, point_size=1,
+                          mask_pixel_rate=3, view_num=1024, distance=1.6, downsample_num=10000, removal_radius=10000)
+    dp = DepthPrompting(cfg)
+    g = golden("scans13_fps16384.npz")
+    for k, arr in ((0, g["partial"]), (5, g["gt"]), (9, g["partial"])):
+        pts = torch.from_numpy(np.ascontiguousarray(arr[k][:6000])).cuda()
+        vis, cnt, _ = dp.hidden_point_removal(pts, dp.viewpoints, 10000.0)
+        eyes = torch.as_tensor(np.asarray(dp.viewpoints, np.float64)).cuda()
+        c, n = eyes.shape[0], pts.shape[0]
+        v2 = torch.zeros(c, n, device="cuda", dtype=torch.uint8)
+        c2 = torch.empty(c, device="cuda", dtype=torch.int32)
+        ex = torch.empty(c, device="cuda", dtype=torch.uint8)
+        second = ctypes.c_int(0)
+        rc = _lib.on_device_of(pts, _lib.lib.genpc_hpr_best_view_counts, c, n, _lib.ptr(pts), _lib.ptr(eyes), 10000.0,
+                               _lib.ptr(v2), _lib.ptr(c2), _lib.ptr(ex), ctypes.addressof(second))
+        assert rc == 1, _lib.last_error()
+        exact = ex.bool()
+        assert int(torch.argmax(c2)) == int(torch.argmax(cnt))
+        assert bool(exact[int(torch.argmax(cnt))]) and 0 < int(exact.sum()) < c          # something was pruned
+        assert torch.equal(c2[exact], cnt[exact]) and torch.equal(v2[exact].bool(), vis[exact])
+        assert bool((c2[~exact] <= cnt[~exact]).all()) and bool((c2[~exact] < cnt.max()).all())
+        assert dp.viewpoint_select(pts) == int(torch.argmax(cnt))
+        print("scan %d: %d of %d views exact" % (k, int(exact.sum()), c))
+    # ties: every viewpoint twice -> the first copy wins, both copies stay exact
+    eyes2 = torch.cat([eyes[:512], eyes[:512]])
+    vis_t, cnt_t, _ = dp.hidden_point_removal(pts, eyes2.cpu().numpy(), 10000.0)
+    _, cnt_b, _ = dp.hidden_point_removal(pts, eyes2.cpu().numpy(), 10000.0, best_only=True)
+    assert int(torch.argmax(cnt_b)) == int(torch.argmax(cnt_t)) < 512
+    best = int(torch.argmax(cnt_t))
+    assert int(cnt_b[best]) == int(cnt_b[best + 512]) == int(cnt_t[best])
