@@ -1,5 +1,5 @@
 // nn.h -- declarations shared by the nearest-neighbour kernels (chamfer.hip: VALU and
-// fp32-MFMA paths, nn_bf16.hip: split-bf16 MFMA path): launch descriptor, the
+// fp32-MFMA paths, nn_f16.hip + nn_finish.hip: split-f16 MFMA filter and its exact finish): launch descriptor, the
 // reference's distance arithmetic, candidate lists and the exact re-scan.
 #pragma once
 #include "common.h"
@@ -32,7 +32,7 @@ struct NNDir {
     int *out_i;
     unsigned long long *part;   // per-slice partials [S, B*nq] (S > 1): distance bits << 32 | chunk
     int nq, nt;
-    // split-bf16 path (nn_bf16.hip)
+    // split-f16 path (nn_f16.hip / nn_finish.hip)
     float *tmaxp;           // partial maxima of |t'|^2 [B][ntmax] (per slice, or per split block)
     const uint4 *arec;      // pre-split targets [B][4 planes][ntp] x 16 B
     int ntp, ntmax;         // nt rounded up to 128; entries of tmaxp per batch element

@@ -1,8 +1,8 @@
 // nn_f16.hip -- nearest-neighbour filter with ONE v_mfma_f32_32x32x16_f16 per 32x32 tile.
 //
-// Same filter-and-prove scheme as nn_bf16.hip (which needs two chained bf16
-// instructions per tile: three 8-bit pieces per operand, 27 products).  An f16 piece
-// carries 11 bits, so two pieces v = h + l (h = RN16(v), l = RN16(v - h), residual
+// Filter-and-prove scheme (the finish half is nn_finish.hip).  A split-bf16 variant would
+// need two chained instructions per tile (three 8-bit pieces per operand, 27 products) and
+// was retired in round 3.  An f16 piece carries 11 bits, so two pieces v = h + l (h = RN16(v), l = RN16(v - h), residual
 // <= 2^-22 |v|) and all four products per coordinate fit the K = 16 of a single
 // instruction:
 //     lanes  0..31 (k 0..7):   A = [xh,xh,xl,xl, yh,yh,yl,yl]   B = [qxh,qxl,qxh,qxl, qyh,qyl,qyh,qyl]
