@@ -32,7 +32,8 @@ __device__ __forceinline__ unsigned f2key(float f)
 }
 __device__ __forceinline__ float key2f(unsigned k)
 {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+    // branch-free: the select form crashes hipcc 7.2's instruction selection inside project_write_kernel
+    return __uint_as_float(k ^ ((unsigned)((int)~k >> 31) | 0x80000000u));
 }
 
 __device__ __forceinline__ void project_point(const float *v, float focal, float A, float B, float px, float py,
@@ -47,134 +48,239 @@ __device__ __forceinline__ void project_point(const float *v, float focal, float
     oz = __fmaf_rn(A, zc, B) / w;
 }
 
-// Pass 1: per-camera bounding box of the NDC xy, nothing stored per point.
-// Lane = camera (its view matrix in registers), the block's points come from LDS as broadcast
-// reads: no per-point global loads (three strided dword loads per (camera, point) kept the first
-// version at the texture-address rate: 152 us for 1024 x 71372), no cross-lane reduction inside
-// the loop -- a lane's running extremes are its camera's.  A block covers 64 cameras x one of
-// kBoxSplits slices of the cloud and stores its partial box; project_box_reduce_kernel folds the
-// slices and derives the rescale constants once per camera.
-constexpr int kBoxChunk = 2048;        // points staged per LDS round (24 KiB)
-constexpr int kBoxSplits = 64;         // slices of the cloud: 16 camera groups x 64 = 1024 blocks at C = 1024
+// Pass 1: per-camera bounding box of the NDC xy, nothing stored per point.  Two kernels, exact result:
+//
+//  (a) project_bbox_approx_kernel -- every (camera, point) once, CHEAPLY: the camera-space coordinates with the
+//      oracle's own operations (packed fp32: two points per instruction), the two quotients as a * v_rcp(w)
+//      (relative error < 2^-22 against the correctly rounded quotient the oracle computes), running float
+//      min/max per (camera, slice of the cloud).  Lane = camera (view matrix in registers), wave = slice (256 of
+//      them), its points broadcast from LDS (SoA so that a 16-byte read delivers four x's as two register pairs).
+//  (b) project_box_exact_kernel, one block per camera -- a slice can hold the exact extreme only if its
+//      approximate extreme is within 2^-19 (relative to the largest |quotient|) of the best one: typically four
+//      or five of the 256.  A camera whose approximate pass met a non-finite quotient takes all its slices.
+//  (c) same kernel -- the candidate slices again with IEEE divisions (lane = point), exact min/max through
+//      order-preserving keys: the camera's final box.
+//
+// Rounding is monotone, so the maximum of the rounded quotients is attained at the point of the largest true
+// quotient, which (b) can not drop: |approx - exact| <= 2^-22 |exact| for every point, the window is 8 x wider
+// and carries an absolute 2^-120 for flushed denormals.  (A brute-force exact pass, round 2, spent 116 us on two
+// IEEE divisions per pair; a single pass that divides exactly only inside a running window divides every time
+// because a wave divides whenever one lane asks.)
+constexpr int kBoxBlocks = 64;                       // blocks per camera group: 16 groups x 64 = 1024 blocks at C = 1024
+constexpr int kBoxSlices = kBoxBlocks * (kPBlock / kWave);      // 256 slices of the cloud, one per wave
+constexpr int kBoxChunk = 512;                       // points a wave stages per LDS round (6 KiB, wave-private)
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(kPBlock) void project_bbox_kernel(int c, int n, const float *__restrict__ view, float focal,
-                                                               const float *__restrict__ xyz, unsigned *__restrict__ part)
+__device__ __forceinline__ int slice_len(int n) { return ((n + kBoxSlices - 1) / kBoxSlices + 3) & ~3; }   // multiple of 4
+
+__global__ __launch_bounds__(kPBlock) void project_bbox_approx_kernel(int c, int n, const float *__restrict__ view, float focal,
+                                                                      const float *__restrict__ xyz, float *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) float pts[kBoxChunk * 3 + 16];      // + a padding group: the last group of four is read whole
-    __shared__ unsigned s_box[kPBlock / kWave][4][kWave];
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float s_pts[kPBlock / kWave][3][kBoxChunk];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int cam = blockIdx.y * kWave + lane;
-    const int split = blockIdx.x;
+    const int slice = blockIdx.x * (kPBlock / kWave) + wave;
+    float *sx = s_pts[wave][0], *sy = s_pts[wave][1], *sz = s_pts[wave][2];
     const float *V = view + (size_t)(cam < c ? cam : c - 1) * 12;
     float v[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) v[k] = V[k];
-    const int per = (n + kBoxSplits - 1) / kBoxSplits;
-    const int p_begin = split * per, p_end = min(n, p_begin + per);
-    unsigned mnx = 0xffffffffu, mny = 0xffffffffu, mxx = 0xffffffffu, mxy = 0xffffffffu;
+    const v2f v0 = {v[0], v[0]}, v1 = {v[1], v[1]}, v2 = {v[2], v[2]}, v3 = {v[3], v[3]};
+    const v2f v4 = {v[4], v[4]}, v5 = {v[5], v[5]}, v6 = {v[6], v[6]}, v7 = {v[7], v[7]};
+    const v2f v8 = {v[8], v[8]}, v9 = {v[9], v[9]}, v10 = {v[10], v[10]}, v11 = {v[11], v[11]};
+    const v2f foc = {focal, focal}, zero = {0.0f, 0.0f};
+    const int per = slice_len(n);
+    const int p_begin = min(n, slice * per), p_end = min(n, p_begin + per);
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    v2f bad = {0.0f, 0.0f};                 // becomes NaN when a quotient is not finite
+    // the staging area is the wave's own: LDS operations of one wave complete in order, no block barrier
     for (int p0 = p_begin; p0 < p_end; p0 += kBoxChunk) {
         const int cnt = min(kBoxChunk, p_end - p0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < cnt * 3; i += kPBlock) pts[i] = xyz[(size_t)p0 * 3 + i];
-        __syncthreads();
-        // the block's four waves take interleaved groups of four points: three 16-byte broadcast reads
-        // deliver them, four independent division chains per lane
+        for (int i = lane; i < cnt * 3; i += kWave) {
+            const float val = xyz[(size_t)p0 * 3 + i];
+            const int pt = i / 3, comp = i - pt * 3;
+            (comp == 0 ? sx : (comp == 1 ? sy : sz))[pt] = val;
+        }
+        // groups of four are read whole: pad the last one with copies of the chunk's first point
         const int groups = (cnt + 3) >> 2;
-        for (int g = wave; g < groups; g += kPBlock / kWave) {
-            const float4 a0 = *(const float4 *)&pts[g * 12 + 0], a1 = *(const float4 *)&pts[g * 12 + 4],
-                         a2 = *(const float4 *)&pts[g * 12 + 8];
-            const float c4[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+        if (lane < groups * 4 - cnt) {
+            const float x0 = xyz[(size_t)p0 * 3 + 0], y0 = xyz[(size_t)p0 * 3 + 1], z0 = xyz[(size_t)p0 * 3 + 2];
+            sx[cnt + lane] = x0; sy[cnt + lane] = y0; sz[cnt + lane] = z0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 2
+        for (int g = 0; g < groups; g++) {
+            const float4 X = *(const float4 *)&sx[g * 4], Y = *(const float4 *)&sy[g * 4], Z = *(const float4 *)&sz[g * 4];
+            const v2f px[2] = {{X.x, X.y}, {X.z, X.w}}, py[2] = {{Y.x, Y.y}, {Y.z, Y.w}}, pz[2] = {{Z.x, Z.y}, {Z.z, Z.w}};
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const float px = c4[t * 3 + 0], py = c4[t * 3 + 1], pz = c4[t * 3 + 2];
-                const float xc = __fadd_rn(__fmaf_rn(v[2], pz, __fmaf_rn(v[1], py, __fmul_rn(v[0], px))), v[3]);
-                const float yc = __fadd_rn(__fmaf_rn(v[6], pz, __fmaf_rn(v[5], py, __fmul_rn(v[4], px))), v[7]);
-                const float zc = __fadd_rn(__fmaf_rn(v[10], pz, __fmaf_rn(v[9], py, __fmul_rn(v[8], px))), v[11]);
+            for (int h = 0; h < 2; h++) {
+                // the oracle's operation order: fadd(fma(v2, z, fma(v1, y, fmul(v0, x))), v3)
+                const v2f xc = __builtin_elementwise_fma(v2, pz[h], __builtin_elementwise_fma(v1, py[h], v0 * px[h])) + v3;
+                const v2f yc = __builtin_elementwise_fma(v6, pz[h], __builtin_elementwise_fma(v5, py[h], v4 * px[h])) + v7;
+                const v2f zc = __builtin_elementwise_fma(v10, pz[h], __builtin_elementwise_fma(v9, py[h], v8 * px[h])) + v11;
+                const v2f r = {__builtin_amdgcn_rcpf(-zc.x), __builtin_amdgcn_rcpf(-zc.y)};
+                const v2f qx = (foc * xc) * r, qy = (foc * yc) * r;
+                mnx = fminf(fminf(mnx, qx.x), qx.y); mxx = fmaxf(fmaxf(mxx, qx.x), qx.y);
+                mny = fminf(fminf(mny, qy.x), qy.y); mxy = fmaxf(fmaxf(mxy, qy.x), qy.y);
+                bad = __builtin_elementwise_fma(qx, zero, bad);
+                bad = __builtin_elementwise_fma(qy, zero, bad);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (cam < c) {
+        if (bad.x + bad.y != 0.0f) mnx = mny = mxx = mxy = __builtin_nanf("");        // NaN or (never) a non-zero sum
+        *(float4 *)(part + ((size_t)cam * kBoxSlices + slice) * 4) = make_float4(mnx, mny, mxx, mxy);
+    }
+}
+
+// (b) + (c): one block per camera.  Thread = slice: find the candidate slices; then the four waves take one
+// candidate slice each (lane = point, all of a slice's points in flight at once) with IEEE divisions and
+// order-preserving keys; the block's minimum keys are the camera's final box.
+constexpr int kExactUnroll = 5;
+__global__ __launch_bounds__(kPBlock) void project_box_exact_kernel(int n, const float *__restrict__ view, float focal,
+                                                                    const float *__restrict__ xyz, const float *__restrict__ part,
+                                                                    unsigned *__restrict__ keys)
+{
+    static_assert(kBoxSlices == kPBlock, "one thread per slice");
+    __shared__ int s_list[kBoxSlices];
+    __shared__ float s_red[kPBlock / kWave][4];
+    __shared__ int s_cnt[kPBlock / kWave];
+    __shared__ int s_weird;
+    __shared__ unsigned s_keys[4];
+    const int cam = blockIdx.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const float4 b = *(const float4 *)(part + ((size_t)cam * kBoxSlices + threadIdx.x) * 4);
+    if (threadIdx.x < 4) s_keys[threadIdx.x] = 0xffffffffu;
+    if (threadIdx.x == 0) s_weird = 0;
+    float q0 = b.x, q1 = b.y, q2 = b.z, q3 = b.w;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        q0 = fminf(q0, __shfl_xor(q0, off, kWave)); q1 = fminf(q1, __shfl_xor(q1, off, kWave));
+        q2 = fmaxf(q2, __shfl_xor(q2, off, kWave)); q3 = fmaxf(q3, __shfl_xor(q3, off, kWave));
+    }
+    if (lane == 0) { s_red[wave][0] = q0; s_red[wave][1] = q1; s_red[wave][2] = q2; s_red[wave][3] = q3; }
+    __syncthreads();
+    if (__ballot(b.x != b.x) != 0ull && lane == 0) s_weird = 1;
+#pragma unroll
+    for (int w2 = 0; w2 < kPBlock / kWave; w2++) {
+        q0 = fminf(q0, s_red[w2][0]); q1 = fminf(q1, s_red[w2][1]); q2 = fmaxf(q2, s_red[w2][2]); q3 = fmaxf(q3, s_red[w2][3]);
+    }
+    const float big = fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3)));
+    const float tol = __fmaf_rn(big, 1.9073486328125e-06f /* 2^-19 */, 7.52316384526264e-37f /* 2^-120 */);
+    bool cand = b.x <= q0 + tol || b.y <= q1 + tol || b.z >= q2 - tol || b.w >= q3 - tol;
+    __syncthreads();
+    if (s_weird || !(big < INFINITY)) cand = true;            // a non-finite quotient somewhere: every slice exactly
+    const unsigned long long m = __ballot(cand);
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0, ncand = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < kPBlock / kWave; w2++) {
+        base += w2 < wave ? s_cnt[w2] : 0;
+        ncand += s_cnt[w2];
+    }
+    if (cand) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = threadIdx.x;
+    __syncthreads();
+    const int per = slice_len(n);
+    const float *V = view + (size_t)cam * 12;
+    float v[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) v[k] = V[k];
+    unsigned mnx = 0xffffffffu, mny = 0xffffffffu, mxx = 0xffffffffu, mxy = 0xffffffffu;
+    for (int r = wave; r < ncand; r += kPBlock / kWave) {
+        const int p_begin = min(n, s_list[r] * per), p_end = min(n, p_begin + per);
+        for (int p0 = p_begin + lane; p0 < p_end; p0 += kWave * kExactUnroll) {
+            float px[kExactUnroll], py[kExactUnroll], pz[kExactUnroll];
+#pragma unroll
+            for (int u = 0; u < kExactUnroll; u++) {
+                const int pp = min(p0 + u * kWave, p_end - 1);          // past the end: the slice's last point again
+                px[u] = xyz[(size_t)pp * 3 + 0]; py[u] = xyz[(size_t)pp * 3 + 1]; pz[u] = xyz[(size_t)pp * 3 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < kExactUnroll; u++) {
+                const float xc = __fadd_rn(__fmaf_rn(v[2], pz[u], __fmaf_rn(v[1], py[u], __fmul_rn(v[0], px[u]))), v[3]);
+                const float yc = __fadd_rn(__fmaf_rn(v[6], pz[u], __fmaf_rn(v[5], py[u], __fmul_rn(v[4], px[u]))), v[7]);
+                const float zc = __fadd_rn(__fmaf_rn(v[10], pz[u], __fmaf_rn(v[9], py[u], __fmul_rn(v[8], px[u]))), v[11]);
                 const float w = -zc;
                 const unsigned kx = f2key(__fmul_rn(focal, xc) / w), ky = f2key(__fmul_rn(focal, yc) / w);
-                if (g * 4 + t < cnt) {
-                    mnx = min(mnx, kx); mny = min(mny, ky);
-                    mxx = min(mxx, ~kx); mxy = min(mxy, ~ky);
-                }
+                mnx = min(mnx, kx); mny = min(mny, ky);
+                mxx = min(mxx, ~kx); mxy = min(mxy, ~ky);
             }
         }
     }
-    s_box[wave][0][lane] = mnx; s_box[wave][1][lane] = mny; s_box[wave][2][lane] = mxx; s_box[wave][3][lane] = mxy;
-    __syncthreads();
-    if (wave == 0 && cam < c) {
-#pragma unroll
-        for (int w2 = 1; w2 < kPBlock / kWave; w2++) {
-            mnx = min(mnx, s_box[w2][0][lane]); mny = min(mny, s_box[w2][1][lane]);
-            mxx = min(mxx, s_box[w2][2][lane]); mxy = min(mxy, s_box[w2][3][lane]);
-        }
-        unsigned *o = part + ((size_t)cam * kBoxSplits + split) * 4;
-        o[0] = mnx; o[1] = mny; o[2] = mxx; o[3] = mxy;
-    }
-}
-
-// camrec[cam] = view[12] | cx, cy, sc, 0 : everything pass 2 needs per camera, 64 bytes.
-// One wave per camera: lane s holds slice s's partial box (kBoxSplits == 64), shuffles fold them.
-// (A one-thread-per-camera loop over the slices crashes hipcc 7.2's instruction selection.)
-__global__ __launch_bounds__(kWave) void project_box_reduce_kernel(int c, const float *__restrict__ view,
-                                                                   const unsigned *__restrict__ part, int have_box,
-                                                                   float *__restrict__ camrec, float *__restrict__ bbox)
-{
-    static_assert(kBoxSplits == kWave, "one lane per slice");
-    const int cam = blockIdx.x, lane = threadIdx.x;
-    float *o = camrec + (size_t)cam * 16;
-    if (lane < 12) o[lane] = view[(size_t)cam * 12 + lane];
-    unsigned k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
-    if (have_box) {
-        const unsigned *p = part + ((size_t)cam * kBoxSplits + lane) * 4;
-        k0 = p[0]; k1 = p[1]; k2 = p[2]; k3 = p[3];
-    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        k0 = min(k0, (unsigned)__shfl_xor((int)k0, off, kWave));
-        k1 = min(k1, (unsigned)__shfl_xor((int)k1, off, kWave));
-        k2 = min(k2, (unsigned)__shfl_xor((int)k2, off, kWave));
-        k3 = min(k3, (unsigned)__shfl_xor((int)k3, off, kWave));
+        mnx = min(mnx, (unsigned)__shfl_xor((int)mnx, off, kWave)); mny = min(mny, (unsigned)__shfl_xor((int)mny, off, kWave));
+        mxx = min(mxx, (unsigned)__shfl_xor((int)mxx, off, kWave)); mxy = min(mxy, (unsigned)__shfl_xor((int)mxy, off, kWave));
     }
-    if (lane != 0) return;
-    float cx = 0.0f, cy = 0.0f, sc = 1.0f;
-    if (have_box) {
-        const float mnx = key2f(k0), mny = key2f(k1), mxx = key2f(~k2), mxy = key2f(~k3);
-        if (bbox) { bbox[cam * 4 + 0] = mnx; bbox[cam * 4 + 1] = mny; bbox[cam * 4 + 2] = mxx; bbox[cam * 4 + 3] = mxy; }
-        cx = __fadd_rn(mnx, mxx) / 2.0f;
-        cy = __fadd_rn(mny, mxy) / 2.0f;
-        const float sx = __fsub_rn(mxx, mnx), sy = __fsub_rn(mxy, mny);
-        sc = sx > sy ? sx : sy;
+    if (lane == 0) {
+        atomicMin(&s_keys[0], mnx); atomicMin(&s_keys[1], mny); atomicMin(&s_keys[2], mxx); atomicMin(&s_keys[3], mxy);
     }
-    o[12] = cx; o[13] = cy; o[14] = sc; o[15] = 0.0f;
+    __syncthreads();
+    if (threadIdx.x < 4) keys[(size_t)cam * 4 + threadIdx.x] = s_keys[threadIdx.x];
 }
 
-// Pass 2: lane = point (loaded ONCE, kept in registers), loop over the block's 64 cameras whose
-// records come from LDS as broadcast reads; stores are coalesced per camera row.  Projects again
-// (recomputing costs nothing next to a 28 B/point round trip through HBM), rescales
-// (DepthPrompting.py:246-266) and stores uv, depth and, if asked, the NDC point.
+// Pass 2: lane = 4 points (loaded ONCE, kept in registers), loop over the block's 64 cameras whose
+// records come from LDS as broadcast reads.  Projects again (recomputing costs nothing next to a
+// 28 B/point round trip through HBM), rescales (DepthPrompting.py:246-266) and stores uv, depth and,
+// if asked, the NDC point.
+// Store shape (tools/ubench_write3.hip, pure stores of this layout at 1024 x 71372): a wave owns 256
+// consecutive points, lane l the points {2l, 2l+1, 128+2l, 129+2l}, so every store instruction writes one
+// contiguous run (uv 2 x 1 KiB, depth 2 x 512 B per camera row); and consecutive block ids walk the CAMERA
+// groups of one point block, not the point blocks of one camera group: rows are N x 8 B apart and N is
+// not a multiple of 16, so neighbouring point blocks share a partly written 128-byte line per row --
+// launched side by side they cost 172 us against 140 us in this order (plain memset: 129 us).
 constexpr int kCamGroup = 64;
-constexpr int kWritePer = 4;        // consecutive points per lane: uv leaves as two 16-byte stores, depth as one
+constexpr int kWritePer = 4;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
-__global__ __launch_bounds__(kPBlock) void project_write_kernel(int c, int n, const float *__restrict__ camrec, float focal,
+__global__ __launch_bounds__(kPBlock) void project_write_kernel(int c, int n, int cgroups, const float *__restrict__ view,
+                                                                const unsigned *__restrict__ keys, float focal,
                                                                 float A, float B, const float *__restrict__ xyz, int rescale,
                                                                 float padmul, float *__restrict__ transformed,
-                                                                float *__restrict__ uv, float *__restrict__ depth)
+                                                                float *__restrict__ uv, float *__restrict__ depth,
+                                                                float *__restrict__ bbox)
 {
-    __shared__ float4 rec[kCamGroup * 4];
-    const int cam0 = blockIdx.y * kCamGroup;
+    __shared__ float4 rec[kCamGroup * 4];       // per camera: view[12] | cx, cy, sc, 0
+    const int cam0 = (int)(blockIdx.x % (unsigned)cgroups) * kCamGroup;
+    const int pblock = (int)(blockIdx.x / (unsigned)cgroups);
     const int ncam = min(kCamGroup, c - cam0);
-    for (int i = threadIdx.x; i < ncam * 4; i += kPBlock) rec[i] = ((const float4 *)camrec)[(size_t)cam0 * 4 + i];
-    const int j0 = (blockIdx.x * kPBlock + threadIdx.x) * kWritePer;
+    for (int i = threadIdx.x; i < ncam * 3; i += kPBlock) rec[(i / 3) * 4 + i % 3] = ((const float4 *)view)[(size_t)cam0 * 3 + i];
+    if (threadIdx.x < ncam) {
+        // the camera's box (pass 1) -> centre and extent, DepthPrompting.py:246-262
+        float cx = 0.0f, cy = 0.0f, sc = 1.0f;
+        if (keys) {
+            const unsigned *kq = keys + (size_t)(cam0 + threadIdx.x) * 4;
+            const float mnx = key2f(kq[0]), mny = key2f(kq[1]), mxx = key2f(~kq[2]), mxy = key2f(~kq[3]);
+            if (bbox && pblock == 0) {
+                float *bo = bbox + (size_t)(cam0 + threadIdx.x) * 4;
+                bo[0] = mnx; bo[1] = mny; bo[2] = mxx; bo[3] = mxy;
+            }
+            cx = __fmul_rn(__fadd_rn(mnx, mxx), 0.5f);       // == / 2.0f (exact scaling; a subnormal sum halves with the same rounding)
+            cy = __fmul_rn(__fadd_rn(mny, mxy), 0.5f);
+            const float sx = __fsub_rn(mxx, mnx), sy = __fsub_rn(mxy, mny);
+            sc = sx > sy ? sx : sy;
+        }
+        rec[threadIdx.x * 4 + 3] = make_float4(cx, cy, sc, 0.0f);
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int wbase = (pblock * (kPBlock / kWave) + wave) * (kWave * kWritePer);
+    const int j0 = wbase + lane * 2;                 // points j0, j0+1, j0+128, j0+129
     float p[kWritePer][3];
 #pragma unroll
     for (int t = 0; t < kWritePer; t++) {
-        const int jj = j0 + t < n ? j0 + t : n - 1;
+        const int j = j0 + (t >> 1) * 128 + (t & 1);
+        const int jj = j < n ? j : n - 1;
         p[t][0] = xyz[(size_t)jj * 3 + 0]; p[t][1] = xyz[(size_t)jj * 3 + 1]; p[t][2] = xyz[(size_t)jj * 3 + 2];
     }
-    const bool full = j0 + kWritePer <= n;
+    const bool full = wbase + kWave * kWritePer <= n;      // wave-uniform
     __syncthreads();
-    if (j0 >= n) return;
+    if (wbase >= n) return;
     for (int k = 0; k < ncam; k++) {
         const float4 r0 = rec[k * 4 + 0], r1 = rec[k * 4 + 1], r2 = rec[k * 4 + 2], r3 = rec[k * 4 + 3];
         const float v[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
@@ -192,20 +298,30 @@ __global__ __launch_bounds__(kPBlock) void project_write_kernel(int c, int n, co
         }
         const size_t q = (size_t)(cam0 + k) * n + j0;
         if (full) {
-            f4u s0 = {u[0], vv[0], u[1], vv[1]}, s1 = {u[2], vv[2], u[3], vv[3]}, s2 = {oz[0], oz[1], oz[2], oz[3]};
+            f4u s0 = {u[0], vv[0], u[1], vv[1]}, s1 = {u[2], vv[2], u[3], vv[3]};
+            f2u d0 = {oz[0], oz[1]}, d1 = {oz[2], oz[3]};
             *(f4u *)(uv + q * 2) = s0;
-            *(f4u *)(uv + q * 2 + 4) = s1;
-            *(f4u *)(depth + q) = s2;
+            *(f4u *)(uv + (q + 128) * 2) = s1;
+            *(f2u *)(depth + q) = d0;
+            *(f2u *)(depth + q + 128) = d1;
         } else {
-            for (int t = 0; t < kWritePer && j0 + t < n; t++) {
-                uv[(q + t) * 2 + 0] = u[t];
-                uv[(q + t) * 2 + 1] = vv[t];
-                depth[q + t] = oz[t];
+#pragma unroll
+            for (int t = 0; t < kWritePer; t++) {
+                const int off = (t >> 1) * 128 + (t & 1);
+                if (j0 + off < n) {
+                    uv[(q + off) * 2 + 0] = u[t];
+                    uv[(q + off) * 2 + 1] = vv[t];
+                    depth[q + off] = oz[t];
+                }
             }
         }
         if (transformed) {
-            for (int t = 0; t < kWritePer && j0 + t < n; t++) {
-                transformed[(q + t) * 3 + 0] = ox[t]; transformed[(q + t) * 3 + 1] = oy[t]; transformed[(q + t) * 3 + 2] = oz[t];
+#pragma unroll
+            for (int t = 0; t < kWritePer; t++) {
+                const int off = (t >> 1) * 128 + (t & 1);
+                if (j0 + off < n) {
+                    transformed[(q + off) * 3 + 0] = ox[t]; transformed[(q + off) * 3 + 1] = oy[t]; transformed[(q + off) * 3 + 2] = oz[t];
+                }
             }
         }
     }
@@ -327,30 +443,6 @@ __global__ __launch_bounds__(kPBlock) void zbuf_test_kernel(int n, const float *
     if ((threadIdx.x & (kWave - 1)) == 0 && local) atomicAdd(&counts[cam], local);
 }
 
-// one side stream + events per device, created on first use (never destroyed: process lifetime)
-struct SideStream {
-    std::mutex enqueue;      // one caller at a time records / waits on the events below (host side only)
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, done[4] = {nullptr, nullptr, nullptr, nullptr};
-};
-
-static SideStream *side_stream()
-{
-    static std::mutex mu;
-    static SideStream per_dev[64];
-    int dev = 0;
-    if (!check(hipGetDevice(&dev), "hipGetDevice") || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> l(mu);
-    SideStream &s = per_dev[dev];
-    if (!s.stream) {
-        if (!check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
-        if (!check(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming), "hipEventCreate")) return nullptr;
-        for (int i = 0; i < 4; i++)
-            if (!check(hipEventCreateWithFlags(&s.done[i], hipEventDisableTiming), "hipEventCreate")) return nullptr;
-    }
-    return &s;
-}
-
 static int grid_for(long long n, int cap)
 {
     long long g = ceil_div64(n, kPBlock);
@@ -368,52 +460,29 @@ GENPC_API int genpc_get_uvs(int c, int n, const float *view, float focal, float 
     using namespace genpc;
     if (c <= 0 || n <= 0) return 1;
     hipStream_t st = (hipStream_t)stream;
-    // scratch: per-camera records (view | cx, cy, sc) and the per-slice partial boxes
-    const size_t rec_bytes = ((size_t)c * 16 * sizeof(float) + 255) & ~(size_t)255;
-    char *ws = (char *)workspace(2, rec_bytes + (size_t)c * kBoxSplits * 4 * sizeof(unsigned), st);
+    // scratch: per-(camera, slice) approximate boxes, the cameras' final keys
+    const size_t part_bytes = (size_t)c * kBoxSlices * 4 * sizeof(float);
+    char *ws = (char *)workspace(2, part_bytes + (size_t)c * 4 * sizeof(unsigned), st);
     if (!ws) return 0;
-    float *camrec = (float *)ws;
-    unsigned *part = (unsigned *)(ws + rec_bytes);
+    float *part = (float *)ws;
+    unsigned *keys = (unsigned *)(ws + part_bytes);
     const float A = (zfar + znear) / (znear - zfar);
     const float B = (2.0f * zfar * znear) / (znear - zfar);
     const int have_box = (rescale || bbox) ? 1 : 0;
-    // Pass 1 is arithmetic only, pass 2 is bound by its stores (877 MB at 1024 x 71372: ~180 us is
-    // what a plain store kernel needs on this chip, tools/ubench_write.hip).  With many cameras
-    // they are run as a two-stage pipeline over camera groups: the box of group g + 1 is computed on a
-    // side stream while group g is written on the caller's stream (fork / join with events; legal
-    // under stream capture).  Few cameras: one group, no side stream.
-    // (measured: 484 us pipelined vs 365 us back to back at 1024 x 71372 -- the cross-stream events cost more
-    // than the overlap returns; the pipeline stays available for experiments)
-    static const bool pipe = getenv("GENPC_UVS_PIPELINE") != nullptr;
-    const int groups = (pipe && have_box && c >= 256) ? 4 : 1;
-    const int per = ceil_div(ceil_div(c, groups), kCamGroup) * kCamGroup;      // cameras per group, whole write blocks
-    SideStream *side = groups > 1 ? side_stream() : nullptr;
-    if (groups > 1 && !side) return 0;
-    std::unique_lock<std::mutex> guard;
-    if (side) guard = std::unique_lock<std::mutex>(side->enqueue);
-    if (side) {
-        if (!check(hipEventRecord(side->fork, st), "hipEventRecord")) return 0;
-        if (!check(hipStreamWaitEvent(side->stream, side->fork, 0), "hipStreamWaitEvent")) return 0;
+    // Pass 1 is arithmetic only (see above), pass 2 is bound by its stores and five divisions per pair.
+    // (Running pass 1 of one camera group on a side stream under pass 2 of the previous one was measured in
+    // round 2: 484 us against 365 back to back -- the cross-stream events cost more than the overlap returns.)
+    if (have_box) {
+        hipLaunchKernelGGL(project_bbox_approx_kernel, dim3(kBoxBlocks, ceil_div(c, kWave)), dim3(kPBlock), 0, st, c, n, view, focal,
+                           xyz, part);
+        hipLaunchKernelGGL(project_box_exact_kernel, dim3(c), dim3(kPBlock), 0, st, n, view, focal, xyz, (const float *)part, keys);
     }
-    for (int g = 0; g < groups; g++) {
-        const int c0 = g * per, cg = std::min(per, c - c0);
-        if (cg <= 0) break;
-        const float *vw = view + (size_t)c0 * 12;
-        unsigned *pg = part + (size_t)c0 * kBoxSplits * 4;
-        if (have_box) {
-            hipStream_t bs = side ? side->stream : st;
-            hipLaunchKernelGGL(project_bbox_kernel, dim3(kBoxSplits, ceil_div(cg, kWave)), dim3(kPBlock), 0, bs, cg, n, vw, focal, xyz, pg);
-            if (side) {
-                if (!check(hipEventRecord(side->done[g], side->stream), "hipEventRecord")) return 0;
-                if (!check(hipStreamWaitEvent(st, side->done[g], 0), "hipStreamWaitEvent")) return 0;
-            }
-        }
-        hipLaunchKernelGGL(project_box_reduce_kernel, dim3(cg), dim3(kWave), 0, st, cg, vw, (const unsigned *)pg, have_box,
-                           camrec + (size_t)c0 * 16, bbox ? bbox + (size_t)c0 * 4 : nullptr);
-        hipLaunchKernelGGL(project_write_kernel, dim3(ceil_div(n, kPBlock * kWritePer), ceil_div(cg, kCamGroup)), dim3(kPBlock), 0, st, cg,
-                           n, (const float *)(camrec + (size_t)c0 * 16), focal, A, B, xyz, rescale, padmul,
-                           transformed ? transformed + (size_t)c0 * n * 3 : nullptr, uv + (size_t)c0 * n * 2, depth + (size_t)c0 * n);
-    }
+    const int cgroups = ceil_div(c, kCamGroup);
+    const long long wblocks = (long long)ceil_div(n, kPBlock * kWritePer) * cgroups;
+    if (wblocks > 0x7fffffffLL) { set_error("get_uvs: cameras x points exceed one launch"); return 0; }
+    hipLaunchKernelGGL(project_write_kernel, dim3((unsigned)wblocks), dim3(kPBlock), 0, st, c, n, cgroups, view,
+                       have_box ? (const unsigned *)keys : (const unsigned *)nullptr, focal, A, B, xyz, rescale, padmul, transformed, uv,
+                       depth, bbox);
     return check(hipGetLastError(), "get_uvs launch") ? 1 : 0;
 }
 
