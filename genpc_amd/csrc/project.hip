@@ -14,6 +14,7 @@
 // Arithmetic (fma order, IEEE division) matches oracle/genpc_oracle_geom.c bit for
 // bit; min/max are exact, so uv is bit-exact too.
 #include "common.h"
+#include "fastdiv.h"
 #include "../../include/genpc_hip.h"
 
 #include <stdlib.h>
@@ -69,7 +70,6 @@ __device__ __forceinline__ void project_point(const float *v, float focal, float
 constexpr int kBoxBlocks = 64;                       // blocks per camera group: 16 groups x 64 = 1024 blocks at C = 1024
 constexpr int kBoxSlices = kBoxBlocks * (kPBlock / kWave);      // 256 slices of the cloud, one per wave
 constexpr int kBoxChunk = 512;                       // points a wave stages per LDS round (6 KiB, wave-private)
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int slice_len(int n) { return ((n + kBoxSlices - 1) / kBoxSlices + 3) & ~3; }   // multiple of 4
 
@@ -239,6 +239,14 @@ constexpr int kWritePer = 4;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
+__device__ __forceinline__ v2f splat2(float a) { return (v2f){a, a}; }
+
+// Arithmetic of the loop: the oracle's operations (same order, same roundings), two per instruction -- (xc, yc)
+// of a point and zc of two points as packed fp32, the five correctly rounded divisions per (camera, point) as
+// fastdiv.h's shared-reciprocal core (ox, oy, oz share 1/w; the two rescale quotients share the camera's 1/sc,
+// refined once per block).  A wave whose operands leave fastdiv's safe range (a point on the camera plane, a
+// point exactly at the box centre, ...) redoes that camera with the compiler's divisions.
+// (round 2: ~270 VALU + 20 v_rcp per camera and wave, 146 us of issue for 1024 x 71372 -- more than the stores.)
 __global__ __launch_bounds__(kPBlock) void project_write_kernel(int c, int n, int cgroups, const float *__restrict__ view,
                                                                 const unsigned *__restrict__ keys, float focal,
                                                                 float A, float B, const float *__restrict__ xyz, int rescale,
@@ -246,11 +254,17 @@ __global__ __launch_bounds__(kPBlock) void project_write_kernel(int c, int n, in
                                                                 float *__restrict__ uv, float *__restrict__ depth,
                                                                 float *__restrict__ bbox)
 {
-    __shared__ float4 rec[kCamGroup * 4];       // per camera: view[12] | cx, cy, sc, 0
+    // per camera: (v0 v4 v1 v5) (v2 v6 v3 v7) (v8 v9 v10 v11) (cx cy sc 1/sc): rows x and y interleaved so that a
+    // 16-byte broadcast read delivers them as register pairs
+    __shared__ __attribute__((aligned(16))) float rec[kCamGroup * 16];
     const int cam0 = (int)(blockIdx.x % (unsigned)cgroups) * kCamGroup;
     const int pblock = (int)(blockIdx.x / (unsigned)cgroups);
     const int ncam = min(kCamGroup, c - cam0);
-    for (int i = threadIdx.x; i < ncam * 3; i += kPBlock) rec[(i / 3) * 4 + i % 3] = ((const float4 *)view)[(size_t)cam0 * 3 + i];
+    for (int i = threadIdx.x; i < ncam * 12; i += kPBlock) {
+        const int cam = i / 12, j = i - cam * 12;
+        const int pos = j >= 8 ? j : ((j & 3) * 2 + (j >> 2));
+        rec[cam * 16 + pos] = view[(size_t)cam0 * 12 + i];
+    }
     if (threadIdx.x < ncam) {
         // the camera's box (pass 1) -> centre and extent, DepthPrompting.py:246-262
         float cx = 0.0f, cy = 0.0f, sc = 1.0f;
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(kPBlock) void project_write_kernel(int c, int n, in
             const float sx = __fsub_rn(mxx, mnx), sy = __fsub_rn(mxy, mny);
             sc = sx > sy ? sx : sy;
         }
-        rec[threadIdx.x * 4 + 3] = make_float4(cx, cy, sc, 0.0f);
+        *(float4 *)&rec[threadIdx.x * 16 + 12] = make_float4(cx, cy, sc, rcp_refined(sc));
     }
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int wbase = (pblock * (kPBlock / kWave) + wave) * (kWave * kWritePer);
@@ -278,28 +292,69 @@ __global__ __launch_bounds__(kPBlock) void project_write_kernel(int c, int n, in
         const int jj = j < n ? j : n - 1;
         p[t][0] = xyz[(size_t)jj * 3 + 0]; p[t][1] = xyz[(size_t)jj * 3 + 1]; p[t][2] = xyz[(size_t)jj * 3 + 2];
     }
+    const v2f PX[2] = {{p[0][0], p[1][0]}, {p[2][0], p[3][0]}}, PY[2] = {{p[0][1], p[1][1]}, {p[2][1], p[3][1]}},
+              PZ[2] = {{p[0][2], p[1][2]}, {p[2][2], p[3][2]}};
     const bool full = wbase + kWave * kWritePer <= n;      // wave-uniform
     __syncthreads();
     if (wbase >= n) return;
     for (int k = 0; k < ncam; k++) {
-        const float4 r0 = rec[k * 4 + 0], r1 = rec[k * 4 + 1], r2 = rec[k * 4 + 2], r3 = rec[k * 4 + 3];
-        const float v[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-        float u[kWritePer], vv[kWritePer], oz[kWritePer], ox[kWritePer], oy[kWritePer];
+        const float4 r0 = *(const float4 *)&rec[k * 16 + 0], r1 = *(const float4 *)&rec[k * 16 + 4],
+                     r2 = *(const float4 *)&rec[k * 16 + 8], r3 = *(const float4 *)&rec[k * 16 + 12];
+        v2f uvv[kWritePer], oxy[kWritePer], oz[2];
+        DivRange rng;
+        {
+            const v2f vxy0 = {r0.x, r0.y}, vxy1 = {r0.z, r0.w}, vxy2 = {r1.x, r1.y}, vxy3 = {r1.z, r1.w};
+            v2f w[2], rr[2];
 #pragma unroll
-        for (int t = 0; t < kWritePer; t++) {
-            project_point(v, focal, A, B, p[t][0], p[t][1], p[t][2], ox[t], oy[t], oz[t]);
-            if (rescale) {
-                u[t] = __fadd_rn(__fmul_rn(__fsub_rn(ox[t], r3.x) / r3.z, padmul), 0.5f);
-                vv[t] = __fadd_rn(__fmul_rn(__fsub_rn(oy[t], r3.y) / r3.z, padmul), 0.5f);
-            } else {
-                u[t] = __fmul_rn(__fadd_rn(ox[t], 1.0f), 0.5f);
-                vv[t] = __fmul_rn(__fadd_rn(oy[t], 1.0f), 0.5f);
+            for (int h = 0; h < 2; h++) {
+                const v2f zc = __builtin_elementwise_fma(splat2(r2.z), PZ[h], __builtin_elementwise_fma(splat2(r2.y), PY[h], splat2(r2.x) * PX[h])) + splat2(r2.w);
+                w[h] = -zc;
+                const v2f q = {__builtin_amdgcn_rcpf(w[h].x), __builtin_amdgcn_rcpf(w[h].y)};
+                rr[h] = __builtin_elementwise_fma(__builtin_elementwise_fma(-w[h], q, splat2(1.0f)), q, q);
+                const v2f nz = __builtin_elementwise_fma(splat2(A), zc, splat2(B));
+                oz[h] = div_core2(nz, w[h], rr[h]);
+                rng.add(w[h].x, w[h].y);
+                rng.add(nz.x, nz.y);
+            }
+#pragma unroll
+            for (int t = 0; t < kWritePer; t++) {
+                const v2f xy = __builtin_elementwise_fma(vxy2, splat2(p[t][2]), __builtin_elementwise_fma(vxy1, splat2(p[t][1]), vxy0 * splat2(p[t][0]))) + vxy3;
+                const v2f a = splat2(focal) * xy;
+                const float wt = (t & 1) ? w[t >> 1].y : w[t >> 1].x, rt = (t & 1) ? rr[t >> 1].y : rr[t >> 1].x;
+                oxy[t] = div_core2(a, splat2(wt), splat2(rt));
+                rng.add(a.x, a.y);
+                if (rescale) {
+                    const v2f d = oxy[t] - (v2f){r3.x, r3.y};
+                    uvv[t] = div_core2(d, splat2(r3.z), splat2(r3.w)) * splat2(padmul) + splat2(0.5f);
+                    rng.add(d.x, d.y);
+                } else {
+                    uvv[t] = (oxy[t] + splat2(1.0f)) * splat2(0.5f);
+                }
+            }
+            if (rescale) rng.add(r3.z);
+        }
+        if (__ballot(!rng.ok()) != 0ull) {
+            // some operand outside fastdiv's range: this camera again with the compiler's divisions
+            const float v[12] = {r0.x, r0.z, r1.x, r1.z, r0.y, r0.w, r1.y, r1.w, r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+            for (int t = 0; t < kWritePer; t++) {
+                float ox, oy, ozt;
+                project_point(v, focal, A, B, p[t][0], p[t][1], p[t][2], ox, oy, ozt);
+                oxy[t] = (v2f){ox, oy};
+                if (t & 1) oz[t >> 1].y = ozt; else oz[t >> 1].x = ozt;
+                if (rescale) {
+                    uvv[t].x = __fadd_rn(__fmul_rn(__fsub_rn(ox, r3.x) / r3.z, padmul), 0.5f);
+                    uvv[t].y = __fadd_rn(__fmul_rn(__fsub_rn(oy, r3.y) / r3.z, padmul), 0.5f);
+                } else {
+                    uvv[t].x = __fmul_rn(__fadd_rn(ox, 1.0f), 0.5f);
+                    uvv[t].y = __fmul_rn(__fadd_rn(oy, 1.0f), 0.5f);
+                }
             }
         }
         const size_t q = (size_t)(cam0 + k) * n + j0;
         if (full) {
-            f4u s0 = {u[0], vv[0], u[1], vv[1]}, s1 = {u[2], vv[2], u[3], vv[3]};
-            f2u d0 = {oz[0], oz[1]}, d1 = {oz[2], oz[3]};
+            f4u s0 = {uvv[0].x, uvv[0].y, uvv[1].x, uvv[1].y}, s1 = {uvv[2].x, uvv[2].y, uvv[3].x, uvv[3].y};
+            f2u d0 = {oz[0].x, oz[0].y}, d1 = {oz[1].x, oz[1].y};
             *(f4u *)(uv + q * 2) = s0;
             *(f4u *)(uv + (q + 128) * 2) = s1;
             *(f2u *)(depth + q) = d0;
@@ -309,9 +364,9 @@ __global__ __launch_bounds__(kPBlock) void project_write_kernel(int c, int n, in
             for (int t = 0; t < kWritePer; t++) {
                 const int off = (t >> 1) * 128 + (t & 1);
                 if (j0 + off < n) {
-                    uv[(q + off) * 2 + 0] = u[t];
-                    uv[(q + off) * 2 + 1] = vv[t];
-                    depth[q + off] = oz[t];
+                    uv[(q + off) * 2 + 0] = uvv[t].x;
+                    uv[(q + off) * 2 + 1] = uvv[t].y;
+                    depth[q + off] = (t & 1) ? oz[t >> 1].y : oz[t >> 1].x;
                 }
             }
         }
@@ -320,7 +375,8 @@ __global__ __launch_bounds__(kPBlock) void project_write_kernel(int c, int n, in
             for (int t = 0; t < kWritePer; t++) {
                 const int off = (t >> 1) * 128 + (t & 1);
                 if (j0 + off < n) {
-                    transformed[(q + off) * 3 + 0] = ox[t]; transformed[(q + off) * 3 + 1] = oy[t]; transformed[(q + off) * 3 + 2] = oz[t];
+                    transformed[(q + off) * 3 + 0] = oxy[t].x; transformed[(q + off) * 3 + 1] = oxy[t].y;
+                    transformed[(q + off) * 3 + 2] = (t & 1) ? oz[t >> 1].y : oz[t >> 1].x;
                 }
             }
         }

@@ -326,6 +326,13 @@ int genpc_scale_search_scores(int k, int ns, const float *source, int nt,
 int genpc_mfma_f16_probe(int problems, const unsigned short *a, const unsigned short *b,
                          const float *c, float *d, void *stream);
 
+/* fast[i] = csrc/fastdiv.h's shared-reciprocal division num[i] / den[i] (scalar form), fast_packed[i] = its packed
+ * form, ieee[i] = the compiler's correctly rounded division, in_range[i] = 1 where the callers' range test
+ * (both magnitudes in [2^-50, 2^50]) lets the fast form be used: there the three must agree bit for bit
+ * (tests/test_gpu_fastdiv.py).  All arrays device memory, n elements.                              */
+int genpc_fastdiv_probe(long long n, const float *num, const float *den, float *fast,
+                        float *fast_packed, float *ieee, unsigned char *in_range, void *stream);
+
 /* Farthest point sampling --------------------------------------------------- *
  * Deterministic counterpart of fpsample.fps_sampling as the reference uses it
  * (main.py:21-24, reg_xyz.py:215, DepthPrompting.py:88; third-party, random start):

@@ -370,6 +370,30 @@ def test_get_uvs_fuzz(gp, oracle):
         assert np.array_equal(tr.cpu().numpy(), otr, equal_nan=True), (case, n, c)
 
 
+def test_get_uvs_operands_outside_the_fast_division_range(gp, oracle):
+    """The write pass divides with csrc/fastdiv.h inside [2^-50, 2^50] and with the compiler's division outside
+    (per wave and camera); the box pass rescans everything exactly when its approximate pass meets a non-finite
+    quotient.  Operands built to leave the range: zeros (points on a camera axis, a point at the box centre),
+    a point on the camera plane (w = 0 -> infinite quotients), huge and tiny scenes."""
+    torch = gp["torch"]
+    focal = gp["dp"].focal
+    g = np.linspace(-0.5, 0.5, 21, dtype=np.float32)
+    grid = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)          # symmetric, contains the origin and the axes
+    axis_cam = np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, -1.6]], np.float32)       # looks down -z from (0, 0, 1.6)
+    tilted = gp["dp"].cameras[:3].cpu().numpy().reshape(-1, 12)
+    cases = [("zeros", grid, np.concatenate([axis_cam, tilted])),
+             ("camera plane", np.concatenate([grid, np.array([[0.25, 0.125, 1.6]], np.float32)]), axis_cam),
+             ("huge", grid * np.float32(2.0 ** 60), np.concatenate([axis_cam, tilted]) * np.array([1, 1, 1, 2.0 ** 60] * 3, np.float32)),
+             ("tiny", grid * np.float32(2.0 ** -60), np.concatenate([axis_cam, tilted]) * np.array([1, 1, 1, 2.0 ** -60] * 3, np.float32))]
+    for name, xyz, views in cases:
+        for rescale in (True, False):
+            uv, depth, tr = gp["dp"].getUvs(torch.from_numpy(views).cuda(), torch.from_numpy(xyz).cuda(), rescale=rescale, padding=0.15)
+            ouv, od, otr, _ = oracle.get_uvs(views, focal, xyz, rescale=rescale, padding=0.15)
+            assert np.array_equal(tr.cpu().numpy(), otr, equal_nan=True), (name, rescale)
+            assert np.array_equal(depth.cpu().numpy(), od, equal_nan=True), (name, rescale)
+            assert np.array_equal(uv.cpu().numpy(), ouv, equal_nan=True), (name, rescale)
+
+
 def test_paint_and_gather_fuzz(gp, oracle):
     """30 random cases of uvToPixels -> paintPixels (collisions: the highest point index wins) -> gather_colors:
     1 .. 50000 points, resolutions 8 .. 512, point sizes 1 .. 4, uv partly out of range."""
