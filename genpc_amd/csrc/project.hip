@@ -233,7 +233,9 @@ __global__ __launch_bounds__(kPBlock) void project_box_exact_kernel(int n, const
 // contiguous run (uv 2 x 1 KiB, depth 2 x 512 B per camera row); and consecutive block ids walk the CAMERA
 // groups of one point block, not the point blocks of one camera group: rows are N x 8 B apart and N is
 // not a multiple of 16, so neighbouring point blocks share a partly written 128-byte line per row --
-// launched side by side they cost 172 us against 140 us in this order (plain memset: 129 us).
+// launched side by side they cost 172 us against 140 us in this order (plain memset: 129 us).  (Shifting each
+// row's points by (row * n) mod 32 so that every store starts on a 128-byte line gains 5 % on pure stores
+// (tools/ubench_write3.hip, pattern 3) but needs the points from LDS per row: 221 -> 260 us for the call.)
 constexpr int kCamGroup = 64;
 constexpr int kWritePer = 4;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
