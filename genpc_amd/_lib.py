@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GENPC_LIB: an alternative build of the same library (kernel experiments only)
 LIB_PATH = os.environ.get("GENPC_LIB") or os.path.join(_HERE, "lib", "libgenpc_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -55,6 +55,7 @@ SIGNATURES = {
     "genpc_scale_search_scores": (_i, [_i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp]),
     "genpc_voxel_down_sample": (_i, [_i, _vp, _vp, _d, _vp, _vp, _vp, _vp]),
     "genpc_mfma_f16_probe": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "genpc_list_code_probe": (_i, [ctypes.c_longlong, _vp, _vp, _vp, _vp]),
     "genpc_fastdiv_probe": (_i, [ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_fps_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_fps_stats": (_i, [_i, _vp, _vp]),

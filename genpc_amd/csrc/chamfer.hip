@@ -804,7 +804,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         len = best_len;
         (void)lists_of(len, nl);
         a.slice_len = (int)len;
-        pwords = 3 * nl;
+        pwords = 2 * nl;        // (a1, c1) (codes of a2 | a3, c2) per list: list_enc in nn.h
     }
     long long tb = 0;
     int units = 0;

@@ -87,6 +87,25 @@ __device__ __forceinline__ void top3_insert(Top3 &s, float m, int id)
         : "vcc");
 }
 
+// Hand-off of a list from the filter (nn_f16.hip) to the finish step (nn_finish.hip): two 8-byte words per query
+//     (a1, c1)   (code2 : code3, c2)
+// a1 exact (the acceptance threshold is derived from it); a2 and a3 travel as 16-bit codes of LOWER bounds --
+// a2' = fl(a1 + dec(code2)) <= a2, a3' = fl(a2' + dec(code3)) <= a3 -- which is all the finish step needs of them: a
+// unit is evaluated exactly when a2' <= tau (a superset), a query is re-done exhaustively when a3' <= tau (a superset).
+// code = the top 16 bits (8 exponent, 8 mantissa, truncated) of (v - base) minus four ulps of the larger magnitude:
+// the subtraction, the safety term and the decoder's addition round by at most 0.5 + 0.5 ulp(2 max) + 0.5 ulp(2 max)
+// < 3.5 ulp(max) together, so the decoded value never exceeds v.  (Round 2: three words with a3 in a word of its own
+// -- 24 bytes per list, a third of the list traffic the finish step is bound by.)
+__device__ __forceinline__ unsigned list_enc(float base, float v)
+{
+    if (!(v < __builtin_inff())) return v != v ? 0xffffu : 0xff00u;          // +inf: nothing there; NaN stays NaN
+    const float s = fmaxf(fabsf(base), fabsf(v)) * 4.76837158203125e-07f;    // 2^-21
+    const float d = (v - base) - s;
+    if (!(d > 0.0f)) return 0u;                                              // (also a non-finite base)
+    return (__float_as_uint(d) >> 15) & 0xffffu;
+}
+__device__ __forceinline__ float list_dec(float base, unsigned code) { return base + __uint_as_float(code << 15); }
+
 template <int FMA, int LEN>
 __device__ __forceinline__ void rescan_chunk(const float *__restrict__ T, int nt, int base, float qx, float qy,
                                              float qz, float &bd, int &bi)

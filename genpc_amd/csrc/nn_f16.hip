@@ -266,8 +266,8 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
         if (threadIdx.x == 0) D.tmaxp[(size_t)batch * D.slices + slice] = tm;
     }
 
-    // Publish the lists: the two lane halves folded, NL lists of three 8-byte words
-    // (a1,c1) (a2,c2) (a3, -) per query and slice.
+    // Publish the lists: the two lane halves folded, NL lists of two 8-byte words per query and slice
+    // (a1, c1) (codes of a2 and a3, c2): list_enc in nn.h.
     const size_t bnq = (size_t)a.b * nq;
     unsigned long long *P = D.part + (size_t)batch * nq;
 #pragma unroll
@@ -287,12 +287,11 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
             top3_insert(f, o3, -1);
             const int j = q0 + r * 32;
             if (!half && j < nq) {
-                unsigned long long *p = P + (size_t)(slice * NL + n) * 3 * bnq + j;
-                const unsigned long long w0 = ((unsigned long long)__float_as_uint(f.a1) << 32) | (unsigned)f.c1;
-                const unsigned long long w1 = ((unsigned long long)__float_as_uint(f.a2) << 32) | (unsigned)f.c2;
-                p[0] = w0;
-                p[bnq] = w1;
-                p[2 * bnq] = (unsigned long long)__float_as_uint(f.a3) << 32;
+                unsigned long long *p = P + (size_t)(slice * NL + n) * 2 * bnq + j;
+                const unsigned code2 = list_enc(f.a1, f.a2);
+                const unsigned code3 = list_enc(list_dec(f.a1, code2), f.a3);
+                p[0] = ((unsigned long long)__float_as_uint(f.a1) << 32) | (unsigned)f.c1;
+                p[bnq] = ((unsigned long long)((code2 << 16) | code3) << 32) | (unsigned)f.c2;
             }
         }
     }

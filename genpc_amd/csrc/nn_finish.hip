@@ -54,17 +54,17 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     const float *cptr = a.dir[0].t + (size_t)batch * a.dir[0].nt * 3;      // common centre of the filter
     const float ccx = cptr[0], ccy = cptr[1], ccz = cptr[2];
     // this thread's lists: li = part + 4k
-    unsigned long long w0[kMaxLists / 4], w1[kMaxLists / 4], w2[kMaxLists / 4];
+    unsigned long long w0[kMaxLists / 4], w1[kMaxLists / 4];      // (a1, c1), (codes of a2 | a3, c2): list_enc in nn.h
     float amin = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < kMaxLists / 4; k++) {
         const int li = part + 4 * k;
-        w0[k] = w1[k] = w2[k] = 0x7f800000ull << 32;      // (+inf, 0)
+        w0[k] = 0x7f800000ull << 32;      // (+inf, 0)
+        w1[k] = 0xff00ff00ull << 32;      // a2, a3 = +inf
         if (li < nlists) {
-            const unsigned long long *p = P + (size_t)li * 3 * bnq + j;
+            const unsigned long long *p = P + (size_t)li * 2 * bnq + j;
             w0[k] = p[0];
             w1[k] = p[bnq];
-            w2[k] = p[2 * bnq];
         }
     }
 #pragma unroll
@@ -130,9 +130,12 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     };
 #pragma unroll
     for (int k = 0; k < kMaxLists / 4; k++) {
-        if (!(__uint_as_float((unsigned)(w2[k] >> 32)) > tau)) flag = true;
-        consider(__uint_as_float((unsigned)(w0[k] >> 32)), (int)(unsigned)w0[k]);
-        consider(__uint_as_float((unsigned)(w1[k] >> 32)), (int)(unsigned)w1[k]);
+        const float a1 = __uint_as_float((unsigned)(w0[k] >> 32));
+        const unsigned codes = (unsigned)(w1[k] >> 32);
+        const float a2 = list_dec(a1, codes >> 16), a3 = list_dec(a2, codes & 0xffffu);      // lower bounds of a2, a3
+        if (!(a3 > tau)) flag = true;
+        consider(a1, (int)(unsigned)w0[k]);
+        consider(a2, (int)(unsigned)w1[k]);
     }
     if (flag && live) s_qflag[ql] = 1;
     if (a.debug & 32) {      // diagnostics: approximate minimum and candidate count instead of the result

@@ -8,7 +8,7 @@
 // document states: genpc_mfma_f16_probe runs the instruction on caller-supplied operands so that
 // tests/test_gpu_mfma_premise.py can re-measure it wherever the suite runs -- a stepping that accumulates
 // differently fails a test instead of silently corrupting nearest neighbours.
-#include "common.h"
+#include "nn.h"
 #include "fastdiv.h"
 #include "../../include/genpc_hip.h"
 
@@ -62,7 +62,26 @@ __global__ __launch_bounds__(256) void fastdiv_probe_kernel(long long n, const f
     }
 }
 
+// the list hand-off's coded lower bounds (nn.h): out[i] = list_dec(base[i], list_enc(base[i], v[i]))
+__global__ __launch_bounds__(256) void list_code_probe_kernel(long long n, const float *__restrict__ base, const float *__restrict__ v,
+                                                              float *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = list_dec(base[i], list_enc(base[i], v[i]));
+}
+
 }  // namespace genpc
+
+GENPC_API int genpc_list_code_probe(long long n, const float *base, const float *v, float *out, void *stream)
+{
+    using namespace genpc;
+    if (n < 0) return -1;
+    if (n == 0) return 1;
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(list_code_probe_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, n, base,
+                       v, out);
+    return check(hipGetLastError(), "list code probe launch") ? 1 : 0;
+}
 
 GENPC_API int genpc_fastdiv_probe(long long n, const float *num, const float *den, float *fast, float *fast_packed, float *ieee,
                                   unsigned char *in_range, void *stream)

@@ -326,6 +326,11 @@ int genpc_scale_search_scores(int k, int ns, const float *source, int nt,
 int genpc_mfma_f16_probe(int problems, const unsigned short *a, const unsigned short *b,
                          const float *c, float *d, void *stream);
 
+/* out[i] = decode(encode(base[i], v[i])) of the 16-bit lower-bound code the nearest-neighbour filter hands its second and
+ * third list minima to the finish step in (csrc/nn.h: list_enc / list_dec).  For v >= base the result must never exceed
+ * v (tests/test_gpu_fastdiv.py::test_list_codes_are_lower_bounds).  Device memory, n elements.               */
+int genpc_list_code_probe(long long n, const float *base, const float *v, float *out, void *stream);
+
 /* fast[i] = csrc/fastdiv.h's shared-reciprocal division num[i] / den[i] (scalar form), fast_packed[i] = its packed
  * form, ieee[i] = the compiler's correctly rounded division, in_range[i] = 1 where the callers' range test
  * (both magnitudes in [2^-50, 2^50]) lets the fast form be used: there the three must agree bit for bit

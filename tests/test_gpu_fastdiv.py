@@ -106,3 +106,37 @@ def test_out_of_range_is_flagged():
     fast, fast2, ieee, ok = _probe(torch, lib, num, den)
     np.testing.assert_array_equal(ok, [0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1])
     np.testing.assert_array_equal(fast[ok], ieee[ok])
+
+
+def test_list_codes_are_lower_bounds():
+    """csrc/nn.h list_enc / list_dec: the filter hands a2 and a3 to the finish step as 16-bit codes of lower bounds.
+    decode(encode(base, v)) <= v for every v >= base (incl. equal, adjacent floats, opposite signs, heavy cancellation,
+    infinities), and close: within 0.4 % of (v - base) plus a few ulps of the larger magnitude."""
+    import torch
+    from genpc_amd import _lib as lib
+    rng = np.random.default_rng(5)
+    n = 1 << 24
+    base = _random_bits(rng, n, -30, 20)
+    kinds = rng.integers(0, 6, n)
+    gap = np.abs(_random_bits(rng, n, -40, 20))
+    v = base + gap                                                       # generic
+    rel = np.abs(base) * (2.0 ** rng.uniform(-24, -1, n)).astype(np.float32)
+    v = np.where(kinds == 1, base + rel.astype(np.float32), v)          # gaps of a few ulps .. half the magnitude
+    v = np.where(kinds == 2, base, v)                                    # equal
+    v = np.where(kinds == 3, np.nextafter(base, np.float32(np.inf)), v)  # adjacent floats
+    v = np.where(kinds == 4, np.float32(np.inf), v)
+    v = np.where(kinds == 5, np.abs(base) * np.float32(3.0), v)          # across zero when base < 0
+    v = np.maximum(v.astype(np.float32), base)
+    b = torch.from_numpy(base).cuda()
+    vv = torch.from_numpy(v).cuda()
+    out = torch.empty_like(b)
+    rc = lib.on_device_of(b, lib.lib.genpc_list_code_probe, n, lib.ptr(b), lib.ptr(vv), lib.ptr(out))
+    assert rc == 1, lib.last_error()
+    got = out.cpu().numpy()
+    assert (got <= v).all()
+    assert (got >= base).all()
+    fin = np.isfinite(v)
+    assert np.isinf(got[~fin]).all()
+    slack = (v[fin].astype(np.float64) - got[fin].astype(np.float64))
+    allowed = 0.0040 * (v[fin].astype(np.float64) - base[fin].astype(np.float64)) + 6.0 * 2.0 ** -21 * np.maximum(np.abs(v[fin]), np.abs(base[fin])).astype(np.float64)
+    assert (slack <= allowed).all(), float((slack - allowed).max())
