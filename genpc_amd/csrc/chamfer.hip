@@ -762,7 +762,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     // (slices x NL; NL = 2 lists per lane below three slices: a query is flagged only when THREE
     // candidate units fall into one list) within kMaxLists = 16.
     int nl = 1;
-    bool tight = false;
+    bool tight = false, wide = false;
     if (path == 2) {
         auto lists_of = [&](long long l, int &nl_out) {
             int smin = 1 << 30, smax = 0;
@@ -804,6 +804,14 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         len = best_len;
         (void)lists_of(len, nl);
         a.slice_len = (int)len;
+        // Single-round launches whose slice fits the kernel's 2048-target LDS tile: blocks of 8 waves / 1024 queries,
+        // one per CU -- the same two waves per SIMD, but a slice is read, split into f16 pieces and staged once per
+        // 1024 queries instead of once per 512 (the prologue was a third of a block's time: tools/nn_timeline.py).
+        static const bool no_wide = getenv("GENPC_NN_NOWIDE") != nullptr;
+        if (f16 && q == 4 && !tight && !no_wide && len > 1024 && len <= 2048 && blocks_at(len) <= 2 * (long long)kNumCU) {
+            wide = true;
+            for (int d = 0; d < nd; d++) a.dir[d].qblocks = ceil_div(a.dir[d].nq, 2 * qper);
+        }
         pwords = 2 * nl;        // (a1, c1) (codes of a2 | a3, c2) per list: list_enc in nn.h
     }
     long long tb = 0;
@@ -855,7 +863,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         // per QUERY, while the filter's work is per PAIR: short target clouds (many queries per
         // pair) take 64-target units (half the re-read, +10 % filter VALU), long ones 128
         const int fu = cfg.u == 2 || cfg.u == 4 ? cfg.u : (nt_max <= 8192 ? 2 : 4);
-        return launch_nn_f16(a, q, fu, nl, tight ? 1 : 0, tb, st);
+        return launch_nn_f16(a, q, fu, nl, wide ? 2 : (tight ? 1 : 0), tb, st);
     } else if (path) {
         if (q == 2) { if (u == 2) launch_mfma<2, 2>(a, (int)tb, st); else launch_mfma<2, 1>(a, (int)tb, st); }
         else        { if (u == 2) launch_mfma<1, 2>(a, (int)tb, st); else launch_mfma<1, 1>(a, (int)tb, st); }

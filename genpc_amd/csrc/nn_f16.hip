@@ -28,7 +28,16 @@
 namespace genpc {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-constexpr int kHTile = 1024;           // targets per LDS tile: 2 planes x 16 B = 32 KiB
+
+// tools/nn_timeline.py builds a private copy of the library with -DGENPC_NN_TIMELINE: thread 0 of every block stamps the
+// shader clock at the phase boundaries of nn_f16_kernel (nothing of this exists in the shipped library)
+#ifdef GENPC_NN_TIMELINE
+__device__ unsigned long long g_timeline[4096 * 8];
+#define GENPC_TL(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_timeline[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GENPC_TL(k) do {} while (0)
+#endif
+constexpr int kHTile = 1024;           // targets per LDS tile: 2 planes x 16 B = 32 KiB (template parameter HT: 1024 or 2048)
 constexpr double kQTh = 30.0, kTTh = 15.0;
 
 __device__ __forceinline__ unsigned f16_bits(float v) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v); }
@@ -61,9 +70,11 @@ __device__ __forceinline__ float scale_for(float m)
 // 36 -> 59, and a cliff on scan-like clouds whose 512-query blocks overflow the block's work list -- and a
 // Morton-sorted mode that culled whole (query block, slice) pairs: 336 -> 532 us on the 13 scans.  Both lost on
 // the inputs that matter and were removed in round 3; DESIGN.md section 4.1 keeps the measurements.)
-template <int Q, int U, int NL, int W>
-__global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
+template <int Q, int U, int NL, int W, int HT, int WV>
+__global__ __launch_bounds__(WV * kWave, W) void nn_f16_kernel(NNArgs a)
 {
+    // WV waves per block (4, or 8 for the wide single-round form: 1024 queries share one staged slice)
+    constexpr int kThreads = WV * kWave;
     // Hazard: the accumulators are consumed by inline-asm v_min3, which the compiler's hazard
     // recognizer does not pad (an 8-pass MFMA result needs 11 wait states before a VALU
     // read).  The pipeline supplies them by construction when Q >= 2: between the MFMA that
@@ -72,9 +83,10 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
     // once -- measured: 25 % wrong minima -- so that case is not instantiated.
     static_assert(Q >= 2, "one accumulator chain per wave violates the MFMA -> VALU wait states");
     constexpr int kC = 32 * U;
-    constexpr int kRows = kHTile + 64;          // + two spare tiles: the pipeline fetches two tiles ahead
+    constexpr int kRows = HT + 64;              // + two spare tiles: the pipeline fetches two tiles ahead
     __shared__ uint4 plane[2][kRows];
-    __shared__ float s_red[kWavesPerBlock];
+    __shared__ float s_red[WV];
+    GENPC_TL(0);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
     // centred queries of this lane; the block's largest |coordinate| over queries and slice
     float qc0[Q], qc1[Q];
     float mx = 0.0f;
-    const int q0 = (qb * kWavesPerBlock + wave) * (32 * Q) + col;
+    const int q0 = (qb * WV + wave) * (32 * Q) + col;
 #pragma unroll
     for (int r = 0; r < Q; r++) {
         int j = q0 + r * 32;
@@ -113,15 +125,43 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
         const float m0 = fabsf(qc0[r]), m1 = fabsf(qc1[r]);
         mx = fmaxf(mx, fmaxf(m0 < __builtin_inff() ? m0 : 0.0f, m1 < __builtin_inff() ? m1 : 0.0f));
     }
-    for (int t = k_begin + threadIdx.x; t < k_end; t += kBlock) {
-        const float *tp = T + (size_t)t * 3;
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(tp[0] - cx), fabsf(tp[1] - cy)), fabsf(tp[2] - cz)));
+    // raw coordinates of an LDS tile, HT / kBlock targets per thread.  A slice that fits one LDS tile (HT = 2048 at
+    // 1 x 16384^2) is read from memory ONCE: the registers that feed the scale's maximum also feed the staging,
+    // and the whole slice is staged behind a single barrier pair (with 1024-target tiles a block spent 43 % of its
+    // time outside the MFMA loop: 3 us on this pass, 2 us re-reading tile 0, 2 us staging tile 1 between the loops
+    // with every wave waiting for the slowest -- tools/nn_timeline.py).
+    constexpr int kPer = HT / kThreads;
+    float pre[kPer][3];
+    auto prefetch = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < kPer; i++) {
+            int t = t0 + i * kThreads + threadIdx.x;
+            t = t < nt ? t : nt - 1;
+#pragma unroll
+            for (int k = 0; k < 3; k++) pre[i][k] = T[(size_t)t * 3 + k];
+        }
+    };
+    const bool resident = k_end - k_begin <= HT;        // block-uniform
+    if (resident) {
+        if (k_begin < k_end) prefetch(k_begin);
+#pragma unroll
+        for (int i = 0; i < kPer; i++)
+            if (k_begin + i * kThreads + (int)threadIdx.x < k_end)
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(pre[i][0] - cx), fabsf(pre[i][1] - cy)), fabsf(pre[i][2] - cz)));
+    } else {
+        for (int t = k_begin + threadIdx.x; t < k_end; t += kThreads) {
+            const float *tp = T + (size_t)t * 3;
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(tp[0] - cx), fabsf(tp[1] - cy)), fabsf(tp[2] - cz)));
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if (lane == 0) s_red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    mx = s_red[0];
+#pragma unroll
+    for (int w2 = 1; w2 < WV; w2++) mx = fmaxf(mx, s_red[w2]);
+    GENPC_TL(1);
     const float sc = scale_for(mx);             // NaN input: comparisons fail -> 1
     const float isc = 1.0f / sc;                 // exact (power of two)
     const float tsc = -2.0f * sc;
@@ -170,28 +210,16 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
         }
     };
 
-    // raw coordinates of the next LDS tile, kHTile / kBlock targets per thread
-    constexpr int kPer = kHTile / kBlock;
-    float pre[kPer][3];
-    auto prefetch = [&](int t0) {
-#pragma unroll
-        for (int i = 0; i < kPer; i++) {
-            int t = t0 + i * kBlock + threadIdx.x;
-            t = t < nt ? t : nt - 1;
-#pragma unroll
-            for (int k = 0; k < 3; k++) pre[i][k] = T[(size_t)t * 3 + k];
-        }
-    };
     float tmax2 = 0.0f;
     float nf = 0.0f;      // NaN once a target of the slice had a non-finite coordinate
-    if (k_begin < k_end) prefetch(k_begin);
-    for (int t0 = k_begin; t0 < k_end && !(a.debug & 4); t0 += kHTile) {
-        const int tn = min(kHTile, k_end - t0);
+    if (!resident && k_begin < k_end) prefetch(k_begin);
+    for (int t0 = k_begin; t0 < k_end && !(a.debug & 4); t0 += HT) {
+        const int tn = min(HT, k_end - t0);
         const int tn_pad = (tn + kC - 1) / kC * kC;
         __syncthreads();                 // every wave is done reading the previous tile
 #pragma unroll
         for (int i = 0; i < kPer; i++) {
-            const int t = i * kBlock + threadIdx.x;
+            const int t = i * kThreads + threadIdx.x;
             if (t < tn_pad) {
                 // centre, scale, two f16 pieces of -2s x', -2s y', -2s z', s^2 |t'|^2 2^-8
                 const float x = pre[i][0] - cx, y = pre[i][1] - cy, z = pre[i][2] - cz;
@@ -215,8 +243,9 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
                 plane[1][row] = V1;
             }
         }
-        if (t0 + kHTile < k_end) prefetch(t0 + kHTile);
+        if (t0 + HT < k_end) prefetch(t0 + HT);
         __syncthreads();
+        if (t0 == k_begin) GENPC_TL(2); else GENPC_TL(3);
         // prologue of the LDS tile: target tile 0, rows of tiles 0 and 1
         fetch(0, 0);
         fetch(1, 32);
@@ -251,6 +280,7 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
         }
     }
 
+    GENPC_TL(4);
     // max |t'|^2 of the slice, for the bound of the finish step: every query block sees the same targets, the
     // first one publishes
     if (qb == 0) {
@@ -262,7 +292,9 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
         __syncthreads();
         if (lane == 0) s_red[wave] = tmax2;
         __syncthreads();
-        const float tm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        float tm = s_red[0];
+#pragma unroll
+        for (int w2 = 1; w2 < WV; w2++) tm = fmaxf(tm, s_red[w2]);
         if (threadIdx.x == 0) D.tmaxp[(size_t)batch * D.slices + slice] = tm;
     }
 
@@ -295,18 +327,34 @@ __global__ __launch_bounds__(kBlock, W) void nn_f16_kernel(NNArgs a)
             }
         }
     }
+    GENPC_TL(5);
 }
 
 template <int Q, int NL>
-static void launch_main(const NNArgs &a, int blocks, int u, bool tight, hipStream_t st)
+static void launch_main(const NNArgs &a, int blocks, int u, int tight, hipStream_t st)
 {
-    // tight: three waves per SIMD for the 512-query blocks (planner: launches of several rounds)
+    // tight 1: three waves per SIMD for the 512-query blocks (planner: launches of several rounds)
+    // tight 2 (planner: single round, Q = 4, 1024 < slice_len <= 2048): 8-wave blocks of 1024 queries, one per CU
+    // HT = 2048 (the slice resident in LDS, 66 KiB per block) where two waves per SIMD are all the registers allow anyway
+    // and the slice fits: Q = 4, not tight, 1024 < slice_len <= 2048
+    static const int env_ht = getenv("GENPC_NN_HT") ? atoi(getenv("GENPC_NN_HT")) : 0;
+    const bool big = Q == 4 && tight != 1 && a.slice_len > kHTile && a.slice_len <= 2 * kHTile && env_ht != 1024;
+    if (Q == 4 && tight == 2) {
+        if (u == 2) hipLaunchKernelGGL((nn_f16_kernel<4, 2, NL, 1, 2 * kHTile, 8>), dim3(blocks), dim3(8 * kWave), 0, st, a);
+        else hipLaunchKernelGGL((nn_f16_kernel<4, 4, NL, 1, 2 * kHTile, 8>), dim3(blocks), dim3(8 * kWave), 0, st, a);
+        return;
+    }
+    if (big) {
+        if (u == 2) hipLaunchKernelGGL((nn_f16_kernel<4, 2, NL, 2, 2 * kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((nn_f16_kernel<4, 4, NL, 2, 2 * kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
+        return;
+    }
     if (u == 2) {
-        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 3 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 2 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
+        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 3 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 2 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
     } else {
-        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 3 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 2 : 4)>), dim3(blocks), dim3(kBlock), 0, st, a);
+        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 3 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 2 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
     }
 }
 
@@ -332,12 +380,13 @@ int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, long long total_bl
         if (!g_prof_e0) { (void)hipEventCreate(&g_prof_e0); (void)hipEventCreate(&g_prof_e1); }
         (void)hipEventRecord(g_prof_e0, st);
     }
+    // (256-target bookkeeping units, U = 8, in the wide form: filter -0.4 us, finish +1.7 us at 1 x 16384^2 -- not kept)
     if (q == 4) {
-        if (nl == 2) launch_main<4, 2>(a, blocks, u, tight != 0, st);
-        else launch_main<4, 1>(a, blocks, u, tight != 0, st);
+        if (nl == 2) launch_main<4, 2>(a, blocks, u, tight, st);
+        else launch_main<4, 1>(a, blocks, u, tight, st);
     } else {
-        if (nl == 2) launch_main<2, 2>(a, blocks, u, false, st);
-        else launch_main<2, 1>(a, blocks, u, false, st);
+        if (nl == 2) launch_main<2, 2>(a, blocks, u, 0, st);
+        else launch_main<2, 1>(a, blocks, u, 0, st);
     }
     if (g_prof_on) (void)hipEventRecord(g_prof_e1, st);
     if (!check(hipGetLastError(), "nn_f16_kernel launch")) return 0;
@@ -345,6 +394,13 @@ int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, long long total_bl
 }
 
 }  // namespace genpc
+
+#ifdef GENPC_NN_TIMELINE
+extern "C" __attribute__((visibility("default"))) int genpc_nn_timeline_read(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(genpc::g_timeline), sizeof(unsigned long long) * 4096 * 8) == hipSuccess;
+}
+#endif
 
 GENPC_API float genpc_nn_profile(int enable)
 {
