@@ -7,12 +7,25 @@
 // (or with non-finite values) is re-done exhaustively by the block (nn_exhaustive, nn.h: the reference's
 // 512-target tile semantics).  The proof obligation is spelled out in nn_f16.hip and DESIGN.md section 4.1.
 //
+// (Round 3, built and measured against this structure inside one gpurun call, not kept: the threshold computed by all
+// four threads of a query and (i) each list's holder evaluating its candidates itself -- the wave runs the 64-target scan
+// once per list ENTRY in which any lane has a candidate: 1 x 16384^2 32.3 -> 34.9 us; (ii) per-wave work lists built with
+// one prefix sum, no block barrier between threshold and results: 32.5 -> 32.1 us at 1 x 16384^2 but 57.6 -> 60.0 at
+// 4 x 16384 x 8192; (iii) two items per lane and trip: 33.7 / 66.3.  tools/nn_timeline.py shows the phases.)
+//
 // (Round 1-2 history: this kernel was written for a three-piece bf16 filter -- 27 products in two chained
 // v_mfma_f32_32x32x16_bf16 -- which the two-piece f16 filter superseded at half the matrix work; the bf16 kernel,
 // its pre-split / LDS-DMA staging variant and the Morton-sorted culling mode were removed in round 3.)
 #include "nn.h"
 
 namespace genpc {
+
+#ifdef GENPC_NN_TIMELINE       // tools/nn_timeline.py (see nn_f16.hip)
+__device__ unsigned long long g_timeline_fin[4096 * 8];
+#define GENPC_TLF(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_timeline_fin[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GENPC_TLF(k) do {} while (0)
+#endif
 
 constexpr int kFQ = 64;                // queries per finish block
 constexpr int kFWork = 2048;           // work-item capacity (64 queries x 32 pieces)
@@ -30,6 +43,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     __shared__ float s_red[kWavesPerBlock];
     __shared__ int s_fi[kWavesPerBlock];
     __shared__ int s_misc[2];                    // work items, flagged queries
+    GENPC_TLF(0);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     int bid = blockIdx.x;
     const int d = (a.ndir > 1 && bid >= a.dir[1].fin_begin) ? 1 : 0;
@@ -86,6 +100,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     }
     if (threadIdx.x == 0) { s_misc[0] = 0; s_misc[1] = 0; }
     __syncthreads();
+    GENPC_TLF(1);
     tmax2 = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     const float abest = fminf(fminf(s_a[0][ql], s_a[1][ql]), fminf(s_a[2][ql], s_a[3][ql]));
     // the threshold is fp64 arithmetic (three square roots): once per query, shared through LDS
@@ -104,6 +119,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         s_qq[ql] = qq;
     }
     __syncthreads();
+    GENPC_TLF(2);
     const float tau = s_tau[ql];
     qq = s_qq[ql];
     bool flag = (a.debug & 8) != 0 || !(tau == tau);   // test hook / non-finite input: exhaustive pass
@@ -148,6 +164,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         return;
     }
     __syncthreads();
+    GENPC_TLF(3);
     const int nwork = min(s_misc[0], kFWork);
     for (int w = threadIdx.x; w < nwork && !(a.debug & 1); w += kBlock) {
         const unsigned it = s_work[w];
@@ -159,6 +176,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         atomicMin(&s_best[slot], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii);
     }
     __syncthreads();
+    GENPC_TLF(4);
     if (part == 0 && live) {
         if (s_qflag[ql]) {
             s_flagged[atomicAdd(&s_misc[1], 1)] = j;
@@ -176,6 +194,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         atomicAdd(&a.stats[2], (unsigned long long)nwork);
     }
     for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Qp, T, nt, s_flagged[fidx], od, oi, s_red, s_fi);
+    GENPC_TLF(5);
 }
 
 // Second launch of the filtered paths.  kqt / ktt: coefficients of the filter's error bound.
@@ -198,3 +217,10 @@ int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float
 }
 
 }  // namespace genpc
+
+#ifdef GENPC_NN_TIMELINE
+extern "C" __attribute__((visibility("default"))) int genpc_nn_timeline_read_finish(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(genpc::g_timeline_fin), sizeof(unsigned long long) * 4096 * 8) == hipSuccess;
+}
+#endif

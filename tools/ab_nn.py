@@ -1,3 +1,6 @@
+"""Step time of the chamfer forward at three shapes; run it twice in ONE gpurun call -- once with GENPC_LIB pointing at
+a library built from another commit -- to compare kernels on the same box (boxes of the pool differ by +-15 %).
+    GENPC_LIB=$PWD/tools/_lib_head.so python tools/ab_nn.py; python tools/ab_nn.py"""
 import os, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch

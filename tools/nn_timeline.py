@@ -18,10 +18,14 @@ if "--build" in sys.argv:
     B.build(verbose=False)
     os.makedirs(OUT, exist_ok=True)
     cflags = [f for f in B.FLAGS if f != "-shared"]
-    obj = os.path.join(OUT, "nn_f16.o")
-    subprocess.check_call([B.HIPCC] + cflags + ["-DGENPC_NN_TIMELINE", "-c", os.path.join(B.CSRC, "nn_f16.hip"), "-o", obj])
-    objs = [os.path.join(B.LIBDIR, "obj", os.path.basename(s)[:-4] + ".o") for s in B.sources() if not s.endswith("nn_f16.hip")]
-    subprocess.check_call([B.HIPCC, "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + [obj, "-o", os.path.join(OUT, "libgenpc_hip.so")])
+    mine = []
+    for name in ("nn_f16", "nn_finish"):
+        obj = os.path.join(OUT, name + ".o")
+        subprocess.check_call([B.HIPCC] + cflags + ["-DGENPC_NN_TIMELINE", "-c", os.path.join(B.CSRC, name + ".hip"), "-o", obj])
+        mine.append(obj)
+    objs = [os.path.join(B.LIBDIR, "obj", os.path.basename(s)[:-4] + ".o") for s in B.sources()
+            if not s.endswith("nn_f16.hip") and not s.endswith("nn_finish.hip")]
+    subprocess.check_call([B.HIPCC, "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + mine + ["-o", os.path.join(OUT, "libgenpc_hip.so")])
     print(os.path.join(OUT, "libgenpc_hip.so"))
     sys.exit(0)
 
@@ -54,6 +58,18 @@ for k in (1, 2, 3, 4, 5):
     if not ok.any():
         continue
     v = (t[:, k] - t[:, prev])[ok]
+    print("-> %-52s min %7d median %7d max %7d" % (names[k], v.min(), np.median(v), v.max()))
+    prev = k
+v = t[:, 5] - t[:, 0]
+print("   %-52s min %7d median %7d max %7d" % ("whole block", v.min(), np.median(v), v.max()))
+assert L.genpc_nn_timeline_read_finish(buf)
+t = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)
+t = t[t[:, 0] > 0]
+print("finish kernel, %d blocks stamped" % len(t))
+names = {1: "lists, query, |t|max loaded", 2: "thresholds (fp64, one wave)", 3: "work items listed", 4: "candidate pieces evaluated", 5: "results written"}
+prev = 0
+for k in (1, 2, 3, 4, 5):
+    v = t[:, k] - t[:, prev]
     print("-> %-52s min %7d median %7d max %7d" % (names[k], v.min(), np.median(v), v.max()))
     prev = k
 v = t[:, 5] - t[:, 0]
