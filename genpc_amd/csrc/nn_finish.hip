@@ -1,8 +1,8 @@
 // nn_finish.hip -- second launch of the filtered nearest-neighbour paths (the f16 MFMA filter of nn_f16.hip):
 // the exact step.  A block takes 64 queries of one (direction, batch element): it gathers each query's candidate
-// lists, derives the acceptance threshold tau from the smallest approximate value,
-// evaluates every listed tile that is not provably out with the reference's exact
-// arithmetic (work items of 16 targets, spread over the block), and writes
+// lists, evaluates the best-looking unit at once (one piece per thread of the query), derives the acceptance
+// threshold tau from the smallest approximate value, evaluates every OTHER listed tile that is not provably out with
+// the reference's exact arithmetic (work items of 16 targets, spread over the block), and writes
 // (distance, first index).  A query with a list whose THIRD minimum is not provably out
 // (or with non-finite values) is re-done exhaustively by the block (nn_exhaustive, nn.h: the reference's
 // 512-target tile semantics).  The proof obligation is spelled out in nn_f16.hip and DESIGN.md section 4.1.
@@ -36,13 +36,13 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     __shared__ unsigned long long s_best[kFQ];   // (distance bits << 32 | index): atomic min == (distance, first index)
     __shared__ float4 s_q[kFQ];
     __shared__ float s_a[4][kFQ];
+    __shared__ int s_c[4][kFQ];
     __shared__ int s_qflag[kFQ];
-    __shared__ float s_tau[kFQ], s_qq[kFQ];
     __shared__ int s_flagged[kFQ];
     __shared__ unsigned s_work[kFWork];          // query slot << 22 | tile (first target / 32) << 1 | lane half
     __shared__ float s_red[kWavesPerBlock];
     __shared__ int s_fi[kWavesPerBlock];
-    __shared__ int s_misc[2];                    // work items, flagged queries
+    __shared__ int s_misc[3];                    // work items, flagged queries, pieces evaluated (stats hook)
     GENPC_TLF(0);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     int bid = blockIdx.x;
@@ -81,9 +81,14 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
             w1[k] = p[bnq];
         }
     }
+    int cmin = -1, kmin = -1;               // unit of this thread's smallest first minimum
 #pragma unroll
-    for (int k = 0; k < kMaxLists / 4; k++) amin = fminf(amin, __uint_as_float((unsigned)(w0[k] >> 32)));
+    for (int k = 0; k < kMaxLists / 4; k++) {
+        const float a1 = __uint_as_float((unsigned)(w0[k] >> 32));
+        if (a1 < amin) { amin = a1; cmin = (int)(unsigned)w0[k]; kmin = k; }
+    }
     s_a[part][ql] = amin;
+    s_c[part][ql] = cmin;
     // max |t'|^2 over the whole target cloud (per-slice maxima of the filter kernel)
     float tmax2 = 0.0f;
     {
@@ -98,39 +103,63 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         s_best[ql] = ~0ull;
         s_qflag[ql] = 0;
     }
-    if (threadIdx.x == 0) { s_misc[0] = 0; s_misc[1] = 0; }
+    if (threadIdx.x == 0) { s_misc[0] = 0; s_misc[1] = 0; s_misc[2] = 0; }
     __syncthreads();
     GENPC_TLF(1);
     tmax2 = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    const float abest = fminf(fminf(s_a[0][ql], s_a[1][ql]), fminf(s_a[2][ql], s_a[3][ql]));
-    // the threshold is fp64 arithmetic (three square roots): once per query, shared through LDS
-    float qq = 0.0f;
-    if (part == 0) {
-        const float4 qv = s_q[ql];
+    // The query's best unit (smallest first minimum over all its lists; lowest part on ties) is a candidate whatever the
+    // threshold turns out to be -- tau >= its approximate value -- so its pieces are requested NOW, one per thread of
+    // the query (a unit has at most four tiles, a query four threads), and evaluated while nothing else is known yet:
+    // one candidate per query is the rule (4.0-4.2 pieces per query on uniform clouds), so the second memory round trip
+    // starts right behind the first barrier instead of behind the threshold, the work list and two more barriers
+    // (tools/nn_timeline.py: 17.9 k ticks per block before).  Further candidates take the work list below.
+    int bp = 0;
+    float abest = s_a[0][ql];
+#pragma unroll
+    for (int q2 = 1; q2 < 4; q2++) {
+        const float v = s_a[q2][ql];
+        if (v < abest) { abest = v; bp = q2; }
+    }
+    const int cb = s_c[bp][ql];
+    const float4 qv = s_q[ql];
+    unsigned long long mine = ~0ull;
+    int pieces = 0;
+    if (cb >= 0 && live && !(a.debug & 1)) {
+        const int h = cb & 1, c0 = cb & ~1;
+        const int left = (nt - c0 + 31) >> 5;
+        const int n2 = left < upieces ? left : upieces;
+        if (part < n2) {
+            float dd;
+            int ii;
+            rescan_half<FMA>(T, nt, c0 + 32 * part, h, qv.x, qv.y, qv.z, dd, ii);
+            mine = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii;
+            pieces = 1;
+        }
+    }
+    // the threshold is fp64 arithmetic (three square roots); every thread of the query computes it -- the four waves
+    // run side by side, and no barrier stands between it and the lists
+    float tau, qq;
+    {
         const float x = qv.x - ccx, y = qv.y - ccy, z = qv.z - ccz;
         qq = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
-        float t = nn_tau(abest, qq, tmax2, (double)kqt, (double)ktt);
-        if (!(tmax2 >= t2min)) t = __builtin_nanf("");      // below the magnitudes the filter's bound covers: exhaustive
+        tau = nn_tau(abest, qq, tmax2, (double)kqt, (double)ktt);
+        if (!(tmax2 >= t2min)) tau = __builtin_nanf("");      // below the magnitudes the filter's bound covers: exhaustive
         // non-finite targets anywhere in the cloud (the filter publishes +inf) or a non-finite query:
         // the reference's result depends on its 512-target tiling, only nn_exhaustive reproduces it
-        if (!(tmax2 < __builtin_inff()) || !(qq < __builtin_inff())) t = __builtin_nanf("");
-        if (a.debug & 16) t = __builtin_inff();          // test hook: every listed tile is evaluated
-        s_tau[ql] = t;
-        s_qq[ql] = qq;
+        if (!(tmax2 < __builtin_inff()) || !(qq < __builtin_inff())) tau = __builtin_nanf("");
+        if (a.debug & 16) tau = __builtin_inff();          // test hook: every listed tile is evaluated
     }
-    __syncthreads();
+    if (mine != ~0ull) atomicMin(&s_best[ql], mine);
     GENPC_TLF(2);
-    const float tau = s_tau[ql];
-    qq = s_qq[ql];
     bool flag = (a.debug & 8) != 0 || !(tau == tau);   // test hook / non-finite input: exhaustive pass
     int ncand = 0;
-    // a listed tile whose minimum is not provably out becomes work items of 32 targets
-    auto consider = [&](float av, int c) {
+    // any OTHER listed unit whose minimum is not provably out becomes work items of 16 targets for the block
+    auto consider = [&](float av, int c, bool is_best) {
         if (av <= tau) {
             ncand++;
             if (c < 0) {
                 flag = true;
-            } else if (live) {
+            } else if (live && !is_best) {
                 // c = first target of the unit | lane half: rows 8i + 4h + (0..3) of each tile
                 const int h = c & 1, c0 = c & ~1;
                 const int left = (nt - c0 + 31) >> 5;
@@ -150,8 +179,8 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
         const unsigned codes = (unsigned)(w1[k] >> 32);
         const float a2 = list_dec(a1, codes >> 16), a3 = list_dec(a2, codes & 0xffffu);      // lower bounds of a2, a3
         if (!(a3 > tau)) flag = true;
-        consider(a1, (int)(unsigned)w0[k]);
-        consider(a2, (int)(unsigned)w1[k]);
+        consider(a1, (int)(unsigned)w0[k], part == bp && k == kmin);
+        consider(a2, (int)(unsigned)w1[k], false);
     }
     if (flag && live) s_qflag[ql] = 1;
     if (a.debug & 32) {      // diagnostics: approximate minimum and candidate count instead of the result
@@ -166,15 +195,20 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     __syncthreads();
     GENPC_TLF(3);
     const int nwork = min(s_misc[0], kFWork);
-    for (int w = threadIdx.x; w < nwork && !(a.debug & 1); w += kBlock) {
-        const unsigned it = s_work[w];
-        const int slot = (int)(it >> 22);
-        const float4 qv = s_q[slot];
-        float dd;
-        int ii;
-        rescan_half<FMA>(T, nt, (int)((it & 0x3fffffu) >> 1) << 5, (int)(it & 1u), qv.x, qv.y, qv.z, dd, ii);
-        atomicMin(&s_best[slot], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii);
+    if (nwork > 0 && !(a.debug & 1)) {               // block-uniform
+        for (int w = threadIdx.x; w < nwork; w += kBlock) {
+            const unsigned it = s_work[w];
+            const int slot = (int)(it >> 22);
+            const float4 qs = s_q[slot];
+            float dd;
+            int ii;
+            rescan_half<FMA>(T, nt, (int)((it & 0x3fffffu) >> 1) << 5, (int)(it & 1u), qs.x, qs.y, qs.z, dd, ii);
+            atomicMin(&s_best[slot], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii);
+            pieces++;
+        }
+        __syncthreads();
     }
+    if (a.stats && pieces) atomicAdd(&s_misc[2], pieces);
     __syncthreads();
     GENPC_TLF(4);
     if (part == 0 && live) {
@@ -191,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     if (a.stats && threadIdx.x == 0) {
         atomicAdd(&a.stats[0], (unsigned long long)min(kFQ, nq - fb * kFQ));
         atomicAdd(&a.stats[1], (unsigned long long)nflag);
-        atomicAdd(&a.stats[2], (unsigned long long)nwork);
+        atomicAdd(&a.stats[2], (unsigned long long)s_misc[2]);
     }
     for (int fidx = 0; fidx < nflag; fidx++) nn_exhaustive<FMA>(Qp, T, nt, s_flagged[fidx], od, oi, s_red, s_fi);
     GENPC_TLF(5);

@@ -66,7 +66,7 @@ assert L.genpc_nn_timeline_read_finish(buf)
 t = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)
 t = t[t[:, 0] > 0]
 print("finish kernel, %d blocks stamped" % len(t))
-names = {1: "lists, query, |t|max loaded", 2: "thresholds (fp64, one wave)", 3: "work items listed", 4: "candidate pieces evaluated", 5: "results written"}
+names = {1: "lists, query, |t|max loaded", 2: "best unit evaluated, threshold", 3: "further candidates listed", 4: "further candidates evaluated", 5: "results written"}
 prev = 0
 for k in (1, 2, 3, 4, 5):
     v = t[:, k] - t[:, prev]
