@@ -37,8 +37,7 @@
 namespace genpc {
 
 constexpr int kEBlock = 256;
-constexpr int kTile = 2048;        // objects per LDS tile (32 KiB as float4)
-constexpr int kLoadsPerThread = kTile / 256;
+// objects per LDS tile: template parameter TILE of the bid kernel, 2048 (32 KiB as float4) or 1024 (16 KiB)
 constexpr int kZMax = 4;            // object slices per bidder group in the late-round split (measured best of 1..16)
 constexpr int kSplitMaxBidders = 4096;   // bidders per batch element the split scratch can hold
 constexpr int kArrivePerBatch = 1024;    // arrival counters per batch element (>= kSplitMaxBidders * 64 / 256)
@@ -138,7 +137,7 @@ __device__ __forceinline__ int pick_p(int U, int G)
     return P;
 }
 
-template <int FMA, int FILTER>
+template <int FMA, int FILTER, int TILE>
 __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__restrict__ xyz1,
                                                           const float *__restrict__ xyz2,
                                                           const float *__restrict__ price, float eps,
@@ -149,6 +148,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                                                           float4 *__restrict__ parts, int *__restrict__ arrive,
                                                           int *__restrict__ second, int zmax)
 {
+    constexpr int kTile = TILE, kLoadsPerThread = TILE / 256;
     __shared__ float4 tile[kTile];
     const int batch = blockIdx.y;
     const int U = cnt[batch];
@@ -641,8 +641,16 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
             static const int env_p0 = getenv("GENPC_EMD_P0") ? atoi(getenv("GENPC_EMD_P0")) : 0;
             const int force_p = env_p > 0 ? env_p : (it == 0 ? env_p0 : (second != nullptr && b < 32 ? 64 : 0));
             static const bool nofilter = getenv("GENPC_EMD_NOFILTER") != nullptr;
-            bid_fn f = fma ? (nofilter ? emd_bid_kernel<1, 0> : emd_bid_kernel<1, 1>)
-                           : (nofilter ? emd_bid_kernel<0, 0> : emd_bid_kernel<0, 1>);
+            // 1024-object tiles (16 KiB of LDS, 72 VGPRs: eight resident blocks per CU instead of four or five) wherever
+            // the bid is throughput-bound; a single small cloud is latency-bound and pays for the extra barrier pairs
+            // (in-run A/B: 13 x 16384 8.28 -> 7.65 ms, 64 x 2048 1.99 -> 1.80, 1 x 16384 =, 1 x 2048 0.69 -> 0.76;
+            // 512-object tiles: 7.85 / 1.84 / 1.69 / 0.70)
+            static const int env_tile = getenv("GENPC_EMD_TILE") ? atoi(getenv("GENPC_EMD_TILE")) : 0;
+            const bool small_tile = env_tile ? env_tile == 1024 : (long long)b * n > 8192;
+            bid_fn f = small_tile ? (fma ? (nofilter ? emd_bid_kernel<1, 0, 1024> : emd_bid_kernel<1, 1, 1024>)
+                                         : (nofilter ? emd_bid_kernel<0, 0, 1024> : emd_bid_kernel<0, 1, 1024>))
+                                  : (fma ? (nofilter ? emd_bid_kernel<1, 0, 2048> : emd_bid_kernel<1, 1, 2048>)
+                                         : (nofilter ? emd_bid_kernel<0, 0, 2048> : emd_bid_kernel<0, 1, 2048>));
             hipLaunchKernelGGL(f, dim3(G, b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price, eps,
                                (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
                                max_increments, force_p, parts, arrive, second, zmax);
@@ -674,7 +682,7 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
 extern "C" __attribute__((visibility("default"))) int genpc_debug_emd_bid_occupancy(void)
 {
     int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, genpc::emd_bid_kernel<1, 1>, genpc::kEBlock, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, genpc::emd_bid_kernel<1, 1, 1024>, genpc::kEBlock, 0);
     return nb;
 }
 
