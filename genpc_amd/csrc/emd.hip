@@ -36,6 +36,7 @@
 
 namespace genpc {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kEBlock = 256;
 // objects per LDS tile: template parameter TILE of the bid kernel, 2048 (32 KiB as float4) or 1024 (16 KiB)
 constexpr int kZMax = 4;            // object slices per bidder group in the late-round split (measured best of 1..16)
@@ -149,7 +150,9 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                                                           int *__restrict__ second, int zmax)
 {
     constexpr int kTile = TILE, kLoadsPerThread = TILE / 256;
-    __shared__ float4 tile[kTile];
+    // one tile of objects as four planes (x, y, z, price): a 16-byte read delivers four consecutive objects' x as two
+    // register pairs for the packed fp32 filter below
+    __shared__ __attribute__((aligned(16))) float sX[kTile], sY[kTile], sZ[kTile], sP[kTile];
     const int batch = blockIdx.y;
     const int U = cnt[batch];
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt_next[batch] = 0;   // filled by this round's assign
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
 #pragma unroll
             for (int i = 0; i < kLoadsPerThread; i++) {
                 const int t = threadIdx.x + i * kEBlock;
-                if (t < end_k) tile[t] = pre[i];
+                if (t < end_k) { sX[t] = pre[i].x; sY[t] = pre[i].y; sZ[t] = pre[i].z; sP[t] = pre[i].w; }
             }
             __syncthreads();
             if (k2 + kTile < k_hi) fetch(k2 + kTile);
@@ -261,32 +264,43 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
             // runs for the whole wave when any lane passes; for lanes that did not pass
             // it is that same no-op.  Results are therefore bit-identical with and
             // without the filter (GENPC_EMD_NOFILTER=1 disables it for A/B).
-            // Four objects per iteration (4*P divides every tile length: n % 256 == 0,
-            // P <= 64): the four LDS reads are in flight together and a group none of
-            // whose members can matter costs one branch.
-            for (int t = p; t < end_k; t += 4 * P) {
-                float4 o[4];
-                float sq[4];
-                bool maybe[4];
-                bool any4 = false;
+            // Four CONSECUTIVE objects per lane and iteration (4*P divides every tile length: n % 256 == 0,
+            // P <= 64), evaluated two per instruction (packed fp32: same operations, same roundings as
+            // sqdist_e and filter_cb's test); a lane's verdicts stay in SGPRs (one ballot per object), so a
+            // group none of whose members can matter costs 16 packed operations, 4 compares and one scalar branch
+            // (28 instead of 51 instructions per four objects; in-run A/B with the 1024-object tiles: 13 x 16384 7.68 ->
+            // 7.31 ms, 8 x 32768 16.05 -> 15.05 -- with 2048-object tiles and half the resident waves it LOST 6 %;
+            // issuing the next group's LDS reads early costs registers and residency: 7.23 -> 8.6 ms).
+            const v2f x1v = {x1, x1}, y1v = {y1, y1}, z1v = {z1, z1};
+            for (int t = 4 * p; t < end_k; t += 4 * P) {
+                const float4 X4 = *(const float4 *)&sX[t], Y4 = *(const float4 *)&sY[t], Z4 = *(const float4 *)&sZ[t],
+                             W4 = *(const float4 *)&sP[t];
+                const v2f cbv = {cb, cb};
+                v2f sqv[2];
+                unsigned long long pass[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) o[i] = tile[t + i * P];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    sq[i] = sqdist_e<FMA>(o[i].x - x1, o[i].y - y1, o[i].z - z1);
-                    const float tt = __fsub_rn(cb, o[i].w);
-                    maybe[i] = !FILTER || sq[i] < __fmul_rn(tt, tt);
-                    any4 |= maybe[i];
+                for (int h = 0; h < 2; h++) {
+                    const v2f dx = (h ? (v2f){X4.z, X4.w} : (v2f){X4.x, X4.y}) - x1v;
+                    const v2f dy = (h ? (v2f){Y4.z, Y4.w} : (v2f){Y4.x, Y4.y}) - y1v;
+                    const v2f dz = (h ? (v2f){Z4.z, Z4.w} : (v2f){Z4.x, Z4.y}) - z1v;
+                    if (FMA) sqv[h] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+                    else sqv[h] = (dx * dx + dy * dy) + dz * dz;
+                    const v2f tt = cbv - (h ? (v2f){W4.z, W4.w} : (v2f){W4.x, W4.y});
+                    const v2f t2 = tt * tt;
+                    pass[2 * h] = __ballot(!FILTER || sqv[h].x < t2.x);
+                    pass[2 * h + 1] = __ballot(!FILTER || sqv[h].y < t2.y);
                 }
-                if (__any(any4)) {
+                if ((pass[0] | pass[1] | pass[2] | pass[3]) != 0ull) {
+                    const float sq[4] = {sqv[0].x, sqv[0].y, sqv[1].x, sqv[1].y};
+                    const float pr[4] = {W4.x, W4.y, W4.z, W4.w};
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        if (__any(maybe[i])) {
+                        if (pass[i] != 0ull) {
                             const float r = sqrtf(sq[i]);
-                            const float d = (float)((3.0 - (double)r) - (double)o[i].w);
+                            const float d = (float)((3.0 - (double)r) - (double)pr[i]);
                             const bool gt = d > best;
                             const bool gt2 = !gt && d > better;
-                            const int kk = k2 + t + i * P;
+                            const int kk = k2 + t + i;
                             better_i = gt ? best_i : (gt2 ? kk : better_i);
                             better = __builtin_amdgcn_fmed3f(d, best, better);
                             best = fmaxf(best, d);
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
             int *cntp = arrive + (size_t)batch * kArrivePerBatch + grp;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                       // also: every lane is done with the tile
-            int *s_ticket = (int *)tile;
+            int *s_ticket = (int *)sX;
             if (threadIdx.x == 0)
                 *s_ticket = __hip_atomic_fetch_add(cntp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
