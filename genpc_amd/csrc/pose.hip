@@ -383,9 +383,9 @@ __global__ __launch_bounds__(kQBlock) void pose_replicate_kernel(size_t count, i
 //   mask_project_kernel  every point posed (the transform is fused) and projected once: (u, v, rho)
 //   mask_splat_kernel    one block per 16 x 16 image tile and scan: the points whose disc touches
 //                        the tile are compacted into LDS with their colours, then every pixel (four
-//                        threads each) walks the list and accumulates log(1 - a), a and a c of the discs
+//                        threads each) walks the list and accumulates prod (1 - a), a and a c of the discs
 //                        covering it, in list order: no atomics on the image.  Writes the five planes
-//                        L = sum log(1 - a), D = sum a, N_ch = sum a c_ch and adds the tile's sums of
+//                        T = prod (1 - a), D = sum a, N_ch = sum a c_ch and adds the tile's sums of
 //                        I_ch and I_ch^2 to the scan's accumulators.  (Measured at 16384 points, single
 //                        channel: one thread per point walking its own box 634 us per call -- every
 //                        wave pays a full box for its one in-tile lane; a wave per point with LDS
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kQBlock) void pose_transform_project_kernel(int n, 
     }
 }
 
-// The image of a scan is kept as five planes of P = S * S floats: L, D, N_r, N_g, N_b (header comment).
+// The image of a scan is kept as five planes of P = S * S floats: T, D, N_r, N_g, N_b (header comment).
 // `direct` images (genpc_mask_loss: the caller supplies I itself) hold I_r, I_g, I_b in planes 0..2.
 struct PxImg {
     float I[3];
@@ -501,8 +501,8 @@ __device__ __forceinline__ PxImg load_pixel(const float *__restrict__ pl, int P,
         o.A[0] = o.A[1] = o.A[2] = 0.0f;
         return o;
     }
-    const float l = pl[q], d = pl[P + q];
-    o.T = expf(l);
+    const float d = pl[P + q];
+    o.T = pl[q];
     o.O = 1.0f - o.T;
     o.iD = d > 0.0f ? 1.0f / d : 0.0f;
 #pragma unroll
@@ -514,7 +514,7 @@ __device__ __forceinline__ PxImg load_pixel(const float *__restrict__ pl, int P,
 }
 
 // grid (tiles, b).  col: [b, n, 3] colours or nullptr (white).
-__global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const float4 *__restrict__ uvr,
+__global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const float4 *__restrict__ uvr,
                                                                  const float *__restrict__ col, int S,
                                                                  float *__restrict__ planes, double *__restrict__ accum)
 {
@@ -538,37 +538,47 @@ __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const fl
     // thread = (pixel of the tile, one of four interleaved shares of the point list)
     const int pix = threadIdx.x & (kMaskTile * kMaskTile - 1), share = threadIdx.x / (kMaskTile * kMaskTile);
     const float pxc = (float)(tx0 + (pix & (kMaskTile - 1))) + 0.5f, pyc = (float)(ty0 + pix / kMaskTile) + 0.5f;
-    float sum = 0.0f, sd = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
+    float tr = 1.0f, sd = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;      // transmittance prod (1 - a), sums of a and a c
     // Every block reads every point of its scan (16 x 16 tiles: 196 blocks per scan), kSplatPer per thread
     // loaded together; the points whose disc touches the tile are compacted into LDS (one LDS atomic per wave
     // and step), then GATHERED: every pixel walks the list (broadcast reads) and accumulates the discs
     // that cover it, in list order -- no atomics on the image.  (Scattering with LDS float atomics ran at
     // ~0.6 adds per clock per CU: 26 us of the kernel's 36 for 758 points in the busiest tile.)
     for (int j0 = 0; j0 < n; j0 += kSplatBlock * kSplatPer) {
-        float4 q[kSplatPer];
-#pragma unroll
-        for (int i = 0; i < kSplatPer; i++) {
-            const int j = j0 + i * kSplatBlock + threadIdx.x;
-            q[i] = j < n ? uvr[j] : make_float4(0.0f, 0.0f, -1.0f, 0.0f);
-        }
+        // the bounding-box tests keep only a bit per point (four points in flight at a time): the kernel must fit 64
+        // VGPRs so that TWO 1024-thread blocks share a CU -- with all sixteen points of a thread in registers it needed
+        // 128, one block per CU, and a lock-step batch of 8 scans x 4 starts (6272 blocks) ran 8 % slower
         unsigned hit = 0;
 #pragma unroll
-        for (int i = 0; i < kSplatPer; i++) {
-            // the disc's bounding box against the tile
-            if (q[i].z > 0.0f && q[i].x + q[i].z >= (float)tx0 && q[i].x - q[i].z <= (float)(tx1 + 1) &&
-                q[i].y + q[i].z >= (float)ty0 && q[i].y - q[i].z <= (float)(ty1 + 1))
-                hit |= 1u << i;
+        for (int i0 = 0; i0 < kSplatPer; i0 += 4) {
+            float4 q[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = j0 + (i0 + i) * kSplatBlock + threadIdx.x;
+                q[i] = j < n ? uvr[j] : make_float4(0.0f, 0.0f, -1.0f, 0.0f);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // the disc's bounding box against the tile
+                if (q[i].z > 0.0f && q[i].x + q[i].z >= (float)tx0 && q[i].x - q[i].z <= (float)(tx1 + 1) &&
+                    q[i].y + q[i].z >= (float)ty0 && q[i].y - q[i].z <= (float)(ty1 + 1))
+                    hit |= 1u << (i0 + i);
+            }
         }
         // The list is filled in ascending point order -- rank = number of hits before this one in (i, wave, lane)
         // order, which is the order of the point indices j = j0 + i * kSplatBlock + tid -- so that a pixel sums its
         // discs in the same order in every run (an arrival-order list made the whole alignment loop irreproducible:
         // last-bit differences in the image flip a soft-mask pixel in or out of fp32 sigmoid saturation a few steps
         // later).  One table of per-(i, wave) counts, one scan by wave 0, two barriers per round of 16384 points.
-        unsigned long long bal[kSplatPer];
+        // a lane's rank among its wave's hits of step i, eight bits each (the ballots themselves are not kept: 32 SGPRs)
+        unsigned long long rk[kSplatPer / 8];
+#pragma unroll
+        for (int w8 = 0; w8 < kSplatPer / 8; w8++) rk[w8] = 0ull;
 #pragma unroll
         for (int i = 0; i < kSplatPer; i++) {
-            bal[i] = __ballot((hit >> i) & 1u);
-            if (lane == 0) s_tab[i * (kSplatBlock / kWave) + wave] = __popcll(bal[i]);
+            const unsigned long long bl = __ballot((hit >> i) & 1u);
+            if (lane == 0) s_tab[i * (kSplatBlock / kWave) + wave] = __popcll(bl);
+            rk[i >> 3] |= (unsigned long long)__popcll(bl & ((1ull << lane) - 1ull)) << (8 * (i & 7));
         }
         __syncthreads();
         if (wave == 0) {
@@ -595,12 +605,13 @@ __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const fl
 #pragma unroll
             for (int i = 0; i < kSplatPer; i++) {
                 if ((hit >> i) & 1u) {
-                    const int slot = s_tab[i * (kSplatBlock / kWave) + wave] + __popcll(bal[i] & ((1ull << lane) - 1ull)) - f0;
+                    const int slot = s_tab[i * (kSplatBlock / kWave) + wave] + (int)((rk[i >> 3] >> (8 * (i & 7))) & 0xffull) - f0;
                     if (slot >= 0 && slot < kSplatList) {
                         const int j = j0 + i * kSplatBlock + threadIdx.x;
+                        const float4 qh = uvr[j];                 // (a hit is rare: read again rather than kept)
                         float cr = 1.0f, cg = 1.0f, cb = 1.0f;
                         if (col) { cr = col[(size_t)j * 3 + 0]; cg = col[(size_t)j * 3 + 1]; cb = col[(size_t)j * 3 + 2]; }
-                        list[slot] = make_float4(q[i].x, q[i].y, q[i].w, cr);
+                        list[slot] = make_float4(qh.x, qh.y, qh.w, cr);
                         list_gb[slot] = make_float2(cg, cb);
                     }
                 }
@@ -614,7 +625,7 @@ __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const fl
                 if (a > 0.0f) {
                     const float2 gb = list_gb[k];
                     const float ac = fminf(a, kMaskAmax);
-                    sum += __logf(1.0f - ac);
+                    tr *= 1.0f - ac;
                     sd += ac;
                     sr += ac * p.w;
                     sg += ac * gb.x;
@@ -624,7 +635,7 @@ __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const fl
             __syncthreads();
         }
     }
-    part[0][share][pix] = sum;
+    part[0][share][pix] = tr;
     part[1][share][pix] = sd;
     part[2][share][pix] = sr;
     part[3][share][pix] = sg;
@@ -635,12 +646,19 @@ __global__ __launch_bounds__(kSplatBlock) void mask_splat_kernel(int n, const fl
         const int r = ty0 + pix / kMaskTile, cc = tx0 + (pix & (kMaskTile - 1));
         if (r < S && cc < S) {
             float w[5];
+            // plane 0 is the transmittance T = prod (1 - a) itself (round 2 accumulated log(1 - a) per covering disc and
+            // took exp(L) wherever the plane was read: the logarithm was a third of the gather's instructions, and the
+            // gather is what the kernel's time is -- 33 M pixel-disc tests per step of four starts).  (Sorting the list
+            // entries into per-strip index lists so that a wave walks only discs reaching its four rows halves the trips
+            // but costs three more barriers per fill: 42.0 -> 44.3 ms per call, not kept.)
+            w[0] = (part[0][0][pix] * part[0][1][pix]) * (part[0][2][pix] * part[0][3][pix]);
+            planes[(size_t)r * S + cc] = w[0];
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
+            for (int k = 1; k < 5; k++) {
                 w[k] = (part[k][0][pix] + part[k][1][pix]) + (part[k][2][pix] + part[k][3][pix]);
                 planes[(size_t)k * P + (size_t)r * S + cc] = w[k];
             }
-            const float O = 1.0f - expf(w[0]);
+            const float O = 1.0f - w[0];
             const float iD = w[1] > 0.0f ? 1.0f / w[1] : 0.0f;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
