@@ -33,6 +33,7 @@
 #include "../../include/genpc_hip.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace genpc {
 
@@ -138,7 +139,7 @@ __device__ __forceinline__ int pick_p(int U, int G)
     return P;
 }
 
-template <int FMA, int FILTER, int TILE>
+template <int FMA, int FILTER, int TILE, int AHEAD>
 __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__restrict__ xyz1,
                                                           const float *__restrict__ xyz2,
                                                           const float *__restrict__ price, float eps,
@@ -207,16 +208,23 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
         // a chain of load -> barrier -> short scan -> barrier per tile: pure latency).  The first
         // tile is requested before the bidder's own chain of loads (list -> point -> seed objects),
         // on which it does not depend and behind whose waits it would otherwise queue.
-        float4 pre[kLoadsPerThread];
-        auto fetch = [&](int k2) {
+        // AHEAD tiles are in flight (registers) at any time: 1 where many blocks are resident (the other blocks hide the
+        // fetch), 4 in the late rounds of a few clouds, where a unit is a chain -- fetch, stage, a four-trip scan, fetch
+        // ... -- and each tile's fetch latency was exposed (tools: ~2.9 k ticks per 1024-object tile of a unit's 27 k).
+        float4 pre[AHEAD][kLoadsPerThread];
+        auto fetch = [&](auto slot_c, int k2) {
+            constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
             for (int i = 0; i < kLoadsPerThread; i++) {
                 const int k = k2 + threadIdx.x + i * kEBlock;
                 const int kk = k < n ? k : n - 1;
-                pre[i] = make_float4(X2[(size_t)kk * 3 + 0], X2[(size_t)kk * 3 + 1], X2[(size_t)kk * 3 + 2], PR[kk]);
+                pre[slot][i] = make_float4(X2[(size_t)kk * 3 + 0], X2[(size_t)kk * 3 + 1], X2[(size_t)kk * 3 + 2], PR[kk]);
             }
         };
-        if (k_lo < k_hi) fetch(k_lo);
+        if (k_lo < k_hi) fetch(std::integral_constant<int, 0>{}, k_lo);
+        if (AHEAD > 1 && k_lo + kTile < k_hi) fetch(std::integral_constant<int, (AHEAD > 1 ? 1 : 0)>{}, k_lo + kTile);
+        if (AHEAD > 2 && k_lo + 2 * kTile < k_hi) fetch(std::integral_constant<int, (AHEAD > 2 ? 2 : 0)>{}, k_lo + 2 * kTile);
+        if (AHEAD > 3 && k_lo + 3 * kTile < k_hi) fetch(std::integral_constant<int, (AHEAD > 3 ? 3 : 0)>{}, k_lo + 3 * kTile);
         const int u = grp * per_block + wave * per_wave + g;
         const bool active = u < U;
         const int j = L[active ? u : U - 1];
@@ -243,16 +251,17 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
         }
         float cb = filter_cb(fmaxf(better, seed));
 
-        for (int k2 = k_lo; k2 < k_hi; k2 += kTile) {
+        auto tile_step = [&](auto slot_c, int k2) {
+            constexpr int slot = decltype(slot_c)::value;
             const int end_k = min(n, k2 + kTile) - k2;
             __syncthreads();                               // the previous tile has been scanned
 #pragma unroll
             for (int i = 0; i < kLoadsPerThread; i++) {
                 const int t = threadIdx.x + i * kEBlock;
-                if (t < end_k) { sX[t] = pre[i].x; sY[t] = pre[i].y; sZ[t] = pre[i].z; sP[t] = pre[i].w; }
+                if (t < end_k) { sX[t] = pre[slot][i].x; sY[t] = pre[slot][i].y; sZ[t] = pre[slot][i].z; sP[t] = pre[slot][i].w; }
             }
             __syncthreads();
-            if (k2 + kTile < k_hi) fetch(k2 + kTile);
+            if (k2 + AHEAD * kTile < k_hi) fetch(slot_c, k2 + AHEAD * kTile);
             // Pre-filter.  A candidate can change this lane's (best, better) only if its
             // value exceeds `better`, i.e. only if sqrt(s) < 3 - price - better.  That is
             // tested conservatively in squared space with fp32 and no sqrt / fp64:
@@ -310,6 +319,12 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                     cb = filter_cb(fmaxf(better, seed));
                 }
             }
+        };
+        for (int k2 = k_lo; k2 < k_hi; k2 += AHEAD * kTile) {          // block-uniform trip tests
+            tile_step(std::integral_constant<int, 0>{}, k2);
+            if (AHEAD > 1 && k2 + kTile < k_hi) tile_step(std::integral_constant<int, (AHEAD > 1 ? 1 : 0)>{}, k2 + kTile);
+            if (AHEAD > 2 && k2 + 2 * kTile < k_hi) tile_step(std::integral_constant<int, (AHEAD > 2 ? 2 : 0)>{}, k2 + 2 * kTile);
+            if (AHEAD > 3 && k2 + 3 * kTile < k_hi) tile_step(std::integral_constant<int, (AHEAD > 3 ? 3 : 0)>{}, k2 + 3 * kTile);
         }
         // merge the P partial top-2s of a bidder (value-symmetric)
         for (int off = 1; off < P; off <<= 1) {
@@ -661,10 +676,15 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
             // 512-object tiles: 7.85 / 1.84 / 1.69 / 0.70)
             static const int env_tile = getenv("GENPC_EMD_TILE") ? atoi(getenv("GENPC_EMD_TILE")) : 0;
             const bool small_tile = env_tile ? env_tile == 1024 : (long long)b * n > 8192;
-            bid_fn f = small_tile ? (fma ? (nofilter ? emd_bid_kernel<1, 0, 1024> : emd_bid_kernel<1, 1, 1024>)
-                                         : (nofilter ? emd_bid_kernel<0, 0, 1024> : emd_bid_kernel<0, 1, 1024>))
-                                  : (fma ? (nofilter ? emd_bid_kernel<1, 0, 2048> : emd_bid_kernel<1, 1, 2048>)
-                                         : (nofilter ? emd_bid_kernel<0, 0, 2048> : emd_bid_kernel<0, 1, 2048>));
+            // four tiles in flight from round 2 on for a single cloud (see the kernel)
+            static const int env_ahead = getenv("GENPC_EMD_AHEAD") ? atoi(getenv("GENPC_EMD_AHEAD")) : 0;
+            const bool deep = env_ahead ? env_ahead == 4 : (small_tile && it >= 2 && b == 1);      // in-run A/B: 1 x 8192 1.22 -> 1.07 ms, 1 x 16384 -2 %, 2 x 16384 +7 %, 4 x 16384 +15 %
+            bid_fn f = deep ? (fma ? (nofilter ? emd_bid_kernel<1, 0, 1024, 4> : emd_bid_kernel<1, 1, 1024, 4>)
+                                   : (nofilter ? emd_bid_kernel<0, 0, 1024, 4> : emd_bid_kernel<0, 1, 1024, 4>))
+                     : small_tile ? (fma ? (nofilter ? emd_bid_kernel<1, 0, 1024, 1> : emd_bid_kernel<1, 1, 1024, 1>)
+                                         : (nofilter ? emd_bid_kernel<0, 0, 1024, 1> : emd_bid_kernel<0, 1, 1024, 1>))
+                                  : (fma ? (nofilter ? emd_bid_kernel<1, 0, 2048, 1> : emd_bid_kernel<1, 1, 2048, 1>)
+                                         : (nofilter ? emd_bid_kernel<0, 0, 2048, 1> : emd_bid_kernel<0, 1, 2048, 1>));
             hipLaunchKernelGGL(f, dim3(G, b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price, eps,
                                (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
                                max_increments, force_p, parts, arrive, second, zmax);
@@ -696,7 +716,7 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
 extern "C" __attribute__((visibility("default"))) int genpc_debug_emd_bid_occupancy(void)
 {
     int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, genpc::emd_bid_kernel<1, 1, 1024>, genpc::kEBlock, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, genpc::emd_bid_kernel<1, 1, 1024, 1>, genpc::kEBlock, 0);
     return nb;
 }
 
