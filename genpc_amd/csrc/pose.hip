@@ -1170,7 +1170,11 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
                            pstride, 1, rad, S, m.uvr);
     hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, nc, (const float4 *)m.uvr, complete_col,
                        S, m.planes, accum);
-    hipLaunchKernelGGL(mask_sums_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, 0, (const float *)m.mref,
+    // few blocks per image: every block ends in 22 double atomics on the image's accumulators, and 196 blocks x 22 on the
+    // same addresses serialise in L2 (17.5 us for 0.2 M pixels; GENPC_MASK_SUMS_BLOCKS for A/B)
+    static const int env_sb = getenv("GENPC_MASK_SUMS_BLOCKS") ? atoi(getenv("GENPC_MASK_SUMS_BLOCKS")) : 0;
+    const int gs = std::min(gp, env_sb > 0 ? env_sb : 48);      // 196: 221 ms per 8-scan call, 48: 210, 24: 210, 12: 210 (single scan: 42.1 / 41.4 / 41.8 / 43.3)
+    hipLaunchKernelGGL(mask_sums_kernel, dim3(gs, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, 0, (const float *)m.mref,
                        (const float *)m.stats, accum);
     hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, 0, (const float *)m.mref,
                        (const float *)m.stats, mask_weight, m.W1, m.W4, accum);
