@@ -808,7 +808,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         // one per CU -- the same two waves per SIMD, but a slice is read, split into f16 pieces and staged once per
         // 1024 queries instead of once per 512 (the prologue was a third of a block's time: tools/nn_timeline.py).
         static const bool no_wide = getenv("GENPC_NN_NOWIDE") != nullptr;
-        if (f16 && q == 4 && !tight && !no_wide && len > 1024 && len <= 2048 && blocks_at(len) <= 2 * (long long)kNumCU) {
+        if (f16 && q == 4 && !tight && !no_wide && len > 1024 && blocks_at(len) <= 2 * (long long)kNumCU) {
             wide = true;
             for (int d = 0; d < nd; d++) a.dir[d].qblocks = ceil_div(a.dir[d].nq, 2 * qper);
         }
