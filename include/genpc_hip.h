@@ -43,14 +43,13 @@ int genpc_release_workspace(void);
 /* Nearest-neighbour kernel selection, for tests and experiments: every path returns
  * the same bits.  path: 4 cell-sorted pruned exact search (two launches, O(N + M) work when most
  * queries have a target nearby; slower than the filters when many do not -- opt-in), 3 one-f16-MFMA
- * filter (default), 2 split-bf16 MFMA filter, 1 fp32-MFMA filter (default below ~6 M pairs),
- * 0 VALU brute force, < 0 keep.  hooks: bit mask of test hooks
+ * filter (default), 1 fp32-MFMA filter (default below ~6 M pairs), 0 VALU brute force, < 0 keep
+ * (2 was the split-bf16 filter, removed in round 3: rejected).  hooks: bit mask of test hooks
  * (8: every query takes the exhaustive pass, 16: every listed tile is evaluated
- * exactly, 256: bf16 path with pre-split targets staged by LDS-DMA, 512: count what the
- * filtered paths do, see genpc_nn_stats), < 0 keep.  Applies to calls made by the CALLING
+ * exactly, 512: count what the filtered paths do, see genpc_nn_stats), < 0 keep.  Applies to calls made by the CALLING
  * host thread only (thread-local; other threads keep the defaults).  Returns the previous
- * path.  Environment (read once, at first use): GENPC_NN_PATH (valu | mfma32 | bf16 |
- * f16 | grid), GENPC_NN_DEBUG.                                                          */
+ * path.  Environment (read once, at first use): GENPC_NN_PATH (valu | mfma32 | f16 |
+ * grid), GENPC_NN_DEBUG; A/B switches of the f16 filter: GENPC_NN_HT=1024, GENPC_NN_NOWIDE.                                                          */
 int genpc_nn_tune(int path, int hooks);
 /* Counters of the filtered nearest-neighbour paths, accumulated on the current device
  * while hook 512 is set: out[0] queries answered, out[1] queries re-done by the exhaustive
