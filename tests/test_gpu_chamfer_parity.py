@@ -68,6 +68,16 @@ def test_config5_size_elementwise(gp, oracle, shape):
     assert_bits(run_hip(gp, a, b, 1), oracle.chamfer_forward(a, b, 1))
 
 
+@pytest.mark.parametrize("shape", [((1, 12001, 3), (1, 13003, 3)), ((4, 15403, 3), (4, 7855, 3)), ((2, 5000, 3), (2, 20011, 3)),
+                                   ((1, 16384, 3), (1, 3001, 3)), ((3, 9000, 3), (3, 9000, 3))])
+def test_single_round_filter_forms_elementwise(gp, oracle, shape):
+    """Shapes whose launches are a single round with slices over 1024 targets: the filter's 2048-target LDS tiles
+    (slice resident or not), the 8-wave blocks whose last block is partly empty (query counts that are no multiple of
+    1024), the alignment loop's four starts x (15403 vs 7855), and the finish kernel's best-unit speculation on all of them."""
+    a, b = gen_pair(sum(shape[0]) + sum(shape[1]), *shape)
+    assert_bits(run_hip(gp, a, b, 1), oracle.chamfer_forward(a, b, 1), str(shape))
+
+
 def test_thirteen_real_scans_elementwise(gp, oracle, golden):
     """C3 input (13 bundled scans at 16384 points) in one batched call, element-wise."""
     g = golden("scans13_fps16384.npz")
