@@ -35,7 +35,7 @@
 // restates the ordering, the accept test, the grouping and the candidate order: the two produce the same
 // polygons bit for bit, hence the same mask.  That restatement is pinned against qhull (scipy) on random clouds,
 // real scans and lattices.  Deviations from the hull definition: normals tilted from u by more than atan(1e4)
-// are not considered; exact duplicates clip nothing (every copy is reported; qhull keeps one).
+// are not considered; of exact duplicates only the lowest-index copy takes part (qhull keeps one copy too).
 //
 // Measured numbers and the steps that led here: DESIGN.md section 4.6.
 #include "common.h"
@@ -57,11 +57,18 @@ constexpr double kHprBox = 1.0e4;
 
 // p' for every (view, point), stored in Morton order (row pos = point perm[pos]); open3d: |v| = 0 -> 1e-4
 __global__ __launch_bounds__(256) void hpr_flip_kernel(int n, const float *__restrict__ pts, const int *__restrict__ perm,
-                                                      const double *__restrict__ eyes, double radius, double *__restrict__ fl)
+                                                      const double *__restrict__ eyes, double radius, double *__restrict__ fl,
+                                                      const unsigned char *__restrict__ dup)
 {
     const int pos = blockIdx.x * 256 + threadIdx.x, view = blockIdx.y;
     if (pos >= n) return;
     const int i = perm[(size_t)view * n + pos];
+    if (dup[i]) {
+        // a later copy of an exact duplicate: NaN -- hidden, and it cuts nothing (its lowest-index twin stands for both)
+        double *o = fl + ((size_t)view * n + pos) * 3;
+        o[0] = o[1] = o[2] = __builtin_nan("");
+        return;
+    }
     const double vx = (double)pts[(size_t)i * 3 + 0] - eyes[view * 3 + 0];
     const double vy = (double)pts[(size_t)i * 3 + 1] - eyes[view * 3 + 1];
     const double vz = (double)pts[(size_t)i * 3 + 2] - eyes[view * 3 + 2];
@@ -82,6 +89,34 @@ __device__ __forceinline__ unsigned hpr_ord(float f)      // order-preserving fl
 __device__ __forceinline__ float hpr_unord(unsigned o)
 {
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// Exact duplicates.  qhull (open3d's hidden_point_removal) reports ONE copy of a group of coincident points as a hull
+// vertex -- which one is its own business -- so only the copy with the lowest index takes part here: three stable
+// radix sorts (z, y, x keys; -0 counts as +0) order the points lexicographically with the index as the last key, and a
+// point equal to its predecessor is a later copy.
+__global__ __launch_bounds__(256) void hpr_dupkey_kernel(int n, const float *__restrict__ pts, int axis, const int *__restrict__ order,
+                                                        unsigned *__restrict__ keys, int *__restrict__ idx)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int i = order ? order[p] : p;
+    keys[p] = hpr_ord(pts[(size_t)i * 3 + axis] + 0.0f);
+    if (!order) idx[p] = p;
+}
+__global__ __launch_bounds__(256) void hpr_dupmark_kernel(int n, const float *__restrict__ pts, const int *__restrict__ order,
+                                                         unsigned char *__restrict__ dup)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int i = order[p];
+    bool d = false;
+    if (p > 0) {
+        const int j = order[p - 1];
+        d = pts[(size_t)i * 3 + 0] == pts[(size_t)j * 3 + 0] && pts[(size_t)i * 3 + 1] == pts[(size_t)j * 3 + 1] &&
+            pts[(size_t)i * 3 + 2] == pts[(size_t)j * 3 + 2];
+    }
+    dup[i] = d ? 1 : 0;
 }
 
 // bounds[0..2] = min, [3..5] = max of the finite coordinates, as ordered uints (0xffffffff / 0 initially)
@@ -1351,6 +1386,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     const size_t o_hc = off; off += up((size_t)c * sizeof(int));
     const size_t o_und = off; off += up((size_t)c * sizeof(int));
     const size_t o_alive = off; off += up((size_t)c);
+    const size_t o_dup = off; off += up((size_t)n);
     // the split pays when many views share a small cloud (viewpoint_select: 1024 x 10000, 128 -> 88 ms; 64 x 10000: 14.3 -> 16.6, so not there); a few views
     // of a large cloud keep the one-kernel form (GENPC_HPR_SPLIT=0/1 overrides)
     static const int env_split = getenv("GENPC_HPR_SPLIT") ? atoi(getenv("GENPC_HPR_SPLIT")) : -1;
@@ -1368,6 +1404,19 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     if (!check(hipMemsetAsync(status, 0, 256, stream), "hipMemsetAsync(hpr status)")) return 0;
     if (!check(hipMemsetAsync(bounds, 0xff, 12, stream), "hipMemsetAsync(hpr bounds)")) return 0;
     const int g256 = ceil_div(n, 256);
+    // later copies of exact duplicates (the key / index buffers of the view sort are free until then)
+    unsigned char *dup = (unsigned char *)(ws + o_dup);
+    {
+        int *ia = i0, *ib = i1;
+        for (int axis = 2; axis >= 0; axis--) {
+            hipLaunchKernelGGL(hpr_dupkey_kernel, dim3(g256), dim3(256), 0, stream, n, points, axis, axis == 2 ? (const int *)nullptr : (const int *)ia, k0, ia);
+            size_t sb = sort_bytes;
+            if (!check(hipcub::DeviceRadixSort::SortPairs(ws + o_tmp, sb, (const unsigned *)k0, k1, (const int *)ia, ib, n, 0, 32, stream), "hpr duplicate sort"))
+                return 0;
+            std::swap(ia, ib);
+        }
+        hipLaunchKernelGGL(hpr_dupmark_kernel, dim3(g256), dim3(256), 0, stream, n, points, (const int *)ia, dup);
+    }
     hipLaunchKernelGGL(hpr_bounds_kernel, dim3(g256 < 1024 ? g256 : 1024), dim3(256), 0, stream, n, points, bounds);
     hipLaunchKernelGGL(hpr_key_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const unsigned *)bounds, eyes, k0, i0);
     int key_bits = 20;
@@ -1378,7 +1427,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
         return 0;
     HprTile *tiles = (HprTile *)(ws + o_tiles);
     static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept, 32 = no verify phase, 64 = no hand-off of much-cut polygons (results unchanged)
-    hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl);
+    hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl, (const unsigned char *)dup);
     hipLaunchKernelGGL(hpr_tile_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, tiles);
     HprTile *subs = (HprTile *)(ws + o_subs);
     static const int env_clips = getenv("GENPC_HPR_MAXCLIPS") ? atoi(getenv("GENPC_HPR_MAXCLIPS")) : 0;

@@ -164,7 +164,8 @@ int genpc_gather_colors(int n, const int *pix, const float *img, int ch, int h,
  * be NULL): how many points needed the large-polygon pass (lattice-like inputs).
  * Synchronises the stream once (the second pass is sized from the first).  0 if a polygon
  * outgrows 1024 vertices.  Differences from qhull: normals tilted more than atan(1e4) from
- * the point's direction are not considered; exact duplicates are all reported.          */
+ * the point's direction are not considered; of exact duplicates (-0 == +0) only the copy with the
+ * lowest index takes part -- qhull reports one copy of a coincident group too, so counts agree.     */
 int genpc_hpr_visibility(int c, int n, const float *points, const double *eyes,
                          double radius, unsigned char *visible, int *counts,
                          int *second_pass_points, void *stream);

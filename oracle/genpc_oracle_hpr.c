@@ -19,7 +19,9 @@
  *
  * The polygon starts as the square |a|, |b| <= HPR_BOX (normals tilted from u_i by more than atan(HPR_BOX) =
  * 89.994 degrees are not considered: the one deviation from the hull definition, besides roundoff -- qhull
- * merges facets within its own tolerance).  Exact duplicates clip nothing (both copies are reported).
+ * merges facets within its own tolerance).  Exact duplicates: only the copy with the lowest index takes part (it can be
+ * visible and it clips); the other copies are hidden and clip nothing -- qhull reports exactly one copy of a
+ * coincident group as a hull vertex too (which one is its own business), so the COUNTS agree with open3d's.
  * The points are ordered by the 2-D Morton code of their DIRECTION from the eye (20-bit keys, ties by index:
  * points in the same direction -- a surface and what it hides -- are neighbours) and cut into tiles of HPR_TILE; points whose own direction already separates them are accepted at once (see below); the
  * others are taken, in Morton order, in groups of HPR_TILE, and a point takes the candidates tile by tile: its
@@ -116,10 +118,37 @@ static void view_order(int n, const float *pts, const double *eye, int *perm)
     free(keys);
 }
 
+/* dup[i] = 1 when a point with the same coordinates (numerically: -0 == +0) and a lower index exists */
+static int dup_cmp(const void *a, const void *b, void *ctx)
+{
+    const float *dup_pts = (const float *)ctx;
+    const int i = *(const int *)a, j = *(const int *)b;
+    for (int k = 0; k < 3; k++) {
+        const float x = dup_pts[3 * (size_t)i + k], y = dup_pts[3 * (size_t)j + k];
+        if (x < y) return -1;
+        if (x > y) return 1;
+        if (x != y) return (x != x) - (y != y) ? ((x != x) ? 1 : -1) : 0;      /* NaNs last, equal among themselves */
+    }
+    return (i > j) - (i < j);
+}
+static void mark_duplicates(int n, const float *pts, uint8_t *dup)
+{
+    int *idx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) { idx[i] = i; dup[i] = 0; }
+    qsort_r(idx, (size_t)n, sizeof(int), dup_cmp, (void *)pts);
+    for (int p = 1; p < n; p++) {
+        const float *a = pts + 3 * (size_t)idx[p], *b = pts + 3 * (size_t)idx[p - 1];
+        if (a[0] == b[0] && a[1] == b[1] && a[2] == b[2]) dup[idx[p]] = 1;
+    }
+    free(idx);
+}
+
 /* p' of every point for one camera, in the order of perm (open3d: |v| = 0 -> 1e-4) */
-static void flip_points(int n, const float *pts_in, const int *perm, const double *eye, double radius, double *fl)
+static void flip_points(int n, const float *pts_in, const int *perm, const double *eye, double radius, double *fl,
+                        const uint8_t *dup)
 {
     for (int i = 0; i < n; i++) {
+        if (dup[perm[i]]) { fl[3 * i + 0] = fl[3 * i + 1] = fl[3 * i + 2] = NAN; continue; }      /* hidden, clips nothing */
         const float *pts = pts_in + 3 * (size_t)perm[i] - 3 * (size_t)i;      /* so that pts[3 i + k] is point perm[i] */
         const double vx = (double)pts[3 * i + 0] - eye[0];
         const double vy = (double)pts[3 * i + 1] - eye[1];
@@ -165,7 +194,11 @@ ORACLE_API int oracle_hpr_visibility(int n, const float *pts, const double *eye,
     int *perm = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
     if (!fl || !perm) { free(fl); free(perm); return -1; }
     view_order(n, pts, eye, perm);
-    flip_points(n, pts, perm, eye, radius, fl);
+    uint8_t *dup = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+    if (!dup) { free(fl); free(perm); return -1; }
+    mark_duplicates(n, pts, dup);
+    flip_points(n, pts, perm, eye, radius, fl, dup);
+    free(dup);
     /* Early accept (hpr.hip: hpr_accept_kernel): the point's own direction u is already a separating normal
      * when u.p'_j < |p'_i| for every other point (margin 1e-8 |p'_i|): the origin of the (a, b) plane is
      * strictly feasible, the point is visible and no polygon is built. */

@@ -104,12 +104,25 @@ def test_hpr_edge_cases(hp):
     lib = hp["lib"].lib
     rng = np.random.default_rng(3)
     P = (rng.random((500, 3)) - 0.5).astype(np.float32)
-    # duplicates: every copy of a visible point is reported (qhull keeps one: documented difference)
-    D = np.concatenate([P, P[:40]])
-    vis, cnt, _ = hp["run"](D, EYES[:1], 100.0)
-    base, _, _ = hp["run"](P, EYES[:1], 100.0)
-    np.testing.assert_array_equal(vis[0, :500], base[0])
-    np.testing.assert_array_equal(vis[0, 500:], base[0, :40])
+    # exact duplicates (incl. -0 against +0): the lowest-index copy stands for the group, later copies are hidden and cut
+    # nothing; qhull reports one copy per group too (an arbitrary one): its counts and visible locations are these
+    D = np.concatenate([P[:40], P, P[:40], P[100:130]])
+    D[5, 1] = -0.0
+    D[45, 1] = 0.0
+    D[545, 1] = 0.0
+    vis, cnt, _ = hp["run"](D, EYES[:2], 100.0)
+    uniq = np.concatenate([D[:40], D[80:540]])
+    base, bcnt, _ = hp["run"](uniq, EYES[:2], 100.0)
+    np.testing.assert_array_equal(vis[:, :40], base[:, :40])
+    assert not vis[:, 40:80].any() and not vis[:, 540:].any()
+    np.testing.assert_array_equal(vis[:, 80:540], base[:, 40:])
+    np.testing.assert_array_equal(cnt, bcnt)
+    np.testing.assert_array_equal(vis, hp["clip"](D, EYES[:2], 100.0))          # the oracle applies the same rule
+    q = hp["qhull"](D, EYES[:2], 100.0)
+    np.testing.assert_array_equal(q.sum(1), cnt)
+    for v in range(2):
+        locs = lambda m: {tuple(x) for x in (D[m] + np.float32(0.0)).tolist()}
+        assert locs(q[v].astype(bool)) == locs(vis[v].astype(bool))
     # a NaN point is hidden and hides nothing; the eye on a point
     N = P.copy()
     N[7] = np.nan

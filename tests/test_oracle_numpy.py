@@ -295,13 +295,23 @@ def test_hpr_clipping_oracle_equals_qhull(oracle, golden):
     b[hpr.hidden_point_removal(gr, [0, 0, 3.0], 10000.0)] = True
     np.testing.assert_array_equal(a, b)
     assert mv > 24          # larger than the GPU kernel's LDS polygons: the case its second pass exists for
-    # duplicates are all reported; a NaN point is hidden and hides nothing
+    # exact duplicates: the lowest-index copy stands for the group (qhull reports one copy too -- an arbitrary one, so
+    # the visible LOCATIONS and the counts are what agrees); a NaN point is hidden and hides nothing
     P = (rng.random((300, 3)) - 0.5).astype(np.float32)
     base = oracle.hpr_visibility(P, [0, 0, 3.0], 100.0)
-    D = np.concatenate([P, P[:20]])
+    D = np.concatenate([P[:20], P, P[:20], P[40:60]])          # groups of three and of two, lowest copies in front
+    D[5, 2] = -0.0
+    D[25, 2] = 0.0                                             # -0 and +0 are the same coordinate
     d = oracle.hpr_visibility(D, [0, 0, 3.0], 100.0)
-    np.testing.assert_array_equal(d[:300], base)
-    np.testing.assert_array_equal(d[300:], base[:20])
+    base_d = oracle.hpr_visibility(np.concatenate([D[:20], D[40:320]]), [0, 0, 3.0], 100.0)      # the unique points, in order
+    np.testing.assert_array_equal(d[:20], base_d[:20])
+    assert not d[20:40].any() and not d[320:].any()            # later copies are hidden
+    np.testing.assert_array_equal(d[40:320], base_d[20:])
+    q = np.zeros(len(D), bool)
+    q[hpr.hidden_point_removal(D, [0, 0, 3.0], 100.0)] = True
+    assert int(q.sum()) == int(d.sum())                        # qhull's count
+    locs = lambda m: {tuple(x) for x in (D[m] + np.float32(0.0)).tolist()}
+    assert locs(q) == locs(d)                                  # and its visible locations
 
 
 def test_hpr_clipping_oracle_equals_qhull_fuzz(oracle):
