@@ -1169,14 +1169,18 @@ __global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsur
 // the few that are not provably out of reach are taken one by one, in order, the vertex test spread over the
 // lanes and the clip itself done by lane 0.  Same candidates, same order, same arithmetic as the first pass
 // (and the oracle).
+// CAP = vertices a polygon may reach: the pass runs with 128 first (4 KiB of LDS per wave: forty waves per CU instead
+// of the five that two 16 KiB buffers allow) and hands the few polygons that outgrow that to a second launch with
+// kHprOverCap (list2, counted in status[3]); results do not depend on the tier.
+template <int CAP>
 __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double *__restrict__ fl_all,
                                                              const HprTile *__restrict__ tiles_all, unsigned char *__restrict__ vis,
                                                              int *__restrict__ cnt, int *status, const int *__restrict__ list,
                                                              const int *__restrict__ perm, const int *__restrict__ hardlist,
                                                              const int *__restrict__ hardcnt, int no_cull,
-                                                             const unsigned char *__restrict__ alive)
+                                                             const unsigned char *__restrict__ alive, int *__restrict__ list2)
 {
-    __shared__ double2 s_buf[2][kHprOverCap];
+    __shared__ double2 s_buf[2][CAP];
     const int lane = threadIdx.x;
     const int id = list[blockIdx.x], view = id / n, rank = id - view * n;
     if (alive && !alive[view]) return;        // (wave-uniform) a view that cannot be the best any more
@@ -1240,8 +1244,11 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                     for (int o = 32; o > 0; o >>= 1) out += __shfl_xor(out, o, kWave);
                     if (!out) continue;
                     if (out == nv) { nv = 0; break; }
-                    if (nv - out + 2 > kHprOverCap) {
-                        if (lane == 0) atomicExch(&status[1], 2);
+                    if (nv - out + 2 > CAP) {
+                        if (lane == 0) {
+                            if (CAP < kHprOverCap) list2[atomicAdd(&status[3], 1)] = id;      // the large-polygon launch takes it
+                            else atomicExch(&status[1], 2);
+                        }
                         failed = true;
                         nv = 0;
                         break;
@@ -1470,7 +1477,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
                        (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull,
                        max_clips, split, surv, surv_poly, und);
     if (!check(hipGetLastError(), "hpr launch")) return 0;
-    int st[3] = {0, 0, 0};
+    int st[4] = {0, 0, 0, 0};
     if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
     if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
     if (prune) hipLaunchKernelGGL(hpr_prune_kernel, dim3(1), dim3(1024), 0, stream, c, (const int *)counts, (const int *)und, alive);
@@ -1486,16 +1493,31 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     }
     if (second_pass_points) *second_pass_points = st[0];
     if (st[0] > 0) {
-        hipLaunchKernelGGL(hpr_overflow_kernel, dim3(st[0]), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
-                           visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist, (const int *)hardcnt, no_cull,
-                           (const unsigned char *)alive);
-        if (!check(hipGetLastError(), "hpr second pass launch")) return 0;
-        if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
-        if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
+        int *list2 = (int *)k0;          // (the sort's key buffer is free by now; st[0] <= views x points entries)
+        static const bool one_tier = getenv("GENPC_HPR_ONE_TIER") != nullptr;
+        if (!one_tier) {
+            hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(st[0]), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
+                               visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
+                               no_cull, (const unsigned char *)alive, list2);
+            if (!check(hipGetLastError(), "hpr second pass launch")) return 0;
+            if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
+            if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
+        }
+        const int big = one_tier ? st[0] : st[3];
+        if (big > 0) {
+            hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(big), dim3(kWave), 0, stream, n, (const double *)fl,
+                               (const HprTile *)tiles, visible, counts, status, one_tier ? (const int *)list : (const int *)list2,
+                               (const int *)i1, (const int *)hardlist, (const int *)hardcnt, no_cull, (const unsigned char *)alive,
+                               (int *)nullptr);
+            if (!check(hipGetLastError(), "hpr large-polygon launch")) return 0;
+            if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
+            if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
+        }
         if (st[1]) {
             set_error("genpc_hpr_visibility: a normal-cone polygon outgrew 1024 vertices");
             return 0;
         }
+        if (getenv("GENPC_HPR_TIERS")) fprintf(stderr, "hpr: %d points in the wave-per-point pass, %d of them with polygons over 128 vertices\n", second_pass_points ? *second_pass_points : -1, big);
     }
     if (exact) {
         if (prune) {
