@@ -99,6 +99,27 @@ def test_hpr_lattice_takes_the_second_pass(hp):
         np.testing.assert_array_equal(cnt, vis.sum(1))
 
 
+def test_hpr_polygons_over_128_vertices(hp):
+    """A point on the viewing axis inside a ring of 300 points at the same distance from the eye and the same angle
+    from the axis: its normal-cone polygon is a 300-gon -- beyond the 16 vertices of the first pass and beyond the 128
+    of the wave-per-point pass's first tier, i.e. the large-polygon launch.  Masks equal the clipping oracle's and qhull's."""
+    m = 300
+    th = 2.0 * np.pi * (np.arange(m) + 0.25) / m
+    ang = 0.2
+    ring = np.stack([np.sin(ang) * np.cos(th), np.sin(ang) * np.sin(th), np.full(m, np.cos(ang))], 1)
+    rng = np.random.default_rng(11)
+    far = rng.normal(size=(200, 3))
+    far = far / np.linalg.norm(far, axis=1, keepdims=True) * 1.5            # a shell behind: hidden or not, it cuts nothing near the axis
+    P = np.concatenate([[[0.0, 0.0, 1.0]], ring, far]).astype(np.float32)
+    eye = np.zeros((1, 3))
+    for radius in (100.0, 10000.0):
+        vis, cnt, second = hp["run"](P, eye, radius)
+        assert second >= 1 or radius > 100.0      # (at the large radius the point's own direction already separates it)
+        np.testing.assert_array_equal(vis, hp["clip"](P, eye, radius))
+        np.testing.assert_array_equal(vis, hp["qhull"](P, eye, radius))
+        assert vis[0, 0]
+
+
 def test_hpr_edge_cases(hp):
     import torch
     lib = hp["lib"].lib
