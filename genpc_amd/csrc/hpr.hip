@@ -51,7 +51,7 @@
 namespace genpc {
 
 constexpr int kHprThreads = 128;
-constexpr int kHprMaxV = 16;            // polygon vertices per thread in LDS (32 KB per block: four blocks per CU; measured 24 -> 16: 24.7 -> 20.9 ms at 64 x 10000, 12: 32 ms -- too many points fall to the second pass)
+constexpr int kHprMaxV = 10;            // polygon vertices per thread in LDS (20 KB per 128-thread block).  Round 2: 24 -> 16 (24.7 -> 20.9 ms at 64 x 10000; 12 then lost: too many points fell to a second pass that held five waves per CU).  With the second pass's 4 KiB tier the balance moved: 1024 x 10000 blob / scan 83.7 / 51.4 ms at 16, 68.5 / 43.1 at 12, 66.2 / 41.9 at 10, 75.4 / 43.3 at 9, 99 / 52 at 8
 constexpr int kHprOverCap = 1024;       // vertices per polygon in the second pass (2 x 16 KB of LDS per wave)
 constexpr double kHprBox = 1.0e4;
 
