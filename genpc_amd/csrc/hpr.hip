@@ -1169,6 +1169,68 @@ __global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsur
 // the few that are not provably out of reach are taken one by one, in order, the vertex test spread over the
 // lanes and the clip itself done by lane 0.  Same candidates, same order, same arithmetic as the first pass
 // (and the oracle).
+// hpr_clip and hpr_reach by all 64 lanes of a wave (the wave-per-point pass: its heaviest points clip 1000-2000 times
+// polygons of a hundred vertices; with one lane clipping and every lane walking the whole polygon for the reach, a
+// clip cost 36 k ticks and one point set the launch's 24 ms at 2 x 165546).  Every output vertex is computed by the
+// expressions of hpr_clip from the same operands, the maxima of hpr_reach are exact: the polygons are the same bits.
+__device__ __forceinline__ int hpr_clip_wave(const double2 *src, int nv, double A, double B, double C, double2 *dst, int lane)
+{
+    int base = 0;
+    for (int k0 = 0; k0 < nv; k0 += kWave) {
+        const int k = k0 + lane;
+        bool in0 = false, cross = false;
+        double2 cur = make_double2(0.0, 0.0), x = cur;
+        if (k < nv) {
+            const int k2 = k + 1 < nv ? k + 1 : 0;
+            cur = src[k];
+            const double2 nxt = src[k2];
+            const double s0 = cur.x * A + cur.y * B - C;
+            const double s1 = nxt.x * A + nxt.y * B - C;
+            in0 = !(s0 > 0.0);
+            cross = (s0 > 0.0) != (s1 > 0.0) && s0 != 0.0 && s1 != 0.0;
+            if (cross) {
+                const double t = s0 / (s0 - s1);
+                x.x = cur.x + t * (nxt.x - cur.x);
+                x.y = cur.y + t * (nxt.y - cur.y);
+            }
+        }
+        const unsigned long long bi = __ballot(in0), bc = __ballot(cross);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int pos = base + __popcll(bi & lt) + __popcll(bc & lt);
+        if (in0) dst[pos++] = cur;
+        if (cross) dst[pos] = x;
+        base += __popcll(bi) + __popcll(bc);
+    }
+    return base;
+}
+
+__device__ __forceinline__ HprReach hpr_reach_wave(const double2 *p, int nv, int lane)
+{
+    if (nv <= 48) return hpr_reach(p, 1, nv);          // (every lane the same loop: broadcast reads)
+    double m[9] = {0.0, -__builtin_inf(), -__builtin_inf(), -__builtin_inf(), -__builtin_inf(), -__builtin_inf(), -__builtin_inf(),
+                   -__builtin_inf(), -__builtin_inf()};
+    for (int k = lane; k < nv; k += kWave) {
+        const double2 v = p[k];
+        const double r2 = v.x * v.x + v.y * v.y, s = v.x + v.y, t = v.x - v.y;
+        m[0] = r2 > m[0] ? r2 : m[0];
+        m[1] = v.x > m[1] ? v.x : m[1];   m[2] = -v.x > m[2] ? -v.x : m[2];
+        m[3] = v.y > m[3] ? v.y : m[3];   m[4] = -v.y > m[4] ? -v.y : m[4];
+        m[5] = s > m[5] ? s : m[5];       m[8] = -s > m[8] ? -s : m[8];
+        m[6] = t > m[6] ? t : m[6];       m[7] = -t > m[7] ? -t : m[7];
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(m[q], o, kWave);
+            m[q] = other > m[q] ? other : m[q];
+        }
+    }
+    HprReach r;
+    r.d2 = m[0]; r.xp = m[1]; r.xn = m[2]; r.yp = m[3]; r.yn = m[4]; r.pp = m[5]; r.pn = m[6]; r.np = m[7]; r.nn = m[8];
+    return r;
+}
+
 // CAP = vertices a polygon may reach: the pass runs with 128 first (4 KiB of LDS per wave: forty waves per CU instead
 // of the five that two 16 KiB buffers allow) and hands the few polygons that outgrow that to a second launch with
 // kHprOverCap (list2, counted in status[3]); results do not depend on the tier.
@@ -1253,14 +1315,12 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                         nv = 0;
                         break;
                     }
-                    int m = 0;
-                    if (lane == 0) m = hpr_clip(src, 1, nv, Aj, Bj, Cj, s_buf[cur ^ 1], 1);
+                    const int m = hpr_clip_wave(src, nv, Aj, Bj, Cj, s_buf[cur ^ 1], lane);
                     __syncthreads();
-                    m = __shfl(m, 0, kWave);
                     if (m < 3) { nv = 0; break; }
                     nv = m;
                     cur ^= 1;
-                    R = hpr_reach(s_buf[cur], 1, nv);      // (every lane the same loop: broadcast reads)
+                    R = hpr_reach_wave(s_buf[cur], nv, lane);
                 }
             }
     };
