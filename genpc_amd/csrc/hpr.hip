@@ -1500,7 +1500,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     static const int env_clips = getenv("GENPC_HPR_MAXCLIPS") ? atoi(getenv("GENPC_HPR_MAXCLIPS")) : 0;
     // (large clouds: 96 -- 2 x 165546 points 46 -> 40 ms; many views of a small cloud: the second pass fills up
     //  instead -- 1024 x 10000 points 154 ms with 256, 168 with 128, 180 with 96)
-    const int max_clips = (no_cull & 64) ? 0x7fffffff : (env_clips > 0 ? env_clips : (ntiles >= kHprRimTiles ? 96 : 256));
+    const int max_clips = (no_cull & 64) ? 0x7fffffff : (env_clips > 0 ? env_clips : (ntiles >= kHprRimTiles ? 48 : 256));      // (large clouds: 96 -> 48 once the wave-per-point pass clipped by all lanes: 2 x 165546 24.9 -> 21.5 ms)
     unsigned char *hard = (unsigned char *)(ws + o_hard);
     int *hardlist = (int *)(ws + o_hl), *hardcnt = (int *)(ws + o_hc);
     hipLaunchKernelGGL(hpr_accept_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
