@@ -661,7 +661,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                                                          const int *__restrict__ hardcnt, unsigned char *__restrict__ vis,
                                                          int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull, int max_clips,
                                                          int split, int4 *__restrict__ surv, double2 *__restrict__ surv_poly,
-                                                         int *__restrict__ und)
+                                                         int *__restrict__ und, int straggle_from, int straggle_lanes)
 {
     __shared__ double2 s_poly[kHprMaxV * kHprThreads];
     __shared__ double4 s_stage[kHprThreads];      // 64 tile records while testing, then one tile's candidates
@@ -951,7 +951,24 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
             nv = -1;
             active = false;
         }
-        if (__syncthreads_count(active) == 0) break;
+        const int nactive = __syncthreads_count(active);
+        if (nactive == 0) break;
+        // After the first few batches of tiles the points a block still carries restart in the wave-per-point pass, one
+        // wave each: a block that walks on for some of its 128 points holds two waves (and their LDS) for every tile any
+        // of them needs -- block times at 2 x 165546: median 3.1 M ticks, slowest 23 M = the launch -- while the
+        // wave-per-point pass tests 64 candidates against one polygon at a time and clips with all lanes.  Measured
+        // (hand-off from batch 4, all remaining points): 2 x 165546 21.8 -> 14.8 ms (radius 100: 30.6 -> 16.2), 64 x 10000
+        // 12.1 -> 7.3 (15.7 -> 7.3); from batch 16: 9.4, from 64: 12.6.  (The split form for many views of a small cloud
+        // keeps its own second kernel: 1024 x 10000 65 / 39.6 / 43.9 ms against 74 / 36.9 / 42.7 this way.)
+        if (step0 >= straggle_from && nactive <= straggle_lanes && !(no_cull & 8)) {
+            if (active) {
+                over_list[atomicAdd(&status[0], 1)] = view * n + rank;
+                if (und) atomicAdd(&und[view], 1);
+                nv = -1;
+                active = false;
+            }
+            break;
+        }
         // which of the next tiles can still cut somebody's polygon (tested against the polygon as it is now:
         // it only shrinks, so a tile found out of reach stays out of reach)
         if (tid < bsz) {
@@ -1533,9 +1550,13 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
         surv_poly = (double2 *)workspace(20, (size_t)(hc_total > 0 ? hc_total : 1) * kHprMaxV * sizeof(double2), stream);
         if (!surv_poly) return 0;
     }
+    static const int env_sf = getenv("GENPC_HPR_STRAGGLE_FROM") ? atoi(getenv("GENPC_HPR_STRAGGLE_FROM")) : 4;
+    static const int env_sl = getenv("GENPC_HPR_STRAGGLE_LANES") ? atoi(getenv("GENPC_HPR_STRAGGLE_LANES")) : kHprThreads;
+    static const int env_st = getenv("GENPC_HPR_STRAGGLE_TILES") ? atoi(getenv("GENPC_HPR_STRAGGLE_TILES")) : 0;
+    const int straggle_from = ntiles >= env_st ? env_sf : 0x7fffffff, straggle_lanes = env_sl;
     hipLaunchKernelGGL(hpr_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
                        (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull,
-                       max_clips, split, surv, surv_poly, und);
+                       max_clips, split, surv, surv_poly, und, straggle_from, straggle_lanes);
     if (!check(hipGetLastError(), "hpr launch")) return 0;
     int st[4] = {0, 0, 0, 0};
     if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
