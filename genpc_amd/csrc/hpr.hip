@@ -1257,11 +1257,15 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                                                              int *__restrict__ cnt, int *status, const int *__restrict__ list,
                                                              const int *__restrict__ perm, const int *__restrict__ hardlist,
                                                              const int *__restrict__ hardcnt, int no_cull,
-                                                             const unsigned char *__restrict__ alive, int *__restrict__ list2)
+                                                             const unsigned char *__restrict__ alive, int *__restrict__ list2,
+                                                             const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly)
 {
     __shared__ double2 s_buf[2][CAP];
     const int lane = threadIdx.x;
-    const int id = list[blockIdx.x], view = id / n, rank = id - view * n;
+    // surv != null: the points the split first kernel left undecided continue HERE from their saved polygons (home tiles and
+    // verification are behind them), one wave each
+    const bool cont = surv != nullptr;
+    const int id = cont ? surv[blockIdx.x].x : list[blockIdx.x], view = id / n, rank = id - view * n;
     if (alive && !alive[view]) return;        // (wave-uniform) a view that cannot be the best any more
     const int *hl = hardlist + (size_t)view * n;
     const int pos = hl[rank], i = perm[(size_t)view * n + pos];
@@ -1271,7 +1275,10 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     HprFrame f;
     if (!hpr_frame(fl + (size_t)pos * 3, f)) return;      // (cannot happen: the first pass listed it)
     int cur = 0, nv = 4;
-    if (lane == 0) {
+    if (cont) {
+        nv = surv[blockIdx.x].y;
+        if (lane < nv) s_buf[0][lane] = surv_poly[(size_t)blockIdx.x * kHprMaxV + lane];
+    } else if (lane == 0) {
         s_buf[0][0] = make_double2(-kHprBox, -kHprBox);
         s_buf[0][1] = make_double2(kHprBox, -kHprBox);
         s_buf[0][2] = make_double2(kHprBox, kHprBox);
@@ -1342,7 +1349,7 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
             }
     };
     // the same order as the first pass: the home tile and its neighbours, then outward from the group's tile
-    for (int rel = 0; rel < 3 && nv > 0; rel++) {
+    for (int rel = 0; rel < 3 && nv > 0 && !cont; rel++) {
         const int tile = home + (rel == 0 ? 0 : (rel == 1 ? 1 : -1));
         if (tile >= 0 && tile < ntiles) take_tile(tile);
     }
@@ -1350,7 +1357,7 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     // lanes take 64 candidates at a time); strictly feasible everywhere: visible, nothing left to clip.  A wave
     // per point makes a trial cheap (n / 64 steps), so several interior points are tried: the centroid, or -- for
     // a polygon that runs out to the box -- points at decreasing distance from its vertex nearest the origin.
-    if (nv >= 3 && !(no_cull & 32)) {
+    if (nv >= 3 && !(no_cull & 32) && !cont) {
         const double2 *src = s_buf[cur];
         double2 ctr = make_double2(0.0, 0.0), v0 = ctr, v1 = ctr;
         double r0 = __builtin_inf(), r1 = __builtin_inf();
@@ -1471,10 +1478,15 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     const size_t o_und = off; off += up((size_t)c * sizeof(int));
     const size_t o_alive = off; off += up((size_t)c);
     const size_t o_dup = off; off += up((size_t)n);
-    // the split pays when many views share a small cloud (viewpoint_select: 1024 x 10000, 128 -> 88 ms; 64 x 10000: 14.3 -> 16.6, so not there); a few views
-    // of a large cloud keep the one-kernel form (GENPC_HPR_SPLIT=0/1 overrides)
-    static const int env_split = getenv("GENPC_HPR_SPLIT") ? atoi(getenv("GENPC_HPR_SPLIT")) : -1;
-    const int split = env_split >= 0 ? env_split : (ntiles < kHprRimTiles && (long long)c * n >= 4000000ll ? 1 : 0);
+    // Split form (the first kernel stops after the home tiles + verification and saves the undecided points' polygons; a
+    // wave per point continues from them): for clouds of < 256 tiles.  Round 3, first half: only for >= 4 M (view, point)
+    // pairs, with a dense one-thread-per-survivor second kernel (1024 x 10000: 128 -> 88 ms; 64 x 10000 14.3 -> 16.6).  With
+    // the wave-per-point continuation: 1024 x 10000 64 / 39 / 44 -> 58.6 / 32 / 37.5 ms (blob / two scans), 64 x 10000
+    // 7.3 -> 6.9.  A few views of a large cloud keep the one-kernel form (2 x 165546: 14.9 against 17.8 ms): there the lanes
+    // of a block want the same tiles, and staging them once per block through LDS beats per-wave reads
+    // (GENPC_HPR_SPLIT=0/1 overrides).
+    static const int env_split = getenv("GENPC_HPR_SPLIT") && *getenv("GENPC_HPR_SPLIT") ? atoi(getenv("GENPC_HPR_SPLIT")) : -1;
+    const int split = env_split >= 0 ? env_split : (ntiles < kHprRimTiles && (long long)c * n >= 100000ll ? 1 : 0);
     const size_t o_surv = off; off += split ? up(total * sizeof(int4)) : 0;
     // (the survivors' polygons are sized after the accept pass has counted the listed points: a second workspace)
     char *ws = (char *)workspace(17, off, stream);
@@ -1562,7 +1574,11 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
     if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
     if (prune) hipLaunchKernelGGL(hpr_prune_kernel, dim3(1), dim3(1024), 0, stream, c, (const int *)counts, (const int *)und, alive);
-    if (st[2] > 0) {
+    // the undecided points of the split first kernel: a wave each, continuing from the saved polygon (default), or the dense
+    // second kernel of round 3's first half (GENPC_HPR_PHASE2=1)
+    static const bool old_phase2 = getenv("GENPC_HPR_PHASE2") != nullptr;
+    int *list2 = (int *)k0;          // (the sort's key buffer is free by now; at most views x points entries)
+    if (st[2] > 0 && old_phase2) {
         hipLaunchKernelGGL(hpr_subtile_kernel, dim3(ntiles * (kHprThreads / 32) / 2, c), dim3(kWave), 0, stream, n, (const double *)fl, subs);
         hipLaunchKernelGGL(hpr_phase2_kernel, dim3(ceil_div(st[2], kHprThreads)), dim3(kHprThreads), 0, stream, n, st[2],
                            (const double *)fl, (const int *)i1, (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt,
@@ -1571,25 +1587,42 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
         if (!check(hipGetLastError(), "hpr phase 2 launch")) return 0;
         if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
         if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
+    } else if (st[2] > 0) {
+        hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(st[2]), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
+                           visible, counts, status, (const int *)nullptr, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
+                           no_cull, (const unsigned char *)alive, list2, (const int4 *)surv, (const double2 *)surv_poly);
+        if (!check(hipGetLastError(), "hpr continuation launch")) return 0;
     }
     if (second_pass_points) *second_pass_points = st[0];
-    if (st[0] > 0) {
-        int *list2 = (int *)k0;          // (the sort's key buffer is free by now; st[0] <= views x points entries)
+    {
         static const bool one_tier = getenv("GENPC_HPR_ONE_TIER") != nullptr;
-        if (!one_tier) {
-            hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(st[0]), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
+        const bool continued = st[2] > 0 && !old_phase2;
+        const int listed = st[0];
+        if (listed > 0 && !one_tier) {
+            hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(listed), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
                                visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
-                               no_cull, (const unsigned char *)alive, list2);
+                               no_cull, (const unsigned char *)alive, list2, (const int4 *)nullptr, (const double2 *)nullptr);
             if (!check(hipGetLastError(), "hpr second pass launch")) return 0;
+        }
+        if (continued || (listed > 0 && !one_tier)) {
             if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
             if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
         }
-        const int big = one_tier ? st[0] : st[3];
+        // polygons over 128 vertices (from either launch above), or every listed point with GENPC_HPR_ONE_TIER
+        const int big = st[3] + (one_tier ? listed : 0);
+        if (one_tier && listed > 0) {
+            hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(listed), dim3(kWave), 0, stream, n, (const double *)fl,
+                               (const HprTile *)tiles, visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist,
+                               (const int *)hardcnt, no_cull, (const unsigned char *)alive, (int *)nullptr, (const int4 *)nullptr,
+                               (const double2 *)nullptr);
+        }
+        if (st[3] > 0) {
+            hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(st[3]), dim3(kWave), 0, stream, n, (const double *)fl,
+                               (const HprTile *)tiles, visible, counts, status, (const int *)list2, (const int *)i1, (const int *)hardlist,
+                               (const int *)hardcnt, no_cull, (const unsigned char *)alive, (int *)nullptr, (const int4 *)nullptr,
+                               (const double2 *)nullptr);
+        }
         if (big > 0) {
-            hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(big), dim3(kWave), 0, stream, n, (const double *)fl,
-                               (const HprTile *)tiles, visible, counts, status, one_tier ? (const int *)list : (const int *)list2,
-                               (const int *)i1, (const int *)hardlist, (const int *)hardcnt, no_cull, (const unsigned char *)alive,
-                               (int *)nullptr);
             if (!check(hipGetLastError(), "hpr large-polygon launch")) return 0;
             if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
             if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
@@ -1598,7 +1631,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
             set_error("genpc_hpr_visibility: a normal-cone polygon outgrew 1024 vertices");
             return 0;
         }
-        if (getenv("GENPC_HPR_TIERS")) fprintf(stderr, "hpr: %d points in the wave-per-point pass, %d of them with polygons over 128 vertices\n", second_pass_points ? *second_pass_points : -1, big);
+        if (getenv("GENPC_HPR_TIERS")) fprintf(stderr, "hpr: %d points in the wave-per-point pass, %d of them with polygons over 128 vertices\n", listed, big);
     }
     if (exact) {
         if (prune) {
