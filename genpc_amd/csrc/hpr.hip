@@ -25,9 +25,13 @@
 //   hpr_kernel            one thread per left-over (view, point), polygon in LDS ([vertex][thread], <= kHprMaxV):
 //                         (1) the point's home tile, the next, the previous; (2) one interior point of the
 //                         polygon tried as THE normal against everything (strictly feasible: visible);
-//                         (3) all other tiles outward from the group's tile, tiles whose cone cannot reach
-//                         the polygon skipped whole, candidates filtered by two reach bounds, then clipped
-//   hpr_overflow_kernel   polygons that outgrow kHprMaxV, and in large clouds silhouette points: one wave each
+//                         (3) a few batches of the other tiles outward from the group's tile (tiles whose cone
+//                         cannot reach the polygon skipped whole, candidates filtered by two reach bounds, then
+//                         clipped); whatever is undecided then -- and, for clouds under 256 tiles, everything
+//                         undecided after (2), with its polygon saved -- goes to
+//   hpr_overflow_kernel   one WAVE per point (also: polygons that outgrow kHprMaxV): 64 candidates tested against
+//                         the polygon at a time, clips by all lanes; 128-vertex polygons first, larger ones in a
+//                         second launch
 // Every skip and every early decision is conservative (margins 1e-7 .. 1e-10 against fp64 roundoff of 1e-16),
 // so the mask is that of clipping every polygon by every point.
 //
@@ -302,54 +306,6 @@ __global__ __launch_bounds__(kHprThreads) void hpr_tile_kernel(int n, const doub
     }
 }
 
-// The same record for every CHUNK of 32 consecutive positions (four per tile): what lets a lane skip a quarter of a
-// tile it needs.  One wave per two chunks (a 32-lane half each; reductions by shuffles inside the half).
-__global__ __launch_bounds__(kWave) void hpr_subtile_kernel(int n, const double *__restrict__ fl_all, HprTile *__restrict__ subs)
-{
-    const int view = blockIdx.y, lane = threadIdx.x;
-    const int chunk = blockIdx.x * 2 + (lane >> 5);
-    const int nchunks = ceil_div_dev(n, kHprThreads) * (kHprThreads / 32);
-    const int pos = chunk * 32 + (lane & 31);
-    double ux = 0.0, uy = 0.0, uz = 0.0, rho = 0.0;
-    bool ok = false;
-    if (chunk < nchunks && pos < n) {
-        const double *p = fl_all + ((size_t)view * n + pos) * 3;
-        rho = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
-        ok = rho > 0.0 && rho < __builtin_inf();
-        if (ok) { ux = p[0] / rho; uy = p[1] / rho; uz = p[2] / rho; }
-        else rho = 0.0;
-    }
-    double sx = ux, sy = uy, sz = uz, rm = rho;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-        sx += __shfl_xor(sx, o, kWave);
-        sy += __shfl_xor(sy, o, kWave);
-        sz += __shfl_xor(sz, o, kWave);
-        const double r2 = __shfl_xor(rm, o, kWave);
-        rm = rm > r2 ? rm : r2;
-    }
-    const double l = sqrt(sx * sx + sy * sy + sz * sz);
-    const bool axis = l > 0.0 && rm > 0.0;
-    const double wx = axis ? sx / l : 0.0, wy = axis ? sy / l : 0.0, wz = axis ? sz / l : 0.0;
-    double cmin = ok ? ux * wx + uy * wy + uz * wz : 1.0;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-        const double c2 = __shfl_xor(cmin, o, kWave);
-        cmin = cmin < c2 ? cmin : c2;
-    }
-    if ((lane & 31) == 0 && chunk < nchunks) {
-        HprTile t;
-        double c = cmin - 1e-12;          // widen the cone past roundoff
-        if (!axis) c = -1.0;              // no usable axis: never skipped
-        t.wx = wx; t.wy = wy; t.wz = wz;
-        t.cos_phi = c;
-        t.cos2_phi = c * c;
-        t.sin2_phi = 1.0 - c * c + 1e-15;
-        t.sin_phi = sqrt(t.sin2_phi) * (1.0 + 1e-15);
-        t.inv_rho_max = rm > 0.0 ? 1.0 / (rm * (1.0 + 1e-12)) : 0.0;
-        subs[(size_t)view * nchunks + chunk] = t;
-    }
-}
 
 // Sutherland-Hodgman against a A + b B <= C: src (nv vertices, element k at src[k * ss]) -> dst (stride ds);
 // returns the new count.  A vertex exactly on the line is kept and spawns no intersection point.
@@ -655,7 +611,7 @@ constexpr double kHprRimD2 = 1.0e6; // ... a polygon with a vertex farther than 
 constexpr int kHprRimTiles = 256;  // ... and is handed to the second pass if the cloud has at least this many tiles
 
 // status[0] = points handed to the wave-per-point pass, status[1] = error (2: a polygon outgrew kHprOverCap),
-// status[2] = points left undecided for hpr_phase2_kernel
+// status[2] = points left undecided by the split first kernel (continued by the wave-per-point pass)
 __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *__restrict__ fl_all, const int *__restrict__ perm,
                                                          const HprTile *__restrict__ tiles_all, const int *__restrict__ hardlist,
                                                          const int *__restrict__ hardcnt, unsigned char *__restrict__ vis,
@@ -916,10 +872,10 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
             active = false;        // (nv >= 3 stays: reported as visible below)
         }
     }
-    // Phase 2 (every other tile, outward from the group's starting tile) is hpr_phase2_kernel's: only about one
-    // listed point in eight is still undecided here, and a block that carried them on waited for its slowest
-    // lane with the other seven eighths idle (1.5 of a block's 2.7 ms).  The undecided lanes
-    // park their polygons in memory; the second kernel packs them densely, 128 to a block.
+    // Split form: every other tile (outward from the group's starting tile) is the wave-per-point pass's: only about
+    // one listed point in eight is still undecided here, and a block that carried them on waited for its slowest
+    // lane with the other seven eighths idle (1.5 of a block's 2.7 ms).  The undecided lanes park
+    // their polygons in memory; hpr_overflow_kernel continues from them, one wave each.
     if (split && active) {
         const unsigned long long bal = __ballot(true);
         const int lane = tid & (kWave - 1);
@@ -1027,159 +983,6 @@ __global__ __launch_bounds__(1024) void hpr_prune_kernel(int c, const int *__res
     for (int v = threadIdx.x; v < c; v += 1024) alive[v] = cnt[v] + und[v] >= m ? 1 : 0;
 }
 
-// Phase 2 of the polygon pass for the points hpr_kernel left undecided, packed densely: one thread per survivor,
-// polygon back in LDS.  Every lane walks ITS OWN tile sequence -- outward from the starting tile of the group it
-// was listed in (hpr_base_tile of its rank: the order the oracle restates), skipping its three home tiles -- and
-// reads tile records and candidates straight from memory (the lanes of a wave want different tiles; the view's
-// flipped cloud and tile records stay in L2).  Same candidates, same order, same arithmetic as before the split:
-// the skips (tile cone test, reach bounds) are conservative, so when they are evaluated changes no polygon.
-// No block-wide synchronisation: a wave retires as soon as its 64 lanes are decided.
-__global__ __launch_bounds__(kHprThreads) void hpr_phase2_kernel(int n, int nsurv, const double *__restrict__ fl_all,
-                                                                const int *__restrict__ perm, const HprTile *__restrict__ tiles_all,
-                                                                const int *__restrict__ hardlist, const int *__restrict__ hardcnt,
-                                                                const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
-                                                                unsigned char *__restrict__ vis, int *__restrict__ cnt, int *status,
-                                                                int *__restrict__ over_list, int no_cull, int max_clips,
-                                                                const HprTile *__restrict__ subs_all,
-                                                                const unsigned char *__restrict__ alive)
-{
-    __shared__ double2 s_poly[kHprMaxV * kHprThreads];
-    const int tid = threadIdx.x, slot = blockIdx.x * kHprThreads + tid;
-    bool active = slot < nsurv;
-    int view = 0, rank = 0, nv = 0, nclips = 0, pos = 0, i = -1;
-    if (active) {
-        const int4 e = surv[slot];
-        view = e.x / n;
-        rank = e.x - view * n;
-        nv = e.y;
-        nclips = e.z;
-        if (alive && !alive[view]) { active = false; nv = -1; }      // a view that cannot be the best any more
-    }
-    const double *fl = fl_all + (size_t)view * n * 3;
-    const int *hl = hardlist + (size_t)view * n;
-    const int ntiles = ceil_div_dev(n, kHprThreads);
-    const HprTile *tiles = tiles_all + (size_t)view * ntiles;
-    HprFrame f = {};
-    int own = 0, home = 0;
-    double2 *poly = s_poly + tid;
-    if (active) {
-        pos = hl[rank];
-        i = perm[(size_t)view * n + pos];
-        own = hpr_base_tile(hl, hardcnt[view], rank);
-        home = pos / kHprThreads;
-        hpr_frame(fl + (size_t)pos * 3, f);         // (true: hpr_kernel listed it)
-        const double2 *sp = surv_poly + (size_t)slot * kHprMaxV;
-        for (int k = 0; k < nv; k++) poly[k * kHprThreads] = sp[k];
-    }
-    HprReach R = {};
-    if (active) R = hpr_reach(poly, kHprThreads, nv);
-    const HprTile *subs = subs_all + (size_t)view * ntiles * (kHprThreads / 32);
-    double d2_cached = -1.0, cpsi = 1.0, spsi = 0.0;
-    // (cos, sin) of the polygon's angular radius: two fp64 square roots and two divisions -- a hundred
-    // instructions -- recomputed only when a clip has changed the reach
-    auto radius_of_reach = [&]() {
-        if (R.d2 != d2_cached) {
-            const double l = sqrt(1.0 + R.d2) * (1.0 + 1e-15);
-            cpsi = 1.0 / l;
-            spsi = sqrt(R.d2) / l * (1.0 + 1e-15);
-            d2_cached = R.d2;
-        }
-    };
-    // one tile of candidates against this lane's polygon: hpr_kernel's clip_by_tile for a tile that is not the
-    // point's home tile (chunks of 32 in ascending order), candidates read from memory.  A chunk whose own cone
-    // (hpr_subtile_kernel) cannot reach the polygon is skipped whole: 32 candidate tests for one cone test.
-    auto clip_by_tile = [&](int tile) {
-        const int tile0 = tile * kHprThreads;
-        for (int cc = 0; cc < kHprThreads / 32 && active; cc++) {
-            const int c0 = cc * 32;
-            R = hpr_reach(poly, kHprThreads, nv);
-            if (!(no_cull & 1)) {
-                radius_of_reach();
-                if (!hpr_tile_needed(f, cpsi, spsi, poly, kHprThreads, nv, subs[tile * (kHprThreads / 32) + cc])) continue;
-            }
-            unsigned m = 0u;
-#pragma unroll 4
-            for (int t = 0; t < 32; t++) {
-                const int j = tile0 + c0 + t;
-                if (j >= n) break;
-                const double *g = fl + (size_t)j * 3;
-                const double qx = g[0], qy = g[1], qz = g[2];
-                const double A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
-                const double B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
-                const double C = f.rho - (f.ux * qx + f.uy * qy + f.uz * qz);
-                const bool self = qx == f.px && qy == f.py && qz == f.pz;      // the point itself, or an exact duplicate
-                m |= (!self && qx == qx && !hpr_far(R, A, B, C)) ? (1u << t) : 0u;
-            }
-            while (m && active) {
-                const int t = __ffs((int)m) - 1;
-                m &= m - 1;
-                const double *g = fl + (size_t)(tile0 + c0 + t) * 3;
-                const double qx = g[0], qy = g[1], qz = g[2];
-                const double A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
-                const double B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
-                const double C = f.rho - (f.ux * qx + f.uy * qy + f.uz * qz);
-                int out = 0, first = 0, runs = 0;
-                bool prev_out;
-                {
-                    const double2 v = poly[(nv - 1) * kHprThreads];
-                    prev_out = v.x * A + v.y * B - C > 0.0;
-                }
-                for (int k0 = 0; k0 < nv; k0 += 8) {
-                    double2 v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = poly[(k0 + j < kHprMaxV ? k0 + j : kHprMaxV - 1) * kHprThreads];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const bool o = k0 + j < nv && v[j].x * A + v[j].y * B - C > 0.0;
-                        out += o ? 1 : 0;
-                        first = (o && !prev_out) ? k0 + j : first;
-                        runs += (o && !prev_out) ? 1 : 0;
-                        prev_out = k0 + j < nv ? o : prev_out;
-                    }
-                }
-                if (!out) continue;
-                if (out == nv) { nv = 0; active = false; break; }
-                if (nv - out + 2 > kHprMaxV || runs > 1) {
-                    over_list[atomicAdd(&status[0], 1)] = view * n + rank;
-                    nv = -1;
-                    active = false;
-                    break;
-                }
-                const int mm = hpr_clip_inplace(poly, kHprThreads, nv, out, first, A, B, C);
-                if (mm < 3) { nv = 0; active = false; break; }
-                nv = mm;
-                if (++nclips > max_clips) {
-                    over_list[atomicAdd(&status[0], 1)] = view * n + rank;
-                    nv = -1;
-                    active = false;
-                    break;
-                }
-            }
-        }
-    };
-    for (int step = 0; step < 2 * ntiles; step++) {
-        // a polygon that still runs out to the box after the eight nearest tiles belongs to a point on the
-        // silhouette: in a large cloud it goes to the wave-per-point pass (as before the split)
-        if (step == kHprRimStep && ntiles >= kHprRimTiles && active && R.d2 > kHprRimD2 && !(no_cull & 8)) {
-            over_list[atomicAdd(&status[0], 1)] = view * n + rank;
-            nv = -1;
-            active = false;
-        }
-        if (!__any(active)) break;
-        if (!active) continue;
-        const int tile = hpr_tile_of(step, own);
-        if (tile < 0 || tile >= ntiles) continue;
-        if (tile >= home - 1 && tile <= home + 1) continue;          // taken in phase 1
-        if (!(no_cull & 1)) {
-            radius_of_reach();
-            if (!hpr_tile_needed(f, cpsi, spsi, poly, kHprThreads, nv, tiles[tile])) continue;
-        }
-        clip_by_tile(tile);
-    }
-    const bool seen = i >= 0 && nv > 0;
-    if (i >= 0 && nv >= 0) vis[(size_t)view * n + i] = seen ? 1 : 0;
-    if (seen) atomicAdd(&cnt[view], 1);
-}
 
 // second pass: one WAVE per listed point, polygon in LDS (two buffers of kHprOverCap vertices).  Lane b tests
 // tile b of a batch of 64; in a tile that can reach the polygon the 64 lanes test 64 candidates at once, and
@@ -1471,7 +1274,6 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     const size_t o_tmp = off; off += up(sort_bytes);
     const int ntiles = ceil_div(n, kHprThreads);
     const size_t o_tiles = off; off += up((size_t)c * ntiles * sizeof(HprTile));
-    const size_t o_subs = off; off += up((size_t)c * ntiles * (kHprThreads / 32) * sizeof(HprTile));
     const size_t o_hard = off; off += up(total);
     const size_t o_hl = off; off += up(total * sizeof(int));
     const size_t o_hc = off; off += up((size_t)c * sizeof(int));
@@ -1525,7 +1327,6 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept, 32 = no verify phase, 64 = no hand-off of much-cut polygons (results unchanged)
     hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl, (const unsigned char *)dup);
     hipLaunchKernelGGL(hpr_tile_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, tiles);
-    HprTile *subs = (HprTile *)(ws + o_subs);
     static const int env_clips = getenv("GENPC_HPR_MAXCLIPS") ? atoi(getenv("GENPC_HPR_MAXCLIPS")) : 0;
     // (large clouds: 96 -- 2 x 165546 points 46 -> 40 ms; many views of a small cloud: the second pass fills up
     //  instead -- 1024 x 10000 points 154 ms with 256, 168 with 128, 180 with 96)
@@ -1574,20 +1375,9 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
     if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
     if (prune) hipLaunchKernelGGL(hpr_prune_kernel, dim3(1), dim3(1024), 0, stream, c, (const int *)counts, (const int *)und, alive);
-    // the undecided points of the split first kernel: a wave each, continuing from the saved polygon (default), or the dense
-    // second kernel of round 3's first half (GENPC_HPR_PHASE2=1)
-    static const bool old_phase2 = getenv("GENPC_HPR_PHASE2") != nullptr;
+    // the undecided points of the split first kernel: a wave each, continuing from the saved polygon
     int *list2 = (int *)k0;          // (the sort's key buffer is free by now; at most views x points entries)
-    if (st[2] > 0 && old_phase2) {
-        hipLaunchKernelGGL(hpr_subtile_kernel, dim3(ntiles * (kHprThreads / 32) / 2, c), dim3(kWave), 0, stream, n, (const double *)fl, subs);
-        hipLaunchKernelGGL(hpr_phase2_kernel, dim3(ceil_div(st[2], kHprThreads)), dim3(kHprThreads), 0, stream, n, st[2],
-                           (const double *)fl, (const int *)i1, (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt,
-                           (const int4 *)surv, (const double2 *)surv_poly, visible, counts, status, list, no_cull, max_clips,
-                           (const HprTile *)subs, (const unsigned char *)alive);
-        if (!check(hipGetLastError(), "hpr phase 2 launch")) return 0;
-        if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
-        if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
-    } else if (st[2] > 0) {
+    if (st[2] > 0) {
         hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(st[2]), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
                            visible, counts, status, (const int *)nullptr, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
                            no_cull, (const unsigned char *)alive, list2, (const int4 *)surv, (const double2 *)surv_poly);
@@ -1596,7 +1386,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     if (second_pass_points) *second_pass_points = st[0];
     {
         static const bool one_tier = getenv("GENPC_HPR_ONE_TIER") != nullptr;
-        const bool continued = st[2] > 0 && !old_phase2;
+        const bool continued = st[2] > 0;
         const int listed = st[0];
         if (listed > 0 && !one_tier) {
             hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(listed), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
