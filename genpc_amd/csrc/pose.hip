@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kQBlock) void pose_replicate_kernel(size_t count, i
 constexpr int kMaskTile = 16;
 constexpr int kSplatBlock = 1024;  // 16 waves per tile: a wave per point leaves long dependent chains, four waves per SIMD hide them
 constexpr int kSplatPer = 16;      // points per thread and round of the splat (16384 points per round)
-constexpr int kSplatList = 2048;   // in-tile points drawn per fill of the LDS list
+constexpr int kSplatList = 1024;   // in-tile points drawn per fill of the LDS list (full-scan path; the list path holds a whole tile list: kTileCap)
 constexpr float kMaskAmax = 0.999f;
 constexpr float kMaskFocal = 4.0f, kMaskEyeZ = 3.0f, kMaskZnear = 1e-4f, kMaskZfar = 5.0f;
 constexpr float kLumR = 0.299f, kLumG = 0.587f, kLumB = 0.114f;      // compute_soft_mask, diff_obj_pose.py:273
@@ -423,14 +423,91 @@ __device__ __forceinline__ SplatPt splat_project(const float *p, float radius, f
 
 // grid (blocks, b): uvr[e, j] = (u, v, rho, 1 / rho^2), rho = -1 for points the camera does not see.
 // posed != 0: v is the complete cloud and is posed with params first.
+// Per-tile index lists (filled by the projection kernels, read and reset by mask_splat_kernel): bins = { count[b][tiles],
+// idx[b][tiles][kTileCap] }.  A point goes to every tile its disc's bounding box touches -- THE test of the splat kernel, so
+// a tile's list is exactly its hit set; a tile with more than kTileCap hits (the count keeps counting) is drawn by the
+// full scan.  (Every block used to read all projected points of its image: 205 MB of L2 reads per launch of four
+// starts, 43 k ticks for an empty tile.)
+constexpr int kTileCap = 1024;
+constexpr int kBinTiles = 1024;          // tiles per image the block-level histogram holds (S <= 512); larger images: no bins
+constexpr int kBinPer = 4;               // tiles a point's disc may touch on this path (more: the image falls back to the full scan)
+
+// Block-level binning of one point per thread (all threads of the block call it; `valid`: this thread has a point):
+// the tile counts of the block's points are first accumulated in LDS, ONE global atomic per (block, tile) reserves the
+// block's range in the tile's list, then the threads write their indices.  (One global atomic per (point, tile) -- 144 k
+// per launch of four starts, 640 on the counter of a crowded tile -- made the 5 us projection kernel 50 us.)
+__device__ __forceinline__ void bin_points_block(int *__restrict__ cnt, int *__restrict__ idx, int *s_cnt, int *s_base, int S, bool valid,
+                                                 int j, float u, float v, float rho)
+{
+    const int T = (S + kMaskTile - 1) / kMaskTile, tiles = T * T;
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) s_cnt[t] = 0;
+    __syncthreads();
+    int my_tile[kBinPer], my_pos[kBinPer], nmine = 0;
+    bool too_many = false;
+    if (valid && rho > 0.0f) {
+        int tx_lo = (int)floorf((u - rho) / (float)kMaskTile) - 1, tx_hi = (int)floorf((u + rho) / (float)kMaskTile) + 1;
+        int ty_lo = (int)floorf((v - rho) / (float)kMaskTile) - 1, ty_hi = (int)floorf((v + rho) / (float)kMaskTile) + 1;
+        tx_lo = tx_lo < 0 ? 0 : tx_lo; ty_lo = ty_lo < 0 ? 0 : ty_lo;
+        tx_hi = tx_hi > T - 1 ? T - 1 : tx_hi; ty_hi = ty_hi > T - 1 ? T - 1 : ty_hi;
+        for (int ty = ty_lo; ty <= ty_hi; ty++)
+            for (int tx = tx_lo; tx <= tx_hi; tx++) {
+                const int tx0 = tx * kMaskTile, ty0 = ty * kMaskTile;
+                const int tx1 = min(S, tx0 + kMaskTile) - 1, ty1 = min(S, ty0 + kMaskTile) - 1;
+                // mask_splat_kernel's bounding-box test, verbatim
+                if (u + rho >= (float)tx0 && u - rho <= (float)(tx1 + 1) && v + rho >= (float)ty0 && v - rho <= (float)(ty1 + 1)) {
+                    if (nmine < kBinPer) {
+                        my_tile[nmine] = ty * T + tx;
+                        my_pos[nmine] = atomicAdd(&s_cnt[ty * T + tx], 1);
+                        nmine++;
+                    } else {
+                        too_many = true;
+                    }
+                }
+            }
+    }
+    // a disc over more than kBinPer tiles: poison every counter it touches (count > kTileCap: those tiles take the full scan)
+    // (the loop is over the clamped tile range again)
+    if (too_many) {
+        const int T2 = T;
+        for (int ty = 0; ty < T2; ty++)
+            for (int tx = 0; tx < T2; tx++) {
+                const int tx0 = tx * kMaskTile, ty0 = ty * kMaskTile;
+                const int tx1 = min(S, tx0 + kMaskTile) - 1, ty1 = min(S, ty0 + kMaskTile) - 1;
+                if (u + rho >= (float)tx0 && u - rho <= (float)(tx1 + 1) && v + rho >= (float)ty0 && v - rho <= (float)(ty1 + 1))
+                    atomicOr(&cnt[ty * T + tx], 1 << 30);
+            }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
+        const int c = s_cnt[t];
+        s_base[t] = c ? atomicAdd(&cnt[t], c) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kBinPer; k++) {
+        if (k < nmine) {
+            const int pos = s_base[my_tile[k]] + my_pos[k];
+            if (pos < kTileCap) idx[(size_t)my_tile[k] * kTileCap + pos] = j;
+        }
+    }
+    __syncthreads();
+}
+__host__ __device__ __forceinline__ size_t bins_tiles(int S)
+{
+    const size_t T = (size_t)((S + kMaskTile - 1) / kMaskTile);
+    return T * T;
+}
+
 __global__ __launch_bounds__(kQBlock) void mask_project_kernel(int n, const float *__restrict__ v,
                                                                const float *__restrict__ center, int cstride,
                                                                const float *__restrict__ params, int pstride, int posed,
-                                                               float radius, int S, float4 *__restrict__ uvr)
+                                                               float radius, int S, float4 *__restrict__ uvr, int *__restrict__ bins)
 {
     const int e = blockIdx.y;
     v += (size_t)e * n * 3;
     uvr += (size_t)e * n;
+    int *bin_cnt = bins ? bins + (size_t)e * bins_tiles(S) : nullptr;
+    int *bin_idx = bins ? bins + (size_t)gridDim.y * bins_tiles(S) + (size_t)e * bins_tiles(S) * kTileCap : nullptr;
     float R[9], s = 1.0f, c[3] = {0, 0, 0}, t[3] = {0, 0, 0};
     if (posed) {
         center += (size_t)e * cstride;
@@ -441,15 +518,20 @@ __global__ __launch_bounds__(kQBlock) void mask_project_kernel(int n, const floa
         t[0] = params[6]; t[1] = params[7]; t[2] = params[8];
     }
     const float hs = 0.5f * S;
-    for (int j = blockIdx.x * kQBlock + threadIdx.x; j < n; j += gridDim.x * kQBlock) {
-        float p[3] = {v[(size_t)j * 3 + 0], v[(size_t)j * 3 + 1], v[(size_t)j * 3 + 2]};
+    __shared__ int s_cnt[kBinTiles], s_base[kBinTiles];
+    for (int j0 = blockIdx.x * kQBlock; j0 < n; j0 += gridDim.x * kQBlock) {        // (block-uniform: bin_points_block has barriers)
+        const int j = j0 + threadIdx.x;
+        const bool valid = j < n;
+        const int jj = valid ? j : n - 1;
+        float p[3] = {v[(size_t)jj * 3 + 0], v[(size_t)jj * 3 + 1], v[(size_t)jj * 3 + 2]};
         if (posed) {
             float o[3];
             pose_point(R, s, c, t, p[0], p[1], p[2], o);
             p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
         }
         const SplatPt q = splat_project(p, radius, hs);
-        uvr[j] = make_float4(q.u, q.v, q.ok ? q.rho : -1.0f, q.ok ? 1.0f / (q.rho * q.rho) : 0.0f);
+        if (valid) uvr[j] = make_float4(q.u, q.v, q.ok ? q.rho : -1.0f, q.ok ? 1.0f / (q.rho * q.rho) : 0.0f);
+        if (bin_cnt) bin_points_block(bin_cnt, bin_idx, s_cnt, s_base, S, valid && q.ok, j, q.u, q.v, q.rho);
     }
 }
 
@@ -459,12 +541,14 @@ __global__ __launch_bounds__(kQBlock) void pose_transform_project_kernel(int n, 
                                                                          const float *__restrict__ center, int cstride,
                                                                          const float *__restrict__ params, int pstride,
                                                                          float *__restrict__ pts, float radius, int S,
-                                                                         float4 *__restrict__ uvr)
+                                                                         float4 *__restrict__ uvr, int *__restrict__ bins)
 {
     const int e = blockIdx.y;
     v += (size_t)e * n * 3;
     pts += (size_t)e * n * 3;
     uvr += (size_t)e * n;
+    int *bin_cnt = bins ? bins + (size_t)e * bins_tiles(S) : nullptr;
+    int *bin_idx = bins ? bins + (size_t)gridDim.y * bins_tiles(S) + (size_t)e * bins_tiles(S) * kTileCap : nullptr;
     center += (size_t)e * cstride;
     params += (size_t)e * pstride;
     float R[9];
@@ -473,14 +557,21 @@ __global__ __launch_bounds__(kQBlock) void pose_transform_project_kernel(int n, 
     const float c[3] = {center[0], center[1], center[2]};
     const float t[3] = {params[6], params[7], params[8]};
     const float hs = 0.5f * S;
-    for (int j = blockIdx.x * kQBlock + threadIdx.x; j < n; j += gridDim.x * kQBlock) {
+    __shared__ int s_cnt[kBinTiles], s_base[kBinTiles];
+    for (int j0 = blockIdx.x * kQBlock; j0 < n; j0 += gridDim.x * kQBlock) {        // (block-uniform: bin_points_block has barriers)
+        const int j = j0 + threadIdx.x;
+        const bool valid = j < n;
+        const int jj = valid ? j : n - 1;
         float o[3];
-        pose_point(R, s, c, t, v[(size_t)j * 3 + 0], v[(size_t)j * 3 + 1], v[(size_t)j * 3 + 2], o);
-        pts[(size_t)j * 3 + 0] = o[0];
-        pts[(size_t)j * 3 + 1] = o[1];
-        pts[(size_t)j * 3 + 2] = o[2];
+        pose_point(R, s, c, t, v[(size_t)jj * 3 + 0], v[(size_t)jj * 3 + 1], v[(size_t)jj * 3 + 2], o);
         const SplatPt q = splat_project(o, radius, hs);
-        uvr[j] = make_float4(q.u, q.v, q.ok ? q.rho : -1.0f, q.ok ? 1.0f / (q.rho * q.rho) : 0.0f);
+        if (valid) {
+            pts[(size_t)j * 3 + 0] = o[0];
+            pts[(size_t)j * 3 + 1] = o[1];
+            pts[(size_t)j * 3 + 2] = o[2];
+            uvr[j] = make_float4(q.u, q.v, q.ok ? q.rho : -1.0f, q.ok ? 1.0f / (q.rho * q.rho) : 0.0f);
+        }
+        if (bin_cnt) bin_points_block(bin_cnt, bin_idx, s_cnt, s_base, S, valid && q.ok, j, q.u, q.v, q.rho);
     }
 }
 
@@ -516,7 +607,8 @@ __device__ __forceinline__ PxImg load_pixel(const float *__restrict__ pl, int P,
 // grid (tiles, b).  col: [b, n, 3] colours or nullptr (white).
 __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const float4 *__restrict__ uvr,
                                                                  const float *__restrict__ col, int S,
-                                                                 float *__restrict__ planes, double *__restrict__ accum)
+                                                                 float *__restrict__ planes, double *__restrict__ accum,
+                                                                 int *__restrict__ bins)
 {
     static_assert(kSplatBlock == 4 * kMaskTile * kMaskTile, "four threads per pixel of the tile");
     __shared__ float part[5][4][kMaskTile * kMaskTile];
@@ -544,7 +636,54 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     // and step), then GATHERED: every pixel walks the list (broadcast reads) and accumulates the discs
     // that cover it, in list order -- no atomics on the image.  (Scattering with LDS float atomics ran at
     // ~0.6 adds per clock per CU: 26 us of the kernel's 36 for 758 points in the busiest tile.)
-    for (int j0 = 0; j0 < n; j0 += kSplatBlock * kSplatPer) {
+    // The tile's own list (bins, filled by the projection kernel): its indices are put in ascending order -- the fixed
+    // summation order of the gather -- by counting ranks, the entries fetched, and the full scan below is skipped.  A tile
+    // whose list overflowed (or a launch without bins) takes the full scan.
+    __shared__ __attribute__((aligned(16))) int s_sort[kTileCap];
+    int binned = -1;
+    int *bin_cnt = bins ? bins + (size_t)e * bins_tiles(S) : nullptr;
+    const int *bin_idx = bins ? bins + (size_t)gridDim.y * bins_tiles(S) + ((size_t)e * bins_tiles(S) + blockIdx.x) * kTileCap : nullptr;
+    if (bins) binned = bin_cnt[blockIdx.x];
+    const bool by_list = binned >= 0 && binned <= kTileCap;
+    if (by_list && binned > 0) {
+        static_assert(kTileCap <= kSplatBlock && kTileCap <= kSplatList, "one list entry per thread, one fill");
+        const int L = binned, L4 = (L + 3) & ~3;
+        int myj = 0x7fffffff;
+        if ((int)threadIdx.x < L) myj = bin_idx[threadIdx.x];
+        if ((int)threadIdx.x < L4) s_sort[threadIdx.x] = myj;
+        __syncthreads();
+        if ((int)threadIdx.x < L) {
+            int rank = 0;
+            for (int k = 0; k < L4; k += 4) {
+                const int4 o = *(const int4 *)&s_sort[k];
+                rank += (o.x < myj) + (o.y < myj) + (o.z < myj) + (o.w < myj);
+            }
+            const float4 qh = uvr[myj];
+            float cr = 1.0f, cg = 1.0f, cb = 1.0f;
+            if (col) { cr = col[(size_t)myj * 3 + 0]; cg = col[(size_t)myj * 3 + 1]; cb = col[(size_t)myj * 3 + 2]; }
+            list[rank] = make_float4(qh.x, qh.y, qh.w, cr);
+            list_gb[rank] = make_float2(cg, cb);
+        }
+        __syncthreads();
+        for (int k = share; k < L; k += 4) {
+            const float4 p = list[k];
+            const float dx = pxc - p.x, dy = pyc - p.y;
+            const float a = 1.0f - (dx * dx + dy * dy) * p.z;
+            if (a > 0.0f) {
+                const float2 gb = list_gb[k];
+                const float ac = fminf(a, kMaskAmax);
+                tr *= 1.0f - ac;
+                sd += ac;
+                sr += ac * p.w;
+                sg += ac * gb.x;
+                sb += ac * gb.y;
+            }
+        }
+    }
+    // (the count was read above by the threads of this block only: no barrier needed before it is reset for the next launch)
+    __syncthreads();
+    if (bins && threadIdx.x == 0) bin_cnt[blockIdx.x] = 0;
+    for (int j0 = 0; j0 < n && !by_list; j0 += kSplatBlock * kSplatPer) {
         // the bounding-box tests keep only a bit per point (four points in flight at a time): the kernel must fit 64
         // VGPRs so that TWO 1024-thread blocks share a CU -- with all sixteen points of a thread in registers it needed
         // 128, one block per CU, and a lock-step batch of 8 scans x 4 starts (6272 blocks) ran 8 % slower
@@ -1120,6 +1259,13 @@ namespace genpc {
 static int mask_tiles(int S) { const int t = ceil_div(S, kMaskTile); return t * t; }
 
 // scratch of the mask term for b scans of P pixels and up to nmax points (bytes, 256-aligned pieces)
+// GENPC_SPLAT_BINS=0: every tile by the full scan (A/B)
+static bool use_bins(int S)
+{
+    static const bool v = !(getenv("GENPC_SPLAT_BINS") && atoi(getenv("GENPC_SPLAT_BINS")) == 0);
+    return v && bins_tiles(S) <= (size_t)kBinTiles;
+}
+
 struct MaskScratch {
     float *stats;      // [b, 8]
     float *mref;       // [b, P]
@@ -1127,11 +1273,15 @@ struct MaskScratch {
     float *W1;         // [b, P]
     float4 *W4;        // [b, P]
     float4 *uvr;       // [b, nmax]
+    int *bins;         // [b, tiles] counts | [b, tiles, kTileCap] point indices (bin_point)
+    size_t bins_count_bytes;
     static size_t up(size_t x) { return (x + 255) / 256 * 256; }
+    static size_t side(size_t P) { size_t S = (size_t)sqrt((double)P); while (S * S < P) S++; return S; }
+    static size_t bins_bytes(int b, size_t P) { return (size_t)b * bins_tiles((int)side(P)) * (1 + (size_t)kTileCap) * sizeof(int); }
     static size_t bytes(int b, size_t P, size_t nmax)
     {
         return up((size_t)b * 8 * 4) + up((size_t)b * P * 4) + up((size_t)b * 5 * P * 4) + up((size_t)b * P * 4) +
-               up((size_t)b * P * 16) + up((size_t)b * nmax * 16);
+               up((size_t)b * P * 16) + up((size_t)b * nmax * 16) + up(bins_bytes(b, P));
     }
     void carve(char *base, int b, size_t P, size_t nmax)
     {
@@ -1141,9 +1291,13 @@ struct MaskScratch {
         planes = (float *)(base + off); off += up((size_t)b * 5 * P * 4);
         W1 = (float *)(base + off); off += up((size_t)b * P * 4);
         W4 = (float4 *)(base + off); off += up((size_t)b * P * 16);
-        uvr = (float4 *)(base + off);
-        (void)nmax;
+        uvr = (float4 *)(base + off); off += up((size_t)b * nmax * 16);
+        bins = (int *)(base + off);
+        bins_count_bytes = (size_t)b * bins_tiles((int)side(P)) * sizeof(int);
     }
+    // the tile counters are zero between launches (the splat kernel resets what it reads); once per API call for a
+    // workspace that is new or was last used with another batch size
+    bool zero_bins(hipStream_t st) const { return check(hipMemsetAsync(bins, 0, bins_count_bytes, st), "hipMemsetAsync(tile counters)"); }
 };
 
 // splat of the partial clouds (with their colours) + reference soft masks / statistics (once per call)
@@ -1151,9 +1305,9 @@ static int mask_prepare_ref(int b, int np, const float *partial, const float *pa
                             const MaskScratch &m, hipStream_t st)
 {
     hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(np), b), dim3(kQBlock), 0, st, np, partial, (const float *)nullptr, 0,
-                       (const float *)nullptr, 0, 0, radius, S, m.uvr);
+                       (const float *)nullptr, 0, 0, radius, S, m.uvr, use_bins(S) ? m.bins : (int *)nullptr);
     hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, np, (const float4 *)m.uvr, partial_col,
-                       S, m.planes, (double *)nullptr);
+                       S, m.planes, (double *)nullptr, use_bins(S) ? m.bins : (int *)nullptr);
     hipLaunchKernelGGL(mask_ref_kernel, dim3(b), dim3(kMLThreads), 0, st, S, (const float *)m.planes, 0, m.mref, m.stats);
     return check(hipGetLastError(), "mask reference launch") ? 1 : 0;
 }
@@ -1167,9 +1321,9 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
     const int gp = lin_grid((long long)S * S);
     if (!projected)      // (the alignment loop projects in its transform launch)
         hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride, params,
-                           pstride, 1, rad, S, m.uvr);
+                           pstride, 1, rad, S, m.uvr, use_bins(S) ? m.bins : (int *)nullptr);
     hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, nc, (const float4 *)m.uvr, complete_col,
-                       S, m.planes, accum);
+                       S, m.planes, accum, use_bins(S) ? m.bins : (int *)nullptr);
     // few blocks per image: every block ends in 22 double atomics on the image's accumulators, and 196 blocks x 22 on the
     // same addresses serialise in L2 (17.5 us for 0.2 M pixels; GENPC_MASK_SUMS_BLOCKS for A/B)
     static const int env_sb = getenv("GENPC_MASK_SUMS_BLOCKS") ? atoi(getenv("GENPC_MASK_SUMS_BLOCKS")) : 0;
@@ -1199,10 +1353,11 @@ GENPC_API int genpc_splat_image(int n, const float *pts, const float *col, float
     if (!ws) return 0;
     MaskScratch m;
     m.carve(ws, 1, P, n > 0 ? n : 1);
+    if (!m.zero_bins(st)) return 0;
     hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(n > 0 ? n : 1), 1), dim3(kQBlock), 0, st, n, pts, (const float *)nullptr, 0,
-                       (const float *)nullptr, 0, 0, radius, size, m.uvr);
+                       (const float *)nullptr, 0, 0, radius, size, m.uvr, use_bins(size) ? m.bins : (int *)nullptr);
     hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(size), 1), dim3(kSplatBlock), 0, st, n, (const float4 *)m.uvr, col, size,
-                       m.planes, (double *)nullptr);
+                       m.planes, (double *)nullptr, use_bins(size) ? m.bins : (int *)nullptr);
     hipLaunchKernelGGL(mask_image_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, (int)P, (const float *)m.planes, img);
     return check(hipGetLastError(), "splat_image launch") ? 1 : 0;
 }
@@ -1252,6 +1407,7 @@ GENPC_API int genpc_pose_loss_grad(int nc, const float *v, const float *vert_col
     PoseState *S = (PoseState *)(ws + o_state);
     MaskScratch m;
     m.carve(ws + o_mask, 1, P, nmax);
+    if (P && !m.zero_bins(st)) return 0;
     if (!check(hipMemsetAsync(accum, 0, kAcc * sizeof(double), st), "hipMemsetAsync(accum)")) return 0;
     if (!check(hipMemcpyAsync(S->params, params, 10 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy params"))
         return 0;
@@ -1346,6 +1502,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     int *i1 = (int *)(ws + o_i1), *i2 = (int *)(ws + o_i2);
     MaskScratch m = {};
     if (mask) m.carve(ws + o_mask, b, P, (size_t)(nc > np ? nc : np));
+    if (mask && !m.zero_bins(st)) return 0;
     constexpr int kStateFloats = (int)(sizeof(PoseState) / sizeof(float));
     static_assert(sizeof(PoseState) % sizeof(float) == 0, "PoseState must be float-addressable");
 
@@ -1364,7 +1521,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
             if (mask)
                 hipLaunchKernelGGL(pose_transform_project_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
                                    (const float *)center, 4, (const float *)S->params, kStateFloats, pts, 1.1f * radius, render_size,
-                                   m.uvr);
+                                   m.uvr, use_bins(render_size) ? m.bins : (int *)nullptr);
             else
                 hipLaunchKernelGGL(pose_transform_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
                                    (const float *)center, 4, (const float *)S->params, kStateFloats, pts);

@@ -161,6 +161,35 @@ def test_splat_image_vs_oracle(gp, oracle):
     assert float(gp["POSE"].splat_image(torch.zeros(0, 3).cuda(), 0.05, 32).abs().max()) == 0.0
 
 
+def test_splat_tile_lists_and_their_fallbacks(gp, oracle):
+    """The splat reads per-tile index lists the projection kernel fills (pose.hip bin_points_block).  The cases a list
+    cannot hold must give the same image through the full scan: a tile hit by more points than a list holds, discs
+    over more tiles than a point may be listed in, an image with more tiles than the block histogram, and a mixture
+    (a dense knot inside an ordinary cloud: crowded and ordinary tiles in one image)."""
+    torch = gp["torch"]
+    rng = np.random.default_rng(77)
+    _, partial, _ = _shape(6, 3000)
+    knot = (partial[:1] + 0.004 * rng.standard_normal((5000, 3))).astype(np.float32)
+    cases = (
+        ("crowded tile", knot, 0.01, 224),
+        ("knot in a cloud", np.concatenate([partial, knot]), 0.02, 224),
+        ("wide discs", partial[:600], 0.3, 224),
+        ("wide and narrow", np.concatenate([partial[:2000], partial[:1]]), 0.09, 160),
+        ("large image", partial, 0.02, 640),
+        ("one tile", partial[:500], 0.05, 16),
+    )
+    for name, pts, radius, size in cases:
+        col = _colours(rng, len(pts), 0.2)
+        for c in (None, col):
+            img = gp["POSE"].splat_image(torch.from_numpy(pts).cuda(), radius, size,
+                                         None if c is None else torch.from_numpy(c).cuda()).cpu().numpy()
+            ref = oracle.splat_image(pts, radius, size, c)
+            np.testing.assert_allclose(img, ref, atol=2e-4, err_msg=name)
+        # twice through the same scratch: the splat hands the counters back zeroed
+        again = gp["POSE"].splat_image(torch.from_numpy(pts).cuda(), radius, size, torch.from_numpy(col).cuda()).cpu().numpy()
+        np.testing.assert_allclose(again, img, atol=1e-6, err_msg=name)
+
+
 def test_full_loss_and_gradient_vs_oracle(gp, oracle):
     """compute_loss_function as a whole (mask + 3 cd + ortho): loss terms and the 10-vector
     gradient against the oracle (whose loss is pinned to the reference's own code and whose gradient
