@@ -122,18 +122,26 @@ __global__ __launch_bounds__(kIBlock) void icp_accum_kernel(int ns, const float 
     }
 }
 
+// Cyclic Jacobi on the symmetric 4x4.  Converged when the off-diagonal mass is rounding noise RELATIVE to the matrix
+// (an absolute threshold of 1e-300 is never met: a rotated-away element comes back as noise of size 1e-16 |A|, and all 30
+// sweeps ran -- 35 us per ICP pass in one lane, fp64 divisions and square roots; now 5-7 sweeps).
 __device__ void jacobi4(double A[4][4], double V[4][4])
 {
+    double norm2 = 0.0;
     for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+        for (int j = 0; j < 4; j++) {
+            V[i][j] = (i == j) ? 1.0 : 0.0;
+            norm2 += A[i][j] * A[i][j];
+        }
+    const double tiny2 = 1e-36 * norm2;          // an element below 1e-18 |A|: no bit of any eigenvector depends on it
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0.0;
         for (int i = 0; i < 4; i++)
             for (int j = i + 1; j < 4; j++) off += A[i][j] * A[i][j];
-        if (off < 1e-300) break;
+        if (!(off > tiny2)) break;
         for (int p = 0; p < 3; p++)
             for (int q = p + 1; q < 4; q++) {
-                if (fabs(A[p][q]) < 1e-300) continue;
+                if (!(A[p][q] * A[p][q] > tiny2)) continue;
                 const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
@@ -147,6 +155,7 @@ __device__ void jacobi4(double A[4][4], double V[4][4])
                     A[p][k] = c * apk - s * aqk;
                     A[q][k] = s * apk + c * aqk;
                 }
+                A[p][q] = A[q][p] = 0.0;          // (what the rotation was chosen for)
                 for (int k = 0; k < 4; k++) {
                     const double vkp = V[k][p], vkq = V[k][q];
                     V[k][p] = c * vkp - s * vkq;
