@@ -430,12 +430,46 @@ __device__ __forceinline__ SplatPt splat_project(const float *p, float radius, f
 // starts, 43 k ticks for an empty tile.)
 constexpr int kTileCap = 1024;
 constexpr int kBinTiles = 1024;          // tiles per image the block-level histogram holds (S <= 512); larger images: no bins
-constexpr int kBinPer = 4;               // tiles a point's disc may touch on this path (more: the image falls back to the full scan)
+constexpr int kBinPer = 4;               // tiles a listed disc may touch (entries carry the slot in two bits)
+
+// f(tile) for every tile the disc's bounding box touches, in (row, column) order -- mask_splat_kernel's test, verbatim
+template <class F>
+__device__ __forceinline__ void for_each_tile(int S, float u, float v, float rho, F f)
+{
+    const int T = (S + kMaskTile - 1) / kMaskTile;
+    int tx_lo = (int)floorf((u - rho) / (float)kMaskTile) - 1, tx_hi = (int)floorf((u + rho) / (float)kMaskTile) + 1;
+    int ty_lo = (int)floorf((v - rho) / (float)kMaskTile) - 1, ty_hi = (int)floorf((v + rho) / (float)kMaskTile) + 1;
+    tx_lo = tx_lo < 0 ? 0 : tx_lo; ty_lo = ty_lo < 0 ? 0 : ty_lo;
+    tx_hi = tx_hi > T - 1 ? T - 1 : tx_hi; ty_hi = ty_hi > T - 1 ? T - 1 : ty_hi;
+    for (int ty = ty_lo; ty <= ty_hi; ty++)
+        for (int tx = tx_lo; tx <= tx_hi; tx++) {
+            const int tx0 = tx * kMaskTile, ty0 = ty * kMaskTile;
+            const int tx1 = min(S, tx0 + kMaskTile) - 1, ty1 = min(S, ty0 + kMaskTile) - 1;
+            if (u + rho >= (float)tx0 && u - rho <= (float)(tx1 + 1) && v + rho >= (float)ty0 && v - rho <= (float)(ty1 + 1)) f(ty * T + tx);
+        }
+}
+
+// number of tiles a disc touches; slot = position of `tile` among them (-1: not touched)
+__device__ __forceinline__ int tile_count(int S, float u, float v, float rho, int tile, int &slot)
+{
+    int cnt = 0, sl = -1;
+    for_each_tile(S, u, v, rho, [&](int t) {
+        if (t == tile) sl = cnt;
+        cnt++;
+    });
+    slot = sl;
+    return cnt;
+}
+
+constexpr int kBinPoison = 1 << 30;      // set in a tile's counter by a disc that is in no list (over more than kBinPer tiles)
 
 // Block-level binning of one point per thread (all threads of the block call it; `valid`: this thread has a point):
 // the tile counts of the block's points are first accumulated in LDS, ONE global atomic per (block, tile) reserves the
-// block's range in the tile's list, then the threads write their indices.  (One global atomic per (point, tile) -- 144 k
-// per launch of four starts, 640 on the counter of a crowded tile -- made the 5 us projection kernel 50 us.)
+// block's range in the tile's list, then the threads write their entries: point index * 4 + slot, slot = the position
+// of the tile among the point's tiles (where the tile pass of the mask gradient leaves the point's partial sums).
+// (One global atomic per (point, tile) -- 144 k per launch of four starts, 640 on the counter of a crowded tile -- made
+// the 5 us projection kernel 50 us.)  A disc over more than kBinPer tiles is listed nowhere and poisons the counters of
+// its tiles: the splat draws those by the full scan, the mask gradient takes such a point by itself.
 __device__ __forceinline__ void bin_points_block(int *__restrict__ cnt, int *__restrict__ idx, int *s_cnt, int *s_base, int S, bool valid,
                                                  int j, float u, float v, float rho)
 {
@@ -443,51 +477,32 @@ __device__ __forceinline__ void bin_points_block(int *__restrict__ cnt, int *__r
     for (int t = threadIdx.x; t < tiles; t += blockDim.x) s_cnt[t] = 0;
     __syncthreads();
     int my_tile[kBinPer], my_pos[kBinPer], nmine = 0;
-    bool too_many = false;
     if (valid && rho > 0.0f) {
-        int tx_lo = (int)floorf((u - rho) / (float)kMaskTile) - 1, tx_hi = (int)floorf((u + rho) / (float)kMaskTile) + 1;
-        int ty_lo = (int)floorf((v - rho) / (float)kMaskTile) - 1, ty_hi = (int)floorf((v + rho) / (float)kMaskTile) + 1;
-        tx_lo = tx_lo < 0 ? 0 : tx_lo; ty_lo = ty_lo < 0 ? 0 : ty_lo;
-        tx_hi = tx_hi > T - 1 ? T - 1 : tx_hi; ty_hi = ty_hi > T - 1 ? T - 1 : ty_hi;
-        for (int ty = ty_lo; ty <= ty_hi; ty++)
-            for (int tx = tx_lo; tx <= tx_hi; tx++) {
-                const int tx0 = tx * kMaskTile, ty0 = ty * kMaskTile;
-                const int tx1 = min(S, tx0 + kMaskTile) - 1, ty1 = min(S, ty0 + kMaskTile) - 1;
-                // mask_splat_kernel's bounding-box test, verbatim
-                if (u + rho >= (float)tx0 && u - rho <= (float)(tx1 + 1) && v + rho >= (float)ty0 && v - rho <= (float)(ty1 + 1)) {
-                    if (nmine < kBinPer) {
-                        my_tile[nmine] = ty * T + tx;
-                        my_pos[nmine] = atomicAdd(&s_cnt[ty * T + tx], 1);
-                        nmine++;
-                    } else {
-                        too_many = true;
-                    }
+        int none;
+        const int total = tile_count(S, u, v, rho, -1, none);
+        if (total <= kBinPer) {
+            for_each_tile(S, u, v, rho, [&](int t) {
+                if (nmine < kBinPer) {      // (always: keeps the arrays in registers)
+                    my_tile[nmine] = t;
+                    my_pos[nmine] = atomicAdd(&s_cnt[t], 1);
+                    nmine++;
                 }
-            }
-    }
-    // a disc over more than kBinPer tiles: poison every counter it touches (count > kTileCap: those tiles take the full scan)
-    // (the loop is over the clamped tile range again)
-    if (too_many) {
-        const int T2 = T;
-        for (int ty = 0; ty < T2; ty++)
-            for (int tx = 0; tx < T2; tx++) {
-                const int tx0 = tx * kMaskTile, ty0 = ty * kMaskTile;
-                const int tx1 = min(S, tx0 + kMaskTile) - 1, ty1 = min(S, ty0 + kMaskTile) - 1;
-                if (u + rho >= (float)tx0 && u - rho <= (float)(tx1 + 1) && v + rho >= (float)ty0 && v - rho <= (float)(ty1 + 1))
-                    atomicOr(&cnt[ty * T + tx], 1 << 30);
-            }
+            });
+        } else {
+            for_each_tile(S, u, v, rho, [&](int t) { atomicOr(&cnt[t], kBinPoison); });
+        }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
         const int c = s_cnt[t];
-        s_base[t] = c ? atomicAdd(&cnt[t], c) : 0;
+        s_base[t] = c ? (atomicAdd(&cnt[t], c) & (kBinPoison - 1)) : 0;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kBinPer; k++) {
         if (k < nmine) {
             const int pos = s_base[my_tile[k]] + my_pos[k];
-            if (pos < kTileCap) idx[(size_t)my_tile[k] * kTileCap + pos] = j;
+            if (pos < kTileCap) idx[(size_t)my_tile[k] * kTileCap + pos] = j * 4 + k;
         }
     }
     __syncthreads();
@@ -608,7 +623,7 @@ __device__ __forceinline__ PxImg load_pixel(const float *__restrict__ pl, int P,
 __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const float4 *__restrict__ uvr,
                                                                  const float *__restrict__ col, int S,
                                                                  float *__restrict__ planes, double *__restrict__ accum,
-                                                                 int *__restrict__ bins)
+                                                                 int *__restrict__ bins, int keep_bins)
 {
     static_assert(kSplatBlock == 4 * kMaskTile * kMaskTile, "four threads per pixel of the tile");
     __shared__ float part[5][4][kMaskTile * kMaskTile];
@@ -649,7 +664,7 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
         static_assert(kTileCap <= kSplatBlock && kTileCap <= kSplatList, "one list entry per thread, one fill");
         const int L = binned, L4 = (L + 3) & ~3;
         int myj = 0x7fffffff;
-        if ((int)threadIdx.x < L) myj = bin_idx[threadIdx.x];
+        if ((int)threadIdx.x < L) myj = bin_idx[threadIdx.x] >> 2;
         if ((int)threadIdx.x < L4) s_sort[threadIdx.x] = myj;
         __syncthreads();
         if ((int)threadIdx.x < L) {
@@ -680,9 +695,9 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
             }
         }
     }
-    // (the count was read above by the threads of this block only: no barrier needed before it is reset for the next launch)
+    // the count is reset for the next launch by the last kernel that reads the lists: this one, or the mask gradient's tile pass
     __syncthreads();
-    if (bins && threadIdx.x == 0) bin_cnt[blockIdx.x] = 0;
+    if (bins && !keep_bins && threadIdx.x == 0) bin_cnt[blockIdx.x] = 0;
     for (int j0 = 0; j0 < n && !by_list; j0 += kSplatBlock * kSplatPer) {
         // the bounding-box tests keep only a bit per point (four points in flight at a time): the kernel must fit 64
         // VGPRs so that TWO 1024-thread blocks share a CU -- with all sixteen points of a thread in registers it needed
@@ -1097,6 +1112,97 @@ __global__ __launch_bounds__(kQBlock) void mask_w_kernel(int S, const float *__r
     }
 }
 
+// grid (tiles, b), the tile pass of the mask gradient: a tile's W planes in LDS, one thread per entry of the tile's list
+// (bins), the entry's point gathers the weights of its pixels INSIDE the tile and leaves the three sums in its slot of
+// gpart[e, j, kBinPer]; mask_grad_kernel adds a point's slots in order and chains to the pose.  (A thread per point
+// gathering its whole box from global memory was bound by the scattered 16-byte reads: 8 scans in lock-step 150 us, 45 us
+// with the same instructions on coalesced addresses.)  A tile whose list overflowed walks all points of the image.
+// Resets the tile's counter (the splat kept it for this pass).
+constexpr int kGradTileBlock = 1024;
+__global__ __launch_bounds__(kGradTileBlock) void mask_grad_tile_kernel(int n, const float4 *__restrict__ uvr, const float *__restrict__ col,
+                                                                       int S, const float *__restrict__ W1,
+                                                                       const float4 *__restrict__ W4, int *__restrict__ bins,
+                                                                       float4 *__restrict__ gpart)
+{
+    static_assert(kGradTileBlock >= kMaskTile * kMaskTile, "a thread per pixel for the load");
+    __shared__ float4 sW4[kMaskTile * kMaskTile];
+    __shared__ float sW1[kMaskTile * kMaskTile];
+    const int e = blockIdx.y, tile = blockIdx.x;
+    const int tiles_x = (S + kMaskTile - 1) / kMaskTile;
+    const int tx0 = (tile % tiles_x) * kMaskTile, ty0 = (tile / tiles_x) * kMaskTile;
+    const int tx1 = min(S, tx0 + kMaskTile) - 1, ty1 = min(S, ty0 + kMaskTile) - 1;
+    uvr += (size_t)e * n;
+    if (col) col += (size_t)e * n * 3;
+    W1 += (size_t)e * S * S;
+    W4 += (size_t)e * S * S;
+    gpart += (size_t)e * n * kBinPer;
+    int *bin_cnt = bins + (size_t)e * bins_tiles(S);
+    const int *bin_idx = bins + (size_t)gridDim.y * bins_tiles(S) + ((size_t)e * bins_tiles(S) + tile) * kTileCap;
+    if (threadIdx.x < kMaskTile * kMaskTile) {
+        const int px = tx0 + (threadIdx.x & (kMaskTile - 1)), py = ty0 + threadIdx.x / kMaskTile;
+        const bool in = px < S && py < S;
+        sW4[threadIdx.x] = in ? W4[(size_t)py * S + px] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        sW1[threadIdx.x] = in ? W1[(size_t)py * S + px] : 0.0f;
+    }
+    const int count = bin_cnt[tile] & (kBinPoison - 1);
+    __syncthreads();
+    // One thread per entry.  Once the weights come from LDS the gather is VALU-bound (40 instructions a pixel over a box of
+    // 81, and a wave runs the largest box of its lanes), so the walk is cut to the disc: rows whose chord is empty are
+    // skipped, a row is walked over its chord +- a pixel (the test on av below still decides), and 1 / (1 - av) is the
+    // hardware reciprocal (1 ulp; the oracle bar on the gradient is 2e-3).  Sixteen lanes per entry (a lane per row) was no
+    // faster (43.7 us against 44.7 for a thread per entry over the full box; this form 25.6).
+    auto gather = [&](int j, int slot, float4 q) {
+        const float u = q.x, v = q.y, rho = q.z, ir2 = q.w;
+        float cr = 1.0f, cg = 1.0f, cb = 1.0f;
+        if (col) { cr = col[(size_t)j * 3 + 0]; cg = col[(size_t)j * 3 + 1]; cb = col[(size_t)j * 3 + 2]; }
+        // the point's pixel box (mask_grad_kernel's), cut to the tile
+        const int c0 = max(max((int)floorf(u - rho - 0.5f), 0), tx0), c1 = min(min((int)ceilf(u + rho - 0.5f), S - 1), tx1);
+        const int r0 = max(max((int)floorf(v - rho - 0.5f), 0), ty0), r1 = min(min((int)ceilf(v + rho - 0.5f), S - 1), ty1);
+        const float rho2 = rho * rho;
+        float gu = 0.0f, gv = 0.0f, gr = 0.0f;
+        for (int r = r0; r <= r1; r++) {
+            const float dy = (float)r + 0.5f - v;
+            const float h2 = rho2 - dy * dy;
+            if (h2 < -1e-5f * rho2) continue;
+            const float h = sqrtf(fmaxf(h2, 0.0f));
+            const int ca = max((int)floorf(u - h - 0.5f), c0), cz = min((int)ceilf(u + h - 0.5f), c1);
+            const float dy2 = dy * dy;
+            const float4 *rw4 = sW4 + (r - ty0) * kMaskTile - tx0;
+            const float *rw1 = sW1 + (r - ty0) * kMaskTile - tx0;
+            // (the loads behind the test: a branch-free form -- loads first, a selected 0 for pixels outside the disc, two
+            // pixels a trip -- was slower, 25.6 -> 30.9 us)
+            for (int cc = ca; cc <= cz; cc++) {
+                const float dx = (float)cc + 0.5f - u;
+                const float d2 = dx * dx + dy2;
+                const float av = 1.0f - d2 * ir2;
+                if (av <= 0.0f || av >= kMaskAmax) continue;      // outside the disc / clamped: no gradient
+                const float4 w4 = rw4[cc];
+                const float w = rw1[cc] * __builtin_amdgcn_rcpf(1.0f - av) + ((cr * w4.x + cg * w4.y) + (cb * w4.z - w4.w));
+                gu += w * dx;
+                gv += w * dy;
+                gr += w * d2;
+            }
+        }
+        gpart[(size_t)j * kBinPer + slot] = make_float4(gu, gv, gr, 0.0f);
+    };
+    if (count <= kTileCap) {
+        for (int i = threadIdx.x; i < count; i += kGradTileBlock) {
+            const int ent = bin_idx[i];
+            gather(ent >> 2, ent & 3, uvr[ent >> 2]);
+        }
+    } else {
+        for (int j = threadIdx.x; j < n; j += kGradTileBlock) {
+            const float4 q = uvr[j];
+            if (!(q.z > 0.0f)) continue;
+            int slot;
+            const int total = tile_count(S, q.x, q.y, q.z, tile, slot);
+            if (slot >= 0 && total <= kBinPer) gather(j, slot, q);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) bin_cnt[tile] = 0;
+}
+
 // grid (blocks, b): gradient of the mask term with respect to (R, s, t), into accum[0..12].
 template <int kGradSub>
 __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *__restrict__ v,
@@ -1104,7 +1210,8 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
                                                             const float *__restrict__ center, int cstride,
                                                             const float *__restrict__ params, int pstride, float radius,
                                                             int S, const float *__restrict__ W1,
-                                                            const float4 *__restrict__ W4, double *__restrict__ accum)
+                                                            const float4 *__restrict__ W4, double *__restrict__ accum,
+                                                            const float4 *__restrict__ gpart)
 {
     __shared__ double red[13][kQBlock / kWave];
     const int e = blockIdx.y;
@@ -1112,6 +1219,7 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
     if (col) col += (size_t)e * n * 3;
     W1 += (size_t)e * S * S;
     W4 += (size_t)e * S * S;
+    if (gpart) gpart += (size_t)e * n * kBinPer;
     center += (size_t)e * cstride;
     params += (size_t)e * pstride;
     accum += (size_t)e * kAcc;
@@ -1145,7 +1253,19 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
         const int r0 = max((int)floorf(q.v - q.rho - 0.5f), 0), r1 = min((int)ceilf(q.v + q.rho - 0.5f), S - 1);
         const float ir2 = 1.0f / (q.rho * q.rho);
         float gu = 0.0f, gv = 0.0f, gr = 0.0f;
-        if (ok) {
+        // after the tile pass (gpart): the sums of a point over at most kBinPer tiles lie in its slots; a wider disc was
+        // left out there and gathers its box here
+        int ntile = kBinPer + 1;
+        if (kGradSub == 1 && gpart && ok) {
+            int none;
+            ntile = tile_count(S, q.u, q.v, q.rho, -1, none);
+            if (ntile <= kBinPer)
+                for (int k = 0; k < ntile; k++) {
+                    const float4 g = gpart[(size_t)j * kBinPer + k];
+                    gu += g.x; gv += g.y; gr += g.z;
+                }
+        }
+        if (ok && ntile > kBinPer) {
             for (int r = r0 + sub; r <= r1; r += kGradSub) {
                 const float dy = (float)r + 0.5f - q.v;
                 for (int cc = c0; cc <= c1; cc++) {
@@ -1273,7 +1393,8 @@ struct MaskScratch {
     float *W1;         // [b, P]
     float4 *W4;        // [b, P]
     float4 *uvr;       // [b, nmax]
-    int *bins;         // [b, tiles] counts | [b, tiles, kTileCap] point indices (bin_point)
+    int *bins;         // [b, tiles] counts | [b, tiles, kTileCap] entries (bin_points_block)
+    float4 *gpart;     // [b, nmax, kBinPer] per-tile sums of the mask gradient (mask_grad_tile_kernel)
     size_t bins_count_bytes;
     static size_t up(size_t x) { return (x + 255) / 256 * 256; }
     static size_t side(size_t P) { size_t S = (size_t)sqrt((double)P); while (S * S < P) S++; return S; }
@@ -1281,7 +1402,7 @@ struct MaskScratch {
     static size_t bytes(int b, size_t P, size_t nmax)
     {
         return up((size_t)b * 8 * 4) + up((size_t)b * P * 4) + up((size_t)b * 5 * P * 4) + up((size_t)b * P * 4) +
-               up((size_t)b * P * 16) + up((size_t)b * nmax * 16) + up(bins_bytes(b, P));
+               up((size_t)b * P * 16) + up((size_t)b * nmax * 16) + up(bins_bytes(b, P)) + up((size_t)b * nmax * kBinPer * 16);
     }
     void carve(char *base, int b, size_t P, size_t nmax)
     {
@@ -1292,7 +1413,8 @@ struct MaskScratch {
         W1 = (float *)(base + off); off += up((size_t)b * P * 4);
         W4 = (float4 *)(base + off); off += up((size_t)b * P * 16);
         uvr = (float4 *)(base + off); off += up((size_t)b * nmax * 16);
-        bins = (int *)(base + off);
+        bins = (int *)(base + off); off += up(bins_bytes(b, P));
+        gpart = (float4 *)(base + off);
         bins_count_bytes = (size_t)b * bins_tiles((int)side(P)) * sizeof(int);
     }
     // the tile counters are zero between launches (the splat kernel resets what it reads); once per API call for a
@@ -1307,7 +1429,7 @@ static int mask_prepare_ref(int b, int np, const float *partial, const float *pa
     hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(np), b), dim3(kQBlock), 0, st, np, partial, (const float *)nullptr, 0,
                        (const float *)nullptr, 0, 0, radius, S, m.uvr, use_bins(S) ? m.bins : (int *)nullptr);
     hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, np, (const float4 *)m.uvr, partial_col,
-                       S, m.planes, (double *)nullptr, use_bins(S) ? m.bins : (int *)nullptr);
+                       S, m.planes, (double *)nullptr, use_bins(S) ? m.bins : (int *)nullptr, 0);
     hipLaunchKernelGGL(mask_ref_kernel, dim3(b), dim3(kMLThreads), 0, st, S, (const float *)m.planes, 0, m.mref, m.stats);
     return check(hipGetLastError(), "mask reference launch") ? 1 : 0;
 }
@@ -1319,11 +1441,17 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
 {
     const float rad = 1.1f * radius;      // diff_obj_pose.py:385: the posed cloud is drawn with 1.1 x the radius
     const int gp = lin_grid((long long)S * S);
+    // The mask gradient per tile from LDS (mask_grad_tile_kernel + the per-point sum) or per point from global memory
+    // (mask_grad_kernel alone).  Measured at 16384 points per image, 224 x 224: 4 images (one scan's four starts, the W
+    // planes stay in L2) 25.6 + 8.2 us against 29.3; 32 images (8 scans in lock-step: 32 MB of W planes through every 4 MB
+    // L2, the scattered 16-byte reads cost 105 of the per-point kernel's 150 us) 107 + 21 against 150-168.
+    static const int env_tp = getenv("GENPC_MASK_GRAD_TILES") ? atoi(getenv("GENPC_MASK_GRAD_TILES")) : -1;
+    const bool tile_pass = use_bins(S) && (env_tp >= 0 ? env_tp != 0 : b > 4);
     if (!projected)      // (the alignment loop projects in its transform launch)
         hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride, params,
                            pstride, 1, rad, S, m.uvr, use_bins(S) ? m.bins : (int *)nullptr);
     hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, nc, (const float4 *)m.uvr, complete_col,
-                       S, m.planes, accum, use_bins(S) ? m.bins : (int *)nullptr);
+                       S, m.planes, accum, use_bins(S) ? m.bins : (int *)nullptr, tile_pass ? 1 : 0);
     // few blocks per image: every block ends in 22 double atomics on the image's accumulators, and 196 blocks x 22 on the
     // same addresses serialise in L2 (17.5 us for 0.2 M pixels; GENPC_MASK_SUMS_BLOCKS for A/B)
     static const int env_sb = getenv("GENPC_MASK_SUMS_BLOCKS") ? atoi(getenv("GENPC_MASK_SUMS_BLOCKS")) : 0;
@@ -1332,12 +1460,21 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
                        (const float *)m.stats, accum);
     hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, 0, (const float *)m.mref,
                        (const float *)m.stats, mask_weight, m.W1, m.W4, accum);
-    if (b <= 2)      // (measured at 4 x 16384 points, the four starts in lock-step: <1> 35 us, <8> 42)
-        hipLaunchKernelGGL((mask_grad_kernel<8>), dim3(lin_grid((long long)nc * 8), b), dim3(kQBlock), 0, st, nc, complete,
-                           complete_col, center, cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum);
-    else
+    if (tile_pass) {
+        hipLaunchKernelGGL(mask_grad_tile_kernel, dim3(mask_tiles(S), b), dim3(kGradTileBlock), 0, st, nc, (const float4 *)m.uvr,
+                           complete_col, S, (const float *)m.W1, (const float4 *)m.W4, m.bins, m.gpart);
         hipLaunchKernelGGL((mask_grad_kernel<1>), dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, complete_col, center,
-                           cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum);
+                           cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum,
+                           (const float4 *)m.gpart);
+    } else if (b <= 2) {     // (measured at 4 x 16384 points, the four starts in lock-step: <1> 35 us, <8> 42)
+        hipLaunchKernelGGL((mask_grad_kernel<8>), dim3(lin_grid((long long)nc * 8), b), dim3(kQBlock), 0, st, nc, complete,
+                           complete_col, center, cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum,
+                           (const float4 *)nullptr);
+    } else {
+        hipLaunchKernelGGL((mask_grad_kernel<1>), dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, complete_col, center,
+                           cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum,
+                           (const float4 *)nullptr);
+    }
     return check(hipGetLastError(), "mask step launch") ? 1 : 0;
 }
 
@@ -1357,7 +1494,7 @@ GENPC_API int genpc_splat_image(int n, const float *pts, const float *col, float
     hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(n > 0 ? n : 1), 1), dim3(kQBlock), 0, st, n, pts, (const float *)nullptr, 0,
                        (const float *)nullptr, 0, 0, radius, size, m.uvr, use_bins(size) ? m.bins : (int *)nullptr);
     hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(size), 1), dim3(kSplatBlock), 0, st, n, (const float4 *)m.uvr, col, size,
-                       m.planes, (double *)nullptr, use_bins(size) ? m.bins : (int *)nullptr);
+                       m.planes, (double *)nullptr, use_bins(size) ? m.bins : (int *)nullptr, 0);
     hipLaunchKernelGGL(mask_image_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, (int)P, (const float *)m.planes, img);
     return check(hipGetLastError(), "splat_image launch") ? 1 : 0;
 }

@@ -5,6 +5,7 @@ ulp (device expf vs libm expf); pose gradient 1e-4 relative (fp64 reductions in 
 different order); the optimisation loop by outcome (same basin, transform within
 1e-2, loss history within 2 %)."""
 import math
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -188,6 +189,55 @@ def test_splat_tile_lists_and_their_fallbacks(gp, oracle):
         # twice through the same scratch: the splat hands the counters back zeroed
         again = gp["POSE"].splat_image(torch.from_numpy(pts).cuda(), radius, size, torch.from_numpy(col).cuda()).cpu().numpy()
         np.testing.assert_allclose(again, img, atol=1e-6, err_msg=name)
+
+
+def test_mask_gradient_tile_pass_and_its_fallbacks(gp, oracle):
+    """The mask gradient is gathered per tile from the splat's lists (pose.hip mask_grad_tile_kernel) and summed per
+    point; a tile whose list overflowed walks all points, a disc over more than four tiles gathers its own box, an image
+    of more than 1024 tiles has no lists.  Each against the oracle's full loss and gradient."""
+    torch = gp["torch"]
+    if os.environ.get("GENPC_MASK_GRAD_TILES") != "1":
+        # the library takes the tile pass from five images on and reads the switch once per process: this test and the
+        # full-objective test again in a process that forces it for a single image
+        import subprocess
+        import sys
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
+                            "tile_pass_and_its_fallbacks or full_loss_and_gradient_vs_oracle or dark_points"],
+                           env=dict(os.environ, GENPC_MASK_GRAD_TILES="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    rng = np.random.default_rng(5)
+    complete, partial, _ = _shape(4, 2500)
+    knot = (complete[:1] + 0.004 * rng.standard_normal((3000, 3))).astype(np.float32)
+    params = np.array([0.95, 0.05, -0.2, 0.02, 1.05, 0.1, 0.01, -0.02, 0.02, math.log(0.85)], np.float32)
+    cases = (
+        ("crowded tile", np.concatenate([complete, knot]), 0.02, 224),
+        ("wide discs", complete[:800], 0.12, 160),
+        ("wide and narrow tiles", complete, 0.06, 224),
+        ("large image", complete, 0.02, 544),
+        ("one tile", complete[:400], 0.05, 16),
+    )
+    for name, comp, radius, size in cases:
+        c = comp.astype(np.float64).mean(0).astype(np.float32)
+        ccol, pcol = _colours(rng, len(comp), 0.25), _colours(rng, len(partial))
+        for vc, pc in ((None, None), (ccol, pcol)):
+            loss, grad = gp["POSE"].pose_loss_grad(torch.from_numpy(comp).cuda(), torch.from_numpy(c).cuda(), torch.from_numpy(params).cuda(),
+                                                   torch.from_numpy(partial).cuda(), radius, size,
+                                                   vert_col=None if vc is None else torch.from_numpy(vc).cuda(),
+                                                   partial_col=None if pc is None else torch.from_numpy(pc).cuda())
+            opts = oracle.pose_transform(comp, c, params)
+            d1, d2, i1, i2 = oracle.chamfer_forward(opts[None], partial[None], 1)
+            ref = oracle.splat_image(partial, radius, size, pc)
+            lo, g = oracle.pose_full_loss_grad(comp, c, params, partial, d1[0], i1[0], d2[0], i2[0], radius, size, ref, vert_col=vc)
+            np.testing.assert_allclose(loss.cpu().numpy(), lo, rtol=2e-4, atol=1e-5, err_msg=name)
+            gg, go = grad.cpu().numpy().astype(np.float64), g.astype(np.float64)
+            for sl in (slice(0, 6), slice(6, 9), slice(9, 10)):
+                assert np.abs(gg[sl] - go[sl]).max() <= 2e-3 * np.abs(go[sl]).max() + 1e-6, (name, sl, gg[sl], go[sl])
+            # a second call through the same scratch: the lists were handed back empty
+            loss2, grad2 = gp["POSE"].pose_loss_grad(torch.from_numpy(comp).cuda(), torch.from_numpy(c).cuda(), torch.from_numpy(params).cuda(),
+                                                     torch.from_numpy(partial).cuda(), radius, size,
+                                                     vert_col=None if vc is None else torch.from_numpy(vc).cuda(),
+                                                     partial_col=None if pc is None else torch.from_numpy(pc).cuda())
+            assert torch.equal(loss, loss2) and torch.equal(grad, grad2), name
 
 
 def test_full_loss_and_gradient_vs_oracle(gp, oracle):
