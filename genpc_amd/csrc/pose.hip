@@ -429,6 +429,8 @@ __device__ __forceinline__ SplatPt splat_project(const float *p, float radius, f
 // full scan.  (Every block used to read all projected points of its image: 205 MB of L2 reads per launch of four
 // starts, 43 k ticks for an empty tile.)
 constexpr int kTileCap = 1024;
+constexpr int kRankWords = 2048;         // bitmap ranks in the splat: images of up to 65536 points
+constexpr int kRankByCount = 256;        // lists up to this length are ranked by counting
 constexpr int kBinTiles = 1024;          // tiles per image the block-level histogram holds (S <= 512); larger images: no bins
 constexpr int kBinPer = 4;               // tiles a listed disc may touch (entries carry the slot in two bits)
 
@@ -655,32 +657,117 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     // summation order of the gather -- by counting ranks, the entries fetched, and the full scan below is skipped.  A tile
     // whose list overflowed (or a launch without bins) takes the full scan.
     __shared__ __attribute__((aligned(16))) int s_sort[kTileCap];
+    __shared__ unsigned char s_mask[kTileCap];
+    __shared__ unsigned s_bits[kRankWords];
+    __shared__ unsigned short s_pref[kRankWords];
+    __shared__ unsigned short s_strip[4][kTileCap];
+    __shared__ int s_wc[kSplatBlock / kWave][4], s_stot[4];
+    static_assert(kMaskTile == 16 && kSplatBlock / kWave == 16, "a wave = four rows of the tile, four shares");
     int binned = -1;
     int *bin_cnt = bins ? bins + (size_t)e * bins_tiles(S) : nullptr;
     const int *bin_idx = bins ? bins + (size_t)gridDim.y * bins_tiles(S) + ((size_t)e * bins_tiles(S) + blockIdx.x) * kTileCap : nullptr;
-    if (bins) binned = bin_cnt[blockIdx.x];
+    int my_ent = 0;
+    if (bins) {
+        binned = bin_cnt[blockIdx.x];
+        if (threadIdx.x < kTileCap) my_ent = bin_idx[threadIdx.x];      // (before the count is known: one round trip, not two)
+    }
     const bool by_list = binned >= 0 && binned <= kTileCap;
     if (by_list && binned > 0) {
         static_assert(kTileCap <= kSplatBlock && kTileCap <= kSplatList, "one list entry per thread, one fill");
         const int L = binned, L4 = (L + 3) & ~3;
-        int myj = 0x7fffffff;
-        if ((int)threadIdx.x < L) myj = bin_idx[threadIdx.x] >> 2;
-        if ((int)threadIdx.x < L4) s_sort[threadIdx.x] = myj;
-        __syncthreads();
-        if ((int)threadIdx.x < L) {
-            int rank = 0;
-            for (int k = 0; k < L4; k += 4) {
-                const int4 o = *(const int4 *)&s_sort[k];
-                rank += (o.x < myj) + (o.y < myj) + (o.z < myj) + (o.w < myj);
+        const int myj = (int)threadIdx.x < L ? my_ent >> 2 : 0x7fffffff;
+        int rank = 0;
+        if (L > kRankByCount && n <= 32 * kRankWords) {
+            // a long list: rank = number of set bits below the point's own in a bitmap of the image's points (the
+            // counting below is O(L^2): 40 of the launch's 220 us with 32 images, in the crowded tiles)
+            const int words = (n + 31) >> 5;
+            for (int w = threadIdx.x; w < words; w += kSplatBlock) s_bits[w] = 0u;
+            __syncthreads();
+            if ((int)threadIdx.x < L) atomicOr(&s_bits[myj >> 5], 1u << (myj & 31));
+            __syncthreads();
+            // exclusive prefix of the words' popcounts: kRankWords / kSplatBlock consecutive words per thread
+            constexpr int kWPT = kRankWords / kSplatBlock;
+            int c[kWPT], tot = 0;
+#pragma unroll
+            for (int q = 0; q < kWPT; q++) {
+                const int w = threadIdx.x * kWPT + q;
+                c[q] = w < words ? __popc(s_bits[w]) : 0;
+                tot += c[q];
             }
+            int incl = tot;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const int o = __shfl_up(incl, off, kWave);
+                incl += lane >= off ? o : 0;
+            }
+            if (lane == kWave - 1) s_wc[wave][0] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < wave; w++) base += s_wc[w][0];
+            int run = base + incl - tot;
+#pragma unroll
+            for (int q = 0; q < kWPT; q++) {
+                const int w = threadIdx.x * kWPT + q;
+                if (w < words) s_pref[w] = (unsigned short)run;
+                run += c[q];
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < L) rank = s_pref[myj >> 5] + __popc(s_bits[myj >> 5] & ((1u << (myj & 31)) - 1u));
+        } else {
+            if ((int)threadIdx.x < L4) s_sort[threadIdx.x] = myj;
+            __syncthreads();
+            if ((int)threadIdx.x < L) {
+                for (int k = 0; k < L4; k += 4) {
+                    const int4 o = *(const int4 *)&s_sort[k];
+                    rank += (o.x < myj) + (o.y < myj) + (o.z < myj) + (o.w < myj);
+                }
+            }
+        }
+        if ((int)threadIdx.x < L) {
             const float4 qh = uvr[myj];
             float cr = 1.0f, cg = 1.0f, cb = 1.0f;
             if (col) { cr = col[(size_t)myj * 3 + 0]; cg = col[(size_t)myj * 3 + 1]; cb = col[(size_t)myj * 3 + 2]; }
             list[rank] = make_float4(qh.x, qh.y, qh.w, cr);
             list_gb[rank] = make_float2(cg, cb);
+            // the strips (four rows of the tile = the 64 pixels of one wave) the disc can reach
+            unsigned m = 0;
+#pragma unroll
+            for (int st = 0; st < 4; st++)
+                if (qh.y + qh.z >= (float)(ty0 + 4 * st) && qh.y - qh.z <= (float)(ty0 + 4 * st + 4)) m |= 1u << st;
+            s_mask[rank] = (unsigned char)m;
         }
         __syncthreads();
-        for (int k = share; k < L; k += 4) {
+        // Per-strip sublists of the sorted list, in its order: a wave walks the discs that can reach its four rows only
+        // (about half of the tile's).  Ballot ranks inside a wave, a 16 x 4 table of wave counts, its prefix by four threads.
+        {
+            const unsigned m = (int)threadIdx.x < L ? s_mask[threadIdx.x] : 0u;
+            int pre[4];
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const unsigned long long bl = __ballot((m >> st) & 1u);
+                pre[st] = __popcll(bl & ((1ull << lane) - 1ull));
+                if (lane == 0) s_wc[wave][st] = __popcll(bl);
+            }
+            __syncthreads();
+            if (threadIdx.x < 4) {
+                int run = 0;
+                for (int w = 0; w < kSplatBlock / kWave; w++) {
+                    const int c = s_wc[w][threadIdx.x];
+                    s_wc[w][threadIdx.x] = run;
+                    run += c;
+                }
+                s_stot[threadIdx.x] = run;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int st = 0; st < 4; st++)
+                if ((m >> st) & 1u) s_strip[st][s_wc[wave][st] + pre[st]] = (unsigned short)threadIdx.x;
+            __syncthreads();
+        }
+        const int strip = wave & 3;      // (pix = tid & 255: wave w holds rows 4 (w & 3) .. + 3, share w >> 2)
+        const int LS = s_stot[strip];
+        for (int k2 = share; k2 < LS; k2 += 4) {
+            const int k = s_strip[strip][k2];
             const float4 p = list[k];
             const float dx = pxc - p.x, dy = pyc - p.y;
             const float a = 1.0f - (dx * dx + dy * dy) * p.z;

@@ -178,6 +178,7 @@ def test_splat_tile_lists_and_their_fallbacks(gp, oracle):
         ("wide and narrow", np.concatenate([partial[:2000], partial[:1]]), 0.09, 160),
         ("large image", partial, 0.02, 640),
         ("one tile", partial[:500], 0.05, 16),
+        ("long lists (bitmap ranks)", _shape(8, 12000)[0], 0.008, 96),
     )
     for name, pts, radius, size in cases:
         col = _colours(rng, len(pts), 0.2)
