@@ -889,9 +889,9 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
             float w[5];
             // plane 0 is the transmittance T = prod (1 - a) itself (round 2 accumulated log(1 - a) per covering disc and
             // took exp(L) wherever the plane was read: the logarithm was a third of the gather's instructions, and the
-            // gather is what the kernel's time is -- 33 M pixel-disc tests per step of four starts).  (Sorting the list
-            // entries into per-strip index lists so that a wave walks only discs reaching its four rows halves the trips
-            // but costs three more barriers per fill: 42.0 -> 44.3 ms per call, not kept.)
+            // gather is what the kernel's time is -- 33 M pixel-disc tests per step of four starts).  (Per-strip index lists -- a
+            // wave walks only the discs reaching its four rows -- cost three more barriers per FILL of the full scan: 42.0 ->
+            // 44.3 ms per call there; the list path above builds them once per tile and keeps them.)
             w[0] = (part[0][0][pix] * part[0][1][pix]) * (part[0][2][pix] * part[0][3][pix]);
             planes[(size_t)r * S + cc] = w[0];
 #pragma unroll
