@@ -425,10 +425,11 @@ __device__ __forceinline__ SplatPt splat_project(const float *p, float radius, f
 // posed != 0: v is the complete cloud and is posed with params first.
 // Per-tile index lists (filled by the projection kernels, read and reset by mask_splat_kernel): bins = { count[b][tiles],
 // idx[b][tiles][kTileCap] }.  A point goes to every tile its disc's bounding box touches -- THE test of the splat kernel, so
-// a tile's list is exactly its hit set; a tile with more than kTileCap hits (the count keeps counting) is drawn by the
+// a tile's list is exactly its hit set; a tile with more than kSplatCap hits (the count keeps counting) is drawn by the
 // full scan.  (Every block used to read all projected points of its image: 205 MB of L2 reads per launch of four
 // starts, 43 k ticks for an empty tile.)
-constexpr int kTileCap = 1024;
+constexpr int kTileCap = 4096;            // entries a tile's list holds (the mask gradient's tile pass reads them all)
+constexpr int kSplatCap = 1024;          // the splat takes lists up to this length (one entry per thread, one fill)
 constexpr int kRankWords = 2048;         // bitmap ranks in the splat: images of up to 65536 points
 constexpr int kRankByCount = 256;        // lists up to this length are ranked by counting
 constexpr int kBinTiles = 1024;          // tiles per image the block-level histogram holds (S <= 512); larger images: no bins
@@ -656,11 +657,11 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     // The tile's own list (bins, filled by the projection kernel): its indices are put in ascending order -- the fixed
     // summation order of the gather -- by counting ranks, the entries fetched, and the full scan below is skipped.  A tile
     // whose list overflowed (or a launch without bins) takes the full scan.
-    __shared__ __attribute__((aligned(16))) int s_sort[kTileCap];
-    __shared__ unsigned char s_mask[kTileCap];
+    __shared__ __attribute__((aligned(16))) int s_sort[kSplatCap];
+    __shared__ unsigned char s_mask[kSplatCap];
     __shared__ unsigned s_bits[kRankWords];
     __shared__ unsigned short s_pref[kRankWords];
-    __shared__ unsigned short s_strip[4][kTileCap];
+    __shared__ unsigned short s_strip[4][kSplatCap];
     __shared__ int s_wc[kSplatBlock / kWave][4], s_stot[4];
     static_assert(kMaskTile == 16 && kSplatBlock / kWave == 16, "a wave = four rows of the tile, four shares");
     int binned = -1;
@@ -669,21 +670,24 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     int my_ent = 0;
     if (bins) {
         binned = bin_cnt[blockIdx.x];
-        if (threadIdx.x < kTileCap) my_ent = bin_idx[threadIdx.x];      // (before the count is known: one round trip, not two)
+        if (threadIdx.x < kSplatCap) my_ent = bin_idx[threadIdx.x];      // (before the count is known: one round trip, not two)
     }
-    const bool by_list = binned >= 0 && binned <= kTileCap;
+    const bool by_list = binned >= 0 && (binned <= kSplatCap || (binned <= kTileCap && n <= 32 * kRankWords));
     if (by_list && binned > 0) {
-        static_assert(kTileCap <= kSplatBlock && kTileCap <= kSplatList, "one list entry per thread, one fill");
+        static_assert(kSplatCap <= kSplatBlock && kSplatCap <= kSplatList && kSplatCap <= kTileCap, "one list entry per thread and fill");
         const int L = binned, L4 = (L + 3) & ~3;
-        const int myj = (int)threadIdx.x < L ? my_ent >> 2 : 0x7fffffff;
-        int rank = 0;
-        if (L > kRankByCount && n <= 32 * kRankWords) {
+        const bool bitmap = L > kRankByCount && n <= 32 * kRankWords;      // (by_list: L <= kSplatCap otherwise)
+        int rank0 = 0;      // counting path: the rank of this thread's (only) entry
+        if (bitmap) {
             // a long list: rank = number of set bits below the point's own in a bitmap of the image's points (the
             // counting below is O(L^2): 40 of the launch's 220 us with 32 images, in the crowded tiles)
             const int words = (n + 31) >> 5;
             for (int w = threadIdx.x; w < words; w += kSplatBlock) s_bits[w] = 0u;
             __syncthreads();
-            if ((int)threadIdx.x < L) atomicOr(&s_bits[myj >> 5], 1u << (myj & 31));
+            for (int i = threadIdx.x; i < L; i += kSplatBlock) {
+                const int j = (i < kSplatCap ? my_ent : bin_idx[i]) >> 2;
+                atomicOr(&s_bits[j >> 5], 1u << (j & 31));
+            }
             __syncthreads();
             // exclusive prefix of the words' popcounts: kRankWords / kSplatBlock consecutive words per thread
             constexpr int kWPT = kRankWords / kSplatBlock;
@@ -711,74 +715,81 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
                 if (w < words) s_pref[w] = (unsigned short)run;
                 run += c[q];
             }
-            __syncthreads();
-            if ((int)threadIdx.x < L) rank = s_pref[myj >> 5] + __popc(s_bits[myj >> 5] & ((1u << (myj & 31)) - 1u));
         } else {
+            const int myj = (int)threadIdx.x < L ? my_ent >> 2 : 0x7fffffff;
             if ((int)threadIdx.x < L4) s_sort[threadIdx.x] = myj;
             __syncthreads();
             if ((int)threadIdx.x < L) {
                 for (int k = 0; k < L4; k += 4) {
                     const int4 o = *(const int4 *)&s_sort[k];
-                    rank += (o.x < myj) + (o.y < myj) + (o.z < myj) + (o.w < myj);
+                    rank0 += (o.x < myj) + (o.y < myj) + (o.z < myj) + (o.w < myj);
                 }
             }
         }
-        if ((int)threadIdx.x < L) {
-            const float4 qh = uvr[myj];
-            float cr = 1.0f, cg = 1.0f, cb = 1.0f;
-            if (col) { cr = col[(size_t)myj * 3 + 0]; cg = col[(size_t)myj * 3 + 1]; cb = col[(size_t)myj * 3 + 2]; }
-            list[rank] = make_float4(qh.x, qh.y, qh.w, cr);
-            list_gb[rank] = make_float2(cg, cb);
-            // the strips (four rows of the tile = the 64 pixels of one wave) the disc can reach
-            unsigned m = 0;
+        // the sorted list is drawn kSplatCap entries at a time (one fill, unless the tile is crowded beyond that)
+        for (int f0 = 0; f0 < L; f0 += kSplatCap) {
+            __syncthreads();      // ranks ready / the previous fill's gather is done with the list
+            const int Lf = min(kSplatCap, L - f0);
+            for (int i = threadIdx.x; i < L; i += kSplatBlock) {
+                const int myj = (i < kSplatCap ? my_ent : bin_idx[i]) >> 2;
+                const int rank = (bitmap ? s_pref[myj >> 5] + __popc(s_bits[myj >> 5] & ((1u << (myj & 31)) - 1u)) : rank0) - f0;
+                if (rank < 0 || rank >= Lf) continue;
+                const float4 qh = uvr[myj];
+                float cr = 1.0f, cg = 1.0f, cb = 1.0f;
+                if (col) { cr = col[(size_t)myj * 3 + 0]; cg = col[(size_t)myj * 3 + 1]; cb = col[(size_t)myj * 3 + 2]; }
+                list[rank] = make_float4(qh.x, qh.y, qh.w, cr);
+                list_gb[rank] = make_float2(cg, cb);
+                // the strips (four rows of the tile = the 64 pixels of one wave) the disc can reach
+                unsigned m = 0;
 #pragma unroll
-            for (int st = 0; st < 4; st++)
-                if (qh.y + qh.z >= (float)(ty0 + 4 * st) && qh.y - qh.z <= (float)(ty0 + 4 * st + 4)) m |= 1u << st;
-            s_mask[rank] = (unsigned char)m;
-        }
-        __syncthreads();
-        // Per-strip sublists of the sorted list, in its order: a wave walks the discs that can reach its four rows only
-        // (about half of the tile's).  Ballot ranks inside a wave, a 16 x 4 table of wave counts, its prefix by four threads.
-        {
-            const unsigned m = (int)threadIdx.x < L ? s_mask[threadIdx.x] : 0u;
-            int pre[4];
-#pragma unroll
-            for (int st = 0; st < 4; st++) {
-                const unsigned long long bl = __ballot((m >> st) & 1u);
-                pre[st] = __popcll(bl & ((1ull << lane) - 1ull));
-                if (lane == 0) s_wc[wave][st] = __popcll(bl);
+                for (int st = 0; st < 4; st++)
+                    if (qh.y + qh.z >= (float)(ty0 + 4 * st) && qh.y - qh.z <= (float)(ty0 + 4 * st + 4)) m |= 1u << st;
+                s_mask[rank] = (unsigned char)m;
             }
             __syncthreads();
-            if (threadIdx.x < 4) {
-                int run = 0;
-                for (int w = 0; w < kSplatBlock / kWave; w++) {
-                    const int c = s_wc[w][threadIdx.x];
-                    s_wc[w][threadIdx.x] = run;
-                    run += c;
+            // Per-strip sublists of the sorted list, in its order: a wave walks the discs that can reach its four rows only
+            // (about half of the tile's).  Ballot ranks inside a wave, a 16 x 4 table of wave counts, its prefix by four threads.
+            {
+                const unsigned m = (int)threadIdx.x < Lf ? s_mask[threadIdx.x] : 0u;
+                int pre[4];
+#pragma unroll
+                for (int st = 0; st < 4; st++) {
+                    const unsigned long long bl = __ballot((m >> st) & 1u);
+                    pre[st] = __popcll(bl & ((1ull << lane) - 1ull));
+                    if (lane == 0) s_wc[wave][st] = __popcll(bl);
                 }
-                s_stot[threadIdx.x] = run;
-            }
-            __syncthreads();
+                __syncthreads();
+                if (threadIdx.x < 4) {
+                    int run = 0;
+                    for (int w = 0; w < kSplatBlock / kWave; w++) {
+                        const int c = s_wc[w][threadIdx.x];
+                        s_wc[w][threadIdx.x] = run;
+                        run += c;
+                    }
+                    s_stot[threadIdx.x] = run;
+                }
+                __syncthreads();
 #pragma unroll
-            for (int st = 0; st < 4; st++)
-                if ((m >> st) & 1u) s_strip[st][s_wc[wave][st] + pre[st]] = (unsigned short)threadIdx.x;
-            __syncthreads();
-        }
-        const int strip = wave & 3;      // (pix = tid & 255: wave w holds rows 4 (w & 3) .. + 3, share w >> 2)
-        const int LS = s_stot[strip];
-        for (int k2 = share; k2 < LS; k2 += 4) {
-            const int k = s_strip[strip][k2];
-            const float4 p = list[k];
-            const float dx = pxc - p.x, dy = pyc - p.y;
-            const float a = 1.0f - (dx * dx + dy * dy) * p.z;
-            if (a > 0.0f) {
-                const float2 gb = list_gb[k];
-                const float ac = fminf(a, kMaskAmax);
-                tr *= 1.0f - ac;
-                sd += ac;
-                sr += ac * p.w;
-                sg += ac * gb.x;
-                sb += ac * gb.y;
+                for (int st = 0; st < 4; st++)
+                    if ((m >> st) & 1u) s_strip[st][s_wc[wave][st] + pre[st]] = (unsigned short)threadIdx.x;
+                __syncthreads();
+            }
+            const int strip = wave & 3;      // (pix = tid & 255: wave w holds rows 4 (w & 3) .. + 3, share w >> 2)
+            const int LS = s_stot[strip];
+            for (int k2 = share; k2 < LS; k2 += 4) {
+                const int k = s_strip[strip][k2];
+                const float4 p = list[k];
+                const float dx = pxc - p.x, dy = pyc - p.y;
+                const float a = 1.0f - (dx * dx + dy * dy) * p.z;
+                if (a > 0.0f) {
+                    const float2 gb = list_gb[k];
+                    const float ac = fminf(a, kMaskAmax);
+                    tr *= 1.0f - ac;
+                    sd += ac;
+                    sr += ac * p.w;
+                    sg += ac * gb.x;
+                    sb += ac * gb.y;
+                }
             }
         }
     }
@@ -1533,7 +1544,9 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
     // planes stay in L2) 25.6 + 8.2 us against 29.3; 32 images (8 scans in lock-step: 32 MB of W planes through every 4 MB
     // L2, the scattered 16-byte reads cost 105 of the per-point kernel's 150 us) 107 + 21 against 150-168.
     static const int env_tp = getenv("GENPC_MASK_GRAD_TILES") ? atoi(getenv("GENPC_MASK_GRAD_TILES")) : -1;
-    const bool tile_pass = use_bins(S) && (env_tp >= 0 ? env_tp != 0 : b > 4);
+    // (8 x 4 images of 32768 points, 167 points per tile on average: 0.814 s per call with the tile pass, 0.789 without --
+    // crowded tiles take several rounds of the block; 16384 points, 84 per tile: 167 ms against 176)
+    const bool tile_pass = use_bins(S) && (env_tp >= 0 ? env_tp != 0 : b > 4 && nc <= 128 * mask_tiles(S));
     if (!projected)      // (the alignment loop projects in its transform launch)
         hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride, params,
                            pstride, 1, rad, S, m.uvr, use_bins(S) ? m.bins : (int *)nullptr);

@@ -164,7 +164,8 @@ def test_splat_image_vs_oracle(gp, oracle):
 
 def test_splat_tile_lists_and_their_fallbacks(gp, oracle):
     """The splat reads per-tile index lists the projection kernel fills (pose.hip bin_points_block).  The cases a list
-    cannot hold must give the same image through the full scan: a tile hit by more points than a list holds, discs
+    cannot hold must give the same image through the full scan: a tile hit by more points than a list holds (and one whose
+    list is longer than one fill of the splat's LDS list), discs
     over more tiles than a point may be listed in, an image with more tiles than the block histogram, and a mixture
     (a dense knot inside an ordinary cloud: crowded and ordinary tiles in one image)."""
     torch = gp["torch"]
@@ -173,6 +174,7 @@ def test_splat_tile_lists_and_their_fallbacks(gp, oracle):
     knot = (partial[:1] + 0.004 * rng.standard_normal((5000, 3))).astype(np.float32)
     cases = (
         ("crowded tile", knot, 0.01, 224),
+        ("crowded tile, a list of three fills", np.concatenate([partial, knot[:2500]]), 0.01, 224),
         ("knot in a cloud", np.concatenate([partial, knot]), 0.02, 224),
         ("wide discs", partial[:600], 0.3, 224),
         ("wide and narrow", np.concatenate([partial[:2000], partial[:1]]), 0.09, 160),
