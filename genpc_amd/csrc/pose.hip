@@ -634,7 +634,6 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     __shared__ float2 list_gb[kSplatList];    // green, blue
     __shared__ int s_cnt;
     __shared__ int s_tab[kSplatPer * (kSplatBlock / kWave)];      // per (i, wave): hits, then their exclusive prefix
-    __shared__ double red[6][kSplatBlock / kWave];
     const int e = blockIdx.y;
     const int P = S * S;
     const int tiles_x = (S + kMaskTile - 1) / kMaskTile;
@@ -893,8 +892,9 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     part[3][share][pix] = sg;
     part[4][share][pix] = sb;
     __syncthreads();
-    double s1[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0};
+    __shared__ float s_I[3][kMaskTile * kMaskTile];
     if (threadIdx.x < kMaskTile * kMaskTile) {
+        float I3[3] = {0.0f, 0.0f, 0.0f};
         const int r = ty0 + pix / kMaskTile, cc = tx0 + (pix & (kMaskTile - 1));
         if (r < S && cc < S) {
             float w[5];
@@ -913,25 +913,38 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
             const float O = 1.0f - w[0];
             const float iD = w[1] > 0.0f ? 1.0f / w[1] : 0.0f;
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const float I = O * (w[2 + ch] * iD);
-                s1[ch] = (double)I;
-                s2[ch] = (double)I * (double)I;
-            }
+            for (int ch = 0; ch < 3; ch++) I3[ch] = O * (w[2 + ch] * iD);
         }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) s_I[ch][pix] = I3[ch];
     }
     if (accum) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { s1[ch] += __shfl_xor(s1[ch], off, kWave); s2[ch] += __shfl_xor(s2[ch], off, kWave); }
-            if (lane == 0) { red[ch][wave] = s1[ch]; red[3 + ch][wave] = s2[ch]; }
-        }
+        // The tile's sums of I and I^2 per channel (doubles), by ONE wave: four pixels per lane, then the wave's shuffles.
+        // (All sixteen waves used to run the 72 64-bit shuffles of the reduction although only four held pixels: with two
+        // blocks per CU that was 76 of the launch's 200 us at 32 images.)
         __syncthreads();
-        if (threadIdx.x < 6) {
-            double x = 0.0;
-            for (int w2 = 0; w2 < kMaskTile * kMaskTile / kWave; w2++) x += red[threadIdx.x][w2];   // only the first 256 threads held pixels
-            atomicAdd(&accum[16 + threadIdx.x], x);
+        if (wave == 0) {
+            double s1[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < kMaskTile * kMaskTile / kWave; q++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const double I = (double)s_I[ch][lane + q * kWave];
+                    s1[ch] += I;
+                    s2[ch] += I * I;
+                }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { s1[ch] += __shfl_xor(s1[ch], off, kWave); s2[ch] += __shfl_xor(s2[ch], off, kWave); }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    atomicAdd(&accum[16 + ch], s1[ch]);
+                    atomicAdd(&accum[19 + ch], s2[ch]);
+                }
+            }
         }
     }
 }
