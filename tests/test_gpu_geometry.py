@@ -210,10 +210,11 @@ def test_mask_gradient_tile_pass_and_its_fallbacks(gp, oracle):
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     rng = np.random.default_rng(5)
     complete, partial, _ = _shape(4, 2500)
-    knot = (complete[:1] + 0.004 * rng.standard_normal((3000, 3))).astype(np.float32)
+    knot = (complete[:1] + 0.004 * rng.standard_normal((6000, 3))).astype(np.float32)      # more than a list holds (4096)
     params = np.array([0.95, 0.05, -0.2, 0.02, 1.05, 0.1, 0.01, -0.02, 0.02, math.log(0.85)], np.float32)
     cases = (
         ("crowded tile", np.concatenate([complete, knot]), 0.02, 224),
+        ("long list", np.concatenate([complete, knot[:2000]]), 0.02, 224),
         ("wide discs", complete[:800], 0.12, 160),
         ("wide and narrow tiles", complete, 0.06, 224),
         ("large image", complete, 0.02, 544),
