@@ -1763,7 +1763,11 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
 
     const int gb = ceil_div(b, 64);
     hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, -1, 0);
-    const int g_t = lin_grid(nc), g_g = lin_grid((long long)nc + np);
+    // (every block of the gradient kernels ends in 13-22 double atomics on its image's accumulators: with many images in
+    // flight fewer, longer blocks per image -- GENPC_POSE_GRAD_BLOCKS for A/B)
+    static const int env_gb = getenv("GENPC_POSE_GRAD_BLOCKS") ? atoi(getenv("GENPC_POSE_GRAD_BLOCKS")) : 0;
+    // 32 images (8 scans x 4 starts): 96 blocks per image 153.1 ms per call, 48: 151.0, 24: 150.2, 12: 150.4
+    const int g_t = lin_grid(nc), g_g = std::min(env_gb > 0 ? env_gb : (b >= 16 ? 24 : 1024), lin_grid((long long)nc + np));
     const int hstride = starts * (iters + 1);
     for (int s = 0; s < starts; s++) {
         hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, s, lock);
