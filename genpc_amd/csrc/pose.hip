@@ -1579,14 +1579,19 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
         hipLaunchKernelGGL((mask_grad_kernel<1>), dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, complete_col, center,
                            cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum,
                            (const float4 *)m.gpart);
-    } else if (b <= 2) {     // (measured at 4 x 16384 points, the four starts in lock-step: <1> 35 us, <8> 42)
-        hipLaunchKernelGGL((mask_grad_kernel<8>), dim3(lin_grid((long long)nc * 8), b), dim3(kQBlock), 0, st, nc, complete,
-                           complete_col, center, cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum,
-                           (const float4 *)nullptr);
     } else {
-        hipLaunchKernelGGL((mask_grad_kernel<1>), dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, complete_col, center,
-                           cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum,
-                           (const float4 *)nullptr);
+        // lanes per point (measured at 4 x 16384 points, the four starts in lock-step: <1> 35 us, <8> 42)
+        static const int env_sub = getenv("GENPC_MASK_GRAD_SUB") ? atoi(getenv("GENPC_MASK_GRAD_SUB")) : 0;
+        const int sub = env_sub ? env_sub : (b <= 2 ? 8 : 1);
+#define GENPC_LAUNCH_MASK_GRAD(SUB)                                                                                                  \
+        hipLaunchKernelGGL((mask_grad_kernel<SUB>), dim3(lin_grid((long long)nc * SUB), b), dim3(kQBlock), 0, st, nc, complete,      \
+                           complete_col, center, cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum, \
+                           (const float4 *)nullptr)
+        if (sub == 8) GENPC_LAUNCH_MASK_GRAD(8);
+        else if (sub == 4) GENPC_LAUNCH_MASK_GRAD(4);
+        else if (sub == 2) GENPC_LAUNCH_MASK_GRAD(2);
+        else GENPC_LAUNCH_MASK_GRAD(1);
+#undef GENPC_LAUNCH_MASK_GRAD
     }
     return check(hipGetLastError(), "mask step launch") ? 1 : 0;
 }
