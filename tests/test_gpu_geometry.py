@@ -194,6 +194,24 @@ def test_splat_tile_lists_and_their_fallbacks(gp, oracle):
         np.testing.assert_allclose(again, img, atol=1e-6, err_msg=name)
 
 
+def test_splat_fuzz(gp, oracle):
+    """Random clouds, sizes, radii and image sizes through the splat's tile lists (empty tiles, one-entry lists, lists
+    ranked by counting and by bitmap, several fills, overflow, images with no lists) against the oracle's image."""
+    torch = gp["torch"]
+    rng = np.random.default_rng(2024)
+    for case in range(16):
+        n = int(rng.choice([1, 2, 63, 300, 2000, 9000, 20000]))
+        size = int(rng.choice([16, 31, 57, 96, 224, 300, 528]))
+        radius = float(rng.choice([0.004, 0.01, 0.02, 0.05, 0.11]))
+        spread = float(rng.choice([0.02, 0.15, 0.45]))
+        pts = (rng.standard_normal((n, 3)) * spread * np.array([1.0, 0.8, 0.5]) + rng.uniform(-0.2, 0.2, 3)).astype(np.float32)
+        col = _colours(rng, n, 0.2) if case % 2 else None
+        img = gp["POSE"].splat_image(torch.from_numpy(pts).cuda(), radius, size,
+                                     None if col is None else torch.from_numpy(col).cuda()).cpu().numpy()
+        ref = oracle.splat_image(pts, radius, size, col)
+        np.testing.assert_allclose(img, ref, atol=2e-4, err_msg="case %d: n %d size %d radius %g spread %g" % (case, n, size, radius, spread))
+
+
 def test_mask_gradient_tile_pass_and_its_fallbacks(gp, oracle):
     """The mask gradient is gathered per tile from the splat's lists (pose.hip mask_grad_tile_kernel) and summed per
     point; a tile whose list overflowed walks all points, a disc over more than four tiles gathers its own box, an image
