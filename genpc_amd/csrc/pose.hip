@@ -1229,15 +1229,21 @@ __global__ __launch_bounds__(kQBlock) void mask_w_kernel(int S, const float *__r
 // gathering its whole box from global memory was bound by the scattered 16-byte reads: 8 scans in lock-step 150 us, 45 us
 // with the same instructions on coalesced addresses.)  A tile whose list overflowed walks all points of the image.
 // Resets the tile's counter (the splat kept it for this pass).
-constexpr int kGradTileBlock = 1024;
-__global__ __launch_bounds__(kGradTileBlock) void mask_grad_tile_kernel(int n, const float4 *__restrict__ uvr, const float *__restrict__ col,
+// TB threads: 1024 with the entries sorted by piece size when few images are in flight (the crowded tiles are the critical
+// path), 256 unsorted when many are (a tile's list averages 125 entries: fourteen of sixteen waves of a 1024-thread block
+// idle while two blocks fill the CU -- 104 us at 32 images; eight small blocks per CU: see DESIGN 4.5)
+template <int TB, bool SORT>
+__global__ __launch_bounds__(TB) void mask_grad_tile_kernel(int n, const float4 *__restrict__ uvr, const float *__restrict__ col,
                                                                        int S, const float *__restrict__ W1,
                                                                        const float4 *__restrict__ W4, int *__restrict__ bins,
                                                                        float4 *__restrict__ gpart)
 {
-    static_assert(kGradTileBlock >= kMaskTile * kMaskTile, "a thread per pixel for the load");
+    static_assert(TB >= kMaskTile * kMaskTile, "a thread per pixel for the load");
     __shared__ float4 sW4[kMaskTile * kMaskTile];
     __shared__ float sW1[kMaskTile * kMaskTile];
+    __shared__ int s_list[SORT ? kTileCap : 1];
+    __shared__ int s_ccnt[4];
+    static_assert(kTileCap % TB == 0, "whole entries per thread");
     const int e = blockIdx.y, tile = blockIdx.x;
     const int tiles_x = (S + kMaskTile - 1) / kMaskTile;
     const int tx0 = (tile % tiles_x) * kMaskTile, ty0 = (tile / tiles_x) * kMaskTile;
@@ -1296,13 +1302,48 @@ __global__ __launch_bounds__(kGradTileBlock) void mask_grad_tile_kernel(int n, c
         }
         gpart[(size_t)j * kBinPer + slot] = make_float4(gu, gv, gr, 0.0f);
     };
-    if (count <= kTileCap) {
-        for (int i = threadIdx.x; i < count; i += kGradTileBlock) {
+    if (count <= kTileCap && !SORT) {
+        for (int i = threadIdx.x; i < count; i += TB) {
             const int ent = bin_idx[i];
             gather(ent >> 2, ent & 3, uvr[ent >> 2]);
         }
+    } else if (count <= kTileCap) {
+        // Entries in order of the size of their piece of the disc (four classes by the clipped box's area): a wave runs as
+        // long as its largest piece, and a tile's list mixes whole discs (81 pixels) with halves and corners of discs
+        // centred in the neighbouring tiles.  The order inside a class is arbitrary -- every entry writes its own slot.
+        constexpr int kPerThread = SORT ? kTileCap / TB : 1;
+        int my_c[kPerThread], my_pos[kPerThread], my_ent[kPerThread];
+        if (threadIdx.x < 4) s_ccnt[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kPerThread; t++) {
+            const int i = threadIdx.x + t * TB;
+            my_c[t] = -1;
+            if (i < count) {
+                const int ent = bin_idx[i];
+                const float4 q = uvr[ent >> 2];
+                const int c0 = max(max((int)floorf(q.x - q.z - 0.5f), 0), tx0), c1 = min(min((int)ceilf(q.x + q.z - 0.5f), S - 1), tx1);
+                const int r0 = max(max((int)floorf(q.y - q.z - 0.5f), 0), ty0), r1 = min(min((int)ceilf(q.y + q.z - 0.5f), S - 1), ty1);
+                const int area = max(c1 - c0 + 1, 0) * max(r1 - r0 + 1, 0);
+                const int full = (2 * (int)q.z + 3) * (2 * (int)q.z + 3);      // about the unclipped box
+                const int c = 4 * area >= 3 * full ? 0 : (2 * area >= full ? 1 : (4 * area >= full ? 2 : 3));
+                my_ent[t] = ent;
+                my_c[t] = c;
+                my_pos[t] = atomicAdd(&s_ccnt[c], 1);
+            }
+        }
+        __syncthreads();
+        const int o1 = s_ccnt[0], o2 = o1 + s_ccnt[1], o3 = o2 + s_ccnt[2];
+#pragma unroll
+        for (int t = 0; t < kPerThread; t++)
+            if (my_c[t] >= 0) s_list[(my_c[t] == 0 ? 0 : (my_c[t] == 1 ? o1 : (my_c[t] == 2 ? o2 : o3))) + my_pos[t]] = my_ent[t];
+        __syncthreads();
+        for (int i = threadIdx.x; i < count; i += TB) {
+            const int ent = s_list[i];
+            gather(ent >> 2, ent & 3, uvr[ent >> 2]);
+        }
     } else {
-        for (int j = threadIdx.x; j < n; j += kGradTileBlock) {
+        for (int j = threadIdx.x; j < n; j += TB) {
             const float4 q = uvr[j];
             if (!(q.z > 0.0f)) continue;
             int slot;
@@ -1574,8 +1615,12 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
     hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, 0, (const float *)m.mref,
                        (const float *)m.stats, mask_weight, m.W1, m.W4, accum);
     if (tile_pass) {
-        hipLaunchKernelGGL(mask_grad_tile_kernel, dim3(mask_tiles(S), b), dim3(kGradTileBlock), 0, st, nc, (const float4 *)m.uvr,
-                           complete_col, S, (const float *)m.W1, (const float4 *)m.W4, m.bins, m.gpart);
+        if (b > 4)
+            hipLaunchKernelGGL((mask_grad_tile_kernel<256, false>), dim3(mask_tiles(S), b), dim3(256), 0, st, nc, (const float4 *)m.uvr,
+                               complete_col, S, (const float *)m.W1, (const float4 *)m.W4, m.bins, m.gpart);
+        else
+            hipLaunchKernelGGL((mask_grad_tile_kernel<1024, true>), dim3(mask_tiles(S), b), dim3(1024), 0, st, nc, (const float4 *)m.uvr,
+                               complete_col, S, (const float *)m.W1, (const float4 *)m.W4, m.bins, m.gpart);
         hipLaunchKernelGGL((mask_grad_kernel<1>), dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, complete_col, center,
                            cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum,
                            (const float4 *)m.gpart);
