@@ -1363,10 +1363,11 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
                                                             const float *__restrict__ params, int pstride, float radius,
                                                             int S, const float *__restrict__ W1,
                                                             const float4 *__restrict__ W4, double *__restrict__ accum,
-                                                            const float4 *__restrict__ gpart)
+                                                            const float4 *__restrict__ gpart, const float4 *__restrict__ uvr)
 {
     __shared__ double red[13][kQBlock / kWave];
     const int e = blockIdx.y;
+    if (uvr) uvr += (size_t)e * n;
     v += (size_t)e * n * 3;
     if (col) col += (size_t)e * n * 3;
     W1 += (size_t)e * S * S;
@@ -1409,8 +1410,11 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
         // left out there and gathers its box here
         int ntile = kBinPer + 1;
         if (kGradSub == 1 && gpart && ok) {
+            // (counted from the projection's OWN record of the point, which is what the lists were built from -- not from
+            // the values recomputed above, equal as they should be)
+            const float4 rec = uvr[j];
             int none;
-            ntile = tile_count(S, q.u, q.v, q.rho, -1, none);
+            ntile = rec.z > 0.0f ? tile_count(S, rec.x, rec.y, rec.z, -1, none) : 0;
             if (ntile <= kBinPer)
                 for (int k = 0; k < ntile; k++) {
                     const float4 g = gpart[(size_t)j * kBinPer + k];
@@ -1623,7 +1627,7 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
                                complete_col, S, (const float *)m.W1, (const float4 *)m.W4, m.bins, m.gpart);
         hipLaunchKernelGGL((mask_grad_kernel<1>), dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, complete_col, center,
                            cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum,
-                           (const float4 *)m.gpart);
+                           (const float4 *)m.gpart, (const float4 *)m.uvr);
     } else {
         // lanes per point (measured at 4 x 16384 points, the four starts in lock-step: <1> 35 us, <8> 42)
         static const int env_sub = getenv("GENPC_MASK_GRAD_SUB") ? atoi(getenv("GENPC_MASK_GRAD_SUB")) : 0;
@@ -1631,7 +1635,7 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
 #define GENPC_LAUNCH_MASK_GRAD(SUB)                                                                                                  \
         hipLaunchKernelGGL((mask_grad_kernel<SUB>), dim3(lin_grid((long long)nc * SUB), b), dim3(kQBlock), 0, st, nc, complete,      \
                            complete_col, center, cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum, \
-                           (const float4 *)nullptr)
+                           (const float4 *)nullptr, (const float4 *)nullptr)
         if (sub == 8) GENPC_LAUNCH_MASK_GRAD(8);
         else if (sub == 4) GENPC_LAUNCH_MASK_GRAD(4);
         else if (sub == 2) GENPC_LAUNCH_MASK_GRAD(2);
