@@ -1422,15 +1422,22 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
                 }
         }
         if (ok && ntile > kBinPer) {
+            // the walk of mask_grad_tile_kernel: rows with an empty chord skipped, a row over its chord +- a pixel, the
+            // hardware reciprocal for 1 / (1 - av)
+            const float rho2 = q.rho * q.rho;
             for (int r = r0 + sub; r <= r1; r += kGradSub) {
                 const float dy = (float)r + 0.5f - q.v;
-                for (int cc = c0; cc <= c1; cc++) {
+                const float h2 = rho2 - dy * dy;
+                if (h2 < -1e-5f * rho2) continue;
+                const float h = sqrtf(fmaxf(h2, 0.0f));
+                const int ca = max((int)floorf(q.u - h - 0.5f), c0), cz = min((int)ceilf(q.u + h - 0.5f), c1);
+                for (int cc = ca; cc <= cz; cc++) {
                     const float dx = (float)cc + 0.5f - q.u;
                     const float d2 = dx * dx + dy * dy;
                     const float av = 1.0f - d2 * ir2;
                     if (av <= 0.0f || av >= kMaskAmax) continue;      // outside the disc / clamped: no gradient
                     const float4 w4 = W4[(size_t)r * S + cc];
-                    const float w = W1[(size_t)r * S + cc] / (1.0f - av) + ((cr * w4.x + cg * w4.y) + (cb * w4.z - w4.w));
+                    const float w = W1[(size_t)r * S + cc] * __builtin_amdgcn_rcpf(1.0f - av) + ((cr * w4.x + cg * w4.y) + (cb * w4.z - w4.w));
                     gu += w * dx;
                     gv += w * dy;
                     gr += w * d2;
