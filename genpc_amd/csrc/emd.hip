@@ -16,6 +16,9 @@
 //            the list of NEXT round's bidders (losers + evicted owners) is built
 //            here with wave-aggregated appends, which replaces the reference's
 //            four compaction kernels.
+// getmax + assign are ONE launch where they were two list-walking ones (emd_settle_kernel: the bid
+// kernel chains the bidders of an object, every bidder finds the winner by itself), or one
+// single-block launch per cloud (emd_resolve_kernel: small clouds / many clouds, late rounds).
 // Bid layout.  P lanes cooperate on one bidder (P = 1..64, a power of two picked
 // per round from the number of bidders so that the grid stays full when few
 // points are left); lane p of a bidder visits objects k = p (mod P) of a tile of
@@ -148,7 +151,9 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                                                           float *__restrict__ bid_increments,
                                                           float *__restrict__ max_increments, int force_p,
                                                           float4 *__restrict__ parts, int *__restrict__ arrive,
-                                                          int *__restrict__ second, int zmax)
+                                                          int *__restrict__ second, int zmax,
+                                                          unsigned long long *__restrict__ chain_head,
+                                                          unsigned long long *__restrict__ chain_next, unsigned stamp)
 {
     constexpr int kTile = TILE, kLoadsPerThread = TILE / 256;
     // one tile of objects as four planes (x, y, z, price): a 16-byte read delivers four consecutive objects' x as two
@@ -407,6 +412,12 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
             if (second != nullptr) second[(size_t)batch * n + j] = better_i;
             bid_increments[(size_t)batch * n + j] = inc;
             atomic_max_float(&max_increments[(size_t)batch * n + best_i], inc);
+            // the round's bidders of an object as a chain through the object's head word (emd_settle_kernel): a record is
+            // (increment bits << 32) | (stamp << 24) | bidder, the head holds the latest bidder's, next[j] what j displaced
+            if (chain_head != nullptr) {
+                const unsigned long long mine = ((unsigned long long)(unsigned)__float_as_int(inc) << 32) | (stamp << 24) | (unsigned)j;
+                chain_next[(size_t)batch * n + j] = atomicExch(&chain_head[(size_t)batch * n + best_i], mine);
+            }
         }
     }
 }
@@ -470,6 +481,79 @@ __global__ __launch_bounds__(kEBlock) void emd_assign_kernel(int n, const int *_
             max_increments[base + bid_id] = -1e9f;
             // elections are per round; only this thread's own comparison above
             // needed the value, every other bidder of the object compares != j
+            max_idx[base + bid_id] = -1;
+        } else {
+            const int pos = atomicAdd(&cnt_next[batch], 1);
+            list_next[base + pos] = j;
+        }
+    }
+}
+
+// GetMax and Assign of one round in one MULTI-block launch (emd_cuda.cu:181-215).  GetMax needs every bid of the round (a
+// grid-wide dependency, hence the reference's two launches); here every bidder walks the chain of its object's bidders that
+// the bid kernel left (chain_head / chain_next) and finds the winner itself -- the bidder with the highest index among those
+// whose increment lies within 1e-6 of the largest (all of them in the forced last round) -- so all bidders of an object
+// agree without exchanging anything, and the winner does Assign's work.  The largest increment of the chain IS
+// max_increments[object] (increments are >= 0 when eps >= 0, the only case this kernel is launched for; the winner resets
+// that word, so it is not read here).  A chain of one -- the usual case once few bidders are left -- is read off the head
+// word alone: the launch is as deep as Assign was, and GetMax's 4.7 us per round are gone.
+__global__ __launch_bounds__(kEBlock) void emd_settle_kernel(int n, const int *__restrict__ list, const int *__restrict__ cnt,
+                                                             int *__restrict__ list_next, int *__restrict__ cnt_next,
+                                                             int *__restrict__ assignment, int *__restrict__ assignment_inv,
+                                                             float *__restrict__ price, const int *__restrict__ bid,
+                                                             float *__restrict__ max_increments, int *__restrict__ max_idx,
+                                                             const unsigned long long *__restrict__ chain_head,
+                                                             const unsigned long long *__restrict__ chain_next, unsigned stamp,
+                                                             int last)
+{
+    const int batch = blockIdx.y;
+    const int U = cnt[batch];
+    const size_t base = (size_t)batch * n;
+    for (int u = blockIdx.x * kEBlock + threadIdx.x; u < U; u += gridDim.x * kEBlock) {
+        const int j = list[base + u];
+        const int bid_id = bid[base + j];
+        const unsigned long long mynext = chain_next[base + j];      // (what j displaced: read beside bid[j], not behind the head)
+        const unsigned long long head = chain_head[base + bid_id];
+        auto live = [&](unsigned long long r) { return (unsigned)((r >> 24) & 0xffu) == stamp; };
+        auto who = [](unsigned long long r) { return (int)(r & 0xffffffu); };
+        auto inc_of = [](unsigned long long r) { return __int_as_float((int)(r >> 32)); };
+        int winner = who(head);
+        float my_inc = inc_of(head);
+        if (winner != j || live(mynext)) {
+            // several bidders: the largest increment first, then the highest index inside its window
+            float mx = -1e9f;
+            for (unsigned long long r = head; live(r); r = chain_next[base + who(r)]) {
+                const float v = inc_of(r);
+                mx = v > mx ? v : mx;
+                if (who(r) == j) my_inc = v;
+            }
+            winner = -1;
+            for (unsigned long long r = head; live(r); r = chain_next[base + who(r)]) {
+                const double bid_inc = (double)inc_of(r), max_inc = (double)mx;
+                if ((last || (bid_inc - 1e-6 <= max_inc && max_inc <= bid_inc + 1e-6)) && who(r) > winner) winner = who(r);
+            }
+        }
+        const bool elected = winner == j;
+        if (last) {
+            // every remaining bidder takes its object (not a bijection, :201)
+            assignment[base + j] = bid_id;
+            atomicAdd(&price[base + bid_id], my_inc);
+            if (elected) {
+                assignment_inv[base + bid_id] = j;
+                max_increments[base + bid_id] = -1e9f;
+                max_idx[base + bid_id] = -1;
+            }
+        } else if (elected) {
+            const int prev = assignment_inv[base + bid_id];
+            if (prev != -1) {
+                assignment[base + prev] = -1;
+                const int pos = atomicAdd(&cnt_next[batch], 1);
+                list_next[base + pos] = prev;
+            }
+            assignment_inv[base + bid_id] = j;
+            assignment[base + j] = bid_id;
+            price[base + bid_id] = __fadd_rn(price[base + bid_id], my_inc);
+            max_increments[base + bid_id] = -1e9f;
             max_idx[base + bid_id] = -1;
         } else {
             const int pos = atomicAdd(&cnt_next[batch], 1);
@@ -610,8 +694,14 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     const bool want_split = b <= 32;
     const size_t parts_bytes = want_split ? (size_t)b * kSplitMaxBidders * kZMax * sizeof(float4) : 0;
     const size_t second_bytes = ((size_t)total * sizeof(int) + 255) / 256 * 256;
-    char *ws = (char *)workspace(1, arrive_bytes + list_bytes + second_bytes + parts_bytes, st, nullptr, arrive_bytes);
+    // bidder chains per object (emd_settle_kernel): head word per object, link word per bidder
+    static const bool no_settle = getenv("GENPC_EMD_SETTLE") && atoi(getenv("GENPC_EMD_SETTLE")) == 0;
+    const bool settle = !no_settle && eps >= 0.0f && n <= (1 << 24);
+    const size_t chain_bytes = settle ? 2 * (size_t)total * sizeof(unsigned long long) : 0;
+    char *ws = (char *)workspace(1, arrive_bytes + list_bytes + second_bytes + parts_bytes + chain_bytes, st, nullptr, arrive_bytes);
     if (!ws) return 0;
+    unsigned long long *chain_head = settle ? (unsigned long long *)(ws + arrive_bytes + list_bytes + second_bytes + parts_bytes) : nullptr;
+    unsigned long long *chain_next = settle ? chain_head + total : nullptr;
     int *arrive = (int *)ws;
     int *list_b = (int *)(ws + arrive_bytes);
     int *second = (int *)(ws + arrive_bytes + list_bytes);
@@ -655,9 +745,16 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     for (int it = 0; it < iters; it++) {
         const int cur = it & 1, nxt = cur ^ 1;
         const int last = (it == iters - 1);
+        // rounds that took the two list-walking launches take the settle kernel (the single-block resolve keeps its rounds)
+        const bool use_chain = settle && it < resolve_from;
+        const unsigned stamp = (unsigned)(it % 255) + 1u;      // 8 bits in a record: the heads are cleared every 255 rounds
+        if (use_chain && it % 255 == 0 &&
+            !check(hipMemsetAsync(chain_head, 0, (size_t)total * sizeof(unsigned long long), st), "hipMemsetAsync(chain heads)"))
+            return 0;
         {
             typedef void (*bid_fn)(int, const float *, const float *, const float *, float, const int *, const int *,
-                                   int *, int *, float *, float *, int, float4 *, int *, int *, int);
+                                   int *, int *, float *, float *, int, float4 *, int *, int *, int, unsigned long long *,
+                                   unsigned long long *, unsigned);
             static const int zmax_env = getenv("GENPC_EMD_ZMAX") ? atoi(getenv("GENPC_EMD_ZMAX")) : kZMax;
             const int zmax = zmax_env < 1 ? 1 : (zmax_env > kZMax ? kZMax : zmax_env);
             // Lanes per bidder.  Round 0 has no filter seeds: the fewer lanes share a bidder, the sooner a
@@ -687,9 +784,15 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
                                          : (nofilter ? emd_bid_kernel<0, 0, 2048, 1> : emd_bid_kernel<0, 1, 2048, 1>));
             hipLaunchKernelGGL(f, dim3(G, b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price, eps,
                                (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
-                               max_increments, force_p, parts, arrive, second, zmax);
+                               max_increments, force_p, parts, arrive, second, zmax, use_chain ? chain_head : (unsigned long long *)nullptr,
+                               chain_next, stamp);
         }
-        if (it >= resolve_from) {
+        if (use_chain) {
+            hipLaunchKernelGGL(emd_settle_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
+                               (const int *)cnts[cur], lists[nxt], cnts[nxt], assignment, assignment_inv, price,
+                               (const int *)bid, max_increments, max_idx, (const unsigned long long *)chain_head,
+                               (const unsigned long long *)chain_next, stamp, last);
+        } else if (it >= resolve_from) {
             hipLaunchKernelGGL(emd_resolve_kernel, dim3(b), dim3(kResolveBlock), 0, st, n, (const int *)lists[cur],
                                (const int *)cnts[cur], lists[nxt], cnts[nxt], assignment, assignment_inv, price,
                                (const int *)bid, (const float *)bid_increments, max_increments, max_idx, last);
