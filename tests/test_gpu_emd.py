@@ -65,6 +65,22 @@ def test_vs_oracle(gp, oracle, shape, iters, mode):
     np.testing.assert_array_equal(s["bid_increments"], st["bid_increments"])
 
 
+def test_settle_rounds_beyond_the_stamp_period(gp, oracle):
+    """emd_settle_kernel (GetMax + Assign in one launch from the bidder chains) is taken for every round of a single
+    cloud of more than 4096 points; a record carries 8 bits of the round, so the chain heads are cleared every 255 rounds:
+    300 rounds at eps 0.001 (many bidders stay: chains of several bidders in late rounds too), every state array
+    against the oracle; and a negative eps, which keeps the reference's two launches."""
+    a, b = gen_pair(77, (1, 4352, 3), (1, 4352, 3), 0.0)
+    for eps, iters in ((0.001, 300), (-0.0005, 6)):
+        s = run_hip(gp, a, b, eps, iters, 1)
+        d, ass, st = oracle.emd_forward(a, b, eps, iters, 1, return_state=True)
+        np.testing.assert_array_equal(s["assignment"], ass)
+        np.testing.assert_array_equal(s["dist"], d)
+        np.testing.assert_array_equal(s["assignment_inv"], st["assignment_inv"])
+        np.testing.assert_array_equal(s["bid"], st["bid"])
+        np.testing.assert_array_equal(s["bid_increments"], st["bid_increments"])
+
+
 def test_survey_scalars(gp, golden):
     """EMD 0.07579704/0.07364403 (seed 0) and 0.065699235
     (scan 01184), strict arithmetic, through Completionloss.emd_loss."""
