@@ -1561,7 +1561,11 @@ struct MaskScratch {
     size_t bins_count_bytes;
     static size_t up(size_t x) { return (x + 255) / 256 * 256; }
     static size_t side(size_t P) { size_t S = (size_t)sqrt((double)P); while (S * S < P) S++; return S; }
-    static size_t bins_bytes(int b, size_t P) { return (size_t)b * bins_tiles((int)side(P)) * (1 + (size_t)kTileCap) * sizeof(int); }
+    static size_t bins_bytes(int b, size_t P)
+    {
+        const size_t t = bins_tiles((int)side(P));
+        return t <= (size_t)kBinTiles ? (size_t)b * t * (1 + (size_t)kTileCap) * sizeof(int) : 0;      // (no lists for such an image: use_bins)
+    }
     static size_t bytes(int b, size_t P, size_t nmax)
     {
         return up((size_t)b * 8 * 4) + up((size_t)b * P * 4) + up((size_t)b * 5 * P * 4) + up((size_t)b * P * 4) +
@@ -1578,11 +1582,14 @@ struct MaskScratch {
         uvr = (float4 *)(base + off); off += up((size_t)b * nmax * 16);
         bins = (int *)(base + off); off += up(bins_bytes(b, P));
         gpart = (float4 *)(base + off);
-        bins_count_bytes = (size_t)b * bins_tiles((int)side(P)) * sizeof(int);
+        bins_count_bytes = bins_bytes(b, P) ? (size_t)b * bins_tiles((int)side(P)) * sizeof(int) : 0;
     }
     // the tile counters are zero between launches (the splat kernel resets what it reads); once per API call for a
     // workspace that is new or was last used with another batch size
-    bool zero_bins(hipStream_t st) const { return check(hipMemsetAsync(bins, 0, bins_count_bytes, st), "hipMemsetAsync(tile counters)"); }
+    bool zero_bins(hipStream_t st) const
+    {
+        return bins_count_bytes == 0 || check(hipMemsetAsync(bins, 0, bins_count_bytes, st), "hipMemsetAsync(tile counters)");
+    }
 };
 
 // splat of the partial clouds (with their colours) + reference soft masks / statistics (once per call)
