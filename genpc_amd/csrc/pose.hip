@@ -1618,7 +1618,11 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
     static const int env_tp = getenv("GENPC_MASK_GRAD_TILES") ? atoi(getenv("GENPC_MASK_GRAD_TILES")) : -1;
     // (8 x 4 images of 32768 points, 167 points per tile on average: 0.814 s per call with the tile pass, 0.789 without --
     // crowded tiles take several rounds of the block; 16384 points, 84 per tile: 167 ms against 176)
-    const bool tile_pass = use_bins(S) && (env_tp >= 0 ? env_tp != 0 : b > 4 && nc <= 128 * mask_tiles(S));
+    // OPT-IN (GENPC_MASK_GRAD_TILES=1).  On a cloud that fills the image the tile pass wins 5 % with 32 images in flight, but
+    // on a small object (16384 points over ~18 tiles: tools/time_reg_small.py) a few blocks carry all the work and 8 scans
+    // take 328 ms against 191 with the per-point kernel -- which does not care where the points fall.
+    const bool tile_pass = use_bins(S) && env_tp > 0;
+    (void)b;
     if (!projected)      // (the alignment loop projects in its transform launch)
         hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride, params,
                            pstride, 1, rad, S, m.uvr, use_bins(S) ? m.bins : (int *)nullptr);
