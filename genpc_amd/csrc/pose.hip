@@ -428,7 +428,7 @@ __device__ __forceinline__ SplatPt splat_project(const float *p, float radius, f
 // a tile's list is exactly its hit set; a tile with more than kSplatCap hits (the count keeps counting) is drawn by the
 // full scan.  (Every block used to read all projected points of its image: 205 MB of L2 reads per launch of four
 // starts, 43 k ticks for an empty tile.)
-constexpr int kTileCap = 4096;            // entries a tile's list holds (the mask gradient's tile pass reads them all)
+constexpr int kTileCap = 8192;            // entries a tile's list holds (a small object: 16384 points over a dozen tiles; 4096: 72.8 ms per call, 8192: 60.8)
 constexpr int kSplatCap = 1024;          // the splat takes lists up to this length (one entry per thread, one fill)
 constexpr int kRankWords = 2048;         // bitmap ranks in the splat: images of up to 65536 points
 constexpr int kRankByCount = 256;        // lists up to this length are ranked by counting

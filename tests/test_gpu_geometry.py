@@ -171,7 +171,7 @@ def test_splat_tile_lists_and_their_fallbacks(gp, oracle):
     torch = gp["torch"]
     rng = np.random.default_rng(77)
     _, partial, _ = _shape(6, 3000)
-    knot = (partial[:1] + 0.004 * rng.standard_normal((5000, 3))).astype(np.float32)
+    knot = (partial[:1] + 0.004 * rng.standard_normal((9000, 3))).astype(np.float32)      # more than a list holds (8192)
     cases = (
         ("crowded tile", knot, 0.01, 224),
         ("crowded tile, a list of three fills", np.concatenate([partial, knot[:2500]]), 0.01, 224),
@@ -228,7 +228,7 @@ def test_mask_gradient_tile_pass_and_its_fallbacks(gp, oracle):
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     rng = np.random.default_rng(5)
     complete, partial, _ = _shape(4, 2500)
-    knot = (complete[:1] + 0.004 * rng.standard_normal((6000, 3))).astype(np.float32)      # more than a list holds (4096)
+    knot = (complete[:1] + 0.004 * rng.standard_normal((9000, 3))).astype(np.float32)      # more than a list holds (8192)
     params = np.array([0.95, 0.05, -0.2, 0.02, 1.05, 0.1, 0.01, -0.02, 0.02, math.log(0.85)], np.float32)
     cases = (
         ("crowded tile", np.concatenate([complete, knot]), 0.02, 224),
