@@ -380,9 +380,11 @@ __global__ __launch_bounds__(kQBlock) void pose_replicate_kernel(size_t count, i
 // (coverage-weighted colour, order-independent: Pulsar's softmax in depth is NOT reproduced) and keeps
 // the reference's own torch code for what follows the render: per-channel statistical normalisation,
 // luminance, sigmoid soft masks, 30 MSE + BCE + 10 Dice (:204-217,261-278,238-259,304-311).
-//   mask_project_kernel  every point posed (the transform is fused) and projected once: (u, v, rho)
-//   mask_splat_kernel    one block per 16 x 16 image tile and scan: the points whose disc touches
-//                        the tile are compacted into LDS with their colours, then every pixel (four
+//   mask_project_kernel  every point posed (the transform is fused) and projected once: (u, v, rho); the point's
+//                        index goes into the list of every tile its disc's bounding box touches (bin_points_block)
+//   mask_splat_kernel    one block per 16 x 16 image tile and scan: the points of the tile's list (every point
+//                        of the scan when the list overflowed or the image has no lists), in ascending point
+//                        order, are put into LDS with their colours, then every pixel (four
 //                        threads each) walks the list and accumulates prod (1 - a), a and a c of the discs
 //                        covering it, in list order: no atomics on the image.  Writes the five planes
 //                        T = prod (1 - a), D = sum a, N_ch = sum a c_ch and adds the tile's sums of
@@ -396,6 +398,8 @@ __global__ __launch_bounds__(kQBlock) void pose_replicate_kernel(size_t count, i
 //   mask_grad_kernel     one thread per point: gathers the weights over the pixels it covers, chains
 //                        through (u, v, rho) to the point and on to (R, s, t): same 13 accumulators as
 //                        the Chamfer gradient
+//   mask_grad_tile_kernel  opt-in: the same gather per tile from LDS through the tile lists, per-(point, tile)
+//                        sums that mask_grad_kernel then adds
 constexpr int kMaskTile = 16;
 constexpr int kSplatBlock = 1024;  // 16 waves per tile: a wave per point leaves long dependent chains, four waves per SIMD hide them
 constexpr int kSplatPer = 16;      // points per thread and round of the splat (16384 points per round)
