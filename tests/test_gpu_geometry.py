@@ -218,8 +218,8 @@ def test_mask_gradient_tile_pass_and_its_fallbacks(gp, oracle):
     of more than 1024 tiles has no lists.  Each against the oracle's full loss and gradient."""
     torch = gp["torch"]
     if os.environ.get("GENPC_MASK_GRAD_TILES") != "1":
-        # the library takes the tile pass from five images on and reads the switch once per process: this test and the
-        # full-objective test again in a process that forces it for a single image
+        # the tile pass is opt-in and the library reads the switch once per process: this test and the full-objective
+        # test again in a process that turns it on
         import subprocess
         import sys
         r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
