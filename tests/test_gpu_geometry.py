@@ -223,7 +223,7 @@ def test_mask_gradient_tile_pass_and_its_fallbacks(gp, oracle):
         import subprocess
         import sys
         r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
-                            "tile_pass_and_its_fallbacks or full_loss_and_gradient_vs_oracle or dark_points"],
+                            "tile_pass_and_its_fallbacks or full_loss_and_gradient_vs_oracle or dark_points or batched_equals_singles"],
                            env=dict(os.environ, GENPC_MASK_GRAD_TILES="1"), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     rng = np.random.default_rng(5)
