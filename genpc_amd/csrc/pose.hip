@@ -1359,7 +1359,29 @@ __global__ __launch_bounds__(TB) void mask_grad_tile_kernel(int n, const float4 
     if (threadIdx.x == 0) bin_cnt[tile] = 0;
 }
 
-// grid (blocks, b): gradient of the mask term with respect to (R, s, t), into accum[0..12].
+// Workgroups go to the 8 XCDs round-robin by linear id, each XCD with its own 4 MB L2.  A 1-D launch of gx blocks for each
+// of nb images, mapped so that an image's blocks share as few XCDs as possible: its W planes (1 MB at 224 x 224) are then
+// gathered from ONE L2 instead of all eight (32 images in lock-step: 32 MB through every 4 MB L2; measured on the per-point
+// gradient: 168 -> 152 us at 32 images, 30.7 -> 29.3 at 4).
+struct XcdBlock { int e, x; };
+__device__ __forceinline__ XcdBlock xcd_block(int gx, int nb)
+{
+    const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
+    XcdBlock r;
+    if ((nb & 7) == 0) {                       // whole images per XCD
+        r.e = 8 * (k / gx) + xcd;
+        r.x = k % gx;
+    } else if (nb < 8 && 8 % nb == 0 && gx % (8 / nb) == 0) {      // 8 / nb XCDs per image
+        r.e = xcd % nb;
+        r.x = k * (8 / nb) + xcd / nb;
+    } else {
+        r.e = lin / gx;
+        r.x = lin % gx;
+    }
+    return r;
+}
+
+// 1-D grid of gx * nb blocks (xcd_block): gradient of the mask term with respect to (R, s, t), into accum[0..12].
 template <int kGradSub>
 __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *__restrict__ v,
                                                             const float *__restrict__ col,
@@ -1367,10 +1389,12 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
                                                             const float *__restrict__ params, int pstride, float radius,
                                                             int S, const float *__restrict__ W1,
                                                             const float4 *__restrict__ W4, double *__restrict__ accum,
-                                                            const float4 *__restrict__ gpart, const float4 *__restrict__ uvr)
+                                                            const float4 *__restrict__ gpart, const float4 *__restrict__ uvr,
+                                                            int gx, int nb)
 {
     __shared__ double red[13][kQBlock / kWave];
-    const int e = blockIdx.y;
+    const XcdBlock xb = xcd_block(gx, nb);
+    const int e = xb.e;
     if (uvr) uvr += (size_t)e * n;
     v += (size_t)e * n * 3;
     if (col) col += (size_t)e * n * 3;
@@ -1395,7 +1419,7 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
     // lock-step fill the chip with one thread per point, and the idle lanes of the 8-lane form cost 7 % there.
     const int sub = threadIdx.x & (kGradSub - 1);
     const int per_block = kQBlock / kGradSub;
-    for (int j0 = blockIdx.x * per_block; j0 < n; j0 += gridDim.x * per_block) {
+    for (int j0 = xb.x * per_block; j0 < n; j0 += gx * per_block) {
         const int j = j0 + threadIdx.x / kGradSub;
         const bool live = j < n;
         const int jj = live ? j : n - 1;
@@ -1647,17 +1671,17 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
         else
             hipLaunchKernelGGL((mask_grad_tile_kernel<1024, true>), dim3(mask_tiles(S), b), dim3(1024), 0, st, nc, (const float4 *)m.uvr,
                                complete_col, S, (const float *)m.W1, (const float4 *)m.W4, m.bins, m.gpart);
-        hipLaunchKernelGGL((mask_grad_kernel<1>), dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, complete_col, center,
+        hipLaunchKernelGGL((mask_grad_kernel<1>), dim3(lin_grid(nc) * b), dim3(kQBlock), 0, st, nc, complete, complete_col, center,
                            cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum,
-                           (const float4 *)m.gpart, (const float4 *)m.uvr);
+                           (const float4 *)m.gpart, (const float4 *)m.uvr, lin_grid(nc), b);
     } else {
         // lanes per point (measured at 4 x 16384 points, the four starts in lock-step: <1> 35 us, <8> 42)
         static const int env_sub = getenv("GENPC_MASK_GRAD_SUB") ? atoi(getenv("GENPC_MASK_GRAD_SUB")) : 0;
         const int sub = env_sub ? env_sub : (b <= 2 ? 8 : 1);
 #define GENPC_LAUNCH_MASK_GRAD(SUB)                                                                                                  \
-        hipLaunchKernelGGL((mask_grad_kernel<SUB>), dim3(lin_grid((long long)nc * SUB), b), dim3(kQBlock), 0, st, nc, complete,      \
+        hipLaunchKernelGGL((mask_grad_kernel<SUB>), dim3(lin_grid((long long)nc * SUB) * b), dim3(kQBlock), 0, st, nc, complete,      \
                            complete_col, center, cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum, \
-                           (const float4 *)nullptr, (const float4 *)nullptr)
+                           (const float4 *)nullptr, (const float4 *)nullptr, lin_grid((long long)nc * SUB), b)
         if (sub == 8) GENPC_LAUNCH_MASK_GRAD(8);
         else if (sub == 4) GENPC_LAUNCH_MASK_GRAD(4);
         else if (sub == 2) GENPC_LAUNCH_MASK_GRAD(2);
