@@ -626,11 +626,33 @@ __device__ __forceinline__ PxImg load_pixel(const float *__restrict__ pl, int P,
     return o;
 }
 
-// grid (tiles, b).  col: [b, n, 3] colours or nullptr (white).
+// Workgroups go to the 8 XCDs round-robin by linear id, each XCD with its own 4 MB L2.  A 1-D launch of gx blocks for each
+// of nb images, mapped so that an image's blocks share as few XCDs as possible: its W planes (1 MB at 224 x 224) are then
+// gathered from ONE L2 instead of all eight (32 images in lock-step: 32 MB through every 4 MB L2; measured on the per-point
+// gradient: 168 -> 152 us at 32 images, 30.7 -> 29.3 at 4).
+struct XcdBlock { int e, x; };
+__device__ __forceinline__ XcdBlock xcd_block(int gx, int nb)
+{
+    const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
+    XcdBlock r;
+    if ((nb & 7) == 0) {                       // whole images per XCD
+        r.e = 8 * (k / gx) + xcd;
+        r.x = k % gx;
+    } else if (nb < 8 && 8 % nb == 0 && gx % (8 / nb) == 0) {      // 8 / nb XCDs per image
+        r.e = xcd % nb;
+        r.x = k * (8 / nb) + xcd / nb;
+    } else {
+        r.e = lin / gx;
+        r.x = lin % gx;
+    }
+    return r;
+}
+
+// 1-D grid of tiles * nb blocks (xcd_block).  col: [nb, n, 3] colours or nullptr (white).
 __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const float4 *__restrict__ uvr,
                                                                  const float *__restrict__ col, int S,
                                                                  float *__restrict__ planes, double *__restrict__ accum,
-                                                                 int *__restrict__ bins, int keep_bins)
+                                                                 int *__restrict__ bins, int keep_bins, int nb)
 {
     static_assert(kSplatBlock == 4 * kMaskTile * kMaskTile, "four threads per pixel of the tile");
     __shared__ float part[5][4][kMaskTile * kMaskTile];
@@ -638,10 +660,11 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     __shared__ float2 list_gb[kSplatList];    // green, blue
     __shared__ int s_cnt;
     __shared__ int s_tab[kSplatPer * (kSplatBlock / kWave)];      // per (i, wave): hits, then their exclusive prefix
-    const int e = blockIdx.y;
+    const XcdBlock xb = xcd_block(((S + kMaskTile - 1) / kMaskTile) * ((S + kMaskTile - 1) / kMaskTile), nb);
+    const int e = xb.e, tile = xb.x;
     const int P = S * S;
     const int tiles_x = (S + kMaskTile - 1) / kMaskTile;
-    const int tx0 = (blockIdx.x % tiles_x) * kMaskTile, ty0 = (blockIdx.x / tiles_x) * kMaskTile;
+    const int tx0 = (tile % tiles_x) * kMaskTile, ty0 = (tile / tiles_x) * kMaskTile;
     const int tx1 = min(S, tx0 + kMaskTile) - 1, ty1 = min(S, ty0 + kMaskTile) - 1;
     uvr += (size_t)e * n;
     if (col) col += (size_t)e * n * 3;
@@ -669,10 +692,10 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     static_assert(kMaskTile == 16 && kSplatBlock / kWave == 16, "a wave = four rows of the tile, four shares");
     int binned = -1;
     int *bin_cnt = bins ? bins + (size_t)e * bins_tiles(S) : nullptr;
-    const int *bin_idx = bins ? bins + (size_t)gridDim.y * bins_tiles(S) + ((size_t)e * bins_tiles(S) + blockIdx.x) * kTileCap : nullptr;
+    const int *bin_idx = bins ? bins + (size_t)nb * bins_tiles(S) + ((size_t)e * bins_tiles(S) + tile) * kTileCap : nullptr;
     int my_ent = 0;
     if (bins) {
-        binned = bin_cnt[blockIdx.x];
+        binned = bin_cnt[tile];
         if (threadIdx.x < kSplatCap) my_ent = bin_idx[threadIdx.x];      // (before the count is known: one round trip, not two)
     }
     const bool by_list = binned >= 0 && (binned <= kSplatCap || (binned <= kTileCap && n <= 32 * kRankWords));
@@ -798,7 +821,7 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     }
     // the count is reset for the next launch by the last kernel that reads the lists: this one, or the mask gradient's tile pass
     __syncthreads();
-    if (bins && !keep_bins && threadIdx.x == 0) bin_cnt[blockIdx.x] = 0;
+    if (bins && !keep_bins && threadIdx.x == 0) bin_cnt[tile] = 0;
     for (int j0 = 0; j0 < n && !by_list; j0 += kSplatBlock * kSplatPer) {
         // the bounding-box tests keep only a bit per point (four points in flight at a time): the kernel must fit 64
         // VGPRs so that TWO 1024-thread blocks share a CU -- with all sixteen points of a thread in registers it needed
@@ -1359,28 +1382,6 @@ __global__ __launch_bounds__(TB) void mask_grad_tile_kernel(int n, const float4 
     if (threadIdx.x == 0) bin_cnt[tile] = 0;
 }
 
-// Workgroups go to the 8 XCDs round-robin by linear id, each XCD with its own 4 MB L2.  A 1-D launch of gx blocks for each
-// of nb images, mapped so that an image's blocks share as few XCDs as possible: its W planes (1 MB at 224 x 224) are then
-// gathered from ONE L2 instead of all eight (32 images in lock-step: 32 MB through every 4 MB L2; measured on the per-point
-// gradient: 168 -> 152 us at 32 images, 30.7 -> 29.3 at 4).
-struct XcdBlock { int e, x; };
-__device__ __forceinline__ XcdBlock xcd_block(int gx, int nb)
-{
-    const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
-    XcdBlock r;
-    if ((nb & 7) == 0) {                       // whole images per XCD
-        r.e = 8 * (k / gx) + xcd;
-        r.x = k % gx;
-    } else if (nb < 8 && 8 % nb == 0 && gx % (8 / nb) == 0) {      // 8 / nb XCDs per image
-        r.e = xcd % nb;
-        r.x = k * (8 / nb) + xcd / nb;
-    } else {
-        r.e = lin / gx;
-        r.x = lin % gx;
-    }
-    return r;
-}
-
 // 1-D grid of gx * nb blocks (xcd_block): gradient of the mask term with respect to (R, s, t), into accum[0..12].
 template <int kGradSub>
 __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *__restrict__ v,
@@ -1626,8 +1627,8 @@ static int mask_prepare_ref(int b, int np, const float *partial, const float *pa
 {
     hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(np), b), dim3(kQBlock), 0, st, np, partial, (const float *)nullptr, 0,
                        (const float *)nullptr, 0, 0, radius, S, m.uvr, use_bins(S) ? m.bins : (int *)nullptr);
-    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, np, (const float4 *)m.uvr, partial_col,
-                       S, m.planes, (double *)nullptr, use_bins(S) ? m.bins : (int *)nullptr, 0);
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S) * b), dim3(kSplatBlock), 0, st, np, (const float4 *)m.uvr, partial_col,
+                       S, m.planes, (double *)nullptr, use_bins(S) ? m.bins : (int *)nullptr, 0, b);
     hipLaunchKernelGGL(mask_ref_kernel, dim3(b), dim3(kMLThreads), 0, st, S, (const float *)m.planes, 0, m.mref, m.stats);
     return check(hipGetLastError(), "mask reference launch") ? 1 : 0;
 }
@@ -1654,8 +1655,8 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
     if (!projected)      // (the alignment loop projects in its transform launch)
         hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(nc), b), dim3(kQBlock), 0, st, nc, complete, center, cstride, params,
                            pstride, 1, rad, S, m.uvr, use_bins(S) ? m.bins : (int *)nullptr);
-    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S), b), dim3(kSplatBlock), 0, st, nc, (const float4 *)m.uvr, complete_col,
-                       S, m.planes, accum, use_bins(S) ? m.bins : (int *)nullptr, tile_pass ? 1 : 0);
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(S) * b), dim3(kSplatBlock), 0, st, nc, (const float4 *)m.uvr, complete_col,
+                       S, m.planes, accum, use_bins(S) ? m.bins : (int *)nullptr, tile_pass ? 1 : 0, b);
     // few blocks per image: every block ends in 22 double atomics on the image's accumulators, and 196 blocks x 22 on the
     // same addresses serialise in L2 (17.5 us for 0.2 M pixels; GENPC_MASK_SUMS_BLOCKS for A/B)
     static const int env_sb = getenv("GENPC_MASK_SUMS_BLOCKS") ? atoi(getenv("GENPC_MASK_SUMS_BLOCKS")) : 0;
@@ -1706,8 +1707,8 @@ GENPC_API int genpc_splat_image(int n, const float *pts, const float *col, float
     if (!m.zero_bins(st)) return 0;
     hipLaunchKernelGGL(mask_project_kernel, dim3(lin_grid(n > 0 ? n : 1), 1), dim3(kQBlock), 0, st, n, pts, (const float *)nullptr, 0,
                        (const float *)nullptr, 0, 0, radius, size, m.uvr, use_bins(size) ? m.bins : (int *)nullptr);
-    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(size), 1), dim3(kSplatBlock), 0, st, n, (const float4 *)m.uvr, col, size,
-                       m.planes, (double *)nullptr, use_bins(size) ? m.bins : (int *)nullptr, 0);
+    hipLaunchKernelGGL(mask_splat_kernel, dim3(mask_tiles(size)), dim3(kSplatBlock), 0, st, n, (const float4 *)m.uvr, col, size,
+                       m.planes, (double *)nullptr, use_bins(size) ? m.bins : (int *)nullptr, 0, 1);
     hipLaunchKernelGGL(mask_image_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, (int)P, (const float *)m.planes, img);
     return check(hipGetLastError(), "splat_image launch") ? 1 : 0;
 }
