@@ -479,16 +479,36 @@ __device__ __forceinline__ int hpr_base_tile(const int *hl, int nhard, int rank)
 // product per candidate, tiles are skipped with the cone bound for the single normal n = u (D = 0), and the
 // margin (1e-8 of the larger |p'|) is far above anything roundoff does to the clipped polygon, so the answer
 // agrees with the full computation.  Points that fail go through hpr_kernel as before.
+// Blocks go to the 8 XCDs round-robin by linear id, each XCD with its own 4 MB L2.  1-D launches of ntiles blocks for each
+// of c views, mapped so that the blocks of a view run on ONE XCD (c a multiple of 8; otherwise view-major order): they all
+// read the view's flipped points and tile records, and with a view's blocks on eight XCDs every L2 held every view in flight
+// (1 GB fetched from HBM per launch for 246 MB of input at 1024 x 10000).
+__device__ __forceinline__ void hpr_block(int ntiles, int c, int &view, int &tile)
+{
+    const int lin = blockIdx.x;
+    if ((c & 7) == 0) {
+        const int xcd = lin & 7, k = lin >> 3;
+        view = 8 * (k / ntiles) + xcd;
+        tile = k % ntiles;
+    } else {
+        view = lin / ntiles;
+        tile = lin % ntiles;
+    }
+}
+
 __global__ __launch_bounds__(kHprThreads) void hpr_accept_kernel(int n, const double *__restrict__ fl_all, const int *__restrict__ perm,
                                                                 const HprTile *__restrict__ tiles_all, unsigned char *__restrict__ hard,
-                                                                unsigned char *__restrict__ vis, int *__restrict__ cnt, int accept_none)
+                                                                unsigned char *__restrict__ vis, int *__restrict__ cnt, int accept_none,
+                                                                int nviews)
 {
     __shared__ double4 s_stage[kHprThreads];
     __shared__ unsigned long long s_mask;
-    const int view = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int ntiles = ceil_div_dev(n, kHprThreads);
+    int view, own;
+    hpr_block(ntiles, nviews, view, own);
     const double *fl = fl_all + (size_t)view * n * 3;
-    const int pos = blockIdx.x * kHprThreads + tid;
-    const int ntiles = ceil_div_dev(n, kHprThreads), own = blockIdx.x;
+    const int pos = own * kHprThreads + tid;
     const HprTile *tiles = tiles_all + (size_t)view * ntiles;
     HprFrame f;
     bool active = false;
@@ -617,20 +637,22 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                                                          const int *__restrict__ hardcnt, unsigned char *__restrict__ vis,
                                                          int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull, int max_clips,
                                                          int split, int4 *__restrict__ surv, double2 *__restrict__ surv_poly,
-                                                         int *__restrict__ und, int straggle_from, int straggle_lanes)
+                                                         int *__restrict__ und, int straggle_from, int straggle_lanes, int nviews)
 {
     __shared__ double2 s_poly[kHprMaxV * kHprThreads];
     __shared__ double4 s_stage[kHprThreads];      // 64 tile records while testing, then one tile's candidates
     __shared__ unsigned long long s_mask;
     static_assert(sizeof(HprTile) * kHprBatch <= sizeof(double4) * kHprThreads, "the tile records share the staging area");
-    const int view = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int view, blk;
+    hpr_block(ceil_div_dev(n, kHprThreads), nviews, view, blk);
     const double *fl = fl_all + (size_t)view * n * 3;
     // block g of a view owns the points of rank 128 g .. 128 g + 127 in the view's list of points the accept pass
     // left over; its tile order starts at the tile of its middle point (hpr_base_tile: the oracle's rule too)
     const int nhard = hardcnt[view];
-    if ((int)blockIdx.x * kHprThreads >= nhard) return;
+    if (blk * kHprThreads >= nhard) return;
     const int *hl = hardlist + (size_t)view * n;
-    const int rank = blockIdx.x * kHprThreads + tid;
+    const int rank = blk * kHprThreads + tid;
     const int pos = rank < nhard ? hl[rank] : -1;
     const int i = pos >= 0 ? perm[(size_t)view * n + pos] : -1;
     const int ntiles = ceil_div_dev(n, kHprThreads), own = hpr_base_tile(hl, nhard, rank);
@@ -1333,8 +1355,8 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     const int max_clips = (no_cull & 64) ? 0x7fffffff : (env_clips > 0 ? env_clips : (ntiles >= kHprRimTiles ? 48 : 256));      // (large clouds: 96 -> 48 once the wave-per-point pass clipped by all lanes: 2 x 165546 24.9 -> 21.5 ms)
     unsigned char *hard = (unsigned char *)(ws + o_hard);
     int *hardlist = (int *)(ws + o_hl), *hardcnt = (int *)(ws + o_hc);
-    hipLaunchKernelGGL(hpr_accept_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
-                       (const HprTile *)tiles, hard, visible, counts, (no_cull & 16) ? 1 : 0);
+    hipLaunchKernelGGL(hpr_accept_kernel, dim3(ntiles * c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
+                       (const HprTile *)tiles, hard, visible, counts, (no_cull & 16) ? 1 : 0, c);
     hipLaunchKernelGGL(hpr_compact_kernel, dim3(c), dim3(1024), 0, stream, n, (const unsigned char *)hard, hardlist, hardcnt);
     // the undecided points' polygons: at most one per listed point; the listed points are counted by now only on the
     // device, so the buffer is sized for the worst case the accept pass leaves in practice (every point) lazily:
@@ -1367,9 +1389,9 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     static const int env_sl = getenv("GENPC_HPR_STRAGGLE_LANES") ? atoi(getenv("GENPC_HPR_STRAGGLE_LANES")) : kHprThreads;
     static const int env_st = getenv("GENPC_HPR_STRAGGLE_TILES") ? atoi(getenv("GENPC_HPR_STRAGGLE_TILES")) : 0;
     const int straggle_from = ntiles >= env_st ? env_sf : 0x7fffffff, straggle_lanes = env_sl;
-    hipLaunchKernelGGL(hpr_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
+    hipLaunchKernelGGL(hpr_kernel, dim3(ntiles * c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
                        (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull,
-                       max_clips, split, surv, surv_poly, und, straggle_from, straggle_lanes);
+                       max_clips, split, surv, surv_poly, und, straggle_from, straggle_lanes, c);
     if (!check(hipGetLastError(), "hpr launch")) return 0;
     int st[4] = {0, 0, 0, 0};
     if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
