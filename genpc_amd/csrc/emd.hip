@@ -153,17 +153,30 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                                                           float4 *__restrict__ parts, int *__restrict__ arrive,
                                                           int *__restrict__ second, int zmax,
                                                           unsigned long long *__restrict__ chain_head,
-                                                          unsigned long long *__restrict__ chain_next, unsigned stamp)
+                                                          unsigned long long *__restrict__ chain_next, unsigned stamp, int G, int nb)
 {
     constexpr int kTile = TILE, kLoadsPerThread = TILE / 256;
     // one tile of objects as four planes (x, y, z, price): a 16-byte read delivers four consecutive objects' x as two
     // register pairs for the packed fp32 filter below
     __shared__ __attribute__((aligned(16))) float sX[kTile], sY[kTile], sZ[kTile], sP[kTile];
-    const int batch = blockIdx.y;
+    // 1-D grid of G * nb blocks.  The blocks of a cloud run on ONE XCD (blocks go to the XCDs round-robin by linear id), for
+    // the largest multiple of 8 clouds: every block of a cloud re-reads the cloud's objects and prices tile by tile, and with
+    // its blocks on all eight XCDs every 4 MB L2 held every cloud (8 x 32768: 4.2 MB; 14.9 -> 13.9 ms, 64 x 2048 1.74 -> 1.54).
+    int batch, bx;
+    {
+        const int lin = blockIdx.x, nb8 = nb & ~7;      // (the clouds beyond a multiple of 8: the (G, nb) order)
+        if (lin < G * nb8) {
+            const int k = lin >> 3;
+            batch = 8 * (k / G) + (lin & 7);
+            bx = k % G;
+        } else {
+            batch = nb8 + (lin - G * nb8) / G;
+            bx = (lin - G * nb8) % G;
+        }
+    }
     const int U = cnt[batch];
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt_next[batch] = 0;   // filled by this round's assign
+    if (bx == 0 && threadIdx.x == 0) cnt_next[batch] = 0;   // filled by this round's assign
     if (U == 0) return;
-    const int G = gridDim.x;
     const int P = force_p > 0 ? force_p : pick_p(U, G);
     const int per_wave = kWave / P;
     const int per_block = kEBlock / P;
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
     const int tps = (ntiles + Z - 1) / Z;               // tiles per slice
     const int units = NB * Z;
 
-    for (int unit = blockIdx.x; unit < units; unit += G) {
+    for (int unit = bx; unit < units; unit += G) {
         const int grp = unit % NB;
         const int zs = unit / NB;
         const int k_lo = zs * tps * kTile;
@@ -754,7 +767,7 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
         {
             typedef void (*bid_fn)(int, const float *, const float *, const float *, float, const int *, const int *,
                                    int *, int *, float *, float *, int, float4 *, int *, int *, int, unsigned long long *,
-                                   unsigned long long *, unsigned);
+                                   unsigned long long *, unsigned, int, int);
             static const int zmax_env = getenv("GENPC_EMD_ZMAX") ? atoi(getenv("GENPC_EMD_ZMAX")) : kZMax;
             const int zmax = zmax_env < 1 ? 1 : (zmax_env > kZMax ? kZMax : zmax_env);
             // Lanes per bidder.  Round 0 has no filter seeds: the fewer lanes share a bidder, the sooner a
@@ -782,10 +795,10 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
                                          : (nofilter ? emd_bid_kernel<0, 0, 1024, 1> : emd_bid_kernel<0, 1, 1024, 1>))
                                   : (fma ? (nofilter ? emd_bid_kernel<1, 0, 2048, 1> : emd_bid_kernel<1, 1, 2048, 1>)
                                          : (nofilter ? emd_bid_kernel<0, 0, 2048, 1> : emd_bid_kernel<0, 1, 2048, 1>));
-            hipLaunchKernelGGL(f, dim3(G, b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price, eps,
+            hipLaunchKernelGGL(f, dim3(G * b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price, eps,
                                (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
                                max_increments, force_p, parts, arrive, second, zmax, use_chain ? chain_head : (unsigned long long *)nullptr,
-                               chain_next, stamp);
+                               chain_next, stamp, G, b);
         }
         if (use_chain) {
             hipLaunchKernelGGL(emd_settle_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
