@@ -752,13 +752,32 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
                 }
             }
         }
+        // A list of several fills: the point indices in sorted order first (16-bit: the bitmap path holds n <= 65536), in the
+        // LDS of `part`, which is not needed before the epilogue -- every fill then takes its 1024 entries from there instead
+        // of walking the whole list for them (a tile of 5000 entries: five fills of five dependent global reads per thread).
+        static_assert(sizeof(part) >= kTileCap * sizeof(unsigned short) && 32 * kRankWords <= 65536, "the sorted indices fit `part`");
+        unsigned short *s_sorted = (unsigned short *)&part[0][0][0];
+        const bool presorted = L > kSplatCap;      // (implies bitmap)
+        if (presorted) {
+            __syncthreads();      // s_pref is ready
+            for (int i = threadIdx.x; i < L; i += kSplatBlock) {
+                const int myj = (i < kSplatCap ? my_ent : bin_idx[i]) >> 2;
+                s_sorted[s_pref[myj >> 5] + __popc(s_bits[myj >> 5] & ((1u << (myj & 31)) - 1u))] = (unsigned short)myj;
+            }
+        }
         // the sorted list is drawn kSplatCap entries at a time (one fill, unless the tile is crowded beyond that)
         for (int f0 = 0; f0 < L; f0 += kSplatCap) {
             __syncthreads();      // ranks ready / the previous fill's gather is done with the list
             const int Lf = min(kSplatCap, L - f0);
-            for (int i = threadIdx.x; i < L; i += kSplatBlock) {
-                const int myj = (i < kSplatCap ? my_ent : bin_idx[i]) >> 2;
-                const int rank = (bitmap ? s_pref[myj >> 5] + __popc(s_bits[myj >> 5] & ((1u << (myj & 31)) - 1u)) : rank0) - f0;
+            for (int i = threadIdx.x; i < (presorted ? Lf : L); i += kSplatBlock) {
+                int myj, rank;
+                if (presorted) {
+                    myj = s_sorted[f0 + i];
+                    rank = i;
+                } else {
+                    myj = (i < kSplatCap ? my_ent : bin_idx[i]) >> 2;
+                    rank = (bitmap ? s_pref[myj >> 5] + __popc(s_bits[myj >> 5] & ((1u << (myj & 31)) - 1u)) : rank0) - f0;
+                }
                 if (rank < 0 || rank >= Lf) continue;
                 const float4 qh = uvr[myj];
                 float cr = 1.0f, cg = 1.0f, cb = 1.0f;
