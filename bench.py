@@ -400,10 +400,9 @@ def synth_scan(seed, n):
     c = complete.mean(0)
     posed = ((complete - c) * s) @ R.T + c + t
     front = posed[posed[:, 2] > np.median(posed[:, 2]) - 0.02]
-    # resampled to n like a denser sensor would: repeated picks get 2e-4 of noise, not exact copies (a cloud of
-    # exact triplicates is the tie case of the NN filter's proof: its exhaustive pass, measured 703 us per
-    # call at 8 x 32768 against 561 us for the filter itself -- a property of the generator, not of scans)
-    partial = front[rng.integers(0, front.shape[0], n)] + rng.normal(0.0, 2e-4, (n, 3))
+    # plain resampling -- repeated picks are EXACT copies (round 3 added noise here to dodge the NN filter's
+    # tie case; the alignment loop now marks the copies once per call instead: csrc/nn_dedupe.hip)
+    partial = front[rng.integers(0, front.shape[0], n)]
     return complete.astype(np.float32), partial.astype(np.float32), posed.astype(np.float32)
 
 

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GENPC_LIB: an alternative build of the same library (kernel experiments only)
 LIB_PATH = os.environ.get("GENPC_LIB") or os.path.join(_HERE, "lib", "libgenpc_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -29,6 +29,7 @@ SIGNATURES = {
     "genpc_release_workspace": (_i, []),
     "genpc_nn_tune": (_i, [_i, _i]),
     "genpc_nn_stats": (_i, [_vp, _i, _vp]),
+    "genpc_nn_duplicate_mask": (_i, [_i, _i, _vp, _vp, _vp]),
     "genpc_nn_profile": (ctypes.c_float, [_i]),
     "genpc_chamfer_forward": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_nm_distance": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp]),

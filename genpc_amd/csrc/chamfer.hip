@@ -36,6 +36,8 @@
 
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 
 namespace genpc {
 
@@ -655,9 +657,45 @@ static void launch_r(const NNArgs &a, int blocks, hipStream_t st)
         hipLaunchKernelGGL((nn_forward_kernel<R, 0>), dim3(blocks), dim3(kBlock), 0, st, a);
 }
 
-static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0, float *d0, int *i0,
-                      const float *q1, int n1, const float *t1, int m1, float *d1, int *i1, hipStream_t st,
-                      float radius2 = __builtin_inff())
+// Duplicate pre-pass policy of the f16 filter (nn_dedupe.hip).  The pre-pass is two launches with three dependent
+// memory round trips each: 26 us on an idle GPU whatever the size, 59 us at 8 x 32768 x 2 points -- against 33 us for
+// the whole headline step.  So it runs
+//   * when the caller brings the masks (the alignment loop, ICP and the scale search make them once per call: their
+//     clouds' duplicates are the same at every step / for every candidate), or
+//   * while the input asks for it.  The finish kernel adds (a sample of) the queries it had to re-do exhaustively to
+//     a host-visible word, the pre-pass adds (a sample of) the copies it found to another; the NEXT call reads both:
+//     many re-dos switch the pre-pass on, a pre-pass that finds next to nothing switches it off again.  The words are
+//     read without any synchronisation -- a stale value delays the switch by a call; results do not depend on it (the
+//     masks only remove targets that can never be reported).
+// GENPC_NN_DEDUPE=0 / 1 forces it off / on (A/B; tests: hooks 2048 / 4096 of genpc_nn_tune).
+struct DedupeHint {
+    unsigned *host = nullptr;          // cumulative, written by the GPU: [0] exhaustive re-dos, [1] copies found, [2] pre-passes completed (hipHostMalloc, mapped)
+    std::mutex mu;
+    unsigned seen[3] = {0, 0, 0};      // what the host has accounted for
+    bool on = false;
+};
+static DedupeHint *dedupe_hint()
+{
+    static DedupeHint hints[16];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    DedupeHint &h = hints[dev];
+    if (!h.host) {
+        std::lock_guard<std::mutex> l(mu);
+        if (!h.host) {
+            void *p = nullptr;
+            if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+            for (int i = 0; i < 16; i++) ((volatile unsigned *)p)[i] = 0;
+            h.host = (unsigned *)p;
+        }
+    }
+    return &h;
+}
+
+int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0, float *d0, int *i0,
+               const float *q1, int n1, const float *t1, int m1, float *d1, int *i1, hipStream_t st,
+               float radius2, const unsigned *dup0, const unsigned *dup1, int dup_shared)
 {
     // A direction with no queries or no targets does nothing (the reference's
     // loops do not execute, outputs keep the caller's zeros).
@@ -676,6 +714,7 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
     const float *ts[2] = {t0, t1};
     float *ds[2] = {d0, d1};
     int *is[2] = {i0, i1};
+    const unsigned *dups[2] = {dup0, dup1};
     int nqs[2] = {n0, n1}, nts[2] = {m0, m1};
     int nd = 0;
     int nt_max = 0;
@@ -684,6 +723,8 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         NNDir &D = a.dir[nd++];
         D.q = qs[d]; D.t = ts[d]; D.out_d = ds[d]; D.out_i = is[d];
         D.nq = nqs[d]; D.nt = nts[d];
+        D.dupmask = dups[d];
+        D.dup_shared = dups[d] ? dup_shared : 0;
         if (D.nt > nt_max) nt_max = D.nt;
     }
     a.ndir = nd;
@@ -859,6 +900,55 @@ static int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0,
         }
     }
     if (path == 2) {
+        // exact duplicates among the targets (policy above nn_forward)
+        static const int env_dd = getenv("GENPC_NN_DEDUPE") ? atoi(getenv("GENPC_NN_DEDUPE")) : -1;
+        const int force = (a.debug & 2048) ? 0 : ((a.debug & 4096) ? 1 : env_dd);
+        DedupeHint *H = dedupe_hint();
+        bool own_masks = true;
+        for (int d = 0; d < nd; d++) own_masks = own_masks && a.dir[d].dupmask != nullptr;
+        if (force == 0) {
+            for (int d = 0; d < nd; d++) a.dir[d].dupmask = nullptr;
+        } else if (!own_masks) {
+            long long queries = 0, targets = 0;
+            for (int d = 0; d < nd; d++) { queries += (long long)b * a.dir[d].nq; targets += (long long)b * a.dir[d].nt; }
+            bool run = force == 1;
+            if (!run && H) {
+                // Evidence the GPU has delivered since the last look (cumulative words: a host that runs ahead of the
+                // GPU simply sees no news and keeps its state): re-dos of calls that ran without the pre-pass switch
+                // it on, completed pre-passes that found next to nothing switch it off.
+                std::lock_guard<std::mutex> l(H->mu);
+                volatile unsigned *hv = H->host;
+                const unsigned redo = hv[0] - H->seen[0], found = hv[1] - H->seen[1], done = hv[2] - H->seen[2];
+                H->seen[0] += redo; H->seen[1] += found; H->seen[2] += done;
+                if (!H->on) {
+                    if ((long long)redo * 32 > queries) H->on = true;
+                } else if (done > 0 && (long long)(found / done) * 32 < targets) {
+                    H->on = false;
+                }
+                run = H->on;
+            }
+            if (run) {
+                // one pre-pass per distinct target cloud (the two directions' targets are each other's queries)
+                const float *pp[2];
+                int pn[2];
+                unsigned *pm[2];
+                size_t words[2];
+                int nc = 0;
+                for (int d = 0; d < nd; d++) {
+                    pp[nc] = a.dir[d].t;
+                    pn[nc] = a.dir[d].nt;
+                    words[nc] = (nn_dedupe_mask_words(b, pn[nc]) + 63) & ~(size_t)63;
+                    nc++;
+                }
+                unsigned *mw = (unsigned *)workspace(25, (words[0] + (nc > 1 ? words[1] : 0)) * sizeof(unsigned), st);
+                if (!mw) return 0;
+                pm[0] = mw;
+                pm[1] = mw + words[0];
+                if (!launch_nn_dedupe(b, nc, pp, pn, pm, H ? H->host + 1 : nullptr, st)) return 0;
+                for (int d = 0; d < nd; d++) { a.dir[d].dupmask = pm[d]; a.dir[d].dup_shared = 0; }
+            }
+        }
+        a.hint = H ? H->host : nullptr;
         // bookkeeping unit: the finish kernel re-reads 16 targets per tile of every candidate unit --
         // per QUERY, while the filter's work is per PAIR: short target clouds (many queries per
         // pair) take 64-target units (half the re-read, +10 % filter VALU), long ones 128

@@ -19,7 +19,7 @@
 // on the ICP result, so only the winner needs an ICP solve.
 // Numerics follow oracle/genpc_oracle_geom.c (oracle_icp): same fp32 NN, sums in
 // double; sums are reduced in a different order (1e-12 relative).
-#include "common.h"
+#include "nn.h"
 #include "../../include/genpc_hip.h"
 
 #include <math.h>
@@ -311,11 +311,22 @@ GENPC_API int genpc_icp_batch(int k, int ns, const float *source, int nt, const 
                            (const float *)nullptr, tgt);
         tq = tgt;
     }
+    // the target does not move: its duplicate mask (nn_dedupe.hip) is made once for all passes
+    // (one row: the k candidates share the target)
+    unsigned *dup_t = (unsigned *)workspace(27, nn_dedupe_mask_words(1, nt) * sizeof(unsigned), st);
+    if (!dup_t) return 0;
+    {
+        const float *dp[2] = {target, nullptr};
+        const int dn[2] = {nt, 0};
+        unsigned *dm[2] = {dup_t, nullptr};
+        if (!launch_nn_dedupe(1, 1, dp, dn, dm, nullptr, st)) return 0;
+    }
     const float md2 = (float)(max_dist * max_dist);
     for (int pass = 0; pass <= max_iter; pass++) {
         hipLaunchKernelGGL(icp_transform_kernel, dim3(gx(ns), k), dim3(kIBlock), 0, st, ns, source,
                            (const double *)out_T, pts);
-        if (genpc_nm_distance(k, ns, pts, nt, tq, d, idx, stream) != 1) return 0;
+        if (nn_forward(k, 1, pts, ns, tq, nt, d, idx, nullptr, 0, nullptr, 0, nullptr, nullptr, st, __builtin_inff(), dup_t, nullptr, 1) != 1)
+            return 0;
         hipLaunchKernelGGL(icp_accum_kernel, dim3(gx(ns), k), dim3(kIBlock), 0, st, ns, (const float *)pts, target,
                            (const float *)d, (const int *)idx, md2, accum);
         hipLaunchKernelGGL(icp_update_kernel, dim3(ceil_div(k, 64)), dim3(64), 0, st, k, ns, accum, out_T, state, stats,
@@ -345,7 +356,19 @@ GENPC_API int genpc_scale_search_scores(int k, int ns, const float *source, int 
     hipLaunchKernelGGL(replicate_scale_kernel, dim3(gx(ns), k), dim3(kIBlock), 0, st, ns, source, scales, src);
     hipLaunchKernelGGL(replicate_scale_kernel, dim3(gx(nt), k), dim3(kIBlock), 0, st, nt, target,
                        (const float *)nullptr, tgt);
-    if (genpc_chamfer_forward(k, ns, src, nt, tgt, d1, i1, d2, i2, stream) != 1) return 0;
+    // every candidate is a scaled copy of the one source against a copy of the one target: equal points stay equal under
+    // any scale, so ONE row of duplicate marks per cloud (nn_dedupe.hip) serves all k candidates
+    const size_t w_s = (nn_dedupe_mask_words(1, ns) + 63) & ~(size_t)63;
+    unsigned *dup_s = (unsigned *)workspace(27, (w_s + nn_dedupe_mask_words(1, nt)) * sizeof(unsigned), st);
+    if (!dup_s) return 0;
+    unsigned *dup_t = dup_s + w_s;
+    {
+        const float *dp[2] = {target, source};
+        const int dn[2] = {nt, ns};
+        unsigned *dm[2] = {dup_t, dup_s};
+        if (!launch_nn_dedupe(1, 2, dp, dn, dm, nullptr, st)) return 0;
+    }
+    if (nn_forward(k, 2, src, ns, tgt, nt, d1, i1, tgt, nt, src, ns, d2, i2, st, __builtin_inff(), dup_t, dup_s, 1) != 1) return 0;
     hipLaunchKernelGGL(cd_score_kernel, dim3(k), dim3(kIBlock), 0, st, ns, (const float *)d1, nt, (const float *)d2,
                        cd_inv_weight, scores);
     return check(hipGetLastError(), "scale_search_scores launch") ? 1 : 0;

@@ -37,6 +37,8 @@ struct NNDir {
     const uint4 *arec;      // pre-split targets [B][4 planes][ntp] x 16 B
     int ntp, ntmax;         // nt rounded up to 128; entries of tmaxp per batch element
     int fin_begin;          // first nn_finish_kernel block of this direction
+    const unsigned *dupmask;   // [B][ceil(nt / 32)]: targets that are later copies of a bit-identical target (nn_dedupe.hip), or null
+    int dup_shared;            // the mask is [1][ceil(nt / 32)] and serves every batch element (scaled / replicated copies of one cloud)
     int qblocks;       // ceil(nq / (256*R))
     int slices;        // S for this direction: ceil(nt / slice_len)
     int block_begin;   // first block id of this direction
@@ -52,6 +54,8 @@ struct NNArgs {
     int debug;         // experiment switches (GENPC_NN_DEBUG): 1 skip index recovery, 2 skip merge, 4 skip main loop
     int fma;           // arithmetic mode of this call (read once at the entry point; host side only)
     unsigned long long *stats;   // hook 512: [0] queries, [1] exhaustive re-dos, [2] exact pieces; else null
+    int hint_stride;   // every hint_stride-th finish block reports to `hint` (scaled up)
+    unsigned *hint;    // host-visible word: exhaustive re-dos of the filtered path are added to it (dedupe policy, chamfer.hip), or null
     float radius2;     // grid path only: search limit (squared); +inf = none.  Queries with no target within it get (+inf, -1)
 };
 
@@ -296,5 +300,15 @@ __device__ __forceinline__ void rescan_half(const float *__restrict__ T, int nt,
 int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, long long total_blocks, hipStream_t st);
 int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float t2min, hipStream_t st);
 int launch_nn_grid(const NNArgs &a, hipStream_t st);
+size_t nn_dedupe_mask_words(int b, int n);
+int launch_nn_dedupe(int b, int nclouds, const float *const pts[2], const int n[2], unsigned *const masks[2], unsigned *hint,
+                     hipStream_t st);
+// The bidirectional / one-directional nearest-neighbour launch behind genpc_chamfer_forward / genpc_nm_distance
+// (chamfer.hip).  dup0 / dup1: duplicate masks of the TARGET clouds of direction 0 / 1 when the caller keeps them
+// across calls (the alignment loop and ICP: both clouds' duplicates are the same at every step), else null;
+// dup_shared: one mask row serves all batch elements (candidates that are scaled copies of one cloud).
+int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0, float *d0, int *i0, const float *q1,
+               int n1, const float *t1, int m1, float *d1, int *i1, hipStream_t st, float radius2 = __builtin_inff(),
+               const unsigned *dup0 = nullptr, const unsigned *dup1 = nullptr, int dup_shared = 0);
 
 }  // namespace genpc

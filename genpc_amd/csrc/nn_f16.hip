@@ -135,13 +135,19 @@ __global__ __launch_bounds__(WV * kWave, W) void nn_f16_kernel(NNArgs a)
     // with every wave waiting for the slowest -- tools/nn_timeline.py).
     constexpr int kPer = HT / kThreads;
     float pre[kPer][3];
+    // later copies of a bit-identical target (nn_dedupe.hip; bit i: this thread's i-th target of the tile) are staged like
+    // padding: the first copy answers for them, and three equal minima in one list would send the query to the exhaustive pass
+    const unsigned *__restrict__ dupm = D.dupmask ? D.dupmask + (D.dup_shared ? (size_t)0 : (size_t)batch * ((nt + 31) >> 5)) : nullptr;
+    unsigned predup = 0u;
     auto prefetch = [&](int t0) {
+        predup = 0u;
 #pragma unroll
         for (int i = 0; i < kPer; i++) {
             int t = t0 + i * kThreads + threadIdx.x;
             t = t < nt ? t : nt - 1;
 #pragma unroll
             for (int k = 0; k < 3; k++) pre[i][k] = T[(size_t)t * 3 + k];
+            if (dupm) predup |= ((dupm[t >> 5] >> (t & 31)) & 1u) << i;
         }
     };
     const bool resident = k_end - k_begin <= HT;        // block-uniform
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(WV * kWave, W) void nn_f16_kernel(NNArgs a)
                 const unsigned pt = split2(tts * 0.00390625f);
                 uint4 V0 = make_uint4(dup_lo(px), dup_hi(px), dup_lo(py), dup_hi(py));
                 uint4 V1 = make_uint4(dup_lo(pz), dup_hi(pz), pt, 0u);
-                if (t >= tn) {
+                if (t >= tn || ((predup >> i) & 1u)) {
                     // padding: |t'|^2 = +inf (f16 0x7c00) x 2^8 never wins, the other terms are 0
                     V0 = make_uint4(0u, 0u, 0u, 0u);
                     V1 = make_uint4(0u, 0u, 0x7c00u, 0u);

@@ -222,6 +222,12 @@ __global__ __launch_bounds__(kBlock) void nn_finish_kernel(NNArgs a, int nl, int
     }
     __syncthreads();
     const int nflag = s_misc[1];
+    // queries the filter could not settle: the next call's duplicate pre-pass policy reads this (chamfer.hip); blocks
+    // without such queries -- all of them on ordinary input -- do nothing
+    // (sampled: every hint_stride-th block, scaled up -- at most 16 atomics on host memory per launch; they cost ~0.3 us
+    // each and the kernel does not end before the last one has landed)
+    if (nflag && a.hint && threadIdx.x == 0 && blockIdx.x % a.hint_stride == 0 && !(tmax2 != tmax2) && tmax2 < __builtin_inff())
+        __hip_atomic_fetch_add(a.hint, (unsigned)(nflag * a.hint_stride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (a.stats && threadIdx.x == 0) {
         atomicAdd(&a.stats[0], (unsigned long long)min(kFQ, nq - fb * kFQ));
         atomicAdd(&a.stats[1], (unsigned long long)nflag);
@@ -243,6 +249,7 @@ int launch_nn_finish(NNArgs &a, int nl, int upieces, float kqt, float ktt, float
         set_error("chamfer: problem too large for one launch");
         return 0;
     }
+    a.hint_stride = (int)ceil_div64(fb, 16);
     if (a.fma)
         hipLaunchKernelGGL((nn_finish_kernel<1>), dim3((unsigned)fb), dim3(kBlock), 0, st, a, nl, upieces, kqt, ktt, t2min);
     else

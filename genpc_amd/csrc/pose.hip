@@ -21,7 +21,7 @@
 //                           best-of-starts bookkeeping
 // HBM traffic per iteration is O(N): ~24 B/point for the transform, ~28 B/point for
 // the gradient pass; the NN launch dominates (VALU-bound, see chamfer.hip).
-#include "common.h"
+#include "nn.h"
 #include "../../include/genpc_hip.h"
 
 #include <math.h>
@@ -1881,6 +1881,20 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // reference image of the partial cloud (render_reference_image, diff_obj_pose.py:108-134)
     if (mask && !mask_prepare_ref(b, np, partial, partial_col, radius, render_size, m, st)) return 0;
 
+    // Exact duplicates (a partial cloud resampled with replacement, a crop pad-repeated to a fixed size) are the same
+    // at every step -- the partial cloud does not move and equal rest-frame points are posed to equal points -- so
+    // the filter's duplicate masks (nn_dedupe.hip) are made once per call, on the rest-frame clouds.
+    const size_t w_p = (nn_dedupe_mask_words(b, np) + 63) & ~(size_t)63, w_c = (nn_dedupe_mask_words(b, nc) + 63) & ~(size_t)63;
+    unsigned *dup_p = (unsigned *)workspace(26, (w_p + w_c) * sizeof(unsigned), st);
+    if (!dup_p) return 0;
+    unsigned *dup_c = dup_p + w_p;
+    {
+        const float *dp[2] = {partial, complete};
+        const int dn[2] = {np, nc};
+        unsigned *dm[2] = {dup_p, dup_c};
+        if (!launch_nn_dedupe(b, 2, dp, dn, dm, nullptr, st)) return 0;
+    }
+
     const int gb = ceil_div(b, 64);
     hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, -1, 0);
     // (every block of the gradient kernels ends in 13-22 double atomics on its image's accumulators: with many images in
@@ -1899,7 +1913,8 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
             else
                 hipLaunchKernelGGL(pose_transform_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
                                    (const float *)center, 4, (const float *)S->params, kStateFloats, pts);
-            if (genpc_chamfer_forward(b, nc, pts, np, partial, d1, i1, d2, i2, stream) != 1) return 0;
+            if (nn_forward(b, 2, pts, nc, partial, np, d1, i1, partial, np, pts, nc, d2, i2, st, __builtin_inff(), dup_p, dup_c) != 1)
+                return 0;
             hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, st, nc, complete, (const float *)center,
                                4, (const float *)S->params, kStateFloats, np, partial, (const float *)d1,
                                (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, accum);

@@ -46,7 +46,8 @@ int genpc_release_workspace(void);
  * filter (default), 1 fp32-MFMA filter (default below ~6 M pairs), 0 VALU brute force, < 0 keep
  * (2 was the split-bf16 filter, removed in round 3: rejected).  hooks: bit mask of test hooks
  * (8: every query takes the exhaustive pass, 16: every listed tile is evaluated
- * exactly, 512: count what the filtered paths do, see genpc_nn_stats), < 0 keep.  Applies to calls made by the CALLING
+ * exactly, 512: count what the filtered paths do, see genpc_nn_stats, 2048 / 4096: duplicate pre-pass of the f16
+ * filter off / on whatever the policy says), < 0 keep.  Applies to calls made by the CALLING
  * host thread only (thread-local; other threads keep the defaults).  Returns the previous
  * path.  Environment (read once, at first use): GENPC_NN_PATH (valu | mfma32 | f16 |
  * grid), GENPC_NN_DEBUG; A/B switches of the f16 filter: GENPC_NN_HT=1024, GENPC_NN_NOWIDE.                                                          */
@@ -56,6 +57,12 @@ int genpc_nn_tune(int path, int hooks);
  * pass (filter proof failed: exact ties, non-finite input), out[2] exact re-evaluations of
  * 16-/32-target pieces.  Synchronises `stream`; reset != 0 zeroes them afterwards.      */
 int genpc_nn_stats(unsigned long long out[3], int reset, void *stream);
+/* Exact-duplicate pre-pass of the filtered nearest-neighbour path (csrc/nn_dedupe.hip): mask[e][k / 32] bit k % 32 is set
+ * iff point k of cloud e has bit-identical coordinates to a point of lower index in the same cloud -- such a target can
+ * never be reported by the reference's first-index-wins scan (chamfer3D.cu:30-71).  xyz [b, n, 3] float, mask
+ * [b, ceil(n / 32)] uint32 (device, every word written).  The nearest-neighbour entry points run it by themselves where
+ * it pays (hooks 2048 / 4096 of genpc_nn_tune force it off / on); exposed for tests.  Returns 1 / 0 / -1.            */
+int genpc_nn_duplicate_mask(int b, int n, const float *xyz, unsigned *mask, void *stream);
 /* Kernel-level timing for bench.py: while enabled, HIP events bracket the filter kernel
  * (nn_f16_kernel) of every nearest-neighbour call on its stream.  Returns the duration
  * in ms of the last bracketed launch (-1 if none), then sets the switch to `enable`. */
