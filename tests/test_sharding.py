@@ -171,8 +171,8 @@ def test_bench_scan_workload_two_ranks_gloo():
     env.pop("RANK", None)
     bench = os.path.join(ROOT, "bench.py")
 
-    def run(gpus):
-        p = subprocess.run([sys.executable, bench, "--gpus", str(gpus), "--workload", "c4", "--steps", "2", "--warmup", "1",
+    def run(gpus, workload="c4"):
+        p = subprocess.run([sys.executable, bench, "--gpus", str(gpus), "--workload", workload, "--steps", "2", "--warmup", "1",
                             "--no-extra"], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -184,4 +184,11 @@ def test_bench_scan_workload_two_ranks_gloo():
     assert two["config"]["scans"] == 59 and two["steps"] == 2 and two["value"] > 0 and two["extra"]["stub"] is True
     assert one["n_gpus"] == 1 and one["ranks_seen"] == [0]
     assert two["extra"]["scan_table_checksum"] == one["extra"]["scan_table_checksum"]
-    assert two["extra"]["mean_cd_l1_vs_true_pose"] == one["extra"]["mean_cd_l1_vs_true_pose"]
+    assert two["extra"]["mean_cd_l1"] == one["extra"]["mean_cd_l1"]
+    # every rank's own scan count and elapsed time travel with the line (load imbalance: 30 + 29)
+    assert [r["scans"] for r in two["per_rank"]] == [30, 29] and all(r["elapsed_s"] >= 0 for r in two["per_rank"])
+    assert [r["scans"] for r in one["per_rank"]] == [59]
+    # config 3 (13 bundled scans, metric only) through the same path: 7 + 6
+    three = run(2, "c3")
+    assert three["config"]["scans"] == 13 and [r["scans"] for r in three["per_rank"]] == [7, 6]
+    assert three["extra"]["scan_table_checksum"] == run(1, "c3")["extra"]["scan_table_checksum"]
