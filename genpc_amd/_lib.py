@@ -36,6 +36,8 @@ SIGNATURES = {
     "genpc_nm_distance_within": (_i, [_i, _i, _vp, _i, _vp, _f, _vp, _vp, _vp]),
     "genpc_chamfer_backward": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_emd_forward": (_i, [_i, _i, _i] + [_vp] * 14 + [_f, _i, _vp]),
+    "genpc_emd_tune": (_i, [_i, _i]),
+    "genpc_emd_stats": (_i, [_vp, _i, _vp]),
     "genpc_emd_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_get_uvs": (_i, [_i, _i, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
     "genpc_uv_to_pixels": (_i, [_i, _vp, _f, _i, _vp, _vp]),

@@ -32,60 +32,13 @@
 // equal (a tie for first place) the bidder's lanes re-scan and select the tied
 // object with the smallest (reference-thread, index) key, so assignments agree
 // with the oracle even on clouds with duplicated points.
-#include "common.h"
+#include "emd.h"
 #include "../../include/genpc_hip.h"
 
 #include <stdlib.h>
 #include <type_traits>
 
 namespace genpc {
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int kEBlock = 256;
-// objects per LDS tile: template parameter TILE of the bid kernel, 2048 (32 KiB as float4) or 1024 (16 KiB)
-constexpr int kZMax = 4;            // object slices per bidder group in the late-round split (measured best of 1..16)
-constexpr int kSplitMaxBidders = 4096;   // bidders per batch element the split scratch can hold
-constexpr int kArrivePerBatch = 1024;    // arrival counters per batch element (>= kSplitMaxBidders * 64 / 256)
-
-template <int FMA>
-__device__ __forceinline__ float sqdist_e(float dx, float dy, float dz)
-{
-    if (FMA) {
-        float t = __fmul_rn(dy, dy);
-        t = __fmaf_rn(dx, dx, t);
-        return __fmaf_rn(dz, dz, t);
-    } else {
-        float a = __fmul_rn(dx, dx);
-        float b = __fmul_rn(dy, dy);
-        float c = __fmul_rn(dz, dz);
-        return __fadd_rn(__fadd_rn(a, b), c);
-    }
-}
-
-// emd_cuda.cu:142-146
-template <int FMA>
-__device__ __forceinline__ float bid_value(float x1, float y1, float z1, float x2, float y2, float z2, float price)
-{
-    float s = sqdist_e<FMA>(x2 - x1, y2 - y1, z2 - z1);
-    float r = sqrtf(s);   // correctly rounded (hipcc default); __fsqrt_rn is the ~1 ulp native sqrt
-    return (float)((3.0 - (double)r) - (double)price);
-}
-
-// float atomic max; increments are >= 0 in every sane call (eps >= 0), where the
-// int ordering of the bit patterns equals the float ordering even against the
-// -1e9 reset value.  Negative values take the CAS loop of emd_cuda.cu:10-20.
-__device__ __forceinline__ void atomic_max_float(float *addr, float val)
-{
-    if (val >= 0.0f) {
-        atomicMax((int *)addr, __float_as_int(val));
-    } else {
-        int ret = __float_as_int(*addr);
-        while (val > __int_as_float(ret)) {
-            int old = ret;
-            if ((ret = atomicCAS((int *)addr, old, __float_as_int(val))) == old) break;
-        }
-    }
-}
 
 __global__ __launch_bounds__(kEBlock) void emd_init_kernel(int b, int n, int *__restrict__ list, int *__restrict__ cnt_a,
                                                            int *__restrict__ cnt_b)
@@ -96,50 +49,6 @@ __global__ __launch_bounds__(kEBlock) void emd_init_kernel(int b, int n, int *__
         cnt_a[t] = n;
         cnt_b[t] = 0;
     }
-}
-
-// Folds (ob, obb, oi, obi) into (b, bb, bi, bbi): best / second-best values with the
-// index of an object attaining each.  Value-symmetric; on a tie for first place the
-// lower index is kept as `bi` (the reference's order is restored by the tie path).
-__device__ __forceinline__ void merge_top2(float &b, float &bb, int &bi, int &bbi, float ob, float obb, int oi, int obi)
-{
-    float nb2;
-    int nbi;
-    if (b > ob) {
-        nb2 = fmaxf(bb, ob);
-        nbi = ob > bb ? oi : bbi;
-    } else if (ob > b) {
-        nb2 = fmaxf(obb, b);
-        nbi = b > obb ? bi : obi;
-    } else {                       // equal first places: the other one is the second
-        nb2 = b;
-        nbi = ((unsigned)oi < (unsigned)bi) ? bi : oi;
-    }
-    const bool take = ob > b || (ob == b && (unsigned)oi < (unsigned)bi);
-    bi = take ? oi : bi;
-    b = fmaxf(b, ob);
-    bb = nb2;
-    bbi = nbi;
-}
-
-// Threshold of the bid pre-filter for m = max(better, seed): a candidate with squared distance sq
-// and price p >= 0 can only matter if fl32((3 - sqrtf(sq)) - p) > m.  With tt = fl(cb - p), the
-// test  sq < fl(tt * tt)  must pass whenever that holds.  Roundings: cb and tt (relative u each, on
-// magnitudes <= 3 + |m|), the square (u), the correctly rounded sqrtf (u), the fp32 rounding of the
-// value itself (2u |m|); with 0 <= p < 3 + |m| (otherwise tt <= 0 and nothing can matter) the test
-// is safe iff the slack added to (3 - m) is at least u (21 + 9 |m|).  2e-6 (1 + |m|) = 33.5 u (1 + |m|).
-// (The first version used the constant 2e-6: proven only for clouds in the unit cube, |m| <= 3.)
-__device__ __forceinline__ float filter_cb(float m)
-{
-    return __fadd_rn(__fsub_rn(3.0f, m), __fmul_rn(2e-6f, __fadd_rn(1.0f, fabsf(m))));
-}
-
-// lanes-per-bidder for U bidders on a grid of G blocks per batch element
-__device__ __forceinline__ int pick_p(int U, int G)
-{
-    int P = 64;
-    while (P > 1 && ((long long)U * P + kEBlock - 1) / kEBlock > G) P >>= 1;
-    return P;
 }
 
 template <int FMA, int FILTER, int TILE, int AHEAD>
@@ -463,7 +372,8 @@ __global__ __launch_bounds__(kEBlock) void emd_assign_kernel(int n, const int *_
                                                              const int *__restrict__ bid,
                                                              const float *__restrict__ bid_increments,
                                                              float *__restrict__ max_increments,
-                                                             int *__restrict__ max_idx, int last)
+                                                             int *__restrict__ max_idx, int last,
+                                                             const int *__restrict__ pos_of, float *__restrict__ price_s)
 {
     const int batch = blockIdx.y;
     const int U = cnt[batch];
@@ -490,7 +400,9 @@ __global__ __launch_bounds__(kEBlock) void emd_assign_kernel(int n, const int *_
             }
             assignment_inv[base + bid_id] = j;
             assignment[base + j] = bid_id;
-            price[base + bid_id] = __fadd_rn(price[base + bid_id], bid_increments[base + j]);
+            const float np_ = __fadd_rn(price[base + bid_id], bid_increments[base + j]);
+            price[base + bid_id] = np_;
+            if (price_s) price_s[4 * (base + pos_of[base + bid_id])] = np_;
             max_increments[base + bid_id] = -1e9f;
             // elections are per round; only this thread's own comparison above
             // needed the value, every other bidder of the object compares != j
@@ -517,7 +429,7 @@ __global__ __launch_bounds__(kEBlock) void emd_settle_kernel(int n, const int *_
                                                              float *__restrict__ max_increments, int *__restrict__ max_idx,
                                                              const unsigned long long *__restrict__ chain_head,
                                                              const unsigned long long *__restrict__ chain_next, unsigned stamp,
-                                                             int last)
+                                                             int last, const int *__restrict__ pos_of, float *__restrict__ price_s)
 {
     const int batch = blockIdx.y;
     const int U = cnt[batch];
@@ -527,6 +439,7 @@ __global__ __launch_bounds__(kEBlock) void emd_settle_kernel(int n, const int *_
         const int bid_id = bid[base + j];
         const unsigned long long mynext = chain_next[base + j];      // (what j displaced: read beside bid[j], not behind the head)
         const unsigned long long head = chain_head[base + bid_id];
+        const int pos = pos_of ? pos_of[base + bid_id] : 0;          // the object's place in the cell-sorted copy (emd_grid.hip)
         auto live = [&](unsigned long long r) { return (unsigned)((r >> 24) & 0xffu) == stamp; };
         auto who = [](unsigned long long r) { return (int)(r & 0xffffffu); };
         auto inc_of = [](unsigned long long r) { return __int_as_float((int)(r >> 32)); };
@@ -565,7 +478,9 @@ __global__ __launch_bounds__(kEBlock) void emd_settle_kernel(int n, const int *_
             }
             assignment_inv[base + bid_id] = j;
             assignment[base + j] = bid_id;
-            price[base + bid_id] = __fadd_rn(price[base + bid_id], my_inc);
+            const float np_ = __fadd_rn(price[base + bid_id], my_inc);
+            price[base + bid_id] = np_;
+            if (price_s) price_s[4 * (base + pos)] = np_;
             max_increments[base + bid_id] = -1e9f;
             max_idx[base + bid_id] = -1;
         } else {
@@ -587,7 +502,8 @@ __global__ __launch_bounds__(kResolveBlock) void emd_resolve_kernel(int n, const
                                                                     const int *__restrict__ bid,
                                                                     const float *__restrict__ bid_increments,
                                                                     float *__restrict__ max_increments,
-                                                                    int *__restrict__ max_idx, int last)
+                                                                    int *__restrict__ max_idx, int last,
+                                                                    const int *__restrict__ pos_of, float *__restrict__ price_s)
 {
     const int batch = blockIdx.x;
     const int U = cnt[batch];
@@ -622,7 +538,9 @@ __global__ __launch_bounds__(kResolveBlock) void emd_resolve_kernel(int n, const
             }
             assignment_inv[base + bid_id] = j;
             assignment[base + j] = bid_id;
-            price[base + bid_id] = __fadd_rn(price[base + bid_id], bid_increments[base + j]);
+            const float np_ = __fadd_rn(price[base + bid_id], bid_increments[base + j]);
+            price[base + bid_id] = np_;
+            if (price_s) price_s[4 * (base + pos_of[base + bid_id])] = np_;
             max_increments[base + bid_id] = -1e9f;
             max_idx[base + bid_id] = -1;
         } else {
@@ -672,6 +590,31 @@ __global__ __launch_bounds__(kEBlock) void emd_grad_kernel(long long total, int 
 
 }  // namespace genpc
 
+namespace genpc { static thread_local int t_emd_grid = -1, t_emd_hooks = 0; }
+
+/* Bid kernel selection for tests and A/B (thread-local like genpc_nn_tune): 1 the cell-sorted culled bid (emd_grid.hip),
+ * 0 the tiled bid over all objects (emd_bid_kernel), < 0 the default (culled from n = 512 on when eps >= 0).  Returns
+ * the previous setting.  Every choice yields the same bits.  hooks (>= 0 to set): 1 = count what the culled bid does
+ * (genpc_emd_stats). */
+GENPC_API int genpc_emd_tune(int grid, int hooks)
+{
+    const int prev = genpc::t_emd_grid;
+    genpc::t_emd_grid = grid < 0 ? -1 : (grid ? 1 : 0);
+    if (hooks >= 0) genpc::t_emd_hooks = hooks;
+    return prev;
+}
+
+GENPC_API int genpc_emd_stats(unsigned long long out[8], int reset, void *stream)
+{
+    using namespace genpc;
+    unsigned long long *dev = (unsigned long long *)workspace(28, 256, nullptr, nullptr, 256);
+    if (!dev) return 0;
+    if (!check(hipStreamSynchronize((hipStream_t)stream), "genpc_emd_stats sync")) return 0;
+    if (!check(hipMemcpy(out, dev, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost), "genpc_emd_stats copy")) return 0;
+    if (reset && !check(hipMemset(dev, 0, 256), "genpc_emd_stats reset")) return 0;
+    return 1;
+}
+
 GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist,
                                 int *assignment, float *price, int *assignment_inv, int *bid,
                                 float *bid_increments, float *max_increments, int *unass_idx, int *unass_cnt,
@@ -711,8 +654,24 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     static const bool no_settle = getenv("GENPC_EMD_SETTLE") && atoi(getenv("GENPC_EMD_SETTLE")) == 0;
     const bool settle = !no_settle && eps >= 0.0f && n <= (1 << 24);
     const size_t chain_bytes = settle ? 2 * (size_t)total * sizeof(unsigned long long) : 0;
-    char *ws = (char *)workspace(1, arrive_bytes + list_bytes + second_bytes + parts_bytes + chain_bytes, st, nullptr, arrive_bytes);
+    // cell-sorted copy of the objects for the culled bid (emd_grid.hip): needs prices >= 0 (eps >= 0) and the seeds
+    static const int env_grid = getenv("GENPC_EMD_GRID") ? atoi(getenv("GENPC_EMD_GRID")) : -1;
+    static const bool noseed_env = getenv("GENPC_EMD_NOSEED") != nullptr;
+    const bool grid = (t_emd_grid >= 0 ? t_emd_grid != 0 : (env_grid >= 0 ? env_grid != 0 : n >= 512)) && eps >= 0.0f && !noseed_env;
+    auto al256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    const int cells_max = kEGMaxCells;
+    const size_t g_hdr = grid ? al256((size_t)b * sizeof(EGridHdr)) : 0, g_start = grid ? al256((size_t)b * (cells_max + 1) * sizeof(int)) : 0;
+    const size_t g_sorted = grid ? al256((size_t)total * sizeof(float4)) : 0, g_pos = grid ? al256((size_t)total * sizeof(int)) : 0;
+    const size_t g_ps = grid ? al256((size_t)total * sizeof(float)) : 0;
+    const size_t grid_off = arrive_bytes + list_bytes + second_bytes + parts_bytes + chain_bytes;
+    char *ws = (char *)workspace(1, grid_off + g_hdr + g_start + g_sorted + g_pos + g_ps, st, nullptr, arrive_bytes);
     if (!ws) return 0;
+    EGridHdr *g_hdr_p = (EGridHdr *)(ws + grid_off);
+    int *g_start_p = (int *)(ws + grid_off + g_hdr);
+    float4 *g_sorted_p = (float4 *)(ws + grid_off + g_hdr + g_start);
+    int *g_pos_p = grid ? (int *)(ws + grid_off + g_hdr + g_start + g_sorted) : nullptr;
+    int *g_of_p = grid ? (int *)(ws + grid_off + g_hdr + g_start + g_sorted + g_pos) : nullptr;
+    float *g_ps_p = grid ? (float *)g_sorted_p + 3 : nullptr;      // the price of sorted position p: g_ps_p[4 p] (the .w of its entry)
     unsigned long long *chain_head = settle ? (unsigned long long *)(ws + arrive_bytes + list_bytes + second_bytes + parts_bytes) : nullptr;
     unsigned long long *chain_next = settle ? chain_head + total : nullptr;
     int *arrive = (int *)ws;
@@ -731,6 +690,13 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
 
     const int lin_blocks = ceil_div((int)total, kEBlock);
     hipLaunchKernelGGL(emd_init_kernel, dim3(lin_blocks), dim3(kEBlock), 0, st, b, n, lists[0], cnts[0], cnts[1]);
+    if (grid) {
+        // about two objects per cell if the cloud filled its box (surfaces fill far fewer cells, with more objects each)
+        static const int env_ppc = getenv("GENPC_EMD_GRID_PPC_X10") ? atoi(getenv("GENPC_EMD_GRID_PPC_X10")) : 20;
+        int target = (int)((long long)n * 10 / (env_ppc > 0 ? env_ppc : 20));
+        target = target < 8 ? 8 : (target > cells_max * 3 / 4 ? cells_max * 3 / 4 : target);
+        if (!launch_emd_grid_build(b, n, xyz2, price, g_hdr_p, g_start_p, g_sorted_p, g_pos_p, g_of_p, target, cells_max, st)) return 0;
+    }
 
     // Blocks per batch element for the bid kernel: ~16 blocks per CU overall (the bid
     // loop is latency-bound per wave -- LDS read, compare, branch -- and wants >= 8
@@ -764,7 +730,19 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
         if (use_chain && it % 255 == 0 &&
             !check(hipMemsetAsync(chain_head, 0, (size_t)total * sizeof(unsigned long long), st), "hipMemsetAsync(chain heads)"))
             return 0;
-        {
+        if (grid) {
+            EmdGridBid ga{};
+            ga.n = n; ga.G = G; ga.nb = b; ga.cells_max = cells_max; ga.eps = eps; ga.stamp = stamp;
+            static const int env_lpb = getenv("GENPC_EMD_LPB") ? atoi(getenv("GENPC_EMD_LPB")) : 0;
+            ga.force_lpb = env_lpb;
+            ga.xyz1 = xyz1; ga.xyz2 = xyz2; ga.price = price; ga.orig_of = g_of_p;
+            ga.list = lists[cur]; ga.cnt = cnts[cur]; ga.start = g_start_p; ga.cnt_next = cnts[nxt];
+            ga.bid = bid; ga.second = second; ga.bid_increments = bid_increments; ga.max_increments = max_increments;
+            ga.sorted = g_sorted_p; ga.hdr = g_hdr_p;
+            ga.chain_head = use_chain ? chain_head : nullptr; ga.chain_next = chain_next;
+            ga.stats = (t_emd_hooks & 1) ? (unsigned long long *)workspace(28, 256, nullptr, nullptr, 256) : nullptr;
+            launch_emd_bid_grid(ga, fma ? 1 : 0, st);
+        } else {
             typedef void (*bid_fn)(int, const float *, const float *, const float *, float, const int *, const int *,
                                    int *, int *, float *, float *, int, float4 *, int *, int *, int, unsigned long long *,
                                    unsigned long long *, unsigned, int, int);
@@ -804,18 +782,18 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
             hipLaunchKernelGGL(emd_settle_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
                                (const int *)cnts[cur], lists[nxt], cnts[nxt], assignment, assignment_inv, price,
                                (const int *)bid, max_increments, max_idx, (const unsigned long long *)chain_head,
-                               (const unsigned long long *)chain_next, stamp, last);
+                               (const unsigned long long *)chain_next, stamp, last, (const int *)g_pos_p, g_ps_p);
         } else if (it >= resolve_from) {
             hipLaunchKernelGGL(emd_resolve_kernel, dim3(b), dim3(kResolveBlock), 0, st, n, (const int *)lists[cur],
                                (const int *)cnts[cur], lists[nxt], cnts[nxt], assignment, assignment_inv, price,
-                               (const int *)bid, (const float *)bid_increments, max_increments, max_idx, last);
+                               (const int *)bid, (const float *)bid_increments, max_increments, max_idx, last, (const int *)g_pos_p, g_ps_p);
         } else {
             hipLaunchKernelGGL(emd_getmax_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
                                (const int *)cnts[cur], (const int *)bid, (const float *)bid_increments,
                                (const float *)max_increments, max_idx, last);
             hipLaunchKernelGGL(emd_assign_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
                                (const int *)cnts[cur], lists[nxt], cnts[nxt], assignment, assignment_inv, price,
-                               (const int *)bid, (const float *)bid_increments, max_increments, max_idx, last);
+                               (const int *)bid, (const float *)bid_increments, max_increments, max_idx, last, (const int *)g_pos_p, g_ps_p);
         }
     }
     if (fma)

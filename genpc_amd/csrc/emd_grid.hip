@@ -1,0 +1,563 @@
+// emd_grid.hip -- the auction's Bid step (emd_cuda.cu:95-179) with the objects a bidder tests CULLED.
+//
+// The reference's Bid evaluates every (unassigned point, object) pair of a round; so did emd_bid_kernel (emd.hip) --
+// behind a squared-distance pre-filter, but every bidder still walked all n objects (64 MB of L2 -> LDS per late
+// round at n = 16384).  Objects never move; only prices rise, and prices are >= 0 (they start at
+// 0 and every increment is best - better + eps >= eps >= 0).  An object can change a bidder's (best, better) only if
+// its value 3 - |x2 - x1| - price exceeds m = max(better so far, seed), hence only if its squared distance is below
+// fl(cb^2), cb = filter_cb(m) -- the pre-filter's own threshold at price 0 (emd.h).  So the objects are sorted ONCE
+// per call into a uniform grid (emd_grid_build_kernel: one block per cloud, counting sort in LDS, cells numbered
+// x-fastest so that the cells [cx0, cx1] of a (cy, cz) ROW are one contiguous run of the sorted array), and a bidder
+// visits only the rows of the box |p - x1| <= cb around itself whose (y, z) gap is below cb -- with the bound of
+// nn_grid.hip, every rounding accounted for: a skipped row provably holds nothing that could matter, what is visited
+// goes through the SAME per-object pre-filter and the SAME exact fp64 value as before, every object at most once.
+// The top-2 VALUES (duplicates count) and the index of a unique best are therefore the reference's; an exact tie for
+// first place takes the thread-major re-scan of the tiled kernel unchanged.  Bit-identical assignments and prices
+// (tests/test_gpu_emd.py: every parity test runs both bid kernels).
+//
+// Seeds: from its second bid on a point is seeded with the values, at today's prices, of the two objects it ranked
+// first and second last time (as in the tiled kernel); a point that has not bid yet first probes the 3 x 3 rows
+// around its own cell (x range +-1 cell), takes the second-best value found as its seed and skips those cells in the
+// main pass.  Simulated on uniform clouds a late-round bidder then meets ~30 of 16384 objects, on a partial scan
+// against its ground truth 50-350 (tools: /tmp experiment recorded in DESIGN.md section 4.3).
+// Prices live twice: price[] in the caller's object order (the ABI's array) and the .w of the sorted entries, which
+// the settle / resolve kernels keep in step (pos_of[object]) -- a bidder reads (x, y, z, price) as ONE 16-byte entry,
+// consecutive lanes consecutive entries; the object's index (orig_of) is read only for the rare entry that passes.
+#include "emd.h"
+#include "../../include/genpc_hip.h"
+
+#include <stdlib.h>
+
+namespace genpc {
+
+constexpr int kEGBlock = 1024;          // build kernel: one block per cloud
+constexpr int kEGWaves = kEGBlock / kWave;
+constexpr float kEGU16 = 9.5367431640625e-7f;      // 16 u
+constexpr int kTwoPassRows = 25;        // boxes of more (y, z) rows than this take the near cells first (emd_bid_grid_kernel)
+
+__device__ __forceinline__ int egrid_cell1(float p, float lo, float inv, int g)
+{
+    const float t = __fmul_rn(__fsub_rn(p, lo), inv);
+    int c = (int)floorf(t);          // NaN -> 0 (v_cvt_i32_f32); a cloud with non-finite coordinates is searched without culling
+    c = c < 0 ? 0 : c;
+    return c > g - 1 ? g - 1 : c;
+}
+
+// One block per batch element: exact bounding box of the objects, a grid of about cells_target cubic cells over
+// the axes wider than a cell, counting sort in LDS.  Outputs: hdr[batch], start[batch][cells + 1] (first sorted
+// position of every cell, cells numbered (cz gy + cy) gx + cx), sorted[batch][n] = (x, y, z, price),
+// orig_of[batch][position] = object index, pos_of[batch][object] = position.  The order inside a cell is whatever the LDS atomics give: it does not reach any result.
+__global__ __launch_bounds__(kEGBlock) void emd_grid_build_kernel(int n, const float *__restrict__ xyz2, const float *__restrict__ price,
+                                                                  EGridHdr *__restrict__ hdr, int *__restrict__ start,
+                                                                  float4 *__restrict__ sorted, int *__restrict__ pos_of,
+                                                                  int *__restrict__ orig_of, int cells_target, int cells_max)
+{
+    extern __shared__ int s_cnt[];            // cells_max counters, then 2 kEGWaves ints, then 6 kEGWaves floats
+    int *s_w = s_cnt + cells_max;
+    float *s_red = (float *)(s_w + 2 * kEGWaves);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int batch = blockIdx.x;
+    const float *__restrict__ P = xyz2 + (size_t)batch * n * 3;
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    int bad = 0;
+    const float *__restrict__ PR0 = price + (size_t)batch * n;
+    for (int j = threadIdx.x; j < n; j += kEGBlock) {
+        bad |= !(PR0[j] >= 0.0f && PR0[j] < __builtin_inff());      // the culling needs prices >= 0 (the caller's initial state: zeros)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float w = P[(size_t)j * 3 + k];
+            if (fabsf(w) < __builtin_inff()) {
+                mn[k] = fminf(mn[k], w);
+                mx[k] = fmaxf(mx[k], w);
+            } else {
+                bad = 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], o));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o));
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s_red[wave * 6 + k] = mn[k]; s_red[wave * 6 + 3 + k] = mx[k]; }
+    }
+    bad = __syncthreads_or(bad);
+    for (int w = 0; w < kEGWaves; w++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            mn[k] = fminf(mn[k], s_red[w * 6 + k]);
+            mx[k] = fmaxf(mx[k], s_red[w * 6 + 3 + k]);
+        }
+    }
+    // cubic cells of side h, about cells_target of them over the axes wider than h (as nn_grid.hip's grid_setup)
+    float ext[3];
+    bool act[3];
+    int nact = 0;
+    float emax = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (!(mn[k] <= mx[k])) { mn[k] = 0.0f; mx[k] = 0.0f; }
+        ext[k] = mx[k] - mn[k];
+        if (!(ext[k] < __builtin_inff())) ext[k] = 0.0f;
+        act[k] = ext[k] > 0.0f;
+        nact += act[k] ? 1 : 0;
+        emax = fmaxf(emax, ext[k]);
+    }
+    float h = 0.0f;
+    for (int it = 0; it < 3 && nact > 0; it++) {
+        float vol = 1.0f;
+        for (int k = 0; k < 3; k++) if (act[k]) vol *= ext[k] / emax;
+        const float r = vol / (float)cells_target;
+        h = emax * (nact == 3 ? cbrtf(r) : (nact == 2 ? sqrtf(r) : r));
+        bool dropped = false;
+        for (int k = 0; k < 3; k++) {
+            if (act[k] && !(ext[k] > h)) { act[k] = false; nact--; dropped = true; }
+        }
+        if (!dropped) break;
+    }
+    if (!(h > 0.0f) || !(h < __builtin_inff()) || nact == 0) {
+        h = 1.0f;
+        for (int k = 0; k < 3; k++) act[k] = false;
+    }
+    int g[3];
+    for (int rep = 0; rep < 16; rep++) {
+        long long cells = 1;
+        for (int k = 0; k < 3; k++) {
+            float q = act[k] ? ceilf(ext[k] / h) : 1.0f;
+            if (!(q >= 1.0f)) q = 1.0f;
+            if (q > 1024.0f) q = 1024.0f;
+            g[k] = (int)q;
+            cells *= g[k];
+        }
+        if (cells <= cells_max) break;
+        h *= 1.26f;
+        if (rep == 15) { act[0] = act[1] = act[2] = false; }
+    }
+    float inv = 1.0f / h;
+    if (!(inv > 0.0f) || !(inv < __builtin_inff())) {
+        inv = 1.0f; h = 1.0f;
+        for (int k = 0; k < 3; k++) g[k] = 1;
+    }
+    EGridHdr H;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (!act[k]) g[k] = 1;
+        H.lo[k] = mn[k];
+        H.g[k] = g[k];
+        H.slack[k] = kEGU16 * (fabsf(mn[k]) + (float)(g[k] + 1) * h);
+    }
+    H.inv = inv;
+    H.h = h;
+    H.cells = g[0] * g[1] * g[2];
+    H.bad = bad;
+    if (threadIdx.x == 0) hdr[batch] = H;
+    const int cells = H.cells;
+    for (int i = threadIdx.x; i < cells; i += kEGBlock) s_cnt[i] = 0;
+    __syncthreads();
+    auto cell_of = [&](int j) {
+        const int cx = egrid_cell1(P[(size_t)j * 3 + 0], H.lo[0], inv, g[0]), cy = egrid_cell1(P[(size_t)j * 3 + 1], H.lo[1], inv, g[1]);
+        const int cz = egrid_cell1(P[(size_t)j * 3 + 2], H.lo[2], inv, g[2]);
+        return (cz * g[1] + cy) * g[0] + cx;
+    };
+    for (int j = threadIdx.x; j < n; j += kEGBlock) atomicAdd(&s_cnt[cell_of(j)], 1);
+    __syncthreads();
+    // exclusive scan: thread t owns the segment [t per, (t + 1) per); per is odd (LDS banks)
+    const int per = ((cells + kEGBlock - 1) / kEGBlock) | 1;
+    int sum = 0;
+    for (int i = 0; i < per; i++) {
+        const int q = threadIdx.x * per + i;
+        if (q < cells) { const int w = s_cnt[q]; s_cnt[q] = sum; sum += w; }
+    }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == kWave - 1) s_w[wave] = inc;
+    __syncthreads();
+    int base = inc - sum;
+    for (int w = 0; w < wave; w++) base += s_w[w];
+    for (int i = 0; i < per; i++) {
+        const int q = threadIdx.x * per + i;
+        if (q < cells) s_cnt[q] += base;
+    }
+    __syncthreads();
+    int *st = start + (size_t)batch * (cells_max + 1);
+    for (int i = threadIdx.x; i < cells; i += kEGBlock) st[i] = s_cnt[i];
+    if (threadIdx.x == 0) st[cells] = n;
+    __syncthreads();
+    float4 *out = sorted + (size_t)batch * n;
+    int *po = pos_of + (size_t)batch * n;
+    int *ps = orig_of + (size_t)batch * n;
+    for (int j = threadIdx.x; j < n; j += kEGBlock) {
+        const int pos = atomicAdd(&s_cnt[cell_of(j)], 1);
+        out[pos] = make_float4(P[(size_t)j * 3 + 0], P[(size_t)j * 3 + 1], P[(size_t)j * 3 + 2], PR0[j]);
+        po[j] = pos;
+        ps[pos] = j;
+    }
+}
+
+// The Bid step of one round over the grid.  Same outputs as emd_bid_kernel (emd.hip): bid, second, bid_increments,
+// max_increments, the chain records.  LPB lanes share a bidder (a power of two, 8 .. 64, picked per round from the
+// number of bidders like pick_p); a lane takes whole rows of the bidder's box.
+template <int FMA>
+__global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
+{
+    __shared__ int s_pre[kEBlock / kWave][136], s_p0[kEBlock / kWave][136];      // per wave: (64 / LPB) groups x (2 LPB + 1) entries
+    const int n = a.n, G = a.G, nb = a.nb;
+    int batch, bx;
+    {   // the blocks of a cloud on one XCD (as emd_bid_kernel)
+        const int lin = blockIdx.x, nb8 = nb & ~7;
+        if (lin < G * nb8) {
+            const int k = lin >> 3;
+            batch = 8 * (k / G) + (lin & 7);
+            bx = k % G;
+        } else {
+            batch = nb8 + (lin - G * nb8) / G;
+            bx = (lin - G * nb8) % G;
+        }
+    }
+    const int U = a.cnt[batch];
+    if (bx == 0 && threadIdx.x == 0) a.cnt_next[batch] = 0;   // filled by this round's settle / resolve
+    if (U == 0) return;
+    int LPB = a.force_lpb > 0 ? a.force_lpb : pick_p(U, G);
+    LPB = LPB < 8 ? 8 : LPB;
+    const int per_wave = kWave / LPB, per_block = kEBlock / LPB;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int sub = lane & (LPB - 1), grp = lane / LPB;
+    const size_t base = (size_t)batch * n;
+    const float *__restrict__ X1 = a.xyz1 + base * 3;
+    const float *__restrict__ X2 = a.xyz2 + base * 3;
+    const float *__restrict__ PR = a.price + base;
+    const int *__restrict__ L = a.list + base;
+    const float4 *__restrict__ S = a.sorted + base;      // (x, y, z, price) in cell order: settle / resolve keep .w in step
+    const int *__restrict__ OF = a.orig_of + base;       // object index of a sorted position: read only for the rare object that passes
+    const int *__restrict__ ST = a.start + (size_t)batch * (a.cells_max + 1);
+    const EGridHdr H = a.hdr[batch];
+    const int gx = H.g[0], gy = H.g[1], gz = H.g[2];
+    const float h = H.h, inf = __builtin_inff();
+    const float kShrink = 0.99999905f;      // 1 - 2^-20
+    // reference partition, needed only to order exactly tied candidates
+    const int block_cnt = n / 256;
+    const int unass_per_block = (U + block_cnt - 1) / block_cnt;
+    const int thread_per_unass = 256 / unass_per_block;
+
+    const int units = (U + per_block - 1) / per_block;
+    for (int unit = bx; unit < units; unit += G) {
+        const int u = unit * per_block + wave * per_wave + grp;
+        const bool active = u < U;
+        const int j = L[active ? u : U - 1];
+        const float x1 = X1[(size_t)j * 3 + 0], y1 = X1[(size_t)j * 3 + 1], z1 = X1[(size_t)j * 3 + 2];
+        float best = -1e9f, better = -1e9f;
+        int best_i = -1, better_i = -1;
+        float seed = -1e9f;
+        bool seeded = false;
+        unsigned st_rows = 0, st_kept = 0, st_items = 0, st_pass = 0;      // hook counters (a.stats != null only)
+        bool tie_mode = false;                  // second sweep of a bidder whose two best values are equal (below)
+        unsigned long long tie_key = ~0ull;
+        {
+            const int sa = a.bid[base + j], sc = a.second[base + j];
+            if (sc >= 0 && sa != sc && (unsigned)sa < (unsigned)n) {
+                const float da = bid_value<FMA>(x1, y1, z1, X2[(size_t)sa * 3 + 0], X2[(size_t)sa * 3 + 1], X2[(size_t)sa * 3 + 2], PR[sa]);
+                const float dc = bid_value<FMA>(x1, y1, z1, X2[(size_t)sc * 3 + 0], X2[(size_t)sc * 3 + 1], X2[(size_t)sc * 3 + 2], PR[sc]);
+                seed = fminf(da, dc);
+                seeded = true;
+            }
+        }
+        float cb = filter_cb(fmaxf(better, seed));
+        const float sx = H.slack[0] + kEGU16 * fabsf(x1), sy = H.slack[1] + kEGU16 * fabsf(y1), sz = H.slack[2] + kEGU16 * fabsf(z1);
+        // lower bound of |p_a - q_a| over the points p of cell c of an axis (border cells unbounded outwards)
+        auto gap1 = [&](int c, int g, float lo, float q, float s) {
+            const float wl = c > 0 ? __fadd_rn(lo, __fmul_rn((float)c, h)) : -inf;
+            const float wh = c + 1 < g ? __fadd_rn(lo, __fmul_rn((float)(c + 1), h)) : inf;
+            return fmaxf(0.0f, fmaxf((wl - s) - q, (q - s) - wh));
+        };
+        // One batch of runs of the sorted array, two per lane ([pA, pA + lA) and [pB, pB + lB), possibly empty), spread
+        // EVENLY over the group's lanes: exclusive scan of the lengths, then lane `sub` takes the items sub, sub + LPB, ...
+        // of the concatenation (a run of a dense row is hundreds of objects: a lane per row left 63 lanes waiting for one --
+        // the 13 bundled scans took 196 ms against 62 for the tiled kernel).  Consecutive lanes read consecutive entries.
+        // Per item: the pre-filter, the exact value, the lane-local top-2 -- four loads in flight.
+        int *pre = s_pre[wave] + grp * (2 * LPB + 1), *pp0 = s_p0[wave] + grp * (2 * LPB + 1);
+        auto batch_eval = [&](int pA, int lA, int pB, int lB) {
+            // entries = the non-empty runs only (on a surface most rows of a box are empty: a cursor walking 2 LPB entries
+            // with a dependent LDS read each cost more than the objects)
+            const unsigned long long gmask = LPB == 64 ? ~0ull : (((1ull << LPB) - 1ull) << (lane & ~(LPB - 1)));
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long mA = __ballot(lA > 0) & gmask, mB = __ballot(lB > 0) & gmask;
+            const int nA = __popcll(mA), E = nA + __popcll(mB);
+            int incl = lA + lB;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const int t = __shfl_up(incl, o, kWave);
+                if (o < LPB && sub >= o) incl += t;
+            }
+            const int exclA = incl - (lA + lB);
+            const int T = __shfl(incl, (lane & ~(LPB - 1)) + LPB - 1, kWave);
+            // order: all A runs (by lane), then all B runs; a lane's B run starts after every A run and the B runs below it
+            int sumA = lA;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const int t = __shfl_up(sumA, o, kWave);
+                if (o < LPB && sub >= o) sumA += t;
+            }
+            const int totA = __shfl(sumA, (lane & ~(LPB - 1)) + LPB - 1, kWave);
+            const int offA = sumA - lA;                              // A runs of the lanes below
+            const int offB = totA + (exclA - offA);                  // all A runs + B runs of the lanes below
+            if (lA > 0) { const int e = __popcll(mA & below); pre[e] = offA; pp0[e] = pA; }
+            if (lB > 0) { const int e = nA + __popcll(mB & below); pre[e] = offB; pp0[e] = pB; }
+            if (sub == 0) pre[E] = T;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int cur = 0;
+            if (sub == 0) st_items += (unsigned)T;
+            for (int t = sub; t < T; t += 4 * LPB) {
+                float4 o[4];
+                int pos[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int ti = t + i * LPB;
+                    if (ti < T) {
+                        while (ti >= pre[cur + 1]) cur++;
+                        pos[i] = pp0[cur] + (ti - pre[cur]);
+                    } else {
+                        pos[i] = pos[0];             // past the end: re-read the first (t < T), not evaluated
+                    }
+                    o[i] = S[pos[i]];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (t + i * LPB < T) {
+                        const float sq = sqdist_e<FMA>(o[i].x - x1, o[i].y - y1, o[i].z - z1);
+                        const float tt = cb - o[i].w;
+                        if (sq < tt * tt) {
+                            st_pass++;
+                            const float r = sqrtf(sq);
+                            const float d = (float)((3.0 - (double)r) - (double)o[i].w);
+                            if (!tie_mode) {
+                                const bool gt = d > best;
+                                const bool gt2 = !gt && d > better;
+                                const int kk = OF[pos[i]];
+                                better_i = gt ? best_i : (gt2 ? kk : better_i);
+                                better = __builtin_amdgcn_fmed3f(d, best, better);
+                                best = fmaxf(best, d);
+                                best_i = gt ? kk : best_i;
+                                cb = filter_cb(fmaxf(better, seed));
+                            } else if (d == best) {
+                                // an object that ties for first place: its key in the reference's thread-major scan order
+                                // (emd_cuda.cu:108-118,136-139,165-173: the candidate the scan meets first is reported)
+                                const int k = OF[pos[i]];
+                                const int kt = k & 2047;                       // position in the reference's 2048-tile
+                                const int tile0 = k - kt;
+                                const int end_k = min(n, tile0 + 2048) - tile0;
+                                const int delta = (end_k + thread_per_unass - 1) / thread_per_unass;
+                                const unsigned long long kk = ((unsigned long long)(kt / delta) << 32) | (unsigned)k;
+                                tie_key = kk < tie_key ? kk : tie_key;
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();       // the lists are rewritten by the next batch
+        };
+        const int cqx = egrid_cell1(x1, H.lo[0], H.inv, gx), cqy = egrid_cell1(y1, H.lo[1], H.inv, gy), cqz = egrid_cell1(z1, H.lo[2], H.inv, gz);
+        const bool cull = !H.bad && (fabsf(x1) + fabsf(y1)) + fabsf(z1) < inf;
+        // (1) A point that has not bid yet has no seed.  The 3 x 3 x 3 cells around it are scanned with a cheap fp32 proxy of
+        // the value (sqrtf(sq) + price, smaller is better); the two best-looking objects are then VALUED exactly, like the
+        // seeds of a point that has bid before: the second-best over all objects is at least the smaller of any two.
+        // (Letting the lanes run the exact path on whatever they meet first cost 41 fp64 evaluations per point in round
+        // 0, where every lane's first two objects pass: 115 us for 16384 points.)
+        if (!seeded && cull) {
+            float k1 = inf, k2 = inf;
+            int q1 = -1, q2 = -1;
+            for (int r = sub; r < 9; r += LPB) {
+                const int cy = cqy + r % 3 - 1, cz = cqz + r / 3 - 1;
+                if (cy < 0 || cy >= gy || cz < 0 || cz >= gz) continue;
+                const int row = (cz * gy + cy) * gx;
+                const int p1 = ST[row + min(gx - 1, cqx + 1) + 1];
+                for (int p = ST[row + max(0, cqx - 1)]; p < p1; p++) {
+                    const float4 o = S[p];
+                    const float key = sqrtf(sqdist_e<FMA>(o.x - x1, o.y - y1, o.z - z1)) + o.w;
+                    if (key < k1) { k2 = k1; q2 = q1; k1 = key; q1 = p; }
+                    else if (key < k2) { k2 = key; q2 = p; }
+                }
+            }
+            for (int off = 1; off < LPB; off <<= 1) {
+                const float o1 = __shfl_xor(k1, off, kWave), o2 = __shfl_xor(k2, off, kWave);
+                const int p1 = __shfl_xor(q1, off, kWave), p2 = __shfl_xor(q2, off, kWave);
+                // two smallest of {k1, k2, o1, o2} (the lanes' sets are disjoint)
+                if (o1 < k1) { k2 = fminf(k1, o2) == k1 ? k1 : o2; q2 = (k1 <= o2) ? q1 : p2; k1 = o1; q1 = p1; }
+                else { const bool t = o1 < k2; k2 = t ? o1 : k2; q2 = t ? p1 : q2; }
+            }
+            if (q2 >= 0) {
+                const float4 oa = S[q1], ob = S[q2];
+                seed = fminf(bid_value<FMA>(x1, y1, z1, oa.x, oa.y, oa.z, oa.w), bid_value<FMA>(x1, y1, z1, ob.x, ob.y, ob.z, ob.w));
+                cb = filter_cb(seed);
+            }
+        }
+        // the box |p - x1| <= cb (cell function monotone: a point within cb of x1 on an axis lies in [cell(x1 - cb), cell(x1 + cb)])
+        int bx0 = 0, bx1 = gx - 1, by0 = 0, by1 = gy - 1, bz0 = 0, bz1 = gz - 1;
+        auto set_box = [&](float R) {
+            bx0 = egrid_cell1((x1 - R) - sx, H.lo[0], H.inv, gx); bx1 = egrid_cell1((x1 + R) + sx, H.lo[0], H.inv, gx);
+            by0 = egrid_cell1((y1 - R) - sy, H.lo[1], H.inv, gy); by1 = egrid_cell1((y1 + R) + sy, H.lo[1], H.inv, gy);
+            bz0 = egrid_cell1((z1 - R) - sz, H.lo[2], H.inv, gz); bz1 = egrid_cell1((z1 + R) + sz, H.lo[2], H.inv, gz);
+        };
+        if (cull) set_box(filter_cb(seed));
+        // (2) A wide box (stale seeds: the prices of the two objects the point knew have risen since it last bid -- on a
+        // partial scan against its ground truth the boxes grew to 200 rows and 4000 objects per bidder with ~100 exact
+        // evaluations): the 3 x 3 x 3 cells around the point first, on their own.  What they hold is almost always the
+        // true top-2; their second-best value becomes the seed and the box of the main pass shrinks to what can still beat
+        // it.  The cells already tested -- x in [ex0, ex1] of the rows |cy - cqy| <= 1, |cz - cqz| <= 1 -- are skipped there.
+        int ex0 = 1, ex1 = 0;
+        if (cull && (by1 - by0 + 1) * (bz1 - bz0 + 1) > kTwoPassRows) {
+            ex0 = max(0, cqx - 1);
+            ex1 = min(gx - 1, cqx + 1);
+            for (int r0 = 0; r0 < 9; r0 += LPB) {
+                const int r = r0 + sub;
+                const int cy = cqy + r % 3 - 1, cz = cqz + r / 3 - 1;
+                int pA = 0, lA = 0;
+                if (r < 9 && cy >= 0 && cy < gy && cz >= 0 && cz < gz) {
+                    const int row = (cz * gy + cy) * gx;
+                    pA = ST[row + ex0];
+                    lA = ST[row + ex1 + 1] - pA;
+                }
+                batch_eval(pA, lA, 0, 0);
+            }
+            // fold the group's findings: lane 0 of the group keeps them, everybody takes the second-best as the seed
+            for (int off = 1; off < LPB; off <<= 1) {
+                const float ob = __shfl_xor(best, off, kWave), obb = __shfl_xor(better, off, kWave);
+                const int oi = __shfl_xor(best_i, off, kWave), obi = __shfl_xor(better_i, off, kWave);
+                merge_top2(best, better, best_i, better_i, ob, obb, oi, obi);
+            }
+            seed = fmaxf(seed, better);
+            if (sub != 0) { best = -1e9f; better = -1e9f; best_i = -1; better_i = -1; }
+            cb = filter_cb(fmaxf(better, seed));
+            set_box(filter_cb(seed));
+        }
+        auto sweep = [&]() {
+        const int wy = by1 - by0 + 1, nrows = wy * (bz1 - bz0 + 1);
+        for (int r0 = 0; r0 < nrows; r0 += LPB) {         // group-uniform trip count
+            const int r = r0 + sub;
+            int pA = 0, lA = 0, pB = 0, lB = 0;
+            if (r < nrows) {
+                st_rows++;
+                const int rz = r / wy;
+                const int cy = by0 + (r - rz * wy), cz = bz0 + rz;
+                int cx0 = bx0, cx1 = bx1;
+                bool keep = true;
+                if (cull) {
+                    // the row's (y, z) gap against the threshold; what is left of it bounds |dx|: the box becomes a ball
+                    const float gyv = gap1(cy, gy, H.lo[1], y1, sy), gzv = gap1(cz, gz, H.lo[2], z1, sz);
+                    const float lb = __fmaf_rn(gyv, gyv, __fmul_rn(gzv, gzv)) * kShrink;
+                    const float c2 = __fmul_rn(cb, cb);
+                    keep = lb < c2;                          // else nothing in this row can matter (prices >= 0)
+                    if (keep) {
+                        const float W = sqrtf(fmaxf(0.0f, __fmul_rn(c2, 1.000001f) - lb)) * 1.000001f;
+                        cx0 = max(bx0, egrid_cell1((x1 - W) - sx, H.lo[0], H.inv, gx));
+                        cx1 = min(bx1, egrid_cell1((x1 + W) + sx, H.lo[0], H.inv, gx));
+                    }
+                }
+                if (keep && cx0 <= cx1) {
+                    st_kept++;
+                    const int row = (cz * gy + cy) * gx;
+                    const bool probed = ex0 <= ex1 && abs(cy - cqy) <= 1 && abs(cz - cqz) <= 1;
+                    if (!probed) {
+                        pA = ST[row + cx0];
+                        lA = ST[row + cx1 + 1] - pA;
+                    } else {
+                        if (cx0 < ex0) { pA = ST[row + cx0]; lA = ST[row + ex0] - pA; }
+                        if (ex1 < cx1) { pB = ST[row + ex1 + 1]; lB = ST[row + cx1 + 1] - pB; }
+                    }
+                }
+            }
+            batch_eval(pA, lA, pB, lB);
+        }
+        };
+        sweep();
+        // merge the LPB partial top-2s of a bidder (value-symmetric)
+        for (int off = 1; off < LPB; off <<= 1) {
+            const float ob = __shfl_xor(best, off, kWave), obb = __shfl_xor(better, off, kWave);
+            const int oi = __shfl_xor(best_i, off, kWave), obi = __shfl_xor(better_i, off, kWave);
+            merge_top2(best, better, best_i, better_i, ob, obb, oi, obi);
+        }
+        // exact tie for first place: pick the candidate the reference's scan meets first (emd_bid_kernel's path)
+        const bool tie = active && (best == better);
+        if (a.stats) {
+            unsigned v[4] = {st_rows, st_kept, st_items, st_pass};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (!active) v[q] = 0;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v[q] += __shfl_xor(v[q], o);
+            }
+            const unsigned long long nb_act = __popcll(__ballot(active && sub == 0)), nb_tie = __popcll(__ballot(tie && sub == 0)),
+                                     nb_uns = __popcll(__ballot(active && sub == 0 && !seeded));
+            if (lane == 0) {
+                atomicAdd(&a.stats[0], nb_act);
+                atomicAdd(&a.stats[1], (unsigned long long)v[0]);
+                atomicAdd(&a.stats[2], (unsigned long long)v[1]);
+                atomicAdd(&a.stats[3], (unsigned long long)v[2]);
+                atomicAdd(&a.stats[4], (unsigned long long)v[3]);
+                atomicAdd(&a.stats[5], nb_tie);
+                atomicAdd(&a.stats[6], nb_uns);
+            }
+        }
+        // Exact tie for first place: the reference reports the tied object its thread-major scan meets first.  The tied
+        // objects have the value `best`, so they lie inside the ball of anything worth more than the next float below it:
+        // ONE more culled sweep finds them all (the tiled kernel re-scans all n objects with the fp64 value -- a single tie
+        // held a whole launch for ~200 us at n = 16384, and a partial scan against its ground truth has a tie in most rounds).
+        if (__any(tie)) {
+            if (tie) {
+                tie_mode = true;
+                ex0 = 1; ex1 = 0;
+                cb = filter_cb(__uint_as_float(__float_as_uint(best) + (best > 0.0f ? -1 : (best < 0.0f ? 1 : 0))));      // the float below `best` (a +-0 best: itself; 3 - r - p = 0 only for objects ~3 away)
+                if (best == 0.0f) cb = filter_cb(-1e-30f);
+                bx0 = 0; bx1 = gx - 1; by0 = 0; by1 = gy - 1; bz0 = 0; bz1 = gz - 1;
+                if (cull) set_box(cb);
+                sweep();            // (a group's batches use only its own lanes: the other groups of the wave sit this out)
+            }
+            for (int off = 1; off < LPB; off <<= 1) {
+                const unsigned long long o = __shfl_xor(tie_key, off, kWave);
+                tie_key = o < tie_key ? o : tie_key;
+            }
+            if (tie) best_i = (int)(tie_key & 0xffffffffu);
+        }
+        if (active && sub == 0) {
+            const float inc = __fadd_rn(__fsub_rn(best, better), a.eps);
+            a.bid[base + j] = best_i;
+            a.second[base + j] = better_i;
+            a.bid_increments[base + j] = inc;
+            atomic_max_float(&a.max_increments[base + best_i], inc);
+            if (a.chain_head != nullptr) {
+                const unsigned long long mine = ((unsigned long long)(unsigned)__float_as_int(inc) << 32) | (a.stamp << 24) | (unsigned)j;
+                a.chain_next[base + j] = atomicExch(&a.chain_head[base + best_i], mine);
+            }
+        }
+    }
+}
+
+int launch_emd_grid_build(int b, int n, const float *xyz2, const float *price, EGridHdr *hdr, int *start, float4 *sorted, int *pos_of,
+                          int *orig_of, int cells_target, int cells_max, hipStream_t st)
+{
+    const size_t lds = ((size_t)cells_max + 2 * kEGWaves) * sizeof(int) + 6 * kEGWaves * sizeof(float);
+    hipLaunchKernelGGL(emd_grid_build_kernel, dim3(b), dim3(kEGBlock), lds, st, n, xyz2, price, hdr, start, sorted, pos_of, orig_of,
+                       cells_target, cells_max);
+    return check(hipGetLastError(), "emd_grid_build_kernel launch") ? 1 : 0;
+}
+
+int launch_emd_bid_grid(const EmdGridBid &a, int fma, hipStream_t st)
+{
+    if (fma) hipLaunchKernelGGL((emd_bid_grid_kernel<1>), dim3(a.G * a.nb), dim3(kEBlock), 0, st, a);
+    else hipLaunchKernelGGL((emd_bid_grid_kernel<0>), dim3(a.G * a.nb), dim3(kEBlock), 0, st, a);
+    return 1;
+}
+
+}  // namespace genpc

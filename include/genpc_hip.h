@@ -120,6 +120,17 @@ int genpc_emd_forward(int b, int n, int m, const float *xyz1, const float *xyz2,
                       int *unass_cnt_sum, int *cnt_tmp, int *max_idx, float eps,
                       int iters, void *stream);
 
+/* Bid kernel of genpc_emd_forward, for tests and A/B (applies to the calling host thread): 1 the cell-sorted culled
+ * bid (csrc/emd_grid.hip: a bidder visits only the grid rows that can hold an object worth more than its current
+ * second-best), 0 the tiled bid over all objects, < 0 the default (culled from n = 512 on when eps >= 0).  Both give
+ * the same bits.  hooks (>= 0 to set; < 0 keep): 1 = count what the culled bid does (genpc_emd_stats).  Returns the
+ * previous `grid` setting. */
+int genpc_emd_tune(int grid, int hooks);
+/* Counters of the culled bid, accumulated on the current device while hook 1 is set: out[0] bidder-rounds, out[1] rows
+ * of their search boxes, out[2] rows kept by the bound, out[3] objects tested, out[4] exact (fp64) evaluations, out[5]
+ * exact first-place ties (full re-scan), out[6] bidders without seeds (probe).  Synchronises `stream`; reset != 0 zeroes. */
+int genpc_emd_stats(unsigned long long out[8], int reset, void *stream);
+
 /* Replaces emd_cuda_backward (emd_cuda.cu:302-316, emd.backward in
  * emd.cpp:19-23,28): gradxyz[B,n,3] (caller-zeroed) += 2*graddist*(xyz1-xyz2[idx]). */
 int genpc_emd_backward(int b, int n, const float *xyz1, const float *xyz2,
