@@ -117,6 +117,7 @@ struct EmdGridBid {
     const float4 *sorted;
     const EGridHdr *hdr;
     unsigned long long *chain_head, *chain_next;
+    int *chain_cnt;                // bidders per object this round (emd_settle_kernel)
     unsigned long long *stats;     // hook (genpc_emd_tune): [0] bidders, [1] rows of their boxes, [2] rows kept, [3] objects tested, [4] exact evaluations, [5] first-place ties, [6] unseeded bidders; else null
 };
 int launch_emd_grid_build(int b, int n, const float *xyz2, const float *price, EGridHdr *hdr, int *start, float4 *sorted, int *pos_of,

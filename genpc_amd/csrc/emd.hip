@@ -40,11 +40,21 @@
 
 namespace genpc {
 
+// First launch of a call: the list of round 0 (everybody bids), and the library's own per-call state -- no seed yet
+// (second = -1), empty bidder chains, no tickets drawn -- which used to be four memsets in front of the first round
+// (a stream operation each: ~4 us apiece of a 1 ms call).
 __global__ __launch_bounds__(kEBlock) void emd_init_kernel(int b, int n, int *__restrict__ list, int *__restrict__ cnt_a,
-                                                           int *__restrict__ cnt_b)
+                                                           int *__restrict__ cnt_b, int *__restrict__ second,
+                                                           unsigned long long *__restrict__ chain_head,
+                                                           unsigned long long *__restrict__ whead, int *__restrict__ chain_cnt,
+                                                           int *__restrict__ arrived)
 {
     int t = blockIdx.x * kEBlock + threadIdx.x;
-    if (t < b * n) list[t] = t % n;
+    if (t < b * n) {
+        list[t] = t % n;
+        if (second) second[t] = -1;
+        if (chain_head) { chain_head[t] = 0ull; whead[t] = 0ull; chain_cnt[t] = 0; arrived[t] = 0; }
+    }
     if (t < b) {
         cnt_a[t] = n;
         cnt_b[t] = 0;
@@ -62,7 +72,8 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
                                                           float4 *__restrict__ parts, int *__restrict__ arrive,
                                                           int *__restrict__ second, int zmax,
                                                           unsigned long long *__restrict__ chain_head,
-                                                          unsigned long long *__restrict__ chain_next, unsigned stamp, int G, int nb)
+                                                          unsigned long long *__restrict__ chain_next, unsigned stamp, int G, int nb,
+                                                          int *__restrict__ chain_cnt)
 {
     constexpr int kTile = TILE, kLoadsPerThread = TILE / 256;
     // one tile of objects as four planes (x, y, z, price): a 16-byte read delivers four consecutive objects' x as two
@@ -339,6 +350,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
             if (chain_head != nullptr) {
                 const unsigned long long mine = ((unsigned long long)(unsigned)__float_as_int(inc) << 32) | (stamp << 24) | (unsigned)j;
                 chain_next[(size_t)batch * n + j] = atomicExch(&chain_head[(size_t)batch * n + best_i], mine);
+                atomicAdd(&chain_cnt[(size_t)batch * n + best_i], 1);       // how many bid for it this round (no value returned: nothing waits)
             }
         }
     }
@@ -422,27 +434,94 @@ __global__ __launch_bounds__(kEBlock) void emd_assign_kernel(int n, const int *_
 // max_increments[object] (increments are >= 0 when eps >= 0, the only case this kernel is launched for; the winner resets
 // that word, so it is not read here).  A chain of one -- the usual case once few bidders are left -- is read off the head
 // word alone: the launch is as deep as Assign was, and GetMax's 4.7 us per round are gone.
+// LONG chains (round 4).  With L bidders on one object the walks cost L^2 dependent loads: a partial scan whose ground truth
+// is mis-framed (bundled scan 06830: thousands of points bid for the same few boundary objects, every round) took 79 ms
+// where its neighbours take 2-4, and the first rounds of 13 scans 2 ms each.  The bid kernel therefore also counts the
+// bidders of an object (chain_cnt), and an object with more than kChainWalkMax of them is settled without any walk:
+// every bidder tests itself against max_increments[object] (complete: the bid kernel is over; nobody resets it before the
+// end), a bidder outside the window is a loser and re-lists itself at once, one inside raises max_idx (atomicMax) and links
+// itself into a second, short chain of the in-window bidders; then it draws a ticket.  The bidder with the LAST ticket
+// knows every other one is done: it reads the winner, re-lists the other in-window bidders, does Assign's work for the
+// winner and hands the four words back clean.  O(1) per bidder, nobody waits for anybody, one launch.
+constexpr int kChainWalkMax = 4;
 __global__ __launch_bounds__(kEBlock) void emd_settle_kernel(int n, const int *__restrict__ list, const int *__restrict__ cnt,
                                                              int *__restrict__ list_next, int *__restrict__ cnt_next,
                                                              int *__restrict__ assignment, int *__restrict__ assignment_inv,
                                                              float *__restrict__ price, const int *__restrict__ bid,
+                                                             const float *__restrict__ bid_increments,
                                                              float *__restrict__ max_increments, int *__restrict__ max_idx,
                                                              const unsigned long long *__restrict__ chain_head,
                                                              const unsigned long long *__restrict__ chain_next, unsigned stamp,
-                                                             int last, const int *__restrict__ pos_of, float *__restrict__ price_s)
+                                                             int last, const int *__restrict__ pos_of, float *__restrict__ price_s,
+                                                             int *__restrict__ chain_cnt, int *__restrict__ arrived,
+                                                             unsigned long long *__restrict__ whead, unsigned long long *__restrict__ wnext)
 {
     const int batch = blockIdx.y;
     const int U = cnt[batch];
     const size_t base = (size_t)batch * n;
+    auto live = [&](unsigned long long r) { return (unsigned)((r >> 24) & 0xffu) == stamp; };
+    auto who = [](unsigned long long r) { return (int)(r & 0xffffffu); };
+    auto inc_of = [](unsigned long long r) { return __int_as_float((int)(r >> 32)); };
+    auto relist = [&](int jj) {
+        const int pos = atomicAdd(&cnt_next[batch], 1);
+        list_next[base + pos] = jj;
+    };
+    // Assign's work for the winner w of object o (not the forced last round)
+    auto take = [&](int o, int w, float inc_w, int pos_s) {
+        const int prev = assignment_inv[base + o];
+        if (prev != -1) {
+            assignment[base + prev] = -1;
+            relist(prev);
+        }
+        assignment_inv[base + o] = w;
+        assignment[base + w] = o;
+        const float np_ = __fadd_rn(price[base + o], inc_w);
+        price[base + o] = np_;
+        if (price_s) price_s[4 * (base + pos_s)] = np_;
+    };
     for (int u = blockIdx.x * kEBlock + threadIdx.x; u < U; u += gridDim.x * kEBlock) {
         const int j = list[base + u];
         const int bid_id = bid[base + j];
         const unsigned long long mynext = chain_next[base + j];      // (what j displaced: read beside bid[j], not behind the head)
         const unsigned long long head = chain_head[base + bid_id];
+        const int C = chain_cnt[base + bid_id];                      // (0 once a short chain's winner has cleaned up: same path)
         const int pos = pos_of ? pos_of[base + bid_id] : 0;          // the object's place in the cell-sorted copy (emd_grid.hip)
-        auto live = [&](unsigned long long r) { return (unsigned)((r >> 24) & 0xffu) == stamp; };
-        auto who = [](unsigned long long r) { return (int)(r & 0xffffffu); };
-        auto inc_of = [](unsigned long long r) { return __int_as_float((int)(r >> 32)); };
+        if (C > kChainWalkMax) {
+            const float my_inc = bid_increments[base + j];
+            const double bid_inc = (double)my_inc, max_inc = (double)max_increments[base + bid_id];
+            const bool inwin = last || (bid_inc - 1e-6 <= max_inc && max_inc <= bid_inc + 1e-6);
+            if (last) {
+                assignment[base + j] = bid_id;                       // every remaining bidder takes its object (:201)
+                atomicAdd(&price[base + bid_id], my_inc);
+            }
+            if (inwin) {
+                atomicMax(&max_idx[base + bid_id], j);
+                if (!last) {
+                    const unsigned long long old = atomicExch(&whead[base + bid_id], ((unsigned long long)stamp << 24) | (unsigned)j);
+                    __hip_atomic_store(&wnext[base + j], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                relist(j);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my atomics and the link have landed before my ticket is drawn
+            const int ticket = __hip_atomic_fetch_add(&arrived[base + bid_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == C - 1) {
+                const int w = __hip_atomic_load(&max_idx[base + bid_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!last) {
+                    for (unsigned long long r = __hip_atomic_load(&whead[base + bid_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); live(r);
+                         r = __hip_atomic_load(&wnext[base + who(r)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        if (who(r) != w) relist(who(r));
+                    take(bid_id, w, bid_increments[base + w], pos);
+                } else {
+                    assignment_inv[base + bid_id] = w;
+                }
+                max_increments[base + bid_id] = -1e9f;
+                max_idx[base + bid_id] = -1;
+                chain_cnt[base + bid_id] = 0;
+                __hip_atomic_store(&arrived[base + bid_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;
+        }
         int winner = who(head);
         float my_inc = inc_of(head);
         if (winner != j || live(mynext)) {
@@ -468,24 +547,15 @@ __global__ __launch_bounds__(kEBlock) void emd_settle_kernel(int n, const int *_
                 assignment_inv[base + bid_id] = j;
                 max_increments[base + bid_id] = -1e9f;
                 max_idx[base + bid_id] = -1;
+                chain_cnt[base + bid_id] = 0;
             }
         } else if (elected) {
-            const int prev = assignment_inv[base + bid_id];
-            if (prev != -1) {
-                assignment[base + prev] = -1;
-                const int pos = atomicAdd(&cnt_next[batch], 1);
-                list_next[base + pos] = prev;
-            }
-            assignment_inv[base + bid_id] = j;
-            assignment[base + j] = bid_id;
-            const float np_ = __fadd_rn(price[base + bid_id], my_inc);
-            price[base + bid_id] = np_;
-            if (price_s) price_s[4 * (base + pos)] = np_;
+            take(bid_id, j, my_inc, pos);
             max_increments[base + bid_id] = -1e9f;
             max_idx[base + bid_id] = -1;
+            chain_cnt[base + bid_id] = 0;
         } else {
-            const int pos = atomicAdd(&cnt_next[batch], 1);
-            list_next[base + pos] = j;
+            relist(j);
         }
     }
 }
@@ -593,7 +663,8 @@ __global__ __launch_bounds__(kEBlock) void emd_grad_kernel(long long total, int 
 namespace genpc { static thread_local int t_emd_grid = -1, t_emd_hooks = 0; }
 
 /* Bid kernel selection for tests and A/B (thread-local like genpc_nn_tune): 1 the cell-sorted culled bid (emd_grid.hip),
- * 0 the tiled bid over all objects (emd_bid_kernel), < 0 the default (culled from n = 512 on when eps >= 0).  Returns
+ * 0 the tiled bid over all objects (emd_bid_kernel), < 0 the default (culled when eps >= 0 and n >= 4096 or B n >= 65536:
+ * a single small cloud is bound by the round's dependent loads, of which the culled bid has more).  Returns
  * the previous setting.  Every choice yields the same bits.  hooks (>= 0 to set): 1 = count what the culled bid does
  * (genpc_emd_stats). */
 GENPC_API int genpc_emd_tune(int grid, int hooks)
@@ -653,11 +724,12 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     // bidder chains per object (emd_settle_kernel): head word per object, link word per bidder
     static const bool no_settle = getenv("GENPC_EMD_SETTLE") && atoi(getenv("GENPC_EMD_SETTLE")) == 0;
     const bool settle = !no_settle && eps >= 0.0f && n <= (1 << 24);
-    const size_t chain_bytes = settle ? 2 * (size_t)total * sizeof(unsigned long long) : 0;
+    // chain_head | chain_next | whead | wnext (8-byte words per object / bidder), chain_cnt | arrived (ints per object)
+    const size_t chain_bytes = settle ? (4 * (size_t)total * sizeof(unsigned long long) + 2 * (size_t)total * sizeof(int) + 255) / 256 * 256 : 0;
     // cell-sorted copy of the objects for the culled bid (emd_grid.hip): needs prices >= 0 (eps >= 0) and the seeds
     static const int env_grid = getenv("GENPC_EMD_GRID") ? atoi(getenv("GENPC_EMD_GRID")) : -1;
     static const bool noseed_env = getenv("GENPC_EMD_NOSEED") != nullptr;
-    const bool grid = (t_emd_grid >= 0 ? t_emd_grid != 0 : (env_grid >= 0 ? env_grid != 0 : n >= 512)) && eps >= 0.0f && !noseed_env;
+    const bool grid = (t_emd_grid >= 0 ? t_emd_grid != 0 : (env_grid >= 0 ? env_grid != 0 : (n >= 4096 || (long long)b * n >= 65536))) && eps >= 0.0f && !noseed_env;
     auto al256 = [](size_t v) { return (v + 255) / 256 * 256; };
     const int cells_max = kEGMaxCells;
     const size_t g_hdr = grid ? al256((size_t)b * sizeof(EGridHdr)) : 0, g_start = grid ? al256((size_t)b * (cells_max + 1) * sizeof(int)) : 0;
@@ -674,12 +746,15 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     float *g_ps_p = grid ? (float *)g_sorted_p + 3 : nullptr;      // the price of sorted position p: g_ps_p[4 p] (the .w of its entry)
     unsigned long long *chain_head = settle ? (unsigned long long *)(ws + arrive_bytes + list_bytes + second_bytes + parts_bytes) : nullptr;
     unsigned long long *chain_next = settle ? chain_head + total : nullptr;
+    unsigned long long *whead = settle ? chain_head + 2 * total : nullptr, *wnext = settle ? chain_head + 3 * total : nullptr;
+    int *chain_cnt = settle ? (int *)(chain_head + 4 * total) : nullptr, *arrived = settle ? chain_cnt + total : nullptr;
+    // (bidder counts and tickets are zero between rounds by construction -- the settling thread hands them back --; they
+    // are cleared once per call with everything else, by emd_init_kernel)
     int *arrive = (int *)ws;
     int *list_b = (int *)(ws + arrive_bytes);
     int *second = (int *)(ws + arrive_bytes + list_bytes);
     float4 *parts = (float4 *)(ws + arrive_bytes + list_bytes + second_bytes);
-    // second-best object of each point's last bid (-1: has not bid yet)
-    if (!check(hipMemsetAsync(second, 0xff, (size_t)total * sizeof(int), st), "hipMemsetAsync(second)")) return 0;
+    // second-best object of each point's last bid (-1: has not bid yet; set by emd_init_kernel)
     static const bool noseed = getenv("GENPC_EMD_NOSEED") != nullptr;
     if (noseed) second = nullptr;
     static const bool nosplit = getenv("GENPC_EMD_NOSPLIT") != nullptr;
@@ -689,7 +764,8 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     const bool fma = arith_mode() != 0;
 
     const int lin_blocks = ceil_div((int)total, kEBlock);
-    hipLaunchKernelGGL(emd_init_kernel, dim3(lin_blocks), dim3(kEBlock), 0, st, b, n, lists[0], cnts[0], cnts[1]);
+    hipLaunchKernelGGL(emd_init_kernel, dim3(lin_blocks), dim3(kEBlock), 0, st, b, n, lists[0], cnts[0], cnts[1], second, chain_head, whead,
+                       chain_cnt, arrived);
     if (grid) {
         // about two objects per cell if the cloud filled its box (surfaces fill far fewer cells, with more objects each)
         static const int env_ppc = getenv("GENPC_EMD_GRID_PPC_X10") ? atoi(getenv("GENPC_EMD_GRID_PPC_X10")) : 20;
@@ -727,8 +803,9 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
         // rounds that took the two list-walking launches take the settle kernel (the single-block resolve keeps its rounds)
         const bool use_chain = settle && it < resolve_from;
         const unsigned stamp = (unsigned)(it % 255) + 1u;      // 8 bits in a record: the heads are cleared every 255 rounds
-        if (use_chain && it % 255 == 0 &&
-            !check(hipMemsetAsync(chain_head, 0, (size_t)total * sizeof(unsigned long long), st), "hipMemsetAsync(chain heads)"))
+        if (use_chain && it > 0 && it % 255 == 0 &&
+            (!check(hipMemsetAsync(chain_head, 0, (size_t)total * sizeof(unsigned long long), st), "hipMemsetAsync(chain heads)") ||
+             !check(hipMemsetAsync(whead, 0, (size_t)total * sizeof(unsigned long long), st), "hipMemsetAsync(window heads)")))
             return 0;
         if (grid) {
             EmdGridBid ga{};
@@ -739,13 +816,13 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
             ga.list = lists[cur]; ga.cnt = cnts[cur]; ga.start = g_start_p; ga.cnt_next = cnts[nxt];
             ga.bid = bid; ga.second = second; ga.bid_increments = bid_increments; ga.max_increments = max_increments;
             ga.sorted = g_sorted_p; ga.hdr = g_hdr_p;
-            ga.chain_head = use_chain ? chain_head : nullptr; ga.chain_next = chain_next;
+            ga.chain_head = use_chain ? chain_head : nullptr; ga.chain_next = chain_next; ga.chain_cnt = chain_cnt;
             ga.stats = (t_emd_hooks & 1) ? (unsigned long long *)workspace(28, 256, nullptr, nullptr, 256) : nullptr;
             launch_emd_bid_grid(ga, fma ? 1 : 0, st);
         } else {
             typedef void (*bid_fn)(int, const float *, const float *, const float *, float, const int *, const int *,
                                    int *, int *, float *, float *, int, float4 *, int *, int *, int, unsigned long long *,
-                                   unsigned long long *, unsigned, int, int);
+                                   unsigned long long *, unsigned, int, int, int *);
             static const int zmax_env = getenv("GENPC_EMD_ZMAX") ? atoi(getenv("GENPC_EMD_ZMAX")) : kZMax;
             const int zmax = zmax_env < 1 ? 1 : (zmax_env > kZMax ? kZMax : zmax_env);
             // Lanes per bidder.  Round 0 has no filter seeds: the fewer lanes share a bidder, the sooner a
@@ -776,13 +853,14 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
             hipLaunchKernelGGL(f, dim3(G * b), dim3(kEBlock), 0, st, n, xyz1, xyz2, (const float *)price, eps,
                                (const int *)lists[cur], (const int *)cnts[cur], cnts[nxt], bid, bid_increments,
                                max_increments, force_p, parts, arrive, second, zmax, use_chain ? chain_head : (unsigned long long *)nullptr,
-                               chain_next, stamp, G, b);
+                               chain_next, stamp, G, b, chain_cnt);
         }
         if (use_chain) {
             hipLaunchKernelGGL(emd_settle_kernel, dim3(GL, b), dim3(kEBlock), 0, st, n, (const int *)lists[cur],
                                (const int *)cnts[cur], lists[nxt], cnts[nxt], assignment, assignment_inv, price,
-                               (const int *)bid, max_increments, max_idx, (const unsigned long long *)chain_head,
-                               (const unsigned long long *)chain_next, stamp, last, (const int *)g_pos_p, g_ps_p);
+                               (const int *)bid, (const float *)bid_increments, max_increments, max_idx,
+                               (const unsigned long long *)chain_head, (const unsigned long long *)chain_next, stamp, last,
+                               (const int *)g_pos_p, g_ps_p, chain_cnt, arrived, whead, wnext);
         } else if (it >= resolve_from) {
             hipLaunchKernelGGL(emd_resolve_kernel, dim3(b), dim3(kResolveBlock), 0, st, n, (const int *)lists[cur],
                                (const int *)cnts[cur], lists[nxt], cnts[nxt], assignment, assignment_inv, price,

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
             if (a.chain_head != nullptr) {
                 const unsigned long long mine = ((unsigned long long)(unsigned)__float_as_int(inc) << 32) | (a.stamp << 24) | (unsigned)j;
                 a.chain_next[base + j] = atomicExch(&a.chain_head[base + best_i], mine);
+                atomicAdd(&a.chain_cnt[base + best_i], 1);
             }
         }
     }

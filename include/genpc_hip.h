@@ -109,8 +109,9 @@ int genpc_chamfer_backward(int b, int n, const float *xyz1, int m,
  * same initial state as emd_module.py:43-54 (assignment/assignment_inv = -1,
  * the rest 0; unass_cnt/unass_cnt_sum/cnt_tmp are int32[512]).  On return:
  * dist[B,n] squared distance to the assigned point, assignment[B,n],
- * assignment_inv, price, bid, bid_increments, max_increments, max_idx hold the
- * final auction state; unass_idx/unass_cnt/unass_cnt_sum/cnt_tmp hold the
+ * assignment_inv, price, bid, bid_increments, max_increments hold the
+ * final auction state; max_idx is election scratch (the reference never resets it, emd_cuda.cu:181-194, and
+ * no caller reads it: here every object that was bid for ends at -1); unass_idx/unass_cnt/unass_cnt_sum/cnt_tmp hold the
  * last round's compaction (order within unass_idx is unspecified, as in the
  * reference).                                                               */
 int genpc_emd_forward(int b, int n, int m, const float *xyz1, const float *xyz2,
@@ -122,7 +123,7 @@ int genpc_emd_forward(int b, int n, int m, const float *xyz1, const float *xyz2,
 
 /* Bid kernel of genpc_emd_forward, for tests and A/B (applies to the calling host thread): 1 the cell-sorted culled
  * bid (csrc/emd_grid.hip: a bidder visits only the grid rows that can hold an object worth more than its current
- * second-best), 0 the tiled bid over all objects, < 0 the default (culled from n = 512 on when eps >= 0).  Both give
+ * second-best), 0 the tiled bid over all objects, < 0 the default (culled when eps >= 0 and n >= 4096 or B n >= 65536).  Both give
  * the same bits.  hooks (>= 0 to set; < 0 keep): 1 = count what the culled bid does (genpc_emd_stats).  Returns the
  * previous `grid` setting. */
 int genpc_emd_tune(int grid, int hooks);

@@ -313,3 +313,24 @@ def test_emd_non_finite_clouds(gp, oracle):
     od, oass = oracle.emd_forward(x, y, 0.005, 12, 1)
     np.testing.assert_array_equal(got["assignment"], oass)
     np.testing.assert_array_equal(got["dist"].view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("iters", [1, 2, 9, 50])
+def test_emd_crowded_objects(gp, oracle, iters):
+    """Hundreds of bidders on a handful of objects, round after round (a partial scan whose ground truth is mis-framed:
+    bundled scan 06830): the settle kernel handles such an object without walking its chain of bidders -- window test,
+    atomicMax, ticket, the last ticket assigns -- also in a forced last round; every state array against the oracle."""
+    rng = np.random.default_rng(50 + iters)
+    b, n = 2, 2048
+    x = (rng.random((b, n, 3), dtype=np.float32) * np.float32(0.05)).astype(np.float32)          # bidders: a small cluster
+    y = (rng.random((b, n, 3), dtype=np.float32) + np.float32(2.0)).astype(np.float32)           # objects: far away ...
+    y[:, :6] = rng.random((b, 6, 3), dtype=np.float32) * np.float32(0.05) + np.float32(0.1)      # ... but six next to the cluster
+    y[1, 6:40] = y[1, 5] + rng.random((34, 3), dtype=np.float32) * np.float32(1e-4)              # and a knot of near-equal ones
+    got = run_hip(gp, x, y, 0.005, iters, 1)
+    d, ass, st = oracle.emd_forward(x, y, 0.005, iters, 1, return_state=True)
+    np.testing.assert_array_equal(got["assignment"], ass)
+    np.testing.assert_array_equal(got["dist"], d)
+    np.testing.assert_array_equal(got["assignment_inv"], st["assignment_inv"])
+    np.testing.assert_array_equal(got["bid"], st["bid"])
+    np.testing.assert_array_equal(got["bid_increments"], st["bid_increments"])
+    np.testing.assert_allclose(got["price"], st["price"], rtol=1e-5, atol=2e-6)
