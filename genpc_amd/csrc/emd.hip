@@ -812,6 +812,8 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
             ga.n = n; ga.G = G; ga.nb = b; ga.cells_max = cells_max; ga.eps = eps; ga.stamp = stamp;
             static const int env_lpb = getenv("GENPC_EMD_LPB") ? atoi(getenv("GENPC_EMD_LPB")) : 0;
             ga.force_lpb = env_lpb;
+            static const int env_xcd = getenv("GENPC_EMD_XCD") ? atoi(getenv("GENPC_EMD_XCD")) : 0;
+            ga.xcd_pin = env_xcd;
             ga.xyz1 = xyz1; ga.xyz2 = xyz2; ga.price = price; ga.orig_of = g_of_p;
             ga.list = lists[cur]; ga.cnt = cnts[cur]; ga.start = g_start_p; ga.cnt_next = cnts[nxt];
             ga.bid = bid; ga.second = second; ga.bid_increments = bid_increments; ga.max_increments = max_increments;

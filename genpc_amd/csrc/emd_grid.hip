@@ -210,18 +210,26 @@ __global__ __launch_bounds__(kEGBlock) void emd_grid_build_kernel(int n, const f
 template <int FMA>
 __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
 {
-    __shared__ int s_pre[kEBlock / kWave][136], s_p0[kEBlock / kWave][136];      // per wave: (64 / LPB) groups x (2 LPB + 1) entries
+    __shared__ int s_pre[kEBlock / kWave][72], s_p0[kEBlock / kWave][72];      // per wave: (64 / LPB) groups x (LPB + 1) entries
+    __shared__ int s_que[kEBlock / kWave][512];                                 // per wave: (64 / LPB) groups x 8 LPB queued entries
     const int n = a.n, G = a.G, nb = a.nb;
     int batch, bx;
-    {   // the blocks of a cloud on one XCD (as emd_bid_kernel)
+    {
+        // Clouds interleaved over the block ids (and with them over the XCDs): the clouds of a call differ in work here --
+        // bidders left, sizes of their boxes; a mis-framed scan keeps ten times the work of its neighbours -- and
+        // emd_bid_kernel's "a cloud's blocks on one XCD" (its objects stay in that XCD's L2) made the launch as long as
+        // the heaviest cloud on an eighth of the chip.  GENPC_EMD_XCD=1 restores it for A/B.
         const int lin = blockIdx.x, nb8 = nb & ~7;
-        if (lin < G * nb8) {
+        if (a.xcd_pin && lin < G * nb8) {
             const int k = lin >> 3;
             batch = 8 * (k / G) + (lin & 7);
             bx = k % G;
-        } else {
+        } else if (a.xcd_pin) {
             batch = nb8 + (lin - G * nb8) / G;
             bx = (lin - G * nb8) % G;
+        } else {
+            batch = lin % nb;
+            bx = lin / nb;
         }
     }
     const int U = a.cnt[batch];
@@ -260,8 +268,10 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
         float seed = -1e9f;
         bool seeded = false;
         unsigned st_rows = 0, st_kept = 0, st_items = 0, st_pass = 0;      // hook counters (a.stats != null only)
-        bool tie_mode = false;                  // second sweep of a bidder whose two best values are equal (below)
+        int mode = 0;                           // what a batch does with an entry: 0 bid, 1 collect the objects tied for first place, 2 proxy scan
         unsigned long long tie_key = ~0ull;
+        float k1 = inf, k2 = inf;               // proxy scan: the two smallest sqrtf(sq) + price of this lane and where
+        int q1 = -1, q2 = -1;
         {
             const int sa = a.bid[base + j], sc = a.second[base + j];
             if (sc >= 0 && sa != sc && (unsigned)sa < (unsigned)n) {
@@ -279,48 +289,80 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
             const float wh = c + 1 < g ? __fadd_rn(lo, __fmul_rn((float)(c + 1), h)) : inf;
             return fmaxf(0.0f, fmaxf((wl - s) - q, (q - s) - wh));
         };
-        // One batch of runs of the sorted array, two per lane ([pA, pA + lA) and [pB, pB + lB), possibly empty), spread
+        // One batch of runs of the sorted array, one per lane ([pA, pA + lA), possibly empty), spread
         // EVENLY over the group's lanes: exclusive scan of the lengths, then lane `sub` takes the items sub, sub + LPB, ...
         // of the concatenation (a run of a dense row is hundreds of objects: a lane per row left 63 lanes waiting for one --
         // the 13 bundled scans took 196 ms against 62 for the tiled kernel).  Consecutive lanes read consecutive entries.
         // Per item: the pre-filter, the exact value, the lane-local top-2 -- four loads in flight.
-        int *pre = s_pre[wave] + grp * (2 * LPB + 1), *pp0 = s_p0[wave] + grp * (2 * LPB + 1);
-        auto batch_eval = [&](int pA, int lA, int pB, int lB) {
-            // entries = the non-empty runs only (on a surface most rows of a box are empty: a cursor walking 2 LPB entries
+        int *pre = s_pre[wave] + grp * (LPB + 1), *pp0 = s_p0[wave] + grp * (LPB + 1);
+        int *que = s_que[wave] + grp * (8 * LPB);
+        int qn = 0;                              // queued entries (the same number in every lane of the group)
+        const unsigned long long gmask = LPB == 64 ? ~0ull : (((1ull << LPB) - 1ull) << (lane & ~(LPB - 1)));
+        // the queued entries, one per lane: exact value (emd_cuda.cu:142-146), lane-local top-2 (or the tie key), then a
+        // tighter threshold for what follows: the largest lane-local second-best of the group is the value of a second object
+        auto flush = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int e = sub; e < qn; e += LPB) {
+                const int ps = que[e];
+                const float4 o = S[ps];
+                st_pass++;
+                const float d = bid_value<FMA>(x1, y1, z1, o.x, o.y, o.z, o.w);
+                if (mode == 0) {
+                    const bool gt = d > best;
+                    const bool gt2 = !gt && d > better;
+                    const int kk = OF[ps];
+                    better_i = gt ? best_i : (gt2 ? kk : better_i);
+                    better = __builtin_amdgcn_fmed3f(d, best, better);
+                    best = fmaxf(best, d);
+                    best_i = gt ? kk : best_i;
+                } else if (d == best) {
+                    // an object that ties for first place: its key in the reference's thread-major scan order
+                    // (emd_cuda.cu:108-118,136-139,165-173: the candidate the scan meets first is reported)
+                    const int k = OF[ps];
+                    const int kt = k & 2047;                       // position in the reference's 2048-tile
+                    const int tile0 = k - kt;
+                    const int end_k = min(n, tile0 + 2048) - tile0;
+                    const int delta = (end_k + thread_per_unass - 1) / thread_per_unass;
+                    const unsigned long long kk = ((unsigned long long)(kt / delta) << 32) | (unsigned)k;
+                    tie_key = kk < tie_key ? kk : tie_key;
+                }
+            }
+            qn = 0;
+            if (mode == 0) {
+                float gb = better;
+                for (int off = 1; off < LPB; off <<= 1) gb = fmaxf(gb, __shfl_xor(gb, off, kWave));
+                seed = fmaxf(seed, gb);
+                cb = filter_cb(fmaxf(better, seed));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        auto batch_eval = [&](int pA, int lA) {
+            // entries = the non-empty runs only (on a surface most rows of a box are empty: a cursor walking LPB entries
             // with a dependent LDS read each cost more than the objects)
-            const unsigned long long gmask = LPB == 64 ? ~0ull : (((1ull << LPB) - 1ull) << (lane & ~(LPB - 1)));
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const unsigned long long mA = __ballot(lA > 0) & gmask, mB = __ballot(lB > 0) & gmask;
-            const int nA = __popcll(mA), E = nA + __popcll(mB);
-            int incl = lA + lB;
+            const unsigned long long mA = __ballot(lA > 0) & gmask;
+            const int E = __popcll(mA);
+            int incl = lA;
 #pragma unroll
             for (int o = 1; o < kWave; o <<= 1) {
                 const int t = __shfl_up(incl, o, kWave);
                 if (o < LPB && sub >= o) incl += t;
             }
-            const int exclA = incl - (lA + lB);
             const int T = __shfl(incl, (lane & ~(LPB - 1)) + LPB - 1, kWave);
-            // order: all A runs (by lane), then all B runs; a lane's B run starts after every A run and the B runs below it
-            int sumA = lA;
-#pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) {
-                const int t = __shfl_up(sumA, o, kWave);
-                if (o < LPB && sub >= o) sumA += t;
-            }
-            const int totA = __shfl(sumA, (lane & ~(LPB - 1)) + LPB - 1, kWave);
-            const int offA = sumA - lA;                              // A runs of the lanes below
-            const int offB = totA + (exclA - offA);                  // all A runs + B runs of the lanes below
-            if (lA > 0) { const int e = __popcll(mA & below); pre[e] = offA; pp0[e] = pA; }
-            if (lB > 0) { const int e = nA + __popcll(mB & below); pre[e] = offB; pp0[e] = pB; }
+            if (lA > 0) { const int e = __popcll(mA & ((1ull << lane) - 1ull)); pre[e] = incl - lA; pp0[e] = pA; }
             if (sub == 0) pre[E] = T;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int cur = 0;
             if (sub == 0) st_items += (unsigned)T;
-            for (int t = sub; t < T; t += 4 * LPB) {
+            for (int t0 = 0; t0 < T; t0 += 4 * LPB) {      // group-uniform trip count (the queue length below is kept in step by every lane)
+                const int t = t0 + sub;
                 float4 o[4];
                 int pos[4];
+                bool pass[4] = {false, false, false, false};
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int ti = t + i * LPB;
@@ -328,7 +370,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
                         while (ti >= pre[cur + 1]) cur++;
                         pos[i] = pp0[cur] + (ti - pre[cur]);
                     } else {
-                        pos[i] = pos[0];             // past the end: re-read the first (t < T), not evaluated
+                        pos[i] = pp0[0];             // past the end: re-read the batch's first entry (T > 0), not evaluated
                     }
                     o[i] = S[pos[i]];
                 }
@@ -336,33 +378,27 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
                 for (int i = 0; i < 4; i++) {
                     if (t + i * LPB < T) {
                         const float sq = sqdist_e<FMA>(o[i].x - x1, o[i].y - y1, o[i].z - z1);
-                        const float tt = cb - o[i].w;
-                        if (sq < tt * tt) {
-                            st_pass++;
-                            const float r = sqrtf(sq);
-                            const float d = (float)((3.0 - (double)r) - (double)o[i].w);
-                            if (!tie_mode) {
-                                const bool gt = d > best;
-                                const bool gt2 = !gt && d > better;
-                                const int kk = OF[pos[i]];
-                                better_i = gt ? best_i : (gt2 ? kk : better_i);
-                                better = __builtin_amdgcn_fmed3f(d, best, better);
-                                best = fmaxf(best, d);
-                                best_i = gt ? kk : best_i;
-                                cb = filter_cb(fmaxf(better, seed));
-                            } else if (d == best) {
-                                // an object that ties for first place: its key in the reference's thread-major scan order
-                                // (emd_cuda.cu:108-118,136-139,165-173: the candidate the scan meets first is reported)
-                                const int k = OF[pos[i]];
-                                const int kt = k & 2047;                       // position in the reference's 2048-tile
-                                const int tile0 = k - kt;
-                                const int end_k = min(n, tile0 + 2048) - tile0;
-                                const int delta = (end_k + thread_per_unass - 1) / thread_per_unass;
-                                const unsigned long long kk = ((unsigned long long)(kt / delta) << 32) | (unsigned)k;
-                                tie_key = kk < tie_key ? kk : tie_key;
-                            }
+                        if (mode == 2) {
+                            const float key = sqrtf(sq) + o[i].w;
+                            if (key < k1) { k2 = k1; q2 = q1; k1 = key; q1 = pos[i]; }
+                            else if (key < k2) { k2 = key; q2 = pos[i]; }
+                            continue;
                         }
+                        const float tt = cb - o[i].w;
+                        pass[i] = sq < tt * tt;
                     }
+                }
+                if (mode != 2) {
+                    // entries that pass the filter are QUEUED, not valued on the spot: the exact path (sqrt, fp64) is ~50
+                    // instructions that the whole wave executes whenever any lane passes -- with 8 bidders to a wave on the
+                    // 13 scans that was half of the kernel's instructions (86 serialised passes per wave)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const unsigned long long m = __ballot(pass[i]) & gmask;
+                        if (pass[i]) que[qn + __popcll(m & ((1ull << lane) - 1ull))] = pos[i];
+                        qn += __popcll(m);
+                    }
+                    if (qn > 4 * LPB) flush();       // (room for one more trip of 4 LPB entries)
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -370,39 +406,6 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
         };
         const int cqx = egrid_cell1(x1, H.lo[0], H.inv, gx), cqy = egrid_cell1(y1, H.lo[1], H.inv, gy), cqz = egrid_cell1(z1, H.lo[2], H.inv, gz);
         const bool cull = !H.bad && (fabsf(x1) + fabsf(y1)) + fabsf(z1) < inf;
-        // (1) A point that has not bid yet has no seed.  The 3 x 3 x 3 cells around it are scanned with a cheap fp32 proxy of
-        // the value (sqrtf(sq) + price, smaller is better); the two best-looking objects are then VALUED exactly, like the
-        // seeds of a point that has bid before: the second-best over all objects is at least the smaller of any two.
-        // (Letting the lanes run the exact path on whatever they meet first cost 41 fp64 evaluations per point in round
-        // 0, where every lane's first two objects pass: 115 us for 16384 points.)
-        if (!seeded && cull) {
-            float k1 = inf, k2 = inf;
-            int q1 = -1, q2 = -1;
-            for (int r = sub; r < 9; r += LPB) {
-                const int cy = cqy + r % 3 - 1, cz = cqz + r / 3 - 1;
-                if (cy < 0 || cy >= gy || cz < 0 || cz >= gz) continue;
-                const int row = (cz * gy + cy) * gx;
-                const int p1 = ST[row + min(gx - 1, cqx + 1) + 1];
-                for (int p = ST[row + max(0, cqx - 1)]; p < p1; p++) {
-                    const float4 o = S[p];
-                    const float key = sqrtf(sqdist_e<FMA>(o.x - x1, o.y - y1, o.z - z1)) + o.w;
-                    if (key < k1) { k2 = k1; q2 = q1; k1 = key; q1 = p; }
-                    else if (key < k2) { k2 = key; q2 = p; }
-                }
-            }
-            for (int off = 1; off < LPB; off <<= 1) {
-                const float o1 = __shfl_xor(k1, off, kWave), o2 = __shfl_xor(k2, off, kWave);
-                const int p1 = __shfl_xor(q1, off, kWave), p2 = __shfl_xor(q2, off, kWave);
-                // two smallest of {k1, k2, o1, o2} (the lanes' sets are disjoint)
-                if (o1 < k1) { k2 = fminf(k1, o2) == k1 ? k1 : o2; q2 = (k1 <= o2) ? q1 : p2; k1 = o1; q1 = p1; }
-                else { const bool t = o1 < k2; k2 = t ? o1 : k2; q2 = t ? p1 : q2; }
-            }
-            if (q2 >= 0) {
-                const float4 oa = S[q1], ob = S[q2];
-                seed = fminf(bid_value<FMA>(x1, y1, z1, oa.x, oa.y, oa.z, oa.w), bid_value<FMA>(x1, y1, z1, ob.x, ob.y, ob.z, ob.w));
-                cb = filter_cb(seed);
-            }
-        }
         // the box |p - x1| <= cb (cell function monotone: a point within cb of x1 on an axis lies in [cell(x1 - cb), cell(x1 + cb)])
         int bx0 = 0, bx1 = gx - 1, by0 = 0, by1 = gy - 1, bz0 = 0, bz1 = gz - 1;
         auto set_box = [&](float R) {
@@ -410,16 +413,18 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
             by0 = egrid_cell1((y1 - R) - sy, H.lo[1], H.inv, gy); by1 = egrid_cell1((y1 + R) + sy, H.lo[1], H.inv, gy);
             bz0 = egrid_cell1((z1 - R) - sz, H.lo[2], H.inv, gz); bz1 = egrid_cell1((z1 + R) + sz, H.lo[2], H.inv, gz);
         };
-        if (cull) set_box(filter_cb(seed));
-        // (2) A wide box (stale seeds: the prices of the two objects the point knew have risen since it last bid -- on a
-        // partial scan against its ground truth the boxes grew to 200 rows and 4000 objects per bidder with ~100 exact
-        // evaluations): the 3 x 3 x 3 cells around the point first, on their own.  What they hold is almost always the
-        // true top-2; their second-best value becomes the seed and the box of the main pass shrinks to what can still beat
-        // it.  The cells already tested -- x in [ex0, ex1] of the rows |cy - cqy| <= 1, |cz - cqz| <= 1 -- are skipped there.
-        int ex0 = 1, ex1 = 0;
-        if (cull && (by1 - by0 + 1) * (bz1 - bz0 + 1) > kTwoPassRows) {
-            ex0 = max(0, cqx - 1);
-            ex1 = min(gx - 1, cqx + 1);
+        if (cull) set_box(cb);
+        // A point without a seed (its first bid) or with a stale one (the prices of the two objects it knew have risen since
+        // it last bid: on a partial scan against its ground truth the boxes grew to 200 rows and 4000 objects per bidder):
+        // the 3 x 3 x 3 cells around it are scanned with a cheap fp32 proxy of the value (sqrtf(sq) + price, smaller is
+        // better); the two best-looking objects are then VALUED exactly, like the seeds of a point that has bid before
+        // -- the second-best over all objects is at least the smaller of any two -- and the box shrinks to what can still
+        // beat that.  (Letting the lanes run the exact path on whatever they meet first cost 41 fp64 evaluations per point
+        // in round 0, where every lane's first two objects pass the filter: 115 us for 16384 points; and with 8 points
+        // to a wave on the 13 scans the exact path, taken whenever ANY lane passes, was half of the kernel's instructions.)
+        if (cull && (!seeded || (by1 - by0 + 1) * (bz1 - bz0 + 1) > kTwoPassRows)) {
+            mode = 2;
+            const int ex0 = max(0, cqx - 1), ex1 = min(gx - 1, cqx + 1);
             for (int r0 = 0; r0 < 9; r0 += LPB) {
                 const int r = r0 + sub;
                 const int cy = cqy + r % 3 - 1, cz = cqz + r / 3 - 1;
@@ -429,24 +434,28 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
                     pA = ST[row + ex0];
                     lA = ST[row + ex1 + 1] - pA;
                 }
-                batch_eval(pA, lA, 0, 0);
+                batch_eval(pA, lA);
             }
-            // fold the group's findings: lane 0 of the group keeps them, everybody takes the second-best as the seed
+            mode = 0;
             for (int off = 1; off < LPB; off <<= 1) {
-                const float ob = __shfl_xor(best, off, kWave), obb = __shfl_xor(better, off, kWave);
-                const int oi = __shfl_xor(best_i, off, kWave), obi = __shfl_xor(better_i, off, kWave);
-                merge_top2(best, better, best_i, better_i, ob, obb, oi, obi);
+                const float o1 = __shfl_xor(k1, off, kWave), o2 = __shfl_xor(k2, off, kWave);
+                const int p1 = __shfl_xor(q1, off, kWave), p2 = __shfl_xor(q2, off, kWave);
+                // two smallest of {k1, k2, o1, o2} (the lanes' sets are disjoint)
+                if (o1 < k1) { k2 = fminf(k1, o2) == k1 ? k1 : o2; q2 = (k1 <= o2) ? q1 : p2; k1 = o1; q1 = p1; }
+                else { const bool t = o1 < k2; k2 = t ? o1 : k2; q2 = t ? p1 : q2; }
             }
-            seed = fmaxf(seed, better);
-            if (sub != 0) { best = -1e9f; better = -1e9f; best_i = -1; better_i = -1; }
-            cb = filter_cb(fmaxf(better, seed));
-            set_box(filter_cb(seed));
+            if (q2 >= 0) {
+                const float4 oa = S[q1], ob = S[q2];
+                seed = fmaxf(seed, fminf(bid_value<FMA>(x1, y1, z1, oa.x, oa.y, oa.z, oa.w), bid_value<FMA>(x1, y1, z1, ob.x, ob.y, ob.z, ob.w)));
+                cb = filter_cb(seed);
+                set_box(cb);
+            }
         }
         auto sweep = [&]() {
         const int wy = by1 - by0 + 1, nrows = wy * (bz1 - bz0 + 1);
         for (int r0 = 0; r0 < nrows; r0 += LPB) {         // group-uniform trip count
             const int r = r0 + sub;
-            int pA = 0, lA = 0, pB = 0, lB = 0;
+            int pA = 0, lA = 0;
             if (r < nrows) {
                 st_rows++;
                 const int rz = r / wy;
@@ -468,20 +477,15 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
                 if (keep && cx0 <= cx1) {
                     st_kept++;
                     const int row = (cz * gy + cy) * gx;
-                    const bool probed = ex0 <= ex1 && abs(cy - cqy) <= 1 && abs(cz - cqz) <= 1;
-                    if (!probed) {
-                        pA = ST[row + cx0];
-                        lA = ST[row + cx1 + 1] - pA;
-                    } else {
-                        if (cx0 < ex0) { pA = ST[row + cx0]; lA = ST[row + ex0] - pA; }
-                        if (ex1 < cx1) { pB = ST[row + ex1 + 1]; lB = ST[row + cx1 + 1] - pB; }
-                    }
+                    pA = ST[row + cx0];
+                    lA = ST[row + cx1 + 1] - pA;
                 }
             }
-            batch_eval(pA, lA, pB, lB);
+            batch_eval(pA, lA);
         }
         };
         sweep();
+        flush();
         // merge the LPB partial top-2s of a bidder (value-symmetric)
         for (int off = 1; off < LPB; off <<= 1) {
             const float ob = __shfl_xor(best, off, kWave), obb = __shfl_xor(better, off, kWave);
@@ -516,13 +520,13 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
         // held a whole launch for ~200 us at n = 16384, and a partial scan against its ground truth has a tie in most rounds).
         if (__any(tie)) {
             if (tie) {
-                tie_mode = true;
-                ex0 = 1; ex1 = 0;
+                mode = 1;
                 cb = filter_cb(__uint_as_float(__float_as_uint(best) + (best > 0.0f ? -1 : (best < 0.0f ? 1 : 0))));      // the float below `best` (a +-0 best: itself; 3 - r - p = 0 only for objects ~3 away)
                 if (best == 0.0f) cb = filter_cb(-1e-30f);
                 bx0 = 0; bx1 = gx - 1; by0 = 0; by1 = gy - 1; bz0 = 0; bz1 = gz - 1;
                 if (cull) set_box(cb);
                 sweep();            // (a group's batches use only its own lanes: the other groups of the wave sit this out)
+                flush();
             }
             for (int off = 1; off < LPB; off <<= 1) {
                 const unsigned long long o = __shfl_xor(tie_key, off, kWave);
