@@ -466,16 +466,16 @@ __global__ __launch_bounds__(kEBlock) void emd_settle_kernel(int n, const int *_
         const int pos = atomicAdd(&cnt_next[batch], 1);
         list_next[base + pos] = jj;
     };
-    // Assign's work for the winner w of object o (not the forced last round)
-    auto take = [&](int o, int w, float inc_w, int pos_s) {
-        const int prev = assignment_inv[base + o];
+    // Assign's work for the winner w of object o (not the forced last round); prev / old price: the object's owner and
+    // price, requested by every bidder beside the chain head (a winner's path would otherwise be two round trips longer)
+    auto take = [&](int o, int w, float inc_w, int pos_s, int prev, float old_price) {
         if (prev != -1) {
             assignment[base + prev] = -1;
             relist(prev);
         }
         assignment_inv[base + o] = w;
         assignment[base + w] = o;
-        const float np_ = __fadd_rn(price[base + o], inc_w);
+        const float np_ = __fadd_rn(old_price, inc_w);
         price[base + o] = np_;
         if (price_s) price_s[4 * (base + pos_s)] = np_;
     };
@@ -486,6 +486,8 @@ __global__ __launch_bounds__(kEBlock) void emd_settle_kernel(int n, const int *_
         const unsigned long long head = chain_head[base + bid_id];
         const int C = chain_cnt[base + bid_id];                      // (0 once a short chain's winner has cleaned up: same path)
         const int pos = pos_of ? pos_of[base + bid_id] : 0;          // the object's place in the cell-sorted copy (emd_grid.hip)
+        const int owner = assignment_inv[base + bid_id];             // (only this object's winner writes these two, and only at the end)
+        const float old_price = price[base + bid_id];
         if (C > kChainWalkMax) {
             const float my_inc = bid_increments[base + j];
             const double bid_inc = (double)my_inc, max_inc = (double)max_increments[base + bid_id];
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(kEBlock) void emd_settle_kernel(int n, const int *_
                     for (unsigned long long r = __hip_atomic_load(&whead[base + bid_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); live(r);
                          r = __hip_atomic_load(&wnext[base + who(r)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                         if (who(r) != w) relist(who(r));
-                    take(bid_id, w, bid_increments[base + w], pos);
+                    take(bid_id, w, bid_increments[base + w], pos, owner, old_price);
                 } else {
                     assignment_inv[base + bid_id] = w;
                 }
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(kEBlock) void emd_settle_kernel(int n, const int *_
                 chain_cnt[base + bid_id] = 0;
             }
         } else if (elected) {
-            take(bid_id, j, my_inc, pos);
+            take(bid_id, j, my_inc, pos, owner, old_price);
             max_increments[base + bid_id] = -1e9f;
             max_idx[base + bid_id] = -1;
             chain_cnt[base + bid_id] = 0;

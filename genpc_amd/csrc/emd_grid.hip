@@ -50,13 +50,18 @@ __device__ __forceinline__ int egrid_cell1(float p, float lo, float inv, int g)
 __global__ __launch_bounds__(kEGBlock) void emd_grid_build_kernel(int n, const float *__restrict__ xyz2, const float *__restrict__ price,
                                                                   EGridHdr *__restrict__ hdr, int *__restrict__ start,
                                                                   float4 *__restrict__ sorted, int *__restrict__ pos_of,
-                                                                  int *__restrict__ orig_of, int cells_target, int cells_max)
+                                                                  int *__restrict__ orig_of, int cells_target, int cells_max, int K)
 {
+    // K blocks per cloud (a single cloud on one CU took 48 us of a 1 ms call): block k sorts the cells [c0, c1) of the
+    // cell index space -- a contiguous piece of the sorted output.  Every block reads ALL points of the cloud (box, cell of
+    // each point: arithmetic only), but only the points of its own cells go through the LDS histogram, the scan and the
+    // scatter; the piece's first output position is the number of points in lower cells, which the block counts while it
+    // classifies: no communication between the blocks (the scheme of nn_grid.hip's grid_build_kernel).
     extern __shared__ int s_cnt[];            // cells_max counters, then 2 kEGWaves ints, then 6 kEGWaves floats
     int *s_w = s_cnt + cells_max;
     float *s_red = (float *)(s_w + 2 * kEGWaves);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int batch = blockIdx.x;
+    const int batch = blockIdx.x / K, kb = blockIdx.x % K;
     const float *__restrict__ P = xyz2 + (size_t)batch * n * 3;
     float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
@@ -156,23 +161,29 @@ __global__ __launch_bounds__(kEGBlock) void emd_grid_build_kernel(int n, const f
     H.h = h;
     H.cells = g[0] * g[1] * g[2];
     H.bad = bad;
-    if (threadIdx.x == 0) hdr[batch] = H;
+    if (threadIdx.x == 0 && kb == 0) hdr[batch] = H;
     const int cells = H.cells;
-    for (int i = threadIdx.x; i < cells; i += kEGBlock) s_cnt[i] = 0;
+    const int c0 = (int)(((long long)kb * cells) / K), c1 = (int)(((long long)(kb + 1) * cells) / K), width = c1 - c0;
+    for (int i = threadIdx.x; i < width; i += kEGBlock) s_cnt[i] = 0;
     __syncthreads();
     auto cell_of = [&](int j) {
         const int cx = egrid_cell1(P[(size_t)j * 3 + 0], H.lo[0], inv, g[0]), cy = egrid_cell1(P[(size_t)j * 3 + 1], H.lo[1], inv, g[1]);
         const int cz = egrid_cell1(P[(size_t)j * 3 + 2], H.lo[2], inv, g[2]);
         return (cz * g[1] + cy) * g[0] + cx;
     };
-    for (int j = threadIdx.x; j < n; j += kEGBlock) atomicAdd(&s_cnt[cell_of(j)], 1);
+    int below = 0;
+    for (int j = threadIdx.x; j < n; j += kEGBlock) {
+        const int c = cell_of(j);
+        below += c < c0 ? 1 : 0;
+        if (c >= c0 && c < c1) atomicAdd(&s_cnt[c - c0], 1);
+    }
     __syncthreads();
     // exclusive scan: thread t owns the segment [t per, (t + 1) per); per is odd (LDS banks)
-    const int per = ((cells + kEGBlock - 1) / kEGBlock) | 1;
+    const int per = ((width + kEGBlock - 1) / kEGBlock) | 1;
     int sum = 0;
     for (int i = 0; i < per; i++) {
         const int q = threadIdx.x * per + i;
-        if (q < cells) { const int w = s_cnt[q]; s_cnt[q] = sum; sum += w; }
+        if (q < width) { const int w = s_cnt[q]; s_cnt[q] = sum; sum += w; }
     }
     int inc = sum;
 #pragma unroll
@@ -180,24 +191,32 @@ __global__ __launch_bounds__(kEGBlock) void emd_grid_build_kernel(int n, const f
         const int t = __shfl_up(inc, o);
         if (lane >= o) inc += t;
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) below += __shfl_xor(below, o);
     if (lane == kWave - 1) s_w[wave] = inc;
+    if (lane == 0) s_w[kEGWaves + wave] = below;
     __syncthreads();
     int base = inc - sum;
-    for (int w = 0; w < wave; w++) base += s_w[w];
+    for (int w = 0; w < kEGWaves; w++) {
+        base += w < wave ? s_w[w] : 0;
+        base += s_w[kEGWaves + w];
+    }
     for (int i = 0; i < per; i++) {
         const int q = threadIdx.x * per + i;
-        if (q < cells) s_cnt[q] += base;
+        if (q < width) s_cnt[q] += base;
     }
     __syncthreads();
     int *st = start + (size_t)batch * (cells_max + 1);
-    for (int i = threadIdx.x; i < cells; i += kEGBlock) st[i] = s_cnt[i];
-    if (threadIdx.x == 0) st[cells] = n;
+    for (int i = threadIdx.x; i < width; i += kEGBlock) st[c0 + i] = s_cnt[i];
+    if (threadIdx.x == 0 && kb == K - 1) st[cells] = n;
     __syncthreads();
     float4 *out = sorted + (size_t)batch * n;
     int *po = pos_of + (size_t)batch * n;
     int *ps = orig_of + (size_t)batch * n;
     for (int j = threadIdx.x; j < n; j += kEGBlock) {
-        const int pos = atomicAdd(&s_cnt[cell_of(j)], 1);
+        const int c = cell_of(j);
+        if (c < c0 || c >= c1) continue;
+        const int pos = atomicAdd(&s_cnt[c - c0], 1);
         out[pos] = make_float4(P[(size_t)j * 3 + 0], P[(size_t)j * 3 + 1], P[(size_t)j * 3 + 2], PR0[j]);
         po[j] = pos;
         ps[pos] = j;
@@ -553,8 +572,12 @@ int launch_emd_grid_build(int b, int n, const float *xyz2, const float *price, E
                           int *orig_of, int cells_target, int cells_max, hipStream_t st)
 {
     const size_t lds = ((size_t)cells_max + 2 * kEGWaves) * sizeof(int) + 6 * kEGWaves * sizeof(float);
-    hipLaunchKernelGGL(emd_grid_build_kernel, dim3(b), dim3(kEGBlock), lds, st, n, xyz2, price, hdr, start, sorted, pos_of, orig_of,
-                       cells_target, cells_max);
+    // pieces per cloud: enough blocks to spread a few clouds over the chip, one when there are many clouds anyway
+    static const int env_k = getenv("GENPC_EMD_GRID_K") ? atoi(getenv("GENPC_EMD_GRID_K")) : 0;
+    int K = env_k > 0 ? env_k : (b >= 32 ? 1 : (b >= 8 ? 2 : (n >= 8192 ? 8 : 4)));
+    K = K > 64 ? 64 : K;
+    hipLaunchKernelGGL(emd_grid_build_kernel, dim3(b * K), dim3(kEGBlock), lds, st, n, xyz2, price, hdr, start, sorted, pos_of, orig_of,
+                       cells_target, cells_max, K);
     return check(hipGetLastError(), "emd_grid_build_kernel launch") ? 1 : 0;
 }
 
