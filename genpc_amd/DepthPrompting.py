@@ -70,9 +70,16 @@ class DepthPrompting:
     """cfg needs: device, fovy, res, padding, rescale, point_size, mask_pixel_rate
     (configs/config.yaml keys, unchanged)."""
 
-    def __init__(self, cfg, cameras=None, focal=None):
+    def __init__(self, cfg, cameras=None, focal=None, inpainter=None, depth2image=None):
+        """inpainter / depth2image: the two generator stages of stage 1 (depth inpainting: Flux fill / DDNM / cv2,
+        DepthPrompting.py:196-227; depth-conditioned image generation: ControlNet / Flux / Qwen, :42-67,77-82) are
+        stock torch modules outside this library (north_star) -- pass them as callables:
+        ``inpainter(raw_depth [3,R,R], mask [3,R,R]) -> depth [3,R,R] tensor (or a PIL image)`` and
+        ``depth2image(depth PIL image, category, size) -> PIL image`` (the reference's ``.generate``)."""
         self.cfg = cfg
         self.device = torch.device(cfg.device)
+        self.inpainter = inpainter
+        self.depth2image = depth2image
         if cameras is None:
             cameras, self.viewpoints, focal = create_cameras(
                 num_views=cfg.view_num, distance=cfg.distance, fovy=cfg.fovy, device=self.device)
@@ -185,43 +192,109 @@ class DepthPrompting:
                                                      best_only=True)
         return int(torch.argmax(counts))
 
-    # DepthPrompting.py:100-187 (getDepth up to the raw depth image; the inpainting that follows is stock
-    # diffusion / cv2 code and stays with the reference)
+    # DepthPrompting.py:69-85
+    def getImage(self, xyz, flag, rgb=None, depth_gen=True, img_gen=True):
+        """Stage 1 with the reference's signature (main.py:54): the depth prompt of the scan -- getDepth writes
+        ``raw_depth.png``, ``mask.png``, ``depth.png`` (through the injected inpainter), ``point_uv.npy``,
+        ``viewpoint.npy`` and ``camera.pth`` under ``{cfg.output_path}/{flag}/`` -- then the depth-conditioned image
+        (``img.png``, through the injected generator).  rgb None: random colours like the reference's getRandomColor
+        (they only tint the sparse image).  Returns getDepth's dict (None with depth_gen=False)."""
+        print("Stage 1 : Depth Prompting.....")
+        import os
+        import time
+        from PIL import Image
+        start = time.time()
+        base = f"{self.cfg.output_path}/{flag}"
+        if rgb is None:
+            # getRandomColor (utils/dataUtils.py:157-160): SH2RGB(random / 255) = random / 255 * 0.2820948 + 0.5
+            rgb = torch.from_numpy(np.random.random((xyz.shape[0], 3)) / 255.0 * 0.28209479177387814 + 0.5).float().to(xyz.device)
+        out = self.getDepth(xyz, flag, rgb) if depth_gen else None
+        if not os.path.exists(f"{base}/depth.png"):
+            raise RuntimeError("DepthPrompting.getImage: %s/depth.png does not exist -- depth inpainting is a stock module "
+                               "outside this library; construct DepthPrompting(cfg, inpainter=callable(raw_depth, mask))" % base)
+        self.depth = Image.open(f"{base}/depth.png").convert("RGB")                               # load_image (:76)
+        if img_gen:
+            if self.depth2image is None:
+                raise RuntimeError("DepthPrompting.getImage: the depth-conditioned image generator is a stock module outside "
+                                   "this library; construct DepthPrompting(cfg, depth2image=callable(depth, category, size))")
+            print(" Image Generation.....")
+            from .utils.dataUtils import getCategory
+            self.image = self.depth2image(self.depth, getCategory(flag), getattr(self.cfg, "generate_res", 512))
+            self.image.save(f"{base}/img.png")
+        print(f" Take {int(time.time() - start)} seconds")
+        return out
+
+    # DepthPrompting.py:100-237
     def getDepth(self, xyz, flag=None, rgb=None):
-        """The geometric half of the reference's getDepth: projection from every camera, viewpoint
-        selection by hidden-point removal (view_num == 6: view 1), the opposite viewpoint's camera,
-        hidden-point removal of the WHOLE cloud from both, the depth-sum heuristic that picks one of
-        the two (:154-175), pixels, and getRawDepth on the visible points.  Sets self.point_uv /
-        self.view / self.cam like the reference and returns a dict with sparse_img, raw_depth,
-        hole_mask1, hole_mask2, view_index, used_opposite, visible (bool [N]), depth_sums."""
+        """The reference's getDepth: viewpoint selection by hidden-point removal (view_num == 6: view 1), the
+        opposite viewpoint's camera, hidden-point removal of the WHOLE cloud from both, the depth-sum heuristic that
+        picks one of the two (:154-175), pixels, getRawDepth on the visible points, and -- when `flag` names a
+        directory under cfg.output_path -- the stage's files (:196-237): ``raw_depth.png``, ``mask.png``, ``depth.png``
+        (if an inpainter was injected), ``point_uv.npy``, ``viewpoint.npy``, ``camera.pth`` (a dict of plain tensors:
+        the 3x4 world->camera matrix, eye, focal -- kaolin's Camera object is not a dependency).
+        SELECT FIRST, PROJECT SECOND: the reference projects the cloud through all 1024 cameras ([1024,N,3], 0.9 GB
+        at N = 71 k) and then consumes two rows; here only the chosen camera and its opposite are projected
+         -- getUvs is per camera, so the two rows are the same bits.
+        Sets self.point_uv / self.view / self.cam like the reference; returns a dict with sparse_img, raw_depth,
+        hole_mask1, hole_mask2, view_index, used_opposite, visible (bool [N]), depth_sums, uv, depth, pixels."""
         xyz = xyz.contiguous().float()
         n = xyz.shape[0]
         rgb = torch.ones(n, 3, device=xyz.device) if rgb is None else rgb
-        point_uvs, point_depths, _ = self.getUvs(self.cameras, xyz, rescale=self.cfg.rescale, padding=self.cfg.padding,
-                                                 want_transformed=False)
         best = 1 if getattr(self.cfg, "view_num", 0) == 6 else self.viewpoint_select(xyz)
         original = np.asarray(self.viewpoints[best], np.float64)
         opposite = -original
         opp_cam = torch.from_numpy(look_at(opposite, np.zeros(3), calculate_up_vector(opposite, np.zeros(3)))).to(xyz.device)
-        opp_uvs, opp_depths, _ = self.getUvs(opp_cam[None], xyz, rescale=self.cfg.rescale, padding=self.cfg.padding,
-                                             want_transformed=False)
+        two = torch.stack([self.cameras.reshape(-1, 12)[best].to(xyz.device), opp_cam])
+        uv2, depth2, _ = self.getUvs(two, xyz, rescale=self.cfg.rescale, padding=self.cfg.padding, want_transformed=False)
         radius = getattr(self.cfg, "removal_radius", 10000)
         vis, _, _ = self.hidden_point_removal(xyz, np.stack([original, opposite]), radius)      # both viewpoints, one call
-        sum1 = float(point_depths[best][vis[0]].sum())
-        sum2 = float(opp_depths[0][vis[1]].sum())
+        sum1 = float(depth2[0][vis[0]].sum())
+        sum2 = float(depth2[1][vis[1]].sum())
         if sum1 >= sum2:
-            used_opposite, visible, uvs, depths = False, vis[0], point_uvs[best], point_depths[best]
-            self.view, self.cam = original, self.cameras[best]
+            used_opposite, visible, uvs, depths = False, vis[0], uv2[0], depth2[0]
+            self.view, self.cam = original, two[0]
         else:
-            used_opposite, visible, uvs, depths = True, vis[1], opp_uvs[0], opp_depths[0]
+            used_opposite, visible, uvs, depths = True, vis[1], uv2[1], depth2[1]
             self.view, self.cam = opposite, opp_cam
         pix = self.uvToPixels(uvs, self.cfg.res).long()
         sparse_img, raw_depth, hole1, hole2 = self.getRawDepth(
             pix[visible], depths[visible], colors=rgb[visible].contiguous(), dataset=getattr(self.cfg, "dataset", None),
             res=self.cfg.res, point_size=self.cfg.point_size, mask_pixel_rate=self.cfg.mask_pixel_rate)
         self.point_uv = uvs
-        return dict(sparse_img=sparse_img, raw_depth=raw_depth, hole_mask1=hole1, hole_mask2=hole2, view_index=best,
-                    used_opposite=used_opposite, visible=visible, depth_sums=(sum1, sum2), uv=uvs, depth=depths, pixels=pix)
+        out = dict(sparse_img=sparse_img, raw_depth=raw_depth, hole_mask1=hole1, hole_mask2=hole2, view_index=best,
+                   used_opposite=used_opposite, visible=visible, depth_sums=(sum1, sum2), uv=uvs, depth=depths, pixels=pix)
+        if isinstance(flag, str) and getattr(self.cfg, "output_path", None):
+            self._write_stage1_files(flag, out)
+        return out
+
+    @staticmethod
+    def _save_image(t, path):
+        """torchvision.utils.save_image for one [3,H,W] image in [0,1]: mul(255).add(0.5).clamp(0,255) -> uint8 PNG."""
+        from PIL import Image
+        a = t.detach().float().mul(255).add(0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+        Image.fromarray(a).save(path)
+
+    def _write_stage1_files(self, flag, out):
+        """DepthPrompting.py:196-237."""
+        import os
+        base = f"{self.cfg.output_path}/{flag}"
+        os.makedirs(base, exist_ok=True)
+        self._save_image(out["raw_depth"], f"{base}/raw_depth.png")
+        # the reference's mask choice: hole_mask1 for 'flux' / 'cv2', hole_mask2 for 'DDNM' (:200-227)
+        mask = out["hole_mask2"] if str(getattr(self.cfg, "inpainter", "")).upper().startswith("DDNM") else out["hole_mask1"]
+        self._save_image(mask, f"{base}/mask.png")
+        if self.inpainter is not None:
+            print(" Inpainting depth...")
+            depth = self.inpainter(out["raw_depth"], mask)
+            if torch.is_tensor(depth):
+                self._save_image(depth, f"{base}/depth.png")
+            else:
+                depth.save(f"{base}/depth.png")
+        np.save(f"{base}/point_uv.npy", self.point_uv.detach().cpu().numpy())
+        np.save(f"{base}/viewpoint.npy", np.asarray(self.view))
+        torch.save({"view": self.cam.detach().cpu().reshape(3, 4), "eye": torch.as_tensor(np.asarray(self.view, np.float64)),
+                    "focal": float(self.focal), "fovy": float(self.cfg.fovy),
+                    "cam_res": int(getattr(self.cfg, "cam_res", self.cfg.res))}, f"{base}/camera.pth")
 
     def uvToPixels(self, uvs, res):
         """DepthPrompting.py:179-184: (uv*res).long(), swap to (row, col), clip."""

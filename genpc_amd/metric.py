@@ -30,6 +30,26 @@ def evaluate_scans(pred, gt, eps=0.005, iters=50):
     return torch.stack([cd_l1, cd_l2, emd], dim=1)
 
 
+def cd_l1_cpu_plumbing(pred, gt, chunk=512):
+    """BASELINE config 1: CD-L1 of CPU tensors in plain torch -- the metric's plumbing without a GPU.  NOT a
+    fallback: nothing in the library routes here (CPU tensors handed to chamfer_3DDist / emdModule raise); a caller that
+    wants the CPU number asks for it by name (``python -m genpc_amd.metric --cpu``).  Direct form in the reference's
+    operation order, fp32: d = ((x2-x1)^2 + (y2-y1)^2) + (z2-z1)^2, min over the other cloud, then
+    (mean sqrt d1 + mean sqrt d2) / 2 (utils/loss_util.py:25-29).  pred, gt: [S,N,3] / [S,M,3] float32 CPU."""
+    if pred.is_cuda or gt.is_cuda:
+        raise ValueError("cd_l1_cpu_plumbing is the CPU plumbing path; GPU tensors go through evaluate_scans")
+    pred, gt = pred.float(), gt.float()
+
+    def one_way(a, b):                      # [N,3] x [M,3] -> [N] squared NN distances
+        out = []
+        for i in range(0, a.shape[0], chunk):
+            d = b[None, :, :] - a[i:i + chunk, None, :]
+            out.append(((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).min(1).values)
+        return torch.cat(out)
+    rows = [(torch.sqrt(one_way(p, g)).mean() + torch.sqrt(one_way(g, p)).mean()) / 2 for p, g in zip(pred, gt)]
+    return torch.stack(rows)
+
+
 def evaluate_sharded(pred_np, gt_np, device=None, max_batch=16, metric_fn=None, backend=None):
     """Round-robin shard of the S scans over the ranks of the default process group
     (initialised here if the launcher's WORLD_SIZE > 1 and nobody did yet); every rank
@@ -64,7 +84,15 @@ def main():
     ap = argparse.ArgumentParser()
     here = os.path.dirname(os.path.abspath(__file__))
     ap.add_argument("--npz", default=os.path.join(here, "..", "tests", "golden", "scans13_fps16384.npz"))
+    ap.add_argument("--cpu", action="store_true", help="BASELINE config 1: CD-L1 only, plain torch on the CPU (plumbing, no GPU)")
     args = ap.parse_args()
+    if args.cpu:
+        z = np.load(args.npz)
+        cd = cd_l1_cpu_plumbing(torch.from_numpy(z["partial"]), torch.from_numpy(z["gt"]))
+        ids = z["ids"] if "ids" in z.files else [str(i) for i in range(len(cd))]
+        for flag, v in zip(ids, cd):
+            print(f"Flag: {flag}, CD: {float(v) * 100:.3f}")
+        return
     rank, local_rank, world = sharding.init()
     torch.cuda.set_device(local_rank)
     z = np.load(args.npz)

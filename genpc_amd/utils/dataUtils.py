@@ -131,3 +131,11 @@ def get_rotate_matrix(axis, angle):
     if axis == "z":
         return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
     raise ValueError("axis should be x,y,z")
+
+
+def getCategory(flag):
+    """utils/dataUtils.py:601-614 -- the text prompt category of a bundled scan id; unknown ids (the reference raises
+    KeyError) fall back to 'object'."""
+    kv = {"01184": "Wheelie Bin", "05117": "chair", "05452": "armchair", "06127": "Plant vases", "06145": "table",
+          "06188": "vespa", "06830": "Kid tricycle", "07136": "sofa", "07306": "trash can", "09639": "swivel chair"}
+    return kv.get(str(flag), "object")

@@ -94,3 +94,27 @@ def test_color_point_obj_source_and_missing_inputs(tmp_path):
         sa.scaleReg(flag)
     with pytest.raises(RuntimeError, match="stock module"):
         sa.scaleAdapter(xyz, flag, rgb)
+
+
+def test_stage1_getimage_has_the_reference_signature():
+    """main.py:54 calls dp.getImage(xyz=..., flag=..., rgb=..., depth_gen=True, img_gen=True) (DepthPrompting.py:69)."""
+    import inspect
+    from genpc_amd.DepthPrompting import DepthPrompting
+    sig = inspect.signature(DepthPrompting.getImage)
+    assert list(sig.parameters) == ["self", "xyz", "flag", "rgb", "depth_gen", "img_gen"]
+    assert sig.parameters["rgb"].default is None and sig.parameters["depth_gen"].default is True and sig.parameters["img_gen"].default is True
+    assert list(inspect.signature(DepthPrompting.getDepth).parameters)[:4] == ["self", "xyz", "flag", "rgb"]
+
+
+def test_config1_cpu_plumbing_cd_l1(golden):
+    """BASELINE config 1: CD-L1 of scan 01184 vs its ground truth at 2048 points on the CPU, plain torch (an explicit
+    plumbing path, not a fallback): the survey's 0.040335327 to 1e-7, and CPU tensors handed to
+    the library's own loss still raise."""
+    import torch
+    from genpc_amd.metric import cd_l1_cpu_plumbing
+    g = golden("scan01184_fps2048.npz")
+    v = float(cd_l1_cpu_plumbing(torch.from_numpy(g["partial"]), torch.from_numpy(g["gt"]))[0])
+    assert abs(v - 0.040335327) < 1e-7 and abs(v - float(g["cd_l1_m0"])) < 1e-7, v
+    from genpc_amd.utils.loss_util import Completionloss
+    with pytest.raises(RuntimeError, match="GPU tensors only"):
+        Completionloss("cd_l1").get_loss(torch.from_numpy(g["partial"]), torch.from_numpy(g["gt"]))
