@@ -51,6 +51,7 @@ SIGNATURES = {
     "genpc_splat_image": (_i, [_i, _vp, _vp, _f, _i, _vp, _vp]),
     "genpc_mask_loss": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_pose_loss_grad": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "genpc_pose_tune": (_i, [_i]),
     "genpc_pose_optimize_batch": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _f, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp]),
     "genpc_pose_optimize_cd": (_i, [_i, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "genpc_pose_optimize_cd_batch": (_i, [_i, _i, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),

@@ -124,4 +124,15 @@ int launch_emd_grid_build(int b, int n, const float *xyz2, const float *price, E
                           int *orig_of, int cells_target, int cells_max, hipStream_t st);
 int launch_emd_bid_grid(const EmdGridBid &a, int fma, hipStream_t st);
 
+// ---- seeded nearest neighbours of the alignment loop (nn_seeded.hip) ----
+struct SeededGrids {
+    const EGridHdr *hdr_static, *hdr_rest;
+    const int *start_static, *start_rest;
+    const float4 *sorted_static, *sorted_rest;
+};
+size_t seeded_grids_bytes(int b, int nm, int ns);
+int build_seeded_grids(int b, int nm, const float *rest_pts, int ns, const float *static_pts, void *ws, SeededGrids &g, hipStream_t st);
+int launch_nn_seeded(int b, int nm, const float *moving_pts, int ns, const float *static_pts, const SeededGrids &g, const float *center,
+                     int cstride, const float *params, int pstride, float *d1, int *i1, float *d2, int *i2, int fma, hipStream_t st);
+
 }  // namespace genpc

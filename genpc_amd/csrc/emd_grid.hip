@@ -66,9 +66,10 @@ __global__ __launch_bounds__(kEGBlock) void emd_grid_build_kernel(int n, const f
     float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     int bad = 0;
-    const float *__restrict__ PR0 = price + (size_t)batch * n;
+    // price == null: a plain spatial index (nn_seeded.hip): the entries' .w is the point's index
+    const float *__restrict__ PR0 = price ? price + (size_t)batch * n : nullptr;
     for (int j = threadIdx.x; j < n; j += kEGBlock) {
-        bad |= !(PR0[j] >= 0.0f && PR0[j] < __builtin_inff());      // the culling needs prices >= 0 (the caller's initial state: zeros)
+        if (PR0) bad |= !(PR0[j] >= 0.0f && PR0[j] < __builtin_inff());      // the culling needs prices >= 0 (the caller's initial state: zeros)
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const float w = P[(size_t)j * 3 + k];
@@ -211,15 +212,15 @@ __global__ __launch_bounds__(kEGBlock) void emd_grid_build_kernel(int n, const f
     if (threadIdx.x == 0 && kb == K - 1) st[cells] = n;
     __syncthreads();
     float4 *out = sorted + (size_t)batch * n;
-    int *po = pos_of + (size_t)batch * n;
-    int *ps = orig_of + (size_t)batch * n;
+    int *po = pos_of ? pos_of + (size_t)batch * n : nullptr;
+    int *ps = orig_of ? orig_of + (size_t)batch * n : nullptr;
     for (int j = threadIdx.x; j < n; j += kEGBlock) {
         const int c = cell_of(j);
         if (c < c0 || c >= c1) continue;
         const int pos = atomicAdd(&s_cnt[c - c0], 1);
-        out[pos] = make_float4(P[(size_t)j * 3 + 0], P[(size_t)j * 3 + 1], P[(size_t)j * 3 + 2], PR0[j]);
-        po[j] = pos;
-        ps[pos] = j;
+        out[pos] = make_float4(P[(size_t)j * 3 + 0], P[(size_t)j * 3 + 1], P[(size_t)j * 3 + 2], PR0 ? PR0[j] : __int_as_float(j));
+        if (po) po[j] = pos;
+        if (ps) ps[pos] = j;
     }
 }
 

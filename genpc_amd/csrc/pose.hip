@@ -22,6 +22,7 @@
 // HBM traffic per iteration is O(N): ~24 B/point for the transform, ~28 B/point for
 // the gradient pass; the NN launch dominates (VALU-bound, see chamfer.hip).
 #include "nn.h"
+#include "emd.h"
 #include "../../include/genpc_hip.h"
 
 #include <math.h>
@@ -1809,6 +1810,19 @@ GENPC_API int genpc_pose_cd_grad(int nc, const float *v, const float *center, co
     return check(hipMemcpyAsync(loss_out, tmp, 3 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy loss") ? 1 : 0;
 }
 
+namespace genpc { static thread_local int t_pose_seeded = -1; }
+
+/* Nearest-neighbour path of the alignment loop, for tests and A/B (calling host thread): 1 seeded cell search from the
+ * second step on (csrc/nn_seeded.hip; opt-in: it wins when every query keeps a near target and loses on misaligned
+ * starts of real shapes), 0 the brute-force filter at every step (the default), < 0 the default / environment
+ * (GENPC_POSE_SEEDED).  Both give the same bits.  Returns the previous setting. */
+GENPC_API int genpc_pose_tune(int seeded)
+{
+    const int prev = genpc::t_pose_seeded;
+    genpc::t_pose_seeded = seeded < 0 ? -1 : (seeded ? 1 : 0);
+    return prev;
+}
+
 GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, const float *complete_col, int np,
                                         const float *partial, const float *partial_col, float lr, int iters, int starts,
                                         float radius, int render_size, float mask_weight, float *transform,
@@ -1895,6 +1909,24 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
         if (!launch_nn_dedupe(b, 2, dp, dn, dm, nullptr, st)) return 0;
     }
 
+    // OPT-IN (genpc_pose_tune(1) / GENPC_POSE_SEEDED=1): from the second step on every nearest-neighbour query starts from the
+    // index it was answered with a step ago and searches only the ball that answer leaves (nn_seeded.hip): both clouds
+    // sorted once per call into uniform grids, the moving one in its rest frame.  Bit-identical to the brute-force filter.
+    // Measured (round 4): 8 scans of uniform VOLUME clouds 161 -> 120 ms per call (49 -> 66 scans/s: a rotated cube is still
+    // a cube, every query keeps a near target), one scan 33.7 -> 32.2 ms (at that size a step is eight dependent launches,
+    // not their work) -- but config 5's surfaces 0.67 -> 0.84 s: three of the four starts are rotated by 90 / 180 / 270
+    // degrees, most queries of a misaligned start have NO near target, and the ball their old answer leaves crosses the
+    // other surface over hundreds of cells (18 k instructions per wave, 4.8 ms per step against 3.0 for the filter, which
+    // does not care where the points are).  Real shapes look like config 5: off by default.
+    static const int env_seeded = getenv("GENPC_POSE_SEEDED") ? atoi(getenv("GENPC_POSE_SEEDED")) : 0;
+    const bool seeded = (t_pose_seeded >= 0 ? t_pose_seeded : env_seeded) != 0 && nc >= 256 && np >= 256;
+    SeededGrids sg{};
+    if (seeded) {
+        void *gw = workspace(29, seeded_grids_bytes(b, nc, np), st);
+        if (!gw || !build_seeded_grids(b, nc, complete, np, partial, gw, sg, st)) return 0;
+    }
+    const int fma_mode = arith_mode() != 0 ? 1 : 0;
+
     const int gb = ceil_div(b, 64);
     hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, -1, 0);
     // (every block of the gradient kernels ends in 13-22 double atomics on its image's accumulators: with many images in
@@ -1913,8 +1945,12 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
             else
                 hipLaunchKernelGGL(pose_transform_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
                                    (const float *)center, 4, (const float *)S->params, kStateFloats, pts);
-            if (nn_forward(b, 2, pts, nc, partial, np, d1, i1, partial, np, pts, nc, d2, i2, st, __builtin_inff(), dup_p, dup_c) != 1)
+            if (seeded && it > 0) {
+                if (launch_nn_seeded(b, nc, pts, np, partial, sg, center, 4, (const float *)S->params, kStateFloats, d1, i1, d2, i2, fma_mode, st) != 1)
+                    return 0;
+            } else if (nn_forward(b, 2, pts, nc, partial, np, d1, i1, partial, np, pts, nc, d2, i2, st, __builtin_inff(), dup_p, dup_c) != 1) {
                 return 0;
+            }
             hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, st, nc, complete, (const float *)center,
                                4, (const float *)S->params, kStateFloats, np, partial, (const float *)d1,
                                (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, accum);
