@@ -27,6 +27,7 @@ SIGNATURES = {
     "genpc_set_arith_thread": (_i, [_i]),
     "genpc_get_arith": (_i, []),
     "genpc_release_workspace": (_i, []),
+    "genpc_tune_table": (_i, [_vp, _i]),
     "genpc_nn_tune": (_i, [_i, _i]),
     "genpc_nn_stats": (_i, [_vp, _i, _vp]),
     "genpc_nn_duplicate_mask": (_i, [_i, _i, _vp, _vp, _vp]),
@@ -92,6 +93,14 @@ def _load():
 
 
 lib = _load()
+
+
+def tune_table():
+    """The library's tuning switches consulted so far, with their values and defaults (GENPC_* environment variables)."""
+    n = lib.genpc_tune_table(None, 0)
+    buf = ctypes.create_string_buffer(n)
+    lib.genpc_tune_table(ctypes.cast(buf, ctypes.c_void_p), n)
+    return buf.value.decode("utf-8", "replace")
 
 
 def last_error():

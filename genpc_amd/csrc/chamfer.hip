@@ -621,17 +621,25 @@ static const NNConfig &nn_config()
 {
     static const NNConfig c = [] {
         NNConfig k{0, 4, 3, 0, 0, false, false, 0};
-        if (const char *e = getenv("GENPC_NN_R")) k.r = atoi(e);
-        if (const char *e = getenv("GENPC_NN_PATH")) {
-            k.mfma = (e[0] == 'v') ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'f' ? 3 : 4));
-            k.env_path = true;
+        k.r = tune_env("GENPC_NN_R", 0, "VALU nearest-neighbour path: queries per lane (2 | 4, 0 = pick)");
+        if (const char *e = tune_env_str("GENPC_NN_PATH", "nearest-neighbour kernel family: valu | mfma32 | f16 (default) | grid (opt-in)")) {
+            // (anything else used to fall through to the opt-in cell search -- e.g. 'bf16', a family removed in round 3)
+            if (e[0] == 'v') k.mfma = 0;
+            else if (e[0] == 'm') k.mfma = 1;
+            else if (e[0] == 'f') k.mfma = 3;
+            else if (e[0] == 'g') k.mfma = 4;
+            else fprintf(stderr, "genpc_hip: GENPC_NN_PATH=%s is not one of valu | mfma32 | f16 | grid: keeping the default (f16)\n", e);
+            k.env_path = e[0] == 'v' || e[0] == 'm' || e[0] == 'f' || e[0] == 'g';
         }
-        if (const char *e = getenv("GENPC_NN_Q")) k.q = atoi(e);
-        if (const char *e = getenv("GENPC_NN_U")) k.u = atoi(e);
+        k.q = tune_env("GENPC_NN_Q", 0, "MFMA filter: 32-query tiles per wave (2 | 4, 0 = pick)");
+        k.u = tune_env("GENPC_NN_U", 0, "MFMA filter: target tiles per bookkeeping unit (2 | 4, 0 = pick)");
         if (k.q != 1 && k.q != 2 && k.q != 4) k.q = 0;
         if (k.u != 1 && k.u != 2 && k.u != 4) k.u = 0;
-        if (const char *e = getenv("GENPC_NN_WPS")) { k.blocks_per_cu = atoi(e); k.env_wps = true; }
-        if (const char *e = getenv("GENPC_NN_DEBUG")) k.dbg = atoi(e);
+        {
+            const int w = tune_env("GENPC_NN_WPS", 0, "resident blocks per CU the nearest-neighbour planner assumes (0 = per kernel family)");
+            if (w > 0) { k.blocks_per_cu = w; k.env_wps = true; }
+        }
+        k.dbg = tune_env("GENPC_NN_DEBUG", 0, "test hooks of the filtered nearest-neighbour paths (bit mask, see genpc_nn_tune)");
         if (k.r != 2 && k.r != 4) k.r = 0;
         if (k.blocks_per_cu < 1) k.blocks_per_cu = 1;
         return k;
@@ -748,12 +756,12 @@ int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0
     // R = 4 (fewer LDS reads per pair, more independent chains per lane) when the query
     // blocks alone fill the chip; R = 2 otherwise: twice the blocks, half the per-wave
     // epilogue (measured on MI355X: 1x16384^2 87 us vs 97 us, 13x16384^2 870 us vs 835 us).
-    long long want_blocks = (long long)kNumCU * cfg.blocks_per_cu;
+    long long want_blocks = (long long)num_cus() * cfg.blocks_per_cu;
     int r = cfg.r;
     if (!r) {
         long long unsplit4 = 0;
         for (int d = 0; d < nd; d++) unsplit4 += (long long)b * ceil_div(a.dir[d].nq, kBlock * 4);
-        r = unsplit4 >= kNumCU ? 4 : 2;
+        r = unsplit4 >= num_cus() ? 4 : 2;
     }
     // MFMA path: a block covers 128*Q queries; Q = 2 halves the LDS reads and the blocks.
     int q = cfg.q;
@@ -768,7 +776,7 @@ int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0
     }
     // f16 filter: at least two accumulator chains per wave (see the hazard note in nn_f16.hip)
     if (path == 2 && q < 2) q = 2;
-    if (path == 2 && !cfg.env_wps) want_blocks = (long long)kNumCU * (q == 4 ? 2 : (q == 2 ? 3 : 4));   // resident blocks per CU (VGPRs)
+    if (path == 2 && !cfg.env_wps) want_blocks = (long long)num_cus() * (q == 4 ? 2 : (q == 2 ? 3 : 4));   // resident blocks per CU (VGPRs)
     const int qper = path ? 128 * q : kBlock * r;       // queries per block
     const int gran = path == 2 ? 128 : (path ? 64 : kChunk);   // slice granularity: one bookkeeping unit
     int pwords = path ? 3 : 1;                          // 8-byte words per (slice, query)
@@ -791,7 +799,7 @@ int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0
     };
     long long len = ceil_div64(ceil_div64(work, want_blocks), gran) * gran;
     if (len < kChunk * 8) len = kChunk * 8;
-    if (len < kChunk * 16 && blocks_at(kChunk * 16) >= 2 * kNumCU) len = kChunk * 16;
+    if (len < kChunk * 16 && blocks_at(kChunk * 16) >= 2 * num_cus()) len = kChunk * 16;
     if (len > nt_max) len = ceil_div64(nt_max, gran) * gran;
     a.slice_len = (int)len;
     // bookkeeping per 64 targets once a block has enough of them to amortise the coarser
@@ -824,7 +832,7 @@ int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0
         int best_res = 0;
         const bool env_wps = cfg.env_wps;
         for (int res = (f16 && q == 4 && !env_wps) ? 3 : 0; res != 1 && res >= 0; res = (res == 3 ? 2 : -1)) {
-            const long long slots = res ? (long long)kNumCU * res : want_blocks;
+            const long long slots = res ? (long long)num_cus() * res : want_blocks;
             const double per_block = res == 3 ? 3.0 * 0.96 : (res == 2 ? 2.0 : 1.0);
             for (int sc = 1; sc <= 16; sc++) {
                 const long long l = ceil_div64(ceil_div64(nt_max, sc), gran) * gran;
@@ -848,8 +856,8 @@ int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0
         // Single-round launches whose slice fits the kernel's 2048-target LDS tile: blocks of 8 waves / 1024 queries,
         // one per CU -- the same two waves per SIMD, but a slice is read, split into f16 pieces and staged once per
         // 1024 queries instead of once per 512 (the prologue was a third of a block's time: tools/nn_timeline.py).
-        static const bool no_wide = getenv("GENPC_NN_NOWIDE") != nullptr;
-        if (f16 && q == 4 && !tight && !no_wide && len > 1024 && blocks_at(len) <= 2 * (long long)kNumCU) {
+        static const bool no_wide = tune_env("GENPC_NN_NOWIDE", 0, "f16 filter: 1 = no 8-wave blocks for single-round launches") != 0;
+        if (f16 && q == 4 && !tight && !no_wide && len > 1024 && blocks_at(len) <= 2 * (long long)num_cus()) {
             wide = true;
             for (int d = 0; d < nd; d++) a.dir[d].qblocks = ceil_div(a.dir[d].nq, 2 * qper);
         }
@@ -901,7 +909,7 @@ int nn_forward(int b, int ndir, const float *q0, int n0, const float *t0, int m0
     }
     if (path == 2) {
         // exact duplicates among the targets (policy above nn_forward)
-        static const int env_dd = getenv("GENPC_NN_DEDUPE") ? atoi(getenv("GENPC_NN_DEDUPE")) : -1;
+        static const int env_dd = tune_env("GENPC_NN_DEDUPE", -1, "f16 filter: exact-duplicate pre-pass 0 off / 1 on (-1: callers' masks + adaptive policy)");
         const int force = (a.debug & 2048) ? 0 : ((a.debug & 4096) ? 1 : env_dd);
         DedupeHint *H = dedupe_hint();
         bool own_masks = true;

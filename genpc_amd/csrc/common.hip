@@ -3,9 +3,12 @@
 #include "../../include/genpc_hip.h"
 
 #include <atomic>
+#include <string.h>
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <map>
+#include <stdlib.h>
 
 namespace genpc {
 
@@ -52,6 +55,48 @@ bool check(hipError_t e, const char *what)
 }
 
 int arith_mode() { return t_arith >= 0 ? t_arith : g_arith.load(std::memory_order_relaxed); }
+
+struct TuneEntry { int value, dflt; bool set; std::string what, raw; };
+static std::map<std::string, TuneEntry> &tune_registry()
+{
+    static std::map<std::string, TuneEntry> r;
+    return r;
+}
+static std::mutex g_tune_mu;
+
+int tune_env(const char *name, int dflt, const char *what)
+{
+    std::lock_guard<std::mutex> l(g_tune_mu);
+    auto &r = tune_registry();
+    auto it = r.find(name);
+    if (it != r.end()) return it->second.value;
+    const char *e = getenv(name);
+    TuneEntry t{dflt, dflt, false, what ? what : "", ""};
+    if (e && *e) { t.value = atoi(e); t.set = true; t.raw = e; }
+    r[name] = t;
+    return t.value;
+}
+
+const char *tune_env_str(const char *name, const char *what)
+{
+    std::lock_guard<std::mutex> l(g_tune_mu);
+    auto &r = tune_registry();
+    const char *e = getenv(name);
+    if (r.find(name) == r.end()) r[name] = TuneEntry{0, 0, e && *e, what ? what : "", e ? e : ""};
+    return (e && *e) ? e : nullptr;
+}
+
+int num_cus()
+{
+    static std::atomic<int> cache[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    cache[dev].store(v, std::memory_order_relaxed);
+    return v;
+}
 
 void *workspace(int slot, size_t bytes, hipStream_t stream, bool *fresh, size_t zero_prefix)
 {
@@ -103,6 +148,29 @@ GENPC_API const char *genpc_last_error(void)
     std::lock_guard<std::mutex> l(genpc::g_mu);
     copy = genpc::g_err;
     return copy.c_str();
+}
+
+GENPC_API int genpc_tune_table(char *buf, int len)
+{
+    // "NAME=value (default d) -- what" per line, for the switches the process has consulted so far; returns the number
+    // of bytes the whole table needs (call with len 0 to size)
+    std::lock_guard<std::mutex> l(genpc::g_tune_mu);
+    std::string out;
+    for (auto &kv : genpc::tune_registry()) {
+        char line[512];
+        if (!kv.second.raw.empty() && kv.second.value == 0 && kv.second.dflt == 0 && kv.second.raw != "0")
+            snprintf(line, sizeof line, "%s=%s%s -- %s\n", kv.first.c_str(), kv.second.raw.c_str(), kv.second.set ? " (set)" : "", kv.second.what.c_str());
+        else
+            snprintf(line, sizeof line, "%s=%d (default %d%s) -- %s\n", kv.first.c_str(), kv.second.value, kv.second.dflt,
+                     kv.second.set ? ", set" : "", kv.second.what.c_str());
+        out += line;
+    }
+    if (buf && len > 0) {
+        const size_t k = out.size() < (size_t)len - 1 ? out.size() : (size_t)len - 1;
+        memcpy(buf, out.data(), k);
+        buf[k] = 0;
+    }
+    return (int)out.size() + 1;
 }
 
 GENPC_API int genpc_set_arith(int mode)

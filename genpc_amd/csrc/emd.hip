@@ -346,7 +346,8 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_kernel(int n, const float *__
             bid_increments[(size_t)batch * n + j] = inc;
             atomic_max_float(&max_increments[(size_t)batch * n + best_i], inc);
             // the round's bidders of an object as a chain through the object's head word (emd_settle_kernel): a record is
-            // (increment bits << 32) | (stamp << 24) | bidder, the head holds the latest bidder's, next[j] what j displaced
+            // (increment bits << 32) | (stamp << 24) | bidder, the head holds the latest bidder's, next[j] what j displaced.
+            // The bidder field is 24 bits: the chain is only built for n <= 2^24 (`settle` in genpc_emd_forward)
             if (chain_head != nullptr) {
                 const unsigned long long mine = ((unsigned long long)(unsigned)__float_as_int(inc) << 32) | (stamp << 24) | (unsigned)j;
                 chain_next[(size_t)batch * n + j] = atomicExch(&chain_head[(size_t)batch * n + best_i], mine);
@@ -724,13 +725,13 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     const size_t parts_bytes = want_split ? (size_t)b * kSplitMaxBidders * kZMax * sizeof(float4) : 0;
     const size_t second_bytes = ((size_t)total * sizeof(int) + 255) / 256 * 256;
     // bidder chains per object (emd_settle_kernel): head word per object, link word per bidder
-    static const bool no_settle = getenv("GENPC_EMD_SETTLE") && atoi(getenv("GENPC_EMD_SETTLE")) == 0;
+    static const bool no_settle = tune_env("GENPC_EMD_SETTLE", 1, "EMD: 0 = GetMax and Assign as two launches instead of the one-launch settle") == 0;
     const bool settle = !no_settle && eps >= 0.0f && n <= (1 << 24);
     // chain_head | chain_next | whead | wnext (8-byte words per object / bidder), chain_cnt | arrived (ints per object)
     const size_t chain_bytes = settle ? (4 * (size_t)total * sizeof(unsigned long long) + 2 * (size_t)total * sizeof(int) + 255) / 256 * 256 : 0;
     // cell-sorted copy of the objects for the culled bid (emd_grid.hip): needs prices >= 0 (eps >= 0) and the seeds
-    static const int env_grid = getenv("GENPC_EMD_GRID") ? atoi(getenv("GENPC_EMD_GRID")) : -1;
-    static const bool noseed_env = getenv("GENPC_EMD_NOSEED") != nullptr;
+    static const int env_grid = tune_env("GENPC_EMD_GRID", -1, "EMD: 1 culled bid / 0 tiled bid whatever the size (-1 = pick)");
+    static const bool noseed_env = tune_env("GENPC_EMD_NOSEED", 0, "EMD: 1 = no seeds from the previous bid (tiled bid only; disables the culled bid)") != 0;
     const bool grid = (t_emd_grid >= 0 ? t_emd_grid != 0 : (env_grid >= 0 ? env_grid != 0 : (n >= 4096 || (long long)b * n >= 65536))) && eps >= 0.0f && !noseed_env;
     auto al256 = [](size_t v) { return (v + 255) / 256 * 256; };
     const int cells_max = kEGMaxCells;
@@ -757,9 +758,9 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     int *second = (int *)(ws + arrive_bytes + list_bytes);
     float4 *parts = (float4 *)(ws + arrive_bytes + list_bytes + second_bytes);
     // second-best object of each point's last bid (-1: has not bid yet; set by emd_init_kernel)
-    static const bool noseed = getenv("GENPC_EMD_NOSEED") != nullptr;
+    static const bool noseed = tune_env("GENPC_EMD_NOSEED", 0, "EMD: 1 = no seeds from the previous bid (tiled bid only; disables the culled bid)") != 0;
     if (noseed) second = nullptr;
-    static const bool nosplit = getenv("GENPC_EMD_NOSPLIT") != nullptr;
+    static const bool nosplit = tune_env("GENPC_EMD_NOSPLIT", 0, "tiled EMD bid: 1 = no object slices in late rounds") != 0;
     if (nosplit || !want_split) parts = nullptr;
     int *lists[2] = {unass_idx, list_b};
     int *cnts[2] = {unass_cnt, cnt_tmp};
@@ -770,7 +771,7 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
                        chain_cnt, arrived);
     if (grid) {
         // about two objects per cell if the cloud filled its box (surfaces fill far fewer cells, with more objects each)
-        static const int env_ppc = getenv("GENPC_EMD_GRID_PPC_X10") ? atoi(getenv("GENPC_EMD_GRID_PPC_X10")) : 20;
+        static const int env_ppc = tune_env("GENPC_EMD_GRID_PPC_X10", 20, "culled EMD bid: target objects per cell x 10");
         int target = (int)((long long)n * 10 / (env_ppc > 0 ? env_ppc : 20));
         target = target < 8 ? 8 : (target > cells_max * 3 / 4 ? cells_max * 3 / 4 : target);
         if (!launch_emd_grid_build(b, n, xyz2, price, g_hdr_p, g_start_p, g_sorted_p, g_pos_p, g_of_p, target, cells_max, st)) return 0;
@@ -780,12 +781,12 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     // loop is latency-bound per wave -- LDS read, compare, branch -- and wants >= 8
     // waves per SIMD: measured 13x16384, round 0: 3.9 ms at 4/CU, 1.8 ms at 16/CU),
     // never more than the finest split (64 lanes per bidder, all n bidding).
-    int G = ceil_div(kNumCU * 16, b);
+    int G = ceil_div(num_cus() * 16, b);
     if (G > 1024) G = 1024;     // a single cloud: more blocks only add dispatch + hand-off latency (measured)
     const int g_max = ceil_div(n * 64, kEBlock);
     if (G > g_max) G = g_max;
     if (G < 1) G = 1;
-    static const int env_g = getenv("GENPC_EMD_G") ? atoi(getenv("GENPC_EMD_G")) : 0;
+    static const int env_g = tune_env("GENPC_EMD_G", 0, "EMD: bid blocks per cloud (0 = pick)");
     if (env_g > 0) G = env_g;
     // rounds from which GetMax + Assign run as one single-block launch per cloud (few bidders left:
     // ~n/7 after four rounds).  The forced last round takes the same kernel: its bidders are that round's
@@ -794,7 +795,7 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     // (measured, 50 rounds: 1 x 2048 0.75 -> 0.68 ms, 64 x 2048 2.18 -> 1.98, 13 x 16384 8.45 -> 8.19; but
     // 1 x 16384 1.61 -> 1.80: with ~1000-2000 bidders left per round one block walking the list is
     // slower than 64 -- so only for small clouds or many of them)
-    static const int env_rf = getenv("GENPC_EMD_RESOLVE_FROM") ? atoi(getenv("GENPC_EMD_RESOLVE_FROM")) : -1;
+    static const int env_rf = tune_env("GENPC_EMD_RESOLVE_FROM", -1, "EMD: round from which a single block per cloud resolves (-1 = pick)");
     const int resolve_from = env_rf >= 0 ? env_rf : ((n <= 4096 || b >= 8) ? 4 : 0x7fffffff);
     int GL = ceil_div(n, kEBlock);          // list-walking kernels
     if (GL > 64) GL = 64;
@@ -812,9 +813,9 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
         if (grid) {
             EmdGridBid ga{};
             ga.n = n; ga.G = G; ga.nb = b; ga.cells_max = cells_max; ga.eps = eps; ga.stamp = stamp;
-            static const int env_lpb = getenv("GENPC_EMD_LPB") ? atoi(getenv("GENPC_EMD_LPB")) : 0;
+            static const int env_lpb = tune_env("GENPC_EMD_LPB", 0, "culled EMD bid: lanes per bidder (8..64, 0 = pick)");
             ga.force_lpb = env_lpb;
-            static const int env_xcd = getenv("GENPC_EMD_XCD") ? atoi(getenv("GENPC_EMD_XCD")) : 0;
+            static const int env_xcd = tune_env("GENPC_EMD_XCD", 0, "culled EMD bid: 1 = a cloud's blocks on one XCD (the tiled bid's order), 0 = clouds interleaved");
             ga.xcd_pin = env_xcd;
             ga.xyz1 = xyz1; ga.xyz2 = xyz2; ga.price = price; ga.orig_of = g_of_p;
             ga.list = lists[cur]; ga.cnt = cnts[cur]; ga.start = g_start_p; ga.cnt_next = cnts[nxt];
@@ -827,7 +828,7 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
             typedef void (*bid_fn)(int, const float *, const float *, const float *, float, const int *, const int *,
                                    int *, int *, float *, float *, int, float4 *, int *, int *, int, unsigned long long *,
                                    unsigned long long *, unsigned, int, int, int *);
-            static const int zmax_env = getenv("GENPC_EMD_ZMAX") ? atoi(getenv("GENPC_EMD_ZMAX")) : kZMax;
+            static const int zmax_env = tune_env("GENPC_EMD_ZMAX", kZMax, "tiled EMD bid: object slices per bidder group in late rounds (1..4)");
             const int zmax = zmax_env < 1 ? 1 : (zmax_env > kZMax ? kZMax : zmax_env);
             // Lanes per bidder.  Round 0 has no filter seeds: the fewer lanes share a bidder, the sooner a
             // lane's own second-best makes the filter selective (16 lanes: 186 us, 64: 298 us at
@@ -835,18 +836,19 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
             // keeps one bidder's rare exact evaluations from stalling another's lanes (round 1:
             // 95 us against 166 us at 32 lanes), even when that needs more units than blocks.  With
             // many clouds in flight (b >= 32) fewer bidders per staged tile cost more than that (+2 %).
-            static const int env_p = getenv("GENPC_EMD_P") ? atoi(getenv("GENPC_EMD_P")) : 0;
-            static const int env_p0 = getenv("GENPC_EMD_P0") ? atoi(getenv("GENPC_EMD_P0")) : 0;
+            static const int env_p = tune_env("GENPC_EMD_P", 0, "tiled EMD bid: lanes per bidder (0 = pick)");
+            static const int env_p0 = tune_env("GENPC_EMD_P0", 0, "tiled EMD bid: lanes per bidder in round 0 (0 = pick)");
             const int force_p = env_p > 0 ? env_p : (it == 0 ? env_p0 : (second != nullptr && b < 32 ? 64 : 0));
-            static const bool nofilter = getenv("GENPC_EMD_NOFILTER") != nullptr;
-            // 1024-object tiles (16 KiB of LDS, 72 VGPRs: eight resident blocks per CU instead of four or five) wherever
+            static const bool nofilter = tune_env("GENPC_EMD_NOFILTER", 0, "tiled EMD bid: 1 = no squared-distance pre-filter (A/B)") != 0;
+            // 1024-object tiles (16 KiB of LDS; the default filter variant is 78 VGPRs = six waves per SIMD, the unfiltered one
+            // 72 = eight: tools/kmeta.sh emd) wherever
             // the bid is throughput-bound; a single small cloud is latency-bound and pays for the extra barrier pairs
             // (in-run A/B: 13 x 16384 8.28 -> 7.65 ms, 64 x 2048 1.99 -> 1.80, 1 x 16384 =, 1 x 2048 0.69 -> 0.76;
             // 512-object tiles: 7.85 / 1.84 / 1.69 / 0.70)
-            static const int env_tile = getenv("GENPC_EMD_TILE") ? atoi(getenv("GENPC_EMD_TILE")) : 0;
+            static const int env_tile = tune_env("GENPC_EMD_TILE", 0, "tiled EMD bid: objects per LDS tile (1024 | 2048, 0 = pick)");
             const bool small_tile = env_tile ? env_tile == 1024 : (long long)b * n > 8192;
             // four tiles in flight from round 2 on for a single cloud (see the kernel)
-            static const int env_ahead = getenv("GENPC_EMD_AHEAD") ? atoi(getenv("GENPC_EMD_AHEAD")) : 0;
+            static const int env_ahead = tune_env("GENPC_EMD_AHEAD", 0, "tiled EMD bid: object tiles in flight (1 | 4, 0 = pick)");
             const bool deep = env_ahead ? env_ahead == 4 : (small_tile && it >= 2 && b == 1);      // in-run A/B: 1 x 8192 1.22 -> 1.07 ms, 1 x 16384 -2 %, 2 x 16384 +7 %, 4 x 16384 +15 %
             bid_fn f = deep ? (fma ? (nofilter ? emd_bid_kernel<1, 0, 1024, 4> : emd_bid_kernel<1, 1, 1024, 4>)
                                    : (nofilter ? emd_bid_kernel<0, 0, 1024, 4> : emd_bid_kernel<0, 1, 1024, 4>))

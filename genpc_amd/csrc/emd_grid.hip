@@ -574,7 +574,7 @@ int launch_emd_grid_build(int b, int n, const float *xyz2, const float *price, E
 {
     const size_t lds = ((size_t)cells_max + 2 * kEGWaves) * sizeof(int) + 6 * kEGWaves * sizeof(float);
     // pieces per cloud: enough blocks to spread a few clouds over the chip, one when there are many clouds anyway
-    static const int env_k = getenv("GENPC_EMD_GRID_K") ? atoi(getenv("GENPC_EMD_GRID_K")) : 0;
+    static const int env_k = tune_env("GENPC_EMD_GRID_K", 0, "culled EMD bid: pieces per cloud of the grid build (0 = pick)");
     int K = env_k > 0 ? env_k : (b >= 32 ? 1 : (b >= 8 ? 2 : (n >= 8192 ? 8 : 4)));
     K = K > 64 ? 64 : K;
     hipLaunchKernelGGL(emd_grid_build_kernel, dim3(b * K), dim3(kEGBlock), lds, st, n, xyz2, price, hdr, start, sorted, pos_of, orig_of,

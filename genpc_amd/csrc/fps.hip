@@ -424,6 +424,33 @@ static int fps_workgroups(int n)
     return W < 1 ? 1 : W;
 }
 
+// the instantiation launch_fps takes for R points per thread, as an index; its points per thread
+static int fps_class(int R) { return R <= 2 ? 0 : (R <= 4 ? 1 : (R <= 8 ? 2 : (R <= 12 ? 3 : (R <= 16 ? 4 : 5)))); }
+
+// Workgroups of an instantiation one CU holds at a time, as the runtime reports it (registers: fps_kernel<*, 16> is 152
+// VGPRs = 3 per CU, <*, 24> 224 VGPRs = 2; the smaller ones 4+).  The hand-off between a cloud's workgroups needs ALL of
+// the launch resident together, so launches are sized from this, not from a constant (a budget of four per CU
+// admitted grids of the two large instantiations that an idle full chip just holds and a busy or partitioned one does not).
+template <int FMA>
+static int fps_blocks_per_cu(int cls)
+{
+    static int cache[6] = {0, 0, 0, 0, 0, 0};
+    if (cache[cls] > 0) return cache[cls];
+    int nb = 0;
+    hipError_t e = hipSuccess;
+    switch (cls) {
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 2>, kFBlock, 0); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 4>, kFBlock, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 8>, kFBlock, 0); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 12>, kFBlock, 0); break;
+    case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 16>, kFBlock, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 24>, kFBlock, 0); break;
+    }
+    if (e != hipSuccess || nb < 1) nb = 1;
+    cache[cls] = nb;
+    return nb;
+}
+
 }  // namespace genpc
 
 GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *const *xyz, int *const *out_idx, void *stream)
@@ -438,13 +465,25 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    // co-residency budget: four 256-thread workgroups per CU, counted on THIS device (a partitioned or smaller
-    // part has fewer than the 256 CUs of a full MI355X)
+    // co-residency budget: what THIS device holds of the instantiation a launch takes (a partitioned or smaller part
+    // has fewer than the 256 CUs of a full MI355X; another stream's kernels are not counted -- a hand-off that times
+    // out because of them is retried one cloud at a time by genpc_amd/fps.py)
     int dev = 0, cus = 0;
     if (!check(hipGetDevice(&dev), "hipGetDevice")) return 0;
     if (!check(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return 0;
     if (cus < 1) cus = 1;
-    const int budget = cus * 4;
+    const bool fma = arith_mode() != 0;
+    auto budget_of = [&](int R) { return (fma ? fps_blocks_per_cu<1>(fps_class(R)) : fps_blocks_per_cu<0>(fps_class(R))) * cus; };
+    // a cloud's workgroups: as many as its size asks for, fewer (more points per thread) if the device does not hold them
+    auto plan = [&](int npts, int &W, int &R) {
+        W = fps_workgroups(npts);
+        for (;;) {
+            R = ceil_div(ceil_div(npts, W), kFThreads);
+            if (R > kFMaxR) return false;
+            if (W <= budget_of(R) || W == 1) return W <= budget_of(R);
+            W = W > 2 * budget_of(R) ? budget_of(R) : W - 1;
+        }
+    };
     size_t total_slots = 0;
     for (int j = 0; j < c; j++) total_slots += 2 * (size_t)fps_workgroups(n[j]);
     char *ws = (char *)workspace(7, 256 + total_slots * sizeof(FpsSlot), st);
@@ -452,20 +491,21 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
     int *err = (int *)ws;
     FpsSlot *slots = (FpsSlot *)(ws + 256);
     if (!check(hipMemsetAsync(ws, 0, 256 + total_slots * sizeof(FpsSlot), st), "hipMemsetAsync(fps)")) return 0;
-    const bool fma = arith_mode() != 0;
     int slot0 = 0;
     for (int j0 = 0; j0 < c;) {
-        // a launch takes up to kFMaxJobs clouds whose workgroups fit the budget together
+        // a launch takes up to kFMaxJobs clouds; its grid is (largest W) x (clouds), all of it resident together
         FpsJobs jobs = {};
         jobs.stat0 = j0 < 32 ? j0 : 32;
-        int nj = 0, wsum = 0, wmax = 0, rmax = 1;
+        int nj = 0, wmax = 0, rmax = 1;
         while (j0 + nj < c && nj < kFMaxJobs) {
-            const int j = j0 + nj, W = fps_workgroups(n[j]);
-            if (W > budget) {
+            const int j = j0 + nj;
+            int W = 0, R = 0;
+            if (!plan(n[j], W, R)) {
                 set_error("genpc_fps: the cloud needs more co-resident workgroups than the device admits");
                 return 0;
             }
-            if (nj > 0 && wsum + W > budget) break;
+            const int wm = W > wmax ? W : wmax, rm = R > rmax ? R : rmax;
+            if (nj > 0 && (long long)wm * (nj + 1) > budget_of(rm)) break;
             jobs.xyz[nj] = xyz[j];
             jobs.out[nj] = out_idx[j];
             jobs.n[nj] = n[j];
@@ -473,10 +513,8 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
             jobs.W[nj] = W;
             jobs.slot0[nj] = slot0;
             slot0 += 2 * W;
-            wsum += W;
-            wmax = W > wmax ? W : wmax;
-            const int R = ceil_div(ceil_div(n[j], W), kFThreads);
-            rmax = R > rmax ? R : rmax;
+            wmax = wm;
+            rmax = rm;
             nj++;
         }
         if (fma) launch_fps<1>(rmax, dim3(wmax, nj), st, jobs, slots, err);

@@ -47,6 +47,7 @@
 
 #include <limits.h>
 #include <stdlib.h>
+#include <algorithm>
 
 #include <hipcub/hipcub.hpp>
 
@@ -1083,9 +1084,16 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                                                              const int *__restrict__ perm, const int *__restrict__ hardlist,
                                                              const int *__restrict__ hardcnt, int no_cull,
                                                              const unsigned char *__restrict__ alive, int *__restrict__ list2,
-                                                             const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly)
+                                                             const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
+                                                             double2 *__restrict__ gbuf, int gcap)
 {
-    __shared__ double2 s_buf[2][CAP];
+    // CAP == 0: the polygon lives in global memory, gcap vertices per buffer (n + 8: a polygon has at most one edge per
+    // other point and four of the box -- this tier cannot overflow; round 3 returned an error beyond 1024 vertices)
+    __shared__ double2 s_lds[2][CAP > 0 ? CAP : 1];
+    double2 *s_buf[2];
+    s_buf[0] = CAP > 0 ? s_lds[0] : gbuf + (size_t)blockIdx.x * 2 * gcap;
+    s_buf[1] = CAP > 0 ? s_lds[1] : gbuf + ((size_t)blockIdx.x * 2 + 1) * gcap;
+    const int cap = CAP > 0 ? CAP : gcap;
     const int lane = threadIdx.x;
     // surv != null: the points the split first kernel left undecided continue HERE from their saved polygons (home tiles and
     // verification are behind them), one wave each
@@ -1155,10 +1163,11 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                     for (int o = 32; o > 0; o >>= 1) out += __shfl_xor(out, o, kWave);
                     if (!out) continue;
                     if (out == nv) { nv = 0; break; }
-                    if (nv - out + 2 > CAP) {
+                    if (nv - out + 2 > cap) {
                         if (lane == 0) {
-                            if (CAP < kHprOverCap) list2[atomicAdd(&status[3], 1)] = id;      // the large-polygon launch takes it
-                            else atomicExch(&status[1], 2);
+                            if (CAP > 0 && CAP < kHprOverCap) list2[atomicAdd(&status[3], 1)] = id;      // the large-polygon launch takes it
+                            else if (CAP == kHprOverCap) list2[atomicAdd(&status[4], 1)] = id;          // the global-memory tier takes it
+                            else atomicExch(&status[1], 2);                                            // (cannot happen: gcap = n + 8)
                         }
                         failed = true;
                         nv = 0;
@@ -1309,7 +1318,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     // 7.3 -> 6.9.  A few views of a large cloud keep the one-kernel form (2 x 165546: 14.9 against 17.8 ms): there the lanes
     // of a block want the same tiles, and staging them once per block through LDS beats per-wave reads
     // (GENPC_HPR_SPLIT=0/1 overrides).
-    static const int env_split = getenv("GENPC_HPR_SPLIT") && *getenv("GENPC_HPR_SPLIT") ? atoi(getenv("GENPC_HPR_SPLIT")) : -1;
+    static const int env_split = tune_env("GENPC_HPR_SPLIT", -1, "hidden-point removal: 1 two-kernel form (first kernel stops after the home tiles, a wave per point continues), 0 one kernel, -1 pick by size");
     const int split = env_split >= 0 ? env_split : (ntiles < kHprRimTiles && (long long)c * n >= 100000ll ? 1 : 0);
     const size_t o_surv = off; off += split ? up(total * sizeof(int4)) : 0;
     // (the survivors' polygons are sized after the accept pass has counted the listed points: a second workspace)
@@ -1346,10 +1355,10 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
                "hpr radix sort"))
         return 0;
     HprTile *tiles = (HprTile *)(ws + o_tiles);
-    static const int no_cull = getenv("GENPC_HPR_NOCULL") ? atoi(getenv("GENPC_HPR_NOCULL")) : 0;      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept, 32 = no verify phase, 64 = no hand-off of much-cut polygons (results unchanged)
+    static const int no_cull = tune_env("GENPC_HPR_NOCULL", 0, "hidden-point removal: measurement mask (1 every tile, 8 no silhouette hand-off, 16 no early accept, 32 no verify, 64 no hand-off of much-cut polygons)");      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept, 32 = no verify phase, 64 = no hand-off of much-cut polygons (results unchanged)
     hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl, (const unsigned char *)dup);
     hipLaunchKernelGGL(hpr_tile_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, tiles);
-    static const int env_clips = getenv("GENPC_HPR_MAXCLIPS") ? atoi(getenv("GENPC_HPR_MAXCLIPS")) : 0;
+    static const int env_clips = tune_env("GENPC_HPR_MAXCLIPS", 0, "hidden-point removal: clips after which a polygon goes to the wave-per-point pass (0 = pick)");
     // (large clouds: 96 -- 2 x 165546 points 46 -> 40 ms; many views of a small cloud: the second pass fills up
     //  instead -- 1024 x 10000 points 154 ms with 256, 168 with 128, 180 with 96)
     const int max_clips = (no_cull & 64) ? 0x7fffffff : (env_clips > 0 ? env_clips : (ntiles >= kHprRimTiles ? 48 : 256));      // (large clouds: 96 -> 48 once the wave-per-point pass clipped by all lanes: 2 x 165546 24.9 -> 21.5 ms)
@@ -1385,35 +1394,36 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
         surv_poly = (double2 *)workspace(20, (size_t)(hc_total > 0 ? hc_total : 1) * kHprMaxV * sizeof(double2), stream);
         if (!surv_poly) return 0;
     }
-    static const int env_sf = getenv("GENPC_HPR_STRAGGLE_FROM") ? atoi(getenv("GENPC_HPR_STRAGGLE_FROM")) : 4;
-    static const int env_sl = getenv("GENPC_HPR_STRAGGLE_LANES") ? atoi(getenv("GENPC_HPR_STRAGGLE_LANES")) : kHprThreads;
-    static const int env_st = getenv("GENPC_HPR_STRAGGLE_TILES") ? atoi(getenv("GENPC_HPR_STRAGGLE_TILES")) : 0;
+    static const int env_sf = tune_env("GENPC_HPR_STRAGGLE_FROM", 4, "hidden-point removal: tile batches a block walks before the hand-over");
+    static const int env_sl = tune_env("GENPC_HPR_STRAGGLE_LANES", kHprThreads, "hidden-point removal: hand a block's points over when at most this many lanes are still undecided");
+    static const int env_st = tune_env("GENPC_HPR_STRAGGLE_TILES", 0, "hidden-point removal: clouds of at least this many tiles hand undecided points over early");
     const int straggle_from = ntiles >= env_st ? env_sf : 0x7fffffff, straggle_lanes = env_sl;
     hipLaunchKernelGGL(hpr_kernel, dim3(ntiles * c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
                        (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull,
                        max_clips, split, surv, surv_poly, und, straggle_from, straggle_lanes, c);
     if (!check(hipGetLastError(), "hpr launch")) return 0;
-    int st[4] = {0, 0, 0, 0};
+    int st[5] = {0, 0, 0, 0, 0};
     if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
     if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
     if (prune) hipLaunchKernelGGL(hpr_prune_kernel, dim3(1), dim3(1024), 0, stream, c, (const int *)counts, (const int *)und, alive);
     // the undecided points of the split first kernel: a wave each, continuing from the saved polygon
     int *list2 = (int *)k0;          // (the sort's key buffer is free by now; at most views x points entries)
+    int *list3 = (int *)k1;          // (likewise: the points whose polygons outgrow the 1024-vertex tier)
     if (st[2] > 0) {
         hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(st[2]), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
                            visible, counts, status, (const int *)nullptr, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
-                           no_cull, (const unsigned char *)alive, list2, (const int4 *)surv, (const double2 *)surv_poly);
+                           no_cull, (const unsigned char *)alive, list2, (const int4 *)surv, (const double2 *)surv_poly, (double2 *)nullptr, 0);
         if (!check(hipGetLastError(), "hpr continuation launch")) return 0;
     }
     if (second_pass_points) *second_pass_points = st[0];
     {
-        static const bool one_tier = getenv("GENPC_HPR_ONE_TIER") != nullptr;
+        static const bool one_tier = tune_env("GENPC_HPR_ONE_TIER", 0, "hidden-point removal: 1 = every listed point straight to the 1024-vertex tier") != 0;
         const bool continued = st[2] > 0;
         const int listed = st[0];
         if (listed > 0 && !one_tier) {
             hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(listed), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
                                visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
-                               no_cull, (const unsigned char *)alive, list2, (const int4 *)nullptr, (const double2 *)nullptr);
+                               no_cull, (const unsigned char *)alive, list2, (const int4 *)nullptr, (const double2 *)nullptr, (double2 *)nullptr, 0);
             if (!check(hipGetLastError(), "hpr second pass launch")) return 0;
         }
         if (continued || (listed > 0 && !one_tier)) {
@@ -1425,25 +1435,45 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
         if (one_tier && listed > 0) {
             hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(listed), dim3(kWave), 0, stream, n, (const double *)fl,
                                (const HprTile *)tiles, visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist,
-                               (const int *)hardcnt, no_cull, (const unsigned char *)alive, (int *)nullptr, (const int4 *)nullptr,
-                               (const double2 *)nullptr);
+                               (const int *)hardcnt, no_cull, (const unsigned char *)alive, list3, (const int4 *)nullptr,
+                               (const double2 *)nullptr, (double2 *)nullptr, 0);
         }
         if (st[3] > 0) {
             hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(st[3]), dim3(kWave), 0, stream, n, (const double *)fl,
                                (const HprTile *)tiles, visible, counts, status, (const int *)list2, (const int *)i1, (const int *)hardlist,
-                               (const int *)hardcnt, no_cull, (const unsigned char *)alive, (int *)nullptr, (const int4 *)nullptr,
-                               (const double2 *)nullptr);
+                               (const int *)hardcnt, no_cull, (const unsigned char *)alive, list3, (const int4 *)nullptr,
+                               (const double2 *)nullptr, (double2 *)nullptr, 0);
         }
         if (big > 0) {
             if (!check(hipGetLastError(), "hpr large-polygon launch")) return 0;
             if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
             if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
         }
+        // polygons over 1024 vertices (exactly co-spherical input, lattices seen from their centre): a third tier with the
+        // polygon in global memory, n + 8 vertices per buffer -- it cannot overflow -- in chunks of at most 1 GiB of scratch
+        if (st[4] > 0) {
+            const int gcap = n + 8;
+            const size_t per = (size_t)2 * gcap * sizeof(double2);
+            int chunk = (int)std::min<size_t>((size_t)st[4], std::max<size_t>(1, ((size_t)1 << 30) / per));
+            double2 *gbuf = (double2 *)workspace(30, (size_t)chunk * per, stream);
+            if (!gbuf) return 0;
+            for (int c0 = 0; c0 < st[4]; c0 += chunk) {
+                const int cc = std::min(chunk, st[4] - c0);
+                hipLaunchKernelGGL(hpr_overflow_kernel<0>, dim3(cc), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
+                                   visible, counts, status, (const int *)(list3 + c0), (const int *)i1, (const int *)hardlist,
+                                   (const int *)hardcnt, no_cull, (const unsigned char *)alive, (int *)nullptr, (const int4 *)nullptr,
+                                   (const double2 *)nullptr, gbuf, gcap);
+            }
+            if (!check(hipGetLastError(), "hpr global-polygon launch")) return 0;
+            if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
+            if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
+            if (tune_env("GENPC_HPR_TIERS", 0, "hidden-point removal: 1 = report on stderr how many points took the wave-per-point tiers") != 0) fprintf(stderr, "hpr: %d points with polygons over %d vertices (global-memory tier)\n", st[4], kHprOverCap);
+        }
         if (st[1]) {
-            set_error("genpc_hpr_visibility: a normal-cone polygon outgrew 1024 vertices");
+            set_error("genpc_hpr_visibility: internal error (a normal-cone polygon outgrew its buffer)");
             return 0;
         }
-        if (getenv("GENPC_HPR_TIERS")) fprintf(stderr, "hpr: %d points in the wave-per-point pass, %d of them with polygons over 128 vertices\n", listed, big);
+        if (tune_env("GENPC_HPR_TIERS", 0, "hidden-point removal: 1 = report on stderr how many points took the wave-per-point tiers") != 0) fprintf(stderr, "hpr: %d points in the wave-per-point pass, %d of them with polygons over 128 vertices\n", listed, big);
     }
     if (exact) {
         if (prune) {

@@ -346,7 +346,7 @@ static void launch_main(const NNArgs &a, int blocks, int u, int tight, hipStream
     // tight 2 (planner: single round, Q = 4, slice_len > 1024): 8-wave blocks of 1024 queries, one per CU
     // HT = 2048 (66 KiB of LDS per block; a slice of up to 2048 targets is resident) where two waves per SIMD are all the
     // registers allow anyway: Q = 4, not tight, slice_len > 1024 (4 x 16384 x 8192, slices of 4096: 57.9 -> 54.7 us)
-    static const int env_ht = getenv("GENPC_NN_HT") ? atoi(getenv("GENPC_NN_HT")) : 0;
+    static const int env_ht = tune_env("GENPC_NN_HT", 0, "f16 filter: 1024 = never stage 2048-target LDS tiles");
     const bool big = Q == 4 && tight != 1 && a.slice_len > kHTile && env_ht != 1024;
     if (Q == 4 && tight == 2) {
         if (u == 2) hipLaunchKernelGGL((nn_f16_kernel<4, 2, NL, 1, 2 * kHTile, 8>), dim3(blocks), dim3(8 * kWave), 0, st, a);

@@ -582,7 +582,7 @@ int launch_nn_grid(const NNArgs &na, hipStream_t st)
     a.fma = na.fma;
     a.stats = na.stats;
     a.radius2 = na.radius2;
-    static const int near_env = getenv("GENPC_GRID_NEARONLY") ? 1 : 0;
+    static const int near_env = (tune_env("GENPC_GRID_NEARONLY", 0, "cell-sorted nearest-neighbour search: experiment, stop after the 27 near cells") != 0 ? 1 : 0);
     a.near_only = near_env;
     // one direction: only the target cloud is sorted (the queries lose some locality, a whole cloud less to sort)
     a.sort_cloud[0] = na.ndir > 1 ? 1 : 0;
@@ -607,7 +607,7 @@ int launch_nn_grid(const NNArgs &na, hipStream_t st)
     }
     const int nmax = std::max(a.sort_cloud[0] ? a.n[0] : 0, a.n[1]);      // the grid follows the density of the sorted (target) clouds
     // about three points per cell of the denser cloud if it filled the box; surfaces fill ~ G^2 of G^3 cells
-    static const int env_ppc = getenv("GENPC_GRID_PPC_X10") ? atoi(getenv("GENPC_GRID_PPC_X10")) : 30;      // points per cell x 10
+    static const int env_ppc = tune_env("GENPC_GRID_PPC_X10", 30, "cell-sorted nearest-neighbour search: target points per cell x 10");      // points per cell x 10
     int target = (int)((long long)nmax * 10 / (env_ppc > 0 ? env_ppc : 30));
     target = std::max(8, std::min(target, kGridMaxCells / 2));
     a.cells_target = target;
@@ -629,7 +629,7 @@ int launch_nn_grid(const NNArgs &na, hipStream_t st)
     a.sorted_off[0] = 0;
     a.sorted_off[1] = (size_t)a.b * a.n[0];
     // slabs per cloud: enough blocks to occupy a good part of the chip when the batch is small
-    static const int env_k = getenv("GENPC_GRID_K") ? atoi(getenv("GENPC_GRID_K")) : 0;
+    static const int env_k = tune_env("GENPC_GRID_K", 0, "cell-sorted nearest-neighbour search: slab blocks per cloud of the build (0 = pick)");
     int K = std::max(1, std::min(8, 64 / (2 * a.b)));
     K = std::min(K, std::max(1, nmax / 2048));
     if (env_k > 0) K = std::min(env_k, 64);
@@ -644,8 +644,8 @@ int launch_nn_grid(const NNArgs &na, hipStream_t st)
     // bounds a small launch), one when there are that many queries anyway
     long long queries = 0;
     for (int d = 0; d < a.ndir; d++) queries += (long long)a.b * a.n[a.qcloud[d]];
-    const long long want = 8LL * kNumSIMD * kWave;
-    static const int env_lpq = getenv("GENPC_GRID_LPQ") ? atoi(getenv("GENPC_GRID_LPQ")) : 0;
+    const long long want = 8LL * (4 * num_cus()) * kWave;
+    static const int env_lpq = tune_env("GENPC_GRID_LPQ", 0, "cell-sorted nearest-neighbour search: lanes per query (1 | 4 | 16 | 32, 0 = pick)");
     int lpq = queries * 16 <= want ? 32 : (queries * 4 <= want ? 16 : (queries <= want ? 4 : 1));
     if (env_lpq == 1 || env_lpq == 4 || env_lpq == 16 || env_lpq == 32) lpq = env_lpq;
     long long tb = 0;

@@ -1594,7 +1594,7 @@ static int mask_tiles(int S) { const int t = ceil_div(S, kMaskTile); return t * 
 // GENPC_SPLAT_BINS=0: every tile by the full scan (A/B)
 static bool use_bins(int S)
 {
-    static const bool v = !(getenv("GENPC_SPLAT_BINS") && atoi(getenv("GENPC_SPLAT_BINS")) == 0);
+    static const bool v = !(tune_env("GENPC_SPLAT_BINS", 1, "alignment loop: 0 = the colour splat scans every point per tile instead of reading per-tile lists") == 0);
     return v && bins_tiles(S) <= (size_t)kBinTiles;
 }
 
@@ -1664,7 +1664,7 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
     // (mask_grad_kernel alone).  Measured at 16384 points per image, 224 x 224: 4 images (one scan's four starts, the W
     // planes stay in L2) 25.6 + 8.2 us against 29.3; 32 images (8 scans in lock-step: 32 MB of W planes through every 4 MB
     // L2, the scattered 16-byte reads cost 105 of the per-point kernel's 150 us) 107 + 21 against 150-168.
-    static const int env_tp = getenv("GENPC_MASK_GRAD_TILES") ? atoi(getenv("GENPC_MASK_GRAD_TILES")) : -1;
+    static const int env_tp = tune_env("GENPC_MASK_GRAD_TILES", -1, "alignment loop: 1 = the silhouette gradient through the per-tile lists (opt-in), 0 = per point");
     // (8 x 4 images of 32768 points, 167 points per tile on average: 0.814 s per call with the tile pass, 0.789 without --
     // crowded tiles take several rounds of the block; 16384 points, 84 per tile: 167 ms against 176)
     // OPT-IN (GENPC_MASK_GRAD_TILES=1).  On a cloud that fills the image the tile pass wins 5 % with 32 images in flight, but
@@ -1679,7 +1679,7 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
                        S, m.planes, accum, use_bins(S) ? m.bins : (int *)nullptr, tile_pass ? 1 : 0, b);
     // few blocks per image: every block ends in 22 double atomics on the image's accumulators, and 196 blocks x 22 on the
     // same addresses serialise in L2 (17.5 us for 0.2 M pixels; GENPC_MASK_SUMS_BLOCKS for A/B)
-    static const int env_sb = getenv("GENPC_MASK_SUMS_BLOCKS") ? atoi(getenv("GENPC_MASK_SUMS_BLOCKS")) : 0;
+    static const int env_sb = tune_env("GENPC_MASK_SUMS_BLOCKS", 0, "alignment loop: blocks per image of mask_sums_kernel (0 = pick)");
     const int gs = std::min(gp, env_sb > 0 ? env_sb : 48);      // 196: 221 ms per 8-scan call, 48: 210, 24: 210, 12: 210 (single scan: 42.1 / 41.4 / 41.8 / 43.3)
     hipLaunchKernelGGL(mask_sums_kernel, dim3(gs, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, 0, (const float *)m.mref,
                        (const float *)m.stats, accum);
@@ -1697,7 +1697,7 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
                            (const float4 *)m.gpart, (const float4 *)m.uvr, lin_grid(nc), b);
     } else {
         // lanes per point (measured at 4 x 16384 points, the four starts in lock-step: <1> 35 us, <8> 42)
-        static const int env_sub = getenv("GENPC_MASK_GRAD_SUB") ? atoi(getenv("GENPC_MASK_GRAD_SUB")) : 0;
+        static const int env_sub = tune_env("GENPC_MASK_GRAD_SUB", 0, "alignment loop: lanes per point of the per-point silhouette gradient (0 = pick)");
         const int sub = env_sub ? env_sub : (b <= 2 ? 8 : 1);
 #define GENPC_LAUNCH_MASK_GRAD(SUB)                                                                                                  \
         hipLaunchKernelGGL((mask_grad_kernel<SUB>), dim3(lin_grid((long long)nc * SUB) * b), dim3(kQBlock), 0, st, nc, complete,      \
@@ -1838,7 +1838,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // `starts` times the work per launch instead of `starts` passes.  At the reference's sizes every kernel of a
     // step is latency-bound (15403 x 7855 points: 118 us of kernels per step, 804 steps = 95 ms of reg()'s 110),
     // so the wider launches are nearly free.  Same arithmetic per element, same selection rule at the end.
-    static const int env_lock = getenv("GENPC_POSE_LOCKSTEP") ? atoi(getenv("GENPC_POSE_LOCKSTEP")) : 1;
+    static const int env_lock = tune_env("GENPC_POSE_LOCKSTEP", 1, "alignment loop: 0 = the starts of a scan one after the other instead of side by side");
     const int lock = (starts > 1 && env_lock && (long long)b * starts <= 256) ? starts : 0;
     const int scans = b, starts_in = starts;
     float *x_complete = nullptr, *x_partial = nullptr, *x_ccol = nullptr, *x_pcol = nullptr;
@@ -1918,7 +1918,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // degrees, most queries of a misaligned start have NO near target, and the ball their old answer leaves crosses the
     // other surface over hundreds of cells (18 k instructions per wave, 4.8 ms per step against 3.0 for the filter, which
     // does not care where the points are).  Real shapes look like config 5: off by default.
-    static const int env_seeded = getenv("GENPC_POSE_SEEDED") ? atoi(getenv("GENPC_POSE_SEEDED")) : 0;
+    static const int env_seeded = tune_env("GENPC_POSE_SEEDED", 0, "alignment loop: 1 = seeded cell search for the nearest neighbours from the second step on (opt-in)");
     const bool seeded = (t_pose_seeded >= 0 ? t_pose_seeded : env_seeded) != 0 && nc >= 256 && np >= 256;
     SeededGrids sg{};
     if (seeded) {
@@ -1931,7 +1931,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, -1, 0);
     // (every block of the gradient kernels ends in 13-22 double atomics on its image's accumulators: with many images in
     // flight fewer, longer blocks per image -- GENPC_POSE_GRAD_BLOCKS for A/B)
-    static const int env_gb = getenv("GENPC_POSE_GRAD_BLOCKS") ? atoi(getenv("GENPC_POSE_GRAD_BLOCKS")) : 0;
+    static const int env_gb = tune_env("GENPC_POSE_GRAD_BLOCKS", 0, "alignment loop: blocks per image of the gradient kernels (0 = pick)");
     // 32 images (8 scans x 4 starts): 96 blocks per image 153.1 ms per call, 48: 151.0, 24: 150.2, 12: 150.4
     const int g_t = lin_grid(nc), g_g = std::min(env_gb > 0 ? env_gb : (b >= 16 ? 24 : 1024), lin_grid((long long)nc + np));
     const int hstride = starts * (iters + 1);

@@ -25,10 +25,10 @@ def fps_sampling(points, k):
     if rc != 1:
         raise RuntimeError("genpc_fps failed: " + _lib.last_error())
     # index 0 is the start point of every cloud; the kernel writes -1 there when a hand-off
-    # between its workgroups timed out (the samples after it would be garbage)
-    if bool((out[:, 0] != 0).any()):
-        raise RuntimeError("genpc_fps: inter-workgroup hand-off timed out (workgroups of a cloud were not "
-                           "co-resident); no samples returned")
+    # between its workgroups timed out (the samples after it would be garbage): those clouds go again, one at a time
+    bad = torch.nonzero(out[:, 0] != 0).flatten().tolist()
+    for j in bad:
+        out[j] = fps_sampling_multi([pts[j]], [k])[0]
     return out[0] if single else out
 
 
@@ -56,9 +56,16 @@ def fps_sampling_multi(clouds, ks):
         raise ValueError("fps_sampling_multi: need 0 < k <= N <= 262144 for every cloud")
     if rc != 1:
         raise RuntimeError("genpc_fps_multi failed: " + _lib.last_error())
-    if bool(torch.stack([o[0] for o in outs]).ne(0).any()):
-        raise RuntimeError("genpc_fps: inter-workgroup hand-off timed out (workgroups of a cloud were not "
-                           "co-resident); no samples returned")
+    bad = [j for j, o in enumerate(outs) if int(o[0]) != 0]
+    if bad and c > 1:
+        # a hand-off timed out: something else on the GPU kept a cloud's workgroups from running together.  Not an error
+        # yet -- the clouds that failed go again, one at a time (a launch to itself needs a fraction of the device)
+        for j in bad:
+            outs[j] = fps_sampling_multi([pts[j]], [ks[j]])[0]
+        return outs
+    if bad:
+        raise RuntimeError("genpc_fps: inter-workgroup hand-off timed out (the workgroups of the cloud were not "
+                           "co-resident even in a launch of their own); no samples returned")
     return outs
 
 

@@ -196,6 +196,8 @@ def _is_cfg(x):
 def reg(cfg, flag, cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=False, **kwargs):
     """reg_xyz.py:99-223, same signature.
 
+    (Deviation, file form: the PLY's double coordinates are cast to float32 before the voxel grids hash them; open3d
+    hashes the doubles, so a point within float32 rounding of a voxel face can land in the neighbouring voxel.)
     File form (the reference's): ``reg(cfg, flag, cd_inv_weight, diff_init, reg_fine_xyz)`` reads
     ``{cfg.output_path}/{flag}/color_point.ply`` (the partial cloud with the colours colorPoint gave
     it) and ``{flag}_{cfg.generative_model}.glb`` (the generated mesh; 163 840 surface samples with
@@ -209,6 +211,9 @@ def reg(cfg, flag, cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=False, **kwar
     from .optim_registration.diff_obj_pose import object_pose_optimization
     from .utils.dataUtils import read_ply, save_ply_xyzrgb
     from .utils.mesh_io import glb2point
+    unknown = set(kwargs) - {"cd_only_pose", "rng"}
+    if unknown:          # (the file form reads two options; anything else -- a misspelt one -- used to be dropped silently: ADVICE r3)
+        raise TypeError("reg(cfg, flag, ...): unexpected keyword argument(s) %s (the file form takes cd_only_pose, rng)" % sorted(unknown))
     path = cfg.output_path
     ply = f"{path}/{flag}/color_point.ply"
     glb = f"{path}/{flag}/{flag}_{cfg.generative_model}.glb"

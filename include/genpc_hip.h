@@ -38,6 +38,11 @@ const char *genpc_last_error(void);       /* last HIP error string, "" if none *
 int genpc_set_arith(int mode);            /* process default; returns the previous one */
 int genpc_set_arith_thread(int mode);     /* calling thread only, < 0: follow the default; returns the previous override */
 int genpc_get_arith(void);
+/* The table of tuning / A-B switches: every switch is an environment variable GENPC_<NAME>, read once per process
+ * through one function (csrc/common.hip: tune_env) that records it with its default and a line of documentation; none
+ * changes a result.  Writes "NAME=value (default d) -- what" lines for the switches consulted so far into buf (at most
+ * len bytes, NUL-terminated); returns the size the whole table needs (call with len 0 to size the buffer). */
+int genpc_tune_table(char *buf, int len);
 /* Frees the per-device scratch pool (split-target partials, EMD lists). */
 int genpc_release_workspace(void);
 /* Nearest-neighbour kernel selection, for tests and experiments: every path returns
@@ -181,8 +186,8 @@ int genpc_gather_colors(int n, const int *pix, const float *img, int ch, int h,
  * arithmetic; at most 4096 viewpoints and 2^31 - 1 (viewpoint, point) pairs per call).  points[N,3] float, eyes[C,3] DOUBLE (both
  * device), radius > 0; visible[C,N] bytes, counts[C].  second_pass_points (HOST int, may
  * be NULL): how many points needed the large-polygon pass (lattice-like inputs).
- * Synchronises the stream once (the second pass is sized from the first).  0 if a polygon
- * outgrows 1024 vertices.  Differences from qhull: normals tilted more than atan(1e4) from
+ * Synchronises the stream (the later passes are sized from the first's counts).  Polygons of any size: up to 128 and
+ * 1024 vertices in LDS, beyond that in global memory.  Differences from qhull: normals tilted more than atan(1e4) from
  * the point's direction are not considered; of exact duplicates (-0 == +0) only the copy with the
  * lowest index takes part -- qhull reports one copy of a coincident group too, so counts agree.     */
 int genpc_hpr_visibility(int c, int n, const float *points, const double *eyes,

@@ -120,6 +120,27 @@ def test_hpr_polygons_over_128_vertices(hp):
         assert vis[0, 0]
 
 
+def test_hpr_polygons_over_1024_vertices(hp):
+    """The same construction with a ring of 2500 points: a 2500-gon, beyond the 1024 vertices the LDS tiers hold --
+    round 3 returned an error there; the polygon now moves to global memory (n + 8 vertices per buffer: it cannot
+    overflow).  Masks equal the clipping oracle's (its own cap is 4096) and qhull's."""
+    m = 2500
+    th = 2.0 * np.pi * (np.arange(m) + 0.25) / m
+    ang = 0.2
+    ring = np.stack([np.sin(ang) * np.cos(th), np.sin(ang) * np.sin(th), np.full(m, np.cos(ang))], 1)
+    rng = np.random.default_rng(12)
+    far = rng.normal(size=(300, 3))
+    far = far / np.linalg.norm(far, axis=1, keepdims=True) * 1.5
+    P = np.concatenate([[[0.0, 0.0, 1.0]], ring, far]).astype(np.float32)
+    eye = np.zeros((1, 3))
+    vis, cnt, second = hp["run"](P, eye, 100.0)
+    assert second >= 1
+    np.testing.assert_array_equal(vis, hp["clip"](P, eye, 100.0))
+    np.testing.assert_array_equal(vis, hp["qhull"](P, eye, 100.0))
+    np.testing.assert_array_equal(cnt, vis.sum(1))
+    assert vis[0, 0]
+
+
 def test_hpr_edge_cases(hp):
     import torch
     lib = hp["lib"].lib
