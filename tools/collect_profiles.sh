@@ -5,7 +5,7 @@
 # WRITE_SIZE / SQ counter passes (separate runs: TCC has 4 slots, FETCH_SIZE takes 3; never combined
 # with a trace).  Every profiled program is `python3 <script>` directly after `--` (no wrappers).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -24,6 +24,8 @@ family chamfer_B13_16384 tools/prof_chamfer.py 13 16384 3
 family chamfer_B13_16384_scans tools/prof_chamfer.py 13 16384 3 scan
 family emd_B1_16384 tools/prof_emd.py 1 16384 2
 family emd_B13_16384 tools/prof_emd.py 13 16384 1
+family emd_B13_16384_scans tools/prof_emd.py 13 16384 1 scan
+family emd_B1_16384_scan tools/prof_emd.py 1 16384 2 scan
 family get_uvs_1024x71372 tools/prof_uvs.py 3
 family pose_loop_16384x8192 tools/prof_pose.py 16384 8192 20 1
 family scale_search_icp tools/prof_scale_search.py
