@@ -33,7 +33,8 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 // shader clock at the phase boundaries of nn_f16_kernel (nothing of this exists in the shipped library)
 #ifdef GENPC_NN_TIMELINE
 __device__ unsigned long long g_timeline[4096 * 8];
-#define GENPC_TL(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_timeline[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define GENPC_TL(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) { g_timeline[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
+    if ((k) == 0) g_timeline[blockIdx.x * 8 + 6] = wall_clock64(); if ((k) == 5) g_timeline[blockIdx.x * 8 + 7] = wall_clock64(); } } while (0)
 #else
 #define GENPC_TL(k) do {} while (0)
 #endif

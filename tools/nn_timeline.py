@@ -48,6 +48,16 @@ if not hasattr(L, "genpc_nn_timeline_read"):
 buf = (ctypes.c_ulonglong * (4096 * 8))()
 assert L.genpc_nn_timeline_read(buf)
 t = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)
+if os.environ.get("NN_TIMELINE_BLOCKS"):
+    # per XCD (block id % 8): start and end of every block relative to the XCD's first start, in block order
+    # slots 6, 7: the 100 MHz wall clock (one for the chip) at a block's start and end, in 10 ns units from the first start
+    ids = np.nonzero(t[:, 0] > 0)[0]
+    w0 = t[ids, 6].min()
+    print("wall clock: last end %d (x 10 ns)" % (t[ids, 7].max() - w0))
+    for x in range(int(os.environ["NN_TIMELINE_BLOCKS"])):
+        sel = ids[ids % 8 == x]
+        print("XCD %d: block:start-end (x 10 ns)" % x)
+        print(" ".join("%d:%d-%d" % (i, t[i, 6] - w0, t[i, 7] - w0) for i in sel))
 t = t[t[:, 0] > 0]
 print("%d blocks stamped (shader-clock ticks; per-block differences only -- the counter is per XCD)" % len(t))
 names = {1: "scale known (queries + slice read, maximum reduced)", 2: "first LDS tile staged", 3: "second LDS tile staged",
