@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                                                          const int *__restrict__ hardcnt, unsigned char *__restrict__ vis,
                                                          int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull, int max_clips,
                                                          int split, int4 *__restrict__ surv, double2 *__restrict__ surv_poly,
-                                                         int *__restrict__ und, int straggle_from, int straggle_lanes, int nviews)
+                                                         int *__restrict__ und, int straggle_from, int straggle_lanes, int nviews, int home_tiles)
 {
     __shared__ double2 s_poly[kHprMaxV * kHprThreads];
     __shared__ double4 s_stage[kHprThreads];      // 64 tile records while testing, then one tile's candidates
@@ -682,7 +682,19 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     // they come costs 10x more: the lanes meet their cuts at different candidates).
     // Clip the polygon of this lane by the 128 candidates of one tile; `load(k)` returns candidate k of the tile
     // (rows past the end of the cloud: NaN).
-    auto clip_by_tile = [&](int tile, auto load) {
+    // Split form: a point this kernel does not finish is parked with its polygon as the exact path left it and the place
+    // to resume from -- code = 256 x (home tiles done: 0 .. 3) + candidates of the next home tile already taken -- and a
+    // wave of hpr_overflow_kernel continues from there (round 3 restarted such points from the box: 6.5 of 45 ms).
+    auto park = [&](int code) {
+        const int slot = atomicAdd(&status[2], 1);
+        if (und) atomicAdd(&und[view], 1);
+        surv[slot] = make_int4(view * n + rank, nv, pos, code);
+        double2 *sp = surv_poly + (size_t)slot * kHprMaxV;
+        for (int k = 0; k < nv; k++) sp[k] = poly[k * kHprThreads];
+        nv = -1;
+        active = false;
+    };
+    auto clip_by_tile = [&](int tile, int rel, auto load) {
                 // 32 candidates at a time: the marks are taken against the polygon as the previous 32 left it (while
                 // the polygon is still the box every candidate is marked; after the nearest few it is tight and
                 // almost none are)
@@ -735,6 +747,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                         // (runs > 1: on a sliver, roundoff can put the outside vertices in two runs; the in-place clip
                         // assumes one -- the second pass clips like the oracle does, vertex by vertex)
                         if (nv - out + 2 > kHprMaxV || runs > 1) {
+                            if (split && rel >= 0) { park(rel * 256 + cc * 32 + t); break; }      // (candidate t not taken yet)
                             over_list[atomicAdd(&status[0], 1)] = view * n + rank;
                             if (und) atomicAdd(&und[view], 1);
                             nv = -1;
@@ -749,6 +762,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                         // up -- the second pass, a wave per point with the candidates tested in parallel, is the
                         // place for it
                         if (++nclips > max_clips) {
+                            if (split && rel >= 0) { park(rel * 256 + cc * 32 + t + 1); break; }
                             over_list[atomicAdd(&status[0], 1)] = view * n + rank;
                             if (und) atomicAdd(&und[view], 1);
                             nv = -1;
@@ -772,7 +786,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
             s_stage[tid] = q;
         }
         __syncthreads();
-        if (active && wanted) clip_by_tile(tile, [&](int k) { return s_stage[k]; });
+        if (active && wanted) clip_by_tile(tile, -1, [&](int k) { return s_stage[k]; });
         __syncthreads();
     };
     // Phase 1: every point's home tile and its two neighbours, whatever the group's starting tile is (when few
@@ -781,11 +795,11 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     // Each lane reads ITS tiles straight from memory (its neighbours in the wave read the same or the next tile:
     // the lines are shared in L1/L2): staging them through LDS would take the block's tiles one after the other
     // with a few lanes busy on each -- measured 1.0 of a block's 2.7 ms.
-    for (int rel = 0; rel < 3 && active; rel++) {            // home, home + 1, home - 1: nearest first
+    for (int rel = 0; rel < home_tiles && active; rel++) {            // home, home + 1, home - 1: nearest first
         const int tile = home + (rel == 0 ? 0 : (rel == 1 ? 1 : -1));
         if (tile < 0 || tile >= ntiles) continue;
         const int tile0 = tile * kHprThreads;
-        clip_by_tile(tile, [&](int k) {
+        clip_by_tile(tile, rel, [&](int k) {
             const int j = tile0 + k;
             if (j >= n) return make_double4(__builtin_nan(""), 0.0, 0.0, 0.0);
             const double *g = fl + (size_t)j * 3;
@@ -909,7 +923,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
         }
         base = __shfl(base, __ffsll((long long)bal) - 1, kWave);
         const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-        surv[slot] = make_int4(view * n + rank, nv, nclips, 0);
+        surv[slot] = make_int4(view * n + rank, nv, pos, home_tiles * 256);
         double2 *sp = surv_poly + (size_t)slot * kHprMaxV;
         for (int k = 0; k < nv; k++) sp[k] = poly[k * kHprThreads];
         nv = -1;               // decided later
@@ -1190,18 +1204,22 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     // surv != null: the points the split first kernel left undecided continue HERE from their saved polygons (home tiles and
     // verification are behind them), one wave each
     const bool cont = surv != nullptr;
-    const int id = cont ? surv[blockIdx.x].x : list[blockIdx.x], view = id / n, rank = id - view * n;
+    // (a parked point's record carries its position: one dependent load less in front of the first useful one)
+    const int4 rec = cont ? surv[blockIdx.x] : make_int4(list[blockIdx.x], 4, -1, 0);
+    const int id = rec.x, view = id / n, rank = id - view * n;
     if (alive && !alive[view]) return;        // (wave-uniform) a view that cannot be the best any more
     const int *hl = hardlist + (size_t)view * n;
-    const int pos = hl[rank], i = perm[(size_t)view * n + pos];
+    const int pos = cont ? rec.z : hl[rank], i = perm[(size_t)view * n + pos];
     const double *fl = fl_all + (size_t)view * n * 3;
-    const int ntiles = ceil_div_dev(n, kHprThreads), own = hpr_base_tile(hl, hardcnt[view], rank);
+    const int ntiles = ceil_div_dev(n, kHprThreads);
     const HprTile *tiles = tiles_all + (size_t)view * ntiles;
     HprFrame f;
     if (!hpr_frame(fl + (size_t)pos * 3, f)) return;      // (cannot happen: the first pass listed it)
     int cur = 0, nv = 4;
+    // home tiles the exact path has behind it (0 .. 3) and candidates of the next one already taken (hpr_kernel's park)
+    const int rel0 = cont ? rec.w >> 8 : 0, skip0 = cont ? rec.w & 255 : 0;
     if (cont) {
-        nv = surv[blockIdx.x].y;
+        nv = rec.y;
         if (lane < nv) s_buf[0][lane] = surv_poly[(size_t)blockIdx.x * kHprMaxV + lane];
     } else if (lane == 0) {
         s_buf[0][0] = make_double2(-kHprBox, -kHprBox);
@@ -1214,7 +1232,7 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     bool failed = false;
     const int home = pos / kHprThreads;
     // one tile of candidates against the polygon (32 candidates at a time)
-    auto take_tile = [&](int tile) {
+    auto take_tile = [&](int tile, int skip) {
         const int tile0 = tile * kHprThreads;
             // the first pass's order: 32-candidate chunks, in the home tile starting with the point's own
             // (any other tile is taken in ascending order: 64 candidates at a time there)
@@ -1222,10 +1240,11 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
             const int rot = is_home ? ((pos - home * kHprThreads) >> 5) : 0;
             const int width = is_home ? 32 : kWave;
             for (int cc = 0; cc < kHprThreads / width && nv > 0; cc++) {
+                if ((cc + 1) * width <= skip) continue;              // (taken before the point was parked)
                 const int j = tile0 + (is_home ? ((cc + rot) & (kHprThreads / 32 - 1)) * 32 : cc * kWave) + lane;
                 double A = 0.0, B = 0.0, C = 0.0;
                 bool pass = false;
-                if (lane < width && j < n) {
+                if (lane < width && cc * width + lane >= skip && j < n) {
                     const double qx = fl[(size_t)j * 3 + 0], qy = fl[(size_t)j * 3 + 1], qz = fl[(size_t)j * 3 + 2];
                     A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
                     B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
@@ -1274,17 +1293,10 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                 }
             }
     };
-    // the same order as the first pass: the home tile and its neighbours, then outward from the group's tile
-    for (int rel = 0; rel < 3 && nv > 0 && !cont; rel++) {
-        const int tile = home + (rel == 0 ? 0 : (rel == 1 ? 1 : -1));
-        if (tile >= 0 && tile < ntiles) take_tile(tile);
-    }
-    // verify, as in hpr_kernel: an interior point of the polygon as THE normal against every other point (the 64
-    // lanes take 64 candidates at a time); strictly feasible everywhere: visible, nothing left to clip.  A wave
-    // per point makes a trial cheap (n / 64 steps), so several interior points are tried: the centroid, or -- for
-    // a polygon that runs out to the box -- points at decreasing distance from its vertex nearest the origin.
     bool lp_ran = false;
-    if (CAP >= 128 && nv >= 3 && nv <= kHprLpMaxV && !(no_cull & (32 | 128))) {
+    // -> 0 undecided, 1 visible, 2 hidden
+    auto lp_try = [&]() -> int {
+        if (!(CAP >= 128 && nv >= 3 && nv <= kHprLpMaxV && !(no_cull & (32 | 128)))) return 0;
         lp_ran = true;
         const double2 *P = s_buf[cur];
         double2 *scratch = s_buf[cur ^ 1];            // two scratch polygons of up to 64 vertices (CAP >= 128)
@@ -1338,23 +1350,14 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                 const int oj = __shfl_xor(bj, o, kWave);
                 if (ok > bkey || (ok == bkey && oj < bj)) { bkey = ok; bj = oj; }
             }
-            if (bkey < 0.0) {                 // c is strictly feasible: visible
-                if (lane == 0) {
-                    vis[(size_t)view * n + i] = 1;
-                    atomicAdd(&cnt[view], 1);
-                }
-                return;
-            }
+            if (bkey < 0.0) return 1;                 // c is strictly feasible: visible
             const int owner = __ffsll((long long)__ballot(kj == bj && key == bkey)) - 1;
             const double A = __shfl(kA, owner, kWave), B = __shfl(kB, owner, kWave), C = __shfl(kC, owner, kWave);
             bool hidden = hpr_excluded(P, nv, false, 0.0, 0.0, 0.0, A, B, C, lane);
 #pragma unroll
             for (int q = kHprLpIters - 2; q >= 0; q--)
                 if (q < nprev && !hidden) hidden = hpr_excluded(P, nv, true, pA[q], pB[q], pC[q], A, B, C, lane);
-            if (hidden) {
-                if (lane == 0) vis[(size_t)view * n + i] = 0;
-                return;
-            }
+            if (hidden) return 2;
             if (it + 1 == kHprLpIters) break;
             double2 *dst = scratch + (it & 1) * 64;
             const int m = hpr_clip_wave(poly, pn, A, B, C, dst, lane);
@@ -1368,6 +1371,27 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
             nprev++;
         }
         __syncthreads();          // (the walk reuses the scratch buffer)
+        return 0;
+    };
+    auto decided = [&](int d) {
+        if (lane == 0) {
+            vis[(size_t)view * n + i] = d == 1 ? 1 : 0;
+            if (d == 1) atomicAdd(&cnt[view], 1);
+        }
+    };
+    // the first pass's order: the home tile and its neighbours, then outward from the group's tile.  A parked point is
+    // tried before its remaining home tiles are taken (most are decided from the polygon they bring), and again after.
+    if (cont && rel0 < 3) {
+        const int d = lp_try();
+        if (d) { decided(d); return; }
+    }
+    for (int rel = rel0; rel < 3 && nv > 0; rel++) {
+        const int tile = home + (rel == 0 ? 0 : (rel == 1 ? 1 : -1));
+        if (tile >= 0 && tile < ntiles) take_tile(tile, rel == rel0 ? skip0 : 0);
+    }
+    {
+        const int d = lp_try();
+        if (d) { decided(d); return; }
     }
     if (nv >= 3 && !(no_cull & 32) && !cont && !lp_ran) {
         const double2 *src = s_buf[cur];
@@ -1420,6 +1444,7 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
             }
         }
     }
+    const int own = hpr_base_tile(hl, hardcnt[view], rank);
     for (int step0 = 0, bsz = 1; step0 < 2 * ntiles && nv > 0; step0 += bsz, bsz = step0 < kWave ? step0 : kWave) {
         bool need = false;
         if (lane < bsz) {
@@ -1432,7 +1457,7 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
         while (todo && nv > 0) {
             const int b = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            take_tile(hpr_tile_of(step0 + b, own));
+            take_tile(hpr_tile_of(step0 + b, own), 0);
         }
     }
     if (failed) return;
@@ -1576,9 +1601,14 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     static const int env_sl = tune_env("GENPC_HPR_STRAGGLE_LANES", kHprThreads, "hidden-point removal: hand a block's points over when at most this many lanes are still undecided");
     static const int env_st = tune_env("GENPC_HPR_STRAGGLE_TILES", 0, "hidden-point removal: clouds of at least this many tiles hand undecided points over early");
     const int straggle_from = ntiles >= env_st ? env_sf : 0x7fffffff, straggle_lanes = env_sl;
+    // split form: home tiles (the point's own, the next, the previous) the first kernel takes before it tries to verify and
+    // parks what is left; the wave-per-point pass decides most parked points from the polygon they bring and takes the
+    // remaining home tiles only for the others
+    static const int env_ht = tune_env("GENPC_HPR_HOME_TILES", 1, "hidden-point removal, two-kernel form: home tiles (1..3) the first kernel clips by before it parks a point");
+    const int home_tiles = split ? (env_ht < 1 ? 1 : (env_ht > 3 ? 3 : env_ht)) : 3;
     hipLaunchKernelGGL(hpr_kernel, dim3(ntiles * c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
                        (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull,
-                       max_clips, split, surv, surv_poly, und, straggle_from, straggle_lanes, c);
+                       max_clips, split, surv, surv_poly, und, straggle_from, straggle_lanes, c, home_tiles);
     if (!check(hipGetLastError(), "hpr launch")) return 0;
     int st[5] = {0, 0, 0, 0, 0};
     if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
@@ -1593,7 +1623,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
                            no_cull, (const unsigned char *)alive, list2, (const int4 *)surv, (const double2 *)surv_poly, (double2 *)nullptr, 0);
         if (!check(hipGetLastError(), "hpr continuation launch")) return 0;
     }
-    if (second_pass_points) *second_pass_points = st[0];
+    if (second_pass_points) *second_pass_points = st[0] + st[2];      // every point a wave took over (parked or listed)
     {
         static const bool one_tier = tune_env("GENPC_HPR_ONE_TIER", 0, "hidden-point removal: 1 = every listed point straight to the 1024-vertex tier") != 0;
         const bool continued = st[2] > 0;

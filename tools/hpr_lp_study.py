@@ -66,7 +66,7 @@ def morton_order(dirs, axis):
     return np.argsort(spread(q(x)) | (spread(q(y)) << 1), kind="stable")
 
 
-def study(pts, eye, radius=1.0e4):
+def study(pts, eye, radius=1.0e4, home_tiles=3):
     n = len(pts)
     v = pts.astype(np.float64) - eye
     r = np.linalg.norm(v, axis=1)
@@ -91,7 +91,7 @@ def study(pts, eye, radius=1.0e4):
         poly = np.array([[-BOX, -BOX], [BOX, -BOX], [BOX, BOX], [-BOX, BOX]])
         home = i // TILE
         alive = True
-        for tile in (home, home + 1, home - 1):
+        for tile in (home, home + 1, home - 1)[:home_tiles]:
             if tile < 0 or tile >= ntiles or not alive:
                 continue
             js = np.arange(tile * TILE, min(n, tile * TILE + TILE))
@@ -180,4 +180,5 @@ if __name__ == "__main__":
     for k in range(nviews):
         d = rng.normal(size=3); d /= np.linalg.norm(d)
         c = (sub.max(0) + sub.min(0)) / 2
-        print(which, "view", k, study(sub, c + 1.6 * d), flush=True)
+        for ht in (3, 1):
+            print(which, "view", k, "home tiles", ht, study(sub, c + 1.6 * d, home_tiles=ht), flush=True)
