@@ -573,14 +573,17 @@ __global__ __launch_bounds__(kHprThreads) void hpr_accept_kernel(int n, const do
             }
             __syncthreads();
             if (active && ((mine >> b) & 1ull)) {
-                const double thr = 1e-8 * f.rho;
+                // The test has a margin of 1e-8 |p'| and only ever ACCEPTS (a point it turns down takes the exact path), so
+                // its arithmetic need not be the oracle's: fused multiply-adds, and the point itself recognised by its
+                // position instead of by value (14 -> 8 instructions per candidate; the kernel is VALU-bound).
+                const double lim = f.rho - 1e-8 * f.rho;          // C < thr  <=>  u.q > lim
+                const int self_t = tile == own ? tid : -1;
                 bool bad = false;
 #pragma unroll 8
                 for (int t = 0; t < kHprThreads; t++) {
                     const double4 q = s_stage[t];          // rows past the end are NaN: the comparison below is false
-                    const double C = f.rho - (f.ux * q.x + f.uy * q.y + f.uz * q.z);
-                    const bool self = q.x == f.px && q.y == f.py && q.z == f.pz;
-                    bad |= !self && C < thr;
+                    const double d = __builtin_fma(f.uz, q.z, __builtin_fma(f.uy, q.y, f.ux * q.x));
+                    bad |= t != self_t && d > lim;
                 }
                 if (bad) { ok = false; active = false; }
             }
@@ -626,10 +629,42 @@ __global__ __launch_bounds__(1024) void hpr_compact_kernel(int n, const unsigned
     if (tid == 0) hardcnt[view] = s_base;
 }
 
+// tools/hpr_phases.py builds a private copy with -DGENPC_HPR_PROF: per block, shader-clock ticks of hpr_kernel's phases and
+// the trip counts of its clip loop, summed into g_hpr_prof (compiled out of the shipped library)
+#ifdef GENPC_HPR_PROF
+__device__ unsigned long long g_hpr_prof[16];
+#define HPR_PROF_DECL unsigned long long prof_c[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define HPR_PROF_ADD(k, v) do { prof_c[k] += (unsigned long long)(v); } while (0)      // per lane, in registers
+#define HPR_PROF_FLUSH() do { for (int k_ = 0; k_ < 10; k_++) { unsigned long long v_ = prof_c[k_]; if (k_ >= 4 && k_ != 8) { for (int o_ = 32; o_ > 0; o_ >>= 1) { const unsigned long long x_ = __shfl_xor(v_, o_, 64); v_ = k_ == 5 ? (x_ > v_ ? x_ : v_) : v_ + x_; } } \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_hpr_prof[k_], v_); } } while (0)
+#define HPR_PROF_CLOCK() __builtin_readcyclecounter()
+#else
+#define HPR_PROF_DECL do {} while (0)
+#define HPR_PROF_ADD(k, v) do {} while (0)
+#define HPR_PROF_FLUSH() do {} while (0)
+#define HPR_PROF_CLOCK() 0ull
+#endif
 constexpr int kHprBatch = 64;      // tiles tested per round (one bit each)
 constexpr int kHprRimStep = 8;     // after this many tiles ...
 constexpr double kHprRimD2 = 1.0e6; // ... a polygon with a vertex farther than 1000 from the origin is a silhouette point's
 constexpr int kHprRimTiles = 256;  // ... and is handed to the second pass if the cloud has at least this many tiles
+
+// Parked points are stored in eight segments, one per XCD: the blocks of a view run on XCD view % 8 (hpr_block), one view
+// after the other, so a segment holds its views' points grouped by view -- and the wave-per-point kernels send block b to
+// segment b % 8 (the XCD it runs on), where consecutive waves then read ONE view's flipped points and tile records
+// through that XCD's L2 (in one list in order of arrival every L2 saw eight to sixteen views at a time).
+// base[x] = start of segment x (prefix sums of the views' listed points: upper bounds), status[32 + x] = its fill.
+struct HprSegs {
+    int base[9];
+    int on;            // 0: one segment (views not a multiple of 8)
+};
+__device__ __forceinline__ int hpr_seg_of(const HprSegs &sg, int view) { return sg.on ? (view & 7) : 0; }
+// block b of a launch over `8 x longest segment` (or the one segment): its slot, -1 past the segment's end
+__device__ __forceinline__ int hpr_seg_slot(const HprSegs &sg, const int *status, int b)
+{
+    const int x = sg.on ? (b & 7) : 0, k = sg.on ? (b >> 3) : b;
+    return k < status[32 + x] ? sg.base[x] + k : -1;
+}
 
 // status[0] = points handed to the wave-per-point pass, status[1] = error (2: a polygon outgrew kHprOverCap),
 // status[2] = points left undecided by the split first kernel (continued by the wave-per-point pass)
@@ -638,8 +673,9 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                                                          const int *__restrict__ hardcnt, unsigned char *__restrict__ vis,
                                                          int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull, int max_clips,
                                                          int split, int4 *__restrict__ surv, double2 *__restrict__ surv_poly,
-                                                         int *__restrict__ und, int straggle_from, int straggle_lanes, int nviews, int home_tiles)
+                                                         int *__restrict__ und, int straggle_from, int straggle_lanes, int nviews, int home_tiles, HprSegs segs, int chunk_w, int home_chunks)
 {
+    HPR_PROF_DECL;
     __shared__ double2 s_poly[kHprMaxV * kHprThreads];
     __shared__ double4 s_stage[kHprThreads];      // 64 tile records while testing, then one tile's candidates
     __shared__ unsigned long long s_mask;
@@ -686,7 +722,9 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     // to resume from -- code = 256 x (home tiles done: 0 .. 3) + candidates of the next home tile already taken -- and a
     // wave of hpr_overflow_kernel continues from there (round 3 restarted such points from the box: 6.5 of 45 ms).
     auto park = [&](int code) {
-        const int slot = atomicAdd(&status[2], 1);
+        const int sx = hpr_seg_of(segs, view);
+        const int slot = segs.base[sx] + atomicAdd(&status[32 + sx], 1);
+        atomicAdd(&status[2], 1);
         if (und) atomicAdd(&und[view], 1);
         surv[slot] = make_int4(view * n + rank, nv, pos, code);
         double2 *sp = surv_poly + (size_t)slot * kHprMaxV;
@@ -700,20 +738,35 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                 // almost none are)
                 // (in the point's HOME tile the chunks start with its own: nearest neighbours first)
                 const int rot = tile == home ? ((pos - home * kHprThreads) >> 5) : 0;
-                for (int cc = 0; cc < kHprThreads / 32 && active; cc++) {
+                for (int cc = 0; cc < (rel == 0 ? home_chunks : kHprThreads / 32) && active; cc++) {
                     const int c0 = ((cc + rot) & (kHprThreads / 32 - 1)) * 32;
-                    R = hpr_reach(poly, kHprThreads, nv);
+                    for (int s0 = 0; s0 < 32 && active; s0 += chunk_w) {
+                    // Marks: the candidates that CUT the polygon as it is now (a vertex strictly outside) -- the polygon in
+                    // registers, every lane the same straight-line test.  The clip loop below runs as long as its slowest
+                    // lane, at ~500 instructions a trip; with marks from the reach bounds (hpr_far: 17 of 32 candidates
+                    // marked per lane, a few of them real cuts) a wave made 28 trips per 32 candidates with a third of its
+                    // lanes busy (tools/hpr_phases.py).  A candidate that does not cut now cannot cut what is left later.
+                    double2 pv[kHprMaxV];
+#pragma unroll
+                    for (int k = 0; k < kHprMaxV; k++) pv[k] = poly[(k < nv ? k : 0) * kHprThreads];
                     unsigned m = 0u;
-#pragma unroll 4
-                    for (int t = 0; t < 32; t++) {
+#pragma unroll 1
+                    for (int t = s0; t < s0 + chunk_w; t++) {
                         const double4 q = load(c0 + t);      // rows past the end are NaN
                         const double A = f.e1x * q.x + f.e1y * q.y + f.e1z * q.z;
                         const double B = f.e2x * q.x + f.e2y * q.y + f.e2z * q.z;
                         const double C = f.rho - (f.ux * q.x + f.uy * q.y + f.uz * q.z);
                         const bool self = q.x == f.px && q.y == f.py && q.z == f.pz;      // the point itself, or an exact duplicate
-                        m |= (!self && q.x == q.x && !hpr_far(R, A, B, C)) ? (1u << t) : 0u;
+                        bool cut = false;
+#pragma unroll
+                        for (int k = 0; k < kHprMaxV; k++) cut |= pv[k].x * A + pv[k].y * B - C > 0.0;      // (NaN rows: false)
+                        m |= (!self && cut) ? (1u << t) : 0u;
                     }
+                    HPR_PROF_ADD(4, 1);                                   // marking rounds (summed over lanes)
+                    HPR_PROF_ADD(7, __popc(m));                           // marked candidates (summed over lanes)
                     while (m && active) {
+                        HPR_PROF_ADD(5, 1);                               // clip-loop trips (the wave's = its lanes' maximum)
+                        HPR_PROF_ADD(6, 1);                               // ... summed over lanes
                         const int t = __ffs((int)m) - 1;
                         m &= m - 1;
                         const double4 q = load(c0 + t);      // (recomputed: the same values)
@@ -770,6 +823,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                             break;
                         }
                     }
+                    }
                 }
                 };
     // Stage one tile of candidates in LDS and let the lanes that want it clip against it.
@@ -795,6 +849,7 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     // Each lane reads ITS tiles straight from memory (its neighbours in the wave read the same or the next tile:
     // the lines are shared in L1/L2): staging them through LDS would take the block's tiles one after the other
     // with a few lanes busy on each -- measured 1.0 of a block's 2.7 ms.
+    [[maybe_unused]] const unsigned long long prof_t0 = HPR_PROF_CLOCK();
     for (int rel = 0; rel < home_tiles && active; rel++) {            // home, home + 1, home - 1: nearest first
         const int tile = home + (rel == 0 ? 0 : (rel == 1 ? 1 : -1));
         if (tile < 0 || tile >= ntiles) continue;
@@ -814,7 +869,10 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     // meets a counter-example goes on to phase 2 with its polygon untouched (the decision there is the same
     // computation as without this phase).  This is the early accept of hpr_accept_kernel with a better normal.
     // (Interior point: the centroid; for a polygon that runs out to the box, a point near its bounded end.)
-    if (!(no_cull & 32)) {
+    [[maybe_unused]] const unsigned long long prof_t1 = HPR_PROF_CLOCK();
+    HPR_PROF_ADD(0, prof_t1 - prof_t0);            // home tiles
+    HPR_PROF_ADD(8, 1);                            // waves
+    if (!(no_cull & 32) && !(split && !(no_cull & 512))) {
         bool trying = active && nv >= 3;
         double2 ctr = make_double2(0.0, 0.0);
         if (trying) {
@@ -913,17 +971,21 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     // one listed point in eight is still undecided here, and a block that carried them on waited for its slowest
     // lane with the other seven eighths idle (1.5 of a block's 2.7 ms).  The undecided lanes park
     // their polygons in memory; hpr_overflow_kernel continues from them, one wave each.
+    [[maybe_unused]] const unsigned long long prof_t2 = HPR_PROF_CLOCK();
+    HPR_PROF_ADD(1, prof_t2 - prof_t1);            // verify
     if (split && active) {
         const unsigned long long bal = __ballot(true);
         const int lane = tid & (kWave - 1);
         int base = 0;
         if (lane == __ffsll((long long)bal) - 1) {
-            base = atomicAdd(&status[2], __popcll(bal));
+            const int sx = hpr_seg_of(segs, view);
+            base = segs.base[sx] + atomicAdd(&status[32 + sx], __popcll(bal));
+            atomicAdd(&status[2], __popcll(bal));
             if (und) atomicAdd(&und[view], __popcll(bal));      // (a wave's lanes share the view: one block = one view)
         }
         base = __shfl(base, __ffsll((long long)bal) - 1, kWave);
         const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-        surv[slot] = make_int4(view * n + rank, nv, pos, home_tiles * 256);
+        surv[slot] = make_int4(view * n + rank, nv, pos, home_chunks < kHprThreads / 32 ? home_chunks * 32 : home_tiles * 256);
         double2 *sp = surv_poly + (size_t)slot * kHprMaxV;
         for (int k = 0; k < nv; k++) sp[k] = poly[k * kHprThreads];
         nv = -1;               // decided later
@@ -995,6 +1057,8 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
             take_tile(hpr_tile_of(step0 + b, own), ((mine >> b) & 1ull) != 0ull);
         }
     }
+    HPR_PROF_ADD(2, HPR_PROF_CLOCK() - prof_t2);    // park / walk
+    HPR_PROF_FLUSH();
     const bool seen = i >= 0 && nv > 0;
     if (i >= 0 && nv >= 0) vis[(size_t)view * n + i] = seen ? 1 : 0;
     const int c = __syncthreads_count(seen);
@@ -1180,6 +1244,152 @@ __device__ __forceinline__ bool hpr_excluded(const double2 *P, int nv, bool pair
     return __ballot(mine && !(g > m)) == 0ull;
 }
 
+// One point's decision rounds (see above): P = its polygon as the exact path left it (nv <= kHprLpMaxV vertices), scratch =
+// room for two polygons of 64 vertices.  -> 0 undecided, 1 visible, 2 hidden.
+__device__ __forceinline__ int hpr_decide(const HprFrame &f, const double2 *P, int nv, double2 *scratch, const double *__restrict__ fl,
+                                          int n, int ntiles, const HprTile *__restrict__ tiles, int home, int pos, int no_cull, int lane)
+{
+    const double2 *poly = P;
+    int pn = nv, nprev = 0;
+    double pA[kHprLpIters], pB[kHprLpIters], pC[kHprLpIters];
+    for (int it = 0; it < kHprLpIters; it++) {
+        double2 c;
+        if (!hpr_interior(poly, pn, c)) break;
+        const double nx = f.ux + c.x * f.e1x + c.y * f.e2x, ny = f.uy + c.x * f.e1y + c.y * f.e2y,
+                     nz = f.uz + c.x * f.e1z + c.y * f.e2z;
+        const double nn = 1.0 + c.x * c.x + c.y * c.y;
+        const double thr = 1e-10 * f.rho * nn;
+        const double cl = sqrt(nn) * (1.0 + 1e-15), cpsi1 = 1.0 / cl, spsi1 = sqrt(nn - 1.0) / cl * (1.0 + 1e-15);
+        // the candidate c violates most (distance to its line); key < 0: none comes within the margin
+        double key = -1.0, kA = 0.0, kB = 0.0, kC = 0.0;
+        int kj = INT_MAX;
+        bool excl = false;
+        // tiles outward from the point's own: what hides a point is near it in direction, and the first candidate
+        // found to exclude all of P ends the scan (two thirds of the parked points end hidden)
+        for (int t0 = 0; t0 < 2 * ntiles; t0 += kWave) {
+            const int tl = hpr_tile_of(t0 + lane, home);
+            const bool need = tl >= 0 && tl < ntiles && ((no_cull & 1) || hpr_tile_needed(f, cpsi1, spsi1, &c, 0, 1, tiles[tl]));
+            unsigned long long todo = __ballot(need);
+            while (todo) {
+                // two needed tiles at a time: twelve loads in flight instead of six (this loop waits on memory:
+                // every tile is a round trip to L2 or beyond)
+                const int b0 = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                int b1 = -1;
+                if (todo) {
+                    b1 = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                }
+                constexpr int kPer = kHprThreads / kWave;
+                double q[2 * kPer][3];
+                int jj[2 * kPer];
+#pragma unroll
+                for (int e = 0; e < 2 * kPer; e++) {
+                    const int b = e < kPer ? b0 : b1;
+                    const int j = hpr_tile_of(t0 + b, home) * kHprThreads + (e % kPer) * kWave + lane;
+                    jj[e] = (b >= 0 && j < n) ? j : -1;
+                    const int jl = jj[e] >= 0 ? j : pos;           // (a harmless address: the point itself)
+                    q[e][0] = fl[(size_t)jl * 3 + 0];
+                    q[e][1] = fl[(size_t)jl * 3 + 1];
+                    q[e][2] = fl[(size_t)jl * 3 + 2];
+                }
+#pragma unroll
+                for (int e = 0; e < 2 * kPer; e++) {
+                    const double qx = q[e][0], qy = q[e][1], qz = q[e][2];
+                    const double sv = (nx * qx + ny * qy + nz * qz) - f.rho;
+                    const bool self = qx == f.px && qy == f.py && qz == f.pz;
+                    if (jj[e] >= 0 && !self && sv > -thr) {           // (NaN rows: false)
+                        const double A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
+                        const double B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
+                        const double C = f.rho - (f.ux * qx + f.uy * qy + f.uz * qz);
+                        const double l2 = A * A + B * B;
+                        const double k2 = sv > 0.0 ? (l2 > 0.0 ? sv * sv / l2 : __builtin_inf()) : 0.0;
+                        if (k2 > key || (k2 == key && jj[e] < kj)) {
+                            key = k2; kj = jj[e]; kA = A; kB = B; kC = C;
+                        }
+                        // does this candidate alone exclude all of P (hpr_excluded's test, a lane per candidate)?
+                        double smin = __builtin_inf(), mmax = 0.0;
+                        for (int k = 0; k < nv; k++) {
+                            const double2 v = P[k];
+                            const double sk = v.x * A + v.y * B - C, mk = fabs(v.x * A) + fabs(v.y * B) + fabs(C);
+                            smin = sk < smin ? sk : smin;
+                            mmax = mk > mmax ? mk : mmax;
+                        }
+                        excl |= mmax < __builtin_inf() && smin > 1e-9 * mmax;
+                    }
+                }
+                if (__ballot(excl) != 0ull) return 2;
+            }
+        }
+        double bkey = key;
+        int bj = kj;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ok = __shfl_xor(bkey, o, kWave);
+            const int oj = __shfl_xor(bj, o, kWave);
+            if (ok > bkey || (ok == bkey && oj < bj)) { bkey = ok; bj = oj; }
+        }
+        if (bkey < 0.0) return 1;                 // c is strictly feasible: visible
+        const int owner = __ffsll((long long)__ballot(kj == bj && key == bkey)) - 1;
+        const double A = __shfl(kA, owner, kWave), B = __shfl(kB, owner, kWave), C = __shfl(kC, owner, kWave);
+        bool hidden = hpr_excluded(P, nv, false, 0.0, 0.0, 0.0, A, B, C, lane);
+#pragma unroll
+        for (int q = kHprLpIters - 2; q >= 0; q--)
+            if (q < nprev && !hidden) hidden = hpr_excluded(P, nv, true, pA[q], pB[q], pC[q], A, B, C, lane);
+        if (hidden) return 2;
+        if (it + 1 == kHprLpIters) break;
+        double2 *dst = scratch + (it & 1) * 64;
+        const int m = hpr_clip_wave(poly, pn, A, B, C, dst, lane);
+        __syncthreads();
+        if (m < 3 || m > 62) break;
+        poly = dst;
+        pn = m;
+#pragma unroll
+        for (int q = 0; q < kHprLpIters - 1; q++)
+            if (q == nprev) { pA[q] = A; pB[q] = B; pC[q] = C; }
+        nprev++;
+    }
+    return 0;
+}
+
+// The parked points' first try in a kernel of its own: the rounds above wait on memory (a wave lives ~20 us, most of it
+// in a dozen dependent round trips), so what matters is how many waves a CU holds -- this kernel needs a third of the
+// registers of hpr_overflow_kernel, whose walk and clip code the 98 % of the points decided here never run.  Undecided
+// points (and the ones that still have home tiles to take after the try) are listed for hpr_overflow_kernel by slot.
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 8))) void hpr_decide_kernel(int n, const double *__restrict__ fl_all, const HprTile *__restrict__ tiles_all,
+                                                          unsigned char *__restrict__ vis, int *__restrict__ cnt, int *status,
+                                                          const int *__restrict__ perm, int no_cull, const unsigned char *__restrict__ alive,
+                                                          const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
+                                                          int *__restrict__ slots, HprSegs segs)
+{
+    __shared__ double2 s_p[kHprMaxV + 6];
+    __shared__ double2 s_scratch[128];
+    const int lane = threadIdx.x;
+    const int slot = hpr_seg_slot(segs, status, blockIdx.x);
+    if (slot < 0) return;
+    const int4 rec = surv[slot];
+    const int view = rec.x / n, nv = rec.y, pos = rec.z;
+    if (alive && !alive[view]) return;        // (wave-uniform) a view that cannot be the best any more
+    const int i = perm[(size_t)view * n + pos];
+    const double *fl = fl_all + (size_t)view * n * 3;
+    const int ntiles = ceil_div_dev(n, kHprThreads);
+    HprFrame f;
+    if (!hpr_frame(fl + (size_t)pos * 3, f)) return;
+    if (lane < nv) s_p[lane] = surv_poly[(size_t)slot * kHprMaxV + lane];
+    __syncthreads();
+    int d = 0;
+    if (nv >= 3 && !(no_cull & (32 | 128)))
+        d = hpr_decide(f, s_p, nv, s_scratch, fl, n, ntiles, tiles_all + (size_t)view * ntiles, pos / kHprThreads, pos, no_cull, lane);
+    if (lane == 0) {
+        if (d) {
+            vis[(size_t)view * n + i] = d == 1 ? 1 : 0;
+            if (d == 1) atomicAdd(&cnt[view], 1);
+        } else {
+            slots[atomicAdd(&status[5], 1)] = slot;
+        }
+    }
+}
+
 // CAP = vertices a polygon may reach: the pass runs with 128 first (4 KiB of LDS per wave: forty waves per CU instead
 // of the five that two 16 KiB buffers allow) and hands the few polygons that outgrow that to a second launch with
 // kHprOverCap (list2, counted in status[3]); results do not depend on the tier.
@@ -1191,7 +1401,7 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                                                              const int *__restrict__ hardcnt, int no_cull,
                                                              const unsigned char *__restrict__ alive, int *__restrict__ list2,
                                                              const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
-                                                             double2 *__restrict__ gbuf, int gcap)
+                                                             double2 *__restrict__ gbuf, int gcap, const int *__restrict__ slots, HprSegs segs)
 {
     // CAP == 0: the polygon lives in global memory, gcap vertices per buffer (n + 8: a polygon has at most one edge per
     // other point and four of the box -- this tier cannot overflow; round 3 returned an error beyond 1024 vertices)
@@ -1205,7 +1415,10 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     // verification are behind them), one wave each
     const bool cont = surv != nullptr;
     // (a parked point's record carries its position: one dependent load less in front of the first useful one)
-    const int4 rec = cont ? surv[blockIdx.x] : make_int4(list[blockIdx.x], 4, -1, 0);
+    // (slots: the parked points hpr_decide_kernel left undecided -- their first try is behind them)
+    const int slot = !cont ? 0 : (slots ? slots[blockIdx.x] : hpr_seg_slot(segs, status, blockIdx.x));
+    if (slot < 0) return;
+    const int4 rec = cont ? surv[slot] : make_int4(list[blockIdx.x], 4, -1, 0);
     const int id = rec.x, view = id / n, rank = id - view * n;
     if (alive && !alive[view]) return;        // (wave-uniform) a view that cannot be the best any more
     const int *hl = hardlist + (size_t)view * n;
@@ -1220,7 +1433,7 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     const int rel0 = cont ? rec.w >> 8 : 0, skip0 = cont ? rec.w & 255 : 0;
     if (cont) {
         nv = rec.y;
-        if (lane < nv) s_buf[0][lane] = surv_poly[(size_t)blockIdx.x * kHprMaxV + lane];
+        if (lane < nv) s_buf[0][lane] = surv_poly[(size_t)slot * kHprMaxV + lane];
     } else if (lane == 0) {
         s_buf[0][0] = make_double2(-kHprBox, -kHprBox);
         s_buf[0][1] = make_double2(kHprBox, -kHprBox);
@@ -1298,78 +1511,8 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     auto lp_try = [&]() -> int {
         if (!(CAP >= 128 && nv >= 3 && nv <= kHprLpMaxV && !(no_cull & (32 | 128)))) return 0;
         lp_ran = true;
-        const double2 *P = s_buf[cur];
-        double2 *scratch = s_buf[cur ^ 1];            // two scratch polygons of up to 64 vertices (CAP >= 128)
-        const double2 *poly = P;
-        int pn = nv, nprev = 0;
-        double pA[kHprLpIters], pB[kHprLpIters], pC[kHprLpIters];
-        for (int it = 0; it < kHprLpIters; it++) {
-            double2 c;
-            if (!hpr_interior(poly, pn, c)) break;
-            const double nx = f.ux + c.x * f.e1x + c.y * f.e2x, ny = f.uy + c.x * f.e1y + c.y * f.e2y,
-                         nz = f.uz + c.x * f.e1z + c.y * f.e2z;
-            const double nn = 1.0 + c.x * c.x + c.y * c.y;
-            const double thr = 1e-10 * f.rho * nn;
-            const double cl = sqrt(nn) * (1.0 + 1e-15), cpsi1 = 1.0 / cl, spsi1 = sqrt(nn - 1.0) / cl * (1.0 + 1e-15);
-            // the candidate c violates most (distance to its line); key < 0: none comes within the margin
-            double key = -1.0, kA = 0.0, kB = 0.0, kC = 0.0;
-            int kj = INT_MAX;
-            for (int t0 = 0; t0 < ntiles; t0 += kWave) {
-                const int tl = t0 + lane;
-                const bool need = tl < ntiles && ((no_cull & 1) || hpr_tile_needed(f, cpsi1, spsi1, &c, 0, 1, tiles[tl]));
-                unsigned long long todo = __ballot(need);
-                while (todo) {
-                    const int b = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-#pragma unroll
-                    for (int h = 0; h < kHprThreads / kWave; h++) {
-                        const int j = (t0 + b) * kHprThreads + h * kWave + lane;
-                        if (j < n) {
-                            const double qx = fl[(size_t)j * 3 + 0], qy = fl[(size_t)j * 3 + 1], qz = fl[(size_t)j * 3 + 2];
-                            const double sv = (nx * qx + ny * qy + nz * qz) - f.rho;
-                            const bool self = qx == f.px && qy == f.py && qz == f.pz;
-                            if (!self && sv > -thr) {           // (NaN rows: false)
-                                const double A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
-                                const double B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
-                                const double l2 = A * A + B * B;
-                                const double k2 = sv > 0.0 ? (l2 > 0.0 ? sv * sv / l2 : __builtin_inf()) : 0.0;
-                                if (k2 > key) {
-                                    key = k2; kj = j; kA = A; kB = B;
-                                    kC = f.rho - (f.ux * qx + f.uy * qy + f.uz * qz);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            double bkey = key;
-            int bj = kj;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ok = __shfl_xor(bkey, o, kWave);
-                const int oj = __shfl_xor(bj, o, kWave);
-                if (ok > bkey || (ok == bkey && oj < bj)) { bkey = ok; bj = oj; }
-            }
-            if (bkey < 0.0) return 1;                 // c is strictly feasible: visible
-            const int owner = __ffsll((long long)__ballot(kj == bj && key == bkey)) - 1;
-            const double A = __shfl(kA, owner, kWave), B = __shfl(kB, owner, kWave), C = __shfl(kC, owner, kWave);
-            bool hidden = hpr_excluded(P, nv, false, 0.0, 0.0, 0.0, A, B, C, lane);
-#pragma unroll
-            for (int q = kHprLpIters - 2; q >= 0; q--)
-                if (q < nprev && !hidden) hidden = hpr_excluded(P, nv, true, pA[q], pB[q], pC[q], A, B, C, lane);
-            if (hidden) return 2;
-            if (it + 1 == kHprLpIters) break;
-            double2 *dst = scratch + (it & 1) * 64;
-            const int m = hpr_clip_wave(poly, pn, A, B, C, dst, lane);
-            __syncthreads();
-            if (m < 3 || m > 62) break;
-            poly = dst;
-            pn = m;
-#pragma unroll
-            for (int q = 0; q < kHprLpIters - 1; q++)
-                if (q == nprev) { pA[q] = A; pB[q] = B; pC[q] = C; }
-            nprev++;
-        }
+        const int d = hpr_decide(f, s_buf[cur], nv, s_buf[cur ^ 1], fl, n, ntiles, tiles, home, pos, no_cull, lane);
+        if (d) return d;
         __syncthreads();          // (the walk reuses the scratch buffer)
         return 0;
     };
@@ -1381,16 +1524,18 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     };
     // the first pass's order: the home tile and its neighbours, then outward from the group's tile.  A parked point is
     // tried before its remaining home tiles are taken (most are decided from the polygon they bring), and again after.
-    if (cont && rel0 < 3) {
+    if (cont && rel0 < 3 && !slots) {
         const int d = lp_try();
+        if ((no_cull & 256) && lane == 0) atomicAdd(&status[8 + d], 1);        // measurement: [8] undecided, [9] visible, [10] hidden
         if (d) { decided(d); return; }
     }
     for (int rel = rel0; rel < 3 && nv > 0; rel++) {
         const int tile = home + (rel == 0 ? 0 : (rel == 1 ? 1 : -1));
         if (tile >= 0 && tile < ntiles) take_tile(tile, rel == rel0 ? skip0 : 0);
     }
-    {
+    if (!(slots && rel0 >= 3)) {
         const int d = lp_try();
+        if ((no_cull & 256) && lane == 0) atomicAdd(&status[12 + (nv > 0 ? d : 3)], 1);      // second try: [12] undecided, [13], [14], [15] died in the home tiles
         if (d) { decided(d); return; }
     }
     if (nv >= 3 && !(no_cull & 32) && !cont && !lp_ran) {
@@ -1558,7 +1703,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
                "hpr radix sort"))
         return 0;
     HprTile *tiles = (HprTile *)(ws + o_tiles);
-    static const int no_cull = tune_env("GENPC_HPR_NOCULL", 0, "hidden-point removal: measurement mask (1 every tile, 8 no silhouette hand-off, 16 no early accept, 32 no verify, 64 no hand-off of much-cut polygons, 128 no decisions without the walk in the wave-per-point pass)");      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept, 32 = no verify phase, 64 = no hand-off of much-cut polygons (results unchanged)
+    static const int no_cull = tune_env("GENPC_HPR_NOCULL", 0, "hidden-point removal: measurement mask (1 every tile, 8 no silhouette hand-off, 16 no early accept, 32 no verify, 64 no hand-off of much-cut polygons, 128 no decisions without the walk in the wave-per-point pass, 256 count those decisions on stderr, 512 two-kernel form WITH the first kernel's own verify phase)");      // measurement knob: 1 = every tile examined, 8 = no silhouette hand-off, 16 = no early accept, 32 = no verify phase, 64 = no hand-off of much-cut polygons (results unchanged)
     hipLaunchKernelGGL(hpr_flip_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const int *)i1, eyes, radius, fl, (const unsigned char *)dup);
     hipLaunchKernelGGL(hpr_tile_kernel, dim3(ntiles, c), dim3(kHprThreads), 0, stream, n, (const double *)fl, tiles);
     static const int env_clips = tune_env("GENPC_HPR_MAXCLIPS", 0, "hidden-point removal: clips after which a polygon goes to the wave-per-point pass (0 = pick)");
@@ -1581,15 +1726,25 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     unsigned char *alive = prune ? (unsigned char *)(ws + o_alive) : nullptr;
     if (prune && !check(hipMemsetAsync(und, 0, sizeof(int) * (size_t)c, stream), "hipMemsetAsync(hpr und)")) return 0;
     int hc_total = 0;
+    HprSegs segs = {};
     if (split) {
         // sum of hardcnt over the views = an upper bound on the survivors
         int *hc_host = (int *)malloc(sizeof(int) * (size_t)c);
         if (!hc_host) { set_error("genpc_hpr_visibility: out of host memory"); return 0; }
         if (!check(hipMemcpyAsync(hc_host, hardcnt, sizeof(int) * (size_t)c, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr hardcnt)") ||
             !check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) { free(hc_host); return 0; }
-        long long sum = 0;
-        for (int v = 0; v < c; v++) sum += hc_host[v];
+        long long sum = 0, per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        segs.on = (c & 7) == 0 ? 1 : 0;
+        for (int v = 0; v < c; v++) {
+            sum += hc_host[v];
+            per[segs.on ? (v & 7) : 0] += hc_host[v];
+        }
         free(hc_host);
+        if (sum < INT_MAX) {
+            long long at = 0;
+            for (int x = 0; x < 8; x++) { segs.base[x] = (int)at; at += per[x]; }
+            segs.base[8] = (int)at;
+        }
         hc_total = (int)(sum < INT_MAX ? sum : INT_MAX);
     }
     double2 *surv_poly = nullptr;
@@ -1605,12 +1760,16 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     // parks what is left; the wave-per-point pass decides most parked points from the polygon they bring and takes the
     // remaining home tiles only for the others
     static const int env_ht = tune_env("GENPC_HPR_HOME_TILES", 1, "hidden-point removal, two-kernel form: home tiles (1..3) the first kernel clips by before it parks a point");
+    static const int env_cw = tune_env("GENPC_HPR_CHUNK", 32, "hidden-point removal, first kernel: candidates marked at a time against the polygon as the previous ones left it (8, 16 or 32)");
+    const int chunk_w = env_cw == 8 || env_cw == 16 ? env_cw : 32;
     const int home_tiles = split ? (env_ht < 1 ? 1 : (env_ht > 3 ? 3 : env_ht)) : 3;
+    static const int env_hc = tune_env("GENPC_HPR_HOME_CHUNKS", 2, "hidden-point removal, two-kernel form with one home tile: 32-candidate chunks of it (1..4) the first kernel clips by");
+    const int home_chunks = split && home_tiles == 1 ? (env_hc < 1 ? 1 : (env_hc > 4 ? 4 : env_hc)) : 4;
     hipLaunchKernelGGL(hpr_kernel, dim3(ntiles * c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
                        (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull,
-                       max_clips, split, surv, surv_poly, und, straggle_from, straggle_lanes, c, home_tiles);
+                       max_clips, split, surv, surv_poly, und, straggle_from, straggle_lanes, c, home_tiles, segs, chunk_w, home_chunks);
     if (!check(hipGetLastError(), "hpr launch")) return 0;
-    int st[5] = {0, 0, 0, 0, 0};
+    int st[40] = {0};          // (status[16 .. 21] are the bounds of hpr_bounds_kernel, not counters)
     if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
     if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
     if (prune) hipLaunchKernelGGL(hpr_prune_kernel, dim3(1), dim3(1024), 0, stream, c, (const int *)counts, (const int *)und, alive);
@@ -1618,10 +1777,30 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     int *list2 = (int *)k0;          // (the sort's key buffer is free by now; at most views x points entries)
     int *list3 = (int *)k1;          // (likewise: the points whose polygons outgrow the 1024-vertex tier)
     if (st[2] > 0) {
-        hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(st[2]), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
-                           visible, counts, status, (const int *)nullptr, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
-                           no_cull, (const unsigned char *)alive, list2, (const int4 *)surv, (const double2 *)surv_poly, (double2 *)nullptr, 0);
-        if (!check(hipGetLastError(), "hpr continuation launch")) return 0;
+        static const int env_dk = tune_env("GENPC_HPR_DECIDE_KERNEL", 1, "hidden-point removal: 1 = the parked points' first try in a kernel of its own (more waves per CU), 0 = inside the wave-per-point kernel");
+        const int *slots = nullptr;
+        int longest = 0;
+        for (int x = 0; x < 8; x++) longest = std::max(longest, st[32 + x]);
+        const int seg_grid = segs.on ? 8 * longest : longest;          // block b -> segment b % 8
+        int waves = seg_grid;
+        if (env_dk && !(no_cull & (32 | 128))) {
+            int *sl = i0;          // (the sort's index buffer is free by now; at most views x points entries)
+            hipLaunchKernelGGL(hpr_decide_kernel, dim3(seg_grid), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles, visible,
+                               counts, status, (const int *)i1, no_cull, (const unsigned char *)alive, (const int4 *)surv,
+                               (const double2 *)surv_poly, sl, segs);
+            if (!check(hipGetLastError(), "hpr decide launch")) return 0;
+            int left = 0;
+            if (!check(hipMemcpyAsync(&left, status + 5, sizeof(int), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
+            if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
+            slots = sl;
+            waves = left;
+        }
+        if (waves > 0) {
+            hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(waves), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
+                               visible, counts, status, (const int *)nullptr, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
+                               no_cull, (const unsigned char *)alive, list2, (const int4 *)surv, (const double2 *)surv_poly, (double2 *)nullptr, 0, slots, segs);
+            if (!check(hipGetLastError(), "hpr continuation launch")) return 0;
+        }
     }
     if (second_pass_points) *second_pass_points = st[0] + st[2];      // every point a wave took over (parked or listed)
     {
@@ -1631,7 +1810,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
         if (listed > 0 && !one_tier) {
             hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(listed), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
                                visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
-                               no_cull, (const unsigned char *)alive, list2, (const int4 *)nullptr, (const double2 *)nullptr, (double2 *)nullptr, 0);
+                               no_cull, (const unsigned char *)alive, list2, (const int4 *)nullptr, (const double2 *)nullptr, (double2 *)nullptr, 0, (const int *)nullptr, segs);
             if (!check(hipGetLastError(), "hpr second pass launch")) return 0;
         }
         if (continued || (listed > 0 && !one_tier)) {
@@ -1644,13 +1823,13 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
             hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(listed), dim3(kWave), 0, stream, n, (const double *)fl,
                                (const HprTile *)tiles, visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist,
                                (const int *)hardcnt, no_cull, (const unsigned char *)alive, list3, (const int4 *)nullptr,
-                               (const double2 *)nullptr, (double2 *)nullptr, 0);
+                               (const double2 *)nullptr, (double2 *)nullptr, 0, (const int *)nullptr, segs);
         }
         if (st[3] > 0) {
             hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(st[3]), dim3(kWave), 0, stream, n, (const double *)fl,
                                (const HprTile *)tiles, visible, counts, status, (const int *)list2, (const int *)i1, (const int *)hardlist,
                                (const int *)hardcnt, no_cull, (const unsigned char *)alive, list3, (const int4 *)nullptr,
-                               (const double2 *)nullptr, (double2 *)nullptr, 0);
+                               (const double2 *)nullptr, (double2 *)nullptr, 0, (const int *)nullptr, segs);
         }
         if (big > 0) {
             if (!check(hipGetLastError(), "hpr large-polygon launch")) return 0;
@@ -1670,7 +1849,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
                 hipLaunchKernelGGL(hpr_overflow_kernel<0>, dim3(cc), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
                                    visible, counts, status, (const int *)(list3 + c0), (const int *)i1, (const int *)hardlist,
                                    (const int *)hardcnt, no_cull, (const unsigned char *)alive, (int *)nullptr, (const int4 *)nullptr,
-                                   (const double2 *)nullptr, gbuf, gcap);
+                                   (const double2 *)nullptr, gbuf, gcap, (const int *)nullptr, segs);
             }
             if (!check(hipGetLastError(), "hpr global-polygon launch")) return 0;
             if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
@@ -1682,6 +1861,12 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
             return 0;
         }
         if (tune_env("GENPC_HPR_TIERS", 0, "hidden-point removal: 1 = report on stderr how many points took the wave-per-point tiers") != 0) fprintf(stderr, "hpr: %d points in the wave-per-point pass, %d of them with polygons over 128 vertices\n", listed, big);
+        if (no_cull & 256) {
+            int lp[8] = {0};
+            if (check(hipMemcpy(lp, status + 8, sizeof lp, hipMemcpyDeviceToHost), "hipMemcpy(hpr stats)"))
+                fprintf(stderr, "hpr: parked points, first try: %d undecided, %d visible, %d hidden; after the home tiles: %d undecided, %d visible, %d hidden, %d died in the tiles\n",
+                        lp[0], lp[1], lp[2], lp[4], lp[5], lp[6], lp[7]);
+        }
     }
     if (exact) {
         if (prune) {
@@ -1690,6 +1875,18 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     }
     return 1;
 }
+
+#ifdef GENPC_HPR_PROF
+extern "C" __attribute__((visibility("default"))) int genpc_hpr_prof_read(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(genpc::g_hpr_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 0;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(genpc::g_hpr_prof), z, sizeof z) != hipSuccess) return 0;
+    }
+    return 1;
+}
+#endif
 
 GENPC_API int genpc_hpr_visibility(int c, int n, const float *points, const double *eyes, double radius, unsigned char *visible,
                                    int *counts, int *second_pass_points, void *stream_)
