@@ -1263,16 +1263,63 @@ __device__ __forceinline__ int hpr_decide(const HprFrame &f, const double2 *P, i
         // the candidate c violates most (distance to its line); key < 0: none comes within the margin
         double key = -1.0, kA = 0.0, kB = 0.0, kC = 0.0;
         int kj = INT_MAX;
-        bool excl = false;
-        // tiles outward from the point's own: what hides a point is near it in direction, and the first candidate
-        // found to exclude all of P ends the scan (two thirds of the parked points end hidden)
-        for (int t0 = 0; t0 < 2 * ntiles; t0 += kWave) {
+        // Tiles outward from the point's own: what hides a point is near it in direction, and the first candidate found
+        // to exclude all of P ends the scan (two thirds of the parked points end hidden) -- so the own tile and its two
+        // neighbours are taken before any tile record is looked at.  Two tiles at a time (twelve loads in flight: this
+        // loop waits on memory).  A lane tests only its most violated candidate so far for exclusion, once per pair.
+        auto scan_pair = [&](int ta, int tb) -> bool {
+            constexpr int kPer = kHprThreads / kWave;
+            double q[2 * kPer][3];
+            int jj[2 * kPer];
+#pragma unroll
+            for (int e = 0; e < 2 * kPer; e++) {
+                const int tile = e < kPer ? ta : tb;
+                const int j = tile * kHprThreads + (e % kPer) * kWave + lane;
+                jj[e] = (tile >= 0 && j < n) ? j : -1;
+                const int jl = jj[e] >= 0 ? j : pos;           // (a harmless address: the point itself)
+                q[e][0] = fl[(size_t)jl * 3 + 0];
+                q[e][1] = fl[(size_t)jl * 3 + 1];
+                q[e][2] = fl[(size_t)jl * 3 + 2];
+            }
+            bool fresh = false;
+#pragma unroll
+            for (int e = 0; e < 2 * kPer; e++) {
+                const double qx = q[e][0], qy = q[e][1], qz = q[e][2];
+                const double sv = (nx * qx + ny * qy + nz * qz) - f.rho;
+                const bool self = qx == f.px && qy == f.py && qz == f.pz;
+                if (jj[e] >= 0 && !self && sv > -thr) {           // (NaN rows: false)
+                    const double A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
+                    const double B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
+                    const double l2 = A * A + B * B;
+                    const double k2 = sv > 0.0 ? (l2 > 0.0 ? sv * sv / l2 : __builtin_inf()) : 0.0;
+                    if (k2 > key || (k2 == key && jj[e] < kj)) {
+                        key = k2; kj = jj[e]; kA = A; kB = B;
+                        kC = f.rho - (f.ux * qx + f.uy * qy + f.uz * qz);
+                        fresh = true;
+                    }
+                }
+            }
+            // does the lane's candidate alone exclude all of P (hpr_excluded's test, a lane per candidate)?
+            bool excl = false;
+            if (fresh) {
+                double smin = __builtin_inf(), mmax = 0.0;
+                for (int k = 0; k < nv; k++) {
+                    const double2 v = P[k];
+                    const double sk = v.x * kA + v.y * kB - kC, mk = fabs(v.x * kA) + fabs(v.y * kB) + fabs(kC);
+                    smin = sk < smin ? sk : smin;
+                    mmax = mk > mmax ? mk : mmax;
+                }
+                excl = mmax < __builtin_inf() && smin > 1e-9 * mmax;
+            }
+            return __ballot(excl) != 0ull;
+        };
+        for (int ph = 0, t0 = 0; t0 < 2 * ntiles;) {
             const int tl = hpr_tile_of(t0 + lane, home);
-            const bool need = tl >= 0 && tl < ntiles && ((no_cull & 1) || hpr_tile_needed(f, cpsi1, spsi1, &c, 0, 1, tiles[tl]));
+            bool need = tl >= 0 && tl < ntiles;
+            if (ph == 0) need = need && lane < 3;          // the own tile and its neighbours: no questions asked
+            else need = need && t0 + lane >= 3 && ((no_cull & 1) || hpr_tile_needed(f, cpsi1, spsi1, &c, 0, 1, tiles[tl]));
             unsigned long long todo = __ballot(need);
             while (todo) {
-                // two needed tiles at a time: twelve loads in flight instead of six (this loop waits on memory:
-                // every tile is a round trip to L2 or beyond)
                 const int b0 = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 int b1 = -1;
@@ -1280,46 +1327,10 @@ __device__ __forceinline__ int hpr_decide(const HprFrame &f, const double2 *P, i
                     b1 = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
                 }
-                constexpr int kPer = kHprThreads / kWave;
-                double q[2 * kPer][3];
-                int jj[2 * kPer];
-#pragma unroll
-                for (int e = 0; e < 2 * kPer; e++) {
-                    const int b = e < kPer ? b0 : b1;
-                    const int j = hpr_tile_of(t0 + b, home) * kHprThreads + (e % kPer) * kWave + lane;
-                    jj[e] = (b >= 0 && j < n) ? j : -1;
-                    const int jl = jj[e] >= 0 ? j : pos;           // (a harmless address: the point itself)
-                    q[e][0] = fl[(size_t)jl * 3 + 0];
-                    q[e][1] = fl[(size_t)jl * 3 + 1];
-                    q[e][2] = fl[(size_t)jl * 3 + 2];
-                }
-#pragma unroll
-                for (int e = 0; e < 2 * kPer; e++) {
-                    const double qx = q[e][0], qy = q[e][1], qz = q[e][2];
-                    const double sv = (nx * qx + ny * qy + nz * qz) - f.rho;
-                    const bool self = qx == f.px && qy == f.py && qz == f.pz;
-                    if (jj[e] >= 0 && !self && sv > -thr) {           // (NaN rows: false)
-                        const double A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
-                        const double B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
-                        const double C = f.rho - (f.ux * qx + f.uy * qy + f.uz * qz);
-                        const double l2 = A * A + B * B;
-                        const double k2 = sv > 0.0 ? (l2 > 0.0 ? sv * sv / l2 : __builtin_inf()) : 0.0;
-                        if (k2 > key || (k2 == key && jj[e] < kj)) {
-                            key = k2; kj = jj[e]; kA = A; kB = B; kC = C;
-                        }
-                        // does this candidate alone exclude all of P (hpr_excluded's test, a lane per candidate)?
-                        double smin = __builtin_inf(), mmax = 0.0;
-                        for (int k = 0; k < nv; k++) {
-                            const double2 v = P[k];
-                            const double sk = v.x * A + v.y * B - C, mk = fabs(v.x * A) + fabs(v.y * B) + fabs(C);
-                            smin = sk < smin ? sk : smin;
-                            mmax = mk > mmax ? mk : mmax;
-                        }
-                        excl |= mmax < __builtin_inf() && smin > 1e-9 * mmax;
-                    }
-                }
-                if (__ballot(excl) != 0ull) return 2;
+                if (scan_pair(hpr_tile_of(t0 + b0, home), b1 >= 0 ? hpr_tile_of(t0 + b1, home) : -1)) return 2;
             }
+            if (ph == 0) ph = 1;
+            else t0 += kWave;
         }
         double bkey = key;
         int bj = kj;

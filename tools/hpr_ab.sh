@@ -1,4 +1,3 @@
-python -m pytest tests/test_gpu_hpr.py tests/test_gpu_scans.py -x -q 2>&1 | tail -3
+python -m pytest tests/test_gpu_hpr.py -x -q 2>&1 | tail -3
 python tools/time_hpr_1024.py 2>&1 | grep -v amdgpu
 python tools/time_hpr.py 2>&1 | grep -v amdgpu
-python tools/time_vsel.py 2>&1 | grep -v amdgpu | tail -8
