@@ -1,3 +1,3 @@
-python -m pytest tests/test_gpu_hpr.py -x -q 2>&1 | tail -3
-python tools/time_hpr_1024.py 2>&1 | grep -v amdgpu
-python tools/time_hpr.py 2>&1 | grep -v amdgpu
+bash tools/ktrace_any.sh c2scan tools/prof_c2_scan.py
+tail -2 gpurun_out/kt_c2scan/t.log | head -1
+grep "one scan" gpurun_out/kt_c2scan/t.log
