@@ -1813,13 +1813,13 @@ GENPC_API int genpc_pose_cd_grad(int nc, const float *v, const float *center, co
 namespace genpc { static thread_local int t_pose_seeded = -1; }
 
 /* Nearest-neighbour path of the alignment loop, for tests and A/B (calling host thread): 1 seeded cell search from the
- * second step on (csrc/nn_seeded.hip; opt-in: it wins when every query keeps a near target and loses on misaligned
- * starts of real shapes), 0 the brute-force filter at every step (the default), < 0 the default / environment
- * (GENPC_POSE_SEEDED).  Both give the same bits.  Returns the previous setting. */
+ * second step on (csrc/nn_seeded.hip: it wins when every query keeps a near target and loses on misaligned starts of
+ * real shapes), 0 the brute-force filter at every step, 2 whichever of the two the call measures to be faster (the
+ * default), < 0 the default / environment (GENPC_POSE_SEEDED).  All give the same bits.  Returns the previous setting. */
 GENPC_API int genpc_pose_tune(int seeded)
 {
     const int prev = genpc::t_pose_seeded;
-    genpc::t_pose_seeded = seeded < 0 ? -1 : (seeded ? 1 : 0);
+    genpc::t_pose_seeded = seeded < 0 ? -1 : (seeded > 2 ? 2 : seeded);
     return prev;
 }
 
@@ -1918,8 +1918,24 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // degrees, most queries of a misaligned start have NO near target, and the ball their old answer leaves crosses the
     // other surface over hundreds of cells (18 k instructions per wave, 4.8 ms per step against 3.0 for the filter, which
     // does not care where the points are).  Real shapes look like config 5: off by default.
-    static const int env_seeded = tune_env("GENPC_POSE_SEEDED", 0, "alignment loop: 1 = seeded cell search for the nearest neighbours from the second step on (opt-in)");
-    const bool seeded = (t_pose_seeded >= 0 ? t_pose_seeded : env_seeded) != 0 && nc >= 256 && np >= 256;
+    static const int env_seeded = tune_env("GENPC_POSE_SEEDED", 2, "alignment loop, nearest neighbours from the second step on: 1 = seeded cell search, 0 = brute-force filter, 2 = measure both and switch");
+    const int seed_mode = nc >= 256 && np >= 256 ? (t_pose_seeded >= 0 ? t_pose_seeded : env_seeded) : 0;
+    const bool seeded = seed_mode != 0;
+    // Mode 2.  What the seeded search costs depends on the data (a query whose last answer is far away searches a large ball:
+    // the hidden side of a complete shape against a one-sided scan; misaligned starts) and falls as the poses converge; the
+    // filter costs the same at every step.  Both give the same bits, so the choice is free: the first step times the
+    // filter (it is the filter's anyway), every kPoseProbe-th step times the seeded search, and the steps in between
+    // take whichever was faster last (two events and one wait per probe: ~10 per call).
+    constexpr int kPoseProbe = 25;
+    const bool adaptive = seed_mode == 2;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (adaptive && (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess)) {
+        set_error("pose_optimize: hipEventCreate failed");
+        return 0;
+    }
+    float t_filter = 0.0f, t_seeded = __builtin_inff();
+    bool use_seeded = seed_mode == 1;
+    int probe_every = kPoseProbe, next_probe = 1;          // (a probe that loses doubles the distance to the next one)
     SeededGrids sg{};
     if (seeded) {
         void *gw = workspace(29, seeded_grids_bytes(b, nc, np), st);
@@ -1945,11 +1961,30 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
             else
                 hipLaunchKernelGGL(pose_transform_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
                                    (const float *)center, 4, (const float *)S->params, kStateFloats, pts);
-            if (seeded && it > 0) {
+            const bool probe = adaptive && (it == 0 || it == next_probe);      // it 0: the filter; 1, 26, 51 ...: the seeded search
+            const bool this_seeded = seeded && it > 0 && (probe || use_seeded);
+            if (probe) (void)hipEventRecord(ev0, st);
+            if (this_seeded) {
                 if (launch_nn_seeded(b, nc, pts, np, partial, sg, center, 4, (const float *)S->params, kStateFloats, d1, i1, d2, i2, fma_mode, st) != 1)
                     return 0;
             } else if (nn_forward(b, 2, pts, nc, partial, np, d1, i1, partial, np, pts, nc, d2, i2, st, __builtin_inff(), dup_p, dup_c) != 1) {
                 return 0;
+            }
+            if (probe) {
+                float ms = 0.0f;
+                if (hipEventRecord(ev1, st) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess &&
+                    hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
+                    if (this_seeded) t_seeded = ms;
+                    else t_filter = ms;
+                    use_seeded = t_seeded < t_filter;
+                    if (this_seeded) {
+                        probe_every = use_seeded ? kPoseProbe : 2 * probe_every;
+                        next_probe = it + probe_every;
+                    } else {
+                        probe_every = kPoseProbe;
+                        next_probe = 1;
+                    }
+                }
             }
             hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, st, nc, complete, (const float *)center,
                                4, (const float *)S->params, kStateFloats, np, partial, (const float *)d1,
@@ -1967,6 +2002,8 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
                            best_params);
     else
         hipLaunchKernelGGL(pose_end_kernel, dim3(gb), dim3(64), 0, st, b, S, 1, transform, best_params);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
     return check(hipGetLastError(), "pose_optimize launch") ? 1 : 0;
 }
 

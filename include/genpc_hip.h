@@ -296,9 +296,10 @@ int genpc_pose_loss_grad(int nc, const float *v, const float *vert_col, const fl
 /* Nearest-neighbour path of genpc_pose_optimize_batch, for tests and A/B (applies to the calling host thread): 1 the
  * seeded cell search from the second Adam step on (csrc/nn_seeded.hip: every query starts from last step's answer and
  * searches only the ball it leaves; grids built once per call, the moving cloud's in its rest frame), 0 the brute-force
- * filter at every step (the default: on real shapes three of the four starts are misaligned, most of their queries
- * have no near target and the seeded search loses), < 0 the default / environment GENPC_POSE_SEEDED.  Same bits either
- * way.  Returns the previous setting. */
+ * filter at every step (on real shapes three of the four starts are misaligned, most of their queries have no near
+ * target and the seeded search loses), 2 measure both during the call and take the faster one (the default: a few
+ * hipEventSynchronize per call on the call's stream), < 0 the default / environment GENPC_POSE_SEEDED.  Same bits in
+ * every mode.  Returns the previous setting. */
 int genpc_pose_tune(int seeded);
 
 /* object_pose_optimization's loop with the FULL objective for B scans in lock-step: as

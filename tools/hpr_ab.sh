@@ -1,3 +1,7 @@
-bash tools/ktrace_any.sh c2scan tools/prof_c2_scan.py
-tail -2 gpurun_out/kt_c2scan/t.log | head -1
-grep "one scan" gpurun_out/kt_c2scan/t.log
+python -m pytest tests/test_gpu_determinism.py tests/test_gpu_pipeline.py tests/test_gpu_waymo_c4.py tests/test_gpu_geometry.py tests/test_gpu_stage2_files.py -x -q 2>&1 | tail -3
+python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+for k,v in d.get('extra',{}).items():
+    if any(s in k for s in ('c2_pipeline','registration','c5_rank')) and not isinstance(v,dict): print(k,v)
+"
