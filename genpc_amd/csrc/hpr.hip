@@ -1487,6 +1487,7 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                     pass = cuts;
                 }
                 unsigned long long mask = __ballot(pass);
+                bool clipped = false;
                 while (mask && nv > 0) {
                     const int from = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
@@ -1513,8 +1514,12 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                     if (m < 3) { nv = 0; break; }
                     nv = m;
                     cur ^= 1;
-                    R = hpr_reach_wave(s_buf[cur], nv, lane);
+                    clipped = true;
                 }
+                // (the reach bounds only feed conservative rejections, and a clip only shrinks the polygon: refreshed once
+                // per 64 candidates instead of after every clip -- half the instructions of a clip; the slowest walker,
+                // 1400 clips, is what the launch waits for)
+                if (clipped && nv > 0) R = hpr_reach_wave(s_buf[cur], nv, lane);
             }
     };
     bool lp_ran = false;
@@ -1601,6 +1606,9 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
         }
     }
     const int own = hpr_base_tile(hl, hardcnt[view], rank);
+    [[maybe_unused]] const unsigned long long walk_t0 = HPR_PROF_CLOCK();
+    [[maybe_unused]] const int walk_nv0 = nv;
+    [[maybe_unused]] const double walk_d2 = R.d2;
     for (int step0 = 0, bsz = 1; step0 < 2 * ntiles && nv > 0; step0 += bsz, bsz = step0 < kWave ? step0 : kWave) {
         bool need = false;
         if (lane < bsz) {
@@ -1616,6 +1624,17 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
             take_tile(hpr_tile_of(step0 + b, own), 0);
         }
     }
+#ifdef GENPC_HPR_PROF
+    if (lane == 0 && walk_nv0 > 0) {
+        const unsigned long long dt = HPR_PROF_CLOCK() - walk_t0;
+        atomicAdd(&g_hpr_prof[10], 1ull);                       // walkers
+        atomicAdd(&g_hpr_prof[11], dt);                         // their ticks
+        atomicMax(&g_hpr_prof[12], dt);                         // the slowest
+        if (dt > 200000ull) atomicAdd(&g_hpr_prof[13], 1ull);   // walkers over 100 us
+        if (walk_d2 > 1.0e6) { atomicAdd(&g_hpr_prof[14], 1ull); atomicAdd(&g_hpr_prof[15], dt); }      // open polygons: count, ticks
+        if (dt > 200000ull && nv > 0) atomicAdd(&g_hpr_prof[9], 1ull);      // slow walkers that end visible
+    }
+#endif
     if (failed) return;
     if (lane == 0) {
         vis[(size_t)view * n + i] = nv > 0 ? 1 : 0;

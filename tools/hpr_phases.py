@@ -43,3 +43,5 @@ for name, pts in (("blob", blob), ("scan partial 0", torch.from_numpy(g["partial
     print("%s: %d waves; ticks per wave: home tiles %.0f, verify %.0f, park %.0f; per wave: marking rounds x lanes %.1f, marked candidates "
           "%.1f (per lane-round %.1f), clip-loop trips %.1f (max over lanes), %.1f summed over lanes"
           % (name, w, t[0] / w, t[1] / w, t[2] / w, t[4] / w, t[7] / w, t[7] / max(t[4], 1), t[5] / w, t[6] / w))
+    print("   wave-per-point walk: %d walkers, %.0f ticks each on average, slowest %.0f, %d over 200 k ticks (%d of them end visible); "
+          "open polygons (a vertex beyond 1000): %d walkers, %.0f ticks each" % (t[10], t[11] / max(t[10], 1), t[12], t[13], t[9], t[14], t[15] / max(t[14], 1)))
