@@ -133,6 +133,6 @@ struct SeededGrids {
 size_t seeded_grids_bytes(int b, int nm, int ns);
 int build_seeded_grids(int b, int nm, const float *rest_pts, int ns, const float *static_pts, void *ws, SeededGrids &g, hipStream_t st);
 int launch_nn_seeded(int b, int nm, const float *moving_pts, int ns, const float *static_pts, const SeededGrids &g, const float *center,
-                     int cstride, const float *params, int pstride, float *d1, int *i1, float *d2, int *i2, int fma, hipStream_t st);
+                     int cstride, const float *params, int pstride, float *d1, int *i1, float *d2, int *i2, int fma, hipStream_t st, int sample = 1);
 
 }  // namespace genpc

@@ -41,6 +41,7 @@ struct SeededDir {
 struct SeededArgs {
     SeededDir d[2];
     int b, cells_max;
+    int sample;                // > 1: only every sample-th block runs (a timing probe of the alignment loop)
     const float *center; int cstride;
     const float *params; int pstride;
 };
@@ -56,7 +57,7 @@ __device__ __forceinline__ int sgrid_cell1(float p, float lo, float inv, int g)
 template <int FMA>
 __global__ __launch_bounds__(kBlock) void nn_seeded_kernel(SeededArgs a)
 {
-    int bid = blockIdx.x;
+    int bid = blockIdx.x * a.sample;
     const int di = bid >= a.d[1].block_begin ? 1 : 0;
     const SeededDir &D = a.d[di];
     bid -= D.block_begin;
@@ -212,10 +213,11 @@ __global__ __launch_bounds__(kBlock) void nn_seeded_kernel(SeededArgs a)
 // One step's bidirectional query.  dir 0: queries `moving_pts` (the posed cloud, nm points) against the static cloud;
 // dir 1: queries the static cloud (ns points) against the posed cloud through its rest-frame grid.
 int launch_nn_seeded(int b, int nm, const float *moving_pts, int ns, const float *static_pts, const SeededGrids &g, const float *center,
-                     int cstride, const float *params, int pstride, float *d1, int *i1, float *d2, int *i2, int fma, hipStream_t st)
+                     int cstride, const float *params, int pstride, float *d1, int *i1, float *d2, int *i2, int fma, hipStream_t st, int sample)
 {
     SeededArgs a{};
     a.b = b; a.cells_max = kEGMaxCells;
+    a.sample = sample > 1 ? sample : 1;
     a.center = center; a.cstride = cstride; a.params = params; a.pstride = pstride;
     SeededDir &A = a.d[0], &B = a.d[1];
     A.q = moving_pts; A.tpos = static_pts; A.sorted = g.sorted_static; A.start = g.start_static; A.hdr = g.hdr_static; A.seed = i1;
@@ -225,8 +227,9 @@ int launch_nn_seeded(int b, int nm, const float *moving_pts, int ns, const float
     const long long blocks0 = (long long)b * ceil_div(nm * kSLPQ, kBlock), blocks1 = (long long)b * ceil_div(ns * kSLPQ, kBlock);
     if (blocks0 + blocks1 > 0x7fffffffLL) { set_error("nn seeded: problem too large for one launch"); return 0; }
     B.block_begin = (int)blocks0;
-    if (fma) hipLaunchKernelGGL((nn_seeded_kernel<1>), dim3((unsigned)(blocks0 + blocks1)), dim3(kBlock), 0, st, a);
-    else hipLaunchKernelGGL((nn_seeded_kernel<0>), dim3((unsigned)(blocks0 + blocks1)), dim3(kBlock), 0, st, a);
+    const unsigned grid = (unsigned)((blocks0 + blocks1 + a.sample - 1) / a.sample);
+    if (fma) hipLaunchKernelGGL((nn_seeded_kernel<1>), dim3(grid), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((nn_seeded_kernel<0>), dim3(grid), dim3(kBlock), 0, st, a);
     return check(hipGetLastError(), "nn_seeded_kernel launch") ? 1 : 0;
 }
 

@@ -1936,6 +1936,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     float t_filter = 0.0f, t_seeded = __builtin_inff();
     bool use_seeded = seed_mode == 1;
     int probe_every = kPoseProbe, next_probe = 1;          // (a probe that loses doubles the distance to the next one)
+    // (sequential starts: every start probes afresh)
     SeededGrids sg{};
     if (seeded) {
         void *gw = workspace(29, seeded_grids_bytes(b, nc, np), st);
@@ -1952,6 +1953,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     const int g_t = lin_grid(nc), g_g = std::min(env_gb > 0 ? env_gb : (b >= 16 ? 24 : 1024), lin_grid((long long)nc + np));
     const int hstride = starts * (iters + 1);
     for (int s = 0; s < starts; s++) {
+        if (adaptive) { probe_every = kPoseProbe; next_probe = 1; use_seeded = false; t_seeded = __builtin_inff(); }
         hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, s, lock);
         for (int it = 0; it <= iters; it++) {
             if (mask)
@@ -1961,9 +1963,22 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
             else
                 hipLaunchKernelGGL(pose_transform_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
                                    (const float *)center, 4, (const float *)S->params, kStateFloats, pts);
-            const bool probe = adaptive && (it == 0 || it == next_probe);      // it 0: the filter; 1, 26, 51 ...: the seeded search
-            const bool this_seeded = seeded && it > 0 && (probe || use_seeded);
+            // steps 0 and 2 time the filter (the first one carries the call's one-off costs: the smaller of the two counts),
+            // step 1 and then every probe_every-th the seeded search
+            const bool probe_f = adaptive && (it == 0 || it == 2);
+            const bool probe_s = adaptive && it == next_probe && !probe_f;
+            const bool probe = probe_f || probe_s;
+            // A probe of the seeded search while the filter is in use runs on every kPoseSample-th block only, in front of
+            // the filter (which then answers the step, same bits): on a misaligned start of a real scan a full seeded step
+            // costs a millisecond against the filter's 16 us, and three such probes were 5 % of a completed scan.
+            constexpr int kPoseSample = 4;
+            const bool sampled = probe_s && !use_seeded;
+            const bool this_seeded = seeded && it > 0 && !probe_f && use_seeded;
             if (probe) (void)hipEventRecord(ev0, st);
+            if (sampled && launch_nn_seeded(b, nc, pts, np, partial, sg, center, 4, (const float *)S->params, kStateFloats, d1, i1, d2, i2,
+                                            fma_mode, st, kPoseSample) != 1)
+                return 0;
+            if (sampled) (void)hipEventRecord(ev1, st);
             if (this_seeded) {
                 if (launch_nn_seeded(b, nc, pts, np, partial, sg, center, 4, (const float *)S->params, kStateFloats, d1, i1, d2, i2, fma_mode, st) != 1)
                     return 0;
@@ -1972,18 +1987,18 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
             }
             if (probe) {
                 float ms = 0.0f;
-                if (hipEventRecord(ev1, st) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess &&
+                if ((sampled || hipEventRecord(ev1, st) == hipSuccess) && hipEventSynchronize(ev1) == hipSuccess &&
                     hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
-                    if (this_seeded) t_seeded = ms;
-                    else t_filter = ms;
-                    use_seeded = t_seeded < t_filter;
-                    if (this_seeded) {
-                        probe_every = use_seeded ? kPoseProbe : 2 * probe_every;
-                        next_probe = it + probe_every;
+                    if (probe_f) {
+                        t_filter = it == 0 ? ms : (ms < t_filter ? ms : t_filter);
                     } else {
-                        probe_every = kPoseProbe;
-                        next_probe = 1;
+                        t_seeded = sampled ? ms * kPoseSample : ms;      // (a sample's launch overhead counts four times: errs towards the filter)
+                        const bool wins = t_seeded < 0.9f * t_filter;
+                        probe_every = wins ? kPoseProbe : 2 * probe_every;
+                        next_probe = it + probe_every;
                     }
+                    // (the filter is the known quantity: the search must win clearly, and against a clean measurement)
+                    use_seeded = it >= 2 && t_seeded < 0.9f * t_filter;
                 }
             }
             hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, st, nc, complete, (const float *)center,

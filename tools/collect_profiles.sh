@@ -35,4 +35,6 @@ family hpr_2x165546 tools/prof_hpr.py big
 family hpr_1024x10000 tools/prof_hpr1024.py
 family reg_8192_vs_16384 tools/prof_reg.py
 family c2_chain_8192 tools/prof_c2.py
+family c2_chain_8192_scan tools/prof_c2_scan.py
+family reg8_lockstep tools/time_reg8.py
 ls $OUT | head -60

@@ -1,5 +1,8 @@
 """pipeline.complete_scan at BASELINE config 2's shape for rocprofv3.   python3 tools/prof_c2.py"""
 import os, sys
+# (under rocprofv3's kernel tracing every launch costs tens of microseconds more, which biases the alignment loop's own
+#  timing probe towards its single-launch path: the traced run takes the path the untraced run takes)
+os.environ.setdefault("GENPC_POSE_SEEDED", "0")
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
 from genpc_amd import pipeline

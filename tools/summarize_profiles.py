@@ -55,7 +55,9 @@ def counters(d, sub):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-    dst = os.path.join(ROOT, "profiles")
+    # (on the GPU box: `summarize_profiles.py <tag> gpurun_out/profiles_<tag>` next to the collection, then the raw CSVs --
+    # hundreds of MB of kernel traces -- can be deleted there and only the summaries travel back)
+    dst = os.path.join(ROOT, sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     ks = os.path.join(src, "bench", "bench_kernel_stats.csv")
     if os.path.exists(ks):
