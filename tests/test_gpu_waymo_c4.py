@@ -93,7 +93,7 @@ def test_pad_repeated_crops_stay_off_the_exhaustive_pass(env):
     C, P = torch.from_numpy(w["complete"]).cuda(), torch.from_numpy(w["crops"][short]).cuda()
     buf = (ctypes.c_ulonglong * 3)()
     lib.genpc_nn_tune(-1, 512)
-    prev = lib.genpc_pose_tune(0)            # every step through the brute-force filter (the default)
+    prev = lib.genpc_pose_tune(0)            # every step through the brute-force filter (the default measures and picks)
     try:
         lib.genpc_nn_stats(ctypes.cast(buf, ctypes.c_void_p), 1, None)
         T, _, _ = run_loop(env, C, P)
