@@ -15,7 +15,15 @@ the image-to-3D model of the reference, on tensors instead of files.
 
 ``complete_scan`` returns every intermediate product so that tests can check each stage
 against the oracle on the stage's actual input.
+
+Stage 1 and ``reg()`` read the same inputs and nothing of each other (the registration works on coordinates; the
+colours only travel into the fused file), so ``complete_scan`` runs stage 1 on a second HIP stream, driven by a second
+host thread, under the alignment loop: the loop is 1800 small dependent launches that leave most of the chip idle, the
+viewpoint selection is a handful of chip-wide kernels with host round trips of its own.  The library's scratch is keyed
+by stream, its entry points take the stream as an argument, ctypes releases the interpreter lock during a call: the
+two calls share nothing but the inputs.  ``overlap=False`` runs the stages one after the other (same results).
 """
+import threading
 from types import SimpleNamespace
 
 import torch
@@ -43,8 +51,19 @@ def fps_to(xyz, k):
     return torch.cat([xyz, rep], dim=0)
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    # (a high-priority stream for the loop next to it was measured: no difference, 19.5 scans/s either way)
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=key)
+    return _SIDE[key]
+
+
 def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=None, dp=None, metric_points=16384,
-                  fused_points=20000, cd_only_pose=False):
+                  fused_points=20000, cd_only_pose=False, overlap=True):
     """partial_xyz [Np,3]: the observed scan; generated_xyz [Ng,3]: points of the generated shape in
     the generator's frame; generated_img [3,1024,1024]: the image the partial points take their
     colours from.  Returns a dict of every stage's outputs."""
@@ -52,15 +71,46 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
     dp = dp or DepthPrompting(cfg)
     sa = ScaleAdapter(cfg)
     out = {}
-    # ---- stage 1: DepthPrompting.getImage (:100-170) ----
-    g = dp.getDepth(partial_xyz)
+    def stage1():
+        # ---- stage 1: DepthPrompting.getImage (:100-170) ----
+        g = dp.getDepth(partial_xyz)
+        # ---- stage 2, first half: ScaleAdapter.colorPoint (:15-50) ----
+        return g, sa.colorPoint(g["uv"], generated_img)
+
+    def stage2():
+        return reg_xyz.reg(partial_xyz, generated_xyz, generative_model=cfg.generative_model, dataset=cfg.dataset,
+                           cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=True, cd_only_pose=cd_only_pose)
+
+    if overlap and partial_xyz.is_cuda:
+        main = torch.cuda.current_stream(partial_xyz.device)
+        side = _side_stream(partial_xyz.device)
+        side.wait_stream(main)                      # the inputs are the main stream's
+        box = {}
+
+        def run():
+            try:
+                with torch.cuda.device(partial_xyz.device), torch.cuda.stream(side):
+                    box["out"] = stage1()
+            except BaseException as e:              # re-raised on the caller's thread
+                box["err"] = e
+
+        th = threading.Thread(target=run, name="genpc-stage1")
+        th.start()
+        try:
+            res = stage2()
+        finally:
+            th.join()
+        if "err" in box:
+            raise box["err"]
+        main.wait_stream(side)                      # stage 1's products are read on the main stream from here on
+        g, colors = box["out"]
+    else:
+        g, colors = stage1()
+        res = stage2()
     view, uv, depth = g["view_index"], g["uv"][None], g["depth"][None]
     out.update(view=view, used_opposite=g["used_opposite"], visible=g["visible"], uv=g["uv"], depth=g["depth"], pixels=g["pixels"],
                sparse_img=g["sparse_img"], sparse_depth=g["raw_depth"], hole_mask1=g["hole_mask1"], hole_mask2=g["hole_mask2"])
-    # ---- stage 2: ScaleAdapter.scaleAdapter (:15-86) ----
-    out["point_colors"] = sa.colorPoint(uv[0], generated_img)
-    res = reg_xyz.reg(partial_xyz, generated_xyz, generative_model=cfg.generative_model, dataset=cfg.dataset,
-                      cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=True, cd_only_pose=cd_only_pose)
+    out["point_colors"] = colors
     out["reg"] = res
     # the ground truth's metric subsampling (main.py:21) depends on nothing above: it rides along in the fused
     # cloud's FPS launch

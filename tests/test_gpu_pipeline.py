@@ -107,6 +107,29 @@ def test_config2_chain_8192(env, oracle, golden):
     assert m[0] < 0.6 * float(oracle.cd_l1(p1, p2)), (m[0], float(oracle.cd_l1(p1, p2)))
 
 
+def test_stage1_under_the_alignment_loop_changes_nothing(env, golden):
+    """complete_scan runs stage 1 on a second stream / host thread under reg() (pipeline.py); one after the other gives
+    the same bits for every product (three runs of each: a race would show as a difference somewhere)."""
+    torch = env["torch"]
+    partial, gen, img, gt = c2_inputs(golden)
+    Pt, Gt, It, GTt = (torch.from_numpy(x).cuda() for x in (partial, gen, img, gt))
+    ref = env["P"].complete_scan(Pt, Gt, It, GTt, cfg=env["cfg"], dp=env["dp"], overlap=False)
+    keys = ("visible", "uv", "depth", "pixels", "sparse_img", "sparse_depth", "point_colors", "fused", "pred_metric_points")
+    for rep in range(3):
+        for ov in (True, False):
+            out = env["P"].complete_scan(Pt, Gt, It, GTt, cfg=env["cfg"], dp=env["dp"], overlap=ov)
+            assert out["view"] == ref["view"]
+            for k in keys:
+                assert torch.equal(out[k], ref[k]), (k, ov, rep)
+            assert torch.equal(out["reg"]["transformation"], ref["reg"]["transformation"]) if "transformation" in out["reg"] else True
+            assert torch.equal(out["reg"]["source"], ref["reg"]["source"]) and torch.equal(out["reg"]["target"], ref["reg"]["target"])
+            ma, mb = out["metric"], ref["metric"]
+            if isinstance(ma, dict):
+                assert all(torch.equal(torch.as_tensor(ma[k]), torch.as_tensor(mb[k])) for k in mb)
+            else:
+                assert torch.equal(torch.as_tensor(ma), torch.as_tensor(mb))
+
+
 def test_voxel_down_sample_vs_oracle(env, oracle, golden):
     torch = env["torch"]
     g = golden("scans13_fps16384.npz")

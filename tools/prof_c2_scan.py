@@ -1,8 +1,8 @@
 """pipeline.complete_scan on the bundled scan (bench.py's c2_pipeline_8192_scans_per_s input) for rocprofv3.   python3 tools/prof_c2_scan.py"""
-import os, sys
+import os, sys, time
 # (under rocprofv3's kernel tracing every launch costs tens of microseconds more, which biases the alignment loop's own
 #  timing probe towards its single-launch path: the traced run takes the path the untraced run takes)
-os.environ.setdefault("GENPC_POSE_SEEDED", "0"), time
+os.environ.setdefault("GENPC_POSE_SEEDED", "0")
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
