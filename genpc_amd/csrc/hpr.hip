@@ -1167,10 +1167,12 @@ __device__ __forceinline__ HprReach hpr_reach_wave(const double2 *p, int nv, int
 //   hidden: lam s1 + (1 - lam) s2 > m on every vertex of P for some lam in [0, 1] (s_i = a A_i + b B_i - C_i), hence on all
 //     of P (affine).  Every vertex w the walk can still hold once it has taken both candidates satisfies s_i(w) <= eta, eta
 //     = the walk's own rounding: a kept vertex has fl(s_i) <= 0, a crossing is computed on an edge inside P with a position
-//     error of ~1e-16 of the edge's ends, later clips only take convex combinations; eta <= ~12 u M with M = the largest
-//     |a A_i| + |b B_i| + |C_i| over P's vertices (the ends of those edges).  m = 1e-9 M (six orders above eta) therefore
-//     leaves the walk no vertex at all: it ends with the polygon empty, whatever order it takes the candidates in and
-//     whichever of them it skips (it skips only candidates that cut nothing: s_i <= 0 on all its vertices already).
+//     error of ~1e-16 of the edge's ends, later clips only take convex combinations of vertices that carry such errors
+//     already; eta <= (12 + 3 G) u M after G clips, with M = the largest |a A_i| + |b B_i| + |C_i| over P's vertices (the
+//     ends of those edges) and G <= n.  m = (1e-9 + 4e-15 n) M (at least ten times eta for any n, 10^4 times for the
+//     tens of clips a walk really makes) therefore leaves the walk no vertex at all: it ends with the polygon empty,
+//     whatever order it takes the candidates in and whichever of them it skips (it skips only candidates that cut nothing:
+//     s_i <= 0 on all its vertices already).
 constexpr int kHprLpIters = 4;
 constexpr int kHprLpMaxV = 32;         // vertices of P (one per lane in the certificates); scratch polygons: 64
 
@@ -1216,13 +1218,13 @@ __device__ __forceinline__ double hpr_wave_max(double v)
 // does the constraint (A, B, C) alone, or some mix of it with (A1, B1, C1), exclude every vertex of P by the margin?
 // (lane k holds vertex k; nv <= kHprLpMaxV)
 __device__ __forceinline__ bool hpr_excluded(const double2 *P, int nv, bool pair, double A1, double B1, double C1, double A, double B,
-                                             double C, int lane)
+                                             double C, int lane, double margin)
 {
     const bool mine = lane < nv;
     const double2 v = mine ? P[lane] : make_double2(0.0, 0.0);
     const double s2 = v.x * A + v.y * B - C, M2 = fabs(v.x * A) + fabs(v.y * B) + fabs(C);
     const double s1 = pair ? v.x * A1 + v.y * B1 - C1 : 0.0, M1 = pair ? fabs(v.x * A1) + fabs(v.y * B1) + fabs(C1) : 0.0;
-    const double m = 1e-9 * hpr_wave_max(mine ? (M1 > M2 ? M1 : M2) : 0.0);
+    const double m = margin * hpr_wave_max(mine ? (M1 > M2 ? M1 : M2) : 0.0);
     if (!(m < __builtin_inf())) return false;
     if (__ballot(mine && !(s2 > m)) == 0ull) return true;            // the new constraint alone
     if (!pair) return false;
@@ -1249,6 +1251,9 @@ __device__ __forceinline__ bool hpr_excluded(const double2 *P, int nv, bool pair
 __device__ __forceinline__ int hpr_decide(const HprFrame &f, const double2 *P, int nv, double2 *scratch, const double *__restrict__ fl,
                                           int n, int ntiles, const HprTile *__restrict__ tiles, int home, int pos, int no_cull, int lane)
 {
+    // the hidden proof's margin, relative to M (above): the walk's rounding grows with the clips behind a vertex -- a vertex
+    // made by the G-th clip sits on an edge whose ends carry (12 + 3 (G - 1)) u M already -- and G <= n
+    const double margin = 1e-9 + 4e-15 * (double)n;
     const double2 *poly = P;
     int pn = nv, nprev = 0;
     double pA[kHprLpIters], pB[kHprLpIters], pC[kHprLpIters];
@@ -1309,7 +1314,7 @@ __device__ __forceinline__ int hpr_decide(const HprFrame &f, const double2 *P, i
                     smin = sk < smin ? sk : smin;
                     mmax = mk > mmax ? mk : mmax;
                 }
-                excl = mmax < __builtin_inf() && smin > 1e-9 * mmax;
+                excl = mmax < __builtin_inf() && smin > margin * mmax;
             }
             return __ballot(excl) != 0ull;
         };
@@ -1343,10 +1348,10 @@ __device__ __forceinline__ int hpr_decide(const HprFrame &f, const double2 *P, i
         if (bkey < 0.0) return 1;                 // c is strictly feasible: visible
         const int owner = __ffsll((long long)__ballot(kj == bj && key == bkey)) - 1;
         const double A = __shfl(kA, owner, kWave), B = __shfl(kB, owner, kWave), C = __shfl(kC, owner, kWave);
-        bool hidden = hpr_excluded(P, nv, false, 0.0, 0.0, 0.0, A, B, C, lane);
+        bool hidden = hpr_excluded(P, nv, false, 0.0, 0.0, 0.0, A, B, C, lane, margin);
 #pragma unroll
         for (int q = kHprLpIters - 2; q >= 0; q--)
-            if (q < nprev && !hidden) hidden = hpr_excluded(P, nv, true, pA[q], pB[q], pC[q], A, B, C, lane);
+            if (q < nprev && !hidden) hidden = hpr_excluded(P, nv, true, pA[q], pB[q], pC[q], A, B, C, lane, margin);
         if (hidden) return 2;
         if (it + 1 == kHprLpIters) break;
         double2 *dst = scratch + (it & 1) * 64;
