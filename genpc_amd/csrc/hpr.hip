@@ -1290,9 +1290,10 @@ __device__ __forceinline__ int hpr_decide(const HprFrame &f, const double2 *P, i
 #pragma unroll
             for (int e = 0; e < 2 * kPer; e++) {
                 const double qx = q[e][0], qy = q[e][1], qz = q[e][2];
-                const double sv = (nx * qx + ny * qy + nz * qz) - f.rho;
-                const bool self = qx == f.px && qy == f.py && qz == f.pz;
-                if (jj[e] >= 0 && !self && sv > -thr) {           // (NaN rows: false)
+                // (a sieve with the verify margin behind it: fused multiply-adds, and the point itself recognised by its
+                // position -- what passes is valued below with the walk's own operations)
+                const double sv = __builtin_fma(nz, qz, __builtin_fma(ny, qy, nx * qx)) - f.rho;
+                if (jj[e] >= 0 && jj[e] != pos && sv > -thr) {           // (NaN rows: false)
                     const double A = f.e1x * qx + f.e1y * qy + f.e1z * qz;
                     const double B = f.e2x * qx + f.e2y * qy + f.e2z * qz;
                     const double l2 = A * A + B * B;
