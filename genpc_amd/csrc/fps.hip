@@ -158,7 +158,11 @@ constexpr unsigned kProgDone = 0x8000u, kProgFinal = 0x4000u, kProgAbort = 0x200
 // waits for the wave's outstanding GLOBAL stores: ~500 cycles per pick next to the 16-byte publishes).
 __device__ __forceinline__ void prog_store(unsigned *p, unsigned v)
 {
-    asm volatile("" ::: "memory");
+    // The pivots are 16-byte LDS writes, the word a 4-byte one: the wave's earlier LDS writes are PERFORMED before the word is
+    // issued (lgkmcnt counts LDS operations only: ~60 cycles, no global store is waited for).  Belt and braces -- the
+    // failure that prompted it (round 4: a sampling next to the f16 nearest-neighbour filter on another stream drew a sample
+    // too early, silently) turned out to sit on the readers' side: see the workers' pivot reads.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
 }
@@ -224,7 +228,18 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
                 if ((pr >> 16) != (round & 0xffffu)) { __builtin_amdgcn_s_sleep(1); continue; }
                 const unsigned avail = pr & kProgCount;
                 for (; applied < avail; applied++) {
-                    const float cx = s_piv[applied][0], cy = s_piv[applied][1], cz = s_piv[applied][2];
+                    // The pivot travels through SCALAR registers (first lane's copy).  As plain per-lane reads of the one LDS
+                    // address (ds_read_b96 into VGPRs, consumed by packed fp32 ops right behind the wait) the lanes 48-63 of a
+                    // worker wave were seen to use the PREVIOUS pivot now and then while another stream's kernel issued
+                    // v_mfma_f32_32x32x16_f16 on the same SIMD -- one stale running minimum, one sample drawn a step early, the
+                    // rest of the sequence shifted by one, no error (tools/stress_concurrent.py: every run with the f16
+                    // filter or tools/burn.hip's bare MFMA loop next to it, never alone, never next to fp32 MFMA / LDS / VALU
+                    // loads; all extra samples were points held by lanes 48-63).  The mechanism is not established (an isolated
+                    // probe of broadcast reads + packed adds under the same load, tools/lds_probe.hip, shows nothing); with the
+                    // value in SGPRs nine of nine stress runs are clean.  tests/test_gpu_concurrency.py keeps watch.
+                    const float cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_piv[applied][0])));
+                    const float cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_piv[applied][1])));
+                    const float cz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_piv[applied][2])));
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         const float dd = sqdist_f<FMA>(px[r] - cx, py[r] - cy, pz[r] - cz);

@@ -8,6 +8,10 @@ from . import _lib
 
 _L = _lib.lib
 _p = _lib.ptr
+# A/B switch (tools/time_c2_lanes.py): one sampling launch at a time in the process, whatever threads / streams call
+import os as _os
+import threading as _threading
+_ONE_AT_A_TIME = _threading.Lock() if _os.environ.get("GENPC_FPS_LOCK", "0") == "1" else None
 
 
 def fps_sampling(points, k):
@@ -50,8 +54,14 @@ def fps_sampling_multi(clouds, ks):
     k_arr = (ctypes.c_int * c)(*[int(k) for k in ks])
     x_arr = (ctypes.c_void_p * c)(*[p.data_ptr() for p in pts])
     o_arr = (ctypes.c_void_p * c)(*[o.data_ptr() for o in outs])
-    rc = _lib.on_device_of(pts[0], _L.genpc_fps_multi, c, ctypes.addressof(n_arr), ctypes.addressof(k_arr),
-                           ctypes.addressof(x_arr), ctypes.addressof(o_arr))
+    if _ONE_AT_A_TIME is not None:
+        with _ONE_AT_A_TIME:
+            rc = _lib.on_device_of(pts[0], _L.genpc_fps_multi, c, ctypes.addressof(n_arr), ctypes.addressof(k_arr),
+                                   ctypes.addressof(x_arr), ctypes.addressof(o_arr))
+            torch.cuda.current_stream(dev).synchronize()
+    else:
+        rc = _lib.on_device_of(pts[0], _L.genpc_fps_multi, c, ctypes.addressof(n_arr), ctypes.addressof(k_arr),
+                               ctypes.addressof(x_arr), ctypes.addressof(o_arr))
     if rc == -1:
         raise ValueError("fps_sampling_multi: need 0 < k <= N <= 262144 for every cloud")
     if rc != 1:

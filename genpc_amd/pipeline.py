@@ -52,15 +52,23 @@ def fps_to(xyz, k):
 
 
 _SIDE = {}
+_NO_OVERLAP = __import__("os").environ.get("GENPC_C2_NO_OVERLAP", "0") == "1"      # A/B switch
 
 
-def _side_stream(device):
+_SIDE_LOCK = threading.Lock()
+
+
+def _side_stream(device, main):
+    """Stage 1's stream for the scan whose other stages run on `main` (one per main stream: several scans in flight,
+    complete_scans below, must not share it)."""
     # (measured next to it: a high-priority stream for the loop -- no difference, 19.5 scans/s either way; stage 1's stream
     #  confined to three quarters of the CUs with hipExtStreamCreateWithCUMask -- 15.4)
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=key)
-    return _SIDE[key]
+    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (dev, main.cuda_stream)
+    with _SIDE_LOCK:
+        if key not in _SIDE:
+            _SIDE[key] = torch.cuda.Stream(device=dev)
+        return _SIDE[key]
 
 
 def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=None, dp=None, metric_points=16384,
@@ -82,9 +90,9 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
         return reg_xyz.reg(partial_xyz, generated_xyz, generative_model=cfg.generative_model, dataset=cfg.dataset,
                            cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=True, cd_only_pose=cd_only_pose)
 
-    if overlap and partial_xyz.is_cuda:
+    if overlap and partial_xyz.is_cuda and not _NO_OVERLAP:
         main = torch.cuda.current_stream(partial_xyz.device)
-        side = _side_stream(partial_xyz.device)
+        side = _side_stream(partial_xyz.device, main)
         side.wait_stream(main)                      # the inputs are the main stream's
         box = {}
 
@@ -129,3 +137,52 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
         out["gt_metric_points"] = gt
         out["metric"] = evaluate_scans(pred[None].contiguous(), gt[None].contiguous())[0]
     return out
+
+
+def complete_scans(jobs, lanes=2, cfg=None, dps=None, **kw):
+    """Completed scans per second is a throughput: the stages of ONE scan are chains of small dependent launches, two
+    sequential farthest-point samplings and a few chip-wide kernels with host round trips in between -- most of the chip
+    idles most of the time -- and independent scans share nothing (BASELINE north_star: "independent scans shard
+    embarrassingly").  This runs `lanes` scans at a time on one GPU: a host thread, a stream pair and a DepthPrompting
+    object per lane (the library's scratch is keyed by stream; ctypes releases the interpreter lock during a call).
+
+    jobs: sequence of (partial_xyz, generated_xyz, generated_img, gt_xyz) -> list of complete_scan's dicts, in order; every
+    scan's products are the bits a call of complete_scan gives (tests/test_gpu_pipeline.py).  dps: one DepthPrompting per
+    lane to reuse between calls (built here otherwise)."""
+    jobs = list(jobs)
+    if not jobs:
+        return []
+    dev = jobs[0][0].device
+    cfg = cfg or default_cfg(dev)
+    lanes = max(1, min(int(lanes), len(jobs), 4))      # (throughput peaks at four; see DESIGN 6a)
+    caller = torch.cuda.current_stream(dev)
+    results, errors = [None] * len(jobs), []
+    nxt = [0]
+    lock = threading.Lock()
+
+    def lane(li):
+        try:
+            with torch.cuda.device(dev):
+                st = torch.cuda.Stream(device=dev)
+                st.wait_stream(caller)                  # the inputs are the caller's
+                dp = dps[li] if dps else DepthPrompting(cfg)
+                with torch.cuda.stream(st):
+                    while True:
+                        with lock:
+                            k = nxt[0]
+                            nxt[0] += 1
+                        if k >= len(jobs) or errors:
+                            break
+                        results[k] = complete_scan(*jobs[k], cfg=cfg, dp=dp, **kw)
+                st.synchronize()                        # (the lane's products are complete when its thread ends)
+        except BaseException as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=lane, args=(i,), name="genpc-lane-%d" % i) for i in range(lanes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results

@@ -130,6 +130,35 @@ def test_stage1_under_the_alignment_loop_changes_nothing(env, golden):
                 assert torch.equal(torch.as_tensor(ma), torch.as_tensor(mb))
 
 
+def test_scans_in_flight_side_by_side_change_nothing(env, golden):
+    """pipeline.complete_scans: several scans at a time on one GPU (a host thread and a stream pair per lane); every scan's
+    products are the bits of a call of complete_scan on its own."""
+    torch = env["torch"]
+    partial, gen, img, gt = c2_inputs(golden)
+    Pt, Gt, It, GTt = (torch.from_numpy(x).cuda() for x in (partial, gen, img, gt))
+    # a second, different scan: the same shape seen mirrored (different view, different registration)
+    P2 = (Pt * torch.tensor([1.0, -1.0, 1.0], device="cuda")).contiguous()
+    G2 = (Gt * torch.tensor([1.0, -1.0, 1.0], device="cuda")).contiguous()
+    GT2 = (GTt * torch.tensor([1.0, -1.0, 1.0], device="cuda")).contiguous()
+    jobs = [(Pt, Gt, It, GTt), (P2, G2, It, GT2)] * 3
+    ref = [env["P"].complete_scan(*j, cfg=env["cfg"], dp=env["dp"], overlap=False) for j in jobs[:2]]
+    keys = ("visible", "uv", "depth", "point_colors", "fused", "pred_metric_points")
+    for lanes in (2, 3):
+        outs = env["P"].complete_scans(jobs, lanes=lanes, cfg=env["cfg"])
+        assert len(outs) == len(jobs)
+        for k, out in enumerate(outs):
+            r = ref[k % 2]
+            assert out["view"] == r["view"]
+            for key in keys:
+                assert torch.equal(out[key], r[key]), (key, k, lanes)
+            assert torch.equal(out["reg"]["source"], r["reg"]["source"]) and torch.equal(out["reg"]["target"], r["reg"]["target"])
+            ma, mb = out["metric"], r["metric"]
+            if isinstance(ma, dict):
+                assert all(torch.equal(torch.as_tensor(ma[q]), torch.as_tensor(mb[q])) for q in mb)
+            else:
+                assert torch.equal(torch.as_tensor(ma), torch.as_tensor(mb))
+
+
 def test_voxel_down_sample_vs_oracle(env, oracle, golden):
     torch = env["torch"]
     g = golden("scans13_fps16384.npz")

@@ -1,0 +1,125 @@
+"""Entry points called from several host threads on streams of their own: every result must equal the single-threaded one.
+    python3 tools/stress_concurrent.py [threads] [reps]"""
+import os, sys, threading
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from types import SimpleNamespace
+from genpc_amd.fps import fps_sampling, fps_sampling_multi
+from genpc_amd.metric import evaluate_scans
+from genpc_amd.DepthPrompting import DepthPrompting
+from genpc_amd import chamfer_3D
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+z = np.load(os.path.join(ROOT, "tests", "golden", "scans13_fps16384.npz"))
+cfg = SimpleNamespace(device="cuda", fovy=49.1, res=256, cam_res=256, padding=0.15, rescale=True, point_size=1,
+                      mask_pixel_rate=3, view_num=256, distance=1.6, downsample_num=10000, removal_radius=10000)
+
+
+def ops(k):
+    P = torch.from_numpy(z["partial"][k].copy()).cuda()
+    G = torch.from_numpy(z["gt"][k].copy()).cuda()
+    dp = DepthPrompting(cfg)
+
+    def fps():
+        a, b = fps_sampling_multi([torch.cat([P, G[:8192]]).contiguous(), G], [20000, 16384])
+        return torch.cat([a.float(), b.float()])
+
+    def fps1():
+        return fps_sampling(P, 12000).float()
+
+    def emd():
+        return torch.as_tensor(evaluate_scans(P[None].contiguous(), G[None].contiguous())[0]).float().cuda()
+
+    def hpr():
+        vis, cnt, _ = dp.hidden_point_removal(P[:8192].contiguous(), dp.viewpoints, 10000.0, best_only=True)
+        return cnt.float()
+
+    def nn():
+        d1 = torch.empty(1, 16384, device="cuda"); d2 = torch.empty_like(d1)
+        i1 = torch.empty(1, 16384, device="cuda", dtype=torch.int32); i2 = torch.empty_like(i1)
+        chamfer_3D.forward(P[None].contiguous(), G[None].contiguous(), d1, d2, i1, i2)
+        return torch.cat([d1.flatten(), i1.flatten().float(), d2.flatten(), i2.flatten().float()])
+
+    A = torch.rand(4096, 4096, device="cuda")
+    import ctypes
+    burnlib = ctypes.CDLL(os.path.join(ROOT, "tools", "_burn", "libburn.so")) if os.path.exists(os.path.join(ROOT, "tools", "_burn", "libburn.so")) else None
+    scratch = torch.zeros(4, device="cuda")
+
+    def burner(kind):
+        def f():
+            for _ in range(40):
+                burnlib.burn(kind, 400, 256, ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            return torch.zeros(1, device="cuda")
+        return f
+
+    def mm():
+        for _ in range(4):
+            B = A @ A
+        return torch.zeros(1, device="cuda")
+
+    def fill():
+        for _ in range(50):
+            x = torch.empty(1 << 22, device="cuda").fill_(1.0)
+        return torch.zeros(1, device="cuda")
+
+    def sleepy():
+        torch.cuda._sleep(20000000)
+        return torch.zeros(1, device="cuda")
+
+    extra = {("burn_%d" % k): burner(k) for k in (1, 2, 4, 8, 3, 5, 6, 7, 15, 10, 12)} if burnlib else {}
+    return {**extra, "torch_mm": mm, "torch_fill": fill, "torch_sleep": sleepy, "fps_multi": fps, "fps": fps1, "metric_cd_emd": emd, "hpr_best_view": hpr, "chamfer": nn}
+
+
+names = [n for n in ops(0) if not n.startswith("torch_") and not n.startswith("burn_")]
+allnames = list(ops(0))
+ref = {}
+for k in range(T):
+    o = ops(k)
+    for n in allnames:
+        ref[(k, n)] = o[n]().clone()
+torch.cuda.synchronize()
+for n in names:
+    bad = []
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream()
+            o = ops(k)
+            with torch.cuda.stream(st):
+                for _ in range(REPS):
+                    r = o[n]()
+                    st.synchronize()
+                    if not torch.equal(r, ref[(k, n)]):
+                        bad.append((k, int((r != ref[(k, n)]).sum())))
+        except BaseException as e:
+            bad.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(T)]
+    [t.start() for t in th]; [t.join() for t in th]
+    print("%-14s %d threads x %d calls: %s" % (n, T, REPS, "same as single-threaded" if not bad else "DIFFERENT %s" % bad[:6]), flush=True)
+
+# mixed: every thread a different entry point, all at once
+print("mixed:", flush=True)
+bad = []
+def work2(k, n):
+    try:
+        st = torch.cuda.Stream()
+        o = ops(k)
+        with torch.cuda.stream(st):
+            for _ in range(REPS * 3):
+                r = o[n]()
+                st.synchronize()
+                if not torch.equal(r, ref[(k, n)]):
+                    d = (r != ref[(k, n)]).nonzero().flatten()
+                    bad.append((n, k, int(len(d)), "first diff at", int(d[0]), "got", r[d[0]:d[0] + 4].tolist(), "want", ref[(k, n)][d[0]:d[0] + 4].tolist(),
+                                "unique", int(torch.unique(r[:20000]).numel()), "min", float(r.min()), "max", float(r.max())))
+    except BaseException as e:
+        bad.append((n, k, repr(e)))
+for other in [n for n in allnames if n.startswith("burn_")] + ["chamfer"]:
+    bad.clear()
+    pair = ["fps_multi", other, "fps_multi", other]
+    th = [threading.Thread(target=work2, args=(i % T, n)) for i, n in enumerate(pair)]
+    [t.start() for t in th]; [t.join() for t in th]
+    print("fps_multi x2 + %s x2: %s" % (other, "same as single-threaded" if not bad else "DIFFERENT %s" % bad[:10]), flush=True)
