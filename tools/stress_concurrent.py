@@ -69,10 +69,25 @@ def ops(k):
         return torch.zeros(1, device="cuda")
 
     extra = {("burn_%d" % k): burner(k) for k in (1, 2, 4, 8, 3, 5, 6, 7, 15, 10, 12)} if burnlib else {}
+    from genpc_amd.optim_registration.diff_obj_pose import object_pose_optimization
+    from genpc_amd import reg_xyz
+
+    def pose():
+        T = object_pose_optimization(G[None, :8192].contiguous(), (P[None, :4096] * 0.9).contiguous(), radius=0.02, lr=0.01, iters=30, render_size=224)
+        return torch.as_tensor(T).float().flatten().cuda() if not isinstance(T, (tuple, list)) else torch.cat([torch.as_tensor(x).float().flatten().cuda() for x in T if torch.is_tensor(x)])
+
+    def fuse():
+        f = reg_xyz.fuse(P[:8192].contiguous(), G, num_points=12000)
+        return (f[0] if isinstance(f, tuple) else f).float().flatten()
+
+    extra["pose_loop"] = pose
+    extra["fuse_tail"] = fuse
     return {**extra, "torch_mm": mm, "torch_fill": fill, "torch_sleep": sleepy, "fps_multi": fps, "fps": fps1, "metric_cd_emd": emd, "hpr_best_view": hpr, "chamfer": nn}
 
 
 names = [n for n in ops(0) if not n.startswith("torch_") and not n.startswith("burn_")]
+if os.environ.get("STRESS_SOAK", "0") == "1":
+    names = []
 allnames = list(ops(0))
 ref = {}
 for k in range(T):
@@ -117,6 +132,15 @@ def work2(k, n):
                                 "unique", int(torch.unique(r[:20000]).numel()), "min", float(r.min()), "max", float(r.max())))
     except BaseException as e:
         bad.append((n, k, repr(e)))
+SOAK = os.environ.get("STRESS_SOAK", "0") == "1"
+if SOAK:
+    # every entry point next to the one load known to disturb (bare f16 MFMAs on other streams), many repetitions
+    for n in [x for x in allnames if not x.startswith("burn_") and not x.startswith("torch_")]:
+        bad.clear()
+        th = [threading.Thread(target=work2, args=(i % T, nn_)) for i, nn_ in enumerate([n, "burn_1", n, "burn_1", "chamfer"])]
+        [t.start() for t in th]; [t.join() for t in th]
+        print("soak %-14s x2 + burn_1 x2 + chamfer: %s" % (n, "same as single-threaded" if not bad else "DIFFERENT %s" % bad[:4]), flush=True)
+    sys.exit(0)
 for other in [n for n in allnames if n.startswith("burn_")] + ["chamfer"]:
     bad.clear()
     pair = ["fps_multi", other, "fps_multi", other]
