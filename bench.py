@@ -393,16 +393,18 @@ def extras(A, B, n, dev, stream):
             pipeline.complete_scan(a_part, a_gen, img, a_gt, cfg=cfg2, dp=dp2)
         torch.cuda.synchronize()
         extra[name] = round(2.0 / (time.perf_counter() - t0), 3)
-    # completed scans per second is a throughput: four independent scans in flight on the one GPU (pipeline.complete_scans:
+    # completed scans per second is a throughput: six independent scans in flight on the one GPU (pipeline.complete_scans:
     # a host thread and a stream pair per lane; every scan's products are the bits of a call of its own)
-    jobs4 = [(part_s, gen_s, img, gt_s)] * 16
-    dps4 = [DepthPrompting(cfg2) for _ in range(4)]
-    pipeline.complete_scans(jobs4[:4], lanes=4, cfg=cfg2, dps=dps4)
+    lanes_c2 = 6
+    jobs_c2 = [(part_s, gen_s, img, gt_s)] * (4 * lanes_c2)
+    dps_c2 = [DepthPrompting(cfg2) for _ in range(lanes_c2)]
+    pipeline.complete_scans(jobs_c2[:lanes_c2], lanes=lanes_c2, cfg=cfg2, dps=dps_c2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pipeline.complete_scans(jobs4, lanes=4, cfg=cfg2, dps=dps4)
+    pipeline.complete_scans(jobs_c2, lanes=lanes_c2, cfg=cfg2, dps=dps_c2)
     torch.cuda.synchronize()
-    extra["c2_pipeline_8192_4_scans_in_flight_scans_per_s"] = round(len(jobs4) / (time.perf_counter() - t0), 3)
+    extra["c2_pipeline_8192_scans_in_flight"] = lanes_c2
+    extra["c2_pipeline_8192_scans_in_flight_scans_per_s"] = round(len(jobs_c2) / (time.perf_counter() - t0), 3)
     # BASELINE config 5 per-rank shape: 8 scans x 32768 points in lock-step, full objective + metric
     sc = sc5
     C5 = torch.from_numpy(np.stack([x[0] for x in sc])).to(dev)

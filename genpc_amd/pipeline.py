@@ -52,10 +52,22 @@ def fps_to(xyz, k):
 
 
 _SIDE = {}
+_LANE = {}
 _NO_OVERLAP = __import__("os").environ.get("GENPC_C2_NO_OVERLAP", "0") == "1"      # A/B switch
 
 
 _SIDE_LOCK = threading.Lock()
+
+
+def _fresh_stream(dev, avoid=()):
+    """A stream that is none of ours and none of `avoid` (torch deals streams from a pool of 32 per device, round-robin: a
+    new Stream() can BE an old one; two host threads driving one stream would share the library's per-stream scratch)."""
+    taken = {s.cuda_stream for s in list(_SIDE.values()) + list(_LANE.values())} | {int(a) for a in avoid}
+    for _ in range(64):
+        st = torch.cuda.Stream(device=dev)
+        if st.cuda_stream not in taken:
+            return st
+    raise RuntimeError("genpc_amd.pipeline: no unused stream left in torch's pool")
 
 
 def _side_stream(device, main):
@@ -67,7 +79,7 @@ def _side_stream(device, main):
     key = (dev, main.cuda_stream)
     with _SIDE_LOCK:
         if key not in _SIDE:
-            _SIDE[key] = torch.cuda.Stream(device=dev)
+            _SIDE[key] = _fresh_stream(dev, avoid=(main.cuda_stream,))
         return _SIDE[key]
 
 
@@ -90,9 +102,13 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
         return reg_xyz.reg(partial_xyz, generated_xyz, generative_model=cfg.generative_model, dataset=cfg.dataset,
                            cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=True, cd_only_pose=cd_only_pose)
 
+    main = side = None
     if overlap and partial_xyz.is_cuda and not _NO_OVERLAP:
         main = torch.cuda.current_stream(partial_xyz.device)
         side = _side_stream(partial_xyz.device, main)
+        if side.cuda_stream == main.cuda_stream:        # (torch's stream pool wrapped around onto the caller's stream)
+            side = None
+    if side is not None:
         side.wait_stream(main)                      # the inputs are the main stream's
         box = {}
 
@@ -139,6 +155,17 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
     return out
 
 
+def _lane_stream(device, li):
+    """Lane li's stream, made once: torch hands out streams from a pool of 32 per device and wraps around, so a stream made
+    per call would sooner or later BE another lane's stage-1 stream -- two host threads on one stream share the library's
+    scratch (that is what the memory access fault of a six-lane run after a sweep of lane counts was)."""
+    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    with _SIDE_LOCK:
+        if (dev, li) not in _LANE:
+            _LANE[(dev, li)] = _fresh_stream(dev)
+        return _LANE[(dev, li)]
+
+
 def complete_scans(jobs, lanes=2, cfg=None, dps=None, **kw):
     """Completed scans per second is a throughput: the stages of ONE scan are chains of small dependent launches, two
     sequential farthest-point samplings and a few chip-wide kernels with host round trips in between -- most of the chip
@@ -154,7 +181,7 @@ def complete_scans(jobs, lanes=2, cfg=None, dps=None, **kw):
         return []
     dev = jobs[0][0].device
     cfg = cfg or default_cfg(dev)
-    lanes = max(1, min(int(lanes), len(jobs), 4))      # (throughput peaks at four)
+    lanes = max(1, min(int(lanes), len(jobs), 8))      # (throughput peaks at four to six)
     caller = torch.cuda.current_stream(dev)
     results, errors = [None] * len(jobs), []
     nxt = [0]
@@ -163,7 +190,7 @@ def complete_scans(jobs, lanes=2, cfg=None, dps=None, **kw):
     def lane(li):
         try:
             with torch.cuda.device(dev):
-                st = torch.cuda.Stream(device=dev)
+                st = _lane_stream(dev, li)
                 st.wait_stream(caller)                  # the inputs are the caller's
                 dp = dps[li] if dps else DepthPrompting(cfg)
                 with torch.cuda.stream(st):
