@@ -247,6 +247,14 @@ def extras(A, B, n, dev, stream):
         scan()
     torch.cuda.synchronize()
     extra["registration_8k_vs_16k_4x201_plus_metric_scans_per_s"] = round(3.0 / (time.perf_counter() - t0), 3)
+    # ... six such single-scan registrations in flight side by side (independent scans; pipeline.run_in_lanes)
+    from genpc_amd import pipeline as _pl1
+    _pl1.run_in_lanes(lambda li, _: scan(), range(6), 6, dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _pl1.run_in_lanes(lambda li, _: scan(), range(18), 6, dev)
+    torch.cuda.synchronize()
+    extra["registration_8k_vs_16k_6_scans_in_flight_scans_per_s"] = round(18.0 / (time.perf_counter() - t0), 3)
     # the same, 8 scans in lock-step (one batched NN launch per Adam step) + batched metric
     C8 = (torch.rand(8, n, 3, device=dev, generator=gen) - 0.5)
     P8b = (C8[:, :8192] * 0.9).contiguous()
@@ -260,6 +268,18 @@ def extras(A, B, n, dev, stream):
     evaluate_scans(X8, Y8)
     torch.cuda.synchronize()
     extra["registration_batch8_8k_vs_16k_4x201_plus_metric_scans_per_s"] = round(8.0 / (time.perf_counter() - t0), 3)
+    # ... and three such groups in flight side by side (pipeline.run_in_lanes: a host thread and a stream per group)
+    from genpc_amd import pipeline as _pl
+
+    def group8(li, _):
+        object_pose_optimization(C8, P8b, radius=0.02, lr=0.01, iters=200, render_size=224)
+        return evaluate_scans(X8, Y8)
+    _pl.run_in_lanes(group8, range(3), 3, dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _pl.run_in_lanes(group8, range(6), 3, dev)
+    torch.cuda.synchronize()
+    extra["registration_batch8_3_groups_in_flight_scans_per_s"] = round(48.0 / (time.perf_counter() - t0), 3)
     # the same without the silhouette term (round 1's objective), for continuity
     object_pose_optimization(C8, P8b, lr=0.01, iters=200, cd_only=True)
     torch.cuda.synchronize()
@@ -551,36 +571,8 @@ def run_scan_workload(args, rank, world, dev):
             if lanes == 1 or not groups:
                 rows = [one(*g) for g in groups]
                 return torch.cat(rows) if rows else torch.empty(0, 3, device=dev)
-            import threading
             from genpc_amd import pipeline
-            rows, errs, nxt, lock = [None] * len(groups), [], [0], threading.Lock()
-            caller = torch.cuda.current_stream(dev)
-
-            def lane(li):
-                try:
-                    with torch.cuda.device(dev):
-                        st = pipeline._lane_stream(dev, li)
-                        st.wait_stream(caller)
-                        with torch.cuda.stream(st):
-                            while True:
-                                with lock:
-                                    k = nxt[0]
-                                    nxt[0] += 1
-                                if k >= len(groups) or errs:
-                                    break
-                                rows[k] = one(*groups[k])
-                        st.synchronize()
-                except BaseException as e:
-                    errs.append(e)
-
-            th = [threading.Thread(target=lane, args=(i,)) for i in range(lanes)]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            if errs:
-                raise errs[0]
-            return torch.cat(rows)
+            return torch.cat(pipeline.run_in_lanes(lambda li, g: one(*g), groups, lanes, dev))
 
     sync = (lambda: None) if stub else torch.cuda.synchronize
     for _ in range(args.warmup):

@@ -166,6 +166,46 @@ def _lane_stream(device, li):
         return _LANE[(dev, li)]
 
 
+def run_in_lanes(fn, items, lanes, device):
+    """fn(lane_index, item) for every item, `lanes` of them in flight: a host thread and a stream of its own per lane (the
+    caller's stream is waited for first; every lane's stream is synchronised before this returns).  -> results in order."""
+    items = list(items)
+    if not items:
+        return []
+    dev = torch.device(device)
+    lanes = max(1, min(int(lanes), len(items), 8))
+    caller = torch.cuda.current_stream(dev)
+    results, errors = [None] * len(items), []
+    nxt = [0]
+    lock = threading.Lock()
+
+    def lane(li):
+        try:
+            with torch.cuda.device(dev):
+                st = _lane_stream(dev, li)
+                st.wait_stream(caller)                  # the inputs are the caller's
+                with torch.cuda.stream(st):
+                    while True:
+                        with lock:
+                            k = nxt[0]
+                            nxt[0] += 1
+                        if k >= len(items) or errors:
+                            break
+                        results[k] = fn(li, items[k])
+                st.synchronize()                        # (the lane's products are complete when its thread ends)
+        except BaseException as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=lane, args=(i,), name="genpc-lane-%d" % i) for i in range(lanes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results
+
+
 def complete_scans(jobs, lanes=2, cfg=None, dps=None, **kw):
     """Completed scans per second is a throughput: the stages of ONE scan are chains of small dependent launches, two
     sequential farthest-point samplings and a few chip-wide kernels with host round trips in between -- most of the chip
@@ -182,34 +222,11 @@ def complete_scans(jobs, lanes=2, cfg=None, dps=None, **kw):
     dev = jobs[0][0].device
     cfg = cfg or default_cfg(dev)
     lanes = max(1, min(int(lanes), len(jobs), 8))      # (throughput peaks at four to six)
-    caller = torch.cuda.current_stream(dev)
-    results, errors = [None] * len(jobs), []
-    nxt = [0]
-    lock = threading.Lock()
+    own = {}
 
-    def lane(li):
-        try:
-            with torch.cuda.device(dev):
-                st = _lane_stream(dev, li)
-                st.wait_stream(caller)                  # the inputs are the caller's
-                dp = dps[li] if dps else DepthPrompting(cfg)
-                with torch.cuda.stream(st):
-                    while True:
-                        with lock:
-                            k = nxt[0]
-                            nxt[0] += 1
-                        if k >= len(jobs) or errors:
-                            break
-                        results[k] = complete_scan(*jobs[k], cfg=cfg, dp=dp, **kw)
-                st.synchronize()                        # (the lane's products are complete when its thread ends)
-        except BaseException as e:
-            errors.append(e)
+    def one(li, job):
+        if li not in own:
+            own[li] = dps[li] if dps else DepthPrompting(cfg)
+        return complete_scan(*job, cfg=cfg, dp=own[li], **kw)
 
-    threads = [threading.Thread(target=lane, args=(i,), name="genpc-lane-%d" % i) for i in range(lanes)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
-    return results
+    return run_in_lanes(one, jobs, lanes, dev)
