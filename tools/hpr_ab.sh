@@ -1,6 +1,2 @@
-python bench.py --no-cpu-baseline 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-for k,v in d.get('extra',{}).items():
-    if any(s in k for s in ('registration',)) and not isinstance(v,dict): print(k,v)
-"
+timeout 600 python tools/soak_lanes.py 6 180 2>&1 | grep -v amdgpu | tail -3
+timeout 600 python tools/soak_lanes.py 8 160 2>&1 | grep -v amdgpu | tail -3
