@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GENPC_LIB: an alternative build of the same library (kernel experiments only)
 LIB_PATH = os.environ.get("GENPC_LIB") or os.path.join(_HERE, "lib", "libgenpc_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -39,6 +39,7 @@ SIGNATURES = {
     "genpc_emd_forward": (_i, [_i, _i, _i] + [_vp] * 14 + [_f, _i, _vp]),
     "genpc_emd_tune": (_i, [_i, _i]),
     "genpc_emd_stats": (_i, [_vp, _i, _vp]),
+    "genpc_emd_status": (_i, [_i, _vp]),
     "genpc_emd_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_get_uvs": (_i, [_i, _i, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
     "genpc_uv_to_pixels": (_i, [_i, _vp, _f, _i, _vp, _vp]),

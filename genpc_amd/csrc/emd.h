@@ -118,10 +118,17 @@ struct EmdGridBid {
     const EGridHdr *hdr;
     unsigned long long *chain_head, *chain_next;
     int *chain_cnt;                // bidders per object this round (emd_settle_kernel)
+    int *feedback;                 // round 3 only (else null): pinned host word that receives cloud 0's bidder count (emd_auction.hip: which path suits the data)
     unsigned long long *stats;     // hook (genpc_emd_tune): [0] bidders, [1] rows of their boxes, [2] rows kept, [3] objects tested, [4] exact evaluations, [5] first-place ties, [6] unseeded bidders; else null
 };
 int launch_emd_grid_build(int b, int n, const float *xyz2, const float *price, EGridHdr *hdr, int *start, float4 *sorted, int *pos_of,
-                          int *orig_of, int cells_target, int cells_max, hipStream_t st);
+                          int *orig_of, int cells_target, int cells_max, hipStream_t st, float *price_sep = nullptr);
+// ---- all rounds in one launch, threads own the points (emd_auction.hip) ----
+int launch_emd_auction(int b, int n, const float *xyz1, const float *xyz2, float *dist, int *assignment, float *price, int *assignment_inv,
+                       int *bid, float *bid_increments, float *max_increments, int *max_idx, float eps, int iters, int fma, hipStream_t st, bool forced);
+int *emd_feedback_slot(int b, int n, bool device);
+bool persist_reserve(int wgs, int capacity, hipStream_t st);
+void persist_commit(int wgs, hipStream_t st);
 int launch_emd_bid_grid(const EmdGridBid &a, int fma, hipStream_t st);
 
 // ---- seeded nearest neighbours of the alignment loop (nn_seeded.hip) ----

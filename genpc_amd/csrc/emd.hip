@@ -673,7 +673,7 @@ namespace genpc { static thread_local int t_emd_grid = -1, t_emd_hooks = 0; }
 GENPC_API int genpc_emd_tune(int grid, int hooks)
 {
     const int prev = genpc::t_emd_grid;
-    genpc::t_emd_grid = grid < 0 ? -1 : (grid ? 1 : 0);
+    genpc::t_emd_grid = grid < 0 ? -1 : (grid > 2 ? 2 : grid);
     if (hooks >= 0) genpc::t_emd_hooks = hooks;
     return prev;
 }
@@ -714,6 +714,17 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     if (total > 0x7fffffffLL) {
         set_error("emd: B*n too large");
         return 0;
+    }
+    // all rounds in ONE launch whose threads own the points (emd_auction.hip): whenever the whole launch can be resident
+    {
+        static const int env_auction = tune_env("GENPC_EMD_AUCTION", -1, "EMD: 1 all rounds in one launch (threads own the points) / 0 a launch per round step (-1 = pick)");
+        static const bool noseed_a = tune_env("GENPC_EMD_NOSEED", 0, "EMD: 1 = no seeds from the previous bid (tiled bid only; disables the culled bid)") != 0;
+        const bool want = t_emd_grid >= 0 ? t_emd_grid == 2 : (env_auction >= 0 ? env_auction != 0 : true);
+        if (want && eps >= 0.0f && !noseed_a && !(t_emd_hooks & 1)) {
+            const int rc = launch_emd_auction(b, n, xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_increments, max_increments,
+                                              max_idx, eps, iters, arith_mode() != 0 ? 1 : 0, st, t_emd_grid == 2);
+            if (rc >= 0) return rc;
+        }
     }
     // [second bidder list | arrival counters (zeroed on allocation, restored by the
     //  merging block) | per-slice partial top-2s]
@@ -822,6 +833,7 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
             ga.bid = bid; ga.second = second; ga.bid_increments = bid_increments; ga.max_increments = max_increments;
             ga.sorted = g_sorted_p; ga.hdr = g_hdr_p;
             ga.chain_head = use_chain ? chain_head : nullptr; ga.chain_next = chain_next; ga.chain_cnt = chain_cnt;
+            ga.feedback = it == 3 ? emd_feedback_slot(b, n, true) : nullptr;
             ga.stats = (t_emd_hooks & 1) ? (unsigned long long *)workspace(28, 256, nullptr, nullptr, 256) : nullptr;
             launch_emd_bid_grid(ga, fma ? 1 : 0, st);
         } else {

@@ -50,7 +50,8 @@ __device__ __forceinline__ int egrid_cell1(float p, float lo, float inv, int g)
 __global__ __launch_bounds__(kEGBlock) void emd_grid_build_kernel(int n, const float *__restrict__ xyz2, const float *__restrict__ price,
                                                                   EGridHdr *__restrict__ hdr, int *__restrict__ start,
                                                                   float4 *__restrict__ sorted, int *__restrict__ pos_of,
-                                                                  int *__restrict__ orig_of, int cells_target, int cells_max, int K)
+                                                                  int *__restrict__ orig_of, int cells_target, int cells_max, int K,
+                                                                  float *__restrict__ price_sep)
 {
     // K blocks per cloud (a single cloud on one CU took 48 us of a 1 ms call): block k sorts the cells [c0, c1) of the
     // cell index space -- a contiguous piece of the sorted output.  Every block reads ALL points of the cloud (box, cell of
@@ -218,7 +219,9 @@ __global__ __launch_bounds__(kEGBlock) void emd_grid_build_kernel(int n, const f
         const int c = cell_of(j);
         if (c < c0 || c >= c1) continue;
         const int pos = atomicAdd(&s_cnt[c - c0], 1);
-        out[pos] = make_float4(P[(size_t)j * 3 + 0], P[(size_t)j * 3 + 1], P[(size_t)j * 3 + 2], PR0 ? PR0[j] : __int_as_float(j));
+        // price_sep != null (emd_auction.hip): the entry carries the object's index, the prices of the sorted order are an array of their own
+        out[pos] = make_float4(P[(size_t)j * 3 + 0], P[(size_t)j * 3 + 1], P[(size_t)j * 3 + 2], (PR0 && !price_sep) ? PR0[j] : __int_as_float(j));
+        if (price_sep) price_sep[(size_t)batch * n + pos] = PR0 ? PR0[j] : 0.0f;
         if (po) po[j] = pos;
         if (ps) ps[pos] = j;
     }
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
     }
     const int U = a.cnt[batch];
     if (bx == 0 && threadIdx.x == 0) a.cnt_next[batch] = 0;   // filled by this round's settle / resolve
+    if (a.feedback != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.feedback, U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (U == 0) return;
     int LPB = a.force_lpb > 0 ? a.force_lpb : pick_p(U, G);
     LPB = LPB < 8 ? 8 : LPB;
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
 }
 
 int launch_emd_grid_build(int b, int n, const float *xyz2, const float *price, EGridHdr *hdr, int *start, float4 *sorted, int *pos_of,
-                          int *orig_of, int cells_target, int cells_max, hipStream_t st)
+                          int *orig_of, int cells_target, int cells_max, hipStream_t st, float *price_sep)
 {
     const size_t lds = ((size_t)cells_max + 2 * kEGWaves) * sizeof(int) + 6 * kEGWaves * sizeof(float);
     // pieces per cloud: enough blocks to spread a few clouds over the chip, one when there are many clouds anyway
@@ -578,7 +582,7 @@ int launch_emd_grid_build(int b, int n, const float *xyz2, const float *price, E
     int K = env_k > 0 ? env_k : (b >= 32 ? 1 : (b >= 8 ? 2 : (n >= 8192 ? 8 : 4)));
     K = K > 64 ? 64 : K;
     hipLaunchKernelGGL(emd_grid_build_kernel, dim3(b * K), dim3(kEGBlock), lds, st, n, xyz2, price, hdr, start, sorted, pos_of, orig_of,
-                       cells_target, cells_max, K);
+                       cells_target, cells_max, K, price_sep);
     return check(hipGetLastError(), "emd_grid_build_kernel launch") ? 1 : 0;
 }
 

@@ -14,7 +14,7 @@
 // and the point is visible iff the polygon survives clipping by every other point.
 //
 // Pipeline (one call = all viewpoints):
-//   hpr_bounds / hpr_key / hipcub sort   per view, the points in 2-D Morton order of their DIRECTION from the
+//   hpr_bounds / hpr_key / rocprim sort  per view, the points in 2-D Morton order of their DIRECTION from the
 //                         eye: a surface and what it hides become neighbours, so a hidden point meets its
 //                         occluders at once.  The order never changes a result, only when it is reached.
 //   hpr_flip_kernel       p' per (view, position), fp64
@@ -49,7 +49,9 @@
 #include <stdlib.h>
 #include <algorithm>
 
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #pragma clang fp contract(off)
 
@@ -1674,8 +1676,8 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     if (n == 0) return 1;
     const size_t total = (size_t)c * n;
     size_t sort_bytes = 0;
-    if (!check(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
-                                                  (const int *)nullptr, (int *)nullptr, (int)((size_t)c * n), 0, 32, stream),
+    if (!check(rocprim::radix_sort_pairs(nullptr, sort_bytes, (const unsigned *)nullptr, (unsigned *)nullptr, (const int *)nullptr, (int *)nullptr,
+                                         (size_t)c * n, 0u, 32u, stream),
                "hpr sort size"))
         return 0;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -1724,7 +1726,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
         for (int axis = 2; axis >= 0; axis--) {
             hipLaunchKernelGGL(hpr_dupkey_kernel, dim3(g256), dim3(256), 0, stream, n, points, axis, axis == 2 ? (const int *)nullptr : (const int *)ia, k0, ia);
             size_t sb = sort_bytes;
-            if (!check(hipcub::DeviceRadixSort::SortPairs(ws + o_tmp, sb, (const unsigned *)k0, k1, (const int *)ia, ib, n, 0, 32, stream), "hpr duplicate sort"))
+            if (!check(rocprim::radix_sort_pairs(ws + o_tmp, sb, (const unsigned *)k0, k1, (const int *)ia, ib, (size_t)n, 0u, 32u, stream), "hpr duplicate sort"))
                 return 0;
             std::swap(ia, ib);
         }
@@ -1734,8 +1736,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     hipLaunchKernelGGL(hpr_key_kernel, dim3(g256, c), dim3(256), 0, stream, n, points, (const unsigned *)bounds, eyes, k0, i0);
     int key_bits = 20;
     while ((1 << (key_bits - 20)) < c) key_bits++;
-    if (!check(hipcub::DeviceRadixSort::SortPairs(ws + o_tmp, sort_bytes, (const unsigned *)k0, k1, (const int *)i0, i1, (int)total, 0, key_bits,
-                                                  stream),
+    if (!check(rocprim::radix_sort_pairs(ws + o_tmp, sort_bytes, (const unsigned *)k0, k1, (const int *)i0, i1, total, 0u, (unsigned)key_bits, stream),
                "hpr radix sort"))
         return 0;
     HprTile *tiles = (HprTile *)(ws + o_tiles);

@@ -182,7 +182,10 @@ struct PoseState {       // device-resident
     float best_loss;
     float best_params[10];
     int step;            // Adam step of the current start (1-based after the first update)
+    int patience_counter;   // steps since local_best last improved (diff_obj_pose.py:549-556)
+    int stopped;         // the start has run out of patience: its parameters are frozen for the rest of its iterations
 };
+constexpr int kPosePatience = 300;      // diff_obj_pose.py:530
 
 // One thread: finish the gradient (orthogonality term + 6D backward), optionally
 // take the Adam step, record the loss, clear the accumulators.
@@ -254,9 +257,21 @@ __global__ void pose_update_kernel(int b, PoseState *__restrict__ S, double *__r
     S->loss[2] = (float)err;
     S->loss[3] = (float)accum[15];
     for (int k = 0; k < kAcc; k++) accum[k] = 0.0;
+    // Early stop (diff_obj_pose.py:529-556): the reference leaves a start's loop once `patience` steps in a row failed to
+    // improve its best loss.  The launches of a start are enqueued up front here, so a stopped start keeps its parameters
+    // and its best loss through the remaining launches (history: NaN = "iteration not run").
+    if (do_step && S->stopped) {
+        if (history_slot) *history_slot = __builtin_nanf("");
+        return;
+    }
     if (history_slot) *history_slot = loss;
     if (!do_step) return;
-    if (loss < S->local_best) S->local_best = loss;       // diff_obj_pose.py:549-551
+    if (loss < S->local_best) {       // :549-553 (the optimizer step below has been taken by then, as here)
+        S->local_best = loss;
+        S->patience_counter = 0;
+    } else if (++S->patience_counter > kPosePatience) {
+        S->stopped = 1;               // :554-556: break AFTER this iteration's step
+    }
     // torch.optim.Adam, three groups: lr, 0.2 lr, 0.1 lr (diff_obj_pose.py:524-528)
     const int step = ++S->step;
     const double be1 = 0.9, be2 = 0.999, eps = 1e-8;
@@ -295,6 +310,8 @@ __global__ void pose_begin_kernel(int b, PoseState *__restrict__ S, double *__re
     }
     S->local_best = __builtin_inff();
     S->step = 0;
+    S->patience_counter = 0;
+    S->stopped = 0;
 }
 
 // end of a start: keep the FINAL parameters of the start with the lowest loss seen
@@ -1909,7 +1926,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
         if (!launch_nn_dedupe(b, 2, dp, dn, dm, nullptr, st)) return 0;
     }
 
-    // OPT-IN (genpc_pose_tune(1) / GENPC_POSE_SEEDED=1): from the second step on every nearest-neighbour query starts from the
+    // genpc_pose_tune(1) / GENPC_POSE_SEEDED=1 (the default is 2 = adaptive, below): from the second step on every nearest-neighbour query starts from the
     // index it was answered with a step ago and searches only the ball that answer leaves (nn_seeded.hip): both clouds
     // sorted once per call into uniform grids, the moving one in its rest frame.  Bit-identical to the brute-force filter.
     // Measured (round 4): 8 scans of uniform VOLUME clouds 161 -> 120 ms per call (49 -> 66 scans/s: a rotated cube is still
@@ -1928,7 +1945,12 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // take whichever was faster last (two events and one wait per probe: ~10 per call).
     constexpr int kPoseProbe = 25;
     const bool adaptive = seed_mode == 2;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // (the two events are released on EVERY way out of this function, the early `return 0`s of the loop included: ADVICE r4)
+    struct EventPair {
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } evs;
+    hipEvent_t &ev0 = evs.a, &ev1 = evs.b;
     if (adaptive && (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess)) {
         set_error("pose_optimize: hipEventCreate failed");
         return 0;
@@ -2017,8 +2039,6 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
                            best_params);
     else
         hipLaunchKernelGGL(pose_end_kernel, dim3(gb), dim3(64), 0, st, b, S, 1, transform, best_params);
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
     return check(hipGetLastError(), "pose_optimize launch") ? 1 : 0;
 }
 

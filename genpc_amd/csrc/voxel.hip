@@ -9,15 +9,17 @@
 //
 //   voxel_bounds_kernel   min / max of the cloud (order-independent: bitwise reproducible)
 //   voxel_key_kernel      64-bit key (i << 42 | j << 21 | k) per point
-//   hipcub radix sort     (key, point index) pairs -- a library sort; it is stable, so the points
+//   rocprim radix sort    (key, point index) pairs -- ROCm's own primitives library; it is stable, so the points
 //                         of a voxel stay in ascending index order
-//   voxel_head_kernel     run heads; hipcub inclusive scan gives every run its output slot
+//   voxel_head_kernel     run heads; rocprim inclusive scan gives every run its output slot
 //   voxel_mean_kernel     the head of a run sums it in that order, in double: the same additions in
 //                         the same order as a CPU loop over the points -> bit-identical means
 #include "common.h"
 #include "../../include/genpc_hip.h"
 
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace genpc {
 
@@ -152,9 +154,9 @@ GENPC_API int genpc_voxel_down_sample(int n, const float *xyz, const float *colo
     if (n == 0) return check(hipMemsetAsync(out_count, 0, sizeof(int), st), "hipMemsetAsync(voxel count)") ? 1 : 0;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     size_t sort_bytes = 0, scan_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long *)nullptr,
-                                             (unsigned long long *)nullptr, (const int *)nullptr, (int *)nullptr, n, 0, 63, st);
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, (const int *)nullptr, (int *)nullptr, n, st);
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                    (const int *)nullptr, (int *)nullptr, (size_t)n, 0u, 63u, st);
+    (void)rocprim::inclusive_scan(nullptr, scan_bytes, (const int *)nullptr, (int *)nullptr, (size_t)n, rocprim::plus<int>(), st);
     const size_t tmp_bytes = up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
     size_t off = 0;
     const size_t o_bounds = off; off += 256;
@@ -179,12 +181,12 @@ GENPC_API int genpc_voxel_down_sample(int n, const float *xyz, const float *colo
     hipLaunchKernelGGL(voxel_key_kernel, dim3(grid), dim3(kVBlock), 0, st, n, xyz, voxel_size, (const unsigned *)bounds, k0,
                        i0, err);
     size_t sb = tmp_bytes;
-    if (!check(hipcub::DeviceRadixSort::SortPairs(ws + o_tmp, sb, (const unsigned long long *)k0, k1, (const int *)i0, i1, n, 0, 63, st),
+    if (!check(rocprim::radix_sort_pairs(ws + o_tmp, sb, (const unsigned long long *)k0, k1, (const int *)i0, i1, (size_t)n, 0u, 63u, st),
                "voxel radix sort"))
         return 0;
     hipLaunchKernelGGL(voxel_head_kernel, dim3(grid), dim3(kVBlock), 0, st, n, (const unsigned long long *)k1, head);
     sb = tmp_bytes;
-    if (!check(hipcub::DeviceScan::InclusiveSum(ws + o_tmp, sb, (const int *)head, rank, n, st), "voxel scan")) return 0;
+    if (!check(rocprim::inclusive_scan(ws + o_tmp, sb, (const int *)head, rank, (size_t)n, rocprim::plus<int>(), st), "voxel scan")) return 0;
     hipLaunchKernelGGL(voxel_mean_kernel, dim3(grid), dim3(kVBlock), 0, st, n, xyz, (const unsigned long long *)k1, colors,
                        (const int *)i1, (const int *)head, (const int *)rank, out, out_colors, out_count);
     if (!check(hipGetLastError(), "voxel_down_sample launch")) return 0;

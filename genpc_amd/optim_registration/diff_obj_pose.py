@@ -179,7 +179,10 @@ def object_pose_optimization(glb_path, point_path, radius=0.005, lr=0.005, iters
 
     radius / render_size parameterise the silhouette term (splat radius in world units, image side);
     cd_only=True drops that term (Chamfer + orthogonality only).  vis / save_path (the reference's
-    debug GIF) are accepted and unused."""
+    debug GIF) are accepted and unused.  The file form also leaves the reference's side-effect files in
+    the working directory: ``partial.png``, ``partial_mask.png`` (:508-509) and ``final_transform.npy``
+    (:591).  A start stops early after 300 steps without a new best loss (:529-556; never at iters <= 300)."""
+    file_form = False
     if isinstance(glb_path, str) or isinstance(point_path, str):
         if not (isinstance(glb_path, str) and isinstance(point_path, str)):
             raise TypeError("object_pose_optimization: pass two paths or two tensors")
@@ -187,6 +190,7 @@ def object_pose_optimization(glb_path, point_path, radius=0.005, lr=0.005, iters
             device = torch.device("cuda:0")
         partial_xyz, partial_col = load_point_cloud(point_path, device, radius=radius, num_points=8000)      # :502
         complete_xyz, complete_col = load_point_cloud(glb_path, device, radius=radius, num_points=120000)   # :504
+        file_form = True
     else:
         complete_xyz, partial_xyz = glb_path, point_path
     batched = complete_xyz.dim() == 3
@@ -200,6 +204,13 @@ def object_pose_optimization(glb_path, point_path, radius=0.005, lr=0.005, iters
     if partial_col is not None and not batched:
         partial_col = torch.as_tensor(partial_col)[None]
     cc, pc = _col(complete_col, complete_xyz, "complete_col"), _col(partial_col, partial_xyz, "partial_col")
+    if file_form:
+        # the reference's side-effect files in the working directory (:508-509): the reference image and its mask
+        from PIL import Image
+        ref_img = splat_image(partial_xyz[0], radius, render_size, None if pc is None else pc[0])
+        ref_mask = compute_mask_from_rendering(ref_img)
+        Image.fromarray((ref_img.detach().cpu() * 255).to(torch.uint8).numpy()).save("partial.png")
+        Image.fromarray((ref_mask.detach().cpu().numpy() * 255).astype("uint8")).save("partial_mask.png")
     dev = complete_xyz.device
     b = complete_xyz.shape[0]
     T = torch.empty(b, 16, device=dev)
@@ -216,6 +227,9 @@ def object_pose_optimization(glb_path, point_path, radius=0.005, lr=0.005, iters
         final_transform, h, bpn = final_transform[0], h[0], bp[0].cpu().numpy()
     else:
         bpn = bp.cpu().numpy()
+    if file_form:
+        import numpy as np
+        np.save("final_transform.npy", final_transform)      # :591
     if return_history:
         return final_transform, h, bpn
     return final_transform

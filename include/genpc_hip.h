@@ -126,12 +126,17 @@ int genpc_emd_forward(int b, int n, int m, const float *xyz1, const float *xyz2,
                       int *unass_cnt_sum, int *cnt_tmp, int *max_idx, float eps,
                       int iters, void *stream);
 
-/* Bid kernel of genpc_emd_forward, for tests and A/B (applies to the calling host thread): 1 the cell-sorted culled
- * bid (csrc/emd_grid.hip: a bidder visits only the grid rows that can hold an object worth more than its current
- * second-best), 0 the tiled bid over all objects, < 0 the default (culled when eps >= 0 and n >= 4096 or B n >= 65536).  Both give
- * the same bits.  hooks (>= 0 to set; < 0 keep): 1 = count what the culled bid does (genpc_emd_stats).  Returns the
- * previous `grid` setting. */
+/* Implementation of genpc_emd_forward, for tests and A/B (applies to the calling host thread): 2 all rounds in ONE
+ * launch whose threads own the points (csrc/emd_auction.hip; needs eps >= 0 and the whole launch resident: B n <= 3.5 x 256
+ * x CUs, else the call falls back to 1), 1 a launch per round step with the cell-sorted culled bid (csrc/emd_grid.hip: a
+ * bidder visits only the grid rows that can hold an object worth more than its current second-best), 0 the same with the
+ * tiled bid over all objects, < 0 the default (2 when admitted; else 1 when eps >= 0 and n >= 4096 or B n >= 65536; else 0).
+ * All give the same bits.  hooks (>= 0 to set; < 0 keep): 1 = count what the culled bid does (genpc_emd_stats; implies
+ * the launch-per-round path).  Returns the previous setting. */
 int genpc_emd_tune(int grid, int hooks);
+/* Synchronises `stream` and returns 1 if a one-launch EMD call on it was abandoned since the last reset (its workgroups
+ * did not all become resident within the spin bound; that call's dist is NaN), 0 if none, -1 on error. */
+int genpc_emd_status(int reset, void *stream);
 /* Counters of the culled bid, accumulated on the current device while hook 1 is set: out[0] bidder-rounds, out[1] rows
  * of their search boxes, out[2] rows kept by the bound, out[3] objects tested, out[4] exact (fp64) evaluations, out[5]
  * exact first-place ties (full re-scan), out[6] bidders without seeds (probe).  Synchronises `stream`; reset != 0 zeroes. */

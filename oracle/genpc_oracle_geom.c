@@ -410,6 +410,7 @@ ORACLE_API void oracle_pose_optimize_cd(int nc, const float *complete, int np_, 
         float params[10] = {(float)cos(th), 0.0f, (float)sin(th), 0.0f, 1.0f, 0.0f, 0, 0, 0, logf(0.75f)};
         float m[10] = {0}, vv[10] = {0};
         float local_best = INFINITY;
+        int patience_counter = 0;
         for (int it = 0; it <= iters; it++) {
             oracle_pose_transform(nc, complete, center, params, pts);
             oracle_nm_distance(1, nc, pts, np_, partial, d1, i1, fma_mode);
@@ -417,8 +418,14 @@ ORACLE_API void oracle_pose_optimize_cd(int nc, const float *complete, int np_, 
             float lo[3], grad[10];
             oracle_pose_loss_grad(nc, complete, center, params, np_, partial, d1, i1, d2, i2, 3.0f, 0.001f, lo, grad);
             if (history) history[(size_t)st * (iters + 1) + it] = lo[0];
-            if (lo[0] < local_best) local_best = lo[0];
             oracle_adam_step(params, grad, m, vv, it + 1, lr);
+            /* early stop, diff_obj_pose.py:529-556: patience 300, counted after the optimizer step; the iterations a start
+             * does not run are NaN in the history */
+            if (lo[0] < local_best) { local_best = lo[0]; patience_counter = 0; }
+            else if (++patience_counter > 300) {
+                if (history) for (int q = it + 1; q <= iters; q++) history[(size_t)st * (iters + 1) + q] = NAN;
+                break;
+            }
         }
         if (local_best < best_loss) {
             best_loss = local_best;
@@ -733,6 +740,7 @@ ORACLE_API void oracle_pose_optimize(int nc, const float *complete, const float 
         float params[10] = {(float)cos(th), 0.0f, (float)sin(th), 0.0f, 1.0f, 0.0f, 0, 0, 0, logf(0.75f)};
         float m[10] = {0}, vv[10] = {0};
         float local_best = INFINITY;
+        int patience_counter = 0;
         for (int it = 0; it <= iters; it++) {
             oracle_pose_transform(nc, complete, center, params, pts);
             oracle_nm_distance(1, nc, pts, np_, partial, d1, i1, fma_mode);
@@ -741,8 +749,14 @@ ORACLE_API void oracle_pose_optimize(int nc, const float *complete, const float 
             oracle_pose_full_loss_grad(nc, complete, complete_col, center, params, np_, partial, d1, i1, d2, i2, 3.0f, 0.001f,
                                        mask_weight, radius, S, ref, lo, grad);
             if (history) history[(size_t)st * (iters + 1) + it] = lo[0];
-            if (lo[0] < local_best) local_best = lo[0];
             oracle_adam_step(params, grad, m, vv, it + 1, lr);
+            /* early stop, diff_obj_pose.py:529-556: patience 300, counted after the optimizer step; the iterations a start
+             * does not run are NaN in the history */
+            if (lo[0] < local_best) { local_best = lo[0]; patience_counter = 0; }
+            else if (++patience_counter > 300) {
+                if (history) for (int q = it + 1; q <= iters; q++) history[(size_t)st * (iters + 1) + q] = NAN;
+                break;
+            }
         }
         if (local_best < best_loss) {
             best_loss = local_best;

@@ -22,13 +22,17 @@ def gp():
     return dict(torch=torch, lib=_lib, emd=emd, mod=emdModule(), alloc=alloc_state, CL=Completionloss)
 
 
-@pytest.fixture(autouse=True, params=[1, 0], ids=["culled_bid", "tiled_bid"])
+@pytest.fixture(autouse=True, params=[2, 1, 0], ids=["one_launch", "culled_bid", "tiled_bid"])
 def bid_kernel(request, gp):
-    """Every test of this file runs with both Bid kernels: the cell-sorted culled one (csrc/emd_grid.hip, the default
-    from n = 512 on; forced here for smaller clouds too) and the tiled one over all objects (emd_bid_kernel)."""
+    """Every test of this file runs with all three implementations: all rounds in one launch whose threads own the
+    points (csrc/emd_auction.hip, the default whenever the launch fits the chip), a launch per round step with the
+    cell-sorted culled bid (csrc/emd_grid.hip) and with the tiled bid over all objects (emd_bid_kernel)."""
     prev = gp["lib"].lib.genpc_emd_tune(request.param, -1)
     yield request.param
     gp["lib"].lib.genpc_emd_tune(prev, -1)
+    if request.param == 2:
+        # no one-launch call of the test was abandoned (its dist would be NaN)
+        assert gp["lib"].lib.genpc_emd_status(1, None) == 0
 
 
 def run_hip(gp, a, b, eps, iters, mode):

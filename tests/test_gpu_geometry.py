@@ -364,6 +364,27 @@ def test_pose_optimisation_loop(gp, oracle):
     assert T[3].tolist() == [0, 0, 0, 1]
 
 
+def test_pose_loop_early_stop(gp, oracle):
+    """diff_obj_pose.py:529-556: a start leaves its loop once 300 steps in a row have not improved its best loss (the
+    optimizer step of that iteration has been taken).  Never fires at reg()'s iters = 200; with lr = 0 every step after the
+    first fails to improve: iterations 0 .. 301 run, 302 .. 400 do not (NaN in the history), in the library and the oracle."""
+    torch = gp["torch"]
+    complete, partial, _ = _shape(9, 600)
+    T, hist, bp = gp["POSE"].object_pose_optimization(torch.from_numpy(complete).cuda(), torch.from_numpy(partial).cuda(),
+                                                      radius=0.02, lr=0.0, iters=400, return_history=True, cd_only=True)
+    oT, ohist, obp = oracle.pose_optimize_cd(complete, partial, lr=0.0, iters=400, starts=4)
+    assert hist.shape == (4, 401)
+    assert np.isfinite(hist[:, :302]).all() and np.isnan(hist[:, 302:]).all()
+    assert np.isfinite(ohist[:, :302]).all() and np.isnan(ohist[:, 302:]).all()
+    np.testing.assert_allclose(hist[:, :302], ohist[:, :302], rtol=1e-4)
+    np.testing.assert_allclose(T, oT, atol=1e-5)
+    # a normal run (the loss keeps improving) is not cut short: iters = 320 > patience
+    T2, h2, _ = gp["POSE"].object_pose_optimization(torch.from_numpy(complete).cuda(), torch.from_numpy(partial).cuda(),
+                                                    radius=0.02, lr=0.01, iters=320, return_history=True, cd_only=True)
+    best = int(np.argmin(np.nanmin(h2, 1)))
+    assert np.isfinite(h2[best]).all()
+
+
 def test_pose_loop_full_size_property(gp):
     """BASELINE config 5 size (32768 points): registration brings the one-sided
     Chamfer distance of the partial cloud (exactly 0 at the true pose here: the

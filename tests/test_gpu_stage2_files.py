@@ -70,8 +70,20 @@ def test_flag_directory_round_trip(tmp_path):
     pv, pc = POSE.load_point_cloud(ply, torch.device("cuda"), radius=0.02, num_points=8000)
     assert pv.is_cuda and pv.shape == pc.shape and pv.shape[0] < n and 0.0 <= float(pc.min()) and float(pc.max()) <= 1.0
     np.random.seed(0)
-    T_file = POSE.object_pose_optimization(glb, ply, radius=0.02, lr=0.01, iters=40, render_size=224, device=torch.device("cuda"))
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))          # the reference drops its side-effect files into the working directory
+    try:
+        T_file = POSE.object_pose_optimization(glb, ply, radius=0.02, lr=0.01, iters=40, render_size=224, device=torch.device("cuda"))
+    finally:
+        os.chdir(cwd)
     assert T_file.shape == (4, 4) and T_file[3].tolist() == [0, 0, 0, 1]
+    # diff_obj_pose.py:508-509,591: partial.png, partial_mask.png, final_transform.npy
+    from PIL import Image
+    ref = np.asarray(Image.open(str(tmp_path / "partial.png")))
+    msk = np.asarray(Image.open(str(tmp_path / "partial_mask.png")))
+    assert ref.shape == (224, 224, 3) and msk.shape == (224, 224) and set(np.unique(msk)) <= {0, 255} and msk.any()
+    assert ((ref.max(-1) > 0) >= (msk > 0)).all()      # the mask marks rendered pixels only
+    np.testing.assert_array_equal(np.load(str(tmp_path / "final_transform.npy")), T_file)
     s = np.cbrt(np.linalg.det(T_file[:3, :3].astype(np.float64)))
     assert 0.75 < s < 0.95
     # ---- scaleReg(flag) = reg(cfg, flag, 0.5, True, True): writes {flag}_fused.ply with colours

@@ -180,6 +180,62 @@ __global__ __launch_bounds__(256) void k(float *out, float s0, float s1)
 #define OP(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
             BODY8(OP) BODY8(OP)
 #undef OP
+        } else if (KIND == 38) {    // v_min3_u32
+#define OP(i) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 39) {    // v_min_i32
+#define OP(i) asm volatile("v_min_i32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 40) {    // v_max_f32
+#define OP(i) asm volatile("v_max_f32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 41) {    // v_max3_f32
+#define OP(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 42) {    // v_min_u16
+#define OP(i) asm volatile("v_min_u16 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 43) {    // v_pk_min_u16
+#define OP(i) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 44) {    // v_min_f32 dpp row_shr:1
+#define OP(i) asm volatile("v_min_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 45) {    // v_min_f16
+#define OP(i) asm volatile("v_min_f16 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 46) {    // v_add_f32_e64 clamp
+#define OP(i) asm volatile("v_add_f32_e64 %0, %0, %1 clamp" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 47) {    // v_min_f64
+#define OP(i) asm volatile("v_min_f64 %0, %0, %1" : "+v"(dv[i]) : "v"((double)1.0));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 48) {    // v_min3_f16
+#define OP(i) asm volatile("v_min3_f16 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 49) {    // v_min_u32 dpp quad_perm
+#define OP(i) asm volatile("v_min_u32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 50) {    // v_max_u32
+#define OP(i) asm volatile("v_max_u32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            BODY8(OP) BODY8(OP)
+#undef OP
+        } else if (KIND == 51) {    // v_min3_i16
+#define OP(i) asm volatile("v_min3_i16 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+            BODY8(OP) BODY8(OP)
+#undef OP
         }
     }
     float acc = 0;
@@ -212,6 +268,21 @@ int main()
         {"v_pk_minimum3_f16", k<31>, 16, 2}, {"v_min3_i32", k<32>, 16, 1}, {"v_pk_min_i16", k<33>, 16, 2},
         {"v_cvt_pkrtz_f16_f32", k<34>, 16, 1}, {"v_min_u32", k<35>, 16, 1}, {"v_perm_b32", k<36>, 16, 1},
         {"v_and_or_b32", k<37>, 16, 1},
+        // round 5: every remaining way to take a minimum
+        {"v_min3_u32", k<38>, 16, 1},
+        {"v_min_i32", k<39>, 16, 1},
+        {"v_max_f32", k<40>, 16, 1},
+        {"v_max3_f32", k<41>, 16, 1},
+        {"v_min_u16", k<42>, 16, 1},
+        {"v_pk_min_u16", k<43>, 16, 2},
+        {"v_min_f32 dpp row_shr:1", k<44>, 16, 1},
+        {"v_min_f16", k<45>, 16, 1},
+        {"v_add_f32_e64 clamp", k<46>, 16, 1},
+        {"v_min_f64", k<47>, 16, 1},
+        {"v_min3_f16", k<48>, 16, 1},
+        {"v_min_u32 dpp quad_perm", k<49>, 16, 1},
+        {"v_max_u32", k<50>, 16, 1},
+        {"v_min3_i16", k<51>, 16, 1},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
