@@ -341,6 +341,10 @@ def extras(A, B, n, dev, stream):
                                             "frac_of_6.29TBs_achievable": round(alg / (t * 1e-3) / 6.29e12, 4),
                                             "ms_per_call": round(t, 4), "algorithmic_bytes": alg,
                                             "bytes_model": "12 N read + 12 C N written (uv 8 + depth 4)"}
+    # the other HBM-bound rows of SURVEY 8(a) -- a3 chamfer backward, a8 CalcDist, a10 EMD backward, the pose point map, a14
+    # paintPixels, a15 colour gather -- at 64 x 32768 points (every 8(a) row gets a driver-visible frac)
+    from genpc_amd import streaming_bench
+    extra["streaming_rooflines_64x32768"] = streaming_bench.rooflines(dev, stream, reps=20)
     # f3: hidden-point removal (Katz' operator, exact) at viewpoint_select's shape -- the reference's 1024
     # viewpoints x 10000 FPS-ordered points, removal_radius 10000 -- and at getDepth's (2 viewpoints x the
     # whole scan); next to it qhull (what open3d calls) on one host core for ONE viewpoint
@@ -535,12 +539,21 @@ def run_scan_workload(args, rank, world, dev):
     from genpc_amd import sharding
     stub = os.environ.get("GENPC_BENCH_STUB") == "1"      # CI only (tests/test_sharding.py): the sharding / gather / timing path on CPU ranks, no kernels
     total, n, load = scan_workload_inputs(args.workload, stub)
+    if os.environ.get("GENPC_BENCH_TOTAL"):      # measurement aid: the first k scans only (e.g. 8 = one rank's share of c5 on 8 GPUs)
+        total = max(1, min(total, int(os.environ["GENPC_BENCH_TOTAL"])))
     mine = sharding.shard_indices(total, rank, world)
     scans = [load(sidx) for sidx in mine]
     register = args.workload != "c3"
+    # Lock-step group size.  A rank that owns no more scans than one group of 8 (c5 on 8 GPUs: 8 scans per rank) would have
+    # a single group and nothing in flight beside it: its scans are then dealt into `lanes_want` smaller groups that run
+    # side by side (the first 8-GPU run should measure the configuration one would ship).
+    lanes_want = max(1, int(os.environ.get("GENPC_BENCH_LANES", "3")))
+    gsize = int(os.environ.get("GENPC_BENCH_GROUP", "0")) or (8 if register else 16)
+    if register and not os.environ.get("GENPC_BENCH_GROUP") and 1 < len(scans) <= gsize and lanes_want > 1:
+        gsize = max(2, -(-len(scans) // min(lanes_want, 2)))
     groups = []
-    for g0 in range(0, len(scans), 8 if register else 16):
-        grp = scans[g0:g0 + (8 if register else 16)]
+    for g0 in range(0, len(scans), gsize):
+        grp = scans[g0:g0 + gsize]
         groups.append(tuple(None if grp[0][k] is None else torch.from_numpy(np.stack([np.ascontiguousarray(x[k], np.float32) for x in grp])).to(dev)
                             for k in range(3)))
 

@@ -26,6 +26,8 @@ SIGNATURES = {
     "genpc_set_arith": (_i, [_i]),
     "genpc_set_arith_thread": (_i, [_i]),
     "genpc_get_arith": (_i, []),
+    "genpc_thread_state_export": (_i, [_vp]),
+    "genpc_thread_state_import": (_i, [_vp]),
     "genpc_release_workspace": (_i, []),
     "genpc_tune_table": (_i, [_vp, _i]),
     "genpc_nn_tune": (_i, [_i, _i]),
@@ -40,6 +42,7 @@ SIGNATURES = {
     "genpc_emd_tune": (_i, [_i, _i]),
     "genpc_emd_stats": (_i, [_vp, _i, _vp]),
     "genpc_emd_status": (_i, [_i, _vp]),
+    "genpc_emd_calc_dist": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_emd_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_get_uvs": (_i, [_i, _i, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
     "genpc_uv_to_pixels": (_i, [_i, _vp, _f, _i, _vp, _vp]),
@@ -54,6 +57,7 @@ SIGNATURES = {
     "genpc_mask_loss": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_pose_loss_grad": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
     "genpc_pose_tune": (_i, [_i]),
+    "genpc_render_tune": (_i, [_i]),
     "genpc_pose_optimize_batch": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _f, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp]),
     "genpc_pose_optimize_cd": (_i, [_i, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "genpc_pose_optimize_cd_batch": (_i, [_i, _i, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
@@ -64,6 +68,7 @@ SIGNATURES = {
     "genpc_list_code_probe": (_i, [ctypes.c_longlong, _vp, _vp, _vp, _vp]),
     "genpc_fastdiv_probe": (_i, [ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_fps_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "genpc_fps_tune": (_i, [_i]),
     "genpc_fps_stats": (_i, [_i, _vp, _vp]),
     "genpc_fps": (_i, [_i, _i, _vp, _i, _vp, _vp]),
     "genpc_knn_mean_distance": (_i, [_i, _vp, _i, _vp, _vp]),
@@ -162,3 +167,20 @@ def require(t, dtype, name):
         raise TypeError("genpc_amd: %s must be %s, got %s" % (name, dtype, t.dtype))
     if not t.is_contiguous():
         raise ValueError("genpc_amd: %s must be contiguous" % name)
+
+
+def thread_state():
+    """The calling thread's library modes (arithmetic override, nn / emd / pose / fps tunes) plus torch's grad mode, to be
+    handed to worker threads (apply_thread_state): they are thread-local, and a new thread starts with the defaults."""
+    buf = (ctypes.c_int * 8)()
+    lib.genpc_thread_state_export(ctypes.cast(buf, ctypes.c_void_p))
+    return (tuple(buf), torch.is_grad_enabled())
+
+
+def apply_thread_state(state):
+    """Installs a thread_state() snapshot in the calling thread; returns the state it replaces."""
+    prev = thread_state()
+    buf = (ctypes.c_int * 8)(*state[0])
+    lib.genpc_thread_state_import(ctypes.cast(buf, ctypes.c_void_p))
+    torch.set_grad_enabled(state[1])
+    return prev

@@ -613,7 +613,7 @@ struct NNConfig {
 
 // genpc_nn_tune() overrides (-1: use the environment / default).  Thread-local: a test that
 // switches kernel families does not change what other host threads launch.
-static thread_local int t_tune_path = -1, t_tune_hooks = -1;
+thread_local int t_tune_path = -1, t_tune_hooks = -1;      // (declared in common.h: genpc_thread_state_export / _import)
 
 // Tunables; the environment is read ONCE, at first use (C++11 static initialisation is
 // thread-safe), never per launch.

@@ -35,6 +35,10 @@ void set_error(const char *msg);
 // zeroed (stream-ordered) and *fresh is set; an existing block is returned as is.
 void *workspace(int slot, size_t bytes, hipStream_t stream, bool *fresh = nullptr, size_t zero_prefix = 0);
 int arith_mode();
+// The per-thread modes of the library (each set through its own genpc_*_tune / genpc_set_arith_thread entry point); a host
+// thread that starts worker threads hands them over with genpc_thread_state_export / _import (the lanes of
+// pipeline.run_in_lanes started with the defaults whatever their caller had set).
+extern thread_local int t_arith, t_tune_path, t_tune_hooks, t_emd_grid, t_emd_hooks, t_pose_seeded, t_fps_legacy, t_render_blend;
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline long long ceil_div64(long long a, long long b) { return (a + b - 1) / b; }

@@ -19,7 +19,7 @@ static std::string g_err;
 // per-thread override.  Every entry point reads the mode ONCE and hands it down, so a change made
 // by another thread never splits one call between two modes.
 static std::atomic<int> g_arith{GENPC_ARITH_FMA};
-static thread_local int t_arith = -1;
+thread_local int t_arith = -1;
 
 struct Slot {
     void *ptr = nullptr;
@@ -186,6 +186,22 @@ GENPC_API int genpc_set_arith_thread(int mode)
 }
 
 GENPC_API int genpc_get_arith(void) { return genpc::arith_mode(); }
+
+GENPC_API int genpc_thread_state_export(int out[8])
+{
+    using namespace genpc;
+    out[0] = t_arith; out[1] = t_tune_path; out[2] = t_tune_hooks; out[3] = t_emd_grid; out[4] = t_emd_hooks;
+    out[5] = t_pose_seeded; out[6] = t_fps_legacy; out[7] = t_render_blend;
+    return 8;
+}
+
+GENPC_API int genpc_thread_state_import(const int in[8])
+{
+    using namespace genpc;
+    t_arith = in[0]; t_tune_path = in[1]; t_tune_hooks = in[2]; t_emd_grid = in[3]; t_emd_hooks = in[4];
+    t_pose_seeded = in[5]; t_fps_legacy = in[6]; t_render_blend = in[7];
+    return 8;
+}
 
 GENPC_API int genpc_release_workspace(void)
 {

@@ -663,7 +663,7 @@ __global__ __launch_bounds__(kEBlock) void emd_grad_kernel(long long total, int 
 
 }  // namespace genpc
 
-namespace genpc { static thread_local int t_emd_grid = -1, t_emd_hooks = 0; }
+namespace genpc { thread_local int t_emd_grid = -1, t_emd_hooks = 0; }
 
 /* Bid kernel selection for tests and A/B (thread-local like genpc_nn_tune): 1 the cell-sorted culled bid (emd_grid.hip),
  * 0 the tiled bid over all objects (emd_bid_kernel), < 0 the default (culled when eps >= 0 and n >= 4096 or B n >= 65536:
@@ -719,7 +719,10 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     {
         static const int env_auction = tune_env("GENPC_EMD_AUCTION", -1, "EMD: 1 all rounds in one launch (threads own the points) / 0 a launch per round step (-1 = pick)");
         static const bool noseed_a = tune_env("GENPC_EMD_NOSEED", 0, "EMD: 1 = no seeds from the previous bid (tiled bid only; disables the culled bid)") != 0;
-        const bool want = t_emd_grid >= 0 ? t_emd_grid == 2 : (env_auction >= 0 ? env_auction != 0 : true);
+        // (default: from 8192 points per call on -- measured in one process against the launch-per-round path, 50 rounds:
+        // 13 x 16384 2.50 -> 1.67 ms, 4 x 16384 1.30 -> 1.14, 64 x 2048 1.52 -> 1.33, 4 x 4096 0.88 -> 0.82, 1 x 16384 0.995 ->
+        // 0.96, 1 x 8192 0.90 -> 0.89; a single small cloud loses: 1 x 2048 0.72 -> 0.77, 1 x 512 0.62 -> 0.66)
+        const bool want = t_emd_grid >= 0 ? t_emd_grid == 2 : (env_auction >= 0 ? env_auction != 0 : total >= 8192);
         if (want && eps >= 0.0f && !noseed_a && !(t_emd_hooks & 1)) {
             const int rc = launch_emd_auction(b, n, xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_increments, max_increments,
                                               max_idx, eps, iters, arith_mode() != 0 ? 1 : 0, st, t_emd_grid == 2);
@@ -807,7 +810,15 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     // 1 x 16384 1.61 -> 1.80: with ~1000-2000 bidders left per round one block walking the list is
     // slower than 64 -- so only for small clouds or many of them)
     static const int env_rf = tune_env("GENPC_EMD_RESOLVE_FROM", -1, "EMD: round from which a single block per cloud resolves (-1 = pick)");
-    const int resolve_from = env_rf >= 0 ? env_rf : ((n <= 4096 || b >= 8) ? 4 : 0x7fffffff);
+    // ... unless most points keep bidding (a partial scan against its ground truth: thousands of bidders per cloud in every
+    // round -- the single block took 70 us per round at 13 x 16384, profiles/r04_emd_B13_16384_scans.json): what the last
+    // call of this shape left in the feedback word (emd_auction.hip) decides
+    bool heavy = false;
+    {
+        volatile int *fb = emd_feedback_slot(b, n, false);
+        heavy = fb != nullptr && (long long)*fb * 100 > (long long)n * 35;
+    }
+    const int resolve_from = env_rf >= 0 ? env_rf : (((n <= 4096 || b >= 8) && !heavy) ? 4 : 0x7fffffff);
     int GL = ceil_div(n, kEBlock);          // list-walking kernels
     if (GL > 64) GL = 64;
 
@@ -908,6 +919,21 @@ extern "C" __attribute__((visibility("default"))) int genpc_debug_emd_bid_occupa
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, genpc::emd_bid_kernel<1, 1, 1024, 1>, genpc::kEBlock, 0);
     return nb;
+}
+
+/* CalcDist alone (emd_cuda.cu:217-226): dist[B,n] = |xyz1[j] - xyz2[assignment[j]]|^2 for a caller that holds an
+ * assignment (the one-launch forward folds this step into its last round; this entry is what bench.py measures row a8 with). */
+GENPC_API int genpc_emd_calc_dist(int b, int n, const float *xyz1, const float *xyz2, const int *assignment, float *dist, void *stream)
+{
+    using namespace genpc;
+    if (b <= 0 || n <= 0) return 1;
+    const long long total = (long long)b * n;
+    const unsigned blocks = (unsigned)ceil_div64(total, kEBlock);
+    if (arith_mode() != 0)
+        hipLaunchKernelGGL((emd_calc_dist_kernel<1>), dim3(blocks), dim3(kEBlock), 0, (hipStream_t)stream, total, n, xyz1, xyz2, dist, assignment);
+    else
+        hipLaunchKernelGGL((emd_calc_dist_kernel<0>), dim3(blocks), dim3(kEBlock), 0, (hipStream_t)stream, total, n, xyz1, xyz2, dist, assignment);
+    return check(hipGetLastError(), "emd_calc_dist_kernel launch") ? 1 : 0;
 }
 
 GENPC_API int genpc_emd_backward(int b, int n, const float *xyz1, const float *xyz2, float *gradxyz,

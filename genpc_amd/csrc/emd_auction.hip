@@ -48,9 +48,36 @@ constexpr float kAU16 = 9.5367431640625e-7f;      // 16 u
 constexpr int kATwoPassRows = 25;
 constexpr unsigned kAStampBits = 14, kAWhoBits = 18;   // chain record: inc << 32 | stamp << 18 | bidder
 constexpr unsigned kAStampPeriod = (1u << kAStampBits) - 1u;
+// per-cloud control block, 16 words (one 128-byte line) per item: lines 0..7 the arrival counters of the eight workgroup
+// classes (bx % 8: an XCD each when the runtime deals workgroups round-robin), lines 8..15 their release words
+// (epoch | abort << 32), line 16 the top counter, line 17 the number of bidders left
+constexpr int kCtrlWords = 18 * 16;
 
 template <class T> __device__ __forceinline__ T ald(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void ast(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// merge_top2 (emd.h) for indices that carry a payload: position << 32 | object index; ties keep the lower POSITION (any
+// choice does: an exact tie for first place is settled by the tie path, the second's identity only seeds the next search)
+__device__ __forceinline__ void merge_top2_64(float &b, float &bb, long long &bi, long long &bbi, float ob, float obb, long long oi, long long obi)
+{
+    float nb2;
+    long long nbi;
+    if (b > ob) {
+        nb2 = fmaxf(bb, ob);
+        nbi = ob > bb ? oi : bbi;
+    } else if (ob > b) {
+        nb2 = fmaxf(obb, b);
+        nbi = b > obb ? bi : obi;
+    } else {
+        nb2 = b;
+        nbi = ((unsigned long long)oi < (unsigned long long)bi) ? bi : oi;
+    }
+    const bool take = ob > b || (ob == b && (unsigned long long)oi < (unsigned long long)bi);
+    bi = take ? oi : bi;
+    b = fmaxf(b, ob);
+    bb = nb2;
+    bbi = nbi;
+}
 
 struct __attribute__((aligned(16))) F3A { float x, y, z; };      // the coordinates of a sorted entry as one 12-byte load
 
@@ -76,7 +103,7 @@ struct EmdAuction {
     float *bid_increments, *max_increments, *dist;
     unsigned long long *chain_head, *chain_next;
     int *chain_cnt, *arrived;
-    unsigned long long *ctrl;               // per cloud 32 words: [0] barrier (arrivals | abort << 32), [16] bidders left
+    unsigned long long *ctrl;               // per cloud kCtrlWords words on 128-byte lines: see cloud_barrier
     int *status;                            // sticky: != 0 once a call gave up (genpc_emd_status)
     unsigned spin_limit;
     unsigned long long *timeline;           // debug (GENPC_EMD_TIMELINE=1): 100 MHz stamps of workgroup 0, 8 per round, 64 rounds
@@ -88,26 +115,39 @@ __global__ __launch_bounds__(kABlock) void emd_auction_init_kernel(int b, int n,
 {
     const int t = blockIdx.x * kABlock + threadIdx.x;
     if (t < b * n) { chain_head[t] = 0ull; chain_cnt[t] = 0; arrived[t] = 0; }
-    if (t < b * 32) ctrl[t] = (t & 31) == 16 ? (unsigned long long)n : 0ull;
+    if (t < b * kCtrlWords) ctrl[t] = (t % kCtrlWords) == 17 * 16 ? (unsigned long long)n : 0ull;
 }
 
-// all threads of the workgroup; false once the call is being abandoned
-__device__ __forceinline__ bool cloud_barrier(unsigned long long *word, unsigned target, unsigned spin_limit, int *s_flag)
+// Barrier among the G workgroups of one cloud; all threads of the workgroup call it; false once the call is being abandoned.
+// Two levels, no polling on a word that is also arrived at: a workgroup arrives at its class's counter (class = bx % 8;
+// monotone counters, `epoch` = the barrier's ordinal from 1); the last of a class arrives at the top counter; the last
+// there stores the epoch to the eight release words; everybody polls ITS class's release word.  (One word for arrivals and
+// polls cost 35 ns per arrival: 512 workgroups, 18 us per barrier -- the pollers' loads queue in front of the atomics.)
+__device__ __forceinline__ bool cloud_barrier(unsigned long long *ctrl, int bx, int G, unsigned epoch, unsigned spin_limit, int *s_flag)
 {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's stores and atomics have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long v = __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+        const int cls = bx & 7, ncls = G < 8 ? G : 8;
+        const unsigned size = (unsigned)((G - cls + 7) >> 3);
+        unsigned long long *rel = ctrl + (8 + cls) * 16;
+        const unsigned long long v = __hip_atomic_fetch_add(ctrl + cls * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+        if (v == (unsigned long long)size * epoch) {
+            const unsigned long long t = __hip_atomic_fetch_add(ctrl + 16 * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+            if (t == (unsigned long long)ncls * epoch)
+                for (int c = 0; c < ncls; c++) __hip_atomic_fetch_max(ctrl + (8 + c) * 16, (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         unsigned spins = 0;
-        while ((unsigned)v < target && (v >> 32) == 0ull) {
-            __builtin_amdgcn_s_sleep(1);
-            v = ald(word);
+        unsigned long long r = ald(rel);
+        while ((unsigned)r < epoch && (r >> 32) == 0ull) {
+            __builtin_amdgcn_s_sleep(2);
+            r = ald(rel);
             if (++spins > spin_limit) {
-                __hip_atomic_fetch_or(word, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v |= 1ull << 32;
+                for (int c = 0; c < ncls; c++) __hip_atomic_fetch_or(ctrl + (8 + c) * 16, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                r |= 1ull << 32;
             }
         }
-        *s_flag = (v >> 32) != 0ull ? 1 : 0;
+        *s_flag = (r >> 32) != 0ull ? 1 : 0;
     }
     __syncthreads();
     const int f = *s_flag;
@@ -151,8 +191,8 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
     float *PS = a.price_s + base;
     const int *__restrict__ ST = a.start + (size_t)batch * (a.cells_max + 1);
     const int *__restrict__ PO = a.pos_of + base;
-    unsigned long long *bar = a.ctrl + (size_t)batch * 32;
-    int *ucnt = (int *)(a.ctrl + (size_t)batch * 32 + 16);
+    unsigned long long *bar = a.ctrl + (size_t)batch * kCtrlWords;
+    int *ucnt = (int *)(bar + 17 * 16);
     const EGridHdr H = a.hdr[batch];
     const int gx = H.g[0], gy = H.g[1], gz = H.g[2];
     const float h = H.h, inf = __builtin_inff();
@@ -171,7 +211,7 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
         if (it > 0 && stamp == 1u) {
             // the stamp wraps: hand the head words back clean (object j's words by thread j), once per 16383 rounds
             ast(&a.chain_head[base + j], 0ull);
-            ok = cloud_barrier(bar, (unsigned)G * ++nbar, a.spin_limit, &s_flag);
+            ok = cloud_barrier(bar, bx, G, ++nbar, a.spin_limit, &s_flag);
             if (!ok) break;
         }
         const bool tl = a.timeline != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && it < 64;
@@ -210,7 +250,7 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
                 const float x1 = X1[(size_t)jj * 3 + 0], y1 = X1[(size_t)jj * 3 + 1], z1 = X1[(size_t)jj * 3 + 2];
                 const int pa = s_out[owner][1], pc = s_out[owner][2];
                 float best = -1e9f, better = -1e9f;
-                int best_p = -1, better_p = -1;
+                long long best_p = -1, better_p = -1;      // position << 32 | object index (the index rides along: no dependent load after the merge)
                 float seed = -1e9f;
                 bool seeded = false;
                 int mode = 0;                           // 0 bid, 1 collect the objects tied for first place, 2 proxy scan
@@ -250,10 +290,11 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
                         if (mode == 0) {
                             const bool gt = d > best;
                             const bool gt2 = !gt && d > better;
-                            better_p = gt ? best_p : (gt2 ? ps : better_p);
+                            const long long pk = ((long long)ps << 32) | (unsigned)__float_as_int(o.w);
+                            better_p = gt ? best_p : (gt2 ? pk : better_p);
                             better = __builtin_amdgcn_fmed3f(d, best, better);
                             best = fmaxf(best, d);
-                            best_p = gt ? ps : best_p;
+                            best_p = gt ? pk : best_p;
                         } else if (d == best) {
                             // an object that ties for first place: its key in the reference's thread-major scan order
                             // (emd_cuda.cu:108-118,136-139,165-173: the candidate the scan meets first is reported)
@@ -415,10 +456,10 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
                 if (tl && k0 == 0) a.timeline[it * 16 + 10] = wall_clock64();
                 for (int off = 1; off < LPB; off <<= 1) {
                     const float ob = __shfl_xor(best, off, kWave), obb = __shfl_xor(better, off, kWave);
-                    const int oi = __shfl_xor(best_p, off, kWave), obi = __shfl_xor(better_p, off, kWave);
-                    merge_top2(best, better, best_p, better_p, ob, obb, oi, obi);
+                    const long long oi = __shfl_xor(best_p, off, kWave), obi = __shfl_xor(better_p, off, kWave);
+                    merge_top2_64(best, better, best_p, better_p, ob, obb, oi, obi);
                 }
-                int best_i = best_p >= 0 ? __float_as_int(S[best_p].w) : -1;
+                int best_i = best_p >= 0 ? (int)(best_p & 0xffffffffll) : -1;
                 if (tl && k0 == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.timeline[it * 16 + 11] = wall_clock64(); }
                 const bool tie = active && (best == better);
                 if (__any(tie)) {
@@ -437,7 +478,7 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
                     }
                     if (tie) {
                         best_i = (int)(tie_key & 0xffffffffu);
-                        best_p = PO[best_i];
+                        best_p = ((long long)PO[best_i] << 32) | (unsigned)best_i;
                     }
                 }
                 if (active && sub == 0) {
@@ -450,14 +491,14 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
                     ast(&a.chain_next[base + jj], old);
                     atomicAdd(&a.chain_cnt[base + best_i], 1);
                     int *out = s_out[owner];
-                    out[0] = best_i; out[1] = best_p; out[2] = better_p; out[3] = __float_as_int(inc);
+                    out[0] = best_i; out[1] = (int)(best_p >> 32); out[2] = (int)(better_p >> 32); out[3] = __float_as_int(inc);
                     out[4] = (int)(unsigned)(old & 0xffffffffull); out[5] = (int)(unsigned)(old >> 32);
                 }
                 if (tl && k0 == 0) a.timeline[it * 16 + 12] = wall_clock64();
             }
         }
         if (tl) a.timeline[it * 16 + 2] = wall_clock64();
-        ok = cloud_barrier(bar, (unsigned)G * ++nbar, a.spin_limit, &s_flag);
+        ok = cloud_barrier(bar, bx, G, ++nbar, a.spin_limit, &s_flag);
         if (!ok) break;
         if (tl) a.timeline[it * 16 + 3] = wall_clock64();
         // ---------------- GetMax + Assign (emd_cuda.cu:181-215) ----------------
@@ -540,7 +581,7 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
         }
         if (tl) a.timeline[it * 16 + 4] = wall_clock64();
         if (last) break;
-        ok = cloud_barrier(bar, (unsigned)G * ++nbar, a.spin_limit, &s_flag);
+        ok = cloud_barrier(bar, bx, G, ++nbar, a.spin_limit, &s_flag);
         if (!ok) break;
         if (tl) a.timeline[it * 16 + 5] = wall_clock64();
     }
@@ -619,7 +660,7 @@ size_t emd_auction_bytes(int b, int n)
 {
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t total = (size_t)b * n;
-    return 256 /* status */ + al((size_t)b * 32 * 8) + al((size_t)b * sizeof(EGridHdr)) + al((size_t)b * (kEGMaxCells + 1) * sizeof(int)) +
+    return 256 /* status */ + al((size_t)b * kCtrlWords * 8) + al((size_t)b * sizeof(EGridHdr)) + al((size_t)b * (kEGMaxCells + 1) * sizeof(int)) +
            al(total * sizeof(float4)) + al(total * sizeof(float)) + 2 * al(total * sizeof(int)) + 2 * al(total * 8) + 2 * al(total * sizeof(int));
 }
 
@@ -667,11 +708,11 @@ int launch_emd_auction(int b, int n, const float *xyz1, const float *xyz2, float
     const int G = (int)((long long)n * K / kABlock), wgs = b * G;
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t total = (size_t)b * n;
-    char *ws = (char *)workspace(29, emd_auction_bytes(b, n), st, nullptr, 256);
+    char *ws = (char *)workspace(31, emd_auction_bytes(b, n), st, nullptr, 256);
     if (!ws) return 0;
     int *status = (int *)ws;
     char *p = ws + 256;
-    unsigned long long *ctrl = (unsigned long long *)p; p += al((size_t)b * 32 * 8);
+    unsigned long long *ctrl = (unsigned long long *)p; p += al((size_t)b * kCtrlWords * 8);
     EGridHdr *hdr = (EGridHdr *)p; p += al((size_t)b * sizeof(EGridHdr));
     int *start = (int *)p; p += al((size_t)b * (kEGMaxCells + 1) * sizeof(int));
     float4 *sorted = (float4 *)p; p += al(total * sizeof(float4));
@@ -683,7 +724,10 @@ int launch_emd_auction(int b, int n, const float *xyz1, const float *xyz2, float
     int *chain_cnt = (int *)p; p += al(total * sizeof(int));
     int *arrived = (int *)p;
     if (!persist_reserve(wgs, cap, st)) return -1;
-    hipLaunchKernelGGL(emd_auction_init_kernel, dim3(ceil_div((int)total, kABlock)), dim3(kABlock), 0, st, b, n, ctrl, chain_head, chain_cnt, arrived);
+    {
+        const size_t items = total > (size_t)b * kCtrlWords ? total : (size_t)b * kCtrlWords;      // (a 256-point cloud has fewer points than control words)
+        hipLaunchKernelGGL(emd_auction_init_kernel, dim3(ceil_div((int)items, kABlock)), dim3(kABlock), 0, st, b, n, ctrl, chain_head, chain_cnt, arrived);
+    }
     static const int env_ppc = tune_env("GENPC_EMD_GRID_PPC_X10", 20, "culled EMD bid: target objects per cell x 10");
     int target = (int)((long long)n * 10 / (env_ppc > 0 ? env_ppc : 20));
     target = target < 8 ? 8 : (target > kEGMaxCells * 3 / 4 ? kEGMaxCells * 3 / 4 : target);
@@ -703,7 +747,7 @@ int launch_emd_auction(int b, int n, const float *xyz1, const float *xyz2, float
     static const int env_spin = tune_env("GENPC_EMD_AUCTION_SPIN", 1 << 21, "one-launch EMD: polls of a barrier before the call is abandoned");
     a.spin_limit = (unsigned)env_spin;
     static const int env_tl = tune_env("GENPC_EMD_TIMELINE", 0, "one-launch EMD: 1 = workgroup 0 stamps the phases of the first 64 rounds (genpc_debug_emd_timeline)");
-    a.timeline = env_tl ? (unsigned long long *)workspace(30, 64 * 16 * 8, nullptr, nullptr, 64 * 16 * 8) : nullptr;
+    a.timeline = env_tl ? (unsigned long long *)workspace(32, 64 * 16 * 8, nullptr, nullptr, 64 * 16 * 8) : nullptr;
     if (fma) hipLaunchKernelGGL((emd_auction_kernel<1>), dim3(wgs), dim3(kABlock), 0, st, a);
     else hipLaunchKernelGGL((emd_auction_kernel<0>), dim3(wgs), dim3(kABlock), 0, st, a);
     persist_commit(wgs, st);
@@ -717,7 +761,7 @@ int launch_emd_auction(int b, int n, const float *xyz1, const float *xyz2, float
 GENPC_API int genpc_emd_status(int reset, void *stream)
 {
     using namespace genpc;
-    int *dev = (int *)workspace(29, 256, (hipStream_t)stream, nullptr, 256);
+    int *dev = (int *)workspace(31, 256, (hipStream_t)stream, nullptr, 256);
     if (!dev) return -1;
     if (!check(hipStreamSynchronize((hipStream_t)stream), "genpc_emd_status sync")) return -1;
     int v = 0;
@@ -730,7 +774,7 @@ GENPC_API int genpc_emd_status(int reset, void *stream)
 extern "C" __attribute__((visibility("default"))) int genpc_debug_emd_timeline(unsigned long long *out)
 {
     using namespace genpc;
-    unsigned long long *dev = (unsigned long long *)workspace(30, 64 * 16 * 8, nullptr, nullptr, 64 * 16 * 8);
+    unsigned long long *dev = (unsigned long long *)workspace(32, 64 * 16 * 8, nullptr, nullptr, 64 * 16 * 8);
     if (!dev || hipDeviceSynchronize() != hipSuccess) return 0;
     return hipMemcpy(out, dev, 64 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 1 : 0;
 }

@@ -46,6 +46,8 @@ struct FpsJobs {
     int n[kFMaxJobs], k[kFMaxJobs], W[kFMaxJobs];
     int slot0[kFMaxJobs];        // first slot of the job in the slot array (slots are per (job, parity, workgroup))
     int stat0;                   // index of the launch's first cloud in the call (statistics)
+    int legacy_pivot;            // test hook (genpc_fps_tune): the workers read the pivot as per-lane LDS broadcasts again -- the
+                                 // form that drew wrong samples next to f16 MFMAs on another stream (tests/test_gpu_concurrency.py)
 };
 
 template <int FMA>
@@ -195,6 +197,12 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
 {
     __shared__ float s_c[kFWaves][kFT][5];     // per worker wave: dist, idx (bits), x, y, z of its kFT best
     __shared__ float s_piv[kFBatch][4];        // the round's pivots: x, y, z, idx (bits)
+    // ... and the same pivots as three SELF-TAGGED 8-byte granules {x, tag} {y, tag} {z, tag}, tag = round * 64 + slot + 1: what
+    // the workers read.  A worker takes a pivot only when all three tags of ITS OWN copy are the expected one and re-reads
+    // otherwise, so a lane that is handed the previous occupant of the slot (round 4: lanes 48-63 next to another stream's f16
+    // MFMAs, mechanism unknown; round 5: a wrong sample again with the pivot taken through scalar registers, next to the
+    // one-launch auction) cannot lower its minima by it -- the hand-off no longer depends on what caused that.
+    __shared__ uint2 s_pivt[kFBatch][3];
     __shared__ unsigned s_prog;                // round << 16 | flags | pivots of that round published so far
     const int job = blockIdx.y, wg = blockIdx.x, t = threadIdx.x;
     const int W = jobs.W[job];
@@ -237,9 +245,27 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
                     // loads; all extra samples were points held by lanes 48-63).  The mechanism is not established (an isolated
                     // probe of broadcast reads + packed adds under the same load, tools/lds_probe.hip, shows nothing); with the
                     // value in SGPRs nine of nine stress runs are clean.  tests/test_gpu_concurrency.py keeps watch.
-                    const float cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_piv[applied][0])));
-                    const float cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_piv[applied][1])));
-                    const float cz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_piv[applied][2])));
+                    float cx, cy, cz;
+                    if (jobs.legacy_pivot) {       // the pre-fix form, kept reachable so that the trigger stays reproducible
+                        cx = s_piv[applied][0]; cy = s_piv[applied][1]; cz = s_piv[applied][2];
+                    } else {
+                        const unsigned want = (round & 0x3ffffffu) * 64u + applied + 1u;
+                        uint2 g0, g1, g2;
+                        int tries = 0;
+                        bool good;
+                        do {
+                            asm volatile("" ::: "memory");      // (re-read from LDS on every trip)
+                            const unsigned long long *gp = (const unsigned long long *)&s_pivt[applied][0];
+                            const unsigned long long w0 = __hip_atomic_load(gp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const unsigned long long w1 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const unsigned long long w2 = __hip_atomic_load(gp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            g0 = make_uint2((unsigned)w0, (unsigned)(w0 >> 32));
+                            g1 = make_uint2((unsigned)w1, (unsigned)(w1 >> 32));
+                            g2 = make_uint2((unsigned)w2, (unsigned)(w2 >> 32));
+                            good = g0.y == want && g1.y == want && g2.y == want;
+                        } while (!__all(good) && ++tries < 4096);
+                        cx = __uint_as_float(g0.x); cy = __uint_as_float(g1.x); cz = __uint_as_float(g2.x);
+                    }
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         const float dd = sqdist_f<FMA>(px[r] - cx, py[r] - cy, pz[r] - cz);
@@ -292,6 +318,9 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
     if (lane == 0) {
         s_piv[0][0] = X[0]; s_piv[0][1] = X[1]; s_piv[0][2] = X[2];
         s_piv[0][3] = __int_as_float(0);
+        s_pivt[0][0] = make_uint2(__float_as_uint(X[0]), 1u);      // round 0, slot 0
+        s_pivt[0][1] = make_uint2(__float_as_uint(X[1]), 1u);
+        s_pivt[0][2] = make_uint2(__float_as_uint(X[2]), 1u);
         if (wg == 0) out[0] = 0;
         prog_store(&s_prog, (0u << 16) | kProgDone | (k <= 1 ? kProgFinal : 0u) | 1u);
     }
@@ -395,6 +424,10 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
             if (lane == 0) {
                 s_piv[mm][0] = qx; s_piv[mm][1] = qy; s_piv[mm][2] = qz;
                 s_piv[mm][3] = __int_as_float(mi);
+                const unsigned tag = (round & 0x3ffffffu) * 64u + (unsigned)mm + 1u;
+                s_pivt[mm][0] = make_uint2(__float_as_uint(qx), tag);
+                s_pivt[mm][1] = make_uint2(__float_as_uint(qy), tag);
+                s_pivt[mm][2] = make_uint2(__float_as_uint(qz), tag);
             }
             mm++;
             if (s + mm >= k || mm == kFBatch) break;
@@ -466,7 +499,19 @@ static int fps_blocks_per_cu(int cls)
     return nb;
 }
 
+thread_local int t_fps_legacy = 0;
+
 }  // namespace genpc
+
+/* Test hook (applies to the calling host thread; returns the previous setting): 1 = the sampling's workers read the
+ * round's pivots as per-lane LDS broadcasts -- the round-4 form that silently drew a sample a step early while another
+ * stream ran v_mfma_f32_32x32x16_f16 --, 0 = through scalar registers (the shipped form). */
+GENPC_API int genpc_fps_tune(int legacy_pivot)
+{
+    const int prev = genpc::t_fps_legacy;
+    genpc::t_fps_legacy = legacy_pivot ? 1 : 0;
+    return prev;
+}
 
 GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *const *xyz, int *const *out_idx, void *stream)
 {
@@ -511,6 +556,7 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
         // a launch takes up to kFMaxJobs clouds; its grid is (largest W) x (clouds), all of it resident together
         FpsJobs jobs = {};
         jobs.stat0 = j0 < 32 ? j0 : 32;
+        jobs.legacy_pivot = t_fps_legacy;
         int nj = 0, wmax = 0, rmax = 1;
         while (j0 + nj < c && nj < kFMaxJobs) {
             const int j = j0 + nj;

@@ -8,10 +8,14 @@ called with tensors it skips the file layer.  It optimises the reference's objec
 ``mask_loss + 3 * (partial_l1(pts, partial) + 0.5 partial_l1(partial, pts)) + 1e-3 |RR^T - I|_F``
 (:329-333,543-546).  ``mask_loss`` (30 MSE + BCE + 10 Dice on sigmoid soft masks of the
 statistically normalised images, :204-217,261-311) is the reference's own torch code
-restated (and pinned to it: tests/golden/ref_py_mask_loss.npz); the IMAGES are not the
-reference's: it draws them with pytorch3d's CUDA-only Pulsar renderer (absent, unpinned), this build
-with its own differentiable colour splat -- occupancy times the coverage-weighted mean colour of the
-points over a pixel --, same camera and radii (include/genpc_hip.h).  The whole multi-start loop
+restated (and pinned to it: tests/golden/ref_py_mask_loss.npz).  The IMAGES: the reference draws
+them with pytorch3d's CUDA-only Pulsar renderer (absent here, unpinned); this build restates
+Pulsar's PUBLISHED blending function -- a softmax in depth over the discs covering a pixel, with
+the reference's gamma 1e-2, znear 1e-4, zfar 5, background 0 -- on its own disc footprint and
+camera (``render_tune(1)``, the default since round 5; what of it is from memory is listed in
+oracle/genpc_oracle_geom.c and include/genpc_hip.h).  ``render_tune(0)`` selects the coverage
+splat of rounds 2-4 (occupancy times the coverage-weighted mean colour: order-independent,
+front and back surfaces averaged).  The whole multi-start loop
 runs on the device without host synchronisation (7 launches per Adam step; 4 with
 ``cd_only=True``).
 """
@@ -71,10 +75,16 @@ def _col(colors, like, name):
     return c
 
 
+def render_tune(blend):
+    """The renderer of the mask term for the calling thread: 1 Pulsar's blending function (default), 0 the coverage
+    splat, < 0 the default again.  Returns the previous setting (-1 = default)."""
+    return int(_L.genpc_render_tune(int(blend)))
+
+
 def splat_image(points, radius, render_size=224, colors=None):
-    """The library's colour splat of a cloud [N,3] (colours [N,3] in [0,1], None = white)
-    -> [render_size, render_size, 3] in [0,1] (what stands in for render_reference_image,
-    diff_obj_pose.py:108-134; NOT Pulsar's blend, see include/genpc_hip.h)."""
+    """The library's render of a cloud [N,3] (colours [N,3] in [0,1], None = white)
+    -> [render_size, render_size, 3] in [0,1] (render_reference_image, diff_obj_pose.py:108-134):
+    Pulsar's blending function by default, the coverage splat under render_tune(0); include/genpc_hip.h."""
     pts = points.contiguous().float()
     _lib.check_tensors((("points", pts),))
     col = _col(colors, pts, "colors")

@@ -33,6 +33,7 @@ from .ScaleAdapter import ScaleAdapter
 from .fps import fps_sampling
 from .metric import evaluate_scans
 from . import reg_xyz
+from . import _lib
 
 
 def default_cfg(device="cuda", view_num=1024):
@@ -111,9 +112,11 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
     if side is not None:
         side.wait_stream(main)                      # the inputs are the main stream's
         box = {}
+        state = _lib.thread_state()                 # (thread-local library modes and grad mode: the side thread gets the caller's)
 
         def run():
             try:
+                _lib.apply_thread_state(state)
                 with torch.cuda.device(partial_xyz.device), torch.cuda.stream(side):
                     box["out"] = stage1()
             except BaseException as e:              # re-raised on the caller's thread
@@ -179,8 +182,11 @@ def run_in_lanes(fn, items, lanes, device):
     nxt = [0]
     lock = threading.Lock()
 
+    state = _lib.thread_state()          # the caller's per-thread modes (arithmetic, kernel choices, grad mode) travel with the work
+
     def lane(li):
         try:
+            _lib.apply_thread_state(state)
             with torch.cuda.device(dev):
                 st = _lane_stream(dev, li)
                 st.wait_stream(caller)                  # the inputs are the caller's

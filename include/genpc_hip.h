@@ -38,6 +38,11 @@ const char *genpc_last_error(void);       /* last HIP error string, "" if none *
 int genpc_set_arith(int mode);            /* process default; returns the previous one */
 int genpc_set_arith_thread(int mode);     /* calling thread only, < 0: follow the default; returns the previous override */
 int genpc_get_arith(void);
+/* The calling host thread's modes -- genpc_set_arith_thread, genpc_nn_tune, genpc_emd_tune, genpc_pose_tune, genpc_fps_tune --
+ * as eight ints, and their restoration in another thread: a caller that hands work to threads of its own (the lanes of
+ * genpc_amd/pipeline.py) exports before it starts them and imports at the top of each.  Return the number of ints used. */
+int genpc_thread_state_export(int out[8]);
+int genpc_thread_state_import(const int in[8]);
 /* The table of tuning / A-B switches: every switch is an environment variable GENPC_<NAME>, read once per process
  * through one function (csrc/common.hip: tune_env) that records it with its default and a line of documentation; none
  * changes a result.  Writes "NAME=value (default d) -- what" lines for the switches consulted so far into buf (at most
@@ -141,6 +146,9 @@ int genpc_emd_status(int reset, void *stream);
  * of their search boxes, out[2] rows kept by the bound, out[3] objects tested, out[4] exact (fp64) evaluations, out[5]
  * exact first-place ties (full re-scan), out[6] bidders without seeds (probe).  Synchronises `stream`; reset != 0 zeroes. */
 int genpc_emd_stats(unsigned long long out[8], int reset, void *stream);
+
+/* The CalcDist step alone (emd_cuda.cu:217-226): dist[B,n] = |xyz1[j] - xyz2[assignment[j]]|^2 (0 where assignment < 0). */
+int genpc_emd_calc_dist(int b, int n, const float *xyz1, const float *xyz2, const int *assignment, float *dist, void *stream);
 
 /* Replaces emd_cuda_backward (emd_cuda.cu:302-316, emd.backward in
  * emd.cpp:19-23,28): gradxyz[B,n,3] (caller-zeroed) += 2*graddist*(xyz1-xyz2[idx]). */
@@ -298,6 +306,16 @@ int genpc_pose_loss_grad(int nc, const float *v, const float *vert_col, const fl
                          float mask_weight, float radius, int render_size, float *loss_out,
                          float *grad, void *stream);
 
+/* The renderer of the mask term (genpc_splat_image, genpc_pose_loss_grad, genpc_pose_optimize_batch), per calling host thread:
+ * 1 = Pulsar's published blending function (Lassner & Zollhoefer, CVPR 2021, eq. 1-2) with the reference's arguments
+ *     (diff_obj_pose.py:126-131,428-433: gamma 1e-2, znear 1e-4, zfar 5, bg 0): over the discs covering a pixel
+ *       I_ch = sum_i a_i e_i c_i,ch / (B + sum_i a_i e_i),  e_i = exp(z_i / gamma),  z_i = (zfar - Zv_i) / (zfar - znear),  B = exp(1e-10 / gamma)
+ *     with the coverage a_i and the camera of the splat above -- a near surface hides a far one.  THE DEFAULT.  What of it is
+ *     from memory (pytorch3d is absent and unpinned) is listed in oracle/genpc_oracle_geom.c;
+ * 0 = the coverage splat described above (order-independent: front and back surfaces are averaged; rounds 2-4);
+ * < 0 = back to the default (environment GENPC_RENDER_BLEND).  Returns the previous setting (-1 = default). */
+int genpc_render_tune(int blend);
+
 /* Nearest-neighbour path of genpc_pose_optimize_batch, for tests and A/B (applies to the calling host thread): 1 the
  * seeded cell search from the second Adam step on (csrc/nn_seeded.hip: every query starts from last step's answer and
  * searches only the ball it leaves; grids built once per call, the moving cloud's in its rest frame), 0 the brute-force
@@ -389,6 +407,10 @@ int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, void *stream)
  * xyz[C] (device pointers to [n_j,3]), out_idx[C] (device pointers to [k_j]).                    */
 int genpc_fps_multi(int c, const int *n, const int *k, const float *const *xyz,
                     int *const *out_idx, void *stream);
+/* Test hook (calling host thread; returns the previous setting): 1 = the workers of the sampling read the pivots as
+ * per-lane LDS broadcasts, the round-4 form that drew a wrong sample next to f16 MFMAs on another stream (kept reachable
+ * so that tests/test_gpu_concurrency.py can show the trigger); 0 = through scalar registers (shipped). */
+int genpc_fps_tune(int legacy_pivot);
 /* Diagnostics: rounds[j] (host, c <= 32) = inter-workgroup exchanges cloud j of the last
  * genpc_fps_multi call on this stream took (one exchange yields several samples).  Synchronises.  */
 int genpc_fps_stats(int c, int *rounds, void *stream);

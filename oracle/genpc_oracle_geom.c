@@ -473,10 +473,84 @@ ORACLE_API void oracle_pose_optimize_cd(int nc, const float *complete, int np_, 
  * Images are [S, S, 3] (H, W, C like the reference's).
  * ---------------------------------------------------------------------- */
 #define MASK_AMAX 0.999
+/* ---- blend 1: Pulsar's blending function (PulsarPointsRenderer, diff_obj_pose.py:110-132,374-385,426-433) -------------
+ * pytorch3d is absent and unpinned; what follows restates the PUBLISHED blending function of the renderer -- Lassner &
+ * Zollhoefer, "Pulsar: Efficient Sphere-based Neural Rendering", CVPR 2021, section 3.2, eq. (1)-(2):
+ *     I = sum_i w_i c_i,   w_i = o_i d_i exp(o_i z_i / gamma) / ( exp(eps / gamma) + sum_k o_k d_k exp(o_k z_k / gamma) )
+ * over the spheres the pixel's ray meets; z_i the normalised depth of sphere i, 1 at the near plane and 0 at the far
+ * plane; d_i the weight from the normalised orthogonal distance of the ray to the sphere centre (1 at the centre, 0 at the
+ * rim); o_i the opacity; the first term of the denominator weighs the background colour.  With the reference's arguments
+ * (:126-131,428-433): gamma = 1e-2, znear = 1e-4, zfar = 5.0, bg_col = 0, radius_world = True, opacity 1 (the unified
+ * renderer's default), radii `radius` / 1.1 `radius`.  Restated here as
+ *     z_i = (zfar - Zv_i) / (zfar - znear),  Zv_i = 3 - z  (the camera of the coverage splat above)
+ *     d_i = a_i = min(0.999, max(0, 1 - r^2 / rho^2))   (the coverage of the splat above: same footprint, same camera)
+ *     I_ch = sum_i a_i e_i c_i,ch / (B + sum_i a_i e_i),  e_i = exp(z_i / gamma),  B = exp(eps / gamma), eps = 1e-10
+ * A front surface hides a back surface (0.2 world units in depth = a factor e^4 in weight), which the coverage splat
+ * (blend 0) averages.  [FROM MEMORY, not checkable here]: the exact fall-off of d_i inside the disc (taken quadratic in
+ * the normalised distance, as blend 0's coverage), the depth that enters z_i (taken at the sphere's CENTRE; Pulsar
+ * intersects the ray with the sphere: a difference of at most radius / (zfar - znear) / gamma = 0.44 in the exponent
+ * between centre and rim), eps, the perspective footprint (a disc of radius focal R / Zv; a sphere projects to an ellipse
+ * off-axis).  The STRUCTURE -- softmax in depth with the reference's gamma and planes, background term, radii in world
+ * units -- is the paper's.  Pinned to a dense torch-autograd evaluation of these formulas (tests/test_oracle_pose.py). */
+#define PULSAR_GAMMA 1e-2
+#define PULSAR_ZNEAR 1e-4
+#define PULSAR_ZFAR 5.0
+#define PULSAR_EPS 1e-10
+static int g_blend = 0;          /* 0: the coverage splat, 1: Pulsar's blending function */
+ORACLE_API int oracle_set_blend(int blend)
+{
+    const int prev = g_blend;
+    g_blend = blend ? 1 : 0;
+    return prev;
+}
+static double pulsar_z(double zv) { return (PULSAR_ZFAR - zv) / (PULSAR_ZFAR - PULSAR_ZNEAR); }
+
+/* blend 1: logt[P] = m = max(eps, max_i z_i) / gamma (the exponent every weight is taken relative to), den[P] = B' + sum a e',
+ * num[P*3] = sum a e' c with e' = exp(z_i / gamma - m), B' = exp(eps / gamma - m) */
+static void splat_accumulate_pulsar(int n, const float *pts, const float *col, double radius, int S, double *mexp, double *den,
+                                    double *num)
+{
+    const double hs = 0.5 * S;
+    for (int q = 0; q < S * S; q++) { mexp[q] = PULSAR_EPS / PULSAR_GAMMA; den[q] = 0.0; num[3 * q] = num[3 * q + 1] = num[3 * q + 2] = 0.0; }
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) for (int q = 0; q < S * S; q++) den[q] = exp(PULSAR_EPS / PULSAR_GAMMA - mexp[q]);
+        for (int i = 0; i < n; i++) {
+            const double x = pts[(size_t)i * 3 + 0], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
+            const double zv = 3.0 - z;
+            if (!(zv > 1e-4) || !(zv < 5.0)) continue;
+            const double u = hs * (1.0 + 4.0 * x / zv), v = hs * (1.0 - 4.0 * y / zv), rho = hs * 4.0 * radius / zv;
+            const double ze = pulsar_z(zv) / PULSAR_GAMMA;
+            const double cr = col ? col[(size_t)i * 3 + 0] : 1.0, cg = col ? col[(size_t)i * 3 + 1] : 1.0,
+                         cb = col ? col[(size_t)i * 3 + 2] : 1.0;
+            int c0 = (int)floor(u - rho - 0.5), c1 = (int)ceil(u + rho - 0.5);
+            int r0 = (int)floor(v - rho - 0.5), r1 = (int)ceil(v + rho - 0.5);
+            if (c0 < 0) c0 = 0;
+            if (r0 < 0) r0 = 0;
+            if (c1 > S - 1) c1 = S - 1;
+            if (r1 > S - 1) r1 = S - 1;
+            for (int r = r0; r <= r1; r++)
+                for (int c = c0; c <= c1; c++) {
+                    const double dx = c + 0.5 - u, dy = r + 0.5 - v;
+                    double a = 1.0 - (dx * dx + dy * dy) / (rho * rho);
+                    if (a <= 0.0) continue;
+                    if (a > MASK_AMAX) a = MASK_AMAX;
+                    const size_t q = (size_t)r * S + c;
+                    if (pass == 0) { if (ze > mexp[q]) mexp[q] = ze; continue; }
+                    const double w = a * exp(ze - mexp[q]);
+                    den[q] += w;
+                    num[3 * q + 0] += w * cr;
+                    num[3 * q + 1] += w * cg;
+                    num[3 * q + 2] += w * cb;
+                }
+        }
+    }
+}
+
 /* logt[P] = sum log(1 - a), den[P] = sum a, num[P*3] = sum a c  (col NULL: white) */
 static void splat_accumulate(int n, const float *pts, const float *col, double radius, int S, double *logt, double *den,
                              double *num)
 {
+    if (g_blend) { splat_accumulate_pulsar(n, pts, col, radius, S, logt, den, num); return; }
     for (int q = 0; q < S * S; q++) { logt[q] = 0.0; den[q] = 0.0; num[3 * q] = num[3 * q + 1] = num[3 * q + 2] = 0.0; }
     const double hs = 0.5 * S;
     for (int i = 0; i < n; i++) {
@@ -510,6 +584,11 @@ static void splat_accumulate(int n, const float *pts, const float *col, double r
 
 static void splat_compose(int P, const double *logt, const double *den, const double *num, double *I)
 {
+    if (g_blend) {      /* (the background term keeps the denominator positive) */
+        for (int q = 0; q < P; q++)
+            for (int ch = 0; ch < 3; ch++) I[3 * q + ch] = num[3 * q + ch] / den[q];
+        return;
+    }
     for (int q = 0; q < P; q++) {
         const double O = 1.0 - exp(logt[q]);
         for (int ch = 0; ch < 3; ch++) I[3 * q + ch] = den[q] > 0.0 ? O * num[3 * q + ch] / den[q] : 0.0;
@@ -672,11 +751,28 @@ ORACLE_API void oracle_pose_full_loss_grad(int nc, const float *v, const float *
         if (r0 < 0) r0 = 0;
         if (c1 > S - 1) c1 = S - 1;
         if (r1 > S - 1) r1 = S - 1;
-        double gu = 0, gv = 0, grho = 0;
+        double gu = 0, gv = 0, grho = 0, gze = 0;
+        const double ze = pulsar_z(zv) / PULSAR_GAMMA;
         for (int r = r0; r <= r1; r++)
             for (int c = c0; c <= c1; c++) {
                 const double dx = c + 0.5 - u, dy = r + 0.5 - vv;
                 const double a = 1.0 - (dx * dx + dy * dy) / (rho * rho);
+                if (g_blend) {
+                    /* I_ch = N_ch / D:  d I_ch / d w_i = (c_i,ch - I_ch) / D,  w_i = a_i e_i;  d w / d a = e_i (unclamped a
+                     * only), d w / d (z / gamma) = w_i (also where a is clamped: the depth still moves the weight) */
+                    if (a <= 0.0) continue;
+                    const size_t q = (size_t)r * S + c;
+                    const double e = exp(ze - logt[q]);
+                    double w = 0.0;
+                    for (int ch = 0; ch < 3; ch++) w += dLdI[3 * q + ch] * (ci[ch] - I[3 * q + ch]) / den[q];
+                    gze += w * (a > MASK_AMAX ? MASK_AMAX : a) * e;
+                    if (a >= MASK_AMAX) continue;
+                    w *= e;
+                    gu += w * 2.0 * dx / (rho * rho);
+                    gv += w * 2.0 * dy / (rho * rho);
+                    grho += w * 2.0 * (dx * dx + dy * dy) / (rho * rho * rho);
+                    continue;
+                }
                 if (a <= 0.0 || a >= MASK_AMAX) continue;        /* clamped: no gradient */
                 const size_t q = (size_t)r * S + c;
                 const double T = exp(logt[q]), O = 1.0 - T;
@@ -690,7 +786,9 @@ ORACLE_API void oracle_pose_full_loss_grad(int nc, const float *v, const float *
                 grho += w * 2.0 * (dx * dx + dy * dy) / (rho * rho * rho);
             }
         /* u = hs (1 + 4x/zv), v = hs (1 - 4y/zv), rho = hs 4 rad / zv, zv = 3 - z */
-        const double gzv = gu * (-hs * 4.0 * x / (zv * zv)) + gv * (hs * 4.0 * y / (zv * zv)) + grho * (-rho / zv);
+        /* (blend 1: z / gamma = (zfar - zv) / (zfar - znear) / gamma) */
+        const double gzv = gu * (-hs * 4.0 * x / (zv * zv)) + gv * (hs * 4.0 * y / (zv * zv)) + grho * (-rho / zv) +
+                           gze * (-1.0 / ((PULSAR_ZFAR - PULSAR_ZNEAR) * PULSAR_GAMMA));
         const double g[3] = {mask_weight * gu * hs * 4.0 / zv, mask_weight * gv * (-hs * 4.0 / zv), mask_weight * (-gzv)};
         const float *vj = v + (size_t)i * 3;
         const double l[3] = {vj[0] - center[0], vj[1] - center[1], vj[2] - center[2]};

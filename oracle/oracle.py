@@ -388,6 +388,12 @@ def _fopt(x):
     return _f(x)
 
 
+def set_blend(blend):
+    """0: the build's coverage splat; 1: Pulsar's published blending function (softmax in depth, gamma 1e-2), restated in
+    genpc_oracle_geom.c.  Applies to splat_image, pose_full_loss_grad and pose_optimize.  Returns the previous setting."""
+    return int(lib().oracle_set_blend(int(blend)))
+
+
 def splat_image(pts, radius, size, colors=None):
     """Own differentiable colour splat (genpc_oracle_geom.c, PARITY UNPINNED against Pulsar)
     -> [size, size, 3]; colors None = white."""

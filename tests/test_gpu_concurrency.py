@@ -20,6 +20,14 @@ def _run(kinds, reps):
     from genpc_amd.fps import fps_sampling_multi
     from genpc_amd import chamfer_3D
     from genpc_amd.metric import evaluate_scans
+    from genpc_amd import _lib, reg_xyz
+    from genpc_amd.DepthPrompting import DepthPrompting
+    from genpc_amd.loss_functions import emdModule
+    from genpc_amd.optim_registration.diff_obj_pose import object_pose_optimization
+    from types import SimpleNamespace
+    em = emdModule()
+    cfg = SimpleNamespace(device="cuda", fovy=49.1, res=256, cam_res=256, padding=0.15, rescale=True, point_size=1,
+                          mask_pixel_rate=3, view_num=256, distance=1.6, downsample_num=10000, removal_radius=10000)
     z = np.load(os.path.join(HERE, "golden", "scans13_fps16384.npz"))
 
     def ops(k):
@@ -30,6 +38,13 @@ def _run(kinds, reps):
             a, b = fps_sampling_multi([torch.cat([P, G[:8192]]).contiguous(), G], [20000, 16384])
             return torch.cat([a.float(), b.float()])
 
+        def fps_legacy():
+            prev = _lib.lib.genpc_fps_tune(1)
+            try:
+                return fps()
+            finally:
+                _lib.lib.genpc_fps_tune(prev)
+
         def chamfer():
             d1 = torch.empty(1, 16384, device="cuda"); d2 = torch.empty_like(d1)
             i1 = torch.empty(1, 16384, device="cuda", dtype=torch.int32); i2 = torch.empty_like(i1)
@@ -39,7 +54,46 @@ def _run(kinds, reps):
         def metric():
             return torch.as_tensor(evaluate_scans(P[None].contiguous(), G[None].contiguous())[0]).float().cuda()
 
-        return {"fps": fps, "chamfer": chamfer, "metric": metric}
+        dp = DepthPrompting(cfg)
+        Pa = P[:6000].contiguous()
+
+        def hpr_full():
+            vis, cnt, _ = dp.hidden_point_removal(Pa, dp.viewpoints[:48], 10000.0)
+            return torch.cat([cnt.float(), vis.float().sum(1)])
+
+        def hpr_best():
+            _, cnt, _ = dp.hidden_point_removal(Pa, dp.viewpoints, 10000.0, best_only=True)
+            return cnt.float().argmax()[None].float()
+
+        def emd_impl(which):
+            def f():
+                prev = _lib.lib.genpc_emd_tune(which, -1)          # (thread-local: set by the thread that calls)
+                try:
+                    d, a = em(P[None, :8192].contiguous(), G[None, :8192].contiguous(), 0.005, 50)
+                finally:
+                    _lib.lib.genpc_emd_tune(prev, -1)
+                return torch.cat([d.flatten(), a.flatten().float()])
+            return f
+
+        def pose():
+            T, h, bp = object_pose_optimization(G[:4096].contiguous(), (P[:2048] * 0.9).contiguous(), radius=0.02, lr=0.01, iters=30,
+                                                render_size=224, return_history=True)
+            return torch.from_numpy(np.concatenate([T.ravel(), h.ravel(), bp.ravel()]).astype(np.float32)).cuda()
+
+        def icp():
+            T, fit, rmse, it = reg_xyz.registration_icp(P[:3000].contiguous(), G[:4000].contiguous(), 0.075)
+            return torch.from_numpy(np.concatenate([T.ravel(), [fit, rmse, it]]).astype(np.float32)).cuda()
+
+        def voxel():
+            return reg_xyz.voxel_down_sample(G, 0.03).flatten()
+
+        def uvs():
+            uv, depth, _ = dp.getUvs(dp.cameras[:64], G, want_transformed=False)
+            return torch.cat([uv.flatten(), depth.flatten()])
+
+        return {"fps": fps, "fps_legacy": fps_legacy, "chamfer": chamfer, "metric": metric, "hpr_full": hpr_full, "hpr_best": hpr_best,
+                "emd_one_launch": emd_impl(2), "emd_culled": emd_impl(1), "emd_tiled": emd_impl(0), "pose": pose, "icp": icp,
+                "voxel": voxel, "uvs": uvs}
 
     ref = {}
     for k in range(3):
@@ -76,5 +130,32 @@ def test_sampling_next_to_the_f16_filter():
     assert _run(["fps", "chamfer", "fps", "chamfer"], reps=12) == []
 
 
+def test_the_pre_fix_pivot_read_still_shows_the_trigger():
+    """The round-4 failure kept reproducible: with the workers reading the pivot as per-lane LDS
+    broadcasts again (genpc_fps_tune(1), per calling thread) the sampling next to the f16 filter drew a wrong sample on every
+    run.  If it still does, the shipped form's clean run above is a meaningful result on this box; if it does not, say so."""
+    bad = _run(["fps_legacy", "chamfer", "fps_legacy", "chamfer"], reps=12)
+    assert all(b[0] == "fps_legacy" for b in bad), bad          # the filter's own results never change
+    if not bad:
+        pytest.skip("the pre-fix pivot read did not misbehave on this box / build: trigger not reproduced")
+
+
 def test_sampling_metric_and_chamfer_together():
     assert _run(["fps", "metric", "chamfer", "fps", "metric", "chamfer"], reps=8) == []
+
+
+@pytest.mark.parametrize("entry", ["hpr_full", "hpr_best", "emd_one_launch", "emd_culled", "emd_tiled", "pose", "icp", "voxel", "uvs"])
+def test_every_entry_point_next_to_the_f16_filter(entry):
+    """the other kernels that read LDS broadcasts (the decision rounds' polygons, the accept pass's staged
+    tiles, the bid's queues, the splat's tile lists) ran beside the f16 filter only in tools/stress_concurrent.py.  Here every
+    entry point runs from two threads beside two threads of the f16 filter, four streams, against its single-threaded bits."""
+    assert _run([entry, "chamfer", entry, "chamfer"], reps=4) == []
+
+
+def test_persistent_launches_side_by_side():
+    """The launches that need all their workgroups resident -- the sampling's hand-off, the one-launch auction -- from five
+    threads at once: the admission (csrc/emd_auction.hip: persist_reserve) keeps the auctions of different streams from
+    waiting for each other's unscheduled workgroups; none is abandoned, all bits are the single-threaded ones."""
+    from genpc_amd import _lib
+    assert _run(["emd_one_launch", "fps", "emd_one_launch", "fps", "emd_one_launch"], reps=4) == []
+    assert _lib.lib.genpc_emd_status(1, None) >= 0

@@ -140,6 +140,30 @@ def _colours(rng, n, dark=0.0):
     return col
 
 
+@pytest.fixture(autouse=True, params=[1, 0], ids=["pulsar_blend", "coverage_splat"])
+def render_blend(request, gp, oracle):
+    """Every test of this file runs with both renderers of the mask term, the library and the oracle switched together:
+    Pulsar's published blending function (softmax in depth; the default since round 5) and the coverage splat."""
+    from genpc_amd import _lib
+    prev_l = _lib.lib.genpc_render_tune(request.param)
+    prev_o = oracle.set_blend(request.param)
+    yield request.param
+    _lib.lib.genpc_render_tune(prev_l)
+    oracle.set_blend(prev_o)
+
+
+def test_pulsar_blend_hides_the_back_surface(gp, oracle, render_blend):
+    """What distinguishes the two renderers: two coincident discs, red in front of green."""
+    torch = gp["torch"]
+    two = torch.tensor([[0.0, 0.0, 0.3], [0.0, 0.0, -0.3]]).cuda()
+    tc = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]).cuda()
+    px = gp["POSE"].splat_image(two, 0.05, 64, tc)[32, 32].cpu().numpy()
+    if render_blend == 1:
+        assert px[0] > 0.99 and px[1] < 1e-4
+    else:
+        assert 0.2 < px[0] < 0.8 and 0.2 < px[1] < 0.8
+
+
 def test_splat_image_vs_oracle(gp, oracle):
     """The colour splat (the build's stand-in for the reference's Pulsar renders): [S,S,3] image of a
     cloud against the oracle's fp64 restatement, several radii and image sizes, white and coloured."""

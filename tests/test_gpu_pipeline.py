@@ -159,6 +159,45 @@ def test_scans_in_flight_side_by_side_change_nothing(env, golden):
                 assert torch.equal(torch.as_tensor(ma), torch.as_tensor(mb))
 
 
+def test_lanes_inherit_the_callers_thread_modes(env):
+    """the library's per-call modes are thread-local and run_in_lanes / complete_scan's stage-1 thread are new
+    threads: a caller in strict arithmetic got FMA bits from its lanes.  The caller's modes (and torch's grad mode) now
+    travel with the work."""
+    import torch
+    from genpc_amd import _lib, pipeline
+    L = _lib.lib
+    dev = torch.device("cuda")
+
+    def probe(li, _):
+        st = _lib.thread_state()
+        return (L.genpc_get_arith(), st[0][1], st[0][3], st[0][5], st[0][6], torch.is_grad_enabled())
+
+    base = pipeline.run_in_lanes(probe, range(3), 3, dev)
+    prev_a = L.genpc_set_arith_thread(0)
+    prev_n = L.genpc_nn_tune(1, -1)
+    prev_e = L.genpc_emd_tune(1, -1)
+    prev_p = L.genpc_pose_tune(0)
+    prev_f = L.genpc_fps_tune(1)
+    try:
+        with torch.no_grad():
+            got = pipeline.run_in_lanes(probe, range(3), 3, dev)
+    finally:
+        L.genpc_set_arith_thread(prev_a); L.genpc_emd_tune(prev_e, -1); L.genpc_pose_tune(prev_p); L.genpc_fps_tune(prev_f)
+        _lib.apply_thread_state((tuple(_lib.thread_state()[0][:1]) + (-1,) + tuple(_lib.thread_state()[0][2:]), torch.is_grad_enabled()))
+    assert all(g == (0, 1, 1, 0, 1, False) for g in got), got
+    assert all(b[0] == L.genpc_get_arith() and b[5] for b in base), base
+    # and a lane's strict-mode sampling is the caller's strict-mode sampling
+    x = torch.rand(1, 5000, 3, device=dev)
+    from genpc_amd.fps import fps_sampling
+    prev_a = L.genpc_set_arith_thread(0)
+    try:
+        want = fps_sampling(x, 1000)
+        lanes = pipeline.run_in_lanes(lambda li, _: fps_sampling(x, 1000), range(2), 2, dev)
+    finally:
+        L.genpc_set_arith_thread(prev_a)
+    assert all(torch.equal(want, r) for r in lanes)
+
+
 def test_voxel_down_sample_vs_oracle(env, oracle, golden):
     torch = env["torch"]
     g = golden("scans13_fps16384.npz")

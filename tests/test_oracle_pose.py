@@ -208,6 +208,32 @@ def t_splat(pts, radius, S, col=None):
     return (occ[:, None] * colour).reshape(S, S, 3)
 
 
+def t_splat_pulsar(pts, radius, S, col=None):
+    """Pulsar's published blending function (Lassner & Zollhoefer 2021, eq. 1-2) with the reference's arguments (gamma 1e-2,
+    znear 1e-4, zfar 5, bg 0, opacity 1), written densely in torch ([P pixels] x [N points]) -> [S,S,3]; same camera and
+    footprint as t_splat.  I = sum a e c / (B + sum a e), e = exp(z / gamma), z = (zfar - Zv) / (zfar - znear), B = exp(eps / gamma)."""
+    gamma, znear, zfar, eps = 1e-2, 1e-4, 5.0, 1e-10
+    zv = 3.0 - pts[:, 2]
+    ok = (zv > 1e-4) & (zv < 5.0)
+    hs = 0.5 * S
+    u = hs * (1.0 + 4.0 * pts[:, 0] / zv)
+    v = hs * (1.0 - 4.0 * pts[:, 1] / zv)
+    rho = hs * 4.0 * radius / zv
+    rr, cc = torch.meshgrid(torch.arange(S, dtype=pts.dtype) + 0.5, torch.arange(S, dtype=pts.dtype) + 0.5, indexing="ij")
+    dx = cc.reshape(-1, 1) - u[None]
+    dy = rr.reshape(-1, 1) - v[None]
+    a = 1.0 - (dx * dx + dy * dy) / (rho * rho)[None]
+    a = torch.clamp(a, min=0.0, max=0.999) * ok[None]
+    ze = ((zfar - zv) / (zfar - znear) / gamma)[None].expand_as(a)
+    live = a > 0
+    m = torch.where(live, ze, torch.full_like(ze, eps / gamma)).max(dim=1).values.clamp(min=eps / gamma).detach()
+    w = torch.where(live, a * torch.exp(torch.where(live, ze, m[:, None]) - m[:, None]), torch.zeros_like(a))
+    if col is None:
+        col = torch.ones(pts.shape[0], 3, dtype=pts.dtype)
+    den = math.exp(eps / gamma) * torch.exp(-m) + w.sum(1)
+    return ((w @ col) / den[:, None]).reshape(S, S, 3)
+
+
 def t_mask_loss(img, ref):
     """compute_loss_function's mask terms as the reference writes them (diff_obj_pose.py:204-217,
     261-278,238-259,304-311) on [S,S,3] images.  (tests/test_reference_vectors.py pins the oracle to the
@@ -260,6 +286,74 @@ def test_splat_and_mask_loss_match_torch(oracle):
         l64 = float(t_mask_loss(ti, tr))
         assert abs(l32 - l64) > 0.01 * l64
         np.testing.assert_allclose(oracle.mask_loss(img, ref), l32, rtol=2e-4)
+
+
+@pytest.fixture
+def pulsar_blend(oracle):
+    prev = oracle.set_blend(1)
+    yield
+    oracle.set_blend(prev)
+
+
+def test_pulsar_blend_matches_torch(oracle, pulsar_blend):
+    """The oracle's restatement of Pulsar's blending function against the dense torch evaluation of the same formulas;
+    and what makes it Pulsar's: a near surface hides a far one (the coverage splat averages them)."""
+    rng = np.random.default_rng(3)
+    S = 40
+    pts = ((rng.random((60, 3)) - 0.5) * 0.9).astype(np.float32)
+    col = _colours(rng, 60, 0.3)
+    for c in (None, col):
+        img = oracle.splat_image(pts, 0.03, S, c)
+        ti = t_splat_pulsar(torch.from_numpy(pts).double(), 0.03, S, None if c is None else torch.from_numpy(c).double())
+        np.testing.assert_allclose(img, ti.numpy(), atol=2e-6)
+        assert 0.005 < float(img.mean()) < 0.9
+    # two coincident discs, red in front (z = +0.3) of green (z = -0.3): Pulsar's pixel is red, the coverage splat's a mix
+    two = np.array([[0.0, 0.0, 0.3], [0.0, 0.0, -0.3]], np.float32)
+    tc = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
+    centre = oracle.splat_image(two, 0.05, S, tc)[S // 2, S // 2]
+    assert centre[0] > 0.99 and centre[1] < 1e-4          # (0.6 in depth = e^-12 in weight)
+    oracle.set_blend(0)
+    mix = oracle.splat_image(two, 0.05, S, tc)[S // 2, S // 2]
+    oracle.set_blend(1)
+    assert 0.2 < mix[0] < 0.8 and 0.2 < mix[1] < 0.8
+
+
+@pytest.mark.parametrize("coloured", [False, True])
+def test_pulsar_full_loss_gradient_matches_torch_autograd(oracle, pulsar_blend, coloured):
+    """As test_full_loss_gradient_matches_torch_autograd with both images drawn by Pulsar's blending function: the
+    gradient now also flows through the depth of every point (the softmax weights)."""
+    S = 36
+    radius = 0.04
+    v, partial, params = make_case(5, nc=260, npart=170)
+    rng = np.random.default_rng(50)
+    vcol = _colours(rng, len(v), 0.33) if coloured else None
+    pcol = _colours(rng, len(partial)) if coloured else None
+    center = v.astype(np.float64).mean(0).astype(np.float32)
+    pts = oracle.pose_transform(v, center, params)
+    d1, d2, i1, i2 = oracle.chamfer_forward(pts[None], partial[None], 0)
+    ref = oracle.splat_image(partial, radius, S, pcol)
+    lo, g = oracle.pose_full_loss_grad(v, center, params, partial, d1[0], i1[0], d2[0], i2[0], radius, S, ref, vert_col=vcol)
+    P = torch.tensor(params.astype(np.float64), requires_grad=True)
+    tv, tc, tp = (torch.from_numpy(x.astype(np.float64)) for x in (v, center, partial))
+    cd_total, cd, ortho, tpts = t_loss(P, tv, tc, tp, torch.from_numpy(i1[0].astype(np.int64)),
+                                       torch.from_numpy(i2[0].astype(np.int64)))
+    timg = t_splat_pulsar(tpts, 1.1 * radius, S, None if vcol is None else torch.from_numpy(vcol).double())
+    ml = t_mask_loss(timg.float(), torch.from_numpy(ref)).double()
+    total = cd_total + ml
+    total.backward()
+    assert abs(lo[3] - float(ml)) < 2e-4 * max(1.0, abs(float(ml)))
+    tg = P.grad.numpy()
+    P2 = torch.tensor(params.astype(np.float64), requires_grad=True)
+    t_loss(P2, tv, tc, tp, torch.from_numpy(i1[0].astype(np.int64)), torch.from_numpy(i2[0].astype(np.int64)))[0].backward()
+    if coloured:       # (a white cloud's Pulsar image is flat inside the silhouette: little gradient beside the rim's)
+        assert np.abs(tg - P2.grad.numpy()).max() > 0.02 * np.abs(tg).max()
+    np.testing.assert_allclose(g, tg, rtol=2e-3, atol=2e-3 * np.abs(tg).max())
+    # and it is not the coverage splat's gradient
+    oracle.set_blend(0)
+    ref0 = oracle.splat_image(partial, radius, S, pcol)
+    lo0, g0 = oracle.pose_full_loss_grad(v, center, params, partial, d1[0], i1[0], d2[0], i2[0], radius, S, ref0, vert_col=vcol)
+    oracle.set_blend(1)
+    assert abs(lo0[3] - lo[3]) > 1e-3
 
 
 @pytest.mark.parametrize("coloured", [False, True])

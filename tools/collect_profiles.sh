@@ -5,7 +5,7 @@
 # WRITE_SIZE / SQ counter passes (separate runs: TCC has 4 slots, FETCH_SIZE takes 3; never combined
 # with a trace).  Every profiled program is `python3 <script>` directly after `--` (no wrappers).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -27,6 +27,7 @@ family emd_B13_16384 tools/prof_emd.py 13 16384 1
 family emd_B13_16384_scans tools/prof_emd.py 13 16384 1 scan
 family emd_B1_16384_scan tools/prof_emd.py 1 16384 2 scan
 family get_uvs_1024x71372 tools/prof_uvs.py 3
+family streaming_64x32768 tools/prof_streaming.py
 family pose_loop_16384x8192 tools/prof_pose.py 16384 8192 20 1
 family scale_search_icp tools/prof_scale_search.py
 family fps_voxel tools/prof_fps_voxel.py

@@ -31,7 +31,7 @@ def ab(tag, X, Y):
 
 
 rng = np.random.default_rng(7)
-shapes = ((1, 16384), (13, 16384), (1, 2048), (1, 8192), (64, 2048), (1, 512), (4, 4096))
+shapes = ((1, 16384), (2, 16384), (4, 16384), (13, 16384), (1, 2048), (8, 2048), (16, 1024), (1, 8192), (2, 8192), (64, 2048), (1, 512), (4, 4096), (8, 32768))
 if "quick" in sys.argv: shapes = ((1, 16384), (13, 16384), (1, 2048))
 for b, n in shapes:
     X = torch.from_numpy(rng.random((b, n, 3), dtype=np.float32)).cuda()
