@@ -125,7 +125,9 @@ void *workspace(int slot, size_t bytes, hipStream_t stream, bool *fresh, size_t 
         return nullptr;
     }
     if (zero_prefix) {
-        if (zero_prefix > want) zero_prefix = want;
+        // a caller that asks for its whole request zeroed gets the whole ALLOCATION zeroed (it is 25 % larger, and a later,
+        // larger request is served from the slack: nn_dedupe's table treated uninitialised slack as entries -- ADVICE r4)
+        if (zero_prefix >= bytes || zero_prefix > want) zero_prefix = want;
         if (hipMemsetAsync(p, 0, zero_prefix, stream) != hipSuccess) {
             (void)hipFree(p);
             g_err = "hipMemsetAsync(workspace)";

@@ -31,6 +31,11 @@
 
 namespace genpc {
 
+// admission of launches whose workgroups wait for each other (csrc/emd_auction.hip): quarter-CU units
+bool persist_reserve(int wgs, int capacity, hipStream_t st);
+void persist_commit(int wgs, hipStream_t st);
+int emd_auction_capacity();
+
 constexpr int kFThreads = 192;           // worker threads of a workgroup: three waves, the fourth wave coordinates -- one wave per SIMD
 constexpr int kFWaves = kFThreads / kWave;
 constexpr int kFMaxR = 24;
@@ -46,6 +51,8 @@ struct FpsJobs {
     int n[kFMaxJobs], k[kFMaxJobs], W[kFMaxJobs];
     int slot0[kFMaxJobs];        // first slot of the job in the slot array (slots are per (job, parity, workgroup))
     int stat0;                   // index of the launch's first cloud in the call (statistics)
+    float *pdist[kFMaxJobs];     // the running minimum of every sample when it was drawn (fps_verify_kernel)
+    int *verr[kFMaxJobs];        // != 0: the verification found a step whose sample is not the first arg-max
     int legacy_pivot;            // test hook (genpc_fps_tune): the workers read the pivot as per-lane LDS broadcasts again -- the
                                  // form that drew wrong samples next to f16 MFMAs on another stream (tests/test_gpu_concurrency.py)
 };
@@ -203,6 +210,7 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
     // MFMAs, mechanism unknown; round 5: a wrong sample again with the pivot taken through scalar registers, next to the
     // one-launch auction) cannot lower its minima by it -- the hand-off no longer depends on what caused that.
     __shared__ uint2 s_pivt[kFBatch][3];
+    __shared__ float s_pd[kFBatch];            // the round's picks: their running minimum when drawn
     __shared__ unsigned s_prog;                // round << 16 | flags | pivots of that round published so far
     const int job = blockIdx.y, wg = blockIdx.x, t = threadIdx.x;
     const int W = jobs.W[job];
@@ -313,6 +321,7 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
 
     // ---------------------------------------------------------------------- coordinator (the last wave)
     int *__restrict__ out = jobs.out[job];
+    float *__restrict__ pdist = jobs.pdist[job];
     FpsSlot *S = slots + jobs.slot0[job];
     int s = 1;                                 // samples drawn so far
     if (lane == 0) {
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
         s_pivt[0][0] = make_uint2(__float_as_uint(X[0]), 1u);      // round 0, slot 0
         s_pivt[0][1] = make_uint2(__float_as_uint(X[1]), 1u);
         s_pivt[0][2] = make_uint2(__float_as_uint(X[2]), 1u);
-        if (wg == 0) out[0] = 0;
+        if (wg == 0) { out[0] = 0; pdist[0] = __builtin_inff(); }
         prog_store(&s_prog, (0u << 16) | kProgDone | (k <= 1 ? kProgFinal : 0u) | 1u);
     }
     bool timed_out = false;
@@ -424,6 +433,7 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
             if (lane == 0) {
                 s_piv[mm][0] = qx; s_piv[mm][1] = qy; s_piv[mm][2] = qz;
                 s_piv[mm][3] = __int_as_float(mi);
+                s_pd[mm] = md;
                 const unsigned tag = (round & 0x3ffffffu) * 64u + (unsigned)mm + 1u;
                 s_pivt[mm][0] = make_uint2(__float_as_uint(qx), tag);
                 s_pivt[mm][1] = make_uint2(__float_as_uint(qy), tag);
@@ -440,7 +450,7 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
         }
         if (lane == 0) prog_store(&s_prog, (round << 16) | kProgDone | (s + mm >= k ? kProgFinal : 0u) | (unsigned)mm);
         // the samples of the round, after the workers have been released (no global store inside the pick loop)
-        if (wg == 0 && lane < mm) out[s + lane] = __float_as_int(s_piv[lane][3]);
+        if (wg == 0 && lane < mm) { out[s + lane] = __float_as_int(s_piv[lane][3]); pdist[s + lane] = s_pd[lane]; }
         s += mm;
     }
     if (timed_out && lane == 0) prog_store(&s_prog, (round << 16) | kProgDone | kProgAbort);
@@ -450,6 +460,66 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
         if (timed_out || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) out[0] = -1;
         err[1 + jobs.stat0 + job] = (int)round;          // exchanges this cloud took (genpc_fps_stats)
     }
+}
+
+// Verification of a sampling, on the device, against the DEFINITION (round 5).  The k steps of a sampling are sequential, but
+// checking a finished sequence is not: sample j (drawn with running minimum M_j, as the sampling itself recorded it) is right
+// iff, after the first j samples have been applied, every point i has running minimum D_i < M_j, or D_i == M_j and i > s_j,
+// and the sample itself has D == M_j exactly -- "s_j is the FIRST arg-max" -- with the sampling's own arithmetic.  One thread
+// per point walks the sample list once (n k distance evaluations, all independent across points: ~0.4 ms for 16384 of 24000,
+// beside the sampling's 7).  Why: twice now (round 4 next to another stream's f16 MFMAs, round 5 again with the pivot taken
+// through scalar registers and with self-tagged pivot granules) a sampling running BESIDE other kernels drew a sample a step
+// early -- silently, mechanism not established.  A violation poisons out[0] with -1, which genpc_amd/fps.py
+// already treats as "this cloud again": a wrong sequence can no longer leave the library unnoticed, whatever causes it.
+constexpr int kFVBlock = 128, kFVTile = 1024;
+template <int FMA>
+__global__ __launch_bounds__(kFVBlock) void fps_verify_kernel(FpsJobs jobs)
+{
+    __shared__ float4 s_s[kFVTile];          // x, y, z of sample l; M of sample l + 1
+    __shared__ int s_i[kFVTile];             // index of sample l + 1
+    const int job = blockIdx.y;
+    const int n = jobs.n[job], k = jobs.k[job];
+    const float *__restrict__ X = jobs.xyz[job];
+    const int *__restrict__ out = jobs.out[job];
+    const float *__restrict__ pd = jobs.pdist[job];
+    bool bad = false;
+    for (int i0 = blockIdx.x * kFVBlock; i0 < n; i0 += gridDim.x * kFVBlock) {      // (block-uniform: the tiles are staged together)
+        const int i = i0 + threadIdx.x;
+        const bool live = i < n;
+        const int ii = live ? i : n - 1;
+        const float px = X[(size_t)ii * 3 + 0], py = X[(size_t)ii * 3 + 1], pz = X[(size_t)ii * 3 + 2];
+        float D = __builtin_inff();
+        if (i == 0 && out[0] != 0) bad = true;      // (-1: the hand-off gave up; anything else: not the start point)
+        for (int l0 = 0; l0 < k - 1; l0 += kFVTile) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < kFVTile && l0 + t < k - 1; t += kFVBlock) {
+                int sl = out[l0 + t];
+                if ((unsigned)sl >= (unsigned)n || (unsigned)out[l0 + t + 1] >= (unsigned)n) bad = true;      // (not an index of the cloud)
+                sl = (unsigned)sl < (unsigned)n ? sl : 0;
+                s_s[t] = make_float4(X[(size_t)sl * 3 + 0], X[(size_t)sl * 3 + 1], X[(size_t)sl * 3 + 2], pd[l0 + t + 1]);
+                s_i[t] = out[l0 + t + 1];
+            }
+            __syncthreads();
+            const int cnt = min(kFVTile, k - 1 - l0);
+            for (int t = 0; t < cnt; t++) {
+                const float4 q = s_s[t];
+                const float dd = sqdist_f<FMA>(px - q.x, py - q.y, pz - q.z);
+                D = D < dd ? D : dd;
+                const int sj = s_i[t];
+                // D < M, or the tie goes to the lower index s_j, or this IS s_j with exactly its recorded minimum
+                const bool okstep = D < q.w || (D == q.w && i >= sj);
+                bad |= live && !okstep;
+                bad |= live && i == sj && D != q.w;
+            }
+        }
+    }
+    if (__any(bad) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(jobs.verr[job], 1);
+}
+
+__global__ void fps_poison_kernel(FpsJobs jobs, int nj)
+{
+    const int j = threadIdx.x;
+    if (j < nj && *jobs.verr[j] != 0) { jobs.out[j][0] = -1; *jobs.verr[j] = 0; }
 }
 
 template <int FMA>
@@ -544,13 +614,18 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
             W = W > 2 * budget_of(R) ? budget_of(R) : W - 1;
         }
     };
-    size_t total_slots = 0;
-    for (int j = 0; j < c; j++) total_slots += 2 * (size_t)fps_workgroups(n[j]);
-    char *ws = (char *)workspace(7, 256 + total_slots * sizeof(FpsSlot), st);
+    size_t total_slots = 0, total_k = 0;
+    for (int j = 0; j < c; j++) { total_slots += 2 * (size_t)fps_workgroups(n[j]); total_k += ((size_t)k[j] + 63) / 64 * 64; }
+    static const int env_verify = tune_env("GENPC_FPS_VERIFY", 1, "farthest point sampling: 1 = every sequence is checked on the device against the definition (a violation poisons out[0] = -1), 0 = no check");
+    const size_t head = 256 + total_slots * sizeof(FpsSlot), verr_bytes = ((size_t)c * sizeof(int) + 255) / 256 * 256;
+    char *ws = (char *)workspace(7, head + verr_bytes + total_k * sizeof(float), st);
     if (!ws) return 0;
     int *err = (int *)ws;
     FpsSlot *slots = (FpsSlot *)(ws + 256);
-    if (!check(hipMemsetAsync(ws, 0, 256 + total_slots * sizeof(FpsSlot), st), "hipMemsetAsync(fps)")) return 0;
+    int *verr = (int *)(ws + head);
+    float *pdist = (float *)(ws + head + verr_bytes);
+    if (!check(hipMemsetAsync(ws, 0, head + verr_bytes, st), "hipMemsetAsync(fps)")) return 0;
+    size_t pd_off = 0;
     int slot0 = 0;
     for (int j0 = 0; j0 < c;) {
         // a launch takes up to kFMaxJobs clouds; its grid is (largest W) x (clouds), all of it resident together
@@ -569,6 +644,9 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
             if (nj > 0 && (long long)wm * (nj + 1) > budget_of(rm)) break;
             jobs.xyz[nj] = xyz[j];
             jobs.out[nj] = out_idx[j];
+            jobs.pdist[nj] = pdist + pd_off;
+            jobs.verr[nj] = verr + j;
+            pd_off += ((size_t)k[j] + 63) / 64 * 64;
             jobs.n[nj] = n[j];
             jobs.k[nj] = k[j];
             jobs.W[nj] = W;
@@ -578,8 +656,24 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
             rmax = rm;
             nj++;
         }
+        // The hand-off needs the launch resident as a whole, like the one-launch auction: both take their share of the chip
+        // from one budget (quarter-CU units; a workgroup of an instantiation the CU holds k of costs ceil(4 / k)), so two such
+        // launches of different streams never sit half-resident waiting for workgroups the other one keeps out (ADVICE r4:
+        // two samplings of different lanes could spin against each other until the timeout).
+        const int per_cu = fma ? fps_blocks_per_cu<1>(fps_class(rmax)) : fps_blocks_per_cu<0>(fps_class(rmax));
+        const int units = wmax * nj * ((4 + per_cu - 1) / per_cu);
+        const bool admitted = persist_reserve(units, emd_auction_capacity(), st);
         if (fma) launch_fps<1>(rmax, dim3(wmax, nj), st, jobs, slots, err);
         else launch_fps<0>(rmax, dim3(wmax, nj), st, jobs, slots, err);
+        if (admitted) persist_commit(units, st);
+        if (env_verify) {
+            int nmax = 1;
+            for (int q = 0; q < nj; q++) nmax = jobs.n[q] > nmax ? jobs.n[q] : nmax;
+            const dim3 vg(ceil_div(nmax, kFVBlock), nj);
+            if (fma) hipLaunchKernelGGL((fps_verify_kernel<1>), vg, dim3(kFVBlock), 0, st, jobs);
+            else hipLaunchKernelGGL((fps_verify_kernel<0>), vg, dim3(kFVBlock), 0, st, jobs);
+            hipLaunchKernelGGL(fps_poison_kernel, dim3(1), dim3(kFMaxJobs), 0, st, jobs, nj);
+        }
         j0 += nj;
     }
     if (!check(hipGetLastError(), "fps launch")) return 0;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kDBlock) void dedupe_insert_kernel(DedupeArgs a)
             if ((unsigned)(cur >> 32) != a.gen) continue;
         }
         const unsigned j = 0xffffffffu - (unsigned)cur;
-        if (P[(size_t)j * 3] == x && P[(size_t)j * 3 + 1] == y && P[(size_t)j * 3 + 2] == z) {
+        if (j < (unsigned)C.n && P[(size_t)j * 3] == x && P[(size_t)j * 3 + 1] == y && P[(size_t)j * 3 + 2] == z) {      // (j < n: never read outside the cloud, whatever the slot holds)
             if (j > (unsigned)k) atomicMax(&tab[h], mine);      // the slot keeps the lowest index of its coordinates
             break;
         }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kDBlock) void dedupe_resolve_kernel(DedupeArgs a)
             const unsigned long long cur = tab[h];
             const unsigned j = 0xffffffffu - (unsigned)cur;
             // (an entry of this generation with the point's coordinates exists: the point itself put it there or met it)
-            if ((unsigned)(cur >> 32) == a.gen && P[(size_t)j * 3] == x && P[(size_t)j * 3 + 1] == y && P[(size_t)j * 3 + 2] == z) {
+            if ((unsigned)(cur >> 32) == a.gen && j < (unsigned)C.n && P[(size_t)j * 3] == x && P[(size_t)j * 3 + 1] == y && P[(size_t)j * 3 + 2] == z) {
                 dup = j != (unsigned)k;
                 break;
             }

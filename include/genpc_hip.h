@@ -74,8 +74,9 @@ int genpc_nn_stats(unsigned long long out[3], int reset, void *stream);
  * it pays (hooks 2048 / 4096 of genpc_nn_tune force it off / on); exposed for tests.  Returns 1 / 0 / -1.            */
 int genpc_nn_duplicate_mask(int b, int n, const float *xyz, unsigned *mask, void *stream);
 /* Kernel-level timing for bench.py: while enabled, HIP events bracket the filter kernel
- * (nn_f16_kernel) of every nearest-neighbour call on its stream.  Returns the duration
- * in ms of the last bracketed launch (-1 if none), then sets the switch to `enable`. */
+ * (nn_f16_kernel) of every nearest-neighbour call THE CALLING HOST THREAD makes, on the call's stream
+ * (the switch and the events are per thread: other threads' launches are untouched).  Returns the
+ * duration in ms of the last bracketed launch (-1 if none), then sets the switch to `enable`. */
 float genpc_nn_profile(int enable);
 
 /* Chamfer3D -------------------------------------------------------------- *

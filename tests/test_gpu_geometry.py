@@ -152,6 +152,18 @@ def render_blend(request, gp, oracle):
     oracle.set_blend(prev_o)
 
 
+def _close_images(img, ref, blend):
+    """fp32 (u, v, rho) against the oracle's fp64: 2e-4 for the coverage splat, whose image fades to 0 at a disc's rim.
+    Pulsar's blending function has a HARD rim (any coverage > 0 outweighs the background by e^40), so a rim pixel whose
+    coverage is positive in one precision and not in the other differs by the disc's whole colour: at most a few pixels in
+    100 000 may, every other pixel within 1e-3 (the softmax weights are ratios of exponentials of fp32 depths)."""
+    if blend == 0:
+        np.testing.assert_allclose(img, ref, atol=2e-4)
+        return
+    bad = np.abs(img.astype(np.float64) - ref).max(-1) > 1e-3
+    assert bad.sum() <= max(3, bad.size // 20000), (int(bad.sum()), bad.size)
+
+
 def test_pulsar_blend_hides_the_back_surface(gp, oracle, render_blend):
     """What distinguishes the two renderers: two coincident discs, red in front of green."""
     torch = gp["torch"]
@@ -164,7 +176,7 @@ def test_pulsar_blend_hides_the_back_surface(gp, oracle, render_blend):
         assert 0.2 < px[0] < 0.8 and 0.2 < px[1] < 0.8
 
 
-def test_splat_image_vs_oracle(gp, oracle):
+def test_splat_image_vs_oracle(gp, oracle, render_blend):
     """The colour splat (the build's stand-in for the reference's Pulsar renders): [S,S,3] image of a
     cloud against the oracle's fp64 restatement, several radii and image sizes, white and coloured."""
     torch = gp["torch"]
@@ -176,7 +188,7 @@ def test_splat_image_vs_oracle(gp, oracle):
                                          None if c is None else torch.from_numpy(c).cuda()).cpu().numpy()
             ref = oracle.splat_image(partial, radius, size, c)
             assert img.shape == (size, size, 3)
-            np.testing.assert_allclose(img, ref, atol=2e-4)      # fp32 (u, v, rho) against fp64: pixels on a disc's rim
+            _close_images(img, ref, render_blend)
             assert 0.002 < img.mean() < 0.9
             if c is None:
                 assert np.array_equal(img[..., 0], img[..., 1]) and np.array_equal(img[..., 0], img[..., 2])
@@ -186,7 +198,7 @@ def test_splat_image_vs_oracle(gp, oracle):
     assert float(gp["POSE"].splat_image(torch.zeros(0, 3).cuda(), 0.05, 32).abs().max()) == 0.0
 
 
-def test_splat_tile_lists_and_their_fallbacks(gp, oracle):
+def test_splat_tile_lists_and_their_fallbacks(gp, oracle, render_blend):
     """The splat reads per-tile index lists the projection kernel fills (pose.hip bin_points_block).  The cases a list
     cannot hold must give the same image through the full scan: a tile hit by more points than a list holds (and one whose
     list is longer than one fill of the splat's LDS list), discs
@@ -212,13 +224,13 @@ def test_splat_tile_lists_and_their_fallbacks(gp, oracle):
             img = gp["POSE"].splat_image(torch.from_numpy(pts).cuda(), radius, size,
                                          None if c is None else torch.from_numpy(c).cuda()).cpu().numpy()
             ref = oracle.splat_image(pts, radius, size, c)
-            np.testing.assert_allclose(img, ref, atol=2e-4, err_msg=name)
+            _close_images(img, ref, render_blend)
         # twice through the same scratch: the splat hands the counters back zeroed
         again = gp["POSE"].splat_image(torch.from_numpy(pts).cuda(), radius, size, torch.from_numpy(col).cuda()).cpu().numpy()
         np.testing.assert_allclose(again, img, atol=1e-6, err_msg=name)
 
 
-def test_splat_fuzz(gp, oracle):
+def test_splat_fuzz(gp, oracle, render_blend):
     """Random clouds, sizes, radii and image sizes through the splat's tile lists (empty tiles, one-entry lists, lists
     ranked by counting and by bitmap, several fills, overflow, images with no lists) against the oracle's image."""
     torch = gp["torch"]
@@ -233,7 +245,7 @@ def test_splat_fuzz(gp, oracle):
         img = gp["POSE"].splat_image(torch.from_numpy(pts).cuda(), radius, size,
                                      None if col is None else torch.from_numpy(col).cuda()).cpu().numpy()
         ref = oracle.splat_image(pts, radius, size, col)
-        np.testing.assert_allclose(img, ref, atol=2e-4, err_msg="case %d: n %d size %d radius %g spread %g" % (case, n, size, radius, spread))
+        _close_images(img, ref, render_blend)
 
 
 def test_mask_gradient_tile_pass_and_its_fallbacks(gp, oracle):
