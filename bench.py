@@ -77,7 +77,7 @@ def time_events(fn, reps, stream):
     return e0.elapsed_time(e1) / reps
 
 
-ROUND_TAG = "r04"          # the profiles/ tag this bench's PMC-derived numbers must come from
+ROUND_TAG = "r05"          # the profiles/ tag this bench's PMC-derived numbers must come from
 
 
 def pmc_traffic(n, kernel_prefix="nn_f16_kernel"):
@@ -201,25 +201,42 @@ def extras(A, B, n, dev, stream):
     from genpc_amd import emd as emd_abi
     from genpc_amd.loss_functions.emd.emd_module import alloc_state
     pairs = 0.0
-    for k in range(1, 51):
-        st = alloc_state(1, n, n, dev)
-        emd_abi.forward(X, Y, st["dist"], st["assignment"], st["price"], st["assignment_inv"], st["bid"],
-                        st["bid_increments"], st["max_increments"], st["unass_idx"], st["unass_cnt"], st["unass_cnt_sum"],
-                        st["cnt_tmp"], st["max_idx"], 0.005, k)
-        pairs += float((st["unass_cnt"] if (k - 1) % 2 == 0 else st["cnt_tmp"])[0].item()) * n
+    prev_impl = _lib.lib.genpc_emd_tune(1, -1)      # (the bidder counts live in the launch-per-round path's list buffers)
+    try:
+        for k in range(1, 51):
+            st = alloc_state(1, n, n, dev)
+            emd_abi.forward(X, Y, st["dist"], st["assignment"], st["price"], st["assignment_inv"], st["bid"],
+                            st["bid_increments"], st["max_increments"], st["unass_idx"], st["unass_cnt"], st["unass_cnt_sum"],
+                            st["cnt_tmp"], st["max_idx"], 0.005, k)
+            pairs += float((st["unass_cnt"] if (k - 1) % 2 == 0 else st["cnt_tmp"])[0].item()) * n
+    finally:
+        _lib.lib.genpc_emd_tune(prev_impl, -1)
     extra["emd_fwd_n%d_roofline" % n] = {
         "bound": "valu-fp32", "unit": "TFLOP/s", "algorithmic_pairs_per_call": pairs, "pairs_over_n2": round(pairs / n / n, 3),
         "flop_per_pair": FLOP_PER_PAIR, "ms_per_call": round(t_emd, 4),
         "achieved": round(FLOP_PER_PAIR * pairs / (t_emd * 1e-3) / 1e12, 3), "peak": PEAK_FP32_TFLOPS,
         "frac": round(FLOP_PER_PAIR * pairs / (t_emd * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
-        "note": "50 rounds x 2 launches (culled bid + settle), latency-bound at B=1; algorithmic pairs = bidders x ALL objects per round (the culled bid tests ~70 of 16384 per bidder)"}
+        "note": "all 50 rounds in one launch whose threads own the points (csrc/emd_auction.hip), latency-bound at B=1: ~12 dependent global round trips and two barriers per round; algorithmic pairs = bidders x ALL objects per round (the culled bid tests ~70 of 16384 per bidder)"}
+    # the same call through the launch-per-round path (round 4's default), for continuity
+    prev_impl = _lib.lib.genpc_emd_tune(1, -1)
+    try:
+        em(X, Y, 0.005, 50)
+        extra["emd_fwd_n%d_launch_per_round_ms" % n] = round(time_events(lambda: em(X, Y, 0.005, 50), 5, stream), 4)
+    finally:
+        _lib.lib.genpc_emd_tune(prev_impl, -1)
     # BASELINE config 3's EMD half: the 13 bundled scans against their ground truth in one call (most points keep
     # bidding for all 50 rounds there -- the regime the bid's culling was built for), and 13 uniform pairs for scale
     P13s, G13s = torch.from_numpy(z13["partial"]).to(dev), torch.from_numpy(z13["gt"]).to(dev)
     em(P13s, G13s, 0.005, 50)
+    torch.cuda.synchronize()          # (the first call's bidder count decides the path of the next ones: it must have arrived)
+    em(P13s, G13s, 0.005, 50)
+    torch.cuda.synchronize()
     extra["emd_fwd_13_bundled_scans_n%d_ms" % n] = round(time_events(lambda: em(P13s, G13s, 0.005, 50), 3, stream), 3)
     U13a, U13b = P13 + 0.5, Q13 + 0.5
     em(U13a, U13b, 0.005, 50)
+    torch.cuda.synchronize()
+    em(U13a, U13b, 0.005, 50)
+    torch.cuda.synchronize()
     extra["emd_fwd_B13_uniform_n%d_ms" % n] = round(time_events(lambda: em(U13a, U13b, 0.005, 50), 3, stream), 3)
     X2 = X[:, :2048].contiguous()
     Y2 = Y[:, :2048].contiguous()

@@ -318,65 +318,78 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
                     __builtin_amdgcn_wave_barrier();
                 };
                 auto batch_eval = [&](int pA, int lA) {
+                    // run by run, as emd_bid_grid_kernel (emd_grid.hip): the batch's non-empty runs compacted into the group's
+                    // list, the group's lanes stride a run together, four runs' first strides in flight
                     const unsigned long long mA = __ballot(lA > 0) & gmask;
                     const int E = __popcll(mA);
-                    int incl = lA;
-#pragma unroll
-                    for (int o = 1; o < kWave; o <<= 1) {
-                        const int t = __shfl_up(incl, o, kWave);
-                        if (o < LPB && sub >= o) incl += t;
-                    }
-                    const int T = __shfl(incl, (lane & ~(LPB - 1)) + LPB - 1, kWave);
-                    if (lA > 0) { const int e = __popcll(mA & ((1ull << lane) - 1ull)); pre[e] = incl - lA; pp0[e] = pA; }
-                    if (sub == 0) pre[E] = T;
+                    if (lA > 0) { const int e = __popcll(mA & ((1ull << lane) - 1ull)); pre[e] = lA; pp0[e] = pA; }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    int cur = 0;
-                    for (int t0 = 0; t0 < T; t0 += 4 * LPB) {      // group-uniform trip count
-                        const int t = t0 + sub;
+                    auto test = [&](const F3A &o, float w, int pos, bool in) -> bool {
+                        if (!in) return false;
+                        const float sq = sqdist_e<FMA>(o.x - x1, o.y - y1, o.z - z1);
+                        if (mode == 2) {
+                            const float key = sqrtf(sq) + w;
+                            if (key < k1) { k2 = k1; q2 = q1; k1 = key; q1 = pos; }
+                            else if (key < k2) { k2 = key; q2 = pos; }
+                            return false;
+                        }
+                        const float tt = cb - w;
+                        return sq < tt * tt;
+                    };
+                    auto enqueue = [&](bool pass, int pos, float w) {
+                        const unsigned long long m = __ballot(pass) & gmask;
+                        if (pass) {
+                            const int at = qn + __popcll(m & ((1ull << lane) - 1ull));
+                            que[at] = pos;
+                            qpr[at] = w;
+                        }
+                        qn += __popcll(m);
+                    };
+                    int longest = 0;
+                    for (int e0 = 0; e0 < E; e0 += 4) {            // group-uniform trip counts throughout
                         F3A o[4];
                         float w[4];
-                        int pos[4];
-                        bool pass[4] = {false, false, false, false};
+                        int ps[4];
+                        bool in[4];
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            const int ti = t + i * LPB;
-                            if (ti < T) {
-                                while (ti >= pre[cur + 1]) cur++;
-                                pos[i] = pp0[cur] + (ti - pre[cur]);
-                            } else {
-                                pos[i] = pp0[0];
-                            }
-                            o[i] = *(const F3A *)&S[pos[i]];
-                            w[i] = ald(&PS[pos[i]]);
+                            const bool have = e0 + i < E;
+                            const int p0 = have ? pp0[e0 + i] : pp0[0], ln = have ? pre[e0 + i] : 0;
+                            longest = max(longest, ln);
+                            in[i] = sub < ln;
+                            ps[i] = p0 + (in[i] ? sub : 0);
+                            o[i] = *(const F3A *)&S[ps[i]];
+                            w[i] = ald(&PS[ps[i]]);
                         }
+                        bool pass[4];
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            if (t + i * LPB < T) {
-                                const float sq = sqdist_e<FMA>(o[i].x - x1, o[i].y - y1, o[i].z - z1);
-                                if (mode == 2) {
-                                    const float key = sqrtf(sq) + w[i];
-                                    if (key < k1) { k2 = k1; q2 = q1; k1 = key; q1 = pos[i]; }
-                                    else if (key < k2) { k2 = key; q2 = pos[i]; }
-                                    continue;
-                                }
-                                const float tt = cb - w[i];
-                                pass[i] = sq < tt * tt;
-                            }
-                        }
-                        if (mode != 2) {
+                        for (int i = 0; i < 4; i++) pass[i] = test(o[i], w[i], ps[i], in[i]);
+                        if (mode != 2 && (__ballot(pass[0] | pass[1] | pass[2] | pass[3]) & gmask) != 0ull) {
 #pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                const unsigned long long m = __ballot(pass[i]) & gmask;
-                                if (pass[i]) {
-                                    const int at = qn + __popcll(m & ((1ull << lane) - 1ull));
-                                    que[at] = pos[i];
-                                    qpr[at] = w[i];
-                                }
-                                qn += __popcll(m);
-                            }
+                            for (int i = 0; i < 4; i++) enqueue(pass[i], ps[i], w[i]);
                             if (qn > 4 * LPB) flush();
+                        }
+                    }
+                    if (longest > LPB) {
+                        for (int e = 0; e < E; e++) {
+                            const int ln = pre[e];
+                            if (ln <= LPB) continue;
+                            const int p0 = pp0[e];
+                            for (int off0 = LPB; off0 < ln; off0 += 2 * LPB) {
+                                const int a0 = off0 + sub, a1 = off0 + LPB + sub;
+                                const bool i0 = a0 < ln, i1 = a1 < ln;
+                                const int pa_i = p0 + (i0 ? a0 : 0), pb_i = p0 + (i1 ? a1 : 0);
+                                const F3A oa = *(const F3A *)&S[pa_i], ob = *(const F3A *)&S[pb_i];
+                                const float wa = ald(&PS[pa_i]), wb = ald(&PS[pb_i]);
+                                const bool pa_ = test(oa, wa, pa_i, i0), pb_ = test(ob, wb, pb_i, i1);
+                                if (mode != 2 && (__ballot(pa_ | pb_) & gmask) != 0ull) {
+                                    enqueue(pa_, pa_i, wa);
+                                    enqueue(pb_, pb_i, wb);
+                                    if (qn > 4 * LPB) flush();
+                                }
+                            }
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

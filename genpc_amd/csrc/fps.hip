@@ -53,6 +53,7 @@ struct FpsJobs {
     int stat0;                   // index of the launch's first cloud in the call (statistics)
     float *pdist[kFMaxJobs];     // the running minimum of every sample when it was drawn (fps_verify_kernel)
     int *verr[kFMaxJobs];        // != 0: the verification found a step whose sample is not the first arg-max
+    int segoff[kFMaxJobs];       // first point of the job in the verification's per-(point, segment) minima
     int legacy_pivot;            // test hook (genpc_fps_tune): the workers read the pivot as per-lane LDS broadcasts again -- the
                                  // form that drew wrong samples next to f16 MFMAs on another stream (tests/test_gpu_concurrency.py)
 };
@@ -471,49 +472,75 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
 // through scalar registers and with self-tagged pivot granules) a sampling running BESIDE other kernels drew a sample a step
 // early -- silently, mechanism not established.  A violation poisons out[0] with -1, which genpc_amd/fps.py
 // already treats as "this cloud again": a wrong sequence can no longer leave the library unnoticed, whatever causes it.
-constexpr int kFVBlock = 128, kFVTile = 1024;
-template <int FMA>
-__global__ __launch_bounds__(kFVBlock) void fps_verify_kernel(FpsJobs jobs)
+constexpr int kFVBlock = 128, kFVTile = 1024, kFVMaxSeg = 16;
+// The sample list is cut into `nseg` segments (grid.z) so that the whole chip takes part (one thread per point alone
+// leaves a 24000-point cloud on 188 two-wave blocks: 1.8 ms beside a 10 ms sampling).  CHECK = 0: the minimum over the
+// segment's samples of the point's distances -> segmin[point][segment]; CHECK = 1: the running minimum enters the segment
+// with the minimum of the earlier segments' results and the segment's steps are checked.  Twice the distance
+// evaluations, nseg times the threads.
+template <int FMA, int CHECK>
+__global__ __launch_bounds__(kFVBlock) void fps_verify_kernel(FpsJobs jobs, float *__restrict__ segmin, int nseg)
 {
     __shared__ float4 s_s[kFVTile];          // x, y, z of sample l; M of sample l + 1
     __shared__ int s_i[kFVTile];             // index of sample l + 1
-    const int job = blockIdx.y;
+    const int job = blockIdx.y, seg = blockIdx.z;
     const int n = jobs.n[job], k = jobs.k[job];
     const float *__restrict__ X = jobs.xyz[job];
     const int *__restrict__ out = jobs.out[job];
     const float *__restrict__ pd = jobs.pdist[job];
+    float *__restrict__ sm = segmin + (size_t)jobs.segoff[job] * nseg;
+    // samples l = 0 .. k - 2 are applied (sample l decides step l + 1); the segment's share, a multiple of 8 long
+    const int per = (((k - 1) + nseg - 1) / nseg + 7) & ~7;
+    const int l_lo = min(seg * per, k - 1), l_hi = min(l_lo + per, k - 1);
     bool bad = false;
     for (int i0 = blockIdx.x * kFVBlock; i0 < n; i0 += gridDim.x * kFVBlock) {      // (block-uniform: the tiles are staged together)
-        const int i = i0 + threadIdx.x;
-        const bool live = i < n;
-        const int ii = live ? i : n - 1;
-        const float px = X[(size_t)ii * 3 + 0], py = X[(size_t)ii * 3 + 1], pz = X[(size_t)ii * 3 + 2];
+        const int i = min(i0 + (int)threadIdx.x, n - 1);      // (lanes past the end repeat the last point)
+        const float px = X[(size_t)i * 3 + 0], py = X[(size_t)i * 3 + 1], pz = X[(size_t)i * 3 + 2];
         float D = __builtin_inff();
-        if (i == 0 && out[0] != 0) bad = true;      // (-1: the hand-off gave up; anything else: not the start point)
-        for (int l0 = 0; l0 < k - 1; l0 += kFVTile) {
+        if (CHECK) {
+            for (int g = 0; g < seg; g++) D = fminf(D, sm[(size_t)i * nseg + g]);
+            if (i == 0 && seg == 0 && out[0] != 0) bad = true;      // (-1: the hand-off gave up; anything else: not the start point)
+        }
+        for (int l0 = l_lo; l0 < l_hi; l0 += kFVTile) {
             __syncthreads();
-            for (int t = threadIdx.x; t < kFVTile && l0 + t < k - 1; t += kFVBlock) {
+            for (int t = threadIdx.x; t < kFVTile && l0 + t < l_hi; t += kFVBlock) {
                 int sl = out[l0 + t];
-                if ((unsigned)sl >= (unsigned)n || (unsigned)out[l0 + t + 1] >= (unsigned)n) bad = true;      // (not an index of the cloud)
+                if (CHECK && ((unsigned)sl >= (unsigned)n || (unsigned)out[l0 + t + 1] >= (unsigned)n)) bad = true;      // (not an index of the cloud)
                 sl = (unsigned)sl < (unsigned)n ? sl : 0;
                 s_s[t] = make_float4(X[(size_t)sl * 3 + 0], X[(size_t)sl * 3 + 1], X[(size_t)sl * 3 + 2], pd[l0 + t + 1]);
                 s_i[t] = out[l0 + t + 1];
             }
             __syncthreads();
-            const int cnt = min(kFVTile, k - 1 - l0);
-            for (int t = 0; t < cnt; t++) {
+            const int cnt = min(kFVTile, l_hi - l0);
+            // eight samples per trip: the LDS reads (broadcasts) and the eight independent distances first, then the
+            // running minimum's short dependent chain
+            int t = 0;
+            for (; t + 8 <= cnt; t += 8) {
+                float4 q[8];
+                int sj[8];
+                float dd[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { q[u] = s_s[t + u]; if (CHECK) sj[u] = s_i[t + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) dd[u] = sqdist_f<FMA>(px - q[u].x, py - q[u].y, pz - q[u].z);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    D = D < dd[u] ? D : dd[u];
+                    // D < M, or the tie goes to the lower index s_j; and s_j itself has exactly its recorded minimum
+                    if (CHECK) bad |= !(D < q[u].w || (D == q[u].w && i >= sj[u])) || (i == sj[u] && D != q[u].w);
+                }
+            }
+            for (; t < cnt; t++) {
                 const float4 q = s_s[t];
                 const float dd = sqdist_f<FMA>(px - q.x, py - q.y, pz - q.z);
                 D = D < dd ? D : dd;
                 const int sj = s_i[t];
-                // D < M, or the tie goes to the lower index s_j, or this IS s_j with exactly its recorded minimum
-                const bool okstep = D < q.w || (D == q.w && i >= sj);
-                bad |= live && !okstep;
-                bad |= live && i == sj && D != q.w;
+                if (CHECK) bad |= !(D < q.w || (D == q.w && i >= sj)) || (i == sj && D != q.w);
             }
         }
+        if (!CHECK && i0 + (int)threadIdx.x < n) sm[(size_t)i * nseg + seg] = D;
     }
-    if (__any(bad) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(jobs.verr[job], 1);
+    if (CHECK && __any(bad) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(jobs.verr[job], 1);      // (padding lanes repeat point n - 1: same verdict)
 }
 
 __global__ void fps_poison_kernel(FpsJobs jobs, int nj)
@@ -618,12 +645,16 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
     for (int j = 0; j < c; j++) { total_slots += 2 * (size_t)fps_workgroups(n[j]); total_k += ((size_t)k[j] + 63) / 64 * 64; }
     static const int env_verify = tune_env("GENPC_FPS_VERIFY", 1, "farthest point sampling: 1 = every sequence is checked on the device against the definition (a violation poisons out[0] = -1), 0 = no check");
     const size_t head = 256 + total_slots * sizeof(FpsSlot), verr_bytes = ((size_t)c * sizeof(int) + 255) / 256 * 256;
-    char *ws = (char *)workspace(7, head + verr_bytes + total_k * sizeof(float), st);
+    size_t total_n = 0;
+    for (int j = 0; j < c; j++) total_n += (size_t)n[j];
+    char *ws = (char *)workspace(7, head + verr_bytes + total_k * sizeof(float) + (env_verify ? total_n * kFVMaxSeg * sizeof(float) : 0), st);
     if (!ws) return 0;
     int *err = (int *)ws;
     FpsSlot *slots = (FpsSlot *)(ws + 256);
     int *verr = (int *)(ws + head);
     float *pdist = (float *)(ws + head + verr_bytes);
+    float *segmin = pdist + total_k;
+    size_t seg_off = 0;
     if (!check(hipMemsetAsync(ws, 0, head + verr_bytes, st), "hipMemsetAsync(fps)")) return 0;
     size_t pd_off = 0;
     int slot0 = 0;
@@ -646,6 +677,8 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
             jobs.out[nj] = out_idx[j];
             jobs.pdist[nj] = pdist + pd_off;
             jobs.verr[nj] = verr + j;
+            jobs.segoff[nj] = (int)seg_off;
+            seg_off += (size_t)n[j];
             pd_off += ((size_t)k[j] + 63) / 64 * 64;
             jobs.n[nj] = n[j];
             jobs.k[nj] = k[j];
@@ -669,9 +702,16 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
         if (env_verify) {
             int nmax = 1;
             for (int q = 0; q < nj; q++) nmax = jobs.n[q] > nmax ? jobs.n[q] : nmax;
-            const dim3 vg(ceil_div(nmax, kFVBlock), nj);
-            if (fma) hipLaunchKernelGGL((fps_verify_kernel<1>), vg, dim3(kFVBlock), 0, st, jobs);
-            else hipLaunchKernelGGL((fps_verify_kernel<0>), vg, dim3(kFVBlock), 0, st, jobs);
+            const int gxv = ceil_div(nmax, kFVBlock);
+            int nseg = (4 * cus) / (gxv * nj > 0 ? gxv * nj : 1);      // about four blocks per CU
+            nseg = nseg < 1 ? 1 : (nseg > kFVMaxSeg ? kFVMaxSeg : nseg);
+            const dim3 vg(gxv, nj, nseg);
+            if (nseg > 1) {
+                if (fma) hipLaunchKernelGGL((fps_verify_kernel<1, 0>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
+                else hipLaunchKernelGGL((fps_verify_kernel<0, 0>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
+            }
+            if (fma) hipLaunchKernelGGL((fps_verify_kernel<1, 1>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
+            else hipLaunchKernelGGL((fps_verify_kernel<0, 1>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
             hipLaunchKernelGGL(fps_poison_kernel, dim3(1), dim3(kFMaxJobs), 0, st, jobs, nj);
         }
         j0 += nj;
