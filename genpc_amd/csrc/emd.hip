@@ -810,15 +810,10 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     // 1 x 16384 1.61 -> 1.80: with ~1000-2000 bidders left per round one block walking the list is
     // slower than 64 -- so only for small clouds or many of them)
     static const int env_rf = tune_env("GENPC_EMD_RESOLVE_FROM", -1, "EMD: round from which a single block per cloud resolves (-1 = pick)");
-    // ... unless most points keep bidding (a partial scan against its ground truth: thousands of bidders per cloud in every
-    // round -- the single block took 70 us per round at 13 x 16384, profiles/r04_emd_B13_16384_scans.json): what the last
-    // call of this shape left in the feedback word (emd_auction.hip) decides
-    bool heavy = false;
-    {
-        volatile int *fb = emd_feedback_slot(b, n, false);
-        heavy = fb != nullptr && (long long)*fb * 100 > (long long)n * 35;
-    }
-    const int resolve_from = env_rf >= 0 ? env_rf : (((n <= 4096 || b >= 8) && !heavy) ? 4 : 0x7fffffff);
+    // (the single block also where most points keep bidding -- a partial scan against its ground truth, thousands of bidders
+    // per cloud in every round: measured in one process on the 13 bundled scans, 19.1 ms against 20.9 with the multi-block
+    // settle, whose per-object tickets and chain walks cost more there than one block's two passes)
+    const int resolve_from = env_rf >= 0 ? env_rf : ((n <= 4096 || b >= 8) ? 4 : 0x7fffffff);
     int GL = ceil_div(n, kEBlock);          // list-walking kernels
     if (GL > 64) GL = 64;
 

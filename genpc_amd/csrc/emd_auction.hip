@@ -51,7 +51,7 @@ constexpr unsigned kAStampPeriod = (1u << kAStampBits) - 1u;
 // per-cloud control block, 16 words (one 128-byte line) per item: lines 0..7 the arrival counters of the eight workgroup
 // classes (bx % 8: an XCD each when the runtime deals workgroups round-robin), lines 8..15 their release words
 // (epoch | abort << 32), line 16 the top counter, line 17 the number of bidders left
-constexpr int kCtrlWords = 18 * 16;
+constexpr int kCtrlWords = 19 * 16;      // (line 18: the one-word barrier of small clouds)
 
 template <class T> __device__ __forceinline__ T ald(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void ast(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -106,6 +106,7 @@ struct EmdAuction {
     unsigned long long *ctrl;               // per cloud kCtrlWords words on 128-byte lines: see cloud_barrier
     int *status;                            // sticky: != 0 once a call gave up (genpc_emd_status)
     unsigned spin_limit;
+    int flat_max;                           // clouds of up to this many workgroups take the one-word barrier
     unsigned long long *timeline;           // debug (GENPC_EMD_TIMELINE=1): 100 MHz stamps of workgroup 0, 8 per round, 64 rounds
 };
 
@@ -123,11 +124,28 @@ __global__ __launch_bounds__(kABlock) void emd_auction_init_kernel(int b, int n,
 // monotone counters, `epoch` = the barrier's ordinal from 1); the last of a class arrives at the top counter; the last
 // there stores the epoch to the eight release words; everybody polls ITS class's release word.  (One word for arrivals and
 // polls cost 35 ns per arrival: 512 workgroups, 18 us per barrier -- the pollers' loads queue in front of the atomics.)
-__device__ __forceinline__ bool cloud_barrier(unsigned long long *ctrl, int bx, int G, unsigned epoch, unsigned spin_limit, int *s_flag)
+__device__ __forceinline__ bool cloud_barrier(unsigned long long *ctrl, int bx, int G, unsigned epoch, unsigned spin_limit, int *s_flag, int flat_max)
 {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's stores and atomics have been acknowledged
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && G <= flat_max) {
+        // few workgroups: ONE word, arrived at without waiting for the old value and polled at a leisurely pace (the polls of
+        // a hundred workgroups a microsecond apart do not get in the way of the arrivals; the two-level form below is four
+        // dependent round trips -- arrive, top, release, poll -- ~4.5 us)
+        unsigned long long *word = ctrl + 18 * 16;
+        (void)__hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        unsigned long long r = ald(word);
+        while ((unsigned)r < (unsigned)G * epoch && (r >> 32) == 0ull) {
+            __builtin_amdgcn_s_sleep(4);
+            r = ald(word);
+            if (++spins > spin_limit) {
+                __hip_atomic_fetch_or(word, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                r |= 1ull << 32;
+            }
+        }
+        *s_flag = (r >> 32) != 0ull ? 1 : 0;
+    } else if (threadIdx.x == 0) {
         const int cls = bx & 7, ncls = G < 8 ? G : 8;
         const unsigned size = (unsigned)((G - cls + 7) >> 3);
         unsigned long long *rel = ctrl + (8 + cls) * 16;
@@ -211,7 +229,7 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
         if (it > 0 && stamp == 1u) {
             // the stamp wraps: hand the head words back clean (object j's words by thread j), once per 16383 rounds
             ast(&a.chain_head[base + j], 0ull);
-            ok = cloud_barrier(bar, bx, G, ++nbar, a.spin_limit, &s_flag);
+            ok = cloud_barrier(bar, bx, G, ++nbar, a.spin_limit, &s_flag, a.flat_max);
             if (!ok) break;
         }
         const bool tl = a.timeline != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && it < 64;
@@ -511,7 +529,7 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
             }
         }
         if (tl) a.timeline[it * 16 + 2] = wall_clock64();
-        ok = cloud_barrier(bar, bx, G, ++nbar, a.spin_limit, &s_flag);
+        ok = cloud_barrier(bar, bx, G, ++nbar, a.spin_limit, &s_flag, a.flat_max);
         if (!ok) break;
         if (tl) a.timeline[it * 16 + 3] = wall_clock64();
         // ---------------- GetMax + Assign (emd_cuda.cu:181-215) ----------------
@@ -594,7 +612,7 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
         }
         if (tl) a.timeline[it * 16 + 4] = wall_clock64();
         if (last) break;
-        ok = cloud_barrier(bar, bx, G, ++nbar, a.spin_limit, &s_flag);
+        ok = cloud_barrier(bar, bx, G, ++nbar, a.spin_limit, &s_flag, a.flat_max);
         if (!ok) break;
         if (tl) a.timeline[it * 16 + 5] = wall_clock64();
     }
@@ -759,6 +777,8 @@ int launch_emd_auction(int b, int n, const float *xyz1, const float *xyz2, float
     a.ctrl = ctrl; a.status = status;
     static const int env_spin = tune_env("GENPC_EMD_AUCTION_SPIN", 1 << 21, "one-launch EMD: polls of a barrier before the call is abandoned");
     a.spin_limit = (unsigned)env_spin;
+    static const int env_flat = tune_env("GENPC_EMD_AUCTION_FLAT", 128, "one-launch EMD: clouds of up to this many workgroups use the one-word barrier");
+    a.flat_max = env_flat;
     static const int env_tl = tune_env("GENPC_EMD_TIMELINE", 0, "one-launch EMD: 1 = workgroup 0 stamps the phases of the first 64 rounds (genpc_debug_emd_timeline)");
     a.timeline = env_tl ? (unsigned long long *)workspace(32, 64 * 16 * 8, nullptr, nullptr, 64 * 16 * 8) : nullptr;
     if (fma) hipLaunchKernelGGL((emd_auction_kernel<1>), dim3(wgs), dim3(kABlock), 0, st, a);

@@ -483,6 +483,7 @@ __global__ __launch_bounds__(kFVBlock) void fps_verify_kernel(FpsJobs jobs, floa
 {
     __shared__ float4 s_s[kFVTile];          // x, y, z of sample l; M of sample l + 1
     __shared__ int s_i[kFVTile];             // index of sample l + 1
+    __shared__ unsigned s_hit[kFVTile / 256];      // per trip of eight samples: one of them is a point of this block
     const int job = blockIdx.y, seg = blockIdx.z;
     const int n = jobs.n[job], k = jobs.k[job];
     const float *__restrict__ X = jobs.xyz[job];
@@ -503,12 +504,16 @@ __global__ __launch_bounds__(kFVBlock) void fps_verify_kernel(FpsJobs jobs, floa
         }
         for (int l0 = l_lo; l0 < l_hi; l0 += kFVTile) {
             __syncthreads();
+            if (CHECK && threadIdx.x < kFVTile / 256) s_hit[threadIdx.x] = 0u;
+            if (CHECK) __syncthreads();
             for (int t = threadIdx.x; t < kFVTile && l0 + t < l_hi; t += kFVBlock) {
                 int sl = out[l0 + t];
                 if (CHECK && ((unsigned)sl >= (unsigned)n || (unsigned)out[l0 + t + 1] >= (unsigned)n)) bad = true;      // (not an index of the cloud)
                 sl = (unsigned)sl < (unsigned)n ? sl : 0;
                 s_s[t] = make_float4(X[(size_t)sl * 3 + 0], X[(size_t)sl * 3 + 1], X[(size_t)sl * 3 + 2], pd[l0 + t + 1]);
-                s_i[t] = out[l0 + t + 1];
+                const int sn = out[l0 + t + 1];
+                s_i[t] = sn;
+                if (CHECK && (unsigned)(sn - i0) < (unsigned)kFVBlock) atomicOr(&s_hit[t >> 8], 1u << ((t >> 3) & 31));
             }
             __syncthreads();
             const int cnt = min(kFVTile, l_hi - l0);
@@ -517,17 +522,37 @@ __global__ __launch_bounds__(kFVBlock) void fps_verify_kernel(FpsJobs jobs, floa
             int t = 0;
             for (; t + 8 <= cnt; t += 8) {
                 float4 q[8];
-                int sj[8];
                 float dd[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { q[u] = s_s[t + u]; if (CHECK) sj[u] = s_i[t + u]; }
+                for (int u = 0; u < 8; u++) q[u] = s_s[t + u];
 #pragma unroll
                 for (int u = 0; u < 8; u++) dd[u] = sqdist_f<FMA>(px - q[u].x, py - q[u].y, pz - q[u].z);
+                if (!CHECK) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) D = D < dd[u] ? D : dd[u];
+                    continue;
+                }
+                // the common case costs one comparison per step: D < M.  A step with D >= M -- the sample itself (D == M), an exact
+                // tie, or a violation -- is rare and looked at again below with the index rule
+                const float D0 = D;
+                bool ge = false;
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     D = D < dd[u] ? D : dd[u];
-                    // D < M, or the tie goes to the lower index s_j; and s_j itself has exactly its recorded minimum
-                    if (CHECK) bad |= !(D < q[u].w || (D == q[u].w && i >= sj[u])) || (i == sj[u] && D != q[u].w);
+                    ge |= D >= q[u].w;
+                }
+                // (a sample whose recorded minimum is too HIGH has D < M at its own step: the trips in which a point of THIS block
+                // is sampled are marked while the tile is staged and take the full rule whatever the comparison says)
+                const bool hit = CHECK && ((s_hit[t >> 8] >> ((t >> 3) & 31)) & 1u) != 0u;
+                if (hit || __any(ge)) {
+                    float E = D0;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        E = E < dd[u] ? E : dd[u];
+                        const int sj = s_i[t + u];
+                        // E < M, or the tie goes to the lower index s_j; and s_j itself has exactly its recorded minimum
+                        bad |= !(E < q[u].w || (E == q[u].w && i >= sj)) || (i == sj && E != q[u].w);
+                    }
                 }
             }
             for (; t < cnt; t++) {

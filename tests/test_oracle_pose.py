@@ -130,6 +130,19 @@ def test_pose_loop_recovers_known_similarity(oracle):
     np.testing.assert_allclose(T[:3, 3], [0.02, -0.01, 0.015], atol=0.01)
 
 
+def test_oracle_loop_stops_after_300_steps_without_improvement(oracle):
+    """diff_obj_pose.py:529-556: patience 300, counted after the optimizer step.  With lr = 0 nothing improves after the
+    first iteration: iterations 0 .. 301 run, the rest are NaN in the history, every start alike; with a live learning rate
+    and iters <= 300 nothing is cut."""
+    v, partial, _ = make_case(3, nc=120, npart=90)
+    T, hist, bp = oracle.pose_optimize_cd(v, partial, lr=0.0, iters=330, starts=2)
+    assert hist.shape == (2, 331)
+    assert np.isfinite(hist[:, :302]).all() and np.isnan(hist[:, 302:]).all()
+    assert (hist[:, :302] == hist[:, :1]).all()
+    T2, h2, _ = oracle.pose_optimize_cd(v, partial, lr=0.01, iters=60, starts=2)
+    assert np.isfinite(h2).all()
+
+
 def test_camera_properties(oracle):
     eyes = oracle.fibonacci_sphere(64, 1.6)
     assert np.allclose(np.linalg.norm(eyes, axis=1), 1.6)

@@ -1,0 +1,44 @@
+"""DESIGN.md = tools/DESIGN.template.md with the <...> tokens replaced by the numbers of a bench.py line:
+    python tools/fill_design.py gpurun_out/bench_r05.json"""
+import json, sys, os
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+e = d["extra"]
+r = d["roofline"]
+tok = {}
+tok["NN_FRAC"] = "%.3f" % r["frac"]
+tok["NN_KERNEL_US"] = "%.1f" % (r["ms_per_launch"] * 1e3)
+tok["NN_STEP_US"] = "%.1f" % (d["ms_per_step"] * 1e3)
+tok["NN_TPAIR"] = "%.1f" % (d["value"] / 1e3)
+tok["EMD_FRAC"] = "%.3f" % e["emd_fwd_n16384_roofline"]["frac"]
+rows = []
+for k, v in e["streaming_rooflines_64x32768"].items():
+    rows.append("| %s | `%s` | %s | %.1f µs | %.0f | %.3f |" % (v["row"], v["kernel"], v["bytes_model"], v["ms_per_launch"] * 1e3, v["achieved"], v["frac"]))
+tok["STREAMING_TABLE"] = "\n".join(rows)
+u = e["get_uvs_1024x71372_roofline"]
+tok["UVS_US"] = "%.0f" % (u["ms_per_call"] * 1e3)
+tok["UVS_FRAC"] = "%.3f" % u["frac"]
+tok["UVS_FRAC629"] = "%.2f" % u["frac_of_6.29TBs_achievable"]
+tok["REG_LINE"] = ("registration + metric of one scan %.1f scans/s (six such scans in flight %.1f), eight scans in lock-step %.1f (three groups in flight "
+                   "%.1f); FPS 4 x 165546 -> 16384 in %.1f ms including its verification; the C2 chain (8192-point partial -> completed scan, metric "
+                   "included) %.1f scans/s one at a time, %.1f with six in flight; the C5 rank shape (8 x 32768) %.1f scans/s"
+                   % (e["registration_8k_vs_16k_4x201_plus_metric_scans_per_s"], e["registration_8k_vs_16k_6_scans_in_flight_scans_per_s"],
+                      e["registration_batch8_8k_vs_16k_4x201_plus_metric_scans_per_s"], e["registration_batch8_3_groups_in_flight_scans_per_s"],
+                      e["fps_4x165546_to_16384_ms"], e["c2_pipeline_8192_scans_per_s"], e["c2_pipeline_8192_scans_in_flight_scans_per_s"],
+                      e["c5_rank_8x32768_registration_plus_metric_scans_per_s"]))
+tok["HPR_1024"] = "%.1f" % e["hpr_1024x10000_R10000_ms"]
+tok["HPR_2"] = "%.1f" % e["hpr_2x165546_R10000_ms"]
+tok["FPS_VERIFY"] = os.environ.get("FPS_VERIFY_SHARE", "a tenth")
+tok["BENCH_LINE"] = ("%.0f Gpair/s (%.1f µs per step, spread %.1f–%.1f), `roofline.frac` %.3f, CPU port %.2f Gpair/s on %d threads; EMD 1 × 16384 %.2f ms, "
+                     "13 bundled scans %.1f ms, 13 uniform %.2f ms; metric %.0f scans/s (`%s`)"
+                     % (d["value"], d["ms_per_step"] * 1e3, d["ms_per_step_spread"]["min"] * 1e3, d["ms_per_step_spread"]["max"] * 1e3, r["frac"],
+                        d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], e["emd_fwd_n16384_eps0.005_it50_ms"],
+                        e["emd_fwd_13_bundled_scans_n16384_ms"], e["emd_fwd_B13_uniform_n16384_ms"], e["metric_cd_emd_n16384_scans_per_s"],
+                        os.path.relpath(sys.argv[1], ROOT) if not sys.argv[1].startswith("profiles") else sys.argv[1]))
+s = open(os.path.join(ROOT, "tools", "DESIGN.template.md")).read()
+for k, v in tok.items():
+    s = s.replace("⟨%s⟩" % k, v)
+left = [w for w in s.split("⟨")[1:]]
+assert not left, [w[:30] for w in left]
+open(os.path.join(ROOT, "DESIGN.md"), "w").write(s)
+print("DESIGN.md written")

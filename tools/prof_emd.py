@@ -18,6 +18,8 @@ else:
     X = torch.from_numpy(rng.random((b, n, 3), dtype=np.float32)).cuda()
     Y = torch.from_numpy(rng.random((b, n, 3), dtype=np.float32)).cuda()
 em = emdModule()
+em(X, Y, 0.005, 50)
+torch.cuda.synchronize()      # (the first call's bidder count -- pinned feedback word -- decides the path of the following ones)
 for _ in range(reps):
     d, a = em(X, Y, 0.005, 50)
 torch.cuda.synchronize()
