@@ -614,6 +614,58 @@ __global__ __launch_bounds__(kBlock) void chamfer_grad_kernel(int b, int n, cons
     }
 }
 
+// The scattered halves of large calls without global atomics (round 5).  The float atomics of PHASE 2 each cost a 64-byte
+// memory transaction (profiles/r05_streaming_64x32768.json: 790 MB of HBM traffic for 4 M points' 24-byte updates, 612 us).
+// Here a block OWNS a tile of kGradTile target rows of one cloud and direction: it walks the index array of the other cloud,
+// accumulates the terms that land in its tile in LDS (ds_add_f32), and adds the tile to the gradient with plain coalesced
+// read-modify-writes -- every output row has exactly one owner, and the own-row launch (PHASE 1) has finished before.
+// grid (tiles, b, 2).
+constexpr int kGradTile = 4096;
+__global__ __launch_bounds__(kBlock) void chamfer_grad_scatter_tiled_kernel(int n, const float *__restrict__ xyz1, int m,
+                                                                            const float *__restrict__ xyz2,
+                                                                            const float *__restrict__ gd1, const int *__restrict__ idx1,
+                                                                            const float *__restrict__ gd2, const int *__restrict__ idx2,
+                                                                            float *__restrict__ gx1, float *__restrict__ gx2)
+{
+    __shared__ float acc[kGradTile * 3];
+    const int dir = blockIdx.z, e = blockIdx.y;
+    // direction 0: queries = cloud 1 (n points), targets = cloud 2 (m rows of gx2); direction 1 the converse
+    const int nq = dir ? m : n, nt = dir ? n : m;
+    const int t0 = blockIdx.x * kGradTile;
+    if (t0 >= nt) return;
+    const float *__restrict__ Q = (dir ? xyz2 : xyz1) + (size_t)e * nq * 3;
+    const float *__restrict__ T = (dir ? xyz1 : xyz2) + (size_t)e * nt * 3;
+    const float *__restrict__ G = (dir ? gd2 : gd1) + (size_t)e * nq;
+    const int *__restrict__ I = (dir ? idx2 : idx1) + (size_t)e * nq;
+    float *__restrict__ O = (dir ? gx1 : gx2) + (size_t)e * nt * 3;
+    const int rows = min(kGradTile, nt - t0);
+    for (int i = threadIdx.x; i < rows * 3; i += kBlock) acc[i] = 0.0f;
+    __syncthreads();
+    // eight indices in flight per thread (one per trip left every trip waiting for its own load: the loop is a walk over the
+    // whole index array in which one entry in eight does anything)
+    for (int q0 = threadIdx.x; q0 < nq; q0 += 8 * kBlock) {
+        int kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = q0 + u * kBlock;
+            kk[u] = q < nq ? I[q] - t0 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = kk[u], q = q0 + u * kBlock;
+            if ((unsigned)k >= (unsigned)rows) continue;
+            const float x1 = Q[(size_t)q * 3 + 0], y1 = Q[(size_t)q * 3 + 1], z1 = Q[(size_t)q * 3 + 2];
+            const float x2 = T[(size_t)(t0 + k) * 3 + 0], y2 = T[(size_t)(t0 + k) * 3 + 1], z2 = T[(size_t)(t0 + k) * 3 + 2];
+            const float g = __fmul_rn(G[q], 2.0f);
+            atomicAdd(&acc[k * 3 + 0], -__fmul_rn(g, x1 - x2));
+            atomicAdd(&acc[k * 3 + 1], -__fmul_rn(g, y1 - y2));
+            atomicAdd(&acc[k * 3 + 2], -__fmul_rn(g, z1 - z2));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * 3; i += kBlock) O[(size_t)t0 * 3 + i] = __fadd_rn(O[(size_t)t0 * 3 + i], acc[i]);
+}
+
 struct NNConfig {
     int r;                // VALU path, queries per lane: 0 = pick, else 2 or 4
     int blocks_per_cu;    // occupancy target used to pick the slice count
@@ -1050,8 +1102,14 @@ GENPC_API int genpc_chamfer_backward(int b, int n, const float *xyz1, int m, con
     if (env_split > 0 && (long long)b * ((long long)n + m) >= env_split) {
         hipLaunchKernelGGL(chamfer_grad_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, b, n, xyz1, m,
                            xyz2, graddist1, idx1, graddist2, idx2, gradxyz1, gradxyz2);
-        hipLaunchKernelGGL(chamfer_grad_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, b, n, xyz1, m,
-                           xyz2, graddist1, idx1, graddist2, idx2, gradxyz1, gradxyz2);
+        static const int env_tiled = tune_env("GENPC_CHAMFER_GRAD_TILED", 1, "chamfer backward, large calls: 1 = the scattered halves through LDS tiles that own their output rows, 0 = global atomics");
+        const int tiles = ceil_div(n > m ? n : m, kGradTile);
+        if (env_tiled && tiles <= 65535 && b <= 65535)
+            hipLaunchKernelGGL(chamfer_grad_scatter_tiled_kernel, dim3(tiles, b, 2), dim3(kBlock), 0, (hipStream_t)stream, n, xyz1, m, xyz2,
+                               graddist1, idx1, graddist2, idx2, gradxyz1, gradxyz2);
+        else
+            hipLaunchKernelGGL(chamfer_grad_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, b, n, xyz1, m,
+                               xyz2, graddist1, idx1, graddist2, idx2, gradxyz1, gradxyz2);
     } else {
         hipLaunchKernelGGL(chamfer_grad_kernel<0>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, b, n, xyz1, m,
                            xyz2, graddist1, idx1, graddist2, idx2, gradxyz1, gradxyz2);

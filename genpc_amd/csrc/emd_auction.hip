@@ -129,9 +129,9 @@ __device__ __forceinline__ bool cloud_barrier(unsigned long long *ctrl, int bx, 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's stores and atomics have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0 && G <= flat_max) {
-        // few workgroups: ONE word, arrived at without waiting for the old value and polled at a leisurely pace (the polls of
-        // a hundred workgroups a microsecond apart do not get in the way of the arrivals; the two-level form below is four
-        // dependent round trips -- arrive, top, release, poll -- ~4.5 us)
+        // A/B form (GENPC_EMD_AUCTION_FLAT, off): ONE word, arrived at without waiting for the old value and polled at a
+        // leisurely pace.  Slower than the two-level form below even at 64 workgroups: a word that is arrived at is a bad word
+        // to poll on this chip.
         unsigned long long *word = ctrl + 18 * 16;
         (void)__hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
@@ -777,7 +777,9 @@ int launch_emd_auction(int b, int n, const float *xyz1, const float *xyz2, float
     a.ctrl = ctrl; a.status = status;
     static const int env_spin = tune_env("GENPC_EMD_AUCTION_SPIN", 1 << 21, "one-launch EMD: polls of a barrier before the call is abandoned");
     a.spin_limit = (unsigned)env_spin;
-    static const int env_flat = tune_env("GENPC_EMD_AUCTION_FLAT", 128, "one-launch EMD: clouds of up to this many workgroups use the one-word barrier");
+    // (measured and OFF: 13 x 16384 -- 64 workgroups per cloud -- 1.68 ms with the two-level barrier, 2.60 with one word per cloud
+    // that is both arrived at and polled, however leisurely the polls; 1 x 16384 at 4 lanes per point 1.05 = 1.05)
+    static const int env_flat = tune_env("GENPC_EMD_AUCTION_FLAT", 0, "one-launch EMD: clouds of up to this many workgroups use a one-word barrier (0 = never: measured slower)");
     a.flat_max = env_flat;
     static const int env_tl = tune_env("GENPC_EMD_TIMELINE", 0, "one-launch EMD: 1 = workgroup 0 stamps the phases of the first 64 rounds (genpc_debug_emd_timeline)");
     a.timeline = env_tl ? (unsigned long long *)workspace(32, 64 * 16 * 8, nullptr, nullptr, 64 * 16 * 8) : nullptr;

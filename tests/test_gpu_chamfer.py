@@ -118,6 +118,32 @@ def test_backward_vs_oracle(gp, oracle):
     np.testing.assert_allclose(B.grad.cpu().numpy(), e2, rtol=1e-5, atol=1e-6)
 
 
+def test_backward_large_call_forms(gp, oracle):
+    """From 262144 points per call the backward is two launches: own rows by plain read-modify-write, then the scattered
+    halves through LDS tiles that own their output rows (csrc/chamfer.hip: chamfer_grad_scatter_tiled_kernel) -- against the
+    oracle, ragged sizes (a last tile of 904 rows, a cloud smaller than a tile), indices that pile up on few targets."""
+    torch = gp["torch"]
+    rng = np.random.default_rng(77)
+    bsz, n, m = 24, 9096, 3000            # 24 x (9096 + 3000) = 290 k points
+    a = (rng.random((bsz, n, 3), dtype=np.float32) - np.float32(0.5))
+    b = (rng.random((bsz, m, 3), dtype=np.float32) - np.float32(0.5))
+    i1 = rng.integers(0, m, (bsz, n)).astype(np.int32)
+    i2 = rng.integers(0, 40, (bsz, m)).astype(np.int32)           # crowded: 3000 queries on 40 targets
+    g1 = rng.random((bsz, n), dtype=np.float32)
+    g2 = rng.random((bsz, m), dtype=np.float32)
+    from genpc_amd import _lib
+    L, p = _lib.lib, _lib.ptr
+    A, B, G1, G2, I1, I2 = (torch.from_numpy(x).cuda() for x in (a, b, g1, g2, i1, i2))
+    ga, gb = torch.zeros_like(A), torch.zeros_like(B)
+    assert _lib.on_device_of(A, L.genpc_chamfer_backward, bsz, n, p(A), m, p(B), p(G1), p(I1), p(G2), p(I2), p(ga), p(gb)) == 1
+    e1, e2 = oracle.chamfer_backward(a, b, g1, g2, i1, i2)
+    np.testing.assert_allclose(ga.cpu().numpy(), e1, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(gb.cpu().numpy(), e2, rtol=2e-5, atol=2e-4)      # (75 terms per crowded row, summed in another order)
+    # it accumulates into what the caller hands in, like the reference (a second call doubles the result)
+    assert _lib.on_device_of(A, L.genpc_chamfer_backward, bsz, n, p(A), m, p(B), p(G1), p(I1), p(G2), p(I2), p(ga), p(gb)) == 1
+    np.testing.assert_allclose(ga.cpu().numpy(), 2 * e1, rtol=1e-5, atol=4e-6)
+
+
 def test_full_size_properties(gp):
     """BASELINE sizes (16384 and 32768 points): size-independent properties.
     (i) self-distance is exactly zero with idx = identity; (ii) a permutation of the
