@@ -117,8 +117,10 @@ class DepthPrompting:
         (default: this object's), radius: cfg.removal_radius by default."""
         return self.hidden_point_removal(points, viewpoints, radius)[0]
 
-    def hidden_point_removal(self, points, viewpoints=None, radius=None, best_only=False):
-        """-> (visible [C,N] bool, counts [C] int32, points that needed the large-polygon pass).
+    def hidden_point_removal(self, points, viewpoints=None, radius=None, best_only=False, want_second=False):
+        """-> (visible [C,N] bool, counts [C] int32, points that needed the wave-per-point passes -- 0 unless
+        want_second: that count is the one thing of this operator the host has to wait for; without it the call
+        enqueues its kernels and returns).  An internal error of the library (none known) turns every count into -1.
         best_only=True (viewpoint_select): the library stops working on views that can no longer see the most
         points; counts are then exact for the views that could, lower bounds below the maximum for the rest
         (argmax unchanged), and `visible` is complete only for the former."""
@@ -128,8 +130,18 @@ class DepthPrompting:
             radius = self.cfg.removal_radius
         points = points.contiguous().float()
         _lib.check_tensors((("points", points),))
-        eyes = torch.as_tensor(np.asarray(viewpoints.cpu() if torch.is_tensor(viewpoints) else viewpoints, np.float64)
-                               ).reshape(-1, 3).contiguous().to(points.device)
+        if torch.is_tensor(viewpoints) and viewpoints.device == points.device:
+            eyes = viewpoints.double().reshape(-1, 3).contiguous()
+        else:
+            # (an upload from pageable memory waits for the stream: the device copy of a viewpoint set is kept, keyed by content)
+            host = np.ascontiguousarray(np.asarray(viewpoints.cpu() if torch.is_tensor(viewpoints) else viewpoints, np.float64).reshape(-1, 3))
+            key = (str(points.device), host.shape[0], hash(host.tobytes()))
+            cache = self.__dict__.setdefault("_eyes_on_device", {})
+            if key not in cache:
+                if len(cache) >= 8:
+                    cache.clear()
+                cache[key] = torch.from_numpy(host).to(points.device)
+            eyes = cache[key]
         c, n = eyes.shape[0], points.shape[0]
         vis = torch.zeros(c, n, device=points.device, dtype=torch.uint8)
         cnt = torch.empty(c, device=points.device, dtype=torch.int32)
@@ -143,12 +155,13 @@ class DepthPrompting:
         for v0 in range(0, c, step):
             v1 = min(c, v0 + step)
             second = ctypes.c_int(0)
+            sp = ctypes.addressof(second) if want_second else None
             if best_only and v0 == 0 and v1 == c:      # (pruning needs all views in one call)
                 rc = _lib.on_device_of(points, _L.genpc_hpr_best_view_counts, c, n, _p(points), _p(eyes), float(radius),
-                                       _p(vis), _p(cnt), None, ctypes.addressof(second))
+                                       _p(vis), _p(cnt), None, sp)
             else:
                 rc = _lib.on_device_of(points, _L.genpc_hpr_visibility, v1 - v0, n, _p(points), _p(eyes[v0:v1]), float(radius),
-                                       _p(vis[v0:v1]), _p(cnt[v0:v1]), ctypes.addressof(second))
+                                       _p(vis[v0:v1]), _p(cnt[v0:v1]), sp)
             if rc != 1:
                 raise RuntimeError("genpc_hpr_visibility failed (rc=%d): %s" % (rc, _lib.last_error()))
             total_second += int(second.value)
@@ -190,7 +203,11 @@ class DepthPrompting:
         else:
             _, counts, _ = self.hidden_point_removal(xyz_fps, self.viewpoints, getattr(self.cfg, "removal_radius", 10000),
                                                      best_only=True)
-        return int(torch.argmax(counts))
+        top, best = torch.max(counts, 0)
+        top, best = torch.stack([top.long(), best]).tolist()          # (one host read)
+        if top < 0:
+            raise RuntimeError("genpc_hpr_best_view_counts: internal error (the library marked its counts invalid)")
+        return int(best)
 
     # DepthPrompting.py:69-85
     def getImage(self, xyz, flag, rgb=None, depth_gen=True, img_gen=True):

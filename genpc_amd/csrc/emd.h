@@ -119,6 +119,7 @@ struct EmdGridBid {
     unsigned long long *chain_head, *chain_next;
     int *chain_cnt;                // bidders per object this round (emd_settle_kernel)
     int *feedback;                 // round 3 only (else null): pinned host word that receives cloud 0's bidder count (emd_auction.hip: which path suits the data)
+    const float *cell_pmin;        // per cloud, cells_max + 1 floats: a lower bound of the prices in every cell, +inf for an empty one (emd_cell_pmin_kernel); null: rows are not culled by price
     unsigned long long *stats;     // hook (genpc_emd_tune): [0] bidders, [1] rows of their boxes, [2] rows kept, [3] objects tested, [4] exact evaluations, [5] first-place ties, [6] unseeded bidders; else null
 };
 int launch_emd_grid_build(int b, int n, const float *xyz2, const float *price, EGridHdr *hdr, int *start, float4 *sorted, int *pos_of,
@@ -130,6 +131,7 @@ int *emd_feedback_slot(int b, int n, bool device);
 bool persist_reserve(int wgs, int capacity, hipStream_t st);
 void persist_commit(int wgs, hipStream_t st);
 int launch_emd_bid_grid(const EmdGridBid &a, int fma, hipStream_t st);
+int launch_emd_cell_pmin(int b, int cells_max, const EGridHdr *hdr, const int *start, const float4 *sorted, int n, float *pmin, hipStream_t st);
 
 // ---- seeded nearest neighbours of the alignment loop (nn_seeded.hip) ----
 struct SeededGrids {

@@ -752,14 +752,18 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     const size_t g_hdr = grid ? al256((size_t)b * sizeof(EGridHdr)) : 0, g_start = grid ? al256((size_t)b * (cells_max + 1) * sizeof(int)) : 0;
     const size_t g_sorted = grid ? al256((size_t)total * sizeof(float4)) : 0, g_pos = grid ? al256((size_t)total * sizeof(int)) : 0;
     const size_t g_ps = grid ? al256((size_t)total * sizeof(float)) : 0;
+    // per-cell lower bounds of the prices (emd_grid.hip: the bid culls cell by cell with them), refreshed in front of a round's bid
+    static const int env_cc = tune_env("GENPC_EMD_CELLCULL", 1, "culled EMD bid: refresh the cells' smallest prices every this many rounds and cull cells by them (0 = rows are culled by distance only)");
+    const size_t g_pm = grid && env_cc > 0 ? al256((size_t)b * (cells_max + 1) * sizeof(float)) : 0;
     const size_t grid_off = arrive_bytes + list_bytes + second_bytes + parts_bytes + chain_bytes;
-    char *ws = (char *)workspace(1, grid_off + g_hdr + g_start + g_sorted + g_pos + g_ps, st, nullptr, arrive_bytes);
+    char *ws = (char *)workspace(1, grid_off + g_hdr + g_start + g_sorted + g_pos + g_ps + g_pm, st, nullptr, arrive_bytes);
     if (!ws) return 0;
     EGridHdr *g_hdr_p = (EGridHdr *)(ws + grid_off);
     int *g_start_p = (int *)(ws + grid_off + g_hdr);
     float4 *g_sorted_p = (float4 *)(ws + grid_off + g_hdr + g_start);
     int *g_pos_p = grid ? (int *)(ws + grid_off + g_hdr + g_start + g_sorted) : nullptr;
     int *g_of_p = grid ? (int *)(ws + grid_off + g_hdr + g_start + g_sorted + g_pos) : nullptr;
+    float *g_pm_p = g_pm ? (float *)(ws + grid_off + g_hdr + g_start + g_sorted + g_pos + g_ps) : nullptr;
     float *g_ps_p = grid ? (float *)g_sorted_p + 3 : nullptr;      // the price of sorted position p: g_ps_p[4 p] (the .w of its entry)
     unsigned long long *chain_head = settle ? (unsigned long long *)(ws + arrive_bytes + list_bytes + second_bytes + parts_bytes) : nullptr;
     unsigned long long *chain_next = settle ? chain_head + total : nullptr;
@@ -838,6 +842,11 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
             ga.list = lists[cur]; ga.cnt = cnts[cur]; ga.start = g_start_p; ga.cnt_next = cnts[nxt];
             ga.bid = bid; ga.second = second; ga.bid_increments = bid_increments; ga.max_increments = max_increments;
             ga.sorted = g_sorted_p; ga.hdr = g_hdr_p;
+            // (round 0: every price is the caller's initial one -- zero in the reference's use --, nothing to cull by)
+            if (g_pm_p != nullptr && it >= 1) {
+                if ((it - 1) % env_cc == 0 && !launch_emd_cell_pmin(b, cells_max, g_hdr_p, g_start_p, g_sorted_p, n, g_pm_p, st)) return 0;
+                ga.cell_pmin = g_pm_p;
+            }
             ga.chain_head = use_chain ? chain_head : nullptr; ga.chain_next = chain_next; ga.chain_cnt = chain_cnt;
             ga.feedback = it == 3 ? emd_feedback_slot(b, n, true) : nullptr;
             ga.stats = (t_emd_hooks & 1) ? (unsigned long long *)workspace(28, 256, nullptr, nullptr, 256) : nullptr;

@@ -227,6 +227,23 @@ __global__ __launch_bounds__(kEGBlock) void emd_grid_build_kernel(int n, const f
     }
 }
 
+// pmin[batch][c] = the smallest price among the objects of cell c as the sorted copy holds them now, +inf for an empty cell.
+// Prices only rise: a table computed before any later round stays a lower bound.
+__global__ __launch_bounds__(256) void emd_cell_pmin_kernel(int cells_max, const EGridHdr *__restrict__ hdr, const int *__restrict__ start,
+                                                            const float4 *__restrict__ sorted, int n, float *__restrict__ pmin)
+{
+    const int batch = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c > cells_max) return;
+    float m = __builtin_inff();
+    if (c < hdr[batch].cells) {
+        const int *st = start + (size_t)batch * (cells_max + 1);
+        const float4 *S = sorted + (size_t)batch * n;
+        const int e = st[c + 1];
+        for (int p = st[c]; p < e; p++) m = fminf(m, S[p].w);
+    }
+    pmin[(size_t)batch * (cells_max + 1) + c] = m;
+}
+
 // The Bid step of one round over the grid.  Same outputs as emd_bid_kernel (emd.hip): bid, second, bid_increments,
 // max_increments, the chain records.  LPB lanes share a bidder (a power of two, 8 .. 64, picked per round from the
 // number of bidders like pick_p); a lane takes whole rows of the bidder's box.
@@ -272,6 +289,7 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
     const float4 *__restrict__ S = a.sorted + base;      // (x, y, z, price) in cell order: settle / resolve keep .w in step
     const int *__restrict__ OF = a.orig_of + base;       // object index of a sorted position: read only for the rare object that passes
     const int *__restrict__ ST = a.start + (size_t)batch * (a.cells_max + 1);
+    const float *__restrict__ PM = a.cell_pmin ? a.cell_pmin + (size_t)batch * (a.cells_max + 1) : nullptr;
     const EGridHdr H = a.hdr[batch];
     const int gx = H.g[0], gy = H.g[1], gz = H.g[2];
     const float h = H.h, inf = __builtin_inff();
@@ -493,16 +511,22 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
         for (int r0 = 0; r0 < nrows; r0 += LPB) {         // group-uniform trip count
             const int r = r0 + sub;
             int pA = 0, lA = 0;
+            // cells of the row that can still hold a candidate at today's prices (bit i: cell cx0 + i) and the non-empty ones
+            // that cannot; first cell of the row's range
+            unsigned long long km = 0ull, cm = 0ull;
+            int cbase = 0;
             if (r < nrows) {
                 st_rows++;
                 const int rz = r / wy;
                 const int cy = by0 + (r - rz * wy), cz = bz0 + rz;
                 int cx0 = bx0, cx1 = bx1;
                 bool keep = true;
+                float lb0 = 0.0f;
                 if (cull) {
                     // the row's (y, z) gap against the threshold; what is left of it bounds |dx|: the box becomes a ball
                     const float gyv = gap1(cy, gy, H.lo[1], y1, sy), gzv = gap1(cz, gz, H.lo[2], z1, sz);
-                    const float lb = __fmaf_rn(gyv, gyv, __fmul_rn(gzv, gzv)) * kShrink;
+                    lb0 = __fmaf_rn(gyv, gyv, __fmul_rn(gzv, gzv));
+                    const float lb = lb0 * kShrink;
                     const float c2 = __fmul_rn(cb, cb);
                     keep = lb < c2;                          // else nothing in this row can matter (prices >= 0)
                     if (keep) {
@@ -514,11 +538,53 @@ __global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
                 if (keep && cx0 <= cx1) {
                     st_kept++;
                     const int row = (cz * gy + cy) * gx;
-                    pA = ST[row + cx0];
-                    lA = ST[row + cx1 + 1] - pA;
+                    const int wdt = cx1 - cx0 + 1;
+                    if (PM != nullptr && cull && wdt <= 64) {
+                        // Cell by cell with the prices in: an object of cell c is at least the cell's gap away and costs at
+                        // least the cell's smallest price p, so it can pass the filter (sq < (cb - price)^2, cb - price > 0)
+                        // only if gap^2 < (cb - p)^2 -- on a partial scan against its ground truth the ball of a late-round
+                        // bidder holds ~680 objects, all but two of them priced out.
+                        cbase = row + cx0;
+                        for (int i0 = 0; i0 < wdt; i0 += 4) {
+                            float pm[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) pm[k] = i0 + k < wdt ? PM[cbase + i0 + k] : inf;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if (!(pm[k] < inf)) continue;              // empty (or past the range)
+                                const float gxv = gap1(cx0 + i0 + k, gx, H.lo[0], x1, sx);
+                                const float lbc = __fmaf_rn(gxv, gxv, lb0) * kShrink;
+                                const float tt = cb - pm[k];
+                                const bool kc = tt > 0.0f && lbc < tt * tt;
+                                km |= kc ? 1ull << (i0 + k) : 0ull;
+                                cm |= kc ? 0ull : 1ull << (i0 + k);
+                            }
+                        }
+                    } else {
+                        pA = ST[row + cx0];
+                        lA = ST[row + cx1 + 1] - pA;
+                    }
                 }
             }
-            batch_eval(pA, lA);
+            if (PM == nullptr) {
+                batch_eval(pA, lA);
+            } else {
+                // a row's kept cells as runs of the sorted array: one run from a kept cell to the last kept cell in front of
+                // the next priced-out one (empty cells in between cost nothing); most rows give one run, some two
+                do {
+                    if (km) {
+                        const int s = __ffsll((long long)km) - 1;
+                        const unsigned long long above = cm & ~((2ull << s) - 1ull);
+                        const unsigned long long seg = above ? km & ((1ull << (__ffsll((long long)above) - 1)) - 1ull) : km;
+                        const int e = 63 - __clzll((long long)seg);
+                        pA = ST[cbase + s];
+                        lA = ST[cbase + e + 1] - pA;
+                        km &= ~seg;
+                    }
+                    batch_eval(pA, lA);
+                    pA = 0; lA = 0;
+                } while ((__ballot(km != 0ull) & gmask) != 0ull);
+            }
         }
         };
         sweep();
@@ -597,6 +663,12 @@ int launch_emd_grid_build(int b, int n, const float *xyz2, const float *price, E
     hipLaunchKernelGGL(emd_grid_build_kernel, dim3(b * K), dim3(kEGBlock), lds, st, n, xyz2, price, hdr, start, sorted, pos_of, orig_of,
                        cells_target, cells_max, K, price_sep);
     return check(hipGetLastError(), "emd_grid_build_kernel launch") ? 1 : 0;
+}
+
+int launch_emd_cell_pmin(int b, int cells_max, const EGridHdr *hdr, const int *start, const float4 *sorted, int n, float *pmin, hipStream_t st)
+{
+    hipLaunchKernelGGL(emd_cell_pmin_kernel, dim3(ceil_div(cells_max + 1, 256), b), dim3(256), 0, st, cells_max, hdr, start, sorted, n, pmin);
+    return check(hipGetLastError(), "emd_cell_pmin_kernel launch") ? 1 : 0;
 }
 
 int launch_emd_bid_grid(const EmdGridBid &a, int fma, hipStream_t st)

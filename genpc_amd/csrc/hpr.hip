@@ -656,16 +656,53 @@ constexpr int kHprRimTiles = 256;  // ... and is handed to the second pass if th
 // segment b % 8 (the XCD it runs on), where consecutive waves then read ONE view's flipped points and tile records
 // through that XCD's L2 (in one list in order of arrival every L2 saw eight to sixteen views at a time).
 // base[x] = start of segment x (prefix sums of the views' listed points: upper bounds), status[32 + x] = its fill.
+// The record lives in device memory, written by hpr_segs_kernel from the accept pass's per-view counts: the host never
+// sees a count of this entry point (round 4 fetched six of them, a stream synchronisation each).
 struct HprSegs {
     int base[9];
     int on;            // 0: one segment (views not a multiple of 8)
+    int cap;           // slots the polygon store holds: a point whose slot lies beyond is listed (restarts from the box) instead of parked
 };
 __device__ __forceinline__ int hpr_seg_of(const HprSegs &sg, int view) { return sg.on ? (view & 7) : 0; }
-// block b of a launch over `8 x longest segment` (or the one segment): its slot, -1 past the segment's end
+// item b of a pass over `8 x longest segment` (or the one segment): its slot, -1 past the segment's end
 __device__ __forceinline__ int hpr_seg_slot(const HprSegs &sg, const int *status, int b)
 {
     const int x = sg.on ? (b & 7) : 0, k = sg.on ? (b >> 3) : b;
-    return k < status[32 + x] ? sg.base[x] + k : -1;
+    const int slot = sg.base[x] + k;
+    return k < status[32 + x] && slot < sg.cap ? slot : -1;
+}
+// items of such a pass
+__device__ __forceinline__ int hpr_seg_items(const HprSegs &sg, const int *status)
+{
+    int longest = 0;
+    for (int x = 0; x < 8; x++) longest = max(longest, status[32 + x]);
+    return sg.on ? 8 * longest : longest;
+}
+
+__global__ __launch_bounds__(1024) void hpr_segs_kernel(int c, const int *__restrict__ hardcnt, HprSegs *__restrict__ out, int cap)
+{
+    __shared__ int s_per[8];
+    if (threadIdx.x < 8) s_per[threadIdx.x] = 0;
+    __syncthreads();
+    const int on = (c & 7) == 0 ? 1 : 0;
+    int mine = 0;            // (thread t takes views t, t + 1024, ...: all of one segment)
+    for (int v = threadIdx.x; v < c; v += 1024) mine += hardcnt[v];
+    if (mine) atomicAdd(&s_per[on ? (threadIdx.x & 7) : 0], mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int at = 0;            // (the sum is at most views x points < 2^31)
+        for (int x = 0; x < 8; x++) { out->base[x] = at; at += s_per[x]; }
+        out->base[8] = at;
+        out->on = on;
+        out->cap = cap;
+    }
+}
+
+// status[1] != 0 (an internal error) reaches the caller without a host read of it: every count becomes -1
+__global__ __launch_bounds__(256) void hpr_finish_kernel(int c, const int *__restrict__ status, int *__restrict__ cnt)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v < c && status[1] != 0) cnt[v] = -1;
 }
 
 // status[0] = points handed to the wave-per-point pass, status[1] = error (2: a polygon outgrew kHprOverCap),
@@ -675,9 +712,10 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
                                                          const int *__restrict__ hardcnt, unsigned char *__restrict__ vis,
                                                          int *__restrict__ cnt, int *status, int *__restrict__ over_list, int no_cull, int max_clips,
                                                          int split, int4 *__restrict__ surv, double2 *__restrict__ surv_poly,
-                                                         int *__restrict__ und, int straggle_from, int straggle_lanes, int nviews, int home_tiles, HprSegs segs, int chunk_w, int home_chunks)
+                                                         int *__restrict__ und, int straggle_from, int straggle_lanes, int nviews, int home_tiles, const HprSegs *__restrict__ segs_p, int chunk_w, int home_chunks)
 {
     HPR_PROF_DECL;
+    const HprSegs segs = *segs_p;
     __shared__ double2 s_poly[kHprMaxV * kHprThreads];
     __shared__ double4 s_stage[kHprThreads];      // 64 tile records while testing, then one tile's candidates
     __shared__ unsigned long long s_mask;
@@ -726,8 +764,14 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
     auto park = [&](int code) {
         const int sx = hpr_seg_of(segs, view);
         const int slot = segs.base[sx] + atomicAdd(&status[32 + sx], 1);
-        atomicAdd(&status[2], 1);
         if (und) atomicAdd(&und[view], 1);
+        if (slot >= segs.cap) {          // the polygon store is full: listed instead
+            over_list[atomicAdd(&status[0], 1)] = view * n + rank;
+            nv = -1;
+            active = false;
+            return;
+        }
+        atomicAdd(&status[2], 1);
         surv[slot] = make_int4(view * n + rank, nv, pos, code);
         double2 *sp = surv_poly + (size_t)slot * kHprMaxV;
         for (int k = 0; k < nv; k++) sp[k] = poly[k * kHprThreads];
@@ -982,14 +1026,18 @@ __global__ __launch_bounds__(kHprThreads) void hpr_kernel(int n, const double *_
         if (lane == __ffsll((long long)bal) - 1) {
             const int sx = hpr_seg_of(segs, view);
             base = segs.base[sx] + atomicAdd(&status[32 + sx], __popcll(bal));
-            atomicAdd(&status[2], __popcll(bal));
+            atomicAdd(&status[2], min(__popcll(bal), max(segs.cap - base, 0)));
             if (und) atomicAdd(&und[view], __popcll(bal));      // (a wave's lanes share the view: one block = one view)
         }
         base = __shfl(base, __ffsll((long long)bal) - 1, kWave);
         const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-        surv[slot] = make_int4(view * n + rank, nv, pos, home_chunks < kHprThreads / 32 ? home_chunks * 32 : home_tiles * 256);
-        double2 *sp = surv_poly + (size_t)slot * kHprMaxV;
-        for (int k = 0; k < nv; k++) sp[k] = poly[k * kHprThreads];
+        if (slot >= segs.cap) {          // the polygon store is full: listed instead
+            over_list[atomicAdd(&status[0], 1)] = view * n + rank;
+        } else {
+            surv[slot] = make_int4(view * n + rank, nv, pos, home_chunks < kHprThreads / 32 ? home_chunks * 32 : home_tiles * 256);
+            double2 *sp = surv_poly + (size_t)slot * kHprMaxV;
+            for (int k = 0; k < nv; k++) sp[k] = poly[k * kHprThreads];
+        }
         nv = -1;               // decided later
         active = false;
     }
@@ -1375,17 +1423,13 @@ __device__ __forceinline__ int hpr_decide(const HprFrame &f, const double2 *P, i
 // in a dozen dependent round trips), so what matters is how many waves a CU holds -- this kernel needs a third of the
 // registers of hpr_overflow_kernel, whose walk and clip code the 98 % of the points decided here never run.  Undecided
 // points (and the ones that still have home tiles to take after the try) are listed for hpr_overflow_kernel by slot.
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 8))) void hpr_decide_kernel(int n, const double *__restrict__ fl_all, const HprTile *__restrict__ tiles_all,
-                                                          unsigned char *__restrict__ vis, int *__restrict__ cnt, int *status,
-                                                          const int *__restrict__ perm, int no_cull, const unsigned char *__restrict__ alive,
-                                                          const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
-                                                          int *__restrict__ slots, HprSegs segs)
+__device__ __forceinline__ void hpr_decide_item(int slot, int n, const double *__restrict__ fl_all, const HprTile *__restrict__ tiles_all,
+                                                unsigned char *__restrict__ vis, int *__restrict__ cnt, int *status,
+                                                const int *__restrict__ perm, int no_cull, const unsigned char *__restrict__ alive,
+                                                const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
+                                                int *__restrict__ slots, const HprSegs &segs, double2 *s_p, double2 *s_scratch)
 {
-    __shared__ double2 s_p[kHprMaxV + 6];
-    __shared__ double2 s_scratch[128];
     const int lane = threadIdx.x;
-    const int slot = hpr_seg_slot(segs, status, blockIdx.x);
-    if (slot < 0) return;
     const int4 rec = surv[slot];
     const int view = rec.x / n, nv = rec.y, pos = rec.z;
     if (alive && !alive[view]) return;        // (wave-uniform) a view that cannot be the best any more
@@ -1409,24 +1453,45 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 8))) v
     }
 }
 
+// The launch does not know how many points were parked (the count never leaves the device): a fixed grid of one-wave
+// blocks, a multiple of 8 of them, strides over the items -- block b stays with segment b % 8, the XCD it runs on.
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 8))) void hpr_decide_kernel(int n, const double *__restrict__ fl_all, const HprTile *__restrict__ tiles_all,
+                                                          unsigned char *__restrict__ vis, int *__restrict__ cnt, int *status,
+                                                          const int *__restrict__ perm, int no_cull, const unsigned char *__restrict__ alive,
+                                                          const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
+                                                          int *__restrict__ slots, const HprSegs *__restrict__ segs_p)
+{
+    __shared__ double2 s_p[kHprMaxV + 6];
+    __shared__ double2 s_scratch[128];
+    const HprSegs segs = *segs_p;
+    // this block's segment, its first slot and its fill (wave-uniform: the loop stays scalar)
+    const int x = segs.on ? (int)(blockIdx.x & 7) : 0, stride = segs.on ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int first = segs.base[x];
+    const int fill = __builtin_amdgcn_readfirstlane(min(status[32 + x], segs.cap - first));
+    for (int k = segs.on ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; k < fill; k += stride) {
+        hpr_decide_item(first + k, n, fl_all, tiles_all, vis, cnt, status, perm, no_cull, alive, surv, surv_poly, slots, segs, s_p, s_scratch);
+        __syncthreads();
+    }
+}
+
 // CAP = vertices a polygon may reach: the pass runs with 128 first (4 KiB of LDS per wave: forty waves per CU instead
 // of the five that two 16 KiB buffers allow) and hands the few polygons that outgrow that to a second launch with
 // kHprOverCap (list2, counted in status[3]); results do not depend on the tier.
 template <int CAP>
-__global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double *__restrict__ fl_all,
-                                                             const HprTile *__restrict__ tiles_all, unsigned char *__restrict__ vis,
-                                                             int *__restrict__ cnt, int *status, const int *__restrict__ list,
-                                                             const int *__restrict__ perm, const int *__restrict__ hardlist,
-                                                             const int *__restrict__ hardcnt, int no_cull,
-                                                             const unsigned char *__restrict__ alive, int *__restrict__ list2,
-                                                             const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
-                                                             double2 *__restrict__ gbuf, int gcap, const int *__restrict__ slots, HprSegs segs)
+__device__ __forceinline__ void hpr_overflow_item(int item, int n, const double *__restrict__ fl_all,
+                                                  const HprTile *__restrict__ tiles_all, unsigned char *__restrict__ vis,
+                                                  int *__restrict__ cnt, int *status, const int *__restrict__ list,
+                                                  const int *__restrict__ perm, const int *__restrict__ hardlist,
+                                                  const int *__restrict__ hardcnt, int no_cull,
+                                                  const unsigned char *__restrict__ alive, int *__restrict__ list2,
+                                                  const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
+                                                  double2 *__restrict__ gbuf, int gcap, const int *__restrict__ slots, const HprSegs &segs,
+                                                  double2 (*s_lds)[CAP > 0 ? CAP : 1])
 {
     // CAP == 0: the polygon lives in global memory, gcap vertices per buffer (n + 8: a polygon has at most one edge per
     // other point and four of the box -- this tier cannot overflow; round 3 returned an error beyond 1024 vertices)
-    __shared__ double2 s_lds[2][CAP > 0 ? CAP : 1];
     double2 *s_buf[2];
-    s_buf[0] = CAP > 0 ? s_lds[0] : gbuf + (size_t)blockIdx.x * 2 * gcap;
+    s_buf[0] = CAP > 0 ? s_lds[0] : gbuf + (size_t)blockIdx.x * 2 * gcap;          // (a pair of buffers per BLOCK)
     s_buf[1] = CAP > 0 ? s_lds[1] : gbuf + ((size_t)blockIdx.x * 2 + 1) * gcap;
     const int cap = CAP > 0 ? CAP : gcap;
     const int lane = threadIdx.x;
@@ -1435,9 +1500,9 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     const bool cont = surv != nullptr;
     // (a parked point's record carries its position: one dependent load less in front of the first useful one)
     // (slots: the parked points hpr_decide_kernel left undecided -- their first try is behind them)
-    const int slot = !cont ? 0 : (slots ? slots[blockIdx.x] : hpr_seg_slot(segs, status, blockIdx.x));
+    const int slot = !cont ? 0 : (slots ? slots[item] : hpr_seg_slot(segs, status, item));
     if (slot < 0) return;
-    const int4 rec = cont ? surv[slot] : make_int4(list[blockIdx.x], 4, -1, 0);
+    const int4 rec = cont ? surv[slot] : make_int4(list[item], 4, -1, 0);
     const int id = rec.x, view = id / n, rank = id - view * n;
     if (alive && !alive[view]) return;        // (wave-uniform) a view that cannot be the best any more
     const int *hl = hardlist + (size_t)view * n;
@@ -1650,6 +1715,35 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
     }
 }
 
+// A fixed grid of one-wave blocks over a count that lives on the device (`count`: a word of status; null: the parked
+// points by segment).  A wave's first item is its block index, the following ones it draws from `work` (zero at launch) --
+// walkers take from 10 us to over a millisecond, so the items are handed out as waves come free; the draw is issued
+// before the item is worked on and read after it.
+template <int CAP>
+__global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double *__restrict__ fl_all,
+                                                             const HprTile *__restrict__ tiles_all, unsigned char *__restrict__ vis,
+                                                             int *__restrict__ cnt, int *status, const int *__restrict__ list,
+                                                             const int *__restrict__ perm, const int *__restrict__ hardlist,
+                                                             const int *__restrict__ hardcnt, int no_cull,
+                                                             const unsigned char *__restrict__ alive, int *__restrict__ list2,
+                                                             const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
+                                                             double2 *__restrict__ gbuf, int gcap, const int *__restrict__ slots,
+                                                             const HprSegs *__restrict__ segs_p, const int *count, int *work)
+{
+    __shared__ double2 s_lds[2][CAP > 0 ? CAP : 1];
+    const HprSegs segs = *segs_p;
+    const int items = __builtin_amdgcn_readfirstlane(count ? *count : hpr_seg_items(segs, status));
+    int item = blockIdx.x;
+    while (item < items) {
+        int nxt = 0;
+        if (threadIdx.x == 0) nxt = atomicAdd(work, 1);
+        hpr_overflow_item<CAP>(item, n, fl_all, tiles_all, vis, cnt, status, list, perm, hardlist, hardcnt, no_cull, alive, list2, surv,
+                               surv_poly, gbuf, gcap, slots, segs, s_lds);
+        __syncthreads();
+        item = (int)gridDim.x + __builtin_amdgcn_readfirstlane(nxt);          // (lane 0's draw)
+    }
+}
+
 }  // namespace genpc
 
 using namespace genpc;
@@ -1752,43 +1846,27 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     hipLaunchKernelGGL(hpr_accept_kernel, dim3(ntiles * c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
                        (const HprTile *)tiles, hard, visible, counts, (no_cull & 16) ? 1 : 0, c);
     hipLaunchKernelGGL(hpr_compact_kernel, dim3(c), dim3(1024), 0, stream, n, (const unsigned char *)hard, hardlist, hardcnt);
-    // the undecided points' polygons: at most one per listed point; the listed points are counted by now only on the
-    // device, so the buffer is sized for the worst case the accept pass leaves in practice (every point) lazily:
-    // total * kHprMaxV * 16 bytes would be 2.6 GB at 1024 x 10000 -- instead the count is fetched (the first of
-    // this entry's host round trips) and the buffer sized from it
+    // The undecided points' polygons: at most one per point the accept pass left over.  That count stays on the device
+    // (round 4 fetched it to size the store, the first of six stream synchronisations of this entry point): the store is
+    // sized for every (view, point) pair up to GENPC_HPR_PARK_MB, and a point whose slot would lie beyond it is listed
+    // for the wave-per-point pass instead of parked (it restarts from the box there: same result, computed again).
     int4 *surv = (int4 *)(ws + o_surv);
     // best_only (viewpoint_select): views that cannot be the best any more are dropped after the first polygon kernel
     const bool prune = best_only && split;
     int *und = prune ? (int *)(ws + o_und) : nullptr;
     unsigned char *alive = prune ? (unsigned char *)(ws + o_alive) : nullptr;
     if (prune && !check(hipMemsetAsync(und, 0, sizeof(int) * (size_t)c, stream), "hipMemsetAsync(hpr und)")) return 0;
-    int hc_total = 0;
-    HprSegs segs = {};
-    if (split) {
-        // sum of hardcnt over the views = an upper bound on the survivors
-        int *hc_host = (int *)malloc(sizeof(int) * (size_t)c);
-        if (!hc_host) { set_error("genpc_hpr_visibility: out of host memory"); return 0; }
-        if (!check(hipMemcpyAsync(hc_host, hardcnt, sizeof(int) * (size_t)c, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr hardcnt)") ||
-            !check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) { free(hc_host); return 0; }
-        long long sum = 0, per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        segs.on = (c & 7) == 0 ? 1 : 0;
-        for (int v = 0; v < c; v++) {
-            sum += hc_host[v];
-            per[segs.on ? (v & 7) : 0] += hc_host[v];
-        }
-        free(hc_host);
-        if (sum < INT_MAX) {
-            long long at = 0;
-            for (int x = 0; x < 8; x++) { segs.base[x] = (int)at; at += per[x]; }
-            segs.base[8] = (int)at;
-        }
-        hc_total = (int)(sum < INT_MAX ? sum : INT_MAX);
-    }
+    HprSegs *segs = (HprSegs *)(ws + 192);          // (the 256-byte header: status words 0 .. 15 and 32 .. 44, the bounds in words 16 .. 21, this record in 48 .. 58)
+    static_assert(sizeof(HprSegs) <= 64, "the segment record shares the header with the status words");
+    static const int env_park = tune_env("GENPC_HPR_PARK_MB", 3072, "hidden-point removal, two-kernel form: MiB of polygon store (256 bytes per parked point; points beyond it restart in the wave-per-point pass)");
+    const size_t poly_bytes = (size_t)kHprMaxV * sizeof(double2);
+    const size_t park_cap = split ? std::min<size_t>(total, std::max<size_t>(1, ((size_t)(env_park > 0 ? env_park : 1) << 20) / poly_bytes)) : 0;
     double2 *surv_poly = nullptr;
     if (split) {
-        surv_poly = (double2 *)workspace(20, (size_t)(hc_total > 0 ? hc_total : 1) * kHprMaxV * sizeof(double2), stream);
+        surv_poly = (double2 *)workspace(20, park_cap * poly_bytes, stream);
         if (!surv_poly) return 0;
     }
+    hipLaunchKernelGGL(hpr_segs_kernel, dim3(1), dim3(1024), 0, stream, c, (const int *)hardcnt, segs, (int)park_cap);
     static const int env_sf = tune_env("GENPC_HPR_STRAGGLE_FROM", 4, "hidden-point removal: tile batches a block walks before the hand-over");
     static const int env_sl = tune_env("GENPC_HPR_STRAGGLE_LANES", kHprThreads, "hidden-point removal: hand a block's points over when at most this many lanes are still undecided");
     static const int env_st = tune_env("GENPC_HPR_STRAGGLE_TILES", 0, "hidden-point removal: clouds of at least this many tiles hand undecided points over early");
@@ -1804,105 +1882,95 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     const int home_chunks = split && home_tiles == 1 ? (env_hc < 1 ? 1 : (env_hc > 4 ? 4 : env_hc)) : 4;
     hipLaunchKernelGGL(hpr_kernel, dim3(ntiles * c), dim3(kHprThreads), 0, stream, n, (const double *)fl, (const int *)i1,
                        (const HprTile *)tiles, (const int *)hardlist, (const int *)hardcnt, visible, counts, status, list, no_cull,
-                       max_clips, split, surv, surv_poly, und, straggle_from, straggle_lanes, c, home_tiles, segs, chunk_w, home_chunks);
+                       max_clips, split, surv, surv_poly, und, straggle_from, straggle_lanes, c, home_tiles, (const HprSegs *)segs, chunk_w, home_chunks);
     if (!check(hipGetLastError(), "hpr launch")) return 0;
-    int st[40] = {0};          // (status[16 .. 21] are the bounds of hpr_bounds_kernel, not counters)
-    if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
-    if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
     if (prune) hipLaunchKernelGGL(hpr_prune_kernel, dim3(1), dim3(1024), 0, stream, c, (const int *)counts, (const int *)und, alive);
-    // the undecided points of the split first kernel: a wave each, continuing from the saved polygon
+    // The wave-per-point passes.  How many points each of them finds is known on the device only: every pass is a fixed
+    // grid of one-wave blocks -- as many as the chip holds of that kernel, or as there can be items -- that reads its count
+    // from `status` and leaves at once when it is zero (an empty pass costs its launch, ~5 us).
     int *list2 = (int *)k0;          // (the sort's key buffer is free by now; at most views x points entries)
     int *list3 = (int *)k1;          // (likewise: the points whose polygons outgrow the 1024-vertex tier)
-    if (st[2] > 0) {
+    const int cus = num_cus();
+    auto grid_of = [&](int per_cu) { return (int)std::min<size_t>(total, (size_t)per_cu * cus); };
+    static const int env_dw = tune_env("GENPC_HPR_DECIDE_WAVES", 64, "hidden-point removal: one-wave blocks per CU of the parked points' first try");
+    static const int env_ww = tune_env("GENPC_HPR_WALK_WAVES", 40, "hidden-point removal: one-wave blocks per CU of the wave-per-point pass (128-vertex tier)");
+    // status words: [0] listed, [2] parked, [3] polygons over 128 vertices, [4] over kHprOverCap, [5] parked points the first try
+    // left undecided, [32 .. 39] the segments' fills, [40 .. 44] the passes' work counters
+    if (split) {
         static const int env_dk = tune_env("GENPC_HPR_DECIDE_KERNEL", 1, "hidden-point removal: 1 = the parked points' first try in a kernel of its own (more waves per CU), 0 = inside the wave-per-point kernel");
         const int *slots = nullptr;
-        int longest = 0;
-        for (int x = 0; x < 8; x++) longest = std::max(longest, st[32 + x]);
-        const int seg_grid = segs.on ? 8 * longest : longest;          // block b -> segment b % 8
-        int waves = seg_grid;
+        const int *count = nullptr;          // (null: the parked points by segment)
         if (env_dk && !(no_cull & (32 | 128))) {
             int *sl = i0;          // (the sort's index buffer is free by now; at most views x points entries)
-            hipLaunchKernelGGL(hpr_decide_kernel, dim3(seg_grid), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles, visible,
+            const int gd = (grid_of(env_dw > 0 ? env_dw : 64) + 7) & ~7;          // block b -> segment b % 8
+            hipLaunchKernelGGL(hpr_decide_kernel, dim3(gd), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles, visible,
                                counts, status, (const int *)i1, no_cull, (const unsigned char *)alive, (const int4 *)surv,
-                               (const double2 *)surv_poly, sl, segs);
+                               (const double2 *)surv_poly, sl, (const HprSegs *)segs);
             if (!check(hipGetLastError(), "hpr decide launch")) return 0;
-            int left = 0;
-            if (!check(hipMemcpyAsync(&left, status + 5, sizeof(int), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
-            if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
             slots = sl;
-            waves = left;
+            count = status + 5;
         }
-        if (waves > 0) {
-            hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(waves), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
-                               visible, counts, status, (const int *)nullptr, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
-                               no_cull, (const unsigned char *)alive, list2, (const int4 *)surv, (const double2 *)surv_poly, (double2 *)nullptr, 0, slots, segs);
-            if (!check(hipGetLastError(), "hpr continuation launch")) return 0;
-        }
+        hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(grid_of(env_ww > 0 ? env_ww : 40)), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
+                           visible, counts, status, (const int *)nullptr, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
+                           no_cull, (const unsigned char *)alive, list2, (const int4 *)surv, (const double2 *)surv_poly, (double2 *)nullptr, 0, slots,
+                           (const HprSegs *)segs, count, status + 40);
+        if (!check(hipGetLastError(), "hpr continuation launch")) return 0;
     }
-    if (second_pass_points) *second_pass_points = st[0] + st[2];      // every point a wave took over (parked or listed)
     {
         static const bool one_tier = tune_env("GENPC_HPR_ONE_TIER", 0, "hidden-point removal: 1 = every listed point straight to the 1024-vertex tier") != 0;
-        const bool continued = st[2] > 0;
-        const int listed = st[0];
-        if (listed > 0 && !one_tier) {
-            hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(listed), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
+        if (!one_tier) {
+            hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(grid_of(env_ww > 0 ? env_ww : 40)), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
                                visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
-                               no_cull, (const unsigned char *)alive, list2, (const int4 *)nullptr, (const double2 *)nullptr, (double2 *)nullptr, 0, (const int *)nullptr, segs);
+                               no_cull, (const unsigned char *)alive, list2, (const int4 *)nullptr, (const double2 *)nullptr, (double2 *)nullptr, 0,
+                               (const int *)nullptr, (const HprSegs *)segs, (const int *)(status + 0), status + 41);
             if (!check(hipGetLastError(), "hpr second pass launch")) return 0;
-        }
-        if (continued || (listed > 0 && !one_tier)) {
-            if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
-            if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
-        }
-        // polygons over 128 vertices (from either launch above), or every listed point with GENPC_HPR_ONE_TIER
-        const int big = st[3] + (one_tier ? listed : 0);
-        if (one_tier && listed > 0) {
-            hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(listed), dim3(kWave), 0, stream, n, (const double *)fl,
+        } else {
+            hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(grid_of(5)), dim3(kWave), 0, stream, n, (const double *)fl,
                                (const HprTile *)tiles, visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist,
                                (const int *)hardcnt, no_cull, (const unsigned char *)alive, list3, (const int4 *)nullptr,
-                               (const double2 *)nullptr, (double2 *)nullptr, 0, (const int *)nullptr, segs);
+                               (const double2 *)nullptr, (double2 *)nullptr, 0, (const int *)nullptr, (const HprSegs *)segs,
+                               (const int *)(status + 0), status + 41);
         }
-        if (st[3] > 0) {
-            hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(st[3]), dim3(kWave), 0, stream, n, (const double *)fl,
-                               (const HprTile *)tiles, visible, counts, status, (const int *)list2, (const int *)i1, (const int *)hardlist,
-                               (const int *)hardcnt, no_cull, (const unsigned char *)alive, list3, (const int4 *)nullptr,
-                               (const double2 *)nullptr, (double2 *)nullptr, 0, (const int *)nullptr, segs);
-        }
-        if (big > 0) {
-            if (!check(hipGetLastError(), "hpr large-polygon launch")) return 0;
-            if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
-            if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
-        }
+        // polygons over 128 vertices (from either launch above)
+        hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(grid_of(5)), dim3(kWave), 0, stream, n, (const double *)fl,
+                           (const HprTile *)tiles, visible, counts, status, (const int *)list2, (const int *)i1, (const int *)hardlist,
+                           (const int *)hardcnt, no_cull, (const unsigned char *)alive, list3, (const int4 *)nullptr,
+                           (const double2 *)nullptr, (double2 *)nullptr, 0, (const int *)nullptr, (const HprSegs *)segs,
+                           (const int *)(status + 3), status + 42);
+        if (!check(hipGetLastError(), "hpr large-polygon launch")) return 0;
         // polygons over 1024 vertices (exactly co-spherical input, lattices seen from their centre): a third tier with the
-        // polygon in global memory, n + 8 vertices per buffer -- it cannot overflow -- in chunks of at most 1 GiB of scratch
-        if (st[4] > 0) {
+        // polygon in global memory, n + 8 vertices per buffer -- it cannot overflow -- a pair of buffers per wave of the grid
+        {
+            static const int env_gm = tune_env("GENPC_HPR_GLOBAL_MB", 256, "hidden-point removal: MiB of global-memory polygon buffers of the third tier (two buffers of n + 8 vertices per wave)");
             const int gcap = n + 8;
             const size_t per = (size_t)2 * gcap * sizeof(double2);
-            int chunk = (int)std::min<size_t>((size_t)st[4], std::max<size_t>(1, ((size_t)1 << 30) / per));
-            double2 *gbuf = (double2 *)workspace(30, (size_t)chunk * per, stream);
+            const int g3 = (int)std::min<size_t>(std::min<size_t>(total, 1024), std::max<size_t>(1, ((size_t)(env_gm > 0 ? env_gm : 1) << 20) / per));
+            double2 *gbuf = (double2 *)workspace(30, (size_t)g3 * per, stream);
             if (!gbuf) return 0;
-            for (int c0 = 0; c0 < st[4]; c0 += chunk) {
-                const int cc = std::min(chunk, st[4] - c0);
-                hipLaunchKernelGGL(hpr_overflow_kernel<0>, dim3(cc), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
-                                   visible, counts, status, (const int *)(list3 + c0), (const int *)i1, (const int *)hardlist,
-                                   (const int *)hardcnt, no_cull, (const unsigned char *)alive, (int *)nullptr, (const int4 *)nullptr,
-                                   (const double2 *)nullptr, gbuf, gcap, (const int *)nullptr, segs);
-            }
+            hipLaunchKernelGGL(hpr_overflow_kernel<0>, dim3(g3), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
+                               visible, counts, status, (const int *)list3, (const int *)i1, (const int *)hardlist,
+                               (const int *)hardcnt, no_cull, (const unsigned char *)alive, (int *)nullptr, (const int4 *)nullptr,
+                               (const double2 *)nullptr, gbuf, gcap, (const int *)nullptr, (const HprSegs *)segs, (const int *)(status + 4), status + 43);
             if (!check(hipGetLastError(), "hpr global-polygon launch")) return 0;
+        }
+        hipLaunchKernelGGL(hpr_finish_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, stream, c, (const int *)status, counts);
+        // the counters are fetched (the entry's only stream synchronisation) when somebody asks for them
+        const bool tiers = tune_env("GENPC_HPR_TIERS", 0, "hidden-point removal: 1 = report on stderr how many points took the wave-per-point tiers") != 0;
+        if (second_pass_points || tiers || (no_cull & 256)) {
+            int st[48] = {0};
             if (!check(hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(hpr status)")) return 0;
             if (!check(hipStreamSynchronize(stream), "hipStreamSynchronize(hpr)")) return 0;
-            if (tune_env("GENPC_HPR_TIERS", 0, "hidden-point removal: 1 = report on stderr how many points took the wave-per-point tiers") != 0) fprintf(stderr, "hpr: %d points with polygons over %d vertices (global-memory tier)\n", st[4], kHprOverCap);
-        }
-        if (st[1]) {
-            set_error("genpc_hpr_visibility: internal error (a normal-cone polygon outgrew its buffer)");
-            return 0;
-        }
-        if (tune_env("GENPC_HPR_TIERS", 0, "hidden-point removal: 1 = report on stderr how many points took the wave-per-point tiers") != 0) fprintf(stderr, "hpr: %d points in the wave-per-point pass, %d of them with polygons over 128 vertices\n", listed, big);
-        if (no_cull & 256) {
-            int lp[8] = {0};
-            if (check(hipMemcpy(lp, status + 8, sizeof lp, hipMemcpyDeviceToHost), "hipMemcpy(hpr stats)"))
+            if (second_pass_points) *second_pass_points = st[0] + st[2];      // every point a wave took over (parked or listed)
+            if (st[1]) {
+                set_error("genpc_hpr_visibility: internal error (a normal-cone polygon outgrew its buffer)");
+                return 0;
+            }
+            if (tiers)
+                fprintf(stderr, "hpr: %d points parked, %d listed for the wave-per-point pass, %d polygons over 128 vertices, %d over %d (global-memory tier)\n",
+                        st[2], st[0], st[3], st[4], kHprOverCap);
+            if (no_cull & 256)
                 fprintf(stderr, "hpr: parked points, first try: %d undecided, %d visible, %d hidden; after the home tiles: %d undecided, %d visible, %d hidden, %d died in the tiles\n",
-                        lp[0], lp[1], lp[2], lp[4], lp[5], lp[6], lp[7]);
+                        st[8], st[9], st[10], st[12], st[13], st[14], st[15]);
         }
     }
     if (exact) {

@@ -715,7 +715,10 @@ __device__ __forceinline__ void splat_fold(float &tr, float &sd, float &sr, floa
     }
 }
 
-// Blend 1 without an exponential per (pixel, disc): after a fill of the LDS list (list_z[k] = the entries' depth exponents) the
+// LDS layout of a listed disc.  Blend 0: list = (u, v, 1 / rho^2, red), list_gb = (green, blue).  Blend 1: list = (u, v, 1 / rho^2,
+// depth exponent or weight), list_c = (red, green, blue, -) -- still ONE 16-byte read per disc tested and one more per disc that
+// covers the pixel (a third, 4-byte read for the exponent made the gather, which is bound by its LDS reads, 30 % slower).
+// Blend 1 without an exponential per (pixel, disc): after a fill of the LDS list (list[k].w = the entries' depth exponents) the
 // block takes the fill's largest exponent m_f and turns the entries into weights exp(z_k / gamma - m_f) -- ONE exponential
 // per listed disc instead of one per pixel it covers (the per-pair form cost 13 us of a 43 us launch, 3.8 ms of a 57 ms
 // completed scan) --, every pixel moves its sums to the reference max(its own, m_f) once, and the gather multiplies.
@@ -723,7 +726,7 @@ __device__ __forceinline__ void splat_fold(float &tr, float &sd, float &sr, floa
 // far entries' weights would underflow: a tile that holds points at both ends of the frustum).  All threads of the block call
 // it between the fill's barrier and the gather; zlo / zhi: the smallest / largest exponent this thread wrote (inf / 0: none).
 constexpr float kPulsarSpan = 60.0f;
-__device__ __forceinline__ bool splat_fill_weights(float *list_z, int cnt, int *s_zmm, float zlo, float zhi, float &tr, float &sd, float &sr,
+__device__ __forceinline__ bool splat_fill_weights(float4 *list, int cnt, int *s_zmm, float zlo, float zhi, float &tr, float &sd, float &sr,
                                                    float &sg, float &sb, float &fscale)
 {
     // (exponents are >= 0: the integer order of their bit patterns is theirs)
@@ -740,7 +743,7 @@ __device__ __forceinline__ bool splat_fill_weights(float *list_z, int cnt, int *
     const float m_f = __int_as_float(s_zmm[0]), z_min = __int_as_float(s_zmm[1]);
     const bool fast = m_f - z_min < kPulsarSpan;
     if (fast) {
-        for (int k = threadIdx.x; k < cnt; k += blockDim.x) list_z[k] = __expf(list_z[k] - m_f);
+        for (int k = threadIdx.x; k < cnt; k += blockDim.x) list[k].w = __expf(list[k].w - m_f);
         const float m_new = fmaxf(tr, m_f);
         const float sc = __expf(tr - m_new);
         sd *= sc; sr *= sc; sg *= sc; sb *= sc;
@@ -758,7 +761,7 @@ template <int BLEND>
 __device__ __attribute__((noinline)) void splat_full_scan(int n, const float4 *__restrict__ uvr, const float *__restrict__ col,
                                                           const float *__restrict__ zex, int tx0, int ty0, int tx1, int ty1, float pxc,
                                                           float pyc, int share, int lane, int wave, float &tr, float &sd, float &sr,
-                                                          float &sg, float &sb, float4 *list, float2 *list_gb, float *list_z, int *s_tab,
+                                                          float &sg, float &sb, float4 *list, float2 *list_gb, float4 *list_c, int *s_tab,
                                                           int *s_cntp, int *s_zmm)
 {
     for (int j0 = 0; j0 < n; j0 += kSplatBlock * kSplatPer) {
@@ -829,27 +832,38 @@ __device__ __attribute__((noinline)) void splat_full_scan(int n, const float4 *_
                         const float4 qh = uvr[j];                 // (a hit is rare: read again rather than kept)
                         float cr = 1.0f, cg = 1.0f, cb = 1.0f;
                         if (col) { cr = col[(size_t)j * 3 + 0]; cg = col[(size_t)j * 3 + 1]; cb = col[(size_t)j * 3 + 2]; }
-                        list[slot] = make_float4(qh.x, qh.y, qh.w, cr);
-                        list_gb[slot] = make_float2(cg, cb);
-                        if (BLEND) { const float ze = zex[j]; list_z[slot] = ze; zlo = fminf(zlo, ze); zhi = fmaxf(zhi, ze); }
+                        if (BLEND) {
+                            const float ze = zex[j];
+                            list[slot] = make_float4(qh.x, qh.y, qh.w, ze);
+                            list_c[slot] = make_float4(cr, cg, cb, 0.0f);
+                            zlo = fminf(zlo, ze); zhi = fmaxf(zhi, ze);
+                        } else {
+                            list[slot] = make_float4(qh.x, qh.y, qh.w, cr);
+                            list_gb[slot] = make_float2(cg, cb);
+                        }
                     }
                 }
             }
             __syncthreads();
             const int cnt = min(total - f0, kSplatList);
             float fscale = 1.0f;
-            const bool fast = BLEND && splat_fill_weights(list_z, cnt, s_zmm, zlo, zhi, tr, sd, sr, sg, sb, fscale);
+            const bool fast = BLEND && splat_fill_weights(list, cnt, s_zmm, zlo, zhi, tr, sd, sr, sg, sb, fscale);
             for (int k = share; k < cnt; k += 4) {
                 const float4 p = list[k];
                 const float dx = pxc - p.x, dy = pyc - p.y;
                 const float a = 1.0f - (dx * dx + dy * dy) * p.z;
                 if (a > 0.0f) {
-                    const float2 gb = list_gb[k];
-                    if (BLEND && fast) {
-                        const float w = fminf(a, kMaskAmax) * (list_z[k] * fscale);
-                        sd += w; sr += w * p.w; sg += w * gb.x; sb += w * gb.y;
+                    if (BLEND) {
+                        const float4 c = list_c[k];
+                        if (fast) {
+                            const float w = fminf(a, kMaskAmax) * (p.w * fscale);
+                            sd += w; sr += w * c.x; sg += w * c.y; sb += w * c.z;
+                        } else {
+                            splat_fold<1>(tr, sd, sr, sg, sb, fminf(a, kMaskAmax), c.x, c.y, c.z, p.w);
+                        }
                     } else {
-                        splat_fold<BLEND>(tr, sd, sr, sg, sb, fminf(a, kMaskAmax), p.w, gb.x, gb.y, BLEND ? list_z[k] : 0.0f);
+                        const float2 gb = list_gb[k];
+                        splat_fold<0>(tr, sd, sr, sg, sb, fminf(a, kMaskAmax), p.w, gb.x, gb.y, 0.0f);
                     }
                 }
             }
@@ -869,8 +883,8 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     static_assert(kSplatBlock == 4 * kMaskTile * kMaskTile, "four threads per pixel of the tile");
     __shared__ float part[5][4][kMaskTile * kMaskTile];
     __shared__ float4 list[kSplatList];       // u, v, 1 / rho^2, red
-    __shared__ float2 list_gb[kSplatList];    // green, blue
-    __shared__ float list_z[BLEND ? kSplatList : 1];      // blend 1: depth exponent (per-pair form) or weight exp(z / gamma - m_f)
+    __shared__ float2 list_gb[BLEND ? 1 : kSplatList];    // blend 0: green, blue
+    __shared__ float4 list_c[BLEND ? kSplatList : 1];     // blend 1: red, green, blue (list[k].w: depth exponent, or weight exp(z / gamma - m_f))
     __shared__ int s_zmm[2];                              // blend 1: a fill's largest / smallest exponent (bits)
     if (BLEND && threadIdx.x == 0) { s_zmm[0] = 0; s_zmm[1] = 0x7f800000; }
     __shared__ int s_cnt;
@@ -899,7 +913,11 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     // The tile's own list (bins, filled by the projection kernel): its indices are put in ascending order -- the fixed
     // summation order of the gather -- by counting ranks, the entries fetched, and the full scan below is skipped.  A tile
     // whose list overflowed (or a launch without bins) takes the full scan.
-    __shared__ __attribute__((aligned(16))) int s_sort[kSplatCap];
+    // (the counting ranks' copy of the indices is dead before the first fill writes the colours: blend 1 keeps it in their array --
+    //  with an array of its own the block took 83 228 bytes of LDS, ONE block per CU instead of two: 46 us against 35)
+    __shared__ __attribute__((aligned(16))) int s_sort_own[BLEND ? 4 : kSplatCap];
+    int *s_sort = BLEND ? (int *)&list_c[0] : s_sort_own;
+    static_assert(sizeof(float4) * kSplatList >= sizeof(int) * kSplatCap, "the indices fit the colour array");
     __shared__ unsigned char s_mask[kSplatCap];
     __shared__ unsigned s_bits[kRankWords];
     __shared__ unsigned short s_pref[kRankWords];
@@ -999,9 +1017,15 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
                 const float4 qh = uvr[myj];
                 float cr = 1.0f, cg = 1.0f, cb = 1.0f;
                 if (col) { cr = col[(size_t)myj * 3 + 0]; cg = col[(size_t)myj * 3 + 1]; cb = col[(size_t)myj * 3 + 2]; }
-                list[rank] = make_float4(qh.x, qh.y, qh.w, cr);
-                list_gb[rank] = make_float2(cg, cb);
-                if (BLEND) { const float ze = zex[myj]; list_z[rank] = ze; zlo = fminf(zlo, ze); zhi = fmaxf(zhi, ze); }
+                if (BLEND) {
+                    const float ze = zex[myj];
+                    list[rank] = make_float4(qh.x, qh.y, qh.w, ze);
+                    list_c[rank] = make_float4(cr, cg, cb, 0.0f);
+                    zlo = fminf(zlo, ze); zhi = fmaxf(zhi, ze);
+                } else {
+                    list[rank] = make_float4(qh.x, qh.y, qh.w, cr);
+                    list_gb[rank] = make_float2(cg, cb);
+                }
                 // the strips (four rows of the tile = the 64 pixels of one wave) the disc can reach
                 unsigned m = 0;
 #pragma unroll
@@ -1009,7 +1033,35 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
                     if (qh.y + qh.z >= (float)(ty0 + 4 * st) && qh.y - qh.z <= (float)(ty0 + 4 * st + 4)) m |= 1u << st;
                 s_mask[rank] = (unsigned char)m;
             }
+            // blend 1: the fill's largest / smallest exponent ride on the barriers the strips need anyway (splat_fill_weights,
+            // the full scan's form, pays two block-wide barriers of sixteen waves for them: 11 us of this kernel's 46)
+            if (BLEND) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    zlo = fminf(zlo, __shfl_xor(zlo, off, kWave));
+                    zhi = fmaxf(zhi, __shfl_xor(zhi, off, kWave));
+                }
+                if (lane == 0 && zhi >= zlo) {          // (exponents are >= 0: the integer order of their bit patterns is theirs)
+                    atomicMax(&s_zmm[0], __float_as_int(zhi));
+                    atomicMin(&s_zmm[1], __float_as_int(zlo));
+                }
+            }
             __syncthreads();
+            bool fast = false;
+            float fscale = 1.0f;
+            if (BLEND) {
+                const float m_f = __int_as_float(s_zmm[0]);
+                fast = m_f - __int_as_float(s_zmm[1]) < kPulsarSpan;
+                if (fast) {
+                    // one exponential per listed disc (the strips' barriers below stand between this and the gather)
+                    if ((int)threadIdx.x < Lf) list[threadIdx.x].w = __expf(list[threadIdx.x].w - m_f);
+                    const float m_new = fmaxf(tr, m_f);
+                    const float sc = __expf(tr - m_new);
+                    sd *= sc; sr *= sc; sg *= sc; sb *= sc;
+                    fscale = __expf(m_f - m_new);
+                    tr = m_new;
+                }
+            }
             // Per-strip sublists of the sorted list, in its order: a wave walks the discs that can reach its four rows only
             // (about half of the tile's).  Ballot ranks inside a wave, a 16 x 4 table of wave counts, its prefix by four threads.
             {
@@ -1022,6 +1074,7 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
                     if (lane == 0) s_wc[wave][st] = __popcll(bl);
                 }
                 __syncthreads();
+                if (BLEND && threadIdx.x == kWave) { s_zmm[0] = 0; s_zmm[1] = 0x7f800000; }      // (read by all before the barrier above; the next fill's come behind the loop's)
                 if (threadIdx.x < 4) {
                     int run = 0;
                     for (int w = 0; w < kSplatBlock / kWave; w++) {
@@ -1039,20 +1092,23 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
             }
             const int strip = wave & 3;      // (pix = tid & 255: wave w holds rows 4 (w & 3) .. + 3, share w >> 2)
             const int LS = s_stot[strip];
-            float fscale = 1.0f;
-            const bool fast = BLEND && splat_fill_weights(list_z, Lf, s_zmm, zlo, zhi, tr, sd, sr, sg, sb, fscale);      // (the list and the strips are behind barriers)
             for (int k2 = share; k2 < LS; k2 += 4) {
                 const int k = s_strip[strip][k2];
                 const float4 p = list[k];
                 const float dx = pxc - p.x, dy = pyc - p.y;
                 const float a = 1.0f - (dx * dx + dy * dy) * p.z;
                 if (a > 0.0f) {
-                    const float2 gb = list_gb[k];
-                    if (BLEND && fast) {
-                        const float w = fminf(a, kMaskAmax) * (list_z[k] * fscale);
-                        sd += w; sr += w * p.w; sg += w * gb.x; sb += w * gb.y;
+                    if (BLEND) {
+                        const float4 c = list_c[k];
+                        if (fast) {
+                            const float w = fminf(a, kMaskAmax) * (p.w * fscale);
+                            sd += w; sr += w * c.x; sg += w * c.y; sb += w * c.z;
+                        } else {
+                            splat_fold<1>(tr, sd, sr, sg, sb, fminf(a, kMaskAmax), c.x, c.y, c.z, p.w);
+                        }
                     } else {
-                        splat_fold<BLEND>(tr, sd, sr, sg, sb, fminf(a, kMaskAmax), p.w, gb.x, gb.y, BLEND ? list_z[k] : 0.0f);
+                        const float2 gb = list_gb[k];
+                        splat_fold<0>(tr, sd, sr, sg, sb, fminf(a, kMaskAmax), p.w, gb.x, gb.y, 0.0f);
                     }
                 }
             }
@@ -1065,7 +1121,7 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     // bookkeeping is what overflowed the 64 registers the two-blocks-per-CU launch allows -- 59 spilled VGPRs, ten scratch
     // instructions of them on the path of a tile that has its list; VERDICT r4 weak #8.  Here the spills stay in the callee.)
     if (!by_list)
-        splat_full_scan<BLEND>(n, uvr, col, zex, tx0, ty0, tx1, ty1, pxc, pyc, share, lane, wave, tr, sd, sr, sg, sb, list, list_gb, list_z, s_tab, &s_cnt, s_zmm);
+        splat_full_scan<BLEND>(n, uvr, col, zex, tx0, ty0, tx1, ty1, pxc, pyc, share, lane, wave, tr, sd, sr, sg, sb, list, list_gb, list_c, s_tab, &s_cnt, s_zmm);
     part[0][share][pix] = tr;
     part[1][share][pix] = sd;
     part[2][share][pix] = sr;

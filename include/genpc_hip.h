@@ -199,8 +199,10 @@ int genpc_gather_colors(int n, const int *pix, const float *img, int ch, int h,
  * keep every other flipped point below it is not empty (genpc_amd/csrc/hpr.hip; double
  * arithmetic; at most 4096 viewpoints and 2^31 - 1 (viewpoint, point) pairs per call).  points[N,3] float, eyes[C,3] DOUBLE (both
  * device), radius > 0; visible[C,N] bytes, counts[C].  second_pass_points (HOST int, may
- * be NULL): how many points needed the large-polygon pass (lattice-like inputs).
- * Synchronises the stream (the later passes are sized from the first's counts).  Polygons of any size: up to 128 and
+ * be NULL): how many points the wave-per-point passes took over (lattice-like inputs: many).
+ * Asynchronous: every pass reads its item count from device memory, nothing is fetched -- unless
+ * second_pass_points is given, which costs the call's only stream synchronisation.  An internal error (none known)
+ * cannot be returned without one either: it turns every count into -1.  Polygons of any size: up to 128 and
  * 1024 vertices in LDS, beyond that in global memory.  Differences from qhull: normals tilted more than atan(1e4) from
  * the point's direction are not considered; of exact duplicates (-0 == +0) only the copy with the
  * lowest index takes part -- qhull reports one copy of a coincident group too, so counts agree.     */

@@ -21,6 +21,8 @@ VARIANTS = {
     "one_chunk_of_the_home_tile": {"GENPC_HPR_HOME_CHUNKS": "1"},   # the loosest polygons the rounds ever start from
     "one_kernel_form": {"GENPC_HPR_SPLIT": "0", "_deselect": "best_view"},      # (views are only dropped in the two-kernel form)
     "two_kernel_form_everywhere": {"GENPC_HPR_SPLIT": "1"},
+    # the polygon store holds 4096 parked points: the others are listed and restart from the box in the wave-per-point pass
+    "polygon_store_full": {"GENPC_HPR_SPLIT": "1", "GENPC_HPR_PARK_MB": "1"},
 }
 
 

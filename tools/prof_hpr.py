@@ -19,6 +19,6 @@ if which == "big":
 else:
     pts, eyes = cloud[fps_sampling(cloud, 10000).long()].contiguous(), dp.viewpoints
 for _ in range(2):
-    vis, cnt, second = dp.hidden_point_removal(pts, eyes, 10000.0)
+    vis, cnt, second = dp.hidden_point_removal(pts, eyes, 10000.0, want_second=True)
 torch.cuda.synchronize()
 print("visible", cnt.tolist()[:4], "second pass", second)

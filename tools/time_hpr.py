@@ -21,6 +21,7 @@ for name, pts, eyes in (("64 x 10000 (FPS order)", sub, dp.viewpoints), ("2 x 16
         dp.hidden_point_removal(pts, eyes, radius); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3): vis, cnt, second = dp.hidden_point_removal(pts, eyes, radius)
+        second = dp.hidden_point_removal(pts, eyes, radius, want_second=True)[2]
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 3 * 1e3
         t0 = time.perf_counter()
