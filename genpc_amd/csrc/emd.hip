@@ -753,7 +753,7 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     const size_t g_sorted = grid ? al256((size_t)total * sizeof(float4)) : 0, g_pos = grid ? al256((size_t)total * sizeof(int)) : 0;
     const size_t g_ps = grid ? al256((size_t)total * sizeof(float)) : 0;
     // per-cell lower bounds of the prices (emd_grid.hip: the bid culls cell by cell with them), refreshed in front of a round's bid
-    static const int env_cc = tune_env("GENPC_EMD_CELLCULL", 1, "culled EMD bid: refresh the cells' smallest prices every this many rounds and cull cells by them (0 = rows are culled by distance only)");
+    static const int env_cc = tune_env("GENPC_EMD_CELLCULL", 2, "culled EMD bid: refresh the cells' smallest prices every this many rounds and cull cells by them (0 = rows are culled by distance only)");
     const size_t g_pm = grid && env_cc > 0 ? al256((size_t)b * (cells_max + 1) * sizeof(float)) : 0;
     const size_t grid_off = arrive_bytes + list_bytes + second_bytes + parts_bytes + chain_bytes;
     char *ws = (char *)workspace(1, grid_off + g_hdr + g_start + g_sorted + g_pos + g_ps + g_pm, st, nullptr, arrive_bytes);

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void emd_cell_pmin_kernel(int cells_max, const
 // max_increments, the chain records.  LPB lanes share a bidder (a power of two, 8 .. 64, picked per round from the
 // number of bidders like pick_p); a lane takes whole rows of the bidder's box.
 template <int FMA>
-__global__ __launch_bounds__(kEBlock) void emd_bid_grid_kernel(EmdGridBid a)
+__global__ __launch_bounds__(kEBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void emd_bid_grid_kernel(EmdGridBid a)
 {
     __shared__ int s_pre[kEBlock / kWave][72], s_p0[kEBlock / kWave][72];      // per wave: (64 / LPB) groups x (LPB + 1) entries
     __shared__ int s_que[kEBlock / kWave][512];                                 // per wave: (64 / LPB) groups x 8 LPB queued entries

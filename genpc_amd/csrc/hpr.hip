@@ -679,9 +679,13 @@ __device__ __forceinline__ int hpr_seg_items(const HprSegs &sg, const int *statu
     return sg.on ? 8 * longest : longest;
 }
 
-__global__ __launch_bounds__(1024) void hpr_segs_kernel(int c, const int *__restrict__ hardcnt, HprSegs *__restrict__ out, int cap)
+// (also clears the work counters of the wave-per-point passes: kHprWorkWords ints, a 128-byte line per counter)
+constexpr int kHprWorkLine = 32, kHprWorkWords = 16 * kHprWorkLine;
+constexpr int kHprDecideChunk = 4;      // consecutive parked points a wave of hpr_decide_kernel takes per draw
+__global__ __launch_bounds__(1024) void hpr_segs_kernel(int c, const int *__restrict__ hardcnt, HprSegs *__restrict__ out, int cap, int *__restrict__ work)
 {
     __shared__ int s_per[8];
+    if (threadIdx.x < kHprWorkWords) work[threadIdx.x] = 0;
     if (threadIdx.x < 8) s_per[threadIdx.x] = 0;
     __syncthreads();
     const int on = (c & 7) == 0 ? 1 : 0;
@@ -1455,11 +1459,11 @@ __device__ __forceinline__ void hpr_decide_item(int slot, int n, const double *_
 
 // The launch does not know how many points were parked (the count never leaves the device): a fixed grid of one-wave
 // blocks, a multiple of 8 of them, strides over the items -- block b stays with segment b % 8, the XCD it runs on.
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 8))) void hpr_decide_kernel(int n, const double *__restrict__ fl_all, const HprTile *__restrict__ tiles_all,
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 8))) void hpr_decide_kernel(int n, const double *__restrict__ fl_all, const HprTile *__restrict__ tiles_all,
                                                           unsigned char *__restrict__ vis, int *__restrict__ cnt, int *status,
                                                           const int *__restrict__ perm, int no_cull, const unsigned char *__restrict__ alive,
                                                           const int4 *__restrict__ surv, const double2 *__restrict__ surv_poly,
-                                                          int *__restrict__ slots, const HprSegs *__restrict__ segs_p)
+                                                          int *__restrict__ slots, const HprSegs *__restrict__ segs_p, int *work)
 {
     __shared__ double2 s_p[kHprMaxV + 6];
     __shared__ double2 s_scratch[128];
@@ -1468,9 +1472,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 8))) v
     const int x = segs.on ? (int)(blockIdx.x & 7) : 0, stride = segs.on ? (int)(gridDim.x >> 3) : (int)gridDim.x;
     const int first = segs.base[x];
     const int fill = __builtin_amdgcn_readfirstlane(min(status[32 + x], segs.cap - first));
-    for (int k = segs.on ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; k < fill; k += stride) {
-        hpr_decide_item(first + k, n, fl_all, tiles_all, vis, cnt, status, perm, no_cull, alive, surv, surv_poly, slots, segs, s_p, s_scratch);
-        __syncthreads();
+    // The first chunk of kHprDecideChunk consecutive points is the block's own; the following ones are drawn from the
+    // segment's counter in order of arrival, so that the waves in flight work on a narrow window of the segment -- a few
+    // views' flipped points and tile records in that XCD's L2, as when every item was a block of its own and the dispatcher
+    // handed them out in order.  (A fixed stride lets the waves drift apart over hundreds of views: 9.2 ms against 6.7 at
+    // 1024 x 10000; a draw per POINT from eight counters in one cache line serialised the launch: 18.8 ms -- the counters
+    // have a 128-byte line each and a draw covers four points.)
+    int k0 = (segs.on ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * kHprDecideChunk;
+    while (k0 < fill) {
+        int nxt = 0;
+        if (threadIdx.x == 0) nxt = atomicAdd(&work[x * kHprWorkLine], 1);          // (issued now, read after the chunk)
+        for (int k = k0; k < min(k0 + kHprDecideChunk, fill); k++) {
+            hpr_decide_item(first + k, n, fl_all, tiles_all, vis, cnt, status, perm, no_cull, alive, surv, surv_poly, slots, segs, s_p, s_scratch);
+            __syncthreads();
+        }
+        k0 = (stride + __builtin_amdgcn_readfirstlane(nxt)) * kHprDecideChunk;
     }
 }
 
@@ -1730,6 +1746,7 @@ __global__ __launch_bounds__(kWave) void hpr_overflow_kernel(int n, const double
                                                              double2 *__restrict__ gbuf, int gcap, const int *__restrict__ slots,
                                                              const HprSegs *__restrict__ segs_p, const int *count, int *work)
 {
+    // (work: this pass's counter, a line of its own)
     __shared__ double2 s_lds[2][CAP > 0 ? CAP : 1];
     const HprSegs segs = *segs_p;
     const int items = __builtin_amdgcn_readfirstlane(count ? *count : hpr_seg_items(segs, status));
@@ -1791,6 +1808,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     const size_t o_und = off; off += up((size_t)c * sizeof(int));
     const size_t o_alive = off; off += up((size_t)c);
     const size_t o_dup = off; off += up((size_t)n);
+    const size_t o_work = off; off += up((size_t)kHprWorkWords * sizeof(int));
     // Split form (the first kernel stops after the home tiles + verification and saves the undecided points' polygons; a
     // wave per point continues from them): for clouds of < 256 tiles.  Round 3, first half: only for >= 4 M (view, point)
     // pairs, with a dense one-thread-per-survivor second kernel (1024 x 10000: 128 -> 88 ms; 64 x 10000 14.3 -> 16.6).  With
@@ -1866,7 +1884,8 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
         surv_poly = (double2 *)workspace(20, park_cap * poly_bytes, stream);
         if (!surv_poly) return 0;
     }
-    hipLaunchKernelGGL(hpr_segs_kernel, dim3(1), dim3(1024), 0, stream, c, (const int *)hardcnt, segs, (int)park_cap);
+    int *work = (int *)(ws + o_work);          // line x: the first try's counter of segment x; lines 8 .. 11: the other passes'
+    hipLaunchKernelGGL(hpr_segs_kernel, dim3(1), dim3(1024), 0, stream, c, (const int *)hardcnt, segs, (int)park_cap, work);
     static const int env_sf = tune_env("GENPC_HPR_STRAGGLE_FROM", 4, "hidden-point removal: tile batches a block walks before the hand-over");
     static const int env_sl = tune_env("GENPC_HPR_STRAGGLE_LANES", kHprThreads, "hidden-point removal: hand a block's points over when at most this many lanes are still undecided");
     static const int env_st = tune_env("GENPC_HPR_STRAGGLE_TILES", 0, "hidden-point removal: clouds of at least this many tiles hand undecided points over early");
@@ -1895,7 +1914,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
     static const int env_dw = tune_env("GENPC_HPR_DECIDE_WAVES", 64, "hidden-point removal: one-wave blocks per CU of the parked points' first try");
     static const int env_ww = tune_env("GENPC_HPR_WALK_WAVES", 40, "hidden-point removal: one-wave blocks per CU of the wave-per-point pass (128-vertex tier)");
     // status words: [0] listed, [2] parked, [3] polygons over 128 vertices, [4] over kHprOverCap, [5] parked points the first try
-    // left undecided, [32 .. 39] the segments' fills, [40 .. 44] the passes' work counters
+    // left undecided, [32 .. 39] the segments' fills (the passes' work counters: `work`, a cache line each)
     if (split) {
         static const int env_dk = tune_env("GENPC_HPR_DECIDE_KERNEL", 1, "hidden-point removal: 1 = the parked points' first try in a kernel of its own (more waves per CU), 0 = inside the wave-per-point kernel");
         const int *slots = nullptr;
@@ -1905,7 +1924,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
             const int gd = (grid_of(env_dw > 0 ? env_dw : 64) + 7) & ~7;          // block b -> segment b % 8
             hipLaunchKernelGGL(hpr_decide_kernel, dim3(gd), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles, visible,
                                counts, status, (const int *)i1, no_cull, (const unsigned char *)alive, (const int4 *)surv,
-                               (const double2 *)surv_poly, sl, (const HprSegs *)segs);
+                               (const double2 *)surv_poly, sl, (const HprSegs *)segs, work);
             if (!check(hipGetLastError(), "hpr decide launch")) return 0;
             slots = sl;
             count = status + 5;
@@ -1913,7 +1932,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
         hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(grid_of(env_ww > 0 ? env_ww : 40)), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
                            visible, counts, status, (const int *)nullptr, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
                            no_cull, (const unsigned char *)alive, list2, (const int4 *)surv, (const double2 *)surv_poly, (double2 *)nullptr, 0, slots,
-                           (const HprSegs *)segs, count, status + 40);
+                           (const HprSegs *)segs, count, work + 8 * kHprWorkLine);
         if (!check(hipGetLastError(), "hpr continuation launch")) return 0;
     }
     {
@@ -1922,21 +1941,21 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
             hipLaunchKernelGGL(hpr_overflow_kernel<128>, dim3(grid_of(env_ww > 0 ? env_ww : 40)), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
                                visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist, (const int *)hardcnt,
                                no_cull, (const unsigned char *)alive, list2, (const int4 *)nullptr, (const double2 *)nullptr, (double2 *)nullptr, 0,
-                               (const int *)nullptr, (const HprSegs *)segs, (const int *)(status + 0), status + 41);
+                               (const int *)nullptr, (const HprSegs *)segs, (const int *)(status + 0), work + 9 * kHprWorkLine);
             if (!check(hipGetLastError(), "hpr second pass launch")) return 0;
         } else {
             hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(grid_of(5)), dim3(kWave), 0, stream, n, (const double *)fl,
                                (const HprTile *)tiles, visible, counts, status, (const int *)list, (const int *)i1, (const int *)hardlist,
                                (const int *)hardcnt, no_cull, (const unsigned char *)alive, list3, (const int4 *)nullptr,
                                (const double2 *)nullptr, (double2 *)nullptr, 0, (const int *)nullptr, (const HprSegs *)segs,
-                               (const int *)(status + 0), status + 41);
+                               (const int *)(status + 0), work + 9 * kHprWorkLine);
         }
         // polygons over 128 vertices (from either launch above)
         hipLaunchKernelGGL(hpr_overflow_kernel<kHprOverCap>, dim3(grid_of(5)), dim3(kWave), 0, stream, n, (const double *)fl,
                            (const HprTile *)tiles, visible, counts, status, (const int *)list2, (const int *)i1, (const int *)hardlist,
                            (const int *)hardcnt, no_cull, (const unsigned char *)alive, list3, (const int4 *)nullptr,
                            (const double2 *)nullptr, (double2 *)nullptr, 0, (const int *)nullptr, (const HprSegs *)segs,
-                           (const int *)(status + 3), status + 42);
+                           (const int *)(status + 3), work + 10 * kHprWorkLine);
         if (!check(hipGetLastError(), "hpr large-polygon launch")) return 0;
         // polygons over 1024 vertices (exactly co-spherical input, lattices seen from their centre): a third tier with the
         // polygon in global memory, n + 8 vertices per buffer -- it cannot overflow -- a pair of buffers per wave of the grid
@@ -1950,7 +1969,7 @@ static int hpr_run(int c, int n, const float *points, const double *eyes, double
             hipLaunchKernelGGL(hpr_overflow_kernel<0>, dim3(g3), dim3(kWave), 0, stream, n, (const double *)fl, (const HprTile *)tiles,
                                visible, counts, status, (const int *)list3, (const int *)i1, (const int *)hardlist,
                                (const int *)hardcnt, no_cull, (const unsigned char *)alive, (int *)nullptr, (const int4 *)nullptr,
-                               (const double2 *)nullptr, gbuf, gcap, (const int *)nullptr, (const HprSegs *)segs, (const int *)(status + 4), status + 43);
+                               (const double2 *)nullptr, gbuf, gcap, (const int *)nullptr, (const HprSegs *)segs, (const int *)(status + 4), work + 11 * kHprWorkLine);
             if (!check(hipGetLastError(), "hpr global-polygon launch")) return 0;
         }
         hipLaunchKernelGGL(hpr_finish_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, stream, c, (const int *)status, counts);

@@ -29,6 +29,7 @@ tok["REG_LINE"] = ("registration + metric of one scan %.1f scans/s (six such sca
 tok["HPR_1024"] = "%.1f" % e["hpr_1024x10000_R10000_ms"]
 tok["HPR_2"] = "%.1f" % e["hpr_2x165546_R10000_ms"]
 tok["FPS_VERIFY"] = os.environ.get("FPS_VERIFY_SHARE", "a tenth")
+tok["HPR_DECIDE"] = os.environ.get("HPR_DECIDE_MS", "7.9 ms")
 tok["BENCH_LINE"] = ("%.0f Gpair/s (%.1f µs per step, spread %.1f–%.1f), `roofline.frac` %.3f, CPU port %.2f Gpair/s on %d threads; EMD 1 × 16384 %.2f ms, "
                      "13 bundled scans %.1f ms, 13 uniform %.2f ms; metric %.0f scans/s (`%s`)"
                      % (d["value"], d["ms_per_step"] * 1e3, d["ms_per_step_spread"]["min"] * 1e3, d["ms_per_step_spread"]["max"] * 1e3, r["frac"],

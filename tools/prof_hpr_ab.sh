@@ -16,5 +16,5 @@ for r in csv.DictReader(open(f[0])):
 PY
 }
 run default GENPC_X=0
-run d100000 GENPC_HPR_DECIDE_WAVES=100000
-run d4096 GENPC_HPR_DECIDE_WAVES=4096
+
+
