@@ -621,7 +621,8 @@ __global__ __launch_bounds__(kBlock) void chamfer_grad_kernel(int b, int n, cons
 // read-modify-writes -- every output row has exactly one owner, and the own-row launch (PHASE 1) has finished before.
 // grid (tiles, b, 2).
 constexpr int kGradTile = 4096;
-__global__ __launch_bounds__(kBlock) void chamfer_grad_scatter_tiled_kernel(int n, const float *__restrict__ xyz1, int m,
+constexpr int kGradBlock = 1024;      // (64 x 32768 both ways: 122 us; 512 threads 144, 256 threads 228 before the loads were batched; capped at 64 VGPRs for two blocks per CU 159)
+__global__ __launch_bounds__(kGradBlock) void chamfer_grad_scatter_tiled_kernel(int n, const float *__restrict__ xyz1, int m,
                                                                             const float *__restrict__ xyz2,
                                                                             const float *__restrict__ gd1, const int *__restrict__ idx1,
                                                                             const float *__restrict__ gd2, const int *__restrict__ idx2,
@@ -639,31 +640,40 @@ __global__ __launch_bounds__(kBlock) void chamfer_grad_scatter_tiled_kernel(int 
     const int *__restrict__ I = (dir ? idx2 : idx1) + (size_t)e * nq;
     float *__restrict__ O = (dir ? gx1 : gx2) + (size_t)e * nt * 3;
     const int rows = min(kGradTile, nt - t0);
-    for (int i = threadIdx.x; i < rows * 3; i += kBlock) acc[i] = 0.0f;
+    for (int i = threadIdx.x; i < rows * 3; i += kGradBlock) acc[i] = 0.0f;
     __syncthreads();
-    // eight indices in flight per thread (one per trip left every trip waiting for its own load: the loop is a walk over the
-    // whole index array in which one entry in eight does anything)
-    for (int q0 = threadIdx.x; q0 < nq; q0 += 8 * kBlock) {
+    // Eight entries per thread and trip, every load of a trip issued before anything waits: the indices, then -- for all eight,
+    // hit or not, at clamped addresses -- the query row, its weight and the target row (L2 hits: a cloud is half a MiB), then
+    // the LDS adds of the hits.  (One entry in eight lands in the tile; fetched only for the hits, behind a branch per entry,
+    // the seven dependent loads of a hit were a round trip each, 128 times per thread: 228 us for 64 x 32768 both ways.)
+    for (int q0 = threadIdx.x; q0 < nq; q0 += 8 * kGradBlock) {
         int kk[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int q = q0 + u * kBlock;
+            const int q = q0 + u * kGradBlock;
             kk[u] = q < nq ? I[q] - t0 : -1;
+        }
+        float qx[8], qy[8], qz[8], gg[8], tx[8], ty[8], tz[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool ok = (unsigned)kk[u] < (unsigned)rows;
+            const int q = ok ? q0 + u * kGradBlock : 0, k = ok ? kk[u] : 0;
+            qx[u] = Q[(size_t)q * 3 + 0]; qy[u] = Q[(size_t)q * 3 + 1]; qz[u] = Q[(size_t)q * 3 + 2];
+            gg[u] = G[q];
+            tx[u] = T[(size_t)(t0 + k) * 3 + 0]; ty[u] = T[(size_t)(t0 + k) * 3 + 1]; tz[u] = T[(size_t)(t0 + k) * 3 + 2];
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int k = kk[u], q = q0 + u * kBlock;
+            const int k = kk[u];
             if ((unsigned)k >= (unsigned)rows) continue;
-            const float x1 = Q[(size_t)q * 3 + 0], y1 = Q[(size_t)q * 3 + 1], z1 = Q[(size_t)q * 3 + 2];
-            const float x2 = T[(size_t)(t0 + k) * 3 + 0], y2 = T[(size_t)(t0 + k) * 3 + 1], z2 = T[(size_t)(t0 + k) * 3 + 2];
-            const float g = __fmul_rn(G[q], 2.0f);
-            atomicAdd(&acc[k * 3 + 0], -__fmul_rn(g, x1 - x2));
-            atomicAdd(&acc[k * 3 + 1], -__fmul_rn(g, y1 - y2));
-            atomicAdd(&acc[k * 3 + 2], -__fmul_rn(g, z1 - z2));
+            const float g = __fmul_rn(gg[u], 2.0f);
+            atomicAdd(&acc[k * 3 + 0], -__fmul_rn(g, qx[u] - tx[u]));
+            atomicAdd(&acc[k * 3 + 1], -__fmul_rn(g, qy[u] - ty[u]));
+            atomicAdd(&acc[k * 3 + 2], -__fmul_rn(g, qz[u] - tz[u]));
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < rows * 3; i += kBlock) O[(size_t)t0 * 3 + i] = __fadd_rn(O[(size_t)t0 * 3 + i], acc[i]);
+    for (int i = threadIdx.x; i < rows * 3; i += kGradBlock) O[(size_t)t0 * 3 + i] = __fadd_rn(O[(size_t)t0 * 3 + i], acc[i]);
 }
 
 struct NNConfig {
@@ -1105,7 +1115,7 @@ GENPC_API int genpc_chamfer_backward(int b, int n, const float *xyz1, int m, con
         static const int env_tiled = tune_env("GENPC_CHAMFER_GRAD_TILED", 1, "chamfer backward, large calls: 1 = the scattered halves through LDS tiles that own their output rows, 0 = global atomics");
         const int tiles = ceil_div(n > m ? n : m, kGradTile);
         if (env_tiled && tiles <= 65535 && b <= 65535)
-            hipLaunchKernelGGL(chamfer_grad_scatter_tiled_kernel, dim3(tiles, b, 2), dim3(kBlock), 0, (hipStream_t)stream, n, xyz1, m, xyz2,
+            hipLaunchKernelGGL(chamfer_grad_scatter_tiled_kernel, dim3(tiles, b, 2), dim3(kGradBlock), 0, (hipStream_t)stream, n, xyz1, m, xyz2,
                                graddist1, idx1, graddist2, idx2, gradxyz1, gradxyz2);
         else
             hipLaunchKernelGGL(chamfer_grad_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, b, n, xyz1, m,

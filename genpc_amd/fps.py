@@ -14,11 +14,102 @@ import threading as _threading
 _ONE_AT_A_TIME = _threading.Lock() if _os.environ.get("GENPC_FPS_LOCK", "0") == "1" else None
 
 
+class FpsCombiner:
+    """Samplings of several host threads in ONE launch.  A sampling is k sequential steps per cloud, its launch needs its
+    workgroups co-resident (csrc/fps.hip) and takes a large share of the admission budget: samplings of different streams
+    run one after the other however many scans are in flight -- 2 x 8.7 ms per completed scan of config 2, the largest
+    serial item of pipeline.complete_scans.  Independent clouds side by side in one launch cost the longest chain, not the
+    sum: while a launch is in flight the requests of the other threads queue up here and leave together in the next one
+    (a leader among the waiting threads runs it on the combiner's stream; every requester's stream waits for the launch's
+    event).  Results are the bits a call of its own gives: clouds never interact.  (Opt-in, GENPC_FPS_COMBINER=1 in
+    pipeline.run_in_lanes: measured, it does not raise the scans in flight -- the numbers are there.)
+
+        with FpsCombiner.installed(device): ...      # fps_sampling / fps_sampling_multi of ANY thread go through it
+    """
+    _current = None
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.cond = _threading.Condition()
+        self.pending = []
+        self.busy = False
+        self.launches = 0
+        self.clouds = 0
+
+    class _Req:
+        __slots__ = ("clouds", "ks", "ready", "outs", "done", "err", "finished")
+
+    def submit(self, clouds, ks):
+        lane = torch.cuda.current_stream(self.device)
+        r = FpsCombiner._Req()
+        r.clouds, r.ks, r.outs, r.err, r.finished = clouds, ks, None, None, False
+        r.ready = torch.cuda.Event()
+        r.ready.record(lane)                     # the clouds are the lane's products
+        batch = None
+        with self.cond:
+            self.pending.append(r)
+            while not r.finished:
+                if not self.busy:
+                    batch, self.pending, self.busy = self.pending, [], True
+                    break
+                self.cond.wait()
+        if batch is not None:                    # this thread leads: one launch for everything that queued up
+            try:
+                with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+                    for q in batch:
+                        self.stream.wait_event(q.ready)
+                    flat_c = [c for q in batch for c in q.clouds]
+                    flat_k = [k for q in batch for k in q.ks]
+                    outs = _fps_multi_direct(flat_c, flat_k)         # (reads the first indices on the host: returns when the launch is done)
+                    done = torch.cuda.Event()
+                    done.record(self.stream)
+                at = 0
+                for q in batch:
+                    q.outs, q.done = outs[at:at + len(q.clouds)], done
+                    at += len(q.clouds)
+                self.launches += 1
+                self.clouds += len(flat_c)
+            except BaseException as e:
+                for q in batch:
+                    q.err = e
+            finally:
+                with self.cond:
+                    self.busy = False
+                    for q in batch:
+                        q.finished = True
+                    self.cond.notify_all()
+        if r.err is not None:
+            raise r.err
+        lane.wait_event(r.done)
+        for o in r.outs:
+            o.record_stream(lane)                # (allocated on the combiner's stream, read on the lane's)
+        return r.outs
+
+    @classmethod
+    def installed(cls, device):
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev = cls._current
+            cls._current = cls(device)
+            try:
+                yield cls._current
+            finally:
+                cls._current = prev
+        return ctx()
+
+
 def fps_sampling(points, k):
     """points: [N,3] or [C,N,3] GPU tensor -> int32 indices [k] or [C,k].  The first
     index is always 0; the kernel writes -1 there if its inter-workgroup hand-off timed
     out (another kernel kept the cloud's workgroups from being co-resident)."""
     single = points.dim() == 2
+    if FpsCombiner._current is not None and points.is_cuda:
+        pts = (points[None] if single else points).contiguous().float()
+        outs = fps_sampling_multi([pts[j] for j in range(pts.shape[0])], [int(k)] * pts.shape[0])
+        return outs[0] if single else torch.stack(outs)
     pts = (points[None] if single else points).contiguous().float()
     _lib.check_tensors((("points", pts),))
     c, n, _ = pts.shape
@@ -32,14 +123,26 @@ def fps_sampling(points, k):
     # between its workgroups timed out (the samples after it would be garbage): those clouds go again, one at a time
     bad = torch.nonzero(out[:, 0] != 0).flatten().tolist()
     for j in bad:
-        out[j] = fps_sampling_multi([pts[j]], [k])[0]
+        out[j] = _fps_multi_direct([pts[j]], [k])[0]
     return out[0] if single else out
 
 
-def fps_sampling_multi(clouds, ks, _attempt=0):
+def fps_sampling_multi(clouds, ks):
     """Several clouds of different sizes / sample counts in ONE pass (FPS is latency-bound: k sequential
     steps per cloud, so independent clouds side by side cost the longest one, not the sum).
     clouds: list of [N_j,3] GPU tensors, ks: list of ints -> list of int32 index tensors [k_j]."""
+    comb = FpsCombiner._current
+    if comb is not None and len(clouds) > 0 and clouds[0].is_cuda and clouds[0].device == comb.device:
+        pts = [c.contiguous().float() for c in clouds]
+        if len(ks) != len(pts) or any(p.dim() != 2 or p.shape[1] != 3 for p in pts):
+            raise ValueError("fps_sampling_multi: need one k per [N,3] cloud")
+        if any(not (0 < int(k) <= p.shape[0] <= 262144) for p, k in zip(pts, ks)):
+            raise ValueError("fps_sampling_multi: need 0 < k <= N <= 262144 for every cloud")
+        return comb.submit(pts, [int(k) for k in ks])
+    return _fps_multi_direct(clouds, ks)
+
+
+def _fps_multi_direct(clouds, ks, _attempt=0):
     import ctypes
     pts = [c.contiguous().float() for c in clouds]
     _lib.check_tensors(tuple(("clouds[%d]" % j, p) for j, p in enumerate(pts)))
@@ -74,7 +177,7 @@ def fps_sampling_multi(clouds, ks, _attempt=0):
         # seen twice for samplings running beside other streams' kernels, cause unknown.  Not an error yet: the clouds that
         # failed go again, one at a time (a launch to itself needs a fraction of the device)
         for j in bad:
-            outs[j] = fps_sampling_multi([pts[j]], [ks[j]], _attempt=_attempt + 1 if c == 1 else _attempt)[0]
+            outs[j] = _fps_multi_direct([pts[j]], [ks[j]], _attempt=_attempt + 1 if c == 1 else _attempt)[0]
         return outs
     if bad:
         raise RuntimeError("genpc_fps: no verified sampling after %d attempts (hand-off timed out or the sequence failed its "
