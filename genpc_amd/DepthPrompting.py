@@ -147,11 +147,11 @@ class DepthPrompting:
         cnt = torch.empty(c, device=points.device, dtype=torch.int32)
         total_second = 0
         # the library takes at most 4096 viewpoints and 2^31 - 1 (viewpoint, point) pairs per call, and its
-        # per-stream workspace holds ~65 bytes per pair plus 256 bytes per point the early accept leaves over
-        # (a third of them at worst in practice: ~150 bytes per pair) and is never released: views are chunked so
-        # that one call stays within cfg.hpr_workspace_bytes (default 4 GiB; 1024 x 10000 pairs is one call)
+        # per-stream workspace holds ~65 bytes per pair plus a 256-byte polygon slot per pair (sized for the worst
+        # case since the counts stay on the device, capped by GENPC_HPR_PARK_MB) and is never released: views are
+        # chunked so that one call stays within cfg.hpr_workspace_bytes (default 4 GiB; 1024 x 10000 pairs is one call)
         budget = int(getattr(self.cfg, "hpr_workspace_bytes", 4 << 30))
-        step = max(1, min(4096, (2 ** 31 - 1) // max(n, 1), budget // (150 * max(n, 1))))
+        step = max(1, min(4096, (2 ** 31 - 1) // max(n, 1), budget // (321 * max(n, 1))))
         for v0 in range(0, c, step):
             v1 = min(c, v0 + step)
             second = ctypes.c_int(0)

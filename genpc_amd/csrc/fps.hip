@@ -273,12 +273,44 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
                             g2 = make_uint2((unsigned)w2, (unsigned)(w2 >> 32));
                             good = g0.y == want && g1.y == want && g2.y == want;
                         } while (!__all(good) && ++tries < 4096);
-                        cx = __uint_as_float(g0.x); cy = __uint_as_float(g1.x); cz = __uint_as_float(g2.x);
+                        // ... and the VALUE every lane uses is lane 0's copy, through scalar registers (tools/fps_reject_probe.py, round 5:
+                        // with six scans in flight 8 % of the samplings failed the device-side check, and every wrong sample -- 44 of 44 --
+                        // was a point held in REGISTER 0 by lanes 48-63 of a worker wave, its running minimum not lowered by one pivot:
+                        // the first arithmetic behind the wait used the previous occupant of the value register in the last sixteen
+                        // lanes although the tag registers of the same loads, compared later, were current)
+                        cx = __uint_as_float(__builtin_amdgcn_readfirstlane(g0.x));
+                        cy = __uint_as_float(__builtin_amdgcn_readfirstlane(g1.x));
+                        cz = __uint_as_float(__builtin_amdgcn_readfirstlane(g2.x));
                     }
+                    // THE CAUSE of the wrong samples (round 5, tools/fps_reject_probe.py; six scans in flight): written plainly, the
+                    // compiler pairs registers r, r + 1 into PACKED fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32),
+                    // and beside other streams' kernels 8 % of the samplings then failed the device-side check -- every wrong sample, 55
+                    // of 55, a point held in the LOW half of a pair (register 0) by lanes 48-63 of a worker wave whose running
+                    // minimum had missed one pivot.  Neither the way the pivot arrives (LDS broadcast, tagged granules, scalar
+                    // registers) nor eight wait states around every DPP step changed the rate; with one register at a time (the
+                    // opaque statements below keep the compiler from pairing) it is 0 of 900 scans.  Why a packed fp32 instruction
+                    // loses its low half in the last sixteen lanes next to another wave's matrix instructions is not known to us.
+                    if (jobs.legacy_pivot) {           // the pre-fix form (test hook): registers r, r + 1 as two-element vectors -> v_pk_*_f32
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        static_assert(R % 2 == 0, "pairs of registers");
 #pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const float dd = sqdist_f<FMA>(px[r] - cx, py[r] - cy, pz[r] - cz);
-                        d[r] = d[r] < dd ? d[r] : dd;       // padding slots stay at -1
+                        for (int r = 0; r < R; r += 2) {
+                            const f32x2 dx = (f32x2){px[r], px[r + 1]} - cx, dy = (f32x2){py[r], py[r + 1]} - cy, dz = (f32x2){pz[r], pz[r + 1]} - cz;
+                            f32x2 dd;
+                            if (FMA) dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+                            else dd = (dx * dx + dy * dy) + dz * dz;
+                            d[r] = d[r] < dd.x ? d[r] : dd.x;
+                            d[r + 1] = d[r + 1] < dd.y ? d[r + 1] : dd.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            float dx = px[r] - cx, dy = py[r] - cy, dz = pz[r] - cz;
+                            asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz));
+                            float dd = sqdist_f<FMA>(dx, dy, dz);
+                            asm volatile("" : "+v"(dd));
+                            d[r] = d[r] < dd ? d[r] : dd;       // padding slots stay at -1
+                        }
                     }
                 }
                 if (pr & kProgDone) break;
@@ -445,7 +477,11 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
             if (lane == 0) prog_store(&s_prog, (round << 16) | (unsigned)mm);       // the workers may take it
 #pragma unroll
             for (int c = 0; c < kFT; c++) {
-                const float dd = sqdist_f<FMA>(cxs[c] - qx, cys[c] - qy, czs[c] - qz);
+                // (one candidate at a time, like the workers' update: no packed fp32 instructions)
+                float dx = cxs[c] - qx, dy = cys[c] - qy, dz = czs[c] - qz;
+                asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz));
+                float dd = sqdist_f<FMA>(dx, dy, dz);
+                asm volatile("" : "+v"(dd));
                 cd[c] = cd[c] < dd ? cd[c] : dd;        // dead entries stay at -2
             }
         }
@@ -571,7 +607,8 @@ __global__ __launch_bounds__(kFVBlock) void fps_verify_kernel(FpsJobs jobs, floa
 __global__ void fps_poison_kernel(FpsJobs jobs, int nj)
 {
     const int j = threadIdx.x;
-    if (j < nj && *jobs.verr[j] != 0) { jobs.out[j][0] = -1; *jobs.verr[j] = 0; }
+    // (-2: the sequence failed the check; a sampling whose hand-off timed out has written -1 itself, and fails the check too)
+    if (j < nj && *jobs.verr[j] != 0) { if (jobs.out[j][0] != -1) jobs.out[j][0] = -2; *jobs.verr[j] = 0; }
 }
 
 template <int FMA>

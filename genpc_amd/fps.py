@@ -12,6 +12,11 @@ _p = _lib.ptr
 import os as _os
 import threading as _threading
 _ONE_AT_A_TIME = _threading.Lock() if _os.environ.get("GENPC_FPS_LOCK", "0") == "1" else None
+# what the device-side verification has seen in this process (tools/soak_lanes.py prints it): clouds sampled, clouds whose
+# hand-off timed out (first index -1) or whose sequence failed the check -- a step's sample was not the first arg-max
+# (first index -2) -- and were sampled again
+stats = {"clouds": 0, "timed_out": 0, "failed_check": 0}
+_stats_lock = _threading.Lock()
 
 
 class FpsCombiner:
@@ -29,7 +34,8 @@ class FpsCombiner:
     _current = None
 
     def __init__(self, device):
-        self.device = torch.device(device)
+        d = torch.device(device)
+        self.device = torch.device("cuda", torch.cuda.current_device() if d.index is None else d.index)
         self.stream = torch.cuda.Stream(device=self.device)
         self.cond = _threading.Condition()
         self.pending = []
@@ -171,6 +177,10 @@ def _fps_multi_direct(clouds, ks, _attempt=0):
         raise RuntimeError("genpc_fps_multi failed: " + _lib.last_error())
     first = torch.stack([o[0] for o in outs]).tolist()          # (one host read for all clouds)
     bad = [j for j, f in enumerate(first) if f != 0]
+    with _stats_lock:
+        stats["clouds"] += c if _attempt == 0 else 0
+        stats["timed_out"] += sum(1 for j in bad if first[j] != -2)
+        stats["failed_check"] += sum(1 for j in bad if first[j] == -2)
     if bad and (c > 1 or _attempt < 3):
         # out[0] == -1: a hand-off timed out (something else on the GPU kept a cloud's workgroups from running together), or
         # the device-side verification (csrc/fps.hip: fps_verify_kernel) found a step whose sample is not the first arg-max --

@@ -402,7 +402,11 @@ int genpc_fastdiv_probe(long long n, const float *num, const float *den, float *
  * (main.py:21-24, reg_xyz.py:215, DepthPrompting.py:88; third-party, random start):
  * start index 0, fp32 squared distances in the library's arithmetic mode, first
  * arg-max.  xyz[C,N,3] -> out_idx[C,k] int32, C clouds side by side.  Returns -1
- * unless 0 < k <= n <= 262144.                                                  */
+ * unless 0 < k <= n <= 262144.  out_idx[c][0] is 0 for a good sequence; -1: the
+ * hand-off among the cloud's workgroups timed out (something kept them from running
+ * together); -2: the finished sequence failed the device-side check of every step
+ * against the definition (GENPC_FPS_VERIFY, on by default) -- sample that cloud again
+ * (genpc_amd/fps.py does).                                                       */
 int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, void *stream);
 
 /* The same for C clouds of DIFFERENT sizes in one pass (the metric's two subsamplings and the fused
@@ -410,9 +414,10 @@ int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, void *stream)
  * xyz[C] (device pointers to [n_j,3]), out_idx[C] (device pointers to [k_j]).                    */
 int genpc_fps_multi(int c, const int *n, const int *k, const float *const *xyz,
                     int *const *out_idx, void *stream);
-/* Test hook (calling host thread; returns the previous setting): 1 = the workers of the sampling read the pivots as
- * per-lane LDS broadcasts, the round-4 form that drew a wrong sample next to f16 MFMAs on another stream (kept reachable
- * so that tests/test_gpu_concurrency.py can show the trigger); 0 = through scalar registers (shipped). */
+/* Test hook (calling host thread; returns the previous setting): 1 = the pre-fix form of the sampling's workers -- pivots read
+ * as per-lane LDS broadcasts and running minima lowered with PACKED fp32 instructions on register pairs, which is what drew
+ * wrong samples next to other streams' matrix instructions (csrc/fps.hip; kept reachable so that
+ * tests/test_gpu_concurrency.py can show the trigger); 0 = one register at a time (shipped). */
 int genpc_fps_tune(int legacy_pivot);
 /* Diagnostics: rounds[j] (host, c <= 32) = inter-workgroup exchanges cloud j of the last
  * genpc_fps_multi call on this stream took (one exchange yields several samples).  Synchronises.  */

@@ -108,6 +108,46 @@ def test_fps_multi_ragged(fg, oracle):
     assert sorted(got[1].cpu().numpy().tolist()) == list(range(16384))      # k == n: a permutation
 
 
+def test_fps_combiner_gives_each_thread_its_own_sequences(fg):
+    """fps.FpsCombiner: samplings of several host threads (a stream each) leave in shared launches; every thread gets the
+    sequences a call of its own gives."""
+    import threading
+    torch = fg["torch"]
+    from genpc_amd.fps import fps_sampling_multi, FpsCombiner
+    rng = np.random.default_rng(5)
+    jobs = [[(rng.random((n, 3), dtype=np.float32) - 0.5) for n in sizes] for sizes in ((9000, 300), (20000,), (4096, 4096, 77), (12000,), (700, 15000))]
+    ks = [[min(len(c), 2500) for c in cl] for cl in jobs]
+    dev_jobs = [[torch.from_numpy(c).cuda() for c in cl] for cl in jobs]
+    want = [[o.cpu().numpy() for o in fps_sampling_multi(cl, k)] for cl, k in zip(dev_jobs, ks)]
+    torch.cuda.synchronize()
+    got, errs = [None] * len(jobs), []
+
+    def run(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(3):                       # (several rounds: requests queue up behind launches in flight)
+                    outs = fps_sampling_multi(dev_jobs[i], ks[i])
+                    single = fg["fps"](dev_jobs[i][0], ks[i][0])
+                torch.cuda.current_stream().synchronize()
+                got[i] = [o.cpu().numpy() for o in outs] + [single.cpu().numpy()]
+        except BaseException as e:
+            errs.append(e)
+
+    with FpsCombiner.installed("cuda") as comb:
+        th = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        assert comb.clouds == 3 * sum(len(j) + 1 for j in jobs) and 1 <= comb.launches <= 3 * 2 * len(jobs)
+    assert FpsCombiner._current is None
+    for w, g in zip(want, got):
+        for a, b in zip(w, g[:-1]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(w[0], g[-1])
+
+
 def test_fps_step_time(fg):
     """Recorded, not asserted tightly: microseconds per sequential step (round 2: 2.8 at 4 x 165546)."""
     torch = fg["torch"]

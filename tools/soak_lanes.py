@@ -31,4 +31,6 @@ for i, o in enumerate(outs):
     same = o["view"] == r["view"] and all(torch.equal(o[k], r[k]) for k in ("visible", "uv", "fused", "pred_metric_points", "gt_metric_points")) \
         and torch.equal(torch.as_tensor(o["metric"]), torch.as_tensor(r["metric"])) and torch.equal(o["reg"]["source"], r["reg"]["source"])
     bad += 0 if same else 1
-print("%d scans, %d lanes: %.1f scans/s, %d differ from a call of their own" % (count, lanes, count / dt, bad))
+from genpc_amd import fps as _fps
+print("%d scans, %d lanes: %.1f scans/s, %d differ from a call of their own; farthest-point samplings: %d clouds, %d hand-offs timed out, %d sequences failed the device-side check (both drawn again)"
+      % (count, lanes, count / dt, bad, _fps.stats["clouds"], _fps.stats["timed_out"], _fps.stats["failed_check"]))
