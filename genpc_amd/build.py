@@ -22,6 +22,12 @@ FLAGS = [
     "-fno-fast-math", "-fvisibility=hidden", "-fgpu-rdc" if False else "-fno-gpu-rdc",
     "-Wall", "-Wno-unused-function",
 ]
+# No packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) anywhere in the library: in the farthest-point
+# sampling they were what drew wrong samples beside other streams' matrix instructions (csrc/fps.hip; the low half
+# of a register pair, lanes 48-63); scalar fp32 instructions give the same bits.  GENPC_PACKED_FP32=1 builds with them (A/B).
+# (The feature is the device compiler's: the host pass prints one "not a recognized feature" line per file, dropped below.)
+if os.environ.get("GENPC_PACKED_FP32", "0") != "1":
+    FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def sources():
@@ -67,7 +73,13 @@ def build(force=False, save_temps=False, verbose=True, jobs=None):
     def run(job):
         if verbose:
             print("[genpc_amd.build]", " ".join(job[0]), flush=True)
-        subprocess.check_call(job[0], cwd=job[1])
+        r = subprocess.run(job[0], cwd=job[1], stderr=subprocess.PIPE, text=True)
+        noise = "'-packed-fp32-ops' is not a recognized feature for this target"
+        err = "\n".join(l for l in r.stderr.splitlines() if noise not in l)
+        if err.strip():
+            print(err, file=sys.stderr, flush=True)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, job[0])
 
     jobs = jobs or int(os.environ.get("GENPC_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:

@@ -1,0 +1,113 @@
+// tools/pk_probe.hip -- does a packed fp32 instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) ever deliver a wrong
+// half when another stream's kernel issues matrix instructions on the same SIMDs?  (csrc/fps.hip, DESIGN.md 6a: the
+// farthest-point sampling's wrong samples went away when its update stopped using them.)
+//
+// probe kernel: every lane keeps two "points" and their running minima twice -- once updated with two-element vector
+// arithmetic (packed instructions), once with scalar instructions behind opaque statements -- against a stream of pivots
+// taken from scalar registers, as the sampling's workers do; after every pivot the two copies are compared bit for bit and a
+// mismatch is recorded (iteration, lane, half, both values).  mode 1: the wave sleeps between pivots (s_sleep), like a worker
+// polling its progress word.
+// burner kernel: v_mfma_f32_32x32x16_f16 in a loop.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/pk_probe.hip -o /tmp/pk_probe && /tmp/pk_probe [seconds] [mode]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <chrono>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Hit { unsigned it, lane_half, packed_bits, scalar_bits; };
+
+__global__ __launch_bounds__(256) void probe_kernel(int iters, int mode, unsigned *nhit, Hit *hits, unsigned long long *done)
+{
+    const unsigned t = blockIdx.x * 256 + threadIdx.x;
+    unsigned s = t * 2654435761u + 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) * (1.0f / 16777216.0f); };
+    const f32x2 px = {rnd(), rnd()}, py = {rnd(), rnd()}, pz = {rnd(), rnd()};
+    f32x2 dp = {1e30f, 1e30f};
+    float d0 = 1e30f, d1 = 1e30f;
+    unsigned u = blockIdx.x * 747796405u + 2891336453u;      // (wave-uniform pivot stream)
+    for (int it = 0; it < iters; it++) {
+        u = u * 1664525u + 1013904223u;
+        const unsigned u1 = u * 22695477u + 1u, u2 = u1 * 22695477u + 1u;
+        const float cx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(u >> 8) * (1.0f / 16777216.0f))));
+        const float cy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(u1 >> 8) * (1.0f / 16777216.0f))));
+        const float cz = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(u2 >> 8) * (1.0f / 16777216.0f))));
+        if (mode & 1) __builtin_amdgcn_s_sleep(1);
+        // packed
+        const f32x2 dx = px - cx, dy = py - cy, dz = pz - cz;
+        const f32x2 dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+        dp.x = dp.x < dd.x ? dp.x : dd.x;
+        dp.y = dp.y < dd.y ? dp.y : dd.y;
+        // scalar
+        float ax = px.x - cx, ay = py.x - cy, az = pz.x - cz, bx = px.y - cx, by = py.y - cy, bz = pz.y - cz;
+        asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(bx), "+v"(by), "+v"(bz));
+        float ta = __fmul_rn(ay, ay), tb = __fmul_rn(by, by);
+        asm volatile("" : "+v"(ta), "+v"(tb));
+        ta = __fmaf_rn(ax, ax, ta); tb = __fmaf_rn(bx, bx, tb);
+        asm volatile("" : "+v"(ta), "+v"(tb));
+        ta = __fmaf_rn(az, az, ta); tb = __fmaf_rn(bz, bz, tb);
+        asm volatile("" : "+v"(ta), "+v"(tb));
+        d0 = d0 < ta ? d0 : ta;
+        d1 = d1 < tb ? d1 : tb;
+        const bool bad0 = __float_as_uint(dp.x) != __float_as_uint(d0), bad1 = __float_as_uint(dp.y) != __float_as_uint(d1);
+        if (bad0 || bad1) {
+            const unsigned k = atomicAdd(nhit, 1u);
+            if (k < 4096) hits[k] = Hit{(unsigned)it, (threadIdx.x & 63u) * 2u + (bad0 ? 0u : 1u), __float_as_uint(bad0 ? dp.x : dp.y), __float_as_uint(bad0 ? d0 : d1)};
+            dp.x = d0; dp.y = d1;          // resynchronise
+        }
+        if ((it & 255) == 0) { d0 = dp.x = 1e30f; d1 = dp.y = 1e30f; }      // (keep the minima moving)
+    }
+    if (threadIdx.x == 0) atomicAdd(done, (unsigned long long)iters);
+}
+
+__global__ __launch_bounds__(512) void burn_kernel(int iters, float *out)
+{
+    f32x16 acc = {0};
+    uint4 a = make_uint4(threadIdx.x, threadIdx.x * 3, threadIdx.x * 5, 0x3c003c00u);
+    for (int it = 0; it < iters; it++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, a), acc, 0, 0, 0);
+        a.x += 1;
+    }
+    float s = 0; for (int e = 0; e < 16; e++) s += acc[e];
+    if (s == 12345.678f) out[0] = s;
+}
+
+int main(int argc, char **argv)
+{
+    const double seconds = argc > 1 ? atof(argv[1]) : 10.0;
+    const int mode = argc > 2 ? atoi(argv[2]) : 0;
+    const int burn = argc > 3 ? atoi(argv[3]) : 1;
+    hipStream_t sa, sb;
+    hipStreamCreate(&sa); hipStreamCreate(&sb);
+    unsigned *nhit; Hit *hits; unsigned long long *done; float *out;
+    hipMalloc(&nhit, 4); hipMalloc(&hits, sizeof(Hit) * 4096); hipMalloc(&done, 8); hipMalloc(&out, 4);
+    hipMemset(nhit, 0, 4); hipMemset(done, 0, 8);
+    const auto t0 = std::chrono::steady_clock::now();
+    int launches = 0;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+        // one probe wave and one burner block per SIMD pair: 512 probe blocks of four waves beside 512 burner blocks of eight
+        hipLaunchKernelGGL(probe_kernel, dim3(512), dim3(256), 0, sa, 200000, mode, nhit, hits, done);
+        if (burn) for (int q = 0; q < 8; q++) hipLaunchKernelGGL(burn_kernel, dim3(512), dim3(512), 0, sb, 20000, out);
+        hipStreamSynchronize(sa);
+        launches++;
+    }
+    hipDeviceSynchronize();
+    unsigned n = 0; unsigned long long d = 0;
+    hipMemcpy(&n, nhit, 4, hipMemcpyDeviceToHost); hipMemcpy(&d, done, 8, hipMemcpyDeviceToHost);
+    Hit *h = (Hit *)malloc(sizeof(Hit) * 4096);
+    hipMemcpy(h, hits, sizeof(Hit) * 4096, hipMemcpyDeviceToHost);
+    printf("mode %d, burner %s: %d launches, %.3g wave-iterations (8 packed instructions each), %u mismatches between the packed and the scalar copy\n",
+           mode, burn ? "on" : "off", launches, (double)d * 4.0, n);
+    int lanes[64] = {0}, halves[2] = {0, 0};
+    for (unsigned k = 0; k < n && k < 4096; k++) { lanes[(h[k].lane_half >> 1) & 63]++; halves[h[k].lane_half & 1]++; }
+    if (n) {
+        printf("  by half: low %d, high %d;  by lane quarter: 0-15 %d, 16-31 %d, 32-47 %d, 48-63 %d\n", halves[0], halves[1],
+               [&] { int s = 0; for (int i = 0; i < 16; i++) s += lanes[i]; return s; }(), [&] { int s = 0; for (int i = 16; i < 32; i++) s += lanes[i]; return s; }(),
+               [&] { int s = 0; for (int i = 32; i < 48; i++) s += lanes[i]; return s; }(), [&] { int s = 0; for (int i = 48; i < 64; i++) s += lanes[i]; return s; }());
+        for (unsigned k = 0; k < n && k < 8; k++)
+            printf("  iteration %u lane %u %s half: packed %08x scalar %08x\n", h[k].it, h[k].lane_half >> 1, (h[k].lane_half & 1) ? "high" : "low", h[k].packed_bits, h[k].scalar_bits);
+    }
+    return 0;
+}
