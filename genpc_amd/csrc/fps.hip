@@ -288,8 +288,9 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
                     // of 55, a point held in the LOW half of a pair (register 0) by lanes 48-63 of a worker wave whose running
                     // minimum had missed one pivot.  Neither the way the pivot arrives (LDS broadcast, tagged granules, scalar
                     // registers) nor eight wait states around every DPP step changed the rate; with one register at a time (the
-                    // opaque statements below keep the compiler from pairing) it is 0 of 900 scans.  Why a packed fp32 instruction
-                    // loses its low half in the last sixteen lanes next to another wave's matrix instructions is not known to us.
+                    // opaque statements below keep the compiler from pairing) it is 0 of 3000 scans.  The instructions alone are not
+                    // it: tools/pk_probe.hip (packed against scalar copies of the same minima, beside a bare MFMA loop) ran 1.4e11
+                    // wave-iterations without a mismatch.  What else of this loop it takes is not known to us.
                     if (jobs.legacy_pivot) {           // the pre-fix form (test hook): registers r, r + 1 as two-element vectors -> v_pk_*_f32
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
                         static_assert(R % 2 == 0, "pairs of registers");
