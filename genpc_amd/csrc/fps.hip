@@ -201,7 +201,7 @@ __device__ __forceinline__ int wave_argbest(float v, int idx, float &m)
 }
 
 template <int FMA, int R>
-__global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slots, int *__restrict__ err)
+__global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops"))) void fps_kernel(FpsJobs jobs, FpsSlot *slots, int *__restrict__ err)
 {
     __shared__ float s_c[kFWaves][kFT][5];     // per worker wave: dist, idx (bits), x, y, z of its kFT best
     __shared__ float s_piv[kFBatch][4];        // the round's pivots: x, y, z, idx (bits)
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
                     // probe of broadcast reads + packed adds under the same load, tools/lds_probe.hip, shows nothing); with the
                     // value in SGPRs nine of nine stress runs are clean.  tests/test_gpu_concurrency.py keeps watch.
                     float cx, cy, cz;
-                    if (jobs.legacy_pivot) {       // the pre-fix form, kept reachable so that the trigger stays reproducible
+                    if (jobs.legacy_pivot & 1) {   // the pre-fix form, kept reachable so that the trigger stays reproducible
                         cx = s_piv[applied][0]; cy = s_piv[applied][1]; cz = s_piv[applied][2];
                     } else {
                         const unsigned want = (round & 0x3ffffffu) * 64u + applied + 1u;
@@ -291,7 +291,11 @@ __global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slo
                     // opaque statements below keep the compiler from pairing) it is 0 of 3000 scans.  The instructions alone are not
                     // it: tools/pk_probe.hip (packed against scalar copies of the same minima, beside a bare MFMA loop) ran 1.4e11
                     // wave-iterations without a mismatch.  What else of this loop it takes is not known to us.
-                    if (jobs.legacy_pivot) {           // the pre-fix form (test hook): registers r, r + 1 as two-element vectors -> v_pk_*_f32
+                    if (jobs.legacy_pivot & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                    if (jobs.legacy_pivot & 8) {
+                        asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\ts_nop 4" : "+v"(cx), "+v"(cy), "+v"(cz));
+                    }
+                    if (jobs.legacy_pivot & 2) {       // the pre-fix form (test hook): registers r, r + 1 as two-element vectors -> v_pk_*_f32
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
                         static_assert(R % 2 == 0, "pairs of registers");
 #pragma unroll
@@ -669,7 +673,9 @@ thread_local int t_fps_legacy = 0;
 GENPC_API int genpc_fps_tune(int legacy_pivot)
 {
     const int prev = genpc::t_fps_legacy;
-    genpc::t_fps_legacy = legacy_pivot ? 1 : 0;
+    // bits (for bisecting the trigger, tools/fps_reject_probe.py): 1 pivots read as per-lane LDS broadcasts, 2 packed update,
+    // 4 sixteen wait states in front of the update, 8 the update's operands copied through fresh VGPRs first; 1 alone = 3, the pre-fix form
+    genpc::t_fps_legacy = legacy_pivot == 1 ? 3 : (legacy_pivot & 15);
     return prev;
 }
 

@@ -9,6 +9,7 @@ from genpc_amd.DepthPrompting import DepthPrompting
 
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+hook = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # genpc_fps_tune bits: the lanes inherit the caller's setting
 seen, lock = [], threading.Lock()
 orig = F._fps_multi_direct
 
@@ -49,9 +50,10 @@ for k in range(6):
     gen_np = ((gt - cc) / (gt.max(0) - gt.min(0)).max()).astype(np.float32)
     jobs.append((torch.from_numpy(z13["partial"][k][:8192].copy()).cuda(), torch.from_numpy(gen_np).cuda(), img, torch.from_numpy(gt.copy()).cuda()))
 dps = [DepthPrompting(cfg) for _ in range(lanes)]
+F._lib.lib.genpc_fps_tune(hook)
 pipeline.complete_scans([jobs[i % 6] for i in range(count)], lanes=lanes, cfg=cfg, dps=dps)
 torch.cuda.synchronize()
-print("%d scans, %d lanes: %d sequences rejected" % (count, lanes, len(seen)))
+print("hook %d: %d scans, %d lanes: %d sequences rejected" % (hook, count, lanes, len(seen)))
 same = 0
 for f, n, k, bad, good in seen:
     bad = bad.copy(); bad[0] = 0

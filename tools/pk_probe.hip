@@ -5,8 +5,8 @@
 // probe kernel: every lane keeps two "points" and their running minima twice -- once updated with two-element vector
 // arithmetic (packed instructions), once with scalar instructions behind opaque statements -- against a stream of pivots
 // taken from scalar registers, as the sampling's workers do; after every pivot the two copies are compared bit for bit and a
-// mismatch is recorded (iteration, lane, half, both values).  mode 1: the wave sleeps between pivots (s_sleep), like a worker
-// polling its progress word.
+// mismatch is recorded (iteration, lane, half, both values).  mode N > 0: the wave sleeps N x 64 clocks between pivots (s_sleep), like a
+// worker waiting for its coordinator.
 // burner kernel: v_mfma_f32_32x32x16_f16 in a loop.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/pk_probe.hip -o /tmp/pk_probe && /tmp/pk_probe [seconds] [mode]
 #include <hip/hip_runtime.h>
@@ -19,8 +19,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct Hit { unsigned it, lane_half, packed_bits, scalar_bits; };
 
-__global__ __launch_bounds__(256) void probe_kernel(int iters, int mode, unsigned *nhit, Hit *hits, unsigned long long *done)
+__global__ __launch_bounds__(256) void probe_kernel(int iters, int mode_, unsigned *nhit, Hit *hits, unsigned long long *done)
 {
+    int mode = mode_;
     const unsigned t = blockIdx.x * 256 + threadIdx.x;
     unsigned s = t * 2654435761u + 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) * (1.0f / 16777216.0f); };
@@ -28,13 +29,30 @@ __global__ __launch_bounds__(256) void probe_kernel(int iters, int mode, unsigne
     f32x2 dp = {1e30f, 1e30f};
     float d0 = 1e30f, d1 = 1e30f;
     unsigned u = blockIdx.x * 747796405u + 2891336453u;      // (wave-uniform pivot stream)
+    // lds != 0: the pivots come out of LDS as per-lane broadcast reads into the registers the arithmetic consumes at once (the
+    // sampling's pre-fix form), a fresh read per iteration into the same registers
+    __shared__ float s_piv[64][4];
+    if (threadIdx.x < 64) { s_piv[threadIdx.x][0] = rnd(); s_piv[threadIdx.x][1] = rnd(); s_piv[threadIdx.x][2] = rnd(); s_piv[threadIdx.x][3] = 0.0f; }
+    __syncthreads();
+    const int lds = mode >> 8;
+    mode &= 255;
     for (int it = 0; it < iters; it++) {
         u = u * 1664525u + 1013904223u;
         const unsigned u1 = u * 22695477u + 1u, u2 = u1 * 22695477u + 1u;
-        const float cx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(u >> 8) * (1.0f / 16777216.0f))));
-        const float cy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(u1 >> 8) * (1.0f / 16777216.0f))));
-        const float cz = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(u2 >> 8) * (1.0f / 16777216.0f))));
-        if (mode & 1) __builtin_amdgcn_s_sleep(1);
+        float cx, cy, cz;
+        if (lds) {
+            const volatile float *pv = &s_piv[(it + (int)blockIdx.x) & 63][0];
+            cx = pv[0]; cy = pv[1]; cz = pv[2];
+        } else {
+            cx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(u >> 8) * (1.0f / 16777216.0f))));
+            cy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(u1 >> 8) * (1.0f / 16777216.0f))));
+            cz = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(u2 >> 8) * (1.0f / 16777216.0f))));
+        }
+        // the wave idles between pivots like a worker waiting for its coordinator: mode = 64-clock units (1, 8, 32 or 127)
+        if (mode == 1) __builtin_amdgcn_s_sleep(1);
+        else if (mode == 8) __builtin_amdgcn_s_sleep(8);
+        else if (mode == 32) __builtin_amdgcn_s_sleep(32);
+        else if (mode == 127) __builtin_amdgcn_s_sleep(127);
         // packed
         const f32x2 dx = px - cx, dy = py - cy, dz = pz - cz;
         const f32x2 dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
@@ -88,7 +106,7 @@ int main(int argc, char **argv)
     int launches = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         // one probe wave and one burner block per SIMD pair: 512 probe blocks of four waves beside 512 burner blocks of eight
-        hipLaunchKernelGGL(probe_kernel, dim3(512), dim3(256), 0, sa, 200000, mode, nhit, hits, done);
+        hipLaunchKernelGGL(probe_kernel, dim3(512), dim3(256), 0, sa, (mode & 255) >= 32 ? 4000 : ((mode & 255) >= 8 ? 20000 : 200000), mode, nhit, hits, done);
         if (burn) for (int q = 0; q < 8; q++) hipLaunchKernelGGL(burn_kernel, dim3(512), dim3(512), 0, sb, 20000, out);
         hipStreamSynchronize(sa);
         launches++;
