@@ -97,6 +97,7 @@ int main(int argc, char **argv)
     const double seconds = argc > 1 ? atof(argv[1]) : 10.0;
     const int mode = argc > 2 ? atoi(argv[2]) : 0;
     const int burn = argc > 3 ? atoi(argv[3]) : 1;
+    const int pblocks = argc > 4 ? atoi(argv[4]) : 512;      // 256: ONE probe wave per SIMD (a worker of the sampling has its SIMD to itself)
     hipStream_t sa, sb;
     hipStreamCreate(&sa); hipStreamCreate(&sb);
     unsigned *nhit; Hit *hits; unsigned long long *done; float *out;
@@ -106,7 +107,7 @@ int main(int argc, char **argv)
     int launches = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         // one probe wave and one burner block per SIMD pair: 512 probe blocks of four waves beside 512 burner blocks of eight
-        hipLaunchKernelGGL(probe_kernel, dim3(512), dim3(256), 0, sa, (mode & 255) >= 32 ? 4000 : ((mode & 255) >= 8 ? 20000 : 200000), mode, nhit, hits, done);
+        hipLaunchKernelGGL(probe_kernel, dim3(pblocks), dim3(256), 0, sa, (mode & 255) >= 32 ? 4000 : ((mode & 255) >= 8 ? 20000 : 200000), mode, nhit, hits, done);
         if (burn) for (int q = 0; q < 8; q++) hipLaunchKernelGGL(burn_kernel, dim3(512), dim3(512), 0, sb, 20000, out);
         hipStreamSynchronize(sa);
         launches++;
@@ -116,8 +117,8 @@ int main(int argc, char **argv)
     hipMemcpy(&n, nhit, 4, hipMemcpyDeviceToHost); hipMemcpy(&d, done, 8, hipMemcpyDeviceToHost);
     Hit *h = (Hit *)malloc(sizeof(Hit) * 4096);
     hipMemcpy(h, hits, sizeof(Hit) * 4096, hipMemcpyDeviceToHost);
-    printf("mode %d, burner %s: %d launches, %.3g wave-iterations (8 packed instructions each), %u mismatches between the packed and the scalar copy\n",
-           mode, burn ? "on" : "off", launches, (double)d * 4.0, n);
+    printf("%d probe blocks, mode %d, burner %s: %d launches, %.3g wave-iterations (8 packed instructions each), %u mismatches between the packed and the scalar copy\n",
+           pblocks, mode, burn ? "on" : "off", launches, (double)d * 4.0, n);
     int lanes[64] = {0}, halves[2] = {0, 0};
     for (unsigned k = 0; k < n && k < 4096; k++) { lanes[(h[k].lane_half >> 1) & 63]++; halves[h[k].lane_half & 1]++; }
     if (n) {
