@@ -304,8 +304,18 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
                             f32x2 dd;
                             if (FMA) dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
                             else dd = (dx * dx + dy * dy) + dz * dz;
-                            d[r] = d[r] < dd.x ? d[r] : dd.x;
-                            d[r + 1] = d[r + 1] < dd.y ? d[r + 1] : dd.y;
+                            if (jobs.legacy_pivot & 16) {      // (bisect: the two results leave the pair through separate 32-bit registers)
+                                float e0 = dd.x, e1 = dd.y;
+                                asm volatile("" : "+v"(e0));
+                                asm volatile("" : "+v"(e1));
+                                d[r] = d[r] < e0 ? d[r] : e0;
+                                d[r + 1] = d[r + 1] < e1 ? d[r + 1] : e1;
+                                asm volatile("" : "+v"(d[r]));
+                                asm volatile("" : "+v"(d[r + 1]));
+                            } else {
+                                d[r] = d[r] < dd.x ? d[r] : dd.x;
+                                d[r + 1] = d[r + 1] < dd.y ? d[r + 1] : dd.y;
+                            }
                         }
                     } else {
 #pragma unroll
@@ -674,8 +684,9 @@ GENPC_API int genpc_fps_tune(int legacy_pivot)
 {
     const int prev = genpc::t_fps_legacy;
     // bits (for bisecting the trigger, tools/fps_reject_probe.py): 1 pivots read as per-lane LDS broadcasts, 2 packed update,
-    // 4 sixteen wait states in front of the update, 8 the update's operands copied through fresh VGPRs first; 1 alone = 3, the pre-fix form
-    genpc::t_fps_legacy = legacy_pivot == 1 ? 3 : (legacy_pivot & 15);
+    // 4 sixteen wait states in front of the update, 8 the update's operands copied through fresh VGPRs first, 16 the packed results
+    // leave their pair through separate 32-bit registers; 1 alone = 3, the pre-fix form
+    genpc::t_fps_legacy = legacy_pivot == 1 ? 3 : (legacy_pivot & 31);
     return prev;
 }
 

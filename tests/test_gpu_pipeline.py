@@ -184,7 +184,7 @@ def test_lanes_inherit_the_callers_thread_modes(env):
     finally:
         L.genpc_set_arith_thread(prev_a); L.genpc_emd_tune(prev_e, -1); L.genpc_pose_tune(prev_p); L.genpc_fps_tune(prev_f)
         _lib.apply_thread_state((tuple(_lib.thread_state()[0][:1]) + (-1,) + tuple(_lib.thread_state()[0][2:]), torch.is_grad_enabled()))
-    assert all(g == (0, 1, 1, 0, 1, False) for g in got), got
+    assert all(g == (0, 1, 1, 0, 3, False) for g in got), got          # (genpc_fps_tune(1) = bits 1 | 2: the pre-fix form)
     assert all(b[0] == L.genpc_get_arith() and b[5] for b in base), base
     # and a lane's strict-mode sampling is the caller's strict-mode sampling
     x = torch.rand(1, 5000, 3, device=dev)
