@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GENPC_LIB: an alternative build of the same library (kernel experiments only)
 LIB_PATH = os.environ.get("GENPC_LIB") or os.path.join(_HERE, "lib", "libgenpc_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

@@ -142,7 +142,7 @@ void *workspace(int slot, size_t bytes, hipStream_t stream, bool *fresh, size_t 
 
 }  // namespace genpc
 
-GENPC_API int genpc_abi_version(void) { return 15; }
+GENPC_API int genpc_abi_version(void) { return 16; }
 
 GENPC_API const char *genpc_last_error(void)
 {

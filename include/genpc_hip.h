@@ -33,7 +33,9 @@ extern "C" {
 #define GENPC_ARITH_FMA 1
 
 /* Library / device ------------------------------------------------------- */
-int genpc_abi_version(void);              /* bumps when a signature changes */
+int genpc_abi_version(void);              /* bumps when a signature or a documented behaviour changes (16: genpc_hpr_* asynchronous,
+                                           * counts -1 on an internal error; genpc_fps*: out_idx[0] -2 = failed the check;
+                                           * genpc_fps_tune takes bits) */
 const char *genpc_last_error(void);       /* last HIP error string, "" if none */
 int genpc_set_arith(int mode);            /* process default; returns the previous one */
 int genpc_set_arith_thread(int mode);     /* calling thread only, < 0: follow the default; returns the previous override */
@@ -417,7 +419,9 @@ int genpc_fps_multi(int c, const int *n, const int *k, const float *const *xyz,
 /* Test hook (calling host thread; returns the previous setting): 1 = the pre-fix form of the sampling's workers -- pivots read
  * as per-lane LDS broadcasts and running minima lowered with PACKED fp32 instructions on register pairs, which is what drew
  * wrong samples next to other streams' matrix instructions (csrc/fps.hip; kept reachable so that
- * tests/test_gpu_concurrency.py can show the trigger); 0 = one register at a time (shipped). */
+ * tests/test_gpu_concurrency.py can show the trigger); 0 = one register at a time (shipped).  Bits, for bisecting the
+ * trigger (tools/fps_reject_probe.py): 1 per-lane LDS pivot reads, 2 packed update, 4 sixteen wait states in front of it,
+ * 8 its operands copied through fresh registers, 16 its results leave their pair through 32-bit registers; 1 alone means 3. */
 int genpc_fps_tune(int legacy_pivot);
 /* Diagnostics: rounds[j] (host, c <= 32) = inter-workgroup exchanges cloud j of the last
  * genpc_fps_multi call on this stream took (one exchange yields several samples).  Synchronises.  */
