@@ -282,15 +282,18 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
                         cy = __uint_as_float(__builtin_amdgcn_readfirstlane(g1.x));
                         cz = __uint_as_float(__builtin_amdgcn_readfirstlane(g2.x));
                     }
-                    // THE CAUSE of the wrong samples (round 5, tools/fps_reject_probe.py; six scans in flight): written plainly, the
-                    // compiler pairs registers r, r + 1 into PACKED fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32),
-                    // and beside other streams' kernels 8 % of the samplings then failed the device-side check -- every wrong sample, 55
-                    // of 55, a point held in the LOW half of a pair (register 0) by lanes 48-63 of a worker wave whose running
-                    // minimum had missed one pivot.  Neither the way the pivot arrives (LDS broadcast, tagged granules, scalar
-                    // registers) nor eight wait states around every DPP step changed the rate; with one register at a time (the
-                    // opaque statements below keep the compiler from pairing) it is 0 of 3000 scans.  The instructions alone are not
-                    // it: tools/pk_probe.hip (packed against scalar copies of the same minima, beside a bare MFMA loop) ran 1.4e11
-                    // wave-iterations without a mismatch.  What else of this loop it takes is not known to us.
+                    // What the wrong samples were (round 5, tools/fps_reject_probe.py; six scans in flight): written plainly, the compiler
+                    // pairs registers r, r + 1 into PACKED fp32 instructions whose subtracts take ONE half of a source pair for both
+                    // lanes (v_pk_add_f32 ... op_sel_hi:[1,0] / op_sel:[0,1]), and beside other streams' kernels 8 % of the samplings
+                    // then failed the device-side check -- every first wrong sample, 55 of 55, a point held in the LOW lane of a pair
+                    // (register 0) by lanes 48-63 of a worker wave whose running minimum had missed one pivot.  The bits of
+                    // genpc_fps_tune select the variants of the bisection (DESIGN.md 6a has the table): the packed form WITH half
+                    // selection fails beside the f16 filter however the pivot arrives and however many wait states surround it (written
+                    // out, bits 2 | 32 | 128: every sampling), the same packed arithmetic on {c, c} pairs WITHOUT half selection never
+                    // (bits 2 | 32), and neither does anything alone on the GPU.  The instruction forms in isolation beside a bare
+                    // MFMA loop (tools/opsel_probe.hip, pk_probe.hip, war_probe.hip) are clean: what else it takes is not known to us.
+                    // Shipped: one register at a time (the opaque statements keep the compiler from pairing), and the whole
+                    // library is built without packed fp32 instructions (genpc_amd/build.py).
                     if (jobs.legacy_pivot & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
                     if (jobs.legacy_pivot & 8) {
                         asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\ts_nop 4" : "+v"(cx), "+v"(cy), "+v"(cz));
@@ -302,7 +305,46 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
                         for (int r = 0; r < R; r += 2) {
                             const f32x2 dx = (f32x2){px[r], px[r + 1]} - cx, dy = (f32x2){py[r], py[r + 1]} - cy, dz = (f32x2){pz[r], pz[r + 1]} - cz;
                             f32x2 dd;
-                            if (FMA) dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+                            if (FMA && (jobs.legacy_pivot & 32)) {
+                                // (bisect: the same six packed instructions written out, four wait states behind each)
+                                const f32x2 pxx = {px[r], px[r + 1]}, pyy = {py[r], py[r + 1]}, pzz = {pz[r], pz[r + 1]};
+                                const f32x2 cxx = {cx, cx}, cyy = {cy, cy}, czz = {cz, cz};
+                                f32x2 ex, ey, ez;
+                                if (jobs.legacy_pivot & 128) {    // (... and with the operand forms the compiler chose where it failed: the pivot
+                                    // as pairs (x, y) and (y, z), a packed subtract taking ONE half of a pair for both of its lanes --
+                                    // op_sel_hi:[1,0] / op_sel:[0,1] --, four wait states behind each instruction)
+                                    const f32x2 cxy = {cx, cy}, cyz = {cy, cz};
+                                    asm volatile("s_nop 3\n\t"
+                                                 "v_pk_add_f32 %0, %4, %7 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3\n\t"
+                                                 "v_pk_add_f32 %1, %5, %8 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3\n\t"
+                                                 "v_pk_add_f32 %2, %6, %8 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3\n\t"
+                                                 "v_pk_mul_f32 %3, %1, %1\n\ts_nop 3\n\t"
+                                                 "v_pk_fma_f32 %3, %0, %0, %3\n\ts_nop 3\n\t"
+                                                 "v_pk_fma_f32 %3, %2, %2, %3\n\ts_nop 3"
+                                                 : "=&v"(ex), "=&v"(ey), "=&v"(ez), "=&v"(dd)
+                                                 : "v"(pxx), "v"(pyy), "v"(pzz), "v"(cxy), "v"(cyz));
+                                } else
+                                if (jobs.legacy_pivot & 64)       // (... and with ONE wait state behind each, what the compiler leaves between dependent ones)
+                                asm volatile("s_nop 0\n\t"
+                                             "v_pk_add_f32 %0, %4, %7 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n\t"
+                                             "v_pk_add_f32 %1, %5, %8 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n\t"
+                                             "v_pk_add_f32 %2, %6, %9 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n\t"
+                                             "v_pk_mul_f32 %3, %1, %1\n\ts_nop 0\n\t"
+                                             "v_pk_fma_f32 %3, %0, %0, %3\n\ts_nop 0\n\t"
+                                             "v_pk_fma_f32 %3, %2, %2, %3\n\ts_nop 0"
+                                             : "=&v"(ex), "=&v"(ey), "=&v"(ez), "=&v"(dd)
+                                             : "v"(pxx), "v"(pyy), "v"(pzz), "v"(cxx), "v"(cyy), "v"(czz));
+                                else
+                                asm volatile("s_nop 3\n\t"
+                                             "v_pk_add_f32 %0, %4, %7 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3\n\t"
+                                             "v_pk_add_f32 %1, %5, %8 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3\n\t"
+                                             "v_pk_add_f32 %2, %6, %9 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3\n\t"
+                                             "v_pk_mul_f32 %3, %1, %1\n\ts_nop 3\n\t"
+                                             "v_pk_fma_f32 %3, %0, %0, %3\n\ts_nop 3\n\t"
+                                             "v_pk_fma_f32 %3, %2, %2, %3\n\ts_nop 3"
+                                             : "=&v"(ex), "=&v"(ey), "=&v"(ez), "=&v"(dd)
+                                             : "v"(pxx), "v"(pyy), "v"(pzz), "v"(cxx), "v"(cyy), "v"(czz));
+                            } else if (FMA) dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
                             else dd = (dx * dx + dy * dy) + dz * dz;
                             if (jobs.legacy_pivot & 16) {      // (bisect: the two results leave the pair through separate 32-bit registers)
                                 float e0 = dd.x, e1 = dd.y;
@@ -685,8 +727,9 @@ GENPC_API int genpc_fps_tune(int legacy_pivot)
     const int prev = genpc::t_fps_legacy;
     // bits (for bisecting the trigger, tools/fps_reject_probe.py): 1 pivots read as per-lane LDS broadcasts, 2 packed update,
     // 4 sixteen wait states in front of the update, 8 the update's operands copied through fresh VGPRs first, 16 the packed results
-    // leave their pair through separate 32-bit registers; 1 alone = 3, the pre-fix form
-    genpc::t_fps_legacy = legacy_pivot == 1 ? 3 : (legacy_pivot & 31);
+    // leave their pair through separate 32-bit registers, 32 (with 2) the packed instructions written out with four wait states behind
+    // each; 1 alone = 3, the pre-fix form
+    genpc::t_fps_legacy = legacy_pivot == 1 ? 3 : (legacy_pivot & 255);
     return prev;
 }
 

@@ -421,7 +421,9 @@ int genpc_fps_multi(int c, const int *n, const int *k, const float *const *xyz,
  * wrong samples next to other streams' matrix instructions (csrc/fps.hip; kept reachable so that
  * tests/test_gpu_concurrency.py can show the trigger); 0 = one register at a time (shipped).  Bits, for bisecting the
  * trigger (tools/fps_reject_probe.py): 1 per-lane LDS pivot reads, 2 packed update, 4 sixteen wait states in front of it,
- * 8 its operands copied through fresh registers, 16 its results leave their pair through 32-bit registers; 1 alone means 3. */
+ * 8 its operands copied through fresh registers, 16 its results leave their pair through 32-bit registers, 32 (with 2) the
+ * six packed instructions written out on {c, c} pairs, four wait states behind each (64: one), 128 (with 2 | 32) written out
+ * with half selection (op_sel) on (x, y) / (y, z) pairs -- the form that fails beside other streams' kernels; 1 alone means 3. */
 int genpc_fps_tune(int legacy_pivot);
 /* Diagnostics: rounds[j] (host, c <= 32) = inter-workgroup exchanges cloud j of the last
  * genpc_fps_multi call on this stream took (one exchange yields several samples).  Synchronises.  */

@@ -134,18 +134,79 @@ def test_sampling_next_to_the_f16_filter():
     assert F.stats["failed_check"] + F.stats["timed_out"] == before, F.stats
 
 
-def test_the_pre_fix_form_still_shows_the_trigger():
-    """The failure kept reproducible.  genpc_fps_tune(1), per calling thread, restores what round 5 found to
-    be the cause: the workers lower their running minima with PACKED fp32 instructions (v_pk_add_f32 / v_pk_fma_f32 on register
-    pairs) -- next to the f16 filter on other streams a point in the low half of a pair, held by lanes 48-63, then misses a
-    pivot now and then (csrc/fps.hip).  The device-side check rejects those sequences and they are drawn again, so the RESULTS
-    stay right; the count of rejected sequences shows the trigger.  If none is rejected on this box, say so."""
-    from genpc_amd import fps as F
-    before = F.stats["failed_check"]
-    bad = _run(["fps_legacy", "chamfer", "fps_legacy", "chamfer"], reps=24)
-    assert bad == [], bad          # (the check and the retry keep every result right)
-    if F.stats["failed_check"] == before:
-        pytest.skip("the packed update did not misbehave on this box / build: trigger not reproduced")
+def test_the_failing_form_still_shows_the_trigger():
+    """The failure kept reproducible.  genpc_fps_tune bits 2 | 32 | 128 (per calling thread) make the workers
+    lower their running minima with PACKED fp32 instructions whose subtracts take ONE half of a source pair for both lanes
+    (op_sel / op_sel_hi) -- the form the compiler had chosen where samplings went wrong beside other streams' kernels
+    (csrc/fps.hip; alone it gives the right sequence, which is asserted first).  The raw entry point is called
+    so that rejected sequences are COUNTED instead of drawn again.  If none is rejected on this box, say so."""
+    import ctypes
+    import threading
+    import torch
+    from genpc_amd import _lib, chamfer_3D
+    z = np.load(os.path.join(HERE, "golden", "scans13_fps16384.npz"))
+    L = _lib.lib
+
+    def raw_fps(X, k):
+        out = torch.empty(k, device="cuda", dtype=torch.int32)
+        n_arr = (ctypes.c_int * 1)(X.shape[0]); k_arr = (ctypes.c_int * 1)(k)
+        x_arr = (ctypes.c_void_p * 1)(X.data_ptr()); o_arr = (ctypes.c_void_p * 1)(out.data_ptr())
+        assert _lib.on_device_of(X, L.genpc_fps_multi, 1, ctypes.addressof(n_arr), ctypes.addressof(k_arr), ctypes.addressof(x_arr), ctypes.addressof(o_arr)) == 1
+        return out
+
+    X0 = torch.from_numpy(np.concatenate([z["partial"][0], z["gt"][0][:4422]])).cuda().contiguous()
+    want = raw_fps(X0, 20000).cpu().numpy()
+    prev = L.genpc_fps_tune(2 | 32 | 128)
+    try:
+        alone = raw_fps(X0, 20000).cpu().numpy()
+    finally:
+        L.genpc_fps_tune(prev)
+    np.testing.assert_array_equal(alone, want)              # alone, the form is right
+    rejected, errs, stop = [0], [], threading.Event()
+
+    def sampler(k):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                X = torch.from_numpy(np.concatenate([z["partial"][k], z["gt"][k][:4422]])).cuda().contiguous()
+                ref = raw_fps(X, 20000).cpu().numpy()
+                p = L.genpc_fps_tune(2 | 32 | 128)
+                try:
+                    for _ in range(16):
+                        got = raw_fps(X, 20000).cpu().numpy()
+                        if got[0] != 0:
+                            rejected[0] += 1
+                        else:
+                            np.testing.assert_array_equal(got, ref)      # whatever passes the check is the right sequence
+                finally:
+                    L.genpc_fps_tune(p)
+        except BaseException as e:
+            errs.append(e)
+
+    def filt(k):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                P = torch.from_numpy(z["partial"][k].copy()).cuda()[None].contiguous(); G = torch.from_numpy(z["gt"][k].copy()).cuda()[None].contiguous()
+                d1 = torch.empty(1, 16384, device="cuda"); d2 = torch.empty_like(d1)
+                i1 = torch.empty(1, 16384, device="cuda", dtype=torch.int32); i2 = torch.empty_like(i1)
+                while not stop.is_set():
+                    for _ in range(50):
+                        chamfer_3D.forward(P, G, d1, d2, i1, i2)
+                    torch.cuda.current_stream().synchronize()
+        except BaseException as e:
+            errs.append(e)
+
+    fs = [threading.Thread(target=filt, args=(k,)) for k in (2, 3)]
+    ss = [threading.Thread(target=sampler, args=(k,)) for k in (0, 1)]
+    for t in fs + ss:
+        t.start()
+    for t in ss:
+        t.join()
+    stop.set()
+    for t in fs:
+        t.join()
+    assert not errs, errs
+    if rejected[0] == 0:
+        pytest.skip("the op_sel form did not misbehave on this box / build: trigger not reproduced")
 
 
 def test_sampling_metric_and_chamfer_together():

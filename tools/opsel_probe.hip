@@ -1,0 +1,93 @@
+// tools/opsel_probe.hip -- the form that fails inside the farthest-point sampling (csrc/fps.hip), in isolation: a packed
+// fp32 instruction whose LOW lane takes the HIGH half of a source pair (op_sel:[0,1]) or whose HIGH lane takes the LOW half
+// (op_sel_hi:[1,0]), on known data, beside another stream's v_mfma_f32_32x32x16_f16 loop.
+//   hipcc --offload-arch=gfx950 -O3 tools/opsel_probe.hip -o /tmp/opsel_probe && /tmp/opsel_probe [seconds] [kind 0|1|2] [burner] [probe blocks] [sleep]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <chrono>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct Hit { unsigned it, lane, got_lo, got_hi; };
+
+template <int KIND, int SLEEP>
+__global__ __launch_bounds__(256) void opsel_kernel(int iters, unsigned *nhit, Hit *hits, unsigned long long *done)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    for (int it = 0; it < iters; it++) {
+        const float A = (float)(it & 1023) + 0.25f, B = (float)(it & 1023) + 4096.5f + (float)lane;
+        f32x2 pair = {A, B};
+        const f32x2 p = {1.0f + (float)lane, 2.0f + (float)lane};
+        f32x2 r;
+        if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
+        // three in a row like the sampling's subtracts; the last one's result is checked
+        if (KIND == 0)        // low lane takes the high half: both lanes p - B
+            asm volatile("s_nop 3\n\tv_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3" : "=&v"(r) : "v"(p), "v"(pair));
+        else if (KIND == 1)   // high lane takes the low half: both lanes p - A
+            asm volatile("s_nop 3\n\tv_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3" : "=&v"(r) : "v"(p), "v"(pair));
+        else                  // plain pair
+            asm volatile("s_nop 3\n\tv_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3" : "=&v"(r) : "v"(p), "v"(pair));
+        const float w0 = p.x - (KIND == 0 ? B : A), w1 = p.y - (KIND == 1 ? A : B);
+        if (__float_as_uint(r.x) != __float_as_uint(w0) || __float_as_uint(r.y) != __float_as_uint(w1)) {
+            const unsigned k = atomicAdd(nhit, 1u);
+            if (k < 4096) hits[k] = Hit{(unsigned)it, lane | (__float_as_uint(r.x) != __float_as_uint(w0) ? 64u : 0u) | (__float_as_uint(r.y) != __float_as_uint(w1) ? 128u : 0u),
+                                        __float_as_uint(r.x), __float_as_uint(r.y)};
+        }
+    }
+    if (threadIdx.x == 0) atomicAdd(done, (unsigned long long)iters);
+}
+
+__global__ __launch_bounds__(512) void burn_kernel(int iters, float *out)
+{
+    f32x16 acc = {0};
+    uint4 a = make_uint4(threadIdx.x, threadIdx.x * 3, threadIdx.x * 5, 0x3c003c00u);
+    for (int it = 0; it < iters; it++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, a), acc, 0, 0, 0);
+        a.x += 1;
+    }
+    float s = 0; for (int e = 0; e < 16; e++) s += acc[e];
+    if (s == 12345.678f) out[0] = s;
+}
+
+template <int KIND> static void launch(int sleep, int pblocks, hipStream_t st, unsigned *nhit, Hit *hits, unsigned long long *done)
+{
+    if (sleep) hipLaunchKernelGGL((opsel_kernel<KIND, 8>), dim3(pblocks), dim3(256), 0, st, 40000, nhit, hits, done);
+    else hipLaunchKernelGGL((opsel_kernel<KIND, 0>), dim3(pblocks), dim3(256), 0, st, 400000, nhit, hits, done);
+}
+
+int main(int argc, char **argv)
+{
+    const double seconds = argc > 1 ? atof(argv[1]) : 10.0;
+    const int kind = argc > 2 ? atoi(argv[2]) : 0;
+    const int burn = argc > 3 ? atoi(argv[3]) : 1;
+    const int pblocks = argc > 4 ? atoi(argv[4]) : 256;
+    const int sleep = argc > 5 ? atoi(argv[5]) : 0;
+    hipStream_t sa, sb;
+    (void)hipStreamCreate(&sa); (void)hipStreamCreate(&sb);
+    unsigned *nhit; Hit *hits; unsigned long long *done; float *out;
+    (void)hipMalloc(&nhit, 8); (void)hipMalloc(&hits, sizeof(Hit) * 4096); (void)hipMalloc(&done, 8); (void)hipMalloc(&out, 4);
+    (void)hipMemset(nhit, 0, 8); (void)hipMemset(done, 0, 8);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+        if (kind == 0) launch<0>(sleep, pblocks, sa, nhit, hits, done);
+        else if (kind == 1) launch<1>(sleep, pblocks, sa, nhit, hits, done);
+        else launch<2>(sleep, pblocks, sa, nhit, hits, done);
+        if (burn) for (int q = 0; q < 8; q++) hipLaunchKernelGGL(burn_kernel, dim3(512), dim3(512), 0, sb, 20000, out);
+        (void)hipStreamSynchronize(sa);
+    }
+    (void)hipDeviceSynchronize();
+    unsigned n = 0; unsigned long long d = 0;
+    (void)hipMemcpy(&n, nhit, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&d, done, 8, hipMemcpyDeviceToHost);
+    Hit *h = (Hit *)malloc(sizeof(Hit) * 4096);
+    (void)hipMemcpy(h, hits, sizeof(Hit) * 4096, hipMemcpyDeviceToHost);
+    const char *names[3] = {"op_sel:[0,1]", "op_sel_hi:[1,0]", "plain pair"};
+    printf("v_pk_add_f32 %s, %d probe blocks, sleep %d, burner %s: %.3g wave-iterations, %u wrong results\n", names[kind % 3], pblocks, sleep, burn ? "on" : "off", (double)d * 4.0, n);
+    int q[4] = {0, 0, 0, 0}, lo = 0, hi = 0;
+    for (unsigned k = 0; k < n && k < 4096; k++) { q[(h[k].lane & 63) >> 4]++; lo += (h[k].lane >> 6) & 1; hi += (h[k].lane >> 7) & 1; }
+    if (n) {
+        printf("  lanes 0-15: %d, 16-31: %d, 32-47: %d, 48-63: %d;  low result wrong: %d, high result wrong: %d\n", q[0], q[1], q[2], q[3], lo, hi);
+        for (unsigned k = 0; k < n && k < 6; k++) printf("  iteration %u lane %u: result = %08x %08x\n", h[k].it, h[k].lane & 63, h[k].got_lo, h[k].got_hi);
+    }
+    return 0;
+}

@@ -34,7 +34,10 @@ __global__ __launch_bounds__(256) void probe_kernel(int iters, int mode_, unsign
     __shared__ float s_piv[64][4];
     if (threadIdx.x < 64) { s_piv[threadIdx.x][0] = rnd(); s_piv[threadIdx.x][1] = rnd(); s_piv[threadIdx.x][2] = rnd(); s_piv[threadIdx.x][3] = 0.0f; }
     __syncthreads();
-    const int lds = mode >> 8;
+    __shared__ unsigned s_pair[64][2];
+    if (threadIdx.x < 64) { s_pair[threadIdx.x][0] = __float_as_uint(rnd()); s_pair[threadIdx.x][1] = 0x00000041u + threadIdx.x * 64u; }
+    __syncthreads();
+    const int lds = (mode >> 8) & 1, opsel = (mode >> 9) & 1;
     mode &= 255;
     for (int it = 0; it < iters; it++) {
         u = u * 1664525u + 1013904223u;
@@ -53,6 +56,25 @@ __global__ __launch_bounds__(256) void probe_kernel(int iters, int mode_, unsign
         else if (mode == 8) __builtin_amdgcn_s_sleep(8);
         else if (mode == 32) __builtin_amdgcn_s_sleep(32);
         else if (mode == 127) __builtin_amdgcn_s_sleep(127);
+        // opsel != 0: the sampling's failing form in isolation -- an 8-byte LDS read returns (value, unrelated word) into a register
+        // pair, and a packed subtract right behind the wait takes the LOW half for both of its lanes (op_sel_hi:[1,0])
+        if (opsel) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 pv;
+            f32x2 dxp;
+            const unsigned a2 = (unsigned)(size_t)&s_pair[(it + (int)blockIdx.x) & 63][0];
+            asm volatile("ds_read_b64 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_pk_add_f32 %1, %3, %0 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1"
+                         : "=&v"(pv), "=&v"(dxp) : "v"(a2), "v"(px) : "memory");
+            const float c = __uint_as_float(pv.x);
+            float r0 = px.x - c, r1 = px.y - c;
+            asm volatile("" : "+v"(r0), "+v"(r1));
+            if (__float_as_uint(dxp.x) != __float_as_uint(r0) || __float_as_uint(dxp.y) != __float_as_uint(r1)) {
+                const unsigned k = atomicAdd(nhit, 1u);
+                const bool b0 = __float_as_uint(dxp.x) != __float_as_uint(r0);
+                if (k < 4096) hits[k] = Hit{(unsigned)it, (threadIdx.x & 63u) * 2u + (b0 ? 0u : 1u), __float_as_uint(b0 ? dxp.x : dxp.y), __float_as_uint(b0 ? r0 : r1)};
+            }
+            continue;
+        }
         // packed
         const f32x2 dx = px - cx, dy = py - cy, dz = pz - cz;
         const f32x2 dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
