@@ -28,6 +28,7 @@
 // word and writes -1 to out[0]; genpc_amd/fps.py raises on it.
 #include "common.h"
 #include "../../include/genpc_hip.h"
+#include <type_traits>
 
 namespace genpc {
 
@@ -244,7 +245,11 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
                 pr = prog_load(&s_prog);
                 if ((pr >> 16) != (round & 0xffffu)) { __builtin_amdgcn_s_sleep(1); continue; }
                 const unsigned avail = pr & kProgCount;
-                for (; applied < avail; applied++) {
+                // (the bisection's variants -- genpc_fps_tune bits, a test hook -- are compiled into a second copy of the loop body: with
+                //  their tests inside the shipped loop a pick cost 0.55 us instead of 0.53)
+                auto apply_pivot = [&](auto hook_tag) {
+                    constexpr bool kHook = decltype(hook_tag)::value;
+                    const int hook_bits = kHook ? jobs.legacy_pivot : 0;
                     // The pivot travels through SCALAR registers (first lane's copy).  As plain per-lane reads of the one LDS
                     // address (ds_read_b96 into VGPRs, consumed by packed fp32 ops right behind the wait) the lanes 48-63 of a
                     // worker wave were seen to use the PREVIOUS pivot now and then while another stream's kernel issued
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
                     // probe of broadcast reads + packed adds under the same load, tools/lds_probe.hip, shows nothing); with the
                     // value in SGPRs nine of nine stress runs are clean.  tests/test_gpu_concurrency.py keeps watch.
                     float cx, cy, cz;
-                    if (jobs.legacy_pivot & 1) {   // the pre-fix form, kept reachable so that the trigger stays reproducible
+                    if (hook_bits & 1) {   // the pre-fix form, kept reachable so that the trigger stays reproducible
                         cx = s_piv[applied][0]; cy = s_piv[applied][1]; cz = s_piv[applied][2];
                     } else {
                         const unsigned want = (round & 0x3ffffffu) * 64u + applied + 1u;
@@ -294,23 +299,23 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
                     // MFMA loop (tools/opsel_probe.hip, pk_probe.hip, war_probe.hip) are clean: what else it takes is not known to us.
                     // Shipped: one register at a time (the opaque statements keep the compiler from pairing), and the whole
                     // library is built without packed fp32 instructions (genpc_amd/build.py).
-                    if (jobs.legacy_pivot & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-                    if (jobs.legacy_pivot & 8) {
+                    if (hook_bits & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                    if (hook_bits & 8) {
                         asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\ts_nop 4" : "+v"(cx), "+v"(cy), "+v"(cz));
                     }
-                    if (jobs.legacy_pivot & 2) {       // the pre-fix form (test hook): registers r, r + 1 as two-element vectors -> v_pk_*_f32
+                    if (hook_bits & 2) {       // the pre-fix form (test hook): registers r, r + 1 as two-element vectors -> v_pk_*_f32
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
                         static_assert(R % 2 == 0, "pairs of registers");
 #pragma unroll
                         for (int r = 0; r < R; r += 2) {
                             const f32x2 dx = (f32x2){px[r], px[r + 1]} - cx, dy = (f32x2){py[r], py[r + 1]} - cy, dz = (f32x2){pz[r], pz[r + 1]} - cz;
                             f32x2 dd;
-                            if (FMA && (jobs.legacy_pivot & 32)) {
+                            if (FMA && (hook_bits & 32)) {
                                 // (bisect: the same six packed instructions written out, four wait states behind each)
                                 const f32x2 pxx = {px[r], px[r + 1]}, pyy = {py[r], py[r + 1]}, pzz = {pz[r], pz[r + 1]};
                                 const f32x2 cxx = {cx, cx}, cyy = {cy, cy}, czz = {cz, cz};
                                 f32x2 ex, ey, ez;
-                                if (jobs.legacy_pivot & 128) {    // (... and with the operand forms the compiler chose where it failed: the pivot
+                                if (hook_bits & 128) {    // (... and with the operand forms the compiler chose where it failed: the pivot
                                     // as pairs (x, y) and (y, z), a packed subtract taking ONE half of a pair for both of its lanes --
                                     // op_sel_hi:[1,0] / op_sel:[0,1] --, four wait states behind each instruction)
                                     const f32x2 cxy = {cx, cy}, cyz = {cy, cz};
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
                                                  : "=&v"(ex), "=&v"(ey), "=&v"(ez), "=&v"(dd)
                                                  : "v"(pxx), "v"(pyy), "v"(pzz), "v"(cxy), "v"(cyz));
                                 } else
-                                if (jobs.legacy_pivot & 64)       // (... and with ONE wait state behind each, what the compiler leaves between dependent ones)
+                                if (hook_bits & 64)       // (... and with ONE wait state behind each, what the compiler leaves between dependent ones)
                                 asm volatile("s_nop 0\n\t"
                                              "v_pk_add_f32 %0, %4, %7 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n\t"
                                              "v_pk_add_f32 %1, %5, %8 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n\t"
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
                                              : "v"(pxx), "v"(pyy), "v"(pzz), "v"(cxx), "v"(cyy), "v"(czz));
                             } else if (FMA) dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
                             else dd = (dx * dx + dy * dy) + dz * dz;
-                            if (jobs.legacy_pivot & 16) {      // (bisect: the two results leave the pair through separate 32-bit registers)
+                            if (hook_bits & 16) {      // (bisect: the two results leave the pair through separate 32-bit registers)
                                 float e0 = dd.x, e1 = dd.y;
                                 asm volatile("" : "+v"(e0));
                                 asm volatile("" : "+v"(e1));
@@ -369,7 +374,9 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
                             d[r] = d[r] < dd ? d[r] : dd;       // padding slots stay at -1
                         }
                     }
-                }
+                                };
+                if (jobs.legacy_pivot != 0) for (; applied < avail; applied++) apply_pivot(std::true_type{});
+                else for (; applied < avail; applied++) apply_pivot(std::false_type{});
                 if (pr & kProgDone) break;
             }
             if (pr & (kProgFinal | kProgAbort)) break;
