@@ -295,8 +295,9 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
                     // genpc_fps_tune select the variants of the bisection (DESIGN.md 6a has the table): the packed form WITH half
                     // selection fails beside the f16 filter however the pivot arrives and however many wait states surround it (written
                     // out, bits 2 | 32 | 128: every sampling), the same packed arithmetic on {c, c} pairs WITHOUT half selection never
-                    // (bits 2 | 32), and neither does anything alone on the GPU.  The instruction forms in isolation beside a bare
-                    // MFMA loop (tools/opsel_probe.hip, pk_probe.hip, war_probe.hip) are clean: what else it takes is not known to us.
+                    // (bits 2 | 32), and neither does anything alone on the GPU.  It reproduces in a plain HIP program: tools/opsel_probe.hip,
+                    // v_pk_add_f32 ... op_sel:[0,1] on known data beside tools/burn.hip's MFMA kernel on another stream -- 2.5e9 wrong
+                    // results in 5 s, all in lanes 48-63, all the low lane's, as if the selected half were 0 (op_sel_hi / plain: none).
                     // Shipped: one register at a time (the opaque statements keep the compiler from pairing), and the whole
                     // library is built without packed fp32 instructions (genpc_amd/build.py).
                     if (hook_bits & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");

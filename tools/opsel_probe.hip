@@ -6,10 +6,22 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <chrono>
+#include <atomic>
+#include <thread>
+#include <vector>
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct Hit { unsigned it, lane, got_lo, got_hi; };
+// tools/burn.hip's kernel itself (burner selector 99 = its kind 1): the neighbour beside which the probe fails when both are
+// launched from Python (tools/opsel_beside_filter.py)
+#define burn_kernel burn_kernel_ref
+#define h16x8 h16x8_ref
+#define f32x16 f32x16_ref
+#include "burn.hip"
+#undef burn_kernel
+#undef h16x8
+#undef f32x16
 
 template <int KIND, int SLEEP>
 __global__ __launch_bounds__(256) void opsel_kernel(int iters, unsigned *nhit, Hit *hits, unsigned long long *done)
@@ -38,13 +50,21 @@ __global__ __launch_bounds__(256) void opsel_kernel(int iters, unsigned *nhit, H
     if (threadIdx.x == 0) atomicAdd(done, (unsigned long long)iters);
 }
 
-__global__ __launch_bounds__(512) void burn_kernel(int iters, float *out)
+// sel (a run-time 0): the accumulator passes through sixteen v_cndmask_b32_e64 (a VOP3 VALU instruction reading the matrix
+// instruction's result registers under an SGPR mask) in front of every MFMA -- tools/burn.hip kind 1, the neighbour beside which
+// the probe fails; sel < 0: a bare chain of dependent MFMAs, beside which it does not
+__global__ __launch_bounds__(512) void burn_kernel(int iters, float *out, int sel)
 {
     f32x16 acc = {0};
     uint4 a = make_uint4(threadIdx.x, threadIdx.x * 3, threadIdx.x * 5, 0x3c003c00u);
     for (int it = 0; it < iters; it++) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, a), acc, 0, 0, 0);
-        a.x += 1;
+        if (sel >= 0) {
+            const f32x16 z = {0};
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, a), (sel & 4) ? z : acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, a), acc, 0, 0, 0);
+            a.x += 1;
+        }
     }
     float s = 0; for (int e = 0; e < 16; e++) s += acc[e];
     if (s == 12345.678f) out[0] = s;
@@ -56,6 +76,15 @@ template <int KIND> static void launch(int sleep, int pblocks, hipStream_t st, u
     else hipLaunchKernelGGL((opsel_kernel<KIND, 0>), dim3(pblocks), dim3(256), 0, st, 400000, nhit, hits, done);
 }
 
+// for tools/opsel_beside_filter.py: one launch on `stream`; counters (two unsigned) and hits (4096 records) are device memory
+extern "C" __attribute__((visibility("default"))) int opsel_launch(int kind, int pblocks, int sleep, unsigned *nhit, void *hits, unsigned long long *done, void *stream)
+{
+    if (kind == 0) launch<0>(sleep, pblocks, (hipStream_t)stream, nhit, (Hit *)hits, done);
+    else if (kind == 1) launch<1>(sleep, pblocks, (hipStream_t)stream, nhit, (Hit *)hits, done);
+    else launch<2>(sleep, pblocks, (hipStream_t)stream, nhit, (Hit *)hits, done);
+    return hipGetLastError() == hipSuccess;
+}
+
 int main(int argc, char **argv)
 {
     const double seconds = argc > 1 ? atof(argv[1]) : 10.0;
@@ -63,26 +92,46 @@ int main(int argc, char **argv)
     const int burn = argc > 3 ? atoi(argv[3]) : 1;
     const int pblocks = argc > 4 ? atoi(argv[4]) : 256;
     const int sleep = argc > 5 ? atoi(argv[5]) : 0;
+    const int biters = argc > 6 ? atoi(argv[6]) : 20000;      // MFMAs per burner wave: 400 = a burner kernel of ~5 us, relaunched all the time
+    const int bblocks = argc > 7 ? atoi(argv[7]) : 512;
+    const int bsel = argc > 8 ? atoi(argv[8]) : 0;            // 0: MFMA + v_cndmask on its results (fails), -1: bare MFMA chain (does not)
     hipStream_t sa, sb;
     (void)hipStreamCreate(&sa); (void)hipStreamCreate(&sb);
     unsigned *nhit; Hit *hits; unsigned long long *done; float *out;
     (void)hipMalloc(&nhit, 8); (void)hipMalloc(&hits, sizeof(Hit) * 4096); (void)hipMalloc(&done, 8); (void)hipMalloc(&out, 4);
     (void)hipMemset(nhit, 0, 8); (void)hipMemset(done, 0, 8);
     const auto t0 = std::chrono::steady_clock::now();
+    // burn >= 2: that many burner streams, each driven by a host thread of its own (as when the library's filter runs on other
+    // streams of other threads), 20 launches per synchronisation
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> bt;
+    if (burn >= 2)
+        for (int q = 0; q < burn; q++)
+            bt.emplace_back([&, q] {
+                hipStream_t s; (void)hipStreamCreate(&s);
+                float *o; (void)hipMalloc(&o, 4);
+                while (!stop.load()) {
+                    for (int j = 0; j < 20; j++) if (bsel == 99) ::burn(1, biters, bblocks, o, s); else hipLaunchKernelGGL(burn_kernel, dim3(bblocks), dim3(512), 0, s, biters, o, bsel);
+                    (void)hipStreamSynchronize(s);
+                }
+            });
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         if (kind == 0) launch<0>(sleep, pblocks, sa, nhit, hits, done);
         else if (kind == 1) launch<1>(sleep, pblocks, sa, nhit, hits, done);
         else launch<2>(sleep, pblocks, sa, nhit, hits, done);
-        if (burn) for (int q = 0; q < 8; q++) hipLaunchKernelGGL(burn_kernel, dim3(512), dim3(512), 0, sb, 20000, out);
+        if (burn == 1) for (int q = 0; q < (biters >= 20000 ? 8 : 2000); q++) if (bsel == 99) ::burn(1, biters, bblocks, out, sb); else hipLaunchKernelGGL(burn_kernel, dim3(bblocks), dim3(512), 0, sb, biters, out, bsel);
         (void)hipStreamSynchronize(sa);
     }
+    stop.store(true);
+    for (auto &t : bt) t.join();
     (void)hipDeviceSynchronize();
     unsigned n = 0; unsigned long long d = 0;
     (void)hipMemcpy(&n, nhit, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&d, done, 8, hipMemcpyDeviceToHost);
     Hit *h = (Hit *)malloc(sizeof(Hit) * 4096);
     (void)hipMemcpy(h, hits, sizeof(Hit) * 4096, hipMemcpyDeviceToHost);
     const char *names[3] = {"op_sel:[0,1]", "op_sel_hi:[1,0]", "plain pair"};
-    printf("v_pk_add_f32 %s, %d probe blocks, sleep %d, burner %s: %.3g wave-iterations, %u wrong results\n", names[kind % 3], pblocks, sleep, burn ? "on" : "off", (double)d * 4.0, n);
+    printf("v_pk_add_f32 %s, %d probe blocks, sleep %d, burner %s (%d blocks x %d MFMAs per launch, %s): %.3g wave-iterations, %u wrong results\n", names[kind % 3], pblocks, sleep,
+           burn ? "on" : "off", bblocks, biters, bsel >= 0 ? "v_cndmask on the results in front of each" : "bare chain", (double)d * 4.0, n);
     int q[4] = {0, 0, 0, 0}, lo = 0, hi = 0;
     for (unsigned k = 0; k < n && k < 4096; k++) { q[(h[k].lane & 63) >> 4]++; lo += (h[k].lane >> 6) & 1; hi += (h[k].lane >> 7) & 1; }
     if (n) {
