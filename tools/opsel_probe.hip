@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <chrono>
 #include <atomic>
 #include <thread>
@@ -70,6 +71,84 @@ __global__ __launch_bounds__(512) void burn_kernel(int iters, float *out, int se
     if (s == 12345.678f) out[0] = s;
 }
 
+// tools/burn.hip's kernel again, with one ingredient removed per variant (burner selectors 100 + V), to see which one the
+// failure needs: V 0 the copy; 1 no LDS / barrier (the operand from registers); 2 no branches on `kind` in the loop (the select
+// stays); 3 the select replaced by a plain dependent chain; 4 the v_cndmask kept but on a register that is NOT the MFMA's result
+template <int V>
+__global__ __launch_bounds__(512) void burn_variant(int kind, int iters, float *out)
+{
+    __shared__ uint4 plane[64];
+    const int t = threadIdx.x;
+    uint4 a;
+    if (V != 1) {
+        for (int i = t; i < 64; i += 512) plane[i] = make_uint4(i, i * 3, i * 5, 0x3c003c00u);
+        __syncthreads();
+        a = plane[t & 63];
+    } else {
+        a = make_uint4(t & 63, (t & 63) * 3, (t & 63) * 5, 0x3c003c00u);
+    }
+    f32x16 acc = {0};
+    float side = (float)t;
+    for (int it = 0; it < iters; it++) {
+        if (V < 2) {
+            if (kind & 2) { const uint4 b = plane[(t * 7 + it * 13) % 64]; a.x ^= b.x; a.y += b.y; a.z ^= b.z; }
+            if (kind & 1) { const f32x16 z = {0}; acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, a), (kind & 4) ? z : acc, 0, 0, 0); }
+        } else if (V == 2) {
+            const f32x16 z = {0};
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, a), (kind & 4) ? z : acc, 0, 0, 0);
+        } else if (V == 3) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, a), acc, 0, 0, 0);
+        } else if (V == 4) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, a), acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 16; q++) asm volatile("v_cndmask_b32_e64 %0, 0, %0, %1" : "+v"(side) : "s"((unsigned long long)(kind & 4 ? 0ull : ~0ull)));
+        } else if (V == 5) {          // no matrix instruction at all; the select's constant operand is 1.0
+#pragma unroll
+            for (int q = 0; q < 16; q++) asm volatile("v_cndmask_b32_e64 %0, 1.0, %0, %1" : "+v"(side) : "s"((unsigned long long)(kind & 4 ? 0ull : ~0ull)));
+        } else if (V == 6) {          // ... the constant in src1 instead of src0
+#pragma unroll
+            for (int q = 0; q < 16; q++) asm volatile("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(side) : "s"((unsigned long long)(kind & 4 ? ~0ull : 0ull)));
+        } else if (V == 7) {          // ... a VOP3 add with the constant 1.0 in src0 (no mask operand)
+#pragma unroll
+            for (int q = 0; q < 16; q++) asm volatile("v_add_f32_e64 %0, 1.0, %0" : "+v"(side));
+        } else if (V == 8) {          // ... the same add in its VOP2 encoding
+#pragma unroll
+            for (int q = 0; q < 16; q++) asm volatile("v_add_f32_e32 %0, 1.0, %0" : "+v"(side));
+        } else {                      // 9 .. 12: the MFMA chain with sixteen VALU instructions on an unrelated register behind each
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, a), acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                if (V == 9) asm volatile("v_cndmask_b32_e64 %0, 1.0, %0, %1" : "+v"(side) : "s"((unsigned long long)(kind & 4 ? 0ull : ~0ull)));      // the constant 1.0
+                else if (V == 10) asm volatile("v_add_f32_e32 %0, 1.0, %0" : "+v"(side));                                                          // a VOP2 add
+                else if (V == 11) asm volatile("v_mov_b32_e32 %0, %0" : "+v"(side));                                                                 // a move, no constant
+                else asm volatile("v_cndmask_b32_e64 %0, %0, %0, %1" : "+v"(side) : "s"((unsigned long long)(kind & 4 ? 0ull : ~0ull)));           // the select without a constant
+            }
+        }
+    }
+    float s = side + (float)a.x;
+    for (int e = 0; e < 16; e++) s += acc[e];
+    if (s == 12345.678f) out[0] = s;
+}
+
+static void launch_variant(int v, int iters, int blocks, float *out, hipStream_t st)
+{
+    switch (v) {
+    case 0: hipLaunchKernelGGL(burn_variant<0>, dim3(blocks), dim3(512), 0, st, 1, iters, out); break;
+    case 1: hipLaunchKernelGGL(burn_variant<1>, dim3(blocks), dim3(512), 0, st, 1, iters, out); break;
+    case 2: hipLaunchKernelGGL(burn_variant<2>, dim3(blocks), dim3(512), 0, st, 1, iters, out); break;
+    case 3: hipLaunchKernelGGL(burn_variant<3>, dim3(blocks), dim3(512), 0, st, 1, iters, out); break;
+    case 4: hipLaunchKernelGGL(burn_variant<4>, dim3(blocks), dim3(512), 0, st, 1, iters, out); break;
+    case 5: hipLaunchKernelGGL(burn_variant<5>, dim3(blocks), dim3(512), 0, st, 1, iters * 8, out); break;
+    case 6: hipLaunchKernelGGL(burn_variant<6>, dim3(blocks), dim3(512), 0, st, 1, iters * 8, out); break;
+    case 7: hipLaunchKernelGGL(burn_variant<7>, dim3(blocks), dim3(512), 0, st, 1, iters * 8, out); break;
+    case 8: hipLaunchKernelGGL(burn_variant<8>, dim3(blocks), dim3(512), 0, st, 1, iters * 8, out); break;
+    case 9: hipLaunchKernelGGL(burn_variant<9>, dim3(blocks), dim3(512), 0, st, 1, iters, out); break;
+    case 10: hipLaunchKernelGGL(burn_variant<10>, dim3(blocks), dim3(512), 0, st, 1, iters, out); break;
+    case 11: hipLaunchKernelGGL(burn_variant<11>, dim3(blocks), dim3(512), 0, st, 1, iters, out); break;
+    default: hipLaunchKernelGGL(burn_variant<12>, dim3(blocks), dim3(512), 0, st, 1, iters, out); break;
+    }
+}
+
 template <int KIND> static void launch(int sleep, int pblocks, hipStream_t st, unsigned *nhit, Hit *hits, unsigned long long *done)
 {
     if (sleep) hipLaunchKernelGGL((opsel_kernel<KIND, 8>), dim3(pblocks), dim3(256), 0, st, 40000, nhit, hits, done);
@@ -111,7 +190,7 @@ int main(int argc, char **argv)
                 hipStream_t s; (void)hipStreamCreate(&s);
                 float *o; (void)hipMalloc(&o, 4);
                 while (!stop.load()) {
-                    for (int j = 0; j < 20; j++) if (bsel == 99) ::burn(1, biters, bblocks, o, s); else hipLaunchKernelGGL(burn_kernel, dim3(bblocks), dim3(512), 0, s, biters, o, bsel);
+                    for (int j = 0; j < 20; j++) if (bsel >= 100) launch_variant(bsel - 100, biters, bblocks, o, s); else if (bsel == 99) ::burn(1, biters, bblocks, o, s); else hipLaunchKernelGGL(burn_kernel, dim3(bblocks), dim3(512), 0, s, biters, o, bsel);
                     (void)hipStreamSynchronize(s);
                 }
             });
@@ -119,7 +198,7 @@ int main(int argc, char **argv)
         if (kind == 0) launch<0>(sleep, pblocks, sa, nhit, hits, done);
         else if (kind == 1) launch<1>(sleep, pblocks, sa, nhit, hits, done);
         else launch<2>(sleep, pblocks, sa, nhit, hits, done);
-        if (burn == 1) for (int q = 0; q < (biters >= 20000 ? 8 : 2000); q++) if (bsel == 99) ::burn(1, biters, bblocks, out, sb); else hipLaunchKernelGGL(burn_kernel, dim3(bblocks), dim3(512), 0, sb, biters, out, bsel);
+        if (burn == 1) for (int q = 0; q < (biters >= 20000 ? 8 : 2000); q++) if (bsel >= 100) launch_variant(bsel - 100, biters, bblocks, out, sb); else if (bsel == 99) ::burn(1, biters, bblocks, out, sb); else hipLaunchKernelGGL(burn_kernel, dim3(bblocks), dim3(512), 0, sb, biters, out, bsel);
         (void)hipStreamSynchronize(sa);
     }
     stop.store(true);
@@ -131,12 +210,16 @@ int main(int argc, char **argv)
     (void)hipMemcpy(h, hits, sizeof(Hit) * 4096, hipMemcpyDeviceToHost);
     const char *names[3] = {"op_sel:[0,1]", "op_sel_hi:[1,0]", "plain pair"};
     printf("v_pk_add_f32 %s, %d probe blocks, sleep %d, burner %s (%d blocks x %d MFMAs per launch, %s): %.3g wave-iterations, %u wrong results\n", names[kind % 3], pblocks, sleep,
-           burn ? "on" : "off", bblocks, biters, bsel >= 0 ? "v_cndmask on the results in front of each" : "bare chain", (double)d * 4.0, n);
+           burn ? "on" : "off", bblocks, biters, bsel >= 100 ? "burn.hip's kernel minus one ingredient" : (bsel == 99 ? "tools/burn.hip's kernel" : (bsel >= 0 ? "v_cndmask on the results in front of each" : "bare chain")), (double)d * 4.0, n);
     int q[4] = {0, 0, 0, 0}, lo = 0, hi = 0;
     for (unsigned k = 0; k < n && k < 4096; k++) { q[(h[k].lane & 63) >> 4]++; lo += (h[k].lane >> 6) & 1; hi += (h[k].lane >> 7) & 1; }
     if (n) {
         printf("  lanes 0-15: %d, 16-31: %d, 32-47: %d, 48-63: %d;  low result wrong: %d, high result wrong: %d\n", q[0], q[1], q[2], q[3], lo, hi);
-        for (unsigned k = 0; k < n && k < 6; k++) printf("  iteration %u lane %u: result = %08x %08x\n", h[k].it, h[k].lane & 63, h[k].got_lo, h[k].got_hi);
+        for (unsigned k = 0; k < n && k < 4; k++) {
+            float lo, hi; memcpy(&lo, &h[k].got_lo, 4); memcpy(&hi, &h[k].got_hi, 4);
+            const unsigned ln = h[k].lane & 63;
+            printf("  iteration %u lane %u: result = (%.2f, %.2f); p = (%.0f, %.0f): the low lane subtracted %.2f\n", h[k].it, ln, lo, hi, 1.0f + ln, 2.0f + ln, 1.0f + ln - lo);
+        }
     }
     return 0;
 }
