@@ -39,9 +39,34 @@ __global__ __launch_bounds__(256) void opsel_kernel(int iters, unsigned *nhit, H
             asm volatile("s_nop 3\n\tv_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3" : "=&v"(r) : "v"(p), "v"(pair));
         else if (KIND == 1)   // high lane takes the low half: both lanes p - A
             asm volatile("s_nop 3\n\tv_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3" : "=&v"(r) : "v"(p), "v"(pair));
-        else                  // plain pair
+        else if (KIND == 2)   // plain pair
             asm volatile("s_nop 3\n\tv_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3" : "=&v"(r) : "v"(p), "v"(pair));
-        const float w0 = p.x - (KIND == 0 ? B : A), w1 = p.y - (KIND == 1 ? A : B);
+        else if (KIND == 3)   // other instructions of the class, the same half selection: a packed multiply ...
+            asm volatile("s_nop 3\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1]\n\ts_nop 3" : "=&v"(r) : "v"(p), "v"(pair));
+        else if (KIND == 4)   // ... a packed move (the LOW lane takes the high half of its one source)
+            asm volatile("s_nop 3\n\tv_pk_mov_b32 %0, %2, %2 op_sel:[1,1]\n\ts_nop 3" : "=&v"(r) : "v"(p), "v"(pair));
+        else if (KIND == 5)   // ... the selection on src0 instead of src1
+            asm volatile("s_nop 3\n\tv_pk_add_f32 %0, %2, %1 op_sel:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n\ts_nop 3" : "=&v"(r) : "v"(p), "v"(pair));
+        else {                // ... and a packed f16 add: the low result takes the HIGH f16 of src1 (one 32-bit register holds the pair)
+            unsigned ph = 0x4400u | (0x4500u << 16), qh = (0x3c00u + (lane & 15u)) | ((0x4000u + (lane & 15u)) << 16), rh;      // p = (4, 5), q = (1 + e, 2 + e')
+            asm volatile("s_nop 3\n\tv_pk_add_f16 %0, %1, %2 op_sel:[0,1]\n\ts_nop 3" : "=&v"(rh) : "v"(ph), "v"(qh));
+            unsigned ref_lo, ref_hi;      // both lanes add q.hi: computed without packed instructions
+            {
+                _Float16 plo = __builtin_bit_cast(_Float16, (unsigned short)(ph & 0xffffu)), phi = __builtin_bit_cast(_Float16, (unsigned short)(ph >> 16));
+                _Float16 qhi = __builtin_bit_cast(_Float16, (unsigned short)(qh >> 16));
+                ref_lo = __builtin_bit_cast(unsigned short, (_Float16)(plo + qhi));
+                ref_hi = __builtin_bit_cast(unsigned short, (_Float16)(phi + qhi));
+            }
+            r.x = __uint_as_float(rh & 0xffffu); r.y = __uint_as_float(rh >> 16);
+            const float w0h = __uint_as_float(ref_lo), w1h = __uint_as_float(ref_hi);
+            if (__float_as_uint(r.x) != __float_as_uint(w0h) || __float_as_uint(r.y) != __float_as_uint(w1h)) {
+                const unsigned k = atomicAdd(nhit, 1u);
+                if (k < 4096) hits[k] = Hit{(unsigned)it, lane | (__float_as_uint(r.x) != __float_as_uint(w0h) ? 64u : 0u) | (__float_as_uint(r.y) != __float_as_uint(w1h) ? 128u : 0u), rh & 0xffffu, rh >> 16};
+            }
+            continue;
+        }
+        const float w0 = KIND == 3 ? p.x * B : (KIND == 4 ? B : p.x - (KIND == 0 || KIND == 5 ? B : A));
+        const float w1 = KIND == 3 ? p.y * B : (KIND == 4 ? B : p.y - (KIND == 1 ? A : B));
         if (__float_as_uint(r.x) != __float_as_uint(w0) || __float_as_uint(r.y) != __float_as_uint(w1)) {
             const unsigned k = atomicAdd(nhit, 1u);
             if (k < 4096) hits[k] = Hit{(unsigned)it, lane | (__float_as_uint(r.x) != __float_as_uint(w0) ? 64u : 0u) | (__float_as_uint(r.y) != __float_as_uint(w1) ? 128u : 0u),
@@ -197,7 +222,11 @@ int main(int argc, char **argv)
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         if (kind == 0) launch<0>(sleep, pblocks, sa, nhit, hits, done);
         else if (kind == 1) launch<1>(sleep, pblocks, sa, nhit, hits, done);
-        else launch<2>(sleep, pblocks, sa, nhit, hits, done);
+        else if (kind == 2) launch<2>(sleep, pblocks, sa, nhit, hits, done);
+        else if (kind == 3) launch<3>(sleep, pblocks, sa, nhit, hits, done);
+        else if (kind == 4) launch<4>(sleep, pblocks, sa, nhit, hits, done);
+        else if (kind == 5) launch<5>(sleep, pblocks, sa, nhit, hits, done);
+        else launch<6>(sleep, pblocks, sa, nhit, hits, done);
         if (burn == 1) for (int q = 0; q < (biters >= 20000 ? 8 : 2000); q++) if (bsel >= 100) launch_variant(bsel - 100, biters, bblocks, out, sb); else if (bsel == 99) ::burn(1, biters, bblocks, out, sb); else hipLaunchKernelGGL(burn_kernel, dim3(bblocks), dim3(512), 0, sb, biters, out, bsel);
         (void)hipStreamSynchronize(sa);
     }
@@ -208,8 +237,9 @@ int main(int argc, char **argv)
     (void)hipMemcpy(&n, nhit, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&d, done, 8, hipMemcpyDeviceToHost);
     Hit *h = (Hit *)malloc(sizeof(Hit) * 4096);
     (void)hipMemcpy(h, hits, sizeof(Hit) * 4096, hipMemcpyDeviceToHost);
-    const char *names[3] = {"op_sel:[0,1]", "op_sel_hi:[1,0]", "plain pair"};
-    printf("v_pk_add_f32 %s, %d probe blocks, sleep %d, burner %s (%d blocks x %d MFMAs per launch, %s): %.3g wave-iterations, %u wrong results\n", names[kind % 3], pblocks, sleep,
+    const char *names[7] = {"v_pk_add_f32 op_sel:[0,1]", "v_pk_add_f32 op_sel_hi:[1,0]", "v_pk_add_f32 plain pair", "v_pk_mul_f32 op_sel:[0,1]", "v_pk_mov_b32 op_sel:[1,1]",
+                            "v_pk_add_f32 op_sel:[1,0] (src0)", "v_pk_add_f16 op_sel:[0,1]"};
+    printf("%s, %d probe blocks, sleep %d, burner %s (%d blocks x %d MFMAs per launch, %s): %.3g wave-iterations, %u wrong results\n", names[kind % 7], pblocks, sleep,
            burn ? "on" : "off", bblocks, biters, bsel >= 100 ? "burn.hip's kernel minus one ingredient" : (bsel == 99 ? "tools/burn.hip's kernel" : (bsel >= 0 ? "v_cndmask on the results in front of each" : "bare chain")), (double)d * 4.0, n);
     int q[4] = {0, 0, 0, 0}, lo = 0, hi = 0;
     for (unsigned k = 0; k < n && k < 4096; k++) { q[(h[k].lane & 63) >> 4]++; lo += (h[k].lane >> 6) & 1; hi += (h[k].lane >> 7) & 1; }
