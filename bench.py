@@ -442,7 +442,7 @@ def extras(A, B, n, dev, stream):
     # completed scans per second is a throughput: six independent scans in flight on the one GPU (pipeline.complete_scans:
     # a host thread and a stream pair per lane; every scan's products are the bits of a call of its own)
     lanes_c2 = 6
-    jobs_c2 = [(part_s, gen_s, img, gt_s)] * (4 * lanes_c2)
+    jobs_c2 = [(part_s, gen_s, img, gt_s)] * (8 * lanes_c2)      # (48 scans: 24 read 34-35 scans/s where long runs of the same lanes read 39-43)
     dps_c2 = [DepthPrompting(cfg2) for _ in range(lanes_c2)]
     pipeline.complete_scans(jobs_c2[:lanes_c2], lanes=lanes_c2, cfg=cfg2, dps=dps_c2)
     torch.cuda.synchronize()
