@@ -1,5 +1,6 @@
+"""Every variant of the sampling's update (genpc_fps_tune bits) ALONE on the GPU: all give the shipped sequence.   python3 tools/fps_hook_alone.py"""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch, numpy as np
 from genpc_amd import fps as F, _lib
 g = torch.Generator(device="cuda"); g.manual_seed(3)
