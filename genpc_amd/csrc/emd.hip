@@ -787,10 +787,19 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     const int lin_blocks = ceil_div((int)total, kEBlock);
     hipLaunchKernelGGL(emd_init_kernel, dim3(lin_blocks), dim3(kEBlock), 0, st, b, n, lists[0], cnts[0], cnts[1], second, chain_head, whead,
                        chain_cnt, arrived);
+    // most points of this shape's last call kept bidding (the feedback word, emd_auction.hip)
+    bool heavy = false;
+    if (const volatile int *fb = emd_feedback_slot(b, n, false)) heavy = (long long)*fb * 100 > (long long)n * 35;
     if (grid) {
         // about two objects per cell if the cloud filled its box (surfaces fill far fewer cells, with more objects each)
         static const int env_ppc = tune_env("GENPC_EMD_GRID_PPC_X10", 20, "culled EMD bid: target objects per cell x 10");
-        int target = (int)((long long)n * 10 / (env_ppc > 0 ? env_ppc : 20));
+        // ... twice that where most points keep bidding (the feedback word of this shape's last call, emd_auction.hip: a partial scan
+        // against its ground truth): the balls hold hundreds of objects there and a row of coarser cells is one run instead of
+        // several (13 bundled scans 18.3 -> 17.4 ms; 80: 18.0, 10: 19.8)
+        static const int env_ppc_heavy = tune_env("GENPC_EMD_GRID_PPC_HEAVY_X10", 40, "culled EMD bid: target objects per cell x 10 for clouds whose last call kept more than a third of their points bidding");
+        int ppc = env_ppc > 0 ? env_ppc : 20;
+        if (heavy && env_ppc_heavy > 0) ppc = env_ppc_heavy;
+        int target = (int)((long long)n * 10 / ppc);
         target = target < 8 ? 8 : (target > cells_max * 3 / 4 ? cells_max * 3 / 4 : target);
         if (!launch_emd_grid_build(b, n, xyz2, price, g_hdr_p, g_start_p, g_sorted_p, g_pos_p, g_of_p, target, cells_max, st)) return 0;
     }
@@ -799,7 +808,9 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
     // loop is latency-bound per wave -- LDS read, compare, branch -- and wants >= 8
     // waves per SIMD: measured 13x16384, round 0: 3.9 ms at 4/CU, 1.8 ms at 16/CU),
     // never more than the finest split (64 lanes per bidder, all n bidding).
-    int G = ceil_div(num_cus() * 16, b);
+    // (heavy clouds -- thousands of bidders per cloud in every round: 36 per CU; 13 bundled scans, blocks per cloud 316 / 512 /
+    //  640 / 768 / 1024: 17.4 / 16.9 / 16.7 / 16.7 / 17.1 ms)
+    int G = ceil_div(num_cus() * (heavy && grid ? 36 : 16), b);
     if (G > 1024) G = 1024;     // a single cloud: more blocks only add dispatch + hand-off latency (measured)
     const int g_max = ceil_div(n * 64, kEBlock);
     if (G > g_max) G = g_max;
