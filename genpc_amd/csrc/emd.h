@@ -107,7 +107,7 @@ struct EGridHdr {            // one per batch element, written by emd_grid_build
     int bad;                // a non-finite coordinate or a negative / non-finite initial price: search without culling
 };
 struct EmdGridBid {
-    int n, G, nb, cells_max, force_lpb, xcd_pin;
+    int n, G, nb, cells_max, force_lpb, xcd_pin, lpb_max;      // lpb_max > 0: at most this many lanes per bidder
     float eps;
     unsigned stamp;
     const float *xyz1, *xyz2, *price;

@@ -846,7 +846,8 @@ GENPC_API int genpc_emd_forward(int b, int n, int m, const float *xyz1, const fl
             EmdGridBid ga{};
             ga.n = n; ga.G = G; ga.nb = b; ga.cells_max = cells_max; ga.eps = eps; ga.stamp = stamp;
             static const int env_lpb = tune_env("GENPC_EMD_LPB", 0, "culled EMD bid: lanes per bidder (8..64, 0 = pick)");
-            ga.force_lpb = env_lpb;
+            ga.force_lpb = env_lpb > 0 ? env_lpb : (heavy ? 16 : 0);      // (thousands of bidders per cloud in every round: sixteen lanes each -- 13 bundled scans 16.7 -> 16.0 ms; 8: 17.4)
+            ga.lpb_max = 0;
             static const int env_xcd = tune_env("GENPC_EMD_XCD", 0, "culled EMD bid: 1 = a cloud's blocks on one XCD (the tiled bid's order), 0 = clouds interleaved");
             ga.xcd_pin = env_xcd;
             ga.xyz1 = xyz1; ga.xyz2 = xyz2; ga.price = price; ga.orig_of = g_of_p;

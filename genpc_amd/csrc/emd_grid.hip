@@ -277,6 +277,7 @@ __global__ __launch_bounds__(kEBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
     if (a.feedback != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.feedback, U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (U == 0) return;
     int LPB = a.force_lpb > 0 ? a.force_lpb : pick_p(U, G);
+    if (a.force_lpb <= 0 && a.lpb_max > 0 && LPB > a.lpb_max) LPB = a.lpb_max;
     LPB = LPB < 8 ? 8 : LPB;
     const int per_wave = kWave / LPB, per_block = kEBlock / LPB;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
