@@ -29,6 +29,7 @@
 #include "common.h"
 #include "../../include/genpc_hip.h"
 #include <type_traits>
+#include <vector>
 
 namespace genpc {
 
@@ -36,6 +37,10 @@ namespace genpc {
 bool persist_reserve(int wgs, int capacity, hipStream_t st);
 void persist_commit(int wgs, hipStream_t st);
 int emd_auction_capacity();
+// fps_grid.hip: the one-workgroup sampling with spatial pruning
+bool fps_grid_takes(int n);
+int fps_grid_run(bool fma, int c, const int *sel, const int *n, const int *k, const float *const *xyz, int *const *out_idx,
+                 float *const *pdist_of, float4 *spt, int *err, hipStream_t st);
 
 constexpr int kFThreads = 192;           // worker threads of a workgroup: three waves, the fourth wave coordinates -- one wave per SIMD
 constexpr int kFWaves = kFThreads / kWave;
@@ -201,8 +206,13 @@ __device__ __forceinline__ int wave_argbest(float v, int idx, float &m)
     return __ffsll((long long)__ballot(cand == best)) - 1;
 }
 
-template <int FMA, int R>
-__global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops"))) void fps_kernel(FpsJobs jobs, FpsSlot *slots, int *__restrict__ err)
+// The body of the sampling.  HOOK = 1 compiles the bisection's variants (genpc_fps_tune bits, packed fp32 written out) into the
+// workers' update: that instantiation is inlined into fps_kernel_hook ONLY, the one kernel of the library that carries the
+// packed-fp32-ops target attribute and is launched when a test asks for a variant; the shipped fps_kernel has no such
+// attribute and no such code (the attribute used to sit on the shipped kernel, its update kept free of packed
+// instructions by opaque statements alone; tests/test_abi.py now exempts fps_kernel_hook by name and nothing else).
+template <int FMA, int R, int HOOK>
+static __device__ __forceinline__ void fps_body(const FpsJobs &jobs, FpsSlot *slots, int *__restrict__ err)
 {
     __shared__ float s_c[kFWaves][kFT][5];     // per worker wave: dist, idx (bits), x, y, z of its kFT best
     __shared__ float s_piv[kFBatch][4];        // the round's pivots: x, y, z, idx (bits)
@@ -376,8 +386,7 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
                         }
                     }
                                 };
-                if (jobs.legacy_pivot != 0) for (; applied < avail; applied++) apply_pivot(std::true_type{});
-                else for (; applied < avail; applied++) apply_pivot(std::false_type{});
+                for (; applied < avail; applied++) apply_pivot(std::integral_constant<bool, HOOK != 0>{});
                 if (pr & kProgDone) break;
             }
             if (pr & (kProgFinal | kProgAbort)) break;
@@ -564,6 +573,18 @@ __global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops")))
     }
 }
 
+template <int FMA, int R>
+__global__ __launch_bounds__(kFBlock) void fps_kernel(FpsJobs jobs, FpsSlot *slots, int *__restrict__ err)
+{
+    fps_body<FMA, R, 0>(jobs, slots, err);
+}
+
+template <int FMA, int R>
+__global__ __launch_bounds__(kFBlock) __attribute__((target("packed-fp32-ops"))) void fps_kernel_hook(FpsJobs jobs, FpsSlot *slots, int *__restrict__ err)
+{
+    fps_body<FMA, R, 1>(jobs, slots, err);
+}
+
 // Verification of a sampling, on the device, against the DEFINITION (round 5).  The k steps of a sampling are sequential, but
 // checking a finished sequence is not: sample j (drawn with running minimum M_j, as the sampling itself recorded it) is right
 // iff, after the first j samples have been applied, every point i has running minimum D_i < M_j, or D_i == M_j and i > s_j,
@@ -679,6 +700,17 @@ __global__ void fps_poison_kernel(FpsJobs jobs, int nj)
 template <int FMA>
 static void launch_fps(int R, dim3 grid, hipStream_t st, const FpsJobs &jobs, FpsSlot *slots, int *err)
 {
+    if (jobs.legacy_pivot != 0) {          // a test asked for one of the bisection's variants
+        switch (R) {
+        case 1: case 2: hipLaunchKernelGGL((fps_kernel_hook<FMA, 2>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+        case 3: case 4: hipLaunchKernelGGL((fps_kernel_hook<FMA, 4>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+        case 5: case 6: case 7: case 8: hipLaunchKernelGGL((fps_kernel_hook<FMA, 8>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+        case 9: case 10: case 11: case 12: hipLaunchKernelGGL((fps_kernel_hook<FMA, 12>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+        case 13: case 14: case 15: case 16: hipLaunchKernelGGL((fps_kernel_hook<FMA, 16>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+        default: hipLaunchKernelGGL((fps_kernel_hook<FMA, 24>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
+        }
+        return;
+    }
     switch (R) {
     case 1: case 2: hipLaunchKernelGGL((fps_kernel<FMA, 2>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
     case 3: case 4: hipLaunchKernelGGL((fps_kernel<FMA, 4>), grid, dim3(kFBlock), 0, st, jobs, slots, err); break;
@@ -706,20 +738,33 @@ static int fps_class(int R) { return R <= 2 ? 0 : (R <= 4 ? 1 : (R <= 8 ? 2 : (R
 template <int FMA>
 static int fps_blocks_per_cu(int cls)
 {
-    static int cache[6] = {0, 0, 0, 0, 0, 0};
-    if (cache[cls] > 0) return cache[cls];
+    // (the hook kernel -- a test's variant of the update -- may need more registers than the shipped one: asked separately)
+    const int hook = (t_fps_legacy & 255) != 0 ? 1 : 0;
+    static int cache[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+    if (cache[hook][cls] > 0) return cache[hook][cls];
     int nb = 0;
     hipError_t e = hipSuccess;
-    switch (cls) {
-    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 2>, kFBlock, 0); break;
-    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 4>, kFBlock, 0); break;
-    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 8>, kFBlock, 0); break;
-    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 12>, kFBlock, 0); break;
-    case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 16>, kFBlock, 0); break;
-    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 24>, kFBlock, 0); break;
+    if (hook) {
+        switch (cls) {
+        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel_hook<FMA, 2>, kFBlock, 0); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel_hook<FMA, 4>, kFBlock, 0); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel_hook<FMA, 8>, kFBlock, 0); break;
+        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel_hook<FMA, 12>, kFBlock, 0); break;
+        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel_hook<FMA, 16>, kFBlock, 0); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel_hook<FMA, 24>, kFBlock, 0); break;
+        }
+    } else {
+        switch (cls) {
+        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 2>, kFBlock, 0); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 4>, kFBlock, 0); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 8>, kFBlock, 0); break;
+        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 12>, kFBlock, 0); break;
+        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 16>, kFBlock, 0); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fps_kernel<FMA, 24>, kFBlock, 0); break;
+        }
     }
     if (e != hipSuccess || nb < 1) nb = 1;
-    cache[cls] = nb;
+    cache[hook][cls] = nb;
     return nb;
 }
 
@@ -737,7 +782,7 @@ GENPC_API int genpc_fps_tune(int legacy_pivot)
     // 4 sixteen wait states in front of the update, 8 the update's operands copied through fresh VGPRs first, 16 the packed results
     // leave their pair through separate 32-bit registers, 32 (with 2) the packed instructions written out with four wait states behind
     // each; 1 alone = 3, the pre-fix form
-    genpc::t_fps_legacy = legacy_pivot == 1 ? 3 : (legacy_pivot & 255);
+    genpc::t_fps_legacy = legacy_pivot == 1 ? 3 : (legacy_pivot & 511);      // bit 256: never the one-workgroup kernel of fps_grid.hip
     return prev;
 }
 
@@ -772,31 +817,88 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
             W = W > 2 * budget_of(R) ? budget_of(R) : W - 1;
         }
     };
-    size_t total_slots = 0, total_k = 0;
-    for (int j = 0; j < c; j++) { total_slots += 2 * (size_t)fps_workgroups(n[j]); total_k += ((size_t)k[j] + 63) / 64 * 64; }
+    // Which kernel: clouds that fit one workgroup's LDS take the pruned sampling of fps_grid.hip (no hand-off, several samples
+    // per round, updates confined to the ball a sample can change), the others the multi-workgroup kernel above.  Same
+    // sequences (tests/test_gpu_fps.py runs both on every case); genpc_fps_tune bit 256 / GENPC_FPS_GRID=0: never the former.
+    static const int env_grid = tune_env("GENPC_FPS_GRID", 1, "farthest point sampling: 1 = clouds of up to 32768 points are sampled by one workgroup with spatial pruning (csrc/fps_grid.hip), 0 = always the multi-workgroup kernel");
+    const bool grid_on = env_grid != 0 && t_fps_legacy == 0;
+    std::vector<int> small, big;
+    for (int j = 0; j < c; j++) (grid_on && fps_grid_takes(n[j]) ? small : big).push_back(j);
+    size_t total_slots = 0, total_k = 0, spt_pts = 0;
+    for (int j : big) total_slots += 2 * (size_t)fps_workgroups(n[j]);
+    for (int j : small) spt_pts += ((size_t)n[j] + 63) & ~(size_t)63;
+    for (int j = 0; j < c; j++) total_k += ((size_t)k[j] + 63) / 64 * 64;
     static const int env_verify = tune_env("GENPC_FPS_VERIFY", 1, "farthest point sampling: 1 = every sequence is checked on the device against the definition (a violation poisons out[0] = -1), 0 = no check");
     const size_t head = 256 + total_slots * sizeof(FpsSlot), verr_bytes = ((size_t)c * sizeof(int) + 255) / 256 * 256;
     size_t total_n = 0;
     for (int j = 0; j < c; j++) total_n += (size_t)n[j];
-    char *ws = (char *)workspace(7, head + verr_bytes + total_k * sizeof(float) + (env_verify ? total_n * kFVMaxSeg * sizeof(float) : 0), st);
+    const size_t pd_bytes = (total_k * sizeof(float) + 255) / 256 * 256;
+    const size_t seg_bytes = env_verify ? (total_n * kFVMaxSeg * sizeof(float) + 255) / 256 * 256 : 0;
+    char *ws = (char *)workspace(7, head + verr_bytes + pd_bytes + seg_bytes + spt_pts * sizeof(float4), st);
     if (!ws) return 0;
     int *err = (int *)ws;
     FpsSlot *slots = (FpsSlot *)(ws + 256);
     int *verr = (int *)(ws + head);
     float *pdist = (float *)(ws + head + verr_bytes);
-    float *segmin = pdist + total_k;
-    size_t seg_off = 0;
+    float *segmin = (float *)(ws + head + verr_bytes + pd_bytes);
+    float4 *spt = (float4 *)(ws + head + verr_bytes + pd_bytes + seg_bytes);
     if (!check(hipMemsetAsync(ws, 0, head + verr_bytes, st), "hipMemsetAsync(fps)")) return 0;
-    size_t pd_off = 0;
+    std::vector<float *> pd_of(c);
+    std::vector<int> seg_of(c);
+    {
+        size_t pd_off = 0, seg_off = 0;
+        for (int j = 0; j < c; j++) {
+            pd_of[j] = pdist + pd_off;
+            seg_of[j] = (int)seg_off;
+            pd_off += ((size_t)k[j] + 63) / 64 * 64;
+            seg_off += (size_t)n[j];
+        }
+    }
+    // the verification of a group of clouds (fps_verify_kernel above), whichever kernel sampled them
+    auto verify = [&](const FpsJobs &jobs, int nj) {
+        if (!env_verify) return;
+        int nmax = 1;
+        for (int q = 0; q < nj; q++) nmax = jobs.n[q] > nmax ? jobs.n[q] : nmax;
+        const int gxv = ceil_div(nmax, kFVBlock);
+        int nseg = (4 * cus) / (gxv * nj > 0 ? gxv * nj : 1);      // about four blocks per CU
+        nseg = nseg < 1 ? 1 : (nseg > kFVMaxSeg ? kFVMaxSeg : nseg);
+        const dim3 vg(gxv, nj, nseg);
+        if (nseg > 1) {
+            if (fma) hipLaunchKernelGGL((fps_verify_kernel<1, 0>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
+            else hipLaunchKernelGGL((fps_verify_kernel<0, 0>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
+        }
+        if (fma) hipLaunchKernelGGL((fps_verify_kernel<1, 1>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
+        else hipLaunchKernelGGL((fps_verify_kernel<0, 1>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
+        hipLaunchKernelGGL(fps_poison_kernel, dim3(1), dim3(kFMaxJobs), 0, st, jobs, nj);
+    };
+    if (!small.empty()) {
+        if (fps_grid_run(fma, (int)small.size(), small.data(), n, k, xyz, out_idx, pd_of.data(), spt, err, st) != 1) return 0;
+        for (size_t q0 = 0; q0 < small.size(); q0 += kFMaxJobs) {
+            FpsJobs jobs = {};
+            int nj = 0;
+            for (; nj < kFMaxJobs && q0 + nj < small.size(); nj++) {
+                const int j = small[q0 + nj];
+                jobs.xyz[nj] = xyz[j];
+                jobs.out[nj] = out_idx[j];
+                jobs.pdist[nj] = pd_of[j];
+                jobs.verr[nj] = verr + j;
+                jobs.segoff[nj] = seg_of[j];
+                jobs.n[nj] = n[j];
+                jobs.k[nj] = k[j];
+            }
+            verify(jobs, nj);
+        }
+    }
     int slot0 = 0;
-    for (int j0 = 0; j0 < c;) {
+    const int cb = (int)big.size();
+    for (int j0 = 0; j0 < cb;) {
         // a launch takes up to kFMaxJobs clouds; its grid is (largest W) x (clouds), all of it resident together
         FpsJobs jobs = {};
-        jobs.stat0 = j0 < 32 ? j0 : 32;
-        jobs.legacy_pivot = t_fps_legacy;
+        jobs.stat0 = big[j0] < 32 ? big[j0] : 32;
+        jobs.legacy_pivot = t_fps_legacy & 255;
         int nj = 0, wmax = 0, rmax = 1;
-        while (j0 + nj < c && nj < kFMaxJobs) {
-            const int j = j0 + nj;
+        while (j0 + nj < cb && nj < kFMaxJobs) {
+            const int j = big[j0 + nj];
             int W = 0, R = 0;
             if (!plan(n[j], W, R)) {
                 set_error("genpc_fps: the cloud needs more co-resident workgroups than the device admits");
@@ -806,11 +908,9 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
             if (nj > 0 && (long long)wm * (nj + 1) > budget_of(rm)) break;
             jobs.xyz[nj] = xyz[j];
             jobs.out[nj] = out_idx[j];
-            jobs.pdist[nj] = pdist + pd_off;
+            jobs.pdist[nj] = pd_of[j];
             jobs.verr[nj] = verr + j;
-            jobs.segoff[nj] = (int)seg_off;
-            seg_off += (size_t)n[j];
-            pd_off += ((size_t)k[j] + 63) / 64 * 64;
+            jobs.segoff[nj] = seg_of[j];
             jobs.n[nj] = n[j];
             jobs.k[nj] = k[j];
             jobs.W[nj] = W;
@@ -830,21 +930,7 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
         if (fma) launch_fps<1>(rmax, dim3(wmax, nj), st, jobs, slots, err);
         else launch_fps<0>(rmax, dim3(wmax, nj), st, jobs, slots, err);
         if (admitted) persist_commit(units, st);
-        if (env_verify) {
-            int nmax = 1;
-            for (int q = 0; q < nj; q++) nmax = jobs.n[q] > nmax ? jobs.n[q] : nmax;
-            const int gxv = ceil_div(nmax, kFVBlock);
-            int nseg = (4 * cus) / (gxv * nj > 0 ? gxv * nj : 1);      // about four blocks per CU
-            nseg = nseg < 1 ? 1 : (nseg > kFVMaxSeg ? kFVMaxSeg : nseg);
-            const dim3 vg(gxv, nj, nseg);
-            if (nseg > 1) {
-                if (fma) hipLaunchKernelGGL((fps_verify_kernel<1, 0>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
-                else hipLaunchKernelGGL((fps_verify_kernel<0, 0>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
-            }
-            if (fma) hipLaunchKernelGGL((fps_verify_kernel<1, 1>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
-            else hipLaunchKernelGGL((fps_verify_kernel<0, 1>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
-            hipLaunchKernelGGL(fps_poison_kernel, dim3(1), dim3(kFMaxJobs), 0, st, jobs, nj);
-        }
+        verify(jobs, nj);
         j0 += nj;
     }
     if (!check(hipGetLastError(), "fps launch")) return 0;
@@ -856,7 +942,7 @@ GENPC_API int genpc_fps_stats(int c, int *rounds, void *stream)
     // exchanges (hand-off rounds) each of the first c <= 32 clouds of the last genpc_fps_multi call on this
     // stream took; synchronises the stream
     using namespace genpc;
-    if (c < 0 || c > 32) return -1;
+    if (c < 0 || c > 60) return -1;
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace(7, 256, st);
     if (!ws) return 0;
