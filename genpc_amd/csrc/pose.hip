@@ -27,6 +27,9 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 // chamfer.hip
 extern "C" int genpc_chamfer_forward(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1,
@@ -1422,6 +1425,66 @@ __global__ __launch_bounds__(kQBlock) void mask_sums_kernel(int S, const float *
     }
 }
 
+// What the backward gather needs per image besides the pixel itself: the Dice term's two coefficients and, per channel, the
+// mean of G and the factor of the standard deviation's own derivative (mask_w_kernel's prologue; the fused gather's too)
+struct MaskCoef {
+    float dice_a, dice_b, meanG[3], kk[3], invP, mask_weight;
+};
+
+__device__ __forceinline__ MaskCoef mask_coefficients(const double *accum, const float *stats, const MaskStats &st, int P, float mask_weight)
+{
+    MaskCoef o;
+    const double den = accum[25] + (double)stats[6] + 1e-6, num = 2.0 * accum[24] + 1e-6;
+    o.dice_a = (float)(-20.0 / den);
+    o.dice_b = (float)(10.0 * num / (den * den));
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const double *s = accum + 26 + 6 * ch;
+        const double sG = s[0] + (double)o.dice_a * s[1] + (double)o.dice_b * s[2];
+        const double sGd = s[3] + (double)o.dice_a * s[4] + (double)o.dice_b * s[5];
+        o.meanG[ch] = (float)(sG / P);
+        const double sd = st.sd[ch];
+        o.kk[ch] = sd > 0.0 ? (float)((st.sdr[ch] + 1e-6) / ((sd + 1e-6) * (sd + 1e-6)) / ((P - 1) * sd) * sGd) : 0.0f;
+    }
+    o.invP = 1.0f / (float)P;
+    o.mask_weight = mask_weight;
+    return o;
+}
+
+__device__ __forceinline__ double mask_loss_value(const double *accum, const float *stats, int P)
+{
+    const double den = accum[25] + (double)stats[6] + 1e-6, num = 2.0 * accum[24] + 1e-6;
+    return 30.0 * accum[22] / P + accum[23] / P + 10.0 * (1.0 - num / den);
+}
+
+// the weights of pixel q (mask_w_kernel's body; the fused gather evaluates it per gathered pixel: same arithmetic, same bits)
+__device__ __forceinline__ void mask_w_pixel(const float *__restrict__ planes, const float *__restrict__ mref, int P, int q, int direct,
+                                             const MaskStats &st, const MaskCoef &cf, float &w1, float4 &w4)
+{
+    const PxImg im = load_pixel(planes, P, q, direct);
+    const MaskPx px = mask_pixel(im.I, mref[q], st);
+    const float Gm = px.dmb * cf.invP + cf.dice_a * px.mr + cf.dice_b;
+    float dI[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+        dI[ch] = cf.mask_weight * (st.k[ch] * (Gm * px.spc[ch] - cf.meanG[ch]) - cf.kk[ch] * (im.I[ch] - st.muf[ch]));
+    if (direct == 2) {
+        // blend 1: I_ch = N'_ch / D', N' and D' sums of w_i = a_i e'_i:  d loss / d w_i = W4.xyz . c_i - W4.w; the gather
+        // multiplies by e'_i = exp(z_i / gamma - m), so W1 carries the pixel's m
+        const float sI = dI[0] * im.I[0] + dI[1] * im.I[1] + dI[2] * im.I[2];
+        w1 = im.T;
+        w4 = make_float4(im.iD * dI[0], im.iD * dI[1], im.iD * dI[2], im.iD * sI);
+    } else if (direct) {
+        w4 = make_float4(dI[0], dI[1], dI[2], 0.0f);
+        w1 = 0.0f;
+    } else {
+        const float sA = dI[0] * im.A[0] + dI[1] * im.A[1] + dI[2] * im.A[2];
+        const float od = im.O * im.iD;
+        w1 = im.T * sA;
+        w4 = make_float4(od * dI[0], od * dI[1], od * dI[2], od * sA);
+    }
+}
+
 // grid (blocks, b): with dI_ch = mask_weight * d mask_loss / d I_ch, the five weights of the backward gather
 //   W1 = T sum_ch dI_ch A_ch     (d O / d a_i = T / (1 - a_i))
 //   W4 = (O / D) (dI_r, dI_g, dI_b, sum_ch dI_ch A_ch)     (d A_ch / d a_i = (c_i,ch - A_ch) / D)
@@ -1441,47 +1504,15 @@ __global__ __launch_bounds__(kQBlock) void mask_w_kernel(int S, const float *__r
     stats += (size_t)e * 8;
     accum += (size_t)e * kAcc;
     const MaskStats st = mask_image_stats(accum, stats, P);
-    const double den = accum[25] + (double)stats[6] + 1e-6, num = 2.0 * accum[24] + 1e-6;
-    const float dice_a = (float)(-20.0 / den), dice_b = (float)(10.0 * num / (den * den));
-    float meanG[3], kk[3];
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-        const double *s = accum + 26 + 6 * ch;
-        const double sG = s[0] + (double)dice_a * s[1] + (double)dice_b * s[2];
-        const double sGd = s[3] + (double)dice_a * s[4] + (double)dice_b * s[5];
-        meanG[ch] = (float)(sG / P);
-        const double sd = st.sd[ch];
-        kk[ch] = sd > 0.0 ? (float)((st.sdr[ch] + 1e-6) / ((sd + 1e-6) * (sd + 1e-6)) / ((P - 1) * sd) * sGd) : 0.0f;
-    }
-    const float invP = 1.0f / (float)P;
+    const MaskCoef cf = mask_coefficients(accum, stats, st, P, mask_weight);
     for (int q = blockIdx.x * kQBlock + threadIdx.x; q < P; q += gridDim.x * kQBlock) {
-        const PxImg im = load_pixel(planes, P, q, direct);
-        const MaskPx px = mask_pixel(im.I, mref[q], st);
-        const float Gm = px.dmb * invP + dice_a * px.mr + dice_b;
-        float dI[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++)
-            dI[ch] = mask_weight * (st.k[ch] * (Gm * px.spc[ch] - meanG[ch]) - kk[ch] * (im.I[ch] - st.muf[ch]));
-        if (direct == 2) {
-            // blend 1: I_ch = N'_ch / D', N' and D' sums of w_i = a_i e'_i:  d loss / d w_i = W4.xyz . c_i - W4.w; the gather
-            // multiplies by e'_i = exp(z_i / gamma - m), so W1 carries the pixel's m
-            const float sI = dI[0] * im.I[0] + dI[1] * im.I[1] + dI[2] * im.I[2];
-            W1[q] = im.T;
-            W4[q] = make_float4(im.iD * dI[0], im.iD * dI[1], im.iD * dI[2], im.iD * sI);
-        } else if (direct) {
-            W4[q] = make_float4(dI[0], dI[1], dI[2], 0.0f);
-            W1[q] = 0.0f;
-        } else {
-            const float sA = dI[0] * im.A[0] + dI[1] * im.A[1] + dI[2] * im.A[2];
-            const float od = im.O * im.iD;
-            W1[q] = im.T * sA;
-            W4[q] = make_float4(od * dI[0], od * dI[1], od * dI[2], od * sA);
-        }
+        float w1;
+        float4 w4;
+        mask_w_pixel(planes, mref, P, q, direct, st, cf, w1, w4);
+        W1[q] = w1;
+        W4[q] = w4;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const double loss = 30.0 * accum[22] / P + accum[23] / P + 10.0 * (1.0 - num / den);
-        accum[15] += (double)mask_weight * loss;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) accum[15] += (double)mask_weight * mask_loss_value(accum, stats, P);
 }
 
 // grid (tiles, b), the tile pass of the mask gradient: a tile's W planes in LDS, one thread per entry of the tile's list
@@ -1630,7 +1661,10 @@ __global__ __launch_bounds__(TB) void mask_grad_tile_kernel(int n, const float4 
 }
 
 // 1-D grid of gx * nb blocks (xcd_block): gradient of the mask term with respect to (R, s, t), into accum[0..12].
-template <int kGradSub, int BLEND>
+// FUSEW (round 6): the per-pixel weights are not read from W1 / W4 but evaluated where they are gathered, from the image's
+// planes and the reference mask with mask_w_kernel's own arithmetic (mask_w_pixel: same bits) -- the alignment loop's step is
+// one launch shorter (mask_w_kernel: 13 us of a 128 us step for 50 k pixels per image); block 0 of an image adds the loss.
+template <int kGradSub, int BLEND, int FUSEW = 0>
 __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *__restrict__ v,
                                                             const float *__restrict__ col,
                                                             const float *__restrict__ center, int cstride,
@@ -1638,7 +1672,9 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
                                                             int S, const float *__restrict__ W1,
                                                             const float4 *__restrict__ W4, double *__restrict__ accum,
                                                             const float4 *__restrict__ gpart, const float4 *__restrict__ uvr,
-                                                            int gx, int nb)
+                                                            int gx, int nb, const float *__restrict__ planes = nullptr,
+                                                            const float *__restrict__ mref = nullptr,
+                                                            const float *__restrict__ stats = nullptr, float mask_weight = 0.0f)
 {
     __shared__ double red[13][kQBlock / kWave];
     const XcdBlock xb = xcd_block(gx, nb);
@@ -1646,12 +1682,25 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
     if (uvr) uvr += (size_t)e * n;
     v += (size_t)e * n * 3;
     if (col) col += (size_t)e * n * 3;
-    W1 += (size_t)e * S * S;
-    W4 += (size_t)e * S * S;
+    const int PP = S * S;
+    if (!FUSEW) {
+        W1 += (size_t)e * PP;
+        W4 += (size_t)e * PP;
+    }
     if (gpart) gpart += (size_t)e * n * kBinPer;
     center += (size_t)e * cstride;
     params += (size_t)e * pstride;
     accum += (size_t)e * kAcc;
+    MaskStats mst = {};
+    MaskCoef mcf = {};
+    if (FUSEW) {
+        planes += (size_t)e * 5 * PP;
+        mref += (size_t)e * PP;
+        stats += (size_t)e * 8;
+        mst = mask_image_stats(accum, stats, PP);
+        mcf = mask_coefficients(accum, stats, mst, PP, mask_weight);
+    }
+    constexpr int kMode = BLEND ? 2 : 0;
     float R[9];
     rot6d_to_matrix(params, R);
     const float s = expf(params[9]);
@@ -1714,8 +1763,11 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
                     const float av = 1.0f - d2 * ir2;
                     if (BLEND) {
                         if (av <= 0.0f) continue;
-                        const float4 w4 = W4[(size_t)r * S + cc];
-                        const float w = ((cr * w4.x + cg * w4.y) + (cb * w4.z - w4.w)) * __expf(ze - W1[(size_t)r * S + cc]);
+                        float4 w4;
+                        float w1;
+                        if (FUSEW) mask_w_pixel(planes, mref, PP, r * S + cc, kMode, mst, mcf, w1, w4);
+                        else { w4 = W4[(size_t)r * S + cc]; w1 = W1[(size_t)r * S + cc]; }
+                        const float w = ((cr * w4.x + cg * w4.y) + (cb * w4.z - w4.w)) * __expf(ze - w1);
                         gz += w * fminf(av, kMaskAmax);
                         if (av >= kMaskAmax) continue;
                         gu += w * dx;
@@ -1724,8 +1776,11 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
                         continue;
                     }
                     if (av <= 0.0f || av >= kMaskAmax) continue;      // outside the disc / clamped: no gradient
-                    const float4 w4 = W4[(size_t)r * S + cc];
-                    const float w = W1[(size_t)r * S + cc] * __builtin_amdgcn_rcpf(1.0f - av) + ((cr * w4.x + cg * w4.y) + (cb * w4.z - w4.w));
+                    float4 w4;
+                    float w1;
+                    if (FUSEW) mask_w_pixel(planes, mref, PP, r * S + cc, kMode, mst, mcf, w1, w4);
+                    else { w4 = W4[(size_t)r * S + cc]; w1 = W1[(size_t)r * S + cc]; }
+                    const float w = w1 * __builtin_amdgcn_rcpf(1.0f - av) + ((cr * w4.x + cg * w4.y) + (cb * w4.z - w4.w));
                     gu += w * dx;
                     gv += w * dy;
                     gr += w * d2;
@@ -1771,6 +1826,7 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
         for (int w2 = 0; w2 < kQBlock / kWave; w2++) x += red[threadIdx.x][w2];
         atomicAdd(&accum[threadIdx.x], x);
     }
+    if (FUSEW && xb.x == 0 && threadIdx.x == 0) accum[15] += (double)mask_weight * mask_loss_value(accum, stats, PP);
 }
 
 // img[P, 3] (H, W, C like the reference's renders) from the five planes
@@ -1949,8 +2005,12 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
     const int gs = std::min(gp, env_sb > 0 ? env_sb : 48);      // 196: 221 ms per 8-scan call, 48: 210, 24: 210, 12: 210 (single scan: 42.1 / 41.4 / 41.8 / 43.3)
     hipLaunchKernelGGL(mask_sums_kernel, dim3(gs, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, mode, (const float *)m.mref,
                        (const float *)m.stats, accum);
-    hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, mode, (const float *)m.mref,
-                       (const float *)m.stats, mask_weight, m.W1, m.W4, accum);
+    // the weights per pixel as a launch of their own (the tile pass reads them from LDS tiles), or evaluated inside the gather
+    static const int env_fw = tune_env("GENPC_MASK_FUSE_W", 1, "alignment loop: 1 = the silhouette gradient evaluates the per-pixel weights where it gathers them (no mask_w launch), 0 = mask_w_kernel + gather");
+    const bool fuse_w = !tile_pass && env_fw != 0;
+    if (!fuse_w)
+        hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, mode, (const float *)m.mref,
+                           (const float *)m.stats, mask_weight, m.W1, m.W4, accum);
     if (tile_pass) {
 #define GENPC_LAUNCH_TILE(TB, SORT, BL)                                                                                              \
         hipLaunchKernelGGL((mask_grad_tile_kernel<TB, SORT, BL>), dim3(mask_tiles(S), b), dim3(TB), 0, st, nc, (const float4 *)m.uvr,   \
@@ -1967,18 +2027,23 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
                                cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum,
                                (const float4 *)m.gpart, (const float4 *)m.uvr, lin_grid(nc), b);
     } else {
-        // lanes per point (measured at 4 x 16384 points, the four starts in lock-step: <1> 35 us, <8> 42)
+        // lanes per point: a thread per point walks its whole pixel box alone (a chain of ~35 dependent gathers at the loop's
+        // radius: 21 us for 4 x 2451 points), eight lanes share it row by row (12.9 us) -- until the points fill the chip by
+        // themselves (measured at 4 x 16384 points, the four starts in lock-step: <1> 35 us, <8> 42)
         static const int env_sub = tune_env("GENPC_MASK_GRAD_SUB", 0, "alignment loop: lanes per point of the per-point silhouette gradient (0 = pick)");
-        const int sub = env_sub ? env_sub : (b <= 2 ? 8 : 1);
-#define GENPC_LAUNCH_MASK_GRAD2(SUB, BL)                                                                                             \
-        hipLaunchKernelGGL((mask_grad_kernel<SUB, BL>), dim3(lin_grid((long long)nc * SUB) * b), dim3(kQBlock), 0, st, nc, complete,  \
+        const int sub = env_sub ? env_sub : ((long long)b * nc <= 24576 || b <= 2 ? 8 : 1);
+#define GENPC_LAUNCH_MASK_GRAD3(SUB, BL, FW)                                                                                         \
+        hipLaunchKernelGGL((mask_grad_kernel<SUB, BL, FW>), dim3(lin_grid((long long)nc * SUB) * b), dim3(kQBlock), 0, st, nc, complete, \
                            complete_col, center, cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum, \
-                           (const float4 *)nullptr, (const float4 *)nullptr, lin_grid((long long)nc * SUB), b)
+                           (const float4 *)nullptr, (const float4 *)nullptr, lin_grid((long long)nc * SUB), b, (const float *)m.planes, \
+                           (const float *)m.mref, (const float *)m.stats, mask_weight)
+#define GENPC_LAUNCH_MASK_GRAD2(SUB, BL) do { if (fuse_w) GENPC_LAUNCH_MASK_GRAD3(SUB, BL, 1); else GENPC_LAUNCH_MASK_GRAD3(SUB, BL, 0); } while (0)
 #define GENPC_LAUNCH_MASK_GRAD(SUB) do { if (blend) GENPC_LAUNCH_MASK_GRAD2(SUB, 1); else GENPC_LAUNCH_MASK_GRAD2(SUB, 0); } while (0)
         if (sub == 8) GENPC_LAUNCH_MASK_GRAD(8);
         else if (sub == 4) GENPC_LAUNCH_MASK_GRAD(4);
         else if (sub == 2) GENPC_LAUNCH_MASK_GRAD(2);
         else GENPC_LAUNCH_MASK_GRAD(1);
+#undef GENPC_LAUNCH_MASK_GRAD3
 #undef GENPC_LAUNCH_MASK_GRAD2
 #undef GENPC_LAUNCH_MASK_GRAD
     }
@@ -2109,6 +2174,36 @@ GENPC_API int genpc_pose_tune(int seeded)
     genpc::t_pose_seeded = seeded < 0 ? -1 : (seeded > 2 ? 2 : seeded);
     return prev;
 }
+
+namespace genpc {
+// The two halves of an Adam step read the posed cloud and nothing of each other -- nearest neighbours + Chamfer gradient
+// (three launches) and the silhouette term (splat, sums, gather) -- and every launch of either is latency-bound on a mostly
+// idle chip: with the full objective the Chamfer half runs on a stream of its own beside the silhouette half (fork behind
+// the transform, join in front of the update; all enqueued up front like the rest, no host synchronisation).  One side
+// stream and a small ring of events per caller's stream, made once and kept for the life of the process.
+struct PoseSide {
+    hipStream_t side = nullptr;
+    hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ok = false;
+};
+static PoseSide *pose_side_of(hipStream_t st)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, PoseSide *> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = table.find({dev, st});
+    if (it != table.end()) return it->second->ok ? it->second : nullptr;
+    PoseSide *p = new PoseSide();
+    p->ok = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 4 && p->ok; i++)
+        p->ok = hipEventCreateWithFlags(&p->fork[i], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming) == hipSuccess;
+    table[{dev, st}] = p;
+    return p->ok ? p : nullptr;
+}
+}  // namespace genpc
 
 GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, const float *complete_col, int np,
                                         const float *partial, const float *partial_col, float lr, int iters, int starts,
@@ -2244,6 +2339,10 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // 32 images (8 scans x 4 starts): 96 blocks per image 153.1 ms per call, 48: 151.0, 24: 150.2, 12: 150.4
     const int g_t = lin_grid(nc), g_g = std::min(env_gb > 0 ? env_gb : (b >= 16 ? 24 : 1024), lin_grid((long long)nc + np));
     const int hstride = starts * (iters + 1);
+    static const int env_dual = tune_env("GENPC_POSE_DUAL", 1, "alignment loop, full objective: 1 = the Chamfer half of a step (nearest neighbours + gradient) on a side stream beside the silhouette half, 0 = one stream");
+    PoseSide *dual = mask && env_dual ? pose_side_of(st) : nullptr;
+    hipStream_t sn = dual ? dual->side : st;        // the stream of the nearest-neighbour launches and pose_grad
+    long long dual_step = 0;
     for (int s = 0; s < starts; s++) {
         if (adaptive) { probe_every = kPoseProbe; next_probe = 1; use_seeded = false; t_seeded = __builtin_inff(); }
         hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, s, lock);
@@ -2257,6 +2356,11 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
                                    (const float *)center, 4, (const float *)S->params, kStateFloats, pts);
             // steps 0 and 2 time the filter (the first one carries the call's one-off costs: the smaller of the two counts),
             // step 1 and then every probe_every-th the seeded search
+            if (dual) {
+                // fork: the side stream's launches of this step wait for the transform
+                (void)hipEventRecord(dual->fork[dual_step & 3], st);
+                (void)hipStreamWaitEvent(sn, dual->fork[dual_step & 3], 0);
+            }
             const bool probe_f = adaptive && (it == 0 || it == 2);
             const bool probe_s = adaptive && it == next_probe && !probe_f;
             const bool probe = probe_f || probe_s;
@@ -2266,20 +2370,20 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
             constexpr int kPoseSample = 4;
             const bool sampled = probe_s && !use_seeded;
             const bool this_seeded = seeded && it > 0 && !probe_f && use_seeded;
-            if (probe) (void)hipEventRecord(ev0, st);
+            if (probe) (void)hipEventRecord(ev0, sn);
             if (sampled && launch_nn_seeded(b, nc, pts, np, partial, sg, center, 4, (const float *)S->params, kStateFloats, d1, i1, d2, i2,
-                                            fma_mode, st, kPoseSample) != 1)
+                                            fma_mode, sn, kPoseSample) != 1)
                 return 0;
-            if (sampled) (void)hipEventRecord(ev1, st);
+            if (sampled) (void)hipEventRecord(ev1, sn);
             if (this_seeded) {
-                if (launch_nn_seeded(b, nc, pts, np, partial, sg, center, 4, (const float *)S->params, kStateFloats, d1, i1, d2, i2, fma_mode, st) != 1)
+                if (launch_nn_seeded(b, nc, pts, np, partial, sg, center, 4, (const float *)S->params, kStateFloats, d1, i1, d2, i2, fma_mode, sn) != 1)
                     return 0;
-            } else if (nn_forward(b, 2, pts, nc, partial, np, d1, i1, partial, np, pts, nc, d2, i2, st, __builtin_inff(), dup_p, dup_c) != 1) {
+            } else if (nn_forward(b, 2, pts, nc, partial, np, d1, i1, partial, np, pts, nc, d2, i2, sn, __builtin_inff(), dup_p, dup_c) != 1) {
                 return 0;
             }
             if (probe) {
                 float ms = 0.0f;
-                if ((sampled || hipEventRecord(ev1, st) == hipSuccess) && hipEventSynchronize(ev1) == hipSuccess &&
+                if ((sampled || hipEventRecord(ev1, sn) == hipSuccess) && hipEventSynchronize(ev1) == hipSuccess &&
                     hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
                     if (probe_f) {
                         t_filter = it == 0 ? ms : (ms < t_filter ? ms : t_filter);
@@ -2293,12 +2397,18 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
                     use_seeded = it >= 2 && t_seeded < 0.9f * t_filter;
                 }
             }
-            hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, st, nc, complete, (const float *)center,
+            hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, sn, nc, complete, (const float *)center,
                                4, (const float *)S->params, kStateFloats, np, partial, (const float *)d1,
                                (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, accum);
             if (mask && !mask_step(b, nc, complete, complete_col, center, 4, S->params, kStateFloats, radius, render_size,
                                    mask_weight, m, accum, st, true))
                 return 0;
+            if (dual) {
+                // join: the update reads both halves' sums
+                (void)hipEventRecord(dual->join[dual_step & 3], sn);
+                (void)hipStreamWaitEvent(st, dual->join[dual_step & 3], 0);
+                dual_step++;
+            }
             hipLaunchKernelGGL(pose_update_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, nc, np, 3.0f, 0.001f, lr, 1,
                                history ? history + (size_t)s * (iters + 1) + it : (float *)nullptr, hstride);
         }
