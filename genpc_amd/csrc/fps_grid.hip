@@ -309,7 +309,16 @@ __global__ __launch_bounds__(kGT) void fps_grid_kernel(FpsGridJobs jobs, int *__
                         const float ddy = fmaxf(fmaxf(by - box_margin - py, py - (by + h + box_margin)), 0.0f);
                         const float ddz = fmaxf(fmaxf(bz - box_margin - pz, pz - (bz + h + box_margin)), 0.0f);
                         const float d2 = (ddx * ddx + ddy * ddy + ddz * ddz) * 0.9999f;
-                        if (d2 < key) nck = (p1 - p0 + 7) >> 3;       // (a running minimum is at most the sample's own when it was drawn)
+                        if (d2 < key) {                               // (a running minimum is at most the sample's own when it was drawn)
+                            nck = (p1 - p0 + 7) >> 3;
+                            // a small cell at the ball's fringe: every point of it may already be closer to an earlier sample
+                            // than the cell is to this one (the chunk maxima bound the cell's running minima from above)
+                            const int j0c = p0 >> 3, j1c = (p1 - 1) >> 3;
+                            if (j1c - j0c <= 2) {
+                                const float bound = fmaxf(chmax[j0c], fmaxf(chmax[(j0c + j1c) >> 1], chmax[j1c]));
+                                if (d2 >= bound) nck = 0;
+                            }
+                        }
                     }
                 }
                 int incl = nck;

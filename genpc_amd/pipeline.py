@@ -16,12 +16,13 @@ the image-to-3D model of the reference, on tensors instead of files.
 ``complete_scan`` returns every intermediate product so that tests can check each stage
 against the oracle on the stage's actual input.
 
-Stage 1 and ``reg()`` read the same inputs and nothing of each other (the registration works on coordinates; the
+Stage 1 and the rest read the same inputs and nothing of each other (the registration works on coordinates; the
 colours only travel into the fused file), so ``complete_scan`` runs stage 1 on a second HIP stream, driven by a second
-host thread, under the alignment loop: the loop is 1800 small dependent launches that leave most of the chip idle, the
-viewpoint selection is a handful of chip-wide kernels with host round trips of its own.  The library's scratch is keyed
-by stream, its entry points take the stream as an argument, ctypes releases the interpreter lock during a call: the
-two calls share nothing but the inputs.  ``overlap=False`` runs the stages one after the other (same results).
+host thread, under the scan's TAIL (fusion + metric: two farthest-point samplings that occupy one compute unit each and
+leave the chip to the viewpoint selection's chip-wide kernels; rounds 3-5 ran it under the alignment loop, whose small
+dependent launches it delayed).  The library's scratch is keyed by stream, its entry points take the stream as an
+argument, ctypes releases the interpreter lock during a call: the two calls share nothing but the inputs.
+``overlap=False`` runs the stages one after the other (same results).
 """
 import threading
 from types import SimpleNamespace
@@ -104,6 +105,22 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
         return reg_xyz.reg(partial_xyz, generated_xyz, generative_model=cfg.generative_model, dataset=cfg.dataset,
                            cd_inv_weight=0.5, diff_init=True, reg_fine_xyz=True, cd_only_pose=cd_only_pose)
 
+    def tail(res):
+        # the ground truth's metric subsampling (main.py:21) depends on nothing above: it rides along in the fused
+        # cloud's FPS launch
+        side_fps = [(gt_xyz, metric_points)] if gt_xyz is not None and gt_xyz.shape[0] >= metric_points else None
+        fused = reg_xyz.fuse(res["source"], res["target"], num_points=fused_points, side_fps=side_fps)
+        gt_idx = None
+        if side_fps:
+            fused, (gt_idx,) = fused
+        t = {"fused": fused}
+        # ---- metric: main.metric (main.py:11-36) ----
+        if gt_xyz is not None:
+            pred = fps_to(fused, metric_points)
+            gt = gt_xyz[gt_idx.long()] if gt_idx is not None else fps_to(gt_xyz, metric_points)
+            t.update(pred=pred, gt=gt, metric=evaluate_scans(pred[None].contiguous(), gt[None].contiguous())[0])
+        return t
+
     main = side = None
     if overlap and partial_xyz.is_cuda and not _NO_OVERLAP:
         main = torch.cuda.current_stream(partial_xyz.device)
@@ -111,6 +128,11 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
         if side.cuda_stream == main.cuda_stream:        # (torch's stream pool wrapped around onto the caller's stream)
             side = None
     if side is not None:
+        # Stage 1 runs under the TAIL of the scan, not under the alignment loop (round 6): the two farthest-point samplings of
+        # the tail are ~9 ms on ONE compute unit each (csrc/fps_grid.hip) and leave the chip to the viewpoint selection's
+        # chip-wide kernels, while the alignment loop's small dependent launches were delayed by them (stage 1 under the loop
+        # hid 2 of its 10 ms; under the tail all of it).
+        res = stage2()
         side.wait_stream(main)                      # the inputs are the main stream's
         box = {}
         state = _lib.thread_state()                 # (thread-local library modes and grad mode: the side thread gets the caller's)
@@ -126,7 +148,7 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
         th = threading.Thread(target=run, name="genpc-stage1")
         th.start()
         try:
-            res = stage2()
+            t = tail(res)
         finally:
             th.join()
         if "err" in box:
@@ -136,26 +158,17 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
     else:
         g, colors = stage1()
         res = stage2()
+        t = tail(res)
     view, uv, depth = g["view_index"], g["uv"][None], g["depth"][None]
     out.update(view=view, used_opposite=g["used_opposite"], visible=g["visible"], uv=g["uv"], depth=g["depth"], pixels=g["pixels"],
                sparse_img=g["sparse_img"], sparse_depth=g["raw_depth"], hole_mask1=g["hole_mask1"], hole_mask2=g["hole_mask2"])
     out["point_colors"] = colors
     out["reg"] = res
-    # the ground truth's metric subsampling (main.py:21) depends on nothing above: it rides along in the fused
-    # cloud's FPS launch
-    side = [(gt_xyz, metric_points)] if gt_xyz is not None and gt_xyz.shape[0] >= metric_points else None
-    fused = reg_xyz.fuse(res["source"], res["target"], num_points=fused_points, side_fps=side)
-    gt_idx = None
-    if side:
-        fused, (gt_idx,) = fused
-    out["fused"] = fused
-    # ---- metric: main.metric (main.py:11-36) ----
+    out["fused"] = t["fused"]
     if gt_xyz is not None:
-        pred = fps_to(fused, metric_points)
-        gt = gt_xyz[gt_idx.long()] if gt_idx is not None else fps_to(gt_xyz, metric_points)
-        out["pred_metric_points"] = pred
-        out["gt_metric_points"] = gt
-        out["metric"] = evaluate_scans(pred[None].contiguous(), gt[None].contiguous())[0]
+        out["pred_metric_points"] = t["pred"]
+        out["gt_metric_points"] = t["gt"]
+        out["metric"] = t["metric"]
     return out
 
 
