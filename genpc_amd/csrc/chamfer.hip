@@ -676,6 +676,92 @@ __global__ __launch_bounds__(kGradBlock) void chamfer_grad_scatter_tiled_kernel(
     for (int i = threadIdx.x; i < rows * 3; i += kGradBlock) O[(size_t)t0 * 3 + i] = __fadd_rn(O[(size_t)t0 * 3 + i], acc[i]);
 }
 
+// Large calls, round 6: ONE pass per direction computes every term once and puts it in both places (chamfer3D.cu:157-171) --
+// a block owns a tile of kGradTile target rows of one cloud; it walks the other cloud's index array, and for the entries that
+// land in its tile (exactly one block per entry) it evaluates the term, adds it to the QUERY's own gradient row (a plain
+// read-modify-write: that row has no other writer in this launch) and accumulates its negative in the tile's LDS copy, which
+// is added to the gradient at the end (a plain coalesced read-modify-write: the tile has one owner).  Direction 0 and
+// direction 1 are two launches (each cloud's gradient is "own rows" in one and "tiles" in the other).  Against round 5's
+// own-row launch + tile launch: the rows, weights and indices are read once, not twice; the hits of a wave's 512 entries are
+// compacted so that only they issue loads (round 5 loaded for all eight entries of a thread at clamped addresses: seven of
+// eight load instructions fetched nothing); the blocks of a batch element share an XCD, so the tiles' walks of the same index
+// array and the partial lines of the own rows meet in one L2.
+constexpr int kGradList = 128;     // compacted hits a wave keeps per trip (more: the hits are dense, the lanes take them in place)
+template <int TILE>
+__global__ __launch_bounds__(kGradBlock) void chamfer_grad_dir_kernel(int b, int tiles, int nq, const float *__restrict__ Qc, int nt,
+                                                                      const float *__restrict__ Tc, const float *__restrict__ Gd,
+                                                                      const int *__restrict__ Ix, float *__restrict__ Oq,
+                                                                      float *__restrict__ Ot)
+{
+    __shared__ float acc[TILE * 3];
+    __shared__ unsigned long long lst[kGradBlock / kWave][kGradList];      // query << 32 | row of the tile
+    int e, tile;
+    {
+        const int lin = blockIdx.x;
+        if ((b & 7) == 0) { const int xcd = lin & 7, k = lin >> 3; e = 8 * (k / tiles) + xcd; tile = k % tiles; }
+        else { e = lin / tiles; tile = lin % tiles; }
+    }
+    if (e >= b) return;
+    const int t0 = tile * TILE;
+    const float *__restrict__ Q = Qc + (size_t)e * nq * 3;
+    const float *__restrict__ T = Tc + (size_t)e * nt * 3;
+    const float *__restrict__ G = Gd + (size_t)e * nq;
+    const int *__restrict__ I = Ix + (size_t)e * nq;
+    float *__restrict__ OQ = Oq + (size_t)e * nq * 3;
+    float *__restrict__ OT = Ot + (size_t)e * nt * 3;
+    const int rows = min(TILE, nt - t0);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < rows * 3; i += kGradBlock) acc[i] = 0.0f;
+    __syncthreads();
+    auto term = [&](int q, int k) {
+        const float qx = Q[(size_t)q * 3 + 0], qy = Q[(size_t)q * 3 + 1], qz = Q[(size_t)q * 3 + 2];
+        const float g = __fmul_rn(G[q], 2.0f);
+        const float tx = T[(size_t)(t0 + k) * 3 + 0], ty = T[(size_t)(t0 + k) * 3 + 1], tz = T[(size_t)(t0 + k) * 3 + 2];
+        const float o0 = OQ[(size_t)q * 3 + 0], o1 = OQ[(size_t)q * 3 + 1], o2 = OQ[(size_t)q * 3 + 2];
+        const float vx = __fmul_rn(g, qx - tx), vy = __fmul_rn(g, qy - ty), vz = __fmul_rn(g, qz - tz);
+        OQ[(size_t)q * 3 + 0] = __fadd_rn(o0, vx);
+        OQ[(size_t)q * 3 + 1] = __fadd_rn(o1, vy);
+        OQ[(size_t)q * 3 + 2] = __fadd_rn(o2, vz);
+        atomicAdd(&acc[k * 3 + 0], -vx);
+        atomicAdd(&acc[k * 3 + 1], -vy);
+        atomicAdd(&acc[k * 3 + 2], -vz);
+    };
+    for (int q0 = threadIdx.x; q0 - (int)threadIdx.x < nq; q0 += 8 * kGradBlock) {      // (wave-uniform trip count)
+        int kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = q0 + u * kGradBlock;
+            kk[u] = q < nq ? I[q] - t0 : -1;
+        }
+        // the wave's hits among its 512 entries
+        int pos[8], total = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool hit = (unsigned)kk[u] < (unsigned)rows;
+            const unsigned long long m = __ballot(hit);
+            pos[u] = hit ? total + (int)__popcll(m & ((1ull << lane) - 1ull)) : -1;
+            total += (int)__popcll(m);
+        }
+        if (total == 0) continue;
+        if (total <= kGradList) {
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (pos[u] >= 0) lst[wave][pos[u]] = ((unsigned long long)(unsigned)(q0 + u * kGradBlock) << 32) | (unsigned)kk[u];
+            // (the list is this wave's own: LDS operations of a wave are performed in order)
+            for (int i = lane; i < total; i += kWave) {
+                const unsigned long long w = lst[wave][i];
+                term((int)(w >> 32), (int)(unsigned)w);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (pos[u] >= 0) term(q0 + u * kGradBlock, kk[u]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * 3; i += kGradBlock) OT[(size_t)t0 * 3 + i] = __fadd_rn(OT[(size_t)t0 * 3 + i], acc[i]);
+}
+
 struct NNConfig {
     int r;                // VALU path, queries per lane: 0 = pick, else 2 or 4
     int blocks_per_cu;    // occupancy target used to pick the slice count
@@ -1108,11 +1194,30 @@ GENPC_API int genpc_chamfer_backward(int b, int n, const float *xyz1, int m, con
         set_error("chamfer backward: problem too large for one launch");
         return 0;
     }
-    static const int env_split = tune_env("GENPC_CHAMFER_GRAD_SPLIT", 262144, "chamfer backward: points (both clouds) from which the own rows and the scattered halves are two launches (0 = never)");
+    static const int env_split = tune_env("GENPC_CHAMFER_GRAD_SPLIT", 262144, "chamfer backward: points (both clouds) from which the gradient is accumulated through LDS tiles that own their output rows instead of global atomics (0 = never)");
     if (env_split > 0 && (long long)b * ((long long)n + m) >= env_split) {
+        static const int env_tiled = tune_env("GENPC_CHAMFER_GRAD_TILED", 2, "chamfer backward, large calls: 2 = one pass per direction (own rows + tiles fused), 1 = own rows and tiles as two launches (round 5), 0 = global atomics");
+        static const int env_tile = tune_env("GENPC_CHAMFER_GRAD_TILE", 4096, "chamfer backward, large calls: target rows a block owns (2048 | 4096 | 8192)");
+        const int tile_rows = env_tile == 2048 || env_tile == 8192 ? env_tile : 4096;
+        const int tiles_n = ceil_div(n, tile_rows), tiles_m = ceil_div(m, tile_rows);
+        const long long bb = (b & 7) == 0 ? b : b;      // (blocks per tile column: the batch; a multiple of eight is dealt XCD by XCD)
+        if (env_tiled == 2 && bb * (tiles_n > tiles_m ? tiles_n : tiles_m) <= 0x7fffffffLL) {
+            // direction 0: queries = cloud 1, tiles of cloud 2's gradient; direction 1 the converse
+#define GENPC_GRAD_DIR(TILE)                                                                                                          \
+            do {                                                                                                                      \
+                hipLaunchKernelGGL(chamfer_grad_dir_kernel<TILE>, dim3((unsigned)(b * tiles_m)), dim3(kGradBlock), 0, (hipStream_t)stream, b, tiles_m, \
+                                   n, xyz1, m, xyz2, graddist1, idx1, gradxyz1, gradxyz2);                                            \
+                hipLaunchKernelGGL(chamfer_grad_dir_kernel<TILE>, dim3((unsigned)(b * tiles_n)), dim3(kGradBlock), 0, (hipStream_t)stream, b, tiles_n, \
+                                   m, xyz2, n, xyz1, graddist2, idx2, gradxyz2, gradxyz1);                                            \
+            } while (0)
+            if (tile_rows == 2048) GENPC_GRAD_DIR(2048);
+            else if (tile_rows == 8192) GENPC_GRAD_DIR(8192);
+            else GENPC_GRAD_DIR(4096);
+#undef GENPC_GRAD_DIR
+            return check(hipGetLastError(), "chamfer_grad_dir_kernel launch") ? 1 : 0;
+        }
         hipLaunchKernelGGL(chamfer_grad_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, b, n, xyz1, m,
                            xyz2, graddist1, idx1, graddist2, idx2, gradxyz1, gradxyz2);
-        static const int env_tiled = tune_env("GENPC_CHAMFER_GRAD_TILED", 1, "chamfer backward, large calls: 1 = the scattered halves through LDS tiles that own their output rows, 0 = global atomics");
         const int tiles = ceil_div(n > m ? n : m, kGradTile);
         if (env_tiled && tiles <= 65535 && b <= 65535)
             hipLaunchKernelGGL(chamfer_grad_scatter_tiled_kernel, dim3(tiles, b, 2), dim3(kGradBlock), 0, (hipStream_t)stream, n, xyz1, m, xyz2,
