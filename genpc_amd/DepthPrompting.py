@@ -66,6 +66,9 @@ def create_cameras(num_views=1024, distance=1.6, fovy=49.1, device="cuda"):
     return torch.from_numpy(views).to(device), eyes, focal
 
 
+import threading as _threading
+_EYES_LOCK = _threading.Lock()
+
 class DepthPrompting:
     """cfg needs: device, fovy, res, padding, rescale, point_size, mask_pixel_rate
     (configs/config.yaml keys, unchanged)."""
@@ -135,13 +138,16 @@ class DepthPrompting:
         else:
             # (an upload from pageable memory waits for the stream: the device copy of a viewpoint set is kept, keyed by content)
             host = np.ascontiguousarray(np.asarray(viewpoints.cpu() if torch.is_tensor(viewpoints) else viewpoints, np.float64).reshape(-1, 3))
-            key = (str(points.device), host.shape[0], hash(host.tobytes()))
-            cache = self.__dict__.setdefault("_eyes_on_device", {})
-            if key not in cache:
-                if len(cache) >= 8:
-                    cache.clear()
-                cache[key] = torch.from_numpy(host).to(points.device)
-            eyes = cache[key]
+            # (keyed by the bytes themselves -- a hash alone could hand a colliding set the wrong viewpoints -- and guarded by a lock:
+            #  one DepthPrompting object may be shared by host threads)
+            key = (str(points.device), host.shape[0], host.tobytes())
+            with _EYES_LOCK:
+                cache = self.__dict__.setdefault("_eyes_on_device", {})
+                eyes = cache.get(key)
+                if eyes is None:
+                    if len(cache) >= 8:
+                        cache.clear()
+                    eyes = cache[key] = torch.from_numpy(host).to(points.device)
         c, n = eyes.shape[0], points.shape[0]
         vis = torch.zeros(c, n, device=points.device, dtype=torch.uint8)
         cnt = torch.empty(c, device=points.device, dtype=torch.int32)

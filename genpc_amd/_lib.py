@@ -42,6 +42,7 @@ SIGNATURES = {
     "genpc_emd_tune": (_i, [_i, _i]),
     "genpc_emd_stats": (_i, [_vp, _i, _vp]),
     "genpc_emd_status": (_i, [_i, _vp]),
+    "genpc_emd_contended": (_i, []),
     "genpc_emd_calc_dist": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_emd_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_get_uvs": (_i, [_i, _i, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "genpc_mask_loss": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_pose_loss_grad": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
     "genpc_pose_tune": (_i, [_i]),
+    "genpc_pose_dual": (_i, [_i]),
     "genpc_render_tune": (_i, [_i]),
     "genpc_pose_optimize_batch": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _f, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp]),
     "genpc_pose_optimize_cd": (_i, [_i, _vp, _i, _vp, _f, _i, _i, _vp, _vp, _vp, _vp]),

@@ -38,6 +38,7 @@
 #include "../../include/genpc_hip.h"
 
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace genpc {
@@ -636,23 +637,31 @@ __global__ __launch_bounds__(kABlock, 4) void emd_auction_kernel(EmdAuction a)
 }
 
 // ---- admission of persistent launches (all workgroups of a launch must be resident together) ----
+// One transaction: persist_reserve() leaves a PENDING entry (no event yet) that already counts against the
+// budget, so two host threads cannot both pass the check in the gap between their reservation and their launch;
+// persist_commit() attaches the event behind the launch, persist_cancel() withdraws the entry when the launch did not
+// happen.  A thread that has to wait does so OUTSIDE the lock (on a copy of the oldest event's handle, or by yielding while
+// the blocker is still pending), so other lanes' commits are not held up behind it.
 struct PersistEntry { hipEvent_t ev; int wgs; hipStream_t stream; int dev; };
 static std::mutex g_persist_mu;
 static std::vector<PersistEntry> g_persist;
 static std::vector<hipEvent_t> g_persist_free;
+// the calling thread's last admitted launch was let in BESIDE other streams' persistent launches: only such a launch can fail to
+// become resident as a whole (genpc_emd_contended(): the Python layer then reads the status word and, if need be, repeats the call)
+static thread_local int t_persist_contended = 0;
 
-// Blocks until `wgs` workgroups fit beside the persistent launches still in flight on OTHER streams of the device
+// Blocks until `wgs` workgroups fit beside the persistent launches in flight (or reserved) on OTHER streams of the device
 // (launches of one stream run one after the other anyway); false if the request alone exceeds `capacity`.
 bool persist_reserve(int wgs, int capacity, hipStream_t st)
 {
     if (wgs > capacity) return false;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> l(g_persist_mu);
+    std::unique_lock<std::mutex> l(g_persist_mu);
     for (;;) {
         int used = 0, oldest = -1;
         for (size_t i = 0; i < g_persist.size();) {
-            if (g_persist[i].dev == dev && hipEventQuery(g_persist[i].ev) == hipSuccess) {
+            if (g_persist[i].dev == dev && g_persist[i].ev && hipEventQuery(g_persist[i].ev) == hipSuccess) {
                 g_persist_free.push_back(g_persist[i].ev);
                 g_persist.erase(g_persist.begin() + i);
                 continue;
@@ -663,21 +672,51 @@ bool persist_reserve(int wgs, int capacity, hipStream_t st)
             }
             i++;
         }
-        if (used + wgs <= capacity || oldest < 0) return true;
-        (void)hipEventSynchronize(g_persist[oldest].ev);
+        if (used + wgs <= capacity || oldest < 0) {
+            g_persist.push_back(PersistEntry{nullptr, wgs, st, dev});      // pending: counted from now on
+            t_persist_contended = used > 0 ? 1 : 0;
+            return true;
+        }
+        const hipEvent_t ev = g_persist[oldest].ev;      // (null: that launch is reserved, not enqueued yet)
+        l.unlock();
+        if (ev) (void)hipEventSynchronize(ev);           // (a recycled handle waits for something else or nothing: the scan above decides)
+        else std::this_thread::yield();
+        l.lock();
     }
 }
 
+// the launch reserved on `st` has been enqueued: its entry gets the event that tells when it is over
 void persist_commit(int wgs, hipStream_t st)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> l(g_persist_mu);
+    size_t at = g_persist.size();
+    for (size_t i = 0; i < g_persist.size(); i++)
+        if (g_persist[i].dev == dev && g_persist[i].stream == st && !g_persist[i].ev && g_persist[i].wgs == wgs) { at = i; break; }
+    if (at == g_persist.size()) return;                  // (nothing reserved: nothing to commit)
     hipEvent_t ev = nullptr;
     if (!g_persist_free.empty()) { ev = g_persist_free.back(); g_persist_free.pop_back(); }
-    else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
-    if (hipEventRecord(ev, st) != hipSuccess) { g_persist_free.push_back(ev); return; }
-    g_persist.push_back(PersistEntry{ev, wgs, st, dev});
+    else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+    if (!ev || hipEventRecord(ev, st) != hipSuccess) {
+        if (ev) g_persist_free.push_back(ev);
+        g_persist.erase(g_persist.begin() + at);         // (cannot be tracked: rather uncounted than counted for ever)
+        return;
+    }
+    g_persist[at].ev = ev;
+}
+
+// the launch reserved on `st` did not happen
+void persist_cancel(int wgs, hipStream_t st)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> l(g_persist_mu);
+    for (size_t i = 0; i < g_persist.size(); i++)
+        if (g_persist[i].dev == dev && g_persist[i].stream == st && !g_persist[i].ev && g_persist[i].wgs == wgs) {
+            g_persist.erase(g_persist.begin() + i);
+            return;
+        }
 }
 
 int emd_auction_capacity()
@@ -762,7 +801,10 @@ int launch_emd_auction(int b, int n, const float *xyz1, const float *xyz2, float
     static const int env_ppc = tune_env("GENPC_EMD_GRID_PPC_X10", 20, "culled EMD bid: target objects per cell x 10");
     int target = (int)((long long)n * 10 / (env_ppc > 0 ? env_ppc : 20));
     target = target < 8 ? 8 : (target > kEGMaxCells * 3 / 4 ? kEGMaxCells * 3 / 4 : target);
-    if (!launch_emd_grid_build(b, n, xyz2, price, hdr, start, sorted, pos_of, orig_of, target, kEGMaxCells, st, price_s)) return 0;
+    if (!launch_emd_grid_build(b, n, xyz2, price, hdr, start, sorted, pos_of, orig_of, target, kEGMaxCells, st, price_s)) {
+        persist_cancel(wgs, st);
+        return 0;
+    }
     EmdAuction a{};
     a.n = n; a.nb = b; a.cells_max = kEGMaxCells; a.iters = iters; a.eps = eps; a.K = K;
     a.feedback = emd_feedback_slot(b, n, true);
@@ -790,6 +832,15 @@ int launch_emd_auction(int b, int n, const float *xyz1, const float *xyz2, float
 }
 
 }  // namespace genpc
+
+/* 1 = the calling thread's last one-launch EMD call was admitted beside persistent launches of other streams (the only
+ * situation in which it can be abandoned: genpc_emd_status then tells); reading clears the flag.  No device access. */
+GENPC_API int genpc_emd_contended(void)
+{
+    const int v = genpc::t_persist_contended;
+    genpc::t_persist_contended = 0;
+    return v;
+}
 
 /* 0 = no one-launch EMD call on this stream's workspace has been abandoned since the last query (synchronises the stream);
  * 1 = one was (its dist is NaN): the launch did not become resident as a whole within the spin bound.  reset != 0 clears. */

@@ -2007,7 +2007,11 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
                        (const float *)m.stats, accum);
     // the weights per pixel as a launch of their own (the tile pass reads them from LDS tiles), or evaluated inside the gather
     static const int env_fw = tune_env("GENPC_MASK_FUSE_W", 1, "alignment loop: 1 = the silhouette gradient evaluates the per-pixel weights where it gathers them (no mask_w launch), 0 = mask_w_kernel + gather");
-    const bool fuse_w = !tile_pass && env_fw != 0;
+    // (only where the gather touches fewer pixels than ~two passes over the image: a point's disc covers ~pi rho^2 pixels, rho =
+    //  S/2 * focal * radius / 3 at the camera's distance -- 2451 points: 0.4 of the image; 16384 points: 2.9 images' worth of
+    //  weights, each 60 instructions where the launch of its own computes them once per pixel)
+    const float rho_px = 0.5f * (float)S * kMaskFocal * rad / kMaskEyeZ;
+    const bool fuse_w = !tile_pass && env_fw != 0 && (double)nc * 3.1416 * rho_px * rho_px <= 2.0 * (double)S * S;
     if (!fuse_w)
         hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, mode, (const float *)m.mref,
                            (const float *)m.stats, mask_weight, m.W1, m.W4, accum);
@@ -2168,6 +2172,19 @@ GENPC_API int genpc_render_tune(int blend)
     return prev;
 }
 
+namespace genpc { static thread_local int t_pose_dual = -1; }
+
+/* The calling host thread's alignment loops: 1 = the Chamfer half of a step on a side stream beside the silhouette half (small
+ * clouds, full objective), 0 = one stream, < 0 = the default (GENPC_POSE_DUAL, on).  pipeline.run_in_lanes switches it off in
+ * its lanes: with several scans in flight the chip is shared already and a second stream per scan costs throughput (six lanes:
+ * 30 scans/s with, 40 without; one scan alone: 45.6 ms with, 48.3 without).  Returns the previous setting. */
+GENPC_API int genpc_pose_dual(int on)
+{
+    const int prev = genpc::t_pose_dual;
+    genpc::t_pose_dual = on < 0 ? -1 : (on ? 1 : 0);
+    return prev;
+}
+
 GENPC_API int genpc_pose_tune(int seeded)
 {
     const int prev = genpc::t_pose_seeded;
@@ -2301,7 +2318,13 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // other surface over hundreds of cells (18 k instructions per wave, 4.8 ms per step against 3.0 for the filter, which
     // does not care where the points are).  Real shapes look like config 5: off by default.
     static const int env_seeded = tune_env("GENPC_POSE_SEEDED", 2, "alignment loop, nearest neighbours from the second step on: 1 = seeded cell search, 0 = brute-force filter, 2 = measure both and switch");
-    const int seed_mode = nc >= 256 && np >= 256 ? (t_pose_seeded >= 0 ? t_pose_seeded : env_seeded) : 0;
+    // (small clouds with the full objective: the nearest-neighbour launches run on the side stream beside the silhouette half
+    //  and are not what a step waits for -- the adaptive mode's timing probes, ~10 host synchronisations per call, would cost
+    //  more than either choice: the filter it is)
+    static const int env_dual0 = tune_env("GENPC_POSE_DUAL", 1, "alignment loop, full objective: 1 = the Chamfer half of a step (nearest neighbours + gradient) on a side stream beside the silhouette half, 0 = one stream");
+    const bool dual_small = mask && (t_pose_dual >= 0 ? t_pose_dual != 0 : env_dual0 != 0) && (long long)b * nc <= 24576;
+    int seed_mode = nc >= 256 && np >= 256 ? (t_pose_seeded >= 0 ? t_pose_seeded : env_seeded) : 0;
+    if (dual_small && t_pose_seeded < 0 && seed_mode == 2) seed_mode = 0;
     const bool seeded = seed_mode != 0;
     // Mode 2.  What the seeded search costs depends on the data (a query whose last answer is far away searches a large ball:
     // the hidden side of a complete shape against a one-sided scan; misaligned starts) and falls as the poses converge; the
@@ -2339,8 +2362,8 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // 32 images (8 scans x 4 starts): 96 blocks per image 153.1 ms per call, 48: 151.0, 24: 150.2, 12: 150.4
     const int g_t = lin_grid(nc), g_g = std::min(env_gb > 0 ? env_gb : (b >= 16 ? 24 : 1024), lin_grid((long long)nc + np));
     const int hstride = starts * (iters + 1);
-    static const int env_dual = tune_env("GENPC_POSE_DUAL", 1, "alignment loop, full objective: 1 = the Chamfer half of a step (nearest neighbours + gradient) on a side stream beside the silhouette half, 0 = one stream");
-    PoseSide *dual = mask && env_dual ? pose_side_of(st) : nullptr;
+    PoseSide *dual = dual_small ? pose_side_of(st) : nullptr;      // (small clouds only: where the launches fill the chip by themselves the two
+                                                                   //  halves only take each other's compute units -- 8 scans in lock-step 77.6 -> 53.2 scans/s)
     hipStream_t sn = dual ? dual->side : st;        // the stream of the nearest-neighbour launches and pose_grad
     long long dual_step = 0;
     for (int s = 0; s < starts; s++) {

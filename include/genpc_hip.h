@@ -145,6 +145,10 @@ int genpc_emd_tune(int grid, int hooks);
 /* Synchronises `stream` and returns 1 if a one-launch EMD call on it was abandoned since the last reset (its workgroups
  * did not all become resident within the spin bound; that call's dist is NaN), 0 if none, -1 on error. */
 int genpc_emd_status(int reset, void *stream);
+/* 1 = the calling host thread's last one-launch EMD call ran beside other streams' persistent launches -- the only situation in
+ * which it can be abandoned (then genpc_emd_status() == 1 and dist is NaN); reading clears the flag; no device access.
+ * genpc_amd/emd.py checks it behind every forward and repeats an abandoned call on the launch-per-round path. */
+int genpc_emd_contended(void);
 /* Counters of the culled bid, accumulated on the current device while hook 1 is set: out[0] bidder-rounds, out[1] rows
  * of their search boxes, out[2] rows kept by the bound, out[3] objects tested, out[4] exact (fp64) evaluations, out[5]
  * exact first-place ties (full re-scan), out[6] bidders without seeds (probe).  Synchronises `stream`; reset != 0 zeroes. */
@@ -329,6 +333,10 @@ int genpc_render_tune(int blend);
  * hipEventSynchronize per call on the call's stream), < 0 the default / environment GENPC_POSE_SEEDED.  Same bits in
  * every mode.  Returns the previous setting. */
 int genpc_pose_tune(int seeded);
+/* The calling host thread's alignment loops (full objective, small clouds): 1 = the Chamfer half of an Adam step -- nearest
+ * neighbours + gradient -- on a side stream beside the silhouette half, 0 = one stream, < 0 = default (GENPC_POSE_DUAL, on).
+ * Same results either way.  Returns the previous setting. */
+int genpc_pose_dual(int on);
 
 /* object_pose_optimization's loop with the FULL objective for B scans in lock-step: as
  * genpc_pose_optimize_cd_batch plus, per Adam step, the splat of the posed cloud, the mask loss

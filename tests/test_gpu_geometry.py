@@ -577,3 +577,10 @@ def test_paint_and_gather_fuzz(gp, oracle):
         oout, oimg = oracle.paint_pixels(res, opix, col, ps)
         np.testing.assert_array_equal(out.cpu().numpy(), oout, err_msg="case %d" % case)
         np.testing.assert_array_equal(img.cpu().numpy(), oimg, err_msg="case %d" % case)
+        # ... and back: every point's colour from the flipped image (ScaleAdapter.py:57-66).  Many points on a small image
+        # take the interleaved-copy gather (csrc/project.hip: one 16-byte read per point), few points the three planar reads.
+        from genpc_amd import _lib
+        got = torch.empty(n, 3, device="cuda")
+        rc = _lib.on_device_of(out, _lib.lib.genpc_gather_colors, n, _lib.ptr(pix), _lib.ptr(out), 3, res, res, _lib.ptr(got))
+        assert rc == 1
+        np.testing.assert_array_equal(got.cpu().numpy(), oracle.gather_colors(opix, oout), err_msg="case %d gather" % case)
