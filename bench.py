@@ -486,6 +486,45 @@ def cpu_baseline(a, b, budget_s=12.0):
                       % (cores, n, reps, dt)}
 
 
+def cpu_context(a, b, budget_s=4.0):
+    """The two other CPU routes SURVEY 8(d) names, for context beside the port (not the baseline): torch.cdist + min on all
+    host threads (matmul expansion: differs from the reference's direct form at ~1e-8) and scipy's cKDTree (a pruned search:
+    it does not evaluate the pairs; its rate is pairs ANSWERED per second)."""
+    import torch as T
+    out = {}
+    n, m = a.shape[1], b.shape[1]
+    try:
+        ta, tb = T.from_numpy(a[0]), T.from_numpy(b[0])
+        def cd():
+            d = T.cdist(ta, tb)
+            return d.min(1), d.min(0)
+        t0 = time.perf_counter(); cd(); dt = time.perf_counter() - t0      # (a slow host: the first call is the measurement)
+        if dt < budget_s / 2:
+            t0 = time.perf_counter(); reps = 0
+            while time.perf_counter() - t0 < budget_s and reps < 20:
+                cd(); reps += 1
+            dt = (time.perf_counter() - t0) / reps
+        out["torch_cdist_min"] = {"gpair_s": round(2.0 * n * m / dt / 1e9, 3), "ms": round(dt * 1e3, 2), "threads": T.get_num_threads()}
+    except Exception as e:
+        out["torch_cdist_min"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        from scipy.spatial import cKDTree
+        def kd():
+            cKDTree(b[0]).query(a[0], k=1, workers=-1)
+            cKDTree(a[0]).query(b[0], k=1, workers=-1)
+        t0 = time.perf_counter(); kd(); dt = time.perf_counter() - t0
+        if dt < budget_s / 2:
+            t0 = time.perf_counter(); reps = 0
+            while time.perf_counter() - t0 < budget_s and reps < 20:
+                kd(); reps += 1
+            dt = (time.perf_counter() - t0) / reps
+        out["scipy_ckdtree"] = {"equivalent_gpair_s": round(2.0 * n * m / dt / 1e9, 3), "ms": round(dt * 1e3, 2),
+                                "note": "tree build + query both ways, workers=-1; a pruned search: pairs answered, not evaluated"}
+    except Exception as e:
+        out["scipy_ckdtree"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
 def maybe_spawn(args):
     """`--gpus N` outside a torchrun environment: start the torchrun form as a CHILD process and
     exit with its code.  Runs before anything initialises a GPU (no exec from a GPU process)."""
@@ -780,7 +819,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "ranks_seen": ranks_seen,
-            "output_checked": "first and last 256 queries of both directions bit-exact vs the oracle",
+            "output_checked": "first and last 256 queries of both directions (512 of 16384 each) bit-exact vs the oracle inside this run; every distance and index of the same input: tests/test_gpu_chamfer_parity.py::test_bench_input_elementwise (-m gpu)",
             "config": {"workload": "chamfer_3DDist.forward B=1 N=M=%d (both directions), one pair per rank" % n,
                        "points": n, "batch": 1, "arith": "fma" if _lib.lib.genpc_get_arith() else "strict",
                        "sharding": "independent scans per rank, no data-path collective"},
@@ -815,6 +854,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(a_np, b_np)
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+            if isinstance(out.get("extra"), dict) and "error" not in out["extra"]:
+                out["extra"]["cpu_context_16384x16384"] = cpu_context(a_np, b_np)
         print(json.dumps(out), flush=True)
 
 
