@@ -347,6 +347,21 @@ def extras(A, B, n, dev, stream):
         "achieved": round(8 * upd / t_fps / 1e12, 2), "peak": PEAK_FP32_TFLOPS, "frac": round(8 * upd / t_fps / 1e12 / PEAK_FP32_TFLOPS, 4),
         "us_per_sequential_step": round(t_fps * 1e6 / 16384, 3), "clouds_side_by_side": 4,
         "note": "latency-bound by construction (sequential argmax chain); round 2: 2.8 us per step"}
+    # ... and the two samplings of a completed scan's tail (pipeline.complete_scan): the fused cloud 24576 -> 20000 and the
+    # metric's 20000 -> 16384, on a bundled scan's surface -- the one-workgroup pruned sampling of csrc/fps_grid.hip
+    try:
+        zf = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "scans13_fps16384.npz"))
+        surf = torch.from_numpy(np.concatenate([zf["partial"][0][:8192], zf["gt"][0]]).astype(np.float32)).to(dev)
+        for key, cloud, k in (("fps_scan_24576_to_20000_ms", surf, 20000), ("fps_scan_20000_to_16384_ms", surf[:20000].contiguous(), 16384)):
+            fps_sampling(cloud, 64)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fps_sampling(cloud, k)
+            torch.cuda.synchronize()
+            extra[key] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+    except Exception as e:
+        extra["fps_scan_error"] = "%s: %s" % (type(e).__name__, e)
     # HBM-bound streaming kernel: getUvs for the reference's 1024 cameras x 71372 points
     cfg = SimpleNamespace(device=str(dev), fovy=49.1, res=256, padding=0.15, rescale=True, point_size=1,
                           mask_pixel_rate=3, view_num=1024, distance=1.6)

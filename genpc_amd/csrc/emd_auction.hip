@@ -798,8 +798,11 @@ int launch_emd_auction(int b, int n, const float *xyz1, const float *xyz2, float
         const size_t items = total > (size_t)b * kCtrlWords ? total : (size_t)b * kCtrlWords;      // (a 256-point cloud has fewer points than control words)
         hipLaunchKernelGGL(emd_auction_init_kernel, dim3(ceil_div((int)items, kABlock)), dim3(kABlock), 0, st, b, n, ctrl, chain_head, chain_cnt, arrived);
     }
-    static const int env_ppc = tune_env("GENPC_EMD_GRID_PPC_X10", 20, "culled EMD bid: target objects per cell x 10");
-    int target = (int)((long long)n * 10 / (env_ppc > 0 ? env_ppc : 20));
+    // (six objects per cell for the one-launch kernel since round 6 -- tools/emd_env_sweep.py, 1 x 16384 / 13 x 16384 uniform: 20 -> 1.04 /
+    //  1.70 ms, 40 -> 0.95 / 1.68, 60 -> 0.89 / 1.67, 80 -> 0.89 / 1.69, 120 -> 0.93 / 1.74: a bidder's ball is a handful of
+    //  longer runs instead of dozens of short ones, each a dependent read of the cell table; the launch-per-round path keeps its own)
+    static const int env_ppc = tune_env("GENPC_EMD_AUCTION_PPC_X10", 60, "one-launch EMD: target objects per cell x 10 of the culled bid's grid");
+    int target = (int)((long long)n * 10 / (env_ppc > 0 ? env_ppc : 60));
     target = target < 8 ? 8 : (target > kEGMaxCells * 3 / 4 ? kEGMaxCells * 3 / 4 : target);
     if (!launch_emd_grid_build(b, n, xyz2, price, hdr, start, sorted, pos_of, orig_of, target, kEGMaxCells, st, price_s)) {
         persist_cancel(wgs, st);

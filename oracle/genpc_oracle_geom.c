@@ -505,6 +505,34 @@ ORACLE_API int oracle_set_blend(int blend)
 }
 static double pulsar_z(double zv) { return (PULSAR_ZFAR - zv) / (PULSAR_ZFAR - PULSAR_ZNEAR); }
 
+/* What of Pulsar's renderer is restated FROM MEMORY can be switched here, in the oracle only, so that the
+ * registration's sensitivity to those choices can be measured (tools/renderer_sensitivity.py; the kernels implement the
+ * defaults):  falloff 0: a = 1 - r^2 / rho^2 (default), 1: a = 1 - r / rho;   depth 0: the sphere's centre enters the exponent
+ * (default), 1: the ray-sphere hit, z = Zv - R sqrt(1 - r^2 / rho^2) (orthographic within the disc). */
+static int g_var_falloff = 0, g_var_depth = 0;
+ORACLE_API void oracle_set_render_variant(int falloff_linear, int depth_hit)
+{
+    g_var_falloff = falloff_linear ? 1 : 0;
+    g_var_depth = depth_hit ? 1 : 0;
+}
+/* coverage a and its derivative with respect to s = r^2 / rho^2 */
+static inline double var_cover(double s, double *da_ds)
+{
+    if (!g_var_falloff) { *da_ds = -1.0; return 1.0 - s; }
+    const double r = sqrt(s);
+    *da_ds = r > 1e-12 ? -0.5 / r : 0.0;
+    return 1.0 - r;
+}
+/* exponent z / gamma of the disc at s = r^2 / rho^2 and its derivative with respect to s (0 for the centre's depth) */
+static inline double var_ze(double zv, double radius, double s, double *dze_ds)
+{
+    if (!g_var_depth) { *dze_ds = 0.0; return pulsar_z(zv) / PULSAR_GAMMA; }
+    const double h = sqrt(s < 1.0 ? 1.0 - s : 0.0);
+    /* z_hit = zv - R h;  d z_hit / d s = R / (2 h);  z / gamma = (zfar - z_hit) / ((zfar - znear) gamma) */
+    *dze_ds = h > 1e-9 ? -(radius / (2.0 * h)) / ((PULSAR_ZFAR - PULSAR_ZNEAR) * PULSAR_GAMMA) : 0.0;
+    return pulsar_z(zv - radius * h) / PULSAR_GAMMA;
+}
+
 /* blend 1: logt[P] = m = max(eps, max_i z_i) / gamma (the exponent every weight is taken relative to), den[P] = B' + sum a e',
  * num[P*3] = sum a e' c with e' = exp(z_i / gamma - m), B' = exp(eps / gamma - m) */
 static void splat_accumulate_pulsar(int n, const float *pts, const float *col, double radius, int S, double *mexp, double *den,
@@ -519,7 +547,6 @@ static void splat_accumulate_pulsar(int n, const float *pts, const float *col, d
             const double zv = 3.0 - z;
             if (!(zv > 1e-4) || !(zv < 5.0)) continue;
             const double u = hs * (1.0 + 4.0 * x / zv), v = hs * (1.0 - 4.0 * y / zv), rho = hs * 4.0 * radius / zv;
-            const double ze = pulsar_z(zv) / PULSAR_GAMMA;
             const double cr = col ? col[(size_t)i * 3 + 0] : 1.0, cg = col ? col[(size_t)i * 3 + 1] : 1.0,
                          cb = col ? col[(size_t)i * 3 + 2] : 1.0;
             int c0 = (int)floor(u - rho - 0.5), c1 = (int)ceil(u + rho - 0.5);
@@ -531,9 +558,12 @@ static void splat_accumulate_pulsar(int n, const float *pts, const float *col, d
             for (int r = r0; r <= r1; r++)
                 for (int c = c0; c <= c1; c++) {
                     const double dx = c + 0.5 - u, dy = r + 0.5 - v;
-                    double a = 1.0 - (dx * dx + dy * dy) / (rho * rho);
+                    const double sq = (dx * dx + dy * dy) / (rho * rho);
+                    double dads, dzds;
+                    double a = var_cover(sq, &dads);
                     if (a <= 0.0) continue;
                     if (a > MASK_AMAX) a = MASK_AMAX;
+                    const double ze = var_ze(zv, radius, sq, &dzds);
                     const size_t q = (size_t)r * S + c;
                     if (pass == 0) { if (ze > mexp[q]) mexp[q] = ze; continue; }
                     const double w = a * exp(ze - mexp[q]);
@@ -752,25 +782,31 @@ ORACLE_API void oracle_pose_full_loss_grad(int nc, const float *v, const float *
         if (c1 > S - 1) c1 = S - 1;
         if (r1 > S - 1) r1 = S - 1;
         double gu = 0, gv = 0, grho = 0, gze = 0;
-        const double ze = pulsar_z(zv) / PULSAR_GAMMA;
         for (int r = r0; r <= r1; r++)
             for (int c = c0; c <= c1; c++) {
                 const double dx = c + 0.5 - u, dy = r + 0.5 - vv;
-                const double a = 1.0 - (dx * dx + dy * dy) / (rho * rho);
+                double a = 1.0 - (dx * dx + dy * dy) / (rho * rho);
                 if (g_blend) {
                     /* I_ch = N_ch / D:  d I_ch / d w_i = (c_i,ch - I_ch) / D,  w_i = a_i e_i;  d w / d a = e_i (unclamped a
-                     * only), d w / d (z / gamma) = w_i (also where a is clamped: the depth still moves the weight) */
+                     * only), d w / d (z / gamma) = w_i (also where a is clamped: the depth still moves the weight).
+                     * With s = r^2 / rho^2:  d s / d u = -2 dx / rho^2, d s / d v = -2 dy / rho^2, d s / d rho = -2 s / rho;
+                     * the default variants have d a / d s = -1 and an exponent that does not depend on s. */
+                    const double sq = (dx * dx + dy * dy) / (rho * rho);
+                    double dads, dzds;
+                    a = var_cover(sq, &dads);
                     if (a <= 0.0) continue;
                     const size_t q = (size_t)r * S + c;
+                    const double ze = var_ze(zv, rad, sq, &dzds);
                     const double e = exp(ze - logt[q]);
                     double w = 0.0;
                     for (int ch = 0; ch < 3; ch++) w += dLdI[3 * q + ch] * (ci[ch] - I[3 * q + ch]) / den[q];
-                    gze += w * (a > MASK_AMAX ? MASK_AMAX : a) * e;
-                    if (a >= MASK_AMAX) continue;
-                    w *= e;
-                    gu += w * 2.0 * dx / (rho * rho);
-                    gv += w * 2.0 * dy / (rho * rho);
-                    grho += w * 2.0 * (dx * dx + dy * dy) / (rho * rho * rho);
+                    const double ac = a > MASK_AMAX ? MASK_AMAX : a;
+                    gze += w * ac * e;
+                    /* d w_i / d s = e (d a / d s, unclamped only) + a e (d ze / d s) */
+                    const double dwds = w * e * ((a >= MASK_AMAX ? 0.0 : dads) + ac * dzds);
+                    gu += dwds * (-2.0 * dx / (rho * rho));
+                    gv += dwds * (-2.0 * dy / (rho * rho));
+                    grho += dwds * (-2.0 * sq / rho);
                     continue;
                 }
                 if (a <= 0.0 || a >= MASK_AMAX) continue;        /* clamped: no gradient */

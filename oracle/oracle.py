@@ -394,6 +394,13 @@ def set_blend(blend):
     return int(lib().oracle_set_blend(int(blend)))
 
 
+def set_render_variant(falloff_linear=0, depth_hit=0):
+    """What of Pulsar's renderer is restated from memory, switchable in the oracle only (tools/renderer_sensitivity.py):
+    falloff_linear 1: coverage 1 - r / rho instead of 1 - r^2 / rho^2; depth_hit 1: the ray-sphere hit instead of the sphere's
+    centre enters the softmax's exponent.  (0, 0) is what the kernels implement."""
+    lib().oracle_set_render_variant(int(falloff_linear), int(depth_hit))
+
+
 def splat_image(pts, radius, size, colors=None):
     """Own differentiable colour splat (genpc_oracle_geom.c, PARITY UNPINNED against Pulsar)
     -> [size, size, 3]; colors None = white."""

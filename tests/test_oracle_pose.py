@@ -221,7 +221,7 @@ def t_splat(pts, radius, S, col=None):
     return (occ[:, None] * colour).reshape(S, S, 3)
 
 
-def t_splat_pulsar(pts, radius, S, col=None):
+def t_splat_pulsar(pts, radius, S, col=None, falloff_linear=False, depth_hit=False):
     """Pulsar's published blending function (Lassner & Zollhoefer 2021, eq. 1-2) with the reference's arguments (gamma 1e-2,
     znear 1e-4, zfar 5, bg 0, opacity 1), written densely in torch ([P pixels] x [N points]) -> [S,S,3]; same camera and
     footprint as t_splat.  I = sum a e c / (B + sum a e), e = exp(z / gamma), z = (zfar - Zv) / (zfar - znear), B = exp(eps / gamma)."""
@@ -235,9 +235,14 @@ def t_splat_pulsar(pts, radius, S, col=None):
     rr, cc = torch.meshgrid(torch.arange(S, dtype=pts.dtype) + 0.5, torch.arange(S, dtype=pts.dtype) + 0.5, indexing="ij")
     dx = cc.reshape(-1, 1) - u[None]
     dy = rr.reshape(-1, 1) - v[None]
-    a = 1.0 - (dx * dx + dy * dy) / (rho * rho)[None]
+    sq = (dx * dx + dy * dy) / (rho * rho)[None]
+    a = 1.0 - (torch.sqrt(sq) if falloff_linear else sq)
     a = torch.clamp(a, min=0.0, max=0.999) * ok[None]
-    ze = ((zfar - zv) / (zfar - znear) / gamma)[None].expand_as(a)
+    if depth_hit:      # the ray-sphere hit (orthographic inside the disc) instead of the sphere's centre
+        zh = zv[None] - radius * torch.sqrt(torch.clamp(1.0 - sq, min=0.0))
+        ze = (zfar - zh) / (zfar - znear) / gamma
+    else:
+        ze = ((zfar - zv) / (zfar - znear) / gamma)[None].expand_as(a)
     live = a > 0
     m = torch.where(live, ze, torch.full_like(ze, eps / gamma)).max(dim=1).values.clamp(min=eps / gamma).detach()
     w = torch.where(live, a * torch.exp(torch.where(live, ze, m[:, None]) - m[:, None]), torch.zeros_like(a))
@@ -367,6 +372,38 @@ def test_pulsar_full_loss_gradient_matches_torch_autograd(oracle, pulsar_blend, 
     lo0, g0 = oracle.pose_full_loss_grad(v, center, params, partial, d1[0], i1[0], d2[0], i2[0], radius, S, ref0, vert_col=vcol)
     oracle.set_blend(1)
     assert abs(lo0[3] - lo[3]) > 1e-3
+
+
+@pytest.mark.parametrize("variant", [(1, 0), (0, 1), (1, 1)])
+def test_renderer_variants_match_torch(oracle, pulsar_blend, variant):
+    """The switchable from-memory choices of the renderer (oracle only: linear fall-off, ray-sphere hit depth; DESIGN.md
+    section 2, tools/renderer_sensitivity.py): image and full-objective gradient against the dense torch evaluation."""
+    fl, dh = variant
+    S, radius = 36, 0.04
+    v, partial, params = make_case(5, nc=260, npart=170)
+    rng = np.random.default_rng(51)
+    vcol, pcol = _colours(rng, len(v), 0.33), _colours(rng, len(partial))
+    center = v.astype(np.float64).mean(0).astype(np.float32)
+    oracle.set_render_variant(fl, dh)
+    try:
+        pts = oracle.pose_transform(v, center, params)
+        d1, d2, i1, i2 = oracle.chamfer_forward(pts[None], partial[None], 0)
+        ref = oracle.splat_image(partial, radius, S, pcol)
+        tref = t_splat_pulsar(torch.from_numpy(partial).double(), radius, S, torch.from_numpy(pcol).double(), bool(fl), bool(dh))
+        np.testing.assert_allclose(ref, tref.numpy(), atol=3e-6)
+        lo, g = oracle.pose_full_loss_grad(v, center, params, partial, d1[0], i1[0], d2[0], i2[0], radius, S, ref, vert_col=vcol)
+    finally:
+        oracle.set_render_variant(0, 0)
+    assert np.abs(ref - oracle.splat_image(partial, radius, S, pcol)).max() > 1e-3       # (not the default renderer's image)
+    P = torch.tensor(params.astype(np.float64), requires_grad=True)
+    tv, tc, tp = (torch.from_numpy(x.astype(np.float64)) for x in (v, center, partial))
+    cd_total, cd, ortho, tpts = t_loss(P, tv, tc, tp, torch.from_numpy(i1[0].astype(np.int64)), torch.from_numpy(i2[0].astype(np.int64)))
+    timg = t_splat_pulsar(tpts, 1.1 * radius, S, torch.from_numpy(vcol).double(), bool(fl), bool(dh))
+    ml = t_mask_loss(timg.float(), torch.from_numpy(ref)).double()
+    (cd_total + ml).backward()
+    assert abs(lo[3] - float(ml)) < 2e-4 * max(1.0, abs(float(ml)))
+    tg = P.grad.numpy()
+    np.testing.assert_allclose(g, tg, rtol=3e-3, atol=3e-3 * np.abs(tg).max())
 
 
 @pytest.mark.parametrize("coloured", [False, True])

@@ -36,10 +36,31 @@ tok["BENCH_LINE"] = ("%.0f Gpair/s (%.1f µs per step, spread %.1f–%.1f), `roo
                         d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], e["emd_fwd_n16384_eps0.005_it50_ms"],
                         e["emd_fwd_13_bundled_scans_n16384_ms"], e["emd_fwd_B13_uniform_n16384_ms"], e["metric_cd_emd_n16384_scans_per_s"],
                         os.path.relpath(sys.argv[1], ROOT) if not sys.argv[1].startswith("profiles") else sys.argv[1]))
+st_ = e["streaming_rooflines_64x32768"]
+tok["A3_FRAC"] = "%.2f" % st_["a3_chamfer_backward"]["frac"]
+tok["A3_US"] = "%.0f" % (st_["a3_chamfer_backward"]["ms_per_launch"] * 1e3)
+tok["A15_FRAC"] = "%.2f" % st_["a15_gather_colors"]["frac"]
+tok["C2_ALONE"] = "%.1f" % e["c2_pipeline_8192_scans_per_s"]
+tok["C2_FLIGHT"] = "%.1f" % e["c2_pipeline_8192_scans_in_flight_scans_per_s"]
+tok["FPS_C2_MS"] = "%.1f" % e.get("fps_scan_24576_to_20000_ms", float("nan"))
+tok["FPS_M_MS"] = "%.1f" % e.get("fps_scan_20000_to_16384_ms", float("nan"))
+tok["FPS_BIG_MS"] = "%.1f" % e["fps_4x165546_to_16384_ms"]
+tok["EMD_1"] = "%.2f" % e["emd_fwd_n16384_eps0.005_it50_ms"]
+tok["EMD_13U"] = "%.2f" % e["emd_fwd_B13_uniform_n16384_ms"]
+tok["EMD_13S"] = "%.1f" % e["emd_fwd_13_bundled_scans_n16384_ms"]
+tok["METRIC"] = "%.0f" % e["metric_cd_emd_n16384_scans_per_s"]
+tok["EMD_PPC_NOTE"] = os.environ.get("EMD_PPC_NOTE", "gives 0.95 against 1.06 ms at 1 x 16384 and is the default from this round on")
+# the renderer sensitivity table (tools/renderer_sensitivity.py)
+rs = json.load(open(os.path.join(ROOT, "profiles", "r06_renderer_sensitivity.json")))
+rows = ["  | input | fall-off | depth in the exponent | CD-L1 partial → aligned | vs default | scale | vs default | winning start |", "  |---|---|---|---|---|---|---|---|"]
+for r_ in rs["rows"]:
+    rows.append("  | %s | %s | %s | %.5f | %+.2f %% | %.4f | %+.2f %% | %d |" % (r_["case"].split(":")[0], r_["falloff"], r_["depth"], r_["cd_partial_l1"],
+                100 * r_["cd_vs_default"], r_["scale"], 100 * r_["scale_vs_default"], r_["best_start"]))
+tok["RENDER_TABLE"] = "\n".join(rows)
 s = open(os.path.join(ROOT, "tools", "DESIGN.template.md")).read()
 for k, v in tok.items():
     s = s.replace("⟨%s⟩" % k, v)
 left = [w for w in s.split("⟨")[1:]]
 assert not left, [w[:30] for w in left]
 open(os.path.join(ROOT, "DESIGN.md"), "w").write(s)
-print("DESIGN.md written")
+print("DESIGN.md written: %d bytes" % len(s.encode()))
