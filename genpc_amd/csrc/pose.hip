@@ -875,13 +875,23 @@ __device__ __attribute__((noinline)) void splat_full_scan(int n, const float4 *_
     }
 }
 
+// tools/splat_timeline.py builds a private copy of the library with -DGENPC_SPLAT_TIMELINE: thread 0 of every block stamps the
+// 100 MHz wall clock at the phase boundaries of mask_splat_kernel (nothing of this exists in the shipped library)
+#ifdef GENPC_SPLAT_TIMELINE
+__device__ unsigned long long g_splat_tl[4096 * 8];
+#define GENPC_STL(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_splat_tl[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define GENPC_STL_VAL(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_splat_tl[blockIdx.x * 8 + (k)] = (unsigned long long)(v); } while (0)
+#else
+#define GENPC_STL(k) do {} while (0)
+#define GENPC_STL_VAL(k, v) do {} while (0)
+#endif
 // 1-D grid of tiles * nb blocks (xcd_block).  col: [nb, n, 3] colours or nullptr (white).  BLEND 1: zex [nb, n] depth exponents.
 template <int BLEND>
 __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const float4 *__restrict__ uvr,
                                                                  const float *__restrict__ col, int S,
                                                                  float *__restrict__ planes, double *__restrict__ accum,
                                                                  int *__restrict__ bins, int keep_bins, int nb,
-                                                                 const float *__restrict__ zex)
+                                                                 const float *__restrict__ zex, int *__restrict__ clean = nullptr)
 {
     static_assert(kSplatBlock == 4 * kMaskTile * kMaskTile, "four threads per pixel of the tile");
     __shared__ float part[5][4][kMaskTile * kMaskTile];
@@ -890,6 +900,7 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     __shared__ float4 list_c[BLEND ? kSplatList : 1];     // blend 1: red, green, blue (list[k].w: depth exponent, or weight exp(z / gamma - m_f))
     __shared__ int s_zmm[2];                              // blend 1: a fill's largest / smallest exponent (bits)
     if (BLEND && threadIdx.x == 0) { s_zmm[0] = 0; s_zmm[1] = 0x7f800000; }
+    GENPC_STL(0);
     __shared__ int s_cnt;
     __shared__ int s_tab[kSplatPer * (kSplatBlock / kWave)];      // per (i, wave): hits, then their exclusive prefix
     const XcdBlock xb = xcd_block(((S + kMaskTile - 1) / kMaskTile) * ((S + kMaskTile - 1) / kMaskTile), nb);
@@ -936,6 +947,16 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
         if (threadIdx.x < kSplatCap) my_ent = bin_idx[threadIdx.x];      // (before the count is known: one round trip, not two)
     }
     const bool by_list = binned >= 0 && (binned <= kSplatCap || (binned <= kTileCap && n <= 32 * kRankWords));
+    GENPC_STL_VAL(7, binned + 1);
+    GENPC_STL(1);
+    // An empty tile whose pixels already hold the background leaves at once (round 6): three of four tiles of a scan's image are
+    // empty at every step, and each held a 1024-thread, 79 KB slot for 9.5 us to rewrite what was there (tools/splat_timeline.py) --
+    // the launch's other blocks waited up to 13 us for a slot.  Its sums of I and I^2 are zero: nothing to add.
+    int *clean_flag = clean && bins ? clean + (size_t)e * bins_tiles(S) + tile : nullptr;
+    if (clean_flag && binned == 0) {
+        const int was_clean = *clean_flag;          // (block-uniform; the only writer of this word is this block, below)
+        if (was_clean) { GENPC_STL(6); return; }
+    }
     if (by_list && binned > 0) {
         static_assert(kSplatCap <= kSplatBlock && kSplatCap <= kSplatList && kSplatCap <= kTileCap, "one list entry per thread and fill");
         const int L = binned, L4 = (L + 3) & ~3;
@@ -1050,6 +1071,7 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
                 }
             }
             __syncthreads();
+            GENPC_STL(2);
             bool fast = false;
             float fscale = 1.0f;
             if (BLEND) {
@@ -1093,6 +1115,7 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
                     if ((m >> st) & 1u) s_strip[st][s_wc[wave][st] + pre[st]] = (unsigned short)threadIdx.x;
                 __syncthreads();
             }
+            GENPC_STL(3);
             const int strip = wave & 3;      // (pix = tid & 255: wave w holds rows 4 (w & 3) .. + 3, share w >> 2)
             const int LS = s_stot[strip];
             for (int k2 = share; k2 < LS; k2 += 4) {
@@ -1119,6 +1142,7 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
     }
     // the count is reset for the next launch by the last kernel that reads the lists: this one, or the mask gradient's tile pass
     __syncthreads();
+    GENPC_STL(4);
     if (bins && !keep_bins && threadIdx.x == 0) bin_cnt[tile] = 0;
     // (the full scan of a tile without a usable list is a function of its own, NOT inlined: its sixteen-points-per-thread
     // bookkeeping is what overflowed the 64 registers the two-blocks-per-CU launch allows -- 59 spilled VGPRs, ten scratch
@@ -1176,6 +1200,8 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) s_I[ch][pix] = I3[ch];
     }
+    GENPC_STL(5);
+    if (clean_flag && threadIdx.x == 0) *clean_flag = binned == 0 ? 1 : 0;
     if (accum) {
         // The tile's sums of I and I^2 per channel (doubles), by ONE wave: four pixels per lane, then the wave's shuffles.
         // (All sixteen waves used to run the 72 64-bit shuffles of the reduction although only four held pixels: with two
@@ -1205,6 +1231,7 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
             }
         }
     }
+    GENPC_STL(6);
 }
 
 constexpr int kMLThreads = 1024;
@@ -1916,6 +1943,8 @@ struct MaskScratch {
     float *zex;        // [b, nmax] blend 1: the depth exponents of the projected points
     int *bins;         // [b, tiles] counts | [b, tiles, kTileCap] entries (bin_points_block)
     float4 *gpart;     // [b, nmax, kBinPer] per-tile sums of the mask gradient (mask_grad_tile_kernel)
+    int *clean;        // [b, tiles]: 1 = the tile's pixels hold the background in all five planes (mask_splat_kernel: an empty tile leaves at once)
+    size_t clean_bytes;
     size_t bins_count_bytes;
     static size_t up(size_t x) { return (x + 255) / 256 * 256; }
     static size_t side(size_t P) { size_t S = (size_t)sqrt((double)P); while (S * S < P) S++; return S; }
@@ -1928,7 +1957,7 @@ struct MaskScratch {
     {
         return up((size_t)b * 8 * 4) + up((size_t)b * P * 4) + up((size_t)b * 5 * P * 4) + up((size_t)b * P * 4) +
                up((size_t)b * P * 16) + up((size_t)b * nmax * 16) + up((size_t)b * nmax * 4) + up(bins_bytes(b, P)) +
-               up((size_t)b * nmax * kBinPer * 16);
+               up((size_t)b * nmax * kBinPer * 16) + up((size_t)b * bins_tiles((int)side(P)) * sizeof(int));
     }
     void carve(char *base, int b, size_t P, size_t nmax)
     {
@@ -1941,13 +1970,17 @@ struct MaskScratch {
         uvr = (float4 *)(base + off); off += up((size_t)b * nmax * 16);
         zex = (float *)(base + off); off += up((size_t)b * nmax * 4);
         bins = (int *)(base + off); off += up(bins_bytes(b, P));
-        gpart = (float4 *)(base + off);
+        gpart = (float4 *)(base + off); off += up((size_t)b * nmax * kBinPer * 16);
+        clean = (int *)(base + off);
+        clean_bytes = (size_t)b * bins_tiles((int)side(P)) * sizeof(int);
         bins_count_bytes = bins_bytes(b, P) ? (size_t)b * bins_tiles((int)side(P)) * sizeof(int) : 0;
     }
     // the tile counters are zero between launches (the splat kernel resets what it reads); once per API call for a
     // workspace that is new or was last used with another batch size
     bool zero_bins(hipStream_t st) const
     {
+        // (the planes of a fresh call hold anything: no tile is known to be clean)
+        if (clean_bytes && !check(hipMemsetAsync(clean, 0, clean_bytes, st), "hipMemsetAsync(tile flags)")) return false;
         return bins_count_bytes == 0 || check(hipMemsetAsync(bins, 0, bins_count_bytes, st), "hipMemsetAsync(tile counters)");
     }
 };
@@ -1961,10 +1994,10 @@ static int mask_prepare_ref(int b, int np, const float *partial, const float *pa
                        (const float *)nullptr, 0, 0, radius, S, m.uvr, use_bins(S) ? m.bins : (int *)nullptr, blend ? m.zex : (float *)nullptr);
     if (blend)
         hipLaunchKernelGGL(mask_splat_kernel<1>, dim3(mask_tiles(S) * b), dim3(kSplatBlock), 0, st, np, (const float4 *)m.uvr, partial_col,
-                           S, m.planes, (double *)nullptr, use_bins(S) ? m.bins : (int *)nullptr, 0, b, (const float *)m.zex);
+                           S, m.planes, (double *)nullptr, use_bins(S) ? m.bins : (int *)nullptr, 0, b, (const float *)m.zex, m.clean);
     else
         hipLaunchKernelGGL(mask_splat_kernel<0>, dim3(mask_tiles(S) * b), dim3(kSplatBlock), 0, st, np, (const float4 *)m.uvr, partial_col,
-                           S, m.planes, (double *)nullptr, use_bins(S) ? m.bins : (int *)nullptr, 0, b, (const float *)nullptr);
+                           S, m.planes, (double *)nullptr, use_bins(S) ? m.bins : (int *)nullptr, 0, b, (const float *)nullptr, m.clean);
     hipLaunchKernelGGL(mask_ref_kernel, dim3(b), dim3(kMLThreads), 0, st, S, (const float *)m.planes, blend ? 2 : 0, m.mref, m.stats);
     return check(hipGetLastError(), "mask reference launch") ? 1 : 0;
 }
@@ -1995,10 +2028,10 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
                            pstride, 1, rad, S, m.uvr, use_bins(S) ? m.bins : (int *)nullptr, blend ? m.zex : (float *)nullptr);
     if (blend)
         hipLaunchKernelGGL(mask_splat_kernel<1>, dim3(mask_tiles(S) * b), dim3(kSplatBlock), 0, st, nc, (const float4 *)m.uvr, complete_col,
-                           S, m.planes, accum, use_bins(S) ? m.bins : (int *)nullptr, tile_pass ? 1 : 0, b, zex);
+                           S, m.planes, accum, use_bins(S) ? m.bins : (int *)nullptr, tile_pass ? 1 : 0, b, zex, m.clean);
     else
         hipLaunchKernelGGL(mask_splat_kernel<0>, dim3(mask_tiles(S) * b), dim3(kSplatBlock), 0, st, nc, (const float4 *)m.uvr, complete_col,
-                           S, m.planes, accum, use_bins(S) ? m.bins : (int *)nullptr, tile_pass ? 1 : 0, b, zex);
+                           S, m.planes, accum, use_bins(S) ? m.bins : (int *)nullptr, tile_pass ? 1 : 0, b, zex, m.clean);
     // few blocks per image: every block ends in 22 double atomics on the image's accumulators, and 196 blocks x 22 on the
     // same addresses serialise in L2 (17.5 us for 0.2 M pixels; GENPC_MASK_SUMS_BLOCKS for A/B)
     static const int env_sb = tune_env("GENPC_MASK_SUMS_BLOCKS", 0, "alignment loop: blocks per image of mask_sums_kernel (0 = pick)");
@@ -2056,6 +2089,13 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
 
 }  // namespace genpc
 
+#ifdef GENPC_SPLAT_TIMELINE
+extern "C" __attribute__((visibility("default"))) int genpc_splat_timeline_read(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(genpc::g_splat_tl), sizeof(unsigned long long) * 4096 * 8) == hipSuccess;
+}
+#endif
+
 GENPC_API int genpc_splat_image(int n, const float *pts, const float *col, float radius, int size, float *img, void *stream)
 {
     using namespace genpc;
@@ -2072,10 +2112,10 @@ GENPC_API int genpc_splat_image(int n, const float *pts, const float *col, float
                        (const float *)nullptr, 0, 0, radius, size, m.uvr, use_bins(size) ? m.bins : (int *)nullptr, blend ? m.zex : (float *)nullptr);
     if (blend)
         hipLaunchKernelGGL(mask_splat_kernel<1>, dim3(mask_tiles(size)), dim3(kSplatBlock), 0, st, n, (const float4 *)m.uvr, col, size,
-                           m.planes, (double *)nullptr, use_bins(size) ? m.bins : (int *)nullptr, 0, 1, (const float *)m.zex);
+                           m.planes, (double *)nullptr, use_bins(size) ? m.bins : (int *)nullptr, 0, 1, (const float *)m.zex, m.clean);
     else
         hipLaunchKernelGGL(mask_splat_kernel<0>, dim3(mask_tiles(size)), dim3(kSplatBlock), 0, st, n, (const float4 *)m.uvr, col, size,
-                           m.planes, (double *)nullptr, use_bins(size) ? m.bins : (int *)nullptr, 0, 1, (const float *)nullptr);
+                           m.planes, (double *)nullptr, use_bins(size) ? m.bins : (int *)nullptr, 0, 1, (const float *)nullptr, m.clean);
     hipLaunchKernelGGL(mask_image_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, (int)P, (const float *)m.planes, img, blend ? 2 : 0);
     return check(hipGetLastError(), "splat_image launch") ? 1 : 0;
 }
