@@ -584,3 +584,24 @@ def test_paint_and_gather_fuzz(gp, oracle):
         rc = _lib.on_device_of(out, _lib.lib.genpc_gather_colors, n, _lib.ptr(pix), _lib.ptr(out), 3, res, res, _lib.ptr(got))
         assert rc == 1
         np.testing.assert_array_equal(got.cpu().numpy(), oracle.gather_colors(opix, oout), err_msg="case %d gather" % case)
+
+
+@pytest.mark.parametrize("n,res,ps", [(300000, 1000, 1), (280000, 512, 2), (262144, 130, 4)])
+def test_paint_many_points_takes_the_tile_elections(gp, oracle, n, res, ps):
+    """paintPixels with many points (csrc/project.hip: from 262144 points on, the owners are elected per 64 x 64-pixel tile in LDS
+    after a counting sort of the points by tile): img, the flipped out and the owners equal the oracle's, collisions and stamps
+    across tile borders included; uv partly out of range."""
+    torch = gp["torch"]
+    rng = np.random.default_rng(n + res)
+    uv = (rng.random((n, 2), dtype=np.float32) * 1.1 - 0.05).astype(np.float32)
+    uv[:1000] = uv[1000:2000]                       # exact collisions: the highest index wins
+    pix = gp["dp"].uvToPixels(torch.from_numpy(uv).cuda(), res)
+    opix = oracle.uv_to_pixels(uv, res)
+    np.testing.assert_array_equal(pix.cpu().numpy(), opix)
+    col = rng.random((n, 3), dtype=np.float32)
+    base = rng.random((3, res, res), dtype=np.float32)
+    img = torch.from_numpy(base.copy()).cuda()
+    out = gp["dp"].paintPixels(img, pix, torch.from_numpy(col).cuda(), ps)
+    oout, oimg = oracle.paint_pixels(res, opix, col, ps, img=base.copy())
+    np.testing.assert_array_equal(out.cpu().numpy(), oout)
+    np.testing.assert_array_equal(img.cpu().numpy(), oimg)
