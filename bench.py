@@ -77,7 +77,7 @@ def time_events(fn, reps, stream):
     return e0.elapsed_time(e1) / reps
 
 
-ROUND_TAG = "r05"          # the profiles/ tag this bench's PMC-derived numbers must come from
+ROUND_TAG = "r06"          # the profiles/ tag this bench's PMC-derived numbers must come from
 
 
 def pmc_traffic(n, kernel_prefix="nn_f16_kernel"):

@@ -5,7 +5,7 @@
 # WRITE_SIZE / SQ counter passes (separate runs: TCC has 4 slots, FETCH_SIZE takes 3; never combined
 # with a trace).  Every profiled program is `python3 <script>` directly after `--` (no wrappers).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -31,6 +31,7 @@ family streaming_64x32768 tools/prof_streaming.py
 family pose_loop_16384x8192 tools/prof_pose.py 16384 8192 20 1
 family scale_search_icp tools/prof_scale_search.py
 family fps_voxel tools/prof_fps_voxel.py
+family fps_scan_24576 tools/prof_fps_scan.py
 family hpr_64x10000 tools/prof_hpr.py small
 family hpr_2x165546 tools/prof_hpr.py big
 family hpr_1024x10000 tools/prof_hpr1024.py
