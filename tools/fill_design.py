@@ -40,6 +40,7 @@ st_ = e["streaming_rooflines_64x32768"]
 tok["A3_FRAC"] = "%.2f" % st_["a3_chamfer_backward"]["frac"]
 tok["A3_US"] = "%.0f" % (st_["a3_chamfer_backward"]["ms_per_launch"] * 1e3)
 tok["A15_FRAC"] = "%.2f" % st_["a15_gather_colors"]["frac"]
+tok["A14_FRAC"] = "%.2f" % st_["a14_paint_pixels"]["frac"]
 tok["C2_ALONE"] = "%.1f" % e["c2_pipeline_8192_scans_per_s"]
 tok["C2_FLIGHT"] = "%.1f" % e["c2_pipeline_8192_scans_in_flight_scans_per_s"]
 tok["FPS_C2_MS"] = "%.1f" % e.get("fps_scan_24576_to_20000_ms", float("nan"))
