@@ -254,7 +254,12 @@ __global__ __launch_bounds__(kGT) void fps_grid_kernel(FpsGridJobs jobs, int *__
     unsigned long long n_items = 0, n_cands = 0;
     const unsigned long long cyc0 = __builtin_readcyclecounter(), wall0 = wall_clock64();
     unsigned n_sweeps = 0, n_over = 0;
+// (tools/fps_grid_check.py --build compiles a private copy with -DGENPC_FPS_TIMELINE; the shipped kernel reads no clock)
+#ifdef GENPC_FPS_TIMELINE
 #define GENPC_GTL(i) do { const unsigned long long now_ = wall_clock64(); tl[i] += now_ - tl0; tl0 = now_; } while (0)
+#else
+#define GENPC_GTL(i) do { (void)tl; (void)tl0; } while (0)
+#endif
 
     // one work item of an update: sample j against <= 8 points of a cell
     auto apply_item = [&](unsigned item) {

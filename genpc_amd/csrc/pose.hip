@@ -2040,11 +2040,11 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
                        (const float *)m.stats, accum);
     // the weights per pixel as a launch of their own (the tile pass reads them from LDS tiles), or evaluated inside the gather
     static const int env_fw = tune_env("GENPC_MASK_FUSE_W", 1, "alignment loop: 1 = the silhouette gradient evaluates the per-pixel weights where it gathers them (no mask_w launch), 0 = mask_w_kernel + gather");
-    // (only where the gather touches fewer pixels than ~three passes over the image: a point's disc covers ~pi rho^2 pixels, rho =
+    // (only where the gather touches fewer pixels than ~three and a half passes over the image (config 2: 4493 points): a point's disc covers ~pi rho^2 pixels, rho =
     //  S/2 * focal * radius / 3 at the camera's distance -- 2451 points: 0.4 of the image; 16384 points: 2.9 images' worth of
     //  weights, each 60 instructions where the launch of its own computes them once per pixel)
     const float rho_px = 0.5f * (float)S * kMaskFocal * rad / kMaskEyeZ;
-    const bool fuse_w = !tile_pass && env_fw != 0 && (double)nc * 3.1416 * rho_px * rho_px <= 3.0 * (double)S * S;
+    const bool fuse_w = !tile_pass && env_fw != 0 && (double)nc * 3.1416 * rho_px * rho_px <= 3.5 * (double)S * S;
     if (!fuse_w)
         hipLaunchKernelGGL(mask_w_kernel, dim3(gp, b), dim3(kQBlock), 0, st, S, (const float *)m.planes, mode, (const float *)m.mref,
                            (const float *)m.stats, mask_weight, m.W1, m.W4, accum);

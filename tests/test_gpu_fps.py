@@ -57,6 +57,39 @@ def test_fps_reproduces_the_scan_fixture(fg, golden, oracle):
     assert out.shape == (4, 16384) and int(out.max()) < 165546
 
 
+def test_fps_one_workgroup_kernel_in_the_pipelines_regime(fg, oracle, golden):
+    """csrc/fps_grid.hip (clouds of up to 24576 points: one workgroup, spatially pruned updates, several samples per round) where
+    the pipeline uses it -- most of the cloud is sampled (24576 -> 20000, 20000 -> 16384 on a bundled scan's surface) -- and on
+    the inputs that stress its rules: exact ties by the thousand (a lattice: the tie path), coordinates whose spacing is a few
+    ulps (far from the origin), a plane (one layer of cells), one repeated point (the running maximum is 0 after the first
+    sample), k == n.  Every sequence equals the oracle's AND the multi-workgroup kernel's (genpc_fps_tune bit 256)."""
+    torch = fg["torch"]
+    L = fg["lib"].lib
+    g = golden("scans13_fps16384.npz")
+    rng = np.random.default_rng(3)
+    surf = np.concatenate([g["partial"][0][:8192], g["gt"][0]]).astype(np.float32)
+    cases = [("scan surface 24576 -> 20000", surf, 20000, 1), ("scan surface 20000 -> 16384", surf[:20000].copy(), 16384, 0),
+             ("uniform 8192 -> 8192", (rng.random((8192, 3), dtype=np.float32) - 0.5), 8192, 1),
+             ("lattice 12^3 x 20000 -> 3000", (rng.integers(0, 12, size=(20000, 3)) / 12.0 - 0.5).astype(np.float32), 3000, 1),
+             ("far from origin 9000 -> 9000", (rng.random((9000, 3), dtype=np.float32) * 0.01 + 1000.0).astype(np.float32), 9000, 0),
+             ("plane 5000 -> 5000", np.concatenate([rng.random((5000, 2), dtype=np.float32), np.zeros((5000, 1), np.float32)], 1), 5000, 1),
+             ("one point 300 times", np.ones((300, 3), np.float32), 300, 1), ("five points", rng.random((5, 3), dtype=np.float32), 5, 0)]
+    for name, x, k, mode in cases:
+        X = torch.from_numpy(x).cuda()
+        prev_a = L.genpc_set_arith(mode)
+        try:
+            got = fg["fps"](X, k).cpu().numpy()
+            prev = L.genpc_fps_tune(256)
+            try:
+                old = fg["fps"](X, k).cpu().numpy()
+            finally:
+                L.genpc_fps_tune(prev)
+        finally:
+            L.genpc_set_arith(prev_a)
+        np.testing.assert_array_equal(got, old, err_msg=name + " (against the multi-workgroup kernel)")
+        np.testing.assert_array_equal(got, oracle.fps(x, k, mode), err_msg=name + " (against the oracle)")
+
+
 def test_fps_bad_args(fg):
     torch = fg["torch"]
     with pytest.raises(ValueError):

@@ -1,7 +1,21 @@
 """The one-workgroup pruned sampling (csrc/fps_grid.hip) against the multi-workgroup kernel and the oracle, with times and
 rounds.   python3 tools/fps_grid_check.py [quick]"""
-import ctypes, os, sys, time
+import ctypes, os, subprocess, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+if "--build" in sys.argv:
+    # a private copy of the library whose sampling kernel stamps its phases (-DGENPC_FPS_TIMELINE): tools/_timeline/libgenpc_hip.so;
+    # run with GENPC_LIB=$PWD/tools/_timeline/libgenpc_hip.so on the GPU box (the shipped kernel reads no clock: the phase columns are 0)
+    from genpc_amd import build as B
+    B.build(verbose=False)
+    OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_timeline")
+    os.makedirs(OUT, exist_ok=True)
+    cflags = [f for f in B.FLAGS if f != "-shared"]
+    obj = os.path.join(OUT, "fps_grid.o")
+    subprocess.check_call([B.HIPCC] + cflags + ["-DGENPC_FPS_TIMELINE", "-c", os.path.join(B.CSRC, "fps_grid.hip"), "-o", obj])
+    objs = [os.path.join(B.LIBDIR, "obj", os.path.basename(x)[:-4] + ".o") for x in B.sources() if not x.endswith("fps_grid.hip")]
+    subprocess.check_call([B.HIPCC, "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + [obj] + ["-o", os.path.join(OUT, "libgenpc_hip.so")])
+    print(os.path.join(OUT, "libgenpc_hip.so"))
+    sys.exit(0)
 import numpy as np, torch
 from genpc_amd import _lib
 from genpc_amd.fps import fps_sampling
@@ -24,7 +38,7 @@ cases.append(("far from origin 9000 -> 9000", (rng.random((9000, 3), dtype=np.fl
 cases.append(("plane 5000 -> 5000", np.concatenate([rng.random((5000, 2), dtype=np.float32), np.zeros((5000, 1), np.float32)], 1), 5000))
 cases.append(("all equal 300 -> 300", np.ones((300, 3), np.float32), 300))
 cases.append(("tiny 5 -> 5", rng.random((5, 3), dtype=np.float32), 5))
-quick = len(sys.argv) > 1
+quick = "quick" in sys.argv
 for name, x, k in cases:
     X = torch.from_numpy(x).cuda()
     res = {}
