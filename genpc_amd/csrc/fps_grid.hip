@@ -125,7 +125,6 @@ __global__ __launch_bounds__(kGT) void fps_grid_kernel(FpsGridJobs jobs, int *__
     float *skey = f + 1024;                   // [kGPick] the round's samples in sampling order
     int *sidx = (int *)(f + 1088);
     float *sx = f + 1152, *sy = f + 1216, *sz = f + 1280;
-    int *conf = (int *)(f + 1344);
     int *plo = (int *)(f + 1408), *pw = (int *)(f + 1472);
     int *scand = (int *)(f + 1536);           // which candidate a sample was
     float *red = f + 1600;                    // [kGWaves * 6]
@@ -498,8 +497,7 @@ __global__ __launch_bounds__(kGT) void fps_grid_kernel(FpsGridJobs jobs, int *__
                 } else cq[t] = make_float4(0.f, 0.f, 0.f, -1.0f);
                 crank[t] = 0; cconf[t] = 0;
             }
-            if (t < kGPick) conf[t] = 1;
-            if (t == 0) sh[5] = 0;
+            if (t == 0) { sh[5] = 0; sh[1] = 0x7fffffff; }
             __syncthreads();
             GENPC_GTL(5);
             n_cands += (unsigned)count;
@@ -533,23 +531,19 @@ __global__ __launch_bounds__(kGT) void fps_grid_kernel(FpsGridJobs jobs, int *__
                 __syncthreads();
                 const int mcap = cap - Ltot;
                 if (t < kGCand) {
+                    // into sampling order (everything that could be drawn; what lies behind the first lowered candidate is ignored),
+                    // and the rank of the first lowered candidate: where the sequence stops (sh[1] was set to a large value)
                     const float4 q = cq[t];
                     const int r = crank[t];
                     if (q.w >= 0.0f && r < mcap) {
                         const int o = Ltot + r;
-                        skey[o] = q.w; sidx[o] = cidx[t]; sx[o] = q.x; sy[o] = q.y; sz[o] = q.z; conf[o] = cconf[t]; scand[o] = t;
+                        skey[o] = q.w; sidx[o] = cidx[t]; sx[o] = q.x; sy[o] = q.y; sz[o] = q.z; scand[o] = t;
+                        if (cconf[t]) atomicMin(&sh[1], r);
                     }
                 }
                 __syncthreads();
-                if (wave == 0) {
-                    const int cf = lane < mcap ? conf[Ltot + lane] : 1;
-                    const unsigned long long mask = __ballot(cf != 0);
-                    int l = mask ? (int)__ffsll((long long)mask) - 1 : kGPick;
-                    l = min(l, mcap);
-                    if (lane == 0) sh[1] = l;
-                }
-                __syncthreads();
-                const int Lsub = sh[1], alive = sh[5];
+                const int alive = sh[5];
+                const int Lsub = min(min(sh[1], alive), mcap);
                 Ltot += Lsub;
                 if (Lsub == 0 || Ltot >= cap || Lsub >= alive || subr >= 3) break;
                 // the candidates left take the new samples into their minima; the drawn ones leave the list
@@ -572,8 +566,7 @@ __global__ __launch_bounds__(kGT) void fps_grid_kernel(FpsGridJobs jobs, int *__
                     if (drawn || (kk >= 0.0f && !(kk >= theta))) cq[t].w = -1.0f;
                     crank[t] = 0; cconf[t] = 0;
                 }
-                if (t < kGPick && t >= Ltot) conf[t] = 1;
-                if (t == 0) sh[5] = 0;
+                if (t == 0) { sh[5] = 0; sh[1] = 0x7fffffff; }
                 __syncthreads();
             }
         }

@@ -2368,6 +2368,10 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     const bool dual_small = mask && (t_pose_dual >= 0 ? t_pose_dual != 0 : env_dual0 != 0) && (long long)b * nc <= 24576;
     int seed_mode = nc >= 256 && np >= 256 ? (t_pose_seeded >= 0 ? t_pose_seeded : env_seeded) : 0;
     if (dual_small && t_pose_seeded < 0 && seed_mode == 2) seed_mode = 0;
+    // ... and so it is for small clouds in general: at the post-voxel sizes of reg() (4 x 4493 against 886 points) a step's
+    // nearest-neighbour launches are ~17 us whichever way (the seeded search forced: 20.3 scans/s against 24.5), the adaptive
+    // mode's ten timing probes each drain the stream (~40 us of nothing enqueued)
+    if (t_pose_seeded < 0 && seed_mode == 2 && (long long)b * nc <= 24576) seed_mode = 0;
     const bool seeded = seed_mode != 0;
     // Mode 2.  What the seeded search costs depends on the data (a query whose last answer is far away searches a large ball:
     // the hidden side of a complete shape against a one-sided scan; misaligned starts) and falls as the poses converge; the
