@@ -2215,7 +2215,7 @@ GENPC_API int genpc_render_tune(int blend)
 namespace genpc { static thread_local int t_pose_dual = -1; }
 
 /* The calling host thread's alignment loops: 1 = the Chamfer half of a step on a side stream beside the silhouette half (small
- * clouds, full objective), 0 = one stream, < 0 = the default (GENPC_POSE_DUAL, off).  pipeline.run_in_lanes switches it off in
+ * clouds, full objective), 0 = one stream, < 0 = the default (GENPC_POSE_DUAL, on).  pipeline.run_in_lanes switches it off in
  * its lanes: with several scans in flight the chip is shared already and a second stream per scan costs throughput (six lanes:
  * 30 scans/s with, 40 without; one scan alone: 45.6 ms with, 48.3 without).  Returns the previous setting. */
 GENPC_API int genpc_pose_dual(int on)
@@ -2253,7 +2253,11 @@ static PoseSide *pose_side_of(hipStream_t st)
     auto it = table.find({dev, st});
     if (it != table.end()) return it->second->ok ? it->second : nullptr;
     PoseSide *p = new PoseSide();
-    p->ok = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess;
+    // (the highest priority class: streams of one class share a handful of hardware queues, and a side stream that lands on its
+    //  main stream's queue runs behind it instead of beside it -- tools/time_c2_streams.py; the class's queues are its own)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    p->ok = hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_hi) == hipSuccess;
     for (int i = 0; i < 4 && p->ok; i++)
         p->ok = hipEventCreateWithFlags(&p->fork[i], hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming) == hipSuccess;
@@ -2361,10 +2365,11 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // (small clouds with the full objective: the nearest-neighbour launches run on the side stream beside the silhouette half
     //  and are not what a step waits for -- the adaptive mode's timing probes, ~10 host synchronisations per call, would cost
     //  more than either choice: the filter it is)
-    // OPT-IN (GENPC_POSE_DUAL=1 / genpc_pose_dual(1)).  What it buys depends on which hardware queues the runtime happens to give the
-    // three streams of a scan (tools/time_c2_streams.py, one scan at a time: 24.4 scans/s without; 25.7 with it on the null stream,
-    // 21.2 on a stream of the caller's own, 24.9 through a lane): a 5 % gain that can turn into a 13 % loss is not a default.
-    static const int env_dual0 = tune_env("GENPC_POSE_DUAL", 0, "alignment loop, full objective: 1 = the Chamfer half of a step (nearest neighbours + gradient) on a side stream beside the silhouette half (opt-in), 0 = one stream");
+    // On by default for small clouds (GENPC_POSE_DUAL=0 / genpc_pose_dual(0): one stream).  The side stream is of the highest
+    // priority class: as a stream of the caller's class it could land on the main stream's hardware queue and run BEHIND it
+    // (tools/time_c2_streams.py, one scan at a time: 24.4 scans/s without a side stream; 25.7 with it on the null stream but 21.2
+    // on a stream of the caller's own; with its own class 25.3 / 25.9).
+    static const int env_dual0 = tune_env("GENPC_POSE_DUAL", 1, "alignment loop, full objective, small clouds: 1 = the Chamfer half of a step (nearest neighbours + gradient) on a side stream beside the silhouette half, 0 = one stream");
     const bool dual_small = mask && (t_pose_dual >= 0 ? t_pose_dual != 0 : env_dual0 != 0) && (long long)b * nc <= 24576;
     int seed_mode = nc >= 256 && np >= 256 ? (t_pose_seeded >= 0 ? t_pose_seeded : env_seeded) : 0;
     if (dual_small && t_pose_seeded < 0 && seed_mode == 2) seed_mode = 0;

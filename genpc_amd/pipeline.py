@@ -62,12 +62,12 @@ _NO_COMBINER = __import__("os").environ.get("GENPC_FPS_COMBINER", "0") != "1"   
 _SIDE_LOCK = threading.Lock()
 
 
-def _fresh_stream(dev, avoid=()):
+def _fresh_stream(dev, avoid=(), priority=0):
     """A stream that is none of ours and none of `avoid` (torch deals streams from a pool of 32 per device, round-robin: a
     new Stream() can BE an old one; two host threads driving one stream would share the library's per-stream scratch)."""
     taken = {s.cuda_stream for s in list(_SIDE.values()) + list(_LANE.values())} | {int(a) for a in avoid}
     for _ in range(64):
-        st = torch.cuda.Stream(device=dev)
+        st = torch.cuda.Stream(device=dev, priority=priority)
         if st.cuda_stream not in taken:
             return st
     raise RuntimeError("genpc_amd.pipeline: no unused stream left in torch's pool")
@@ -82,7 +82,12 @@ def _side_stream(device, main):
     key = (dev, main.cuda_stream)
     with _SIDE_LOCK:
         if key not in _SIDE:
-            _SIDE[key] = _fresh_stream(dev, avoid=(main.cuda_stream,))
+            # A stream of ANOTHER priority class: the runtime deals a class's streams onto a handful of hardware queues (four by
+            # default), and two streams that land on one queue do not overlap at all -- in a process that has made many streams
+            # (bench.py by the time it reaches this line) stage 1 then simply ran behind the tail: 20.4 scans/s where a fresh
+            # process measured 24.6.  The high-priority class has queues of its own.  (GENPC_C2_SIDE_PRIORITY=0: the old choice.)
+            prio = -1 if __import__("os").environ.get("GENPC_C2_SIDE_PRIORITY", "-1") != "0" else 0
+            _SIDE[key] = _fresh_stream(dev, avoid=(main.cuda_stream,), priority=prio)
         return _SIDE[key]
 
 

@@ -334,8 +334,8 @@ int genpc_render_tune(int blend);
  * every mode.  Returns the previous setting. */
 int genpc_pose_tune(int seeded);
 /* The calling host thread's alignment loops (full objective, small clouds): 1 = the Chamfer half of an Adam step -- nearest
- * neighbours + gradient -- on a side stream beside the silhouette half (opt-in: the gain depends on the runtime's queue
- * assignment), 0 = one stream, < 0 = default (GENPC_POSE_DUAL, off).
+ * neighbours + gradient -- on a side stream of the highest priority class beside the silhouette half, 0 = one stream,
+ * < 0 = default (GENPC_POSE_DUAL, on).
  * Same results either way.  Returns the previous setting. */
 int genpc_pose_dual(int on);
 
