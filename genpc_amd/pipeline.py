@@ -60,6 +60,7 @@ _NO_COMBINER = __import__("os").environ.get("GENPC_FPS_COMBINER", "0") != "1"   
 
 
 _SIDE_LOCK = threading.Lock()
+_TLS = threading.local()        # .lanes: how many scans the calling lane thread's run_in_lanes keeps in flight
 
 
 def _fresh_stream(dev, avoid=(), priority=0):
@@ -86,7 +87,9 @@ def _side_stream(device, main):
             # default), and two streams that land on one queue do not overlap at all -- in a process that has made many streams
             # (bench.py by the time it reaches this line) stage 1 then simply ran behind the tail: 20.4 scans/s where a fresh
             # process measured 24.6.  The high-priority class has queues of its own.  (GENPC_C2_SIDE_PRIORITY=0: the old choice.)
-            prio = -1 if __import__("os").environ.get("GENPC_C2_SIDE_PRIORITY", "-1") != "0" else 0
+            # Several scans in flight (run_in_lanes) keep the caller's class: six high-priority stage-1 streams crowd the few queues
+            # of that class (six lanes, three runs each: 46.8 scans/s with the caller's class, 44.8 with the high one).
+            prio = -1 if __import__("os").environ.get("GENPC_C2_SIDE_PRIORITY", "-1") != "0" and getattr(_TLS, "lanes", 1) <= 1 else 0
             _SIDE[key] = _fresh_stream(dev, avoid=(main.cuda_stream,), priority=prio)
         return _SIDE[key]
 
@@ -182,6 +185,7 @@ def _lane_stream(device, li):
     per call would sooner or later BE another lane's stage-1 stream -- two host threads on one stream share the library's
     scratch (that is what the memory access fault of a six-lane run after a sweep of lane counts was)."""
     dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    # (lanes on streams of alternating priority classes, to bring more hardware queues into play: 41.4 scans/s against 46.8)
     with _SIDE_LOCK:
         if (dev, li) not in _LANE:
             _LANE[(dev, li)] = _fresh_stream(dev)
@@ -206,6 +210,7 @@ def run_in_lanes(fn, items, lanes, device):
     def lane(li):
         try:
             _lib.apply_thread_state(state)
+            _TLS.lanes = lanes
             if lanes > 1:
                 # several scans in flight share the chip already: the alignment loop's second stream (csrc/pose.hip) costs
                 # throughput there (six lanes 30 scans/s with it, 40 without) where it saves a scan alone 6 % of its time
