@@ -190,17 +190,11 @@ struct PoseState {       // device-resident
 };
 constexpr int kPosePatience = 300;      // diff_obj_pose.py:530
 
-// One thread: finish the gradient (orthogonality term + 6D backward), optionally
-// take the Adam step, record the loss, clear the accumulators.
-__global__ void pose_update_kernel(int b, PoseState *__restrict__ S, double *__restrict__ accum, int nc, int np,
-                                   float cd_weight, float reg_weight, float lr, int do_step,
-                                   float *__restrict__ history_slot, int history_stride)
+// One thread, one batch element: finish the gradient (orthogonality term + 6D backward), optionally take the Adam step,
+// record the loss; `clear`: zero the element's accumulators.  S may be a private copy of the state (the fused form below).
+__device__ __forceinline__ void pose_update_one(PoseState *S, double *accum, int nc, int np, float cd_weight, float reg_weight, float lr,
+                                                int do_step, float *history_slot, bool clear)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= b) return;
-    S += e;
-    accum += (size_t)e * kAcc;
-    if (history_slot) history_slot += (size_t)e * history_stride;
     float Rf[9];
     rot6d_to_matrix(S->params, Rf);
     const double s = (double)expf(S->params[9]);
@@ -259,7 +253,8 @@ __global__ void pose_update_kernel(int b, PoseState *__restrict__ S, double *__r
     S->loss[1] = (float)cd;
     S->loss[2] = (float)err;
     S->loss[3] = (float)accum[15];
-    for (int k = 0; k < kAcc; k++) accum[k] = 0.0;
+    if (clear)
+        for (int k = 0; k < kAcc; k++) accum[k] = 0.0;
     // Early stop (diff_obj_pose.py:529-556): the reference leaves a start's loop once `patience` steps in a row failed to
     // improve its best loss.  The launches of a start are enqueued up front here, so a stopped start keeps its parameters
     // and its best loss through the remaining launches (history: NaN = "iteration not run").
@@ -286,6 +281,49 @@ __global__ void pose_update_kernel(int b, PoseState *__restrict__ S, double *__r
         const double denom = sqrt((double)S->v[k]) / sqrt(bc2) + eps;
         S->params[k] = (float)(S->params[k] - (l / bc1) * (S->m[k] / denom));
     }
+}
+
+__global__ void pose_update_kernel(int b, PoseState *__restrict__ S, double *__restrict__ accum, int nc, int np,
+                                   float cd_weight, float reg_weight, float lr, int do_step,
+                                   float *__restrict__ history_slot, int history_stride)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= b) return;
+    pose_update_one(S + e, accum + (size_t)e * kAcc, nc, np, cd_weight, reg_weight, lr, do_step,
+                    history_slot ? history_slot + (size_t)e * history_stride : (float *)nullptr, true);
+}
+
+// The update of step k fused into the transform of step k + 1 (round 6: one launch and one kernel boundary less per Adam step).
+// Every block of the transform recomputes the update of ITS batch element from the previous state and the previous step's
+// accumulators (thread 0; the same arithmetic on the same inputs: every block gets the same parameters), block 0 of the element
+// writes the new state to the OTHER state buffer (the other blocks are still reading the old one), records the loss and zeroes
+// the accumulators the new step is about to use (their last reader was the previous transform).
+struct PoseFuse {
+    const PoseState *S_in;
+    PoseState *S_out;
+    double *acc_in, *acc_zero;
+    int do_update, nc, np;
+    float lr;
+    float *history;          // slot of the step being finished (element 0), or null
+    int hstride;
+};
+__device__ __forceinline__ const float *pose_fused_params(const PoseFuse &fu, int e, const float *params, float *s_par)
+{
+    if (!fu.do_update) return params;
+    if (threadIdx.x == 0) {
+        PoseState st = fu.S_in[e];
+        const bool lead = blockIdx.x == 0;
+        pose_update_one(&st, fu.acc_in + (size_t)e * kAcc, fu.nc, fu.np, 3.0f, 0.001f, fu.lr, 1,
+                        lead && fu.history ? fu.history + (size_t)e * fu.hstride : (float *)nullptr, false);
+#pragma unroll
+        for (int k = 0; k < 10; k++) s_par[k] = st.params[k];
+        if (lead) {
+            fu.S_out[e] = st;
+            for (int k = 0; k < kAcc; k++) fu.acc_zero[(size_t)e * kAcc + k] = 0.0;
+        }
+    }
+    __syncthreads();
+    return s_par;
 }
 
 // start < 0: global init.  Otherwise begin start `start` (get_init_rot('y', 90*start),
@@ -598,8 +636,9 @@ __global__ __launch_bounds__(kQBlock) void pose_transform_project_kernel(int n, 
                                                                          const float *__restrict__ params, int pstride,
                                                                          float *__restrict__ pts, float radius, int S,
                                                                          float4 *__restrict__ uvr, int *__restrict__ bins,
-                                                                         float *__restrict__ zex)
+                                                                         float *__restrict__ zex, PoseFuse fu)
 {
+    __shared__ float s_par[10];
     const int e = blockIdx.y;
     v += (size_t)e * n * 3;
     pts += (size_t)e * n * 3;
@@ -608,7 +647,7 @@ __global__ __launch_bounds__(kQBlock) void pose_transform_project_kernel(int n, 
     int *bin_cnt = bins ? bins + (size_t)e * bins_tiles(S) : nullptr;
     int *bin_idx = bins ? bins + (size_t)gridDim.y * bins_tiles(S) + (size_t)e * bins_tiles(S) * kTileCap : nullptr;
     center += (size_t)e * cstride;
-    params += (size_t)e * pstride;
+    params = pose_fused_params(fu, e, params + (size_t)e * pstride, s_par);      // (the previous step's update, when fused)
     float R[9];
     rot6d_to_matrix(params, R);
     const float s = expf(params[9]);
@@ -2310,8 +2349,8 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // scratch: accum[b,kAcc] | state[b] | center[b,4] | pts[b,nc,3] | d1 | d2 | i1 | i2 | mask scratch
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     size_t off = 0;
-    const size_t o_acc = off; off += up((size_t)b * kAcc * sizeof(double));
-    const size_t o_state = off; off += up((size_t)b * sizeof(PoseState));
+    const size_t o_acc = off; off += up((size_t)2 * b * kAcc * sizeof(double));        // two sets: a step's sums are read by the next step's
+    const size_t o_state = off; off += up((size_t)2 * b * sizeof(PoseState));           // transform (the fused update) while that step fills the other
     const size_t o_center = off; off += up((size_t)b * 4 * sizeof(float));
     const size_t o_pts = off; off += up((size_t)b * nc * 12);
     const size_t o_d1 = off; off += up((size_t)b * nc * 4);
@@ -2335,6 +2374,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
 
     // center = mean(vert_pos) per scan (diff_obj_pose.py:362)
     if (!genpc_mean3(b, nc, complete, center, accum, st)) return 0;
+    if (!check(hipMemsetAsync(accum + (size_t)b * kAcc, 0, (size_t)b * kAcc * sizeof(double), st), "hipMemsetAsync(second accumulator set)")) return 0;
     // reference image of the partial cloud (render_reference_image, diff_obj_pose.py:108-134)
     if (mask && !mask_prepare_ref(b, np, partial, partial_col, radius, render_size, m, st)) return 0;
 
@@ -2418,17 +2458,33 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
                                                                    //  halves only take each other's compute units -- 8 scans in lock-step 77.6 -> 53.2 scans/s)
     hipStream_t sn = dual ? dual->side : st;        // the stream of the nearest-neighbour launches and pose_grad
     long long dual_step = 0;
+    static const int env_fuse_upd = tune_env("GENPC_POSE_FUSE_UPDATE", 1, "alignment loop, full objective: 1 = the Adam update of a step inside the next step's transform launch, 0 = a launch of its own");
+    const bool fuse_upd = mask && env_fuse_upd != 0 && b <= 8;      // (measured: 4 elements 25.0 -> 26.1 completed scans/s, 32 elements 75.0 -> 74.1: every block repeats the update)
+    PoseState *Sb[2] = {S, S + b};
+    double *ab[2] = {accum, accum + (size_t)b * kAcc};
     for (int s = 0; s < starts; s++) {
         if (adaptive) { probe_every = kPoseProbe; next_probe = 1; use_seeded = false; t_seeded = __builtin_inff(); }
         hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, s, lock);
         for (int it = 0; it <= iters; it++) {
-            if (mask)
+            // The update of step it - 1 rides in this step's transform (full objective; fuse_upd): state and accumulators ping-pong
+            // between two sets -- this step's kernels read Sc and add into ac, the transform read the other set and zeroed ac.
+            const int cur = fuse_upd ? (it & 1) : 0;
+            PoseState *Sc = Sb[cur];
+            double *ac = ab[cur];
+            if (mask) {
+                PoseFuse fu{};
+                if (fuse_upd && it > 0) {
+                    fu.S_in = Sb[cur ^ 1]; fu.S_out = Sc; fu.acc_in = ab[cur ^ 1]; fu.acc_zero = ac;
+                    fu.do_update = 1; fu.nc = nc; fu.np = np; fu.lr = lr;
+                    fu.history = history ? history + (size_t)s * (iters + 1) + (it - 1) : (float *)nullptr;
+                    fu.hstride = hstride;
+                }
                 hipLaunchKernelGGL(pose_transform_project_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
-                                   (const float *)center, 4, (const float *)S->params, kStateFloats, pts, 1.1f * radius, render_size,
-                                   m.uvr, use_bins(render_size) ? m.bins : (int *)nullptr, render_blend() ? m.zex : (float *)nullptr);
-            else
+                                   (const float *)center, 4, (const float *)Sc->params, kStateFloats, pts, 1.1f * radius, render_size,
+                                   m.uvr, use_bins(render_size) ? m.bins : (int *)nullptr, render_blend() ? m.zex : (float *)nullptr, fu);
+            } else
                 hipLaunchKernelGGL(pose_transform_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
-                                   (const float *)center, 4, (const float *)S->params, kStateFloats, pts);
+                                   (const float *)center, 4, (const float *)Sc->params, kStateFloats, pts);
             // steps 0 and 2 time the filter (the first one carries the call's one-off costs: the smaller of the two counts),
             // step 1 and then every probe_every-th the seeded search
             if (dual) {
@@ -2446,12 +2502,12 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
             const bool sampled = probe_s && !use_seeded;
             const bool this_seeded = seeded && it > 0 && !probe_f && use_seeded;
             if (probe) (void)hipEventRecord(ev0, sn);
-            if (sampled && launch_nn_seeded(b, nc, pts, np, partial, sg, center, 4, (const float *)S->params, kStateFloats, d1, i1, d2, i2,
+            if (sampled && launch_nn_seeded(b, nc, pts, np, partial, sg, center, 4, (const float *)Sc->params, kStateFloats, d1, i1, d2, i2,
                                             fma_mode, sn, kPoseSample) != 1)
                 return 0;
             if (sampled) (void)hipEventRecord(ev1, sn);
             if (this_seeded) {
-                if (launch_nn_seeded(b, nc, pts, np, partial, sg, center, 4, (const float *)S->params, kStateFloats, d1, i1, d2, i2, fma_mode, sn) != 1)
+                if (launch_nn_seeded(b, nc, pts, np, partial, sg, center, 4, (const float *)Sc->params, kStateFloats, d1, i1, d2, i2, fma_mode, sn) != 1)
                     return 0;
             } else if (nn_forward(b, 2, pts, nc, partial, np, d1, i1, partial, np, pts, nc, d2, i2, sn, __builtin_inff(), dup_p, dup_c) != 1) {
                 return 0;
@@ -2473,10 +2529,10 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
                 }
             }
             hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, sn, nc, complete, (const float *)center,
-                               4, (const float *)S->params, kStateFloats, np, partial, (const float *)d1,
-                               (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, accum);
-            if (mask && !mask_step(b, nc, complete, complete_col, center, 4, S->params, kStateFloats, radius, render_size,
-                                   mask_weight, m, accum, st, true))
+                               4, (const float *)Sc->params, kStateFloats, np, partial, (const float *)d1,
+                               (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, ac);
+            if (mask && !mask_step(b, nc, complete, complete_col, center, 4, Sc->params, kStateFloats, radius, render_size,
+                                   mask_weight, m, ac, st, true))
                 return 0;
             if (dual) {
                 // join: the update reads both halves' sums
@@ -2484,9 +2540,15 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
                 (void)hipStreamWaitEvent(st, dual->join[dual_step & 3], 0);
                 dual_step++;
             }
-            hipLaunchKernelGGL(pose_update_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, nc, np, 3.0f, 0.001f, lr, 1,
-                               history ? history + (size_t)s * (iters + 1) + it : (float *)nullptr, hstride);
+            // (fused: the next transform takes the update; the last step's is the launch below, in place)
+            if (!fuse_upd || it == iters)
+                hipLaunchKernelGGL(pose_update_kernel, dim3(gb), dim3(64), 0, st, b, Sc, ac, nc, np, 3.0f, 0.001f, lr, 1,
+                                   history ? history + (size_t)s * (iters + 1) + it : (float *)nullptr, hstride);
         }
+        // the start's final state back into the first set (where the kernels after the loop, and the next start, look for it)
+        if (fuse_upd && (iters & 1) && !check(hipMemcpyAsync(Sb[0], Sb[1], (size_t)b * sizeof(PoseState), hipMemcpyDeviceToDevice, st), "copy pose state")) return 0;
+        // (the set the last transform read still holds the step before last's sums: the next start begins with both sets clear)
+        if (fuse_upd && iters > 0 && !check(hipMemsetAsync(ab[(iters & 1) ^ 1], 0, (size_t)b * kAcc * sizeof(double), st), "hipMemsetAsync(accumulators)")) return 0;
         hipLaunchKernelGGL(pose_end_kernel, dim3(gb), dim3(64), 0, st, b, S, 0, (float *)nullptr, (float *)nullptr);
     }
     if (lock)
