@@ -40,6 +40,42 @@ int arith_mode();
 // pipeline.run_in_lanes started with the defaults whatever their caller had set).
 extern thread_local int t_arith, t_tune_path, t_tune_hooks, t_emd_grid, t_emd_hooks, t_pose_seeded, t_fps_legacy, t_render_blend;
 
+// Wave-wide sums on the DPP network (no LDS round trips: a __shfl_xor tree of a double is twelve ds_bpermute, ~0.25 us of
+// dependent latency per value -- 5 us of mask_sums_kernel's 12).  Call with the wave's lanes active; lanes that are not
+// contribute 0.  (round 6)
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ int dpp_or_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, false); }
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ double dpp_or_zero(double v)
+{
+    return __hiloint2double(dpp_or_zero<CTRL, ROWS>(__double2hiint(v)), dpp_or_zero<CTRL, ROWS>(__double2loint(v)));
+}
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ float dpp_or_zero(float v) { return __int_as_float(dpp_or_zero<CTRL, ROWS>(__float_as_int(v))); }
+// the sum of the wave's values, in LANE 63 (quads, half rows and rows by permutation, then row 0 -> 1 and 2 -> 3, rows 0-1 -> 2-3)
+template <typename T>
+__device__ __forceinline__ T wave_sum63(T x)
+{
+    x += dpp_or_zero<0xB1>(x);           // quad_perm [1,0,3,2]
+    x += dpp_or_zero<0x4E>(x);           // quad_perm [2,3,0,1]
+    x += dpp_or_zero<0x141>(x);          // row_half_mirror
+    x += dpp_or_zero<0x140>(x);          // row_mirror
+    x += dpp_or_zero<0x142, 0xA>(x);     // row_bcast15 into rows 1, 3
+    x += dpp_or_zero<0x143, 0xC>(x);     // row_bcast31 into rows 2, 3
+    return x;
+}
+// inclusive prefix sum over the wave's lanes
+__device__ __forceinline__ int wave_scan_incl(int x)
+{
+    x += dpp_or_zero<0x111>(x);          // row_shr 1, 2, 4, 8
+    x += dpp_or_zero<0x112>(x);
+    x += dpp_or_zero<0x114>(x);
+    x += dpp_or_zero<0x118>(x);
+    x += dpp_or_zero<0x142, 0xA>(x);
+    x += dpp_or_zero<0x143, 0xC>(x);
+    return x;
+}
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline long long ceil_div64(long long a, long long b) { return (a + b - 1) / b; }
 

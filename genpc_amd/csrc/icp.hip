@@ -402,36 +402,6 @@ __device__ __forceinline__ unsigned long long icp_scan_cell(const float4 *__rest
     return key;
 }
 
-// Wave-wide sums on the DPP network (no LDS round trips: the shuffle-tree of 17 doubles cost 7 us per pass).  Call with all lanes active.
-template <int CTRL, int ROWS = 0xf>
-__device__ __forceinline__ int icp_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, false); }
-template <int CTRL, int ROWS = 0xf>
-__device__ __forceinline__ double icp_dpp(double v)
-{
-    return __hiloint2double(icp_dpp<CTRL, ROWS>(__double2hiint(v)), icp_dpp<CTRL, ROWS>(__double2loint(v)));
-}
-// the sum of the wave's values, in lane 63 (quads, half rows and rows by permutation, then row 0 -> 1, 2 -> 3, rows 0-1 -> 2-3)
-__device__ __forceinline__ double icp_wave_sum63(double x)
-{
-    x += icp_dpp<0xB1>(x);           // quad_perm [1,0,3,2]
-    x += icp_dpp<0x4E>(x);           // quad_perm [2,3,0,1]
-    x += icp_dpp<0x141>(x);          // row_half_mirror
-    x += icp_dpp<0x140>(x);          // row_mirror
-    x += icp_dpp<0x142, 0xA>(x);     // row_bcast15 into rows 1, 3
-    x += icp_dpp<0x143, 0xC>(x);     // row_bcast31 into rows 2, 3
-    return x;
-}
-// inclusive prefix sum over the wave's lanes
-__device__ __forceinline__ int icp_wave_scan(int x)
-{
-    x += icp_dpp<0x111>(x);          // row_shr 1, 2, 4, 8
-    x += icp_dpp<0x112>(x);
-    x += icp_dpp<0x114>(x);
-    x += icp_dpp<0x118>(x);
-    x += icp_dpp<0x142, 0xA>(x);
-    x += icp_dpp<0x143, 0xC>(x);
-    return x;
-}
 #define ICP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
@@ -629,7 +599,7 @@ __global__ __launch_bounds__(kFT) void icp_fused_kernel(int ns, const float *__r
             int cnt = __popc(mask);
             ICP_WAVE_SYNC();
             for (;;) {
-                const int incl = icp_wave_scan(cnt);
+                const int incl = wave_scan_incl(cnt);
                 const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
                 if (total == 0) break;
                 int w = incl - cnt;
@@ -672,7 +642,7 @@ __global__ __launch_bounds__(kFT) void icp_fused_kernel(int ns, const float *__r
         // fixed-order reduction: the lanes on the DPP network, then the waves in order
 #pragma unroll
         for (int q = 0; q < 17; q++) {
-            const double x = icp_wave_sum63(acc[q]);
+            const double x = wave_sum63(acc[q]);
             if (lane == kWave - 1) red[q * kFWaves + wave] = x;
         }
         __syncthreads();

@@ -161,10 +161,8 @@ __global__ __launch_bounds__(kQBlock) void pose_grad_kernel(int nc, const float 
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 15; k++) {
-        double x = a[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-        if (lane == 0) red[k][wave] = x;
+        const double x = wave_sum63(a[k]);
+        if (lane == kWave - 1) red[k][wave] = x;
     }
     __syncthreads();
     if (threadIdx.x < 15) {
@@ -1258,10 +1256,10 @@ __global__ __launch_bounds__(kSplatBlock, 8) void mask_splat_kernel(int n, const
                 }
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) { s1[ch] += __shfl_xor(s1[ch], off, kWave); s2[ch] += __shfl_xor(s2[ch], off, kWave); }
+                s1[ch] = wave_sum63(s1[ch]);
+                s2[ch] = wave_sum63(s2[ch]);
             }
-            if (lane == 0) {
+            if (lane == kWave - 1) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
                     atomicAdd(&accum[16 + ch], s1[ch]);
@@ -1281,10 +1279,8 @@ __device__ __forceinline__ void block_sum4(double (&x)[4], double (*red)[kMLThre
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        double y = x[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off, kWave);
-        if (lane == 0) red[k][wave] = y;
+        const double y = wave_sum63(x[k]);
+        if (lane == kWave - 1) red[k][wave] = y;
     }
     __syncthreads();
 #pragma unroll
@@ -1425,10 +1421,8 @@ __global__ __launch_bounds__(kQBlock) void mask_image_sums_kernel(int P, const f
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        double x = a[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-        if (lane == 0) red[i][wave] = x;
+        const double x = wave_sum63(a[i]);
+        if (lane == kWave - 1) red[i][wave] = x;
     }
     __syncthreads();
     if (threadIdx.x < 6) {
@@ -1477,10 +1471,8 @@ __global__ __launch_bounds__(kQBlock) void mask_sums_kernel(int S, const float *
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < kMaskSums; i++) {
-        double x = a[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-        if (lane == 0) red[i][wave] = x;
+        const double x = wave_sum63(a[i]);
+        if (lane == kWave - 1) red[i][wave] = x;
     }
     __syncthreads();
     if (threadIdx.x < kMaskSums) {
@@ -1853,12 +1845,20 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
                 }
             }
         }
+        if (kGradSub == 8) {
+            // the eight lanes of a point: quads by permutation, then the mirror image within the eight (DPP: no LDS round trips)
+            gu += dpp_or_zero<0xB1>(gu); gu += dpp_or_zero<0x4E>(gu); gu += dpp_or_zero<0x141>(gu);
+            gv += dpp_or_zero<0xB1>(gv); gv += dpp_or_zero<0x4E>(gv); gv += dpp_or_zero<0x141>(gv);
+            gr += dpp_or_zero<0xB1>(gr); gr += dpp_or_zero<0x4E>(gr); gr += dpp_or_zero<0x141>(gr);
+            if (BLEND) { gz += dpp_or_zero<0xB1>(gz); gz += dpp_or_zero<0x4E>(gz); gz += dpp_or_zero<0x141>(gz); }
+        } else {
 #pragma unroll
-        for (int off = kGradSub / 2; off > 0; off >>= 1) {
-            gu += __shfl_xor(gu, off, kWave);
-            gv += __shfl_xor(gv, off, kWave);
-            gr += __shfl_xor(gr, off, kWave);
-            if (BLEND) gz += __shfl_xor(gz, off, kWave);
+            for (int off = kGradSub / 2; off > 0; off >>= 1) {
+                gu += __shfl_xor(gu, off, kWave);
+                gv += __shfl_xor(gv, off, kWave);
+                gr += __shfl_xor(gr, off, kWave);
+                if (BLEND) gz += __shfl_xor(gz, off, kWave);
+            }
         }
         if (!ok || sub != 0) continue;
         gu *= 2.0f * ir2; gv *= 2.0f * ir2; gr *= 2.0f * ir2 / q.rho;
@@ -1880,10 +1880,8 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 13; k++) {
-        double x = a[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-        if (lane == 0) red[k][wave] = x;
+        const double x = wave_sum63(a[k]);
+        if (lane == kWave - 1) red[k][wave] = x;
     }
     __syncthreads();
     if (threadIdx.x < 13) {
@@ -2594,10 +2592,8 @@ __global__ __launch_bounds__(kQBlock) void mean3_accum_kernel(int n, const float
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        double x = a[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-        if (lane == 0) red[k][wave] = x;
+        const double x = wave_sum63(a[k]);
+        if (lane == kWave - 1) red[k][wave] = x;
     }
     __syncthreads();
     if (threadIdx.x < 3) {
