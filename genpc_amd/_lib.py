@@ -70,6 +70,8 @@ SIGNATURES = {
     "genpc_list_code_probe": (_i, [ctypes.c_longlong, _vp, _vp, _vp, _vp]),
     "genpc_fastdiv_probe": (_i, [ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_fps_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "genpc_fps_defer": (_i, [_i]),
+    "genpc_fps_deferred_check": (_i, [_vp]),
     "genpc_fps_tune": (_i, [_i]),
     "genpc_fps_stats": (_i, [_i, _vp, _vp]),
     "genpc_fps": (_i, [_i, _i, _vp, _i, _vp, _vp]),

@@ -28,6 +28,8 @@
 // word and writes -1 to out[0]; genpc_amd/fps.py raises on it.
 #include "common.h"
 #include "../../include/genpc_hip.h"
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -697,6 +699,13 @@ __global__ void fps_poison_kernel(FpsJobs jobs, int nj)
     if (j < nj && *jobs.verr[j] != 0) { if (jobs.out[j][0] != -1) jobs.out[j][0] = -2; *jobs.verr[j] = 0; }
 }
 
+// deferred verification (below): a failed check is counted instead of poisoning a result that has left already
+__global__ void fps_count_kernel(FpsJobs jobs, int nj, int *__restrict__ violations)
+{
+    const int j = threadIdx.x;
+    if (j < nj && *jobs.verr[j] != 0) { atomicAdd(violations, 1); *jobs.verr[j] = 0; }
+}
+
 template <int FMA>
 static void launch_fps(int R, dim3 grid, hipStream_t st, const FpsJobs &jobs, FpsSlot *slots, int *err)
 {
@@ -769,6 +778,46 @@ static int fps_blocks_per_cu(int cls)
 }
 
 thread_local int t_fps_legacy = 0;
+
+// Verification OFF the caller's critical path (round 6; genpc_fps_defer).  The check of a finished sequence reads the cloud, the
+// samples and their recorded minima: ~1 ms of chip-wide kernels behind a 4-5 ms sampling, twice per completed scan.  Deferred,
+// the three arrays are copied (stream-ordered, ~0.5 MB) into a buffer of the library's own and the check runs on a side stream
+// of the lowest priority class beside whatever the caller enqueues next; a failed check is COUNTED (the indices have left by
+// then) and genpc_fps_deferred_check() hands the count to the caller, who samples again with the check in line
+// (genpc_amd/pipeline.py does, per completed scan).  Only samplings of the one-workgroup kernel (csrc/fps_grid.hip) are
+// deferred: the failures that made the check necessary were hand-offs between workgroups, which it does not have.
+thread_local int t_fps_defer = 0;
+struct FpsDeferred {
+    hipStream_t side = nullptr;
+    hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, done[4] = {nullptr, nullptr, nullptr, nullptr};
+    char *buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[4] = {0, 0, 0, 0};
+    bool used[4] = {false, false, false, false};
+    int *violations = nullptr;      // device word
+    unsigned next = 0;
+    bool ok = false;
+};
+static std::mutex g_fps_def_mu;
+static std::map<std::pair<int, hipStream_t>, FpsDeferred *> g_fps_def;
+static FpsDeferred *fps_deferred_of(hipStream_t st, bool create)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(g_fps_def_mu);
+    auto it = g_fps_def.find({dev, st});
+    if (it != g_fps_def.end()) return it->second->ok ? it->second : nullptr;
+    if (!create) return nullptr;
+    FpsDeferred *p = new FpsDeferred();
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    p->ok = hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_lo) == hipSuccess;
+    for (int i = 0; i < 4 && p->ok; i++)
+        p->ok = hipEventCreateWithFlags(&p->fork[i], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming) == hipSuccess;
+    p->ok = p->ok && hipMalloc((void **)&p->violations, sizeof(int)) == hipSuccess && hipMemset(p->violations, 0, sizeof(int)) == hipSuccess;
+    g_fps_def[{dev, st}] = p;
+    return p->ok ? p : nullptr;
+}
 
 }  // namespace genpc
 
@@ -855,7 +904,7 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
         }
     }
     // the verification of a group of clouds (fps_verify_kernel above), whichever kernel sampled them
-    auto verify = [&](const FpsJobs &jobs, int nj) {
+    auto verify = [&](const FpsJobs &jobs, int nj, hipStream_t st, float *segmin, int *violations) {
         if (!env_verify) return;
         int nmax = 1;
         for (int q = 0; q < nj; q++) nmax = jobs.n[q] > nmax ? jobs.n[q] : nmax;
@@ -869,8 +918,54 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
         }
         if (fma) hipLaunchKernelGGL((fps_verify_kernel<1, 1>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
         else hipLaunchKernelGGL((fps_verify_kernel<0, 1>), vg, dim3(kFVBlock), 0, st, jobs, segmin, nseg);
-        hipLaunchKernelGGL(fps_poison_kernel, dim3(1), dim3(kFMaxJobs), 0, st, jobs, nj);
+        if (violations) hipLaunchKernelGGL(fps_count_kernel, dim3(1), dim3(kFMaxJobs), 0, st, jobs, nj, violations);
+        else hipLaunchKernelGGL(fps_poison_kernel, dim3(1), dim3(kFMaxJobs), 0, st, jobs, nj);
     };
+    // deferred form: the group's arrays copied behind the sampling, the check on the side stream
+    auto verify_deferred = [&](const FpsJobs &jobs, int nj, FpsDeferred *d) -> bool {
+        auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+        size_t bytes = 256, pts = 0;
+        for (int q = 0; q < nj; q++) {
+            bytes += up((size_t)jobs.n[q] * 12) + 2 * up((size_t)jobs.k[q] * 4);
+            pts += (size_t)jobs.n[q];
+        }
+        bytes += up(pts * kFVMaxSeg * sizeof(float));
+        const int sl = (int)(d->next++ & 3u);
+        if (d->used[sl] && hipStreamWaitEvent(st, d->done[sl], 0) != hipSuccess) return false;       // (the slot's previous check: long finished)
+        if (d->cap[sl] < bytes) {
+            if (d->buf[sl]) {
+                if (hipStreamSynchronize(d->side) != hipSuccess || hipFree(d->buf[sl]) != hipSuccess) return false;
+                d->buf[sl] = nullptr;
+                d->cap[sl] = 0;
+            }
+            if (hipMalloc((void **)&d->buf[sl], bytes + bytes / 4) != hipSuccess) return false;
+            d->cap[sl] = bytes + bytes / 4;
+        }
+        char *b = d->buf[sl];
+        FpsJobs cp = jobs;
+        size_t off = 256, seg = 0;
+        if (hipMemsetAsync(b, 0, 256, st) != hipSuccess) return false;
+        for (int q = 0; q < nj; q++) {
+            const size_t xb = (size_t)jobs.n[q] * 12, kb = (size_t)jobs.k[q] * 4;
+            if (hipMemcpyAsync(b + off, jobs.xyz[q], xb, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+            cp.xyz[q] = (const float *)(b + off); off += up(xb);
+            if (hipMemcpyAsync(b + off, jobs.out[q], kb, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+            cp.out[q] = (int *)(b + off); off += up(kb);
+            if (hipMemcpyAsync(b + off, jobs.pdist[q], kb, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+            cp.pdist[q] = (float *)(b + off); off += up(kb);
+            // (test hook, genpc_fps_defer(2): the check's copy of one recorded minimum is zeroed -- the check must fail)
+            if (t_fps_defer == 2 && jobs.k[q] > 8 && hipMemsetAsync(cp.pdist[q] + 8, 0, sizeof(float), st) != hipSuccess) return false;
+            cp.verr[q] = (int *)b + q;
+            cp.segoff[q] = (int)seg;
+            seg += (size_t)jobs.n[q];
+        }
+        if (hipEventRecord(d->fork[sl], st) != hipSuccess || hipStreamWaitEvent(d->side, d->fork[sl], 0) != hipSuccess) return false;
+        verify(cp, nj, d->side, (float *)(b + off), d->violations);
+        if (hipEventRecord(d->done[sl], d->side) != hipSuccess) return false;
+        d->used[sl] = true;
+        return true;
+    };
+    FpsDeferred *defer = t_fps_defer && env_verify ? fps_deferred_of(st, true) : nullptr;
     if (!small.empty()) {
         if (fps_grid_run(fma, (int)small.size(), small.data(), n, k, xyz, out_idx, pd_of.data(), spt, err, st) != 1) return 0;
         for (size_t q0 = 0; q0 < small.size(); q0 += kFMaxJobs) {
@@ -886,7 +981,7 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
                 jobs.n[nj] = n[j];
                 jobs.k[nj] = k[j];
             }
-            verify(jobs, nj);
+            if (!defer || !verify_deferred(jobs, nj, defer)) verify(jobs, nj, st, segmin, nullptr);
         }
     }
     int slot0 = 0;
@@ -930,11 +1025,30 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
         if (fma) launch_fps<1>(rmax, dim3(wmax, nj), st, jobs, slots, err);
         else launch_fps<0>(rmax, dim3(wmax, nj), st, jobs, slots, err);
         if (admitted) persist_commit(units, st);
-        verify(jobs, nj);
+        verify(jobs, nj, st, segmin, nullptr);
         j0 += nj;
     }
     if (!check(hipGetLastError(), "fps launch")) return 0;
     return 1;
+}
+
+GENPC_API int genpc_fps_defer(int on)
+{
+    const int prev = genpc::t_fps_defer;
+    genpc::t_fps_defer = on == 2 ? 2 : (on ? 1 : 0);
+    return prev;
+}
+
+GENPC_API int genpc_fps_deferred_check(void *stream)
+{
+    using namespace genpc;
+    FpsDeferred *d = fps_deferred_of((hipStream_t)stream, false);
+    if (!d) return 0;
+    int v = 0;
+    if (!check(hipStreamSynchronize(d->side), "hipStreamSynchronize(fps check)")) return -1;
+    if (!check(hipMemcpy(&v, d->violations, sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy(fps check)")) return -1;
+    if (v != 0 && !check(hipMemset(d->violations, 0, sizeof(int)), "hipMemset(fps check)")) return -1;
+    return v;
 }
 
 GENPC_API int genpc_fps_stats(int c, int *rounds, void *stream)

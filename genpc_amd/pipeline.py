@@ -56,6 +56,7 @@ def fps_to(xyz, k):
 _SIDE = {}
 _LANE = {}
 _NO_OVERLAP = __import__("os").environ.get("GENPC_C2_NO_OVERLAP", "0") == "1"      # A/B switch
+_FPS_DEFER = __import__("os").environ.get("GENPC_FPS_DEFER", "1") != "0"              # A/B switch: the samplings' check beside the tail (complete_scan)
 _NO_COMBINER = __import__("os").environ.get("GENPC_FPS_COMBINER", "0") != "1"        # A/B switch (off: see run_in_lanes)
 
 
@@ -127,6 +128,31 @@ def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=No
             pred = fps_to(fused, metric_points)
             gt = gt_xyz[gt_idx.long()] if gt_idx is not None else fps_to(gt_xyz, metric_points)
             t.update(pred=pred, gt=gt, metric=evaluate_scans(pred[None].contiguous(), gt[None].contiguous())[0])
+        return t
+
+    tail_inline = tail
+
+    def tail(res):          # noqa: F811
+        # The samplings' device-side check runs BESIDE what follows them (csrc/fps.hip, genpc_fps_defer: ~1 ms of chip-wide kernels
+        # behind each of the tail's two samplings otherwise); its verdict is collected here, before anything is returned, and a
+        # failed check means the tail again with the check in line.
+        # (with several scans in flight the chip is shared already and the check's side stream only adds to the queues: six lanes
+        #  42.8 scans/s with it, 47.5 without -- in line there)
+        if not (partial_xyz.is_cuda and _FPS_DEFER) or getattr(_TLS, "lanes", 1) > 1:
+            return tail_inline(res)
+        prev = _lib.lib.genpc_fps_defer(1)
+        try:
+            t = tail_inline(res)
+        finally:
+            _lib.lib.genpc_fps_defer(prev)
+        bad = _lib.on_device_of(partial_xyz, _lib.lib.genpc_fps_deferred_check)
+        if bad < 0:
+            raise RuntimeError("genpc_fps_deferred_check failed: " + _lib.last_error())
+        if bad:
+            from . import fps as _fps
+            with _fps._stats_lock:
+                _fps.stats["failed_check"] += int(bad)
+            t = tail_inline(res)
         return t
 
     main = side = None

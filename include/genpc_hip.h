@@ -425,6 +425,16 @@ int genpc_fps(int c, int n, const float *xyz, int k, int *out_idx, void *stream)
  * xyz[C] (device pointers to [n_j,3]), out_idx[C] (device pointers to [k_j]).                    */
 int genpc_fps_multi(int c, const int *n, const int *k, const float *const *xyz,
                     int *const *out_idx, void *stream);
+/* The device-side check of finished sequences OFF the caller's critical path (calling host thread; returns the previous
+ * setting).  1: samplings of clouds the one-workgroup kernel takes (<= 24576 points) return without waiting for their check --
+ * the cloud, the indices and the recorded minima are copied (stream-ordered) and checked on a side stream of the library's own;
+ * a failed check is counted instead of poisoning out_idx[c][0].  genpc_fps_deferred_check(stream) waits for the checks of the
+ * samplings enqueued on `stream` by this device so far and returns how many failed since the last call (-1: error): when it is
+ * not 0 the caller samples again with the check in line (genpc_fps_defer(0)).  genpc_amd/pipeline.py does so once per
+ * completed scan.  0 (default): out_idx is final when the call's work on the stream is.  (2: test hook -- deferred, and the
+ * check's copy of one recorded minimum is zeroed: the check must fail, tests/test_gpu_fps.py.)                                */
+int genpc_fps_defer(int on);
+int genpc_fps_deferred_check(void *stream);
 /* Test hook (calling host thread; returns the previous setting): 1 = the pre-fix form of the sampling's workers -- pivots read
  * as per-lane LDS broadcasts and running minima lowered with PACKED fp32 instructions on register pairs, which is what drew
  * wrong samples next to other streams' matrix instructions (csrc/fps.hip; kept reachable so that

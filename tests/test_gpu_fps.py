@@ -90,6 +90,37 @@ def test_fps_one_workgroup_kernel_in_the_pipelines_regime(fg, oracle, golden):
         np.testing.assert_array_equal(got, oracle.fps(x, k, mode), err_msg=name + " (against the oracle)")
 
 
+def test_fps_check_beside_the_callers_stream(fg):
+    """genpc_fps_defer: the indices leave without waiting for the device-side check, which runs on copies on a side stream;
+    genpc_fps_deferred_check collects the verdict.  Same indices as the in-line form; a check that fails (hook 2 zeroes one
+    recorded minimum of the check's copy) is counted once and the count is then clear."""
+    torch = fg["torch"]
+    from genpc_amd import _lib
+    L = _lib.lib
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    pts = torch.rand(20000, 3, device="cuda", generator=g)
+    ref = fg["fps"](pts, 6000)
+    prev = L.genpc_fps_defer(1)
+    try:
+        for _ in range(6):          # (more calls than the ring of check buffers holds)
+            got = fg["fps"](pts, 6000)
+            assert torch.equal(got, ref)
+        assert _lib.on_device_of(pts, L.genpc_fps_deferred_check) == 0
+        L.genpc_fps_defer(2)
+        got = fg["fps"](pts, 6000)
+        assert torch.equal(got, ref)          # (the sampling itself is untouched)
+        assert _lib.on_device_of(pts, L.genpc_fps_deferred_check) == 1
+        assert _lib.on_device_of(pts, L.genpc_fps_deferred_check) == 0
+        # clouds of the many-workgroup kernel keep the in-line check
+        big = torch.rand(40000, 3, device="cuda", generator=g)
+        L.genpc_fps_defer(1)
+        assert int(fg["fps"](big, 512)[0]) == 0
+        assert _lib.on_device_of(pts, L.genpc_fps_deferred_check) == 0
+    finally:
+        L.genpc_fps_defer(prev)
+
+
 def test_fps_bad_args(fg):
     torch = fg["torch"]
     with pytest.raises(ValueError):
