@@ -13,7 +13,7 @@ tok["NN_TPAIR"] = "%.1f" % (d["value"] / 1e3)
 tok["EMD_FRAC"] = "%.3f" % e["emd_fwd_n16384_roofline"]["frac"]
 rows = []
 for k, v in e["streaming_rooflines_64x32768"].items():
-    rows.append("| %s | `%s` | %s | %.1f µs | %.0f | %.3f |" % (v["row"], v["kernel"], v["bytes_model"], v["ms_per_launch"] * 1e3, v["achieved"], v["frac"]))
+    rows.append("| %s | `%s` | %.0f | %.1f µs | %.0f | %.3f |" % (v["row"], v["kernel"], v["algorithmic_bytes"] / v["points"], v["ms_per_launch"] * 1e3, v["achieved"], v["frac"]))
 tok["STREAMING_TABLE"] = "\n".join(rows)
 u = e["get_uvs_1024x71372_roofline"]
 tok["UVS_US"] = "%.0f" % (u["ms_per_call"] * 1e3)
@@ -50,7 +50,9 @@ tok["EMD_1"] = "%.2f" % e["emd_fwd_n16384_eps0.005_it50_ms"]
 tok["EMD_13U"] = "%.2f" % e["emd_fwd_B13_uniform_n16384_ms"]
 tok["EMD_13S"] = "%.1f" % e["emd_fwd_13_bundled_scans_n16384_ms"]
 tok["METRIC"] = "%.0f" % e["metric_cd_emd_n16384_scans_per_s"]
-tok["EMD_PPC_NOTE"] = os.environ.get("EMD_PPC_NOTE", "gives 0.95 against 1.06 ms at 1 x 16384 and is the default from this round on")
+tok["REG8"] = "%.1f" % e["registration_batch8_8k_vs_16k_4x201_plus_metric_scans_per_s"]
+tok["REG6"] = "%.1f" % e["registration_8k_vs_16k_6_scans_in_flight_scans_per_s"]
+tok["EMD_PPC_NOTE"] = os.environ.get("EMD_PPC_NOTE", "four objects per cell instead of two gives 0.95 against 1.06 ms at 1 x 16384 and is the default from this round on")
 # the renderer sensitivity table (tools/renderer_sensitivity.py)
 rs = json.load(open(os.path.join(ROOT, "profiles", "r06_renderer_sensitivity.json")))
 rows = ["  | input | fall-off | depth in the exponent | CD-L1 partial → aligned | vs default | scale | vs default | winning start |", "  |---|---|---|---|---|---|---|---|"]
