@@ -198,3 +198,53 @@ def test_knn_mean_distance_fuzz(rg, oracle):
         finally:
             _lib.lib.genpc_set_arith(prev)
         np.testing.assert_array_equal(m, oracle.knn_mean_distance(P, k, mode), err_msg="case %d n %d k %d" % (case, n, k))
+
+
+def test_icp_one_workgroup_fuzz(rg, oracle):
+    """The one-workgroup solve (csrc/icp.hip icp_fused_kernel: target grid in LDS, 27-cell search) against the oracle's
+    exhaustive search on inputs that stress the grid: coordinates far from the origin, a correspondence distance far below
+    and far above the cloud's extent (cell-count cap, a single cell), sizes that are no multiple of a wave, duplicated
+    targets and a lattice (exact distance ties: the lower index must win as in the exhaustive search), a source outside the
+    target's bounding box, no inlier at all."""
+    torch = rg["torch"]
+    rng = np.random.default_rng(23)
+    base = shape(8, 2600)
+
+    def lattice(m):
+        g = np.stack(np.meshgrid(*([np.arange(m)] * 3), indexing="ij"), -1).reshape(-1, 3)
+        return (g * np.float32(0.05) - 0.3).astype(np.float32)
+
+    cases = []
+    for off in (0.0, 100.0):
+        tgt = (base + np.float32(off)).astype(np.float32)
+        src = ((base[::3].astype(np.float64) @ rot([0.1, 1, 0.3], 5.0).T) * 1.01 + 0.012 + off).astype(np.float32)
+        cases.append(("offset %g" % off, src, tgt, 0.075))
+    cases.append(("tiny max_dist", (base[::2] + np.float32(2e-4)).astype(np.float32), base, 1e-3))
+    cases.append(("huge max_dist", (base[::5] * np.float32(1.1)).astype(np.float32), base, 10.0))
+    cases.append(("ragged sizes", base[:37] + np.float32(0.01), base[:50], 0.075))
+    dup = np.concatenate([base[:1500], base[:700], base[200:400]])
+    cases.append(("duplicated targets", (base[::2] + np.float32([0.01, -0.005, 0.0])).astype(np.float32), dup, 0.075))
+    lat = lattice(13)
+    cases.append(("lattice ties", (lat[::2] + np.float32(0.025)).astype(np.float32), lat, 0.075))          # midway between lattice points
+    cases.append(("source outside", (base[::4] + np.float32([1.5, 0, 0])).astype(np.float32), base, 0.075))
+    cases.append(("partly outside", (base[::4] * np.float32(1.6)).astype(np.float32), base, 0.05))
+    for name, src, tgt, md in cases:
+        T, fit, rmse, its = rg["R"].registration_icp(torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), md)
+        oT, ofit, ormse, oits = oracle.icp(src, tgt, md)
+        assert fit == ofit and its == oits, (name, fit, ofit, its, oits)
+        np.testing.assert_allclose(T, oT, atol=1e-6 * max(1.0, float(np.abs(tgt).max())), err_msg=name)
+        assert abs(rmse - ormse) < 1e-7, name
+    # a batch of random initial transforms in one call
+    tgt = base
+    src = ((base[1::2].astype(np.float64) @ rot([0, 1, 0.2], 3.0).T) + 0.01).astype(np.float32)
+    inits = []
+    for k in range(7):
+        M = np.eye(4)
+        M[:3, :3] = rot(rng.standard_normal(3), float(rng.uniform(0, 8))) * float(rng.uniform(0.9, 1.1))
+        M[:3, 3] = rng.uniform(-0.03, 0.03, 3)
+        inits.append(M)
+    Tb, fb, rb, ib = rg["R"].registration_icp(torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), 0.075, np.stack(inits))
+    for k in range(7):
+        oT, ofit, ormse, oits = oracle.icp(src, tgt, 0.075, init=inits[k])
+        assert fb[k] == ofit and ib[k] == oits, k
+        np.testing.assert_allclose(Tb[k], oT, atol=1e-6)
