@@ -71,6 +71,7 @@ SIGNATURES = {
     "genpc_fastdiv_probe": (_i, [ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "genpc_fps_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "genpc_fps_defer": (_i, [_i]),
+    "genpc_streams_prepare": (_i, [_vp]),
     "genpc_fps_deferred_check": (_i, [_vp]),
     "genpc_fps_tune": (_i, [_i]),
     "genpc_fps_stats": (_i, [_i, _vp, _vp]),

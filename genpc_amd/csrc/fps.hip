@@ -932,6 +932,13 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
         bytes += up(pts * kFVMaxSeg * sizeof(float));
         const int sl = (int)(d->next++ & 3u);
         if (d->used[sl] && hipStreamWaitEvent(st, d->done[sl], 0) != hipSuccess) return false;       // (the slot's previous check: long finished)
+        if (d->cap[sl] == 0 && !d->used[0] && !d->used[1] && !d->used[2] && !d->used[3]) {
+            // first use: all four buffers at once (an allocation synchronises the device: not inside the caller's second and third call)
+            for (int q = 0; q < 4; q++) {
+                if (hipMalloc((void **)&d->buf[q], bytes + bytes / 4) != hipSuccess) return false;
+                d->cap[q] = bytes + bytes / 4;
+            }
+        }
         if (d->cap[sl] < bytes) {
             if (d->buf[sl]) {
                 if (hipStreamSynchronize(d->side) != hipSuccess || hipFree(d->buf[sl]) != hipSuccess) return false;
@@ -1031,6 +1038,17 @@ GENPC_API int genpc_fps_multi(int c, const int *n, const int *k, const float *co
     if (!check(hipGetLastError(), "fps launch")) return 0;
     return 1;
 }
+
+namespace genpc {
+void fps_deferred_prepare(hipStream_t st)
+{
+    FpsDeferred *d = fps_deferred_of(st, true);
+    if (d) {
+        (void)hipEventRecord(d->fork[0], d->side);
+        (void)hipStreamSynchronize(d->side);
+    }
+}
+}  // namespace genpc
 
 GENPC_API int genpc_fps_defer(int on)
 {

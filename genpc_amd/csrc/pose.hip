@@ -2303,6 +2303,26 @@ static PoseSide *pose_side_of(hipStream_t st)
 }
 }  // namespace genpc
 
+namespace genpc { void fps_deferred_prepare(hipStream_t st); }
+
+/* The side streams the library pairs with `stream` (the alignment loop's second stream, the sampling check's), made NOW and
+ * each given a first command, so that they get their hardware queues before the caller makes other streams: which queue
+ * (and which of the command processor's pipes) a stream lands on is decided when it is first used, and a completed scan
+ * whose side streams were first used after six lane streams existed ran at 26.7 scans/s against 28.9
+ * (tools/c2_after_big.py).  pipeline.run_in_lanes calls it before it makes its lanes. */
+GENPC_API int genpc_streams_prepare(void *stream)
+{
+    using namespace genpc;
+    hipStream_t st = (hipStream_t)stream;
+    PoseSide *p = pose_side_of(st);
+    if (p) {
+        (void)hipEventRecord(p->fork[0], p->side);
+        (void)hipStreamSynchronize(p->side);
+    }
+    fps_deferred_prepare(st);
+    return 1;
+}
+
 GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, const float *complete_col, int np,
                                         const float *partial, const float *partial_col, float lr, int iters, int starts,
                                         float radius, int render_size, float mask_weight, float *transform,

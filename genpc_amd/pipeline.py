@@ -95,6 +95,29 @@ def _side_stream(device, main):
         return _SIDE[key]
 
 
+def prepare_streams(device):
+    """The side streams of the single-scan path for the CURRENT stream of `device` (stage 1's, the alignment loop's, the
+    sampling check's), made and used once NOW.  Which hardware queue a stream gets is decided at its first use, and a
+    completed scan whose side streams came after six lane streams ran at 26.7 scans/s against 28.9 -- call this (or complete a
+    scan) before making other streams when single-scan latency matters.  run_in_lanes does."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return
+    with torch.cuda.device(dev):
+        main = torch.cuda.current_stream(dev)
+        prev = getattr(_TLS, "lanes", 1)
+        _TLS.lanes = 1
+        try:
+            side = _side_stream(dev, main)
+        finally:
+            _TLS.lanes = prev
+        if side.cuda_stream != main.cuda_stream:
+            with torch.cuda.stream(side):
+                torch.zeros(1, device=dev)
+            side.synchronize()
+        _lib.lib.genpc_streams_prepare(_lib._vp(main.cuda_stream))
+
+
 def complete_scan(partial_xyz, generated_xyz, generated_img, gt_xyz=None, cfg=None, dp=None, metric_points=16384,
                   fused_points=20000, cd_only_pose=False, overlap=True):
     """partial_xyz [Np,3]: the observed scan; generated_xyz [Ng,3]: points of the generated shape in
@@ -227,6 +250,7 @@ def run_in_lanes(fn, items, lanes, device):
     dev = torch.device(device)
     lanes = max(1, min(int(lanes), len(items), 8))
     caller = torch.cuda.current_stream(dev)
+    prepare_streams(dev)                 # (the single-scan path's side streams get their queues before the lanes' streams exist)
     results, errors = [None] * len(items), []
     nxt = [0]
     lock = threading.Lock()

@@ -434,6 +434,10 @@ int genpc_fps_multi(int c, const int *n, const int *k, const float *const *xyz,
  * completed scan.  0 (default): out_idx is final when the call's work on the stream is.  (2: test hook -- deferred, and the
  * check's copy of one recorded minimum is zeroed: the check must fail, tests/test_gpu_fps.py.)                                */
 int genpc_fps_defer(int on);
+/* Makes the side streams the library pairs with `stream` (alignment loop, sampling check) and gives each a first command: a
+ * stream's hardware queue is decided when it is first used, and the pairing overlaps best when these come before other
+ * streams of the process (csrc/pose.hip).  Optional; pipeline.run_in_lanes calls it before making its lanes.  Returns 1. */
+int genpc_streams_prepare(void *stream);
 int genpc_fps_deferred_check(void *stream);
 /* Test hook (calling host thread; returns the previous setting): 1 = the pre-fix form of the sampling's workers -- pivots read
  * as per-lane LDS broadcasts and running minima lowered with PACKED fp32 instructions on register pairs, which is what drew
