@@ -99,6 +99,34 @@ __global__ __launch_bounds__(kQBlock) void pose_transform_kernel(int n, const fl
     }
 }
 
+// Waiting for a count another stream's kernel publishes (bounded: ~2 s; a wait that gives up marks ctr[2] and the results of the call
+// become NaN).  Acquire: what the counted blocks wrote before their increment is visible afterwards.
+__device__ __forceinline__ bool pose_wait_count(unsigned *ctr, int which, unsigned target)
+{
+    for (long long spin = 0; spin < (1ll << 24); spin++) {
+        if ((int)(__hip_atomic_load(ctr + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __hip_atomic_store(ctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+// every block of a counted launch, after its work: what it wrote is visible to whoever sees the count
+__device__ __forceinline__ void pose_publish_block(unsigned *ctr, int which)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        __hip_atomic_fetch_add(ctr + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__global__ void pose_wait_kernel(unsigned *ctr, int which, unsigned target)
+{
+    if (threadIdx.x == 0) (void)pose_wait_count(ctr, which, target);
+}
+
 // accum[0..8] = dL/dR (row-major), [9] = dL/ds, [10..12] = dL/dt, [13] = sum sqrt(d1),
 // [14] = sum sqrt(d2).  Thread t < nc: term of complete point t (pts -> partial);
 // nc <= t < nc+np: term of partial point t-nc (partial -> pts), attributed to the
@@ -109,7 +137,7 @@ __global__ __launch_bounds__(kQBlock) void pose_grad_kernel(int nc, const float 
                                                             const float *__restrict__ partial,
                                                             const float *__restrict__ d1, const int *__restrict__ i1,
                                                             const float *__restrict__ d2, const int *__restrict__ i2,
-                                                            float cd_weight, double *__restrict__ accum)
+                                                            float cd_weight, double *__restrict__ accum, unsigned *ctr)
 {
     __shared__ double red[15][kQBlock / kWave];
     const int e = blockIdx.y;
@@ -171,6 +199,7 @@ __global__ __launch_bounds__(kQBlock) void pose_grad_kernel(int nc, const float 
         for (int w2 = 0; w2 < kQBlock / kWave; w2++) x += red[threadIdx.x][w2];
         atomicAdd(&accum[threadIdx.x], x);
     }
+    if (ctr) pose_publish_block(ctr, 1);
 }
 
 struct PoseState {       // device-resident
@@ -304,15 +333,24 @@ struct PoseFuse {
     float lr;
     float *history;          // slot of the step being finished (element 0), or null
     int hstride;
+    // the hand-over between the loop's two streams through device words instead of events (below): ctr[0] counts finished blocks of
+    // the transforms, ctr[1] of pose_grad, ctr[2] != 0: a wait gave up
+    unsigned *ctr;
+    unsigned pg_target;      // the update waits for ctr[1] to reach this (the Chamfer half's sums are complete)
 };
+
 __device__ __forceinline__ const float *pose_fused_params(const PoseFuse &fu, int e, const float *params, float *s_par)
 {
     if (!fu.do_update) return params;
     if (threadIdx.x == 0) {
+        bool gave_up = false;
+        if (fu.ctr) gave_up = !pose_wait_count(fu.ctr, 1, fu.pg_target) || __hip_atomic_load(fu.ctr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         PoseState st = fu.S_in[e];
         const bool lead = blockIdx.x == 0;
         pose_update_one(&st, fu.acc_in + (size_t)e * kAcc, fu.nc, fu.np, 3.0f, 0.001f, fu.lr, 1,
                         lead && fu.history ? fu.history + (size_t)e * fu.hstride : (float *)nullptr, false);
+        if (gave_up)
+            for (int k = 0; k < 10; k++) st.params[k] = __builtin_nanf("");          // (a hand-over that timed out: visibly)
 #pragma unroll
         for (int k = 0; k < 10; k++) s_par[k] = st.params[k];
         if (lead) {
@@ -669,6 +707,7 @@ __global__ __launch_bounds__(kQBlock) void pose_transform_project_kernel(int n, 
         }
         if (bin_cnt) bin_points_block(bin_cnt, bin_idx, s_cnt, s_base, S, valid && q.ok, j, q.u, q.v, q.rho);
     }
+    if (fu.ctr) pose_publish_block(fu.ctr, 0);
 }
 
 // The image of a scan is kept as five planes of P = S * S floats: T, D, N_r, N_g, N_b (header comment).
@@ -2207,7 +2246,7 @@ GENPC_API int genpc_pose_loss_grad(int nc, const float *v, const float *vert_col
     if (!check(hipMemcpyAsync(S->params, params, 10 * sizeof(float), hipMemcpyDeviceToDevice, st), "copy params"))
         return 0;
     hipLaunchKernelGGL(pose_grad_kernel, dim3(lin_grid((long long)nc + np), 1), dim3(kQBlock), 0, st, nc, v, center, 0,
-                       params, 0, np, partial, d1, i1, d2, i2, cd_weight, accum);
+                       params, 0, np, partial, d1, i1, d2, i2, cd_weight, accum, (unsigned *)nullptr);
     if (mask) {
         if (!mask_prepare_ref(1, np, partial, partial_col, radius, render_size, m, st)) return 0;
         if (!mask_step(1, nc, v, vert_col, center, 0, params, 0, radius, render_size, mask_weight, m, accum, st)) return 0;
@@ -2279,6 +2318,11 @@ struct PoseSide {
     hipStream_t side = nullptr;
     hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ok = false;
+    // hand-over through device words (pose_wait_count / pose_publish_block): counts that only grow, so nothing is reset between steps,
+    // starts or calls; a call that returned early leaves `dirty` set and the next one starts from a synchronised, zeroed state
+    unsigned *ctr = nullptr;
+    unsigned tp_count = 0, pg_count = 0;
+    bool dirty = false;
 };
 static PoseSide *pose_side_of(hipStream_t st)
 {
@@ -2298,6 +2342,8 @@ static PoseSide *pose_side_of(hipStream_t st)
     for (int i = 0; i < 4 && p->ok; i++)
         p->ok = hipEventCreateWithFlags(&p->fork[i], hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming) == hipSuccess;
+    if (p->ok && (hipMalloc((void **)&p->ctr, 4 * sizeof(unsigned)) != hipSuccess || hipMemset(p->ctr, 0, 4 * sizeof(unsigned)) != hipSuccess))
+        p->ctr = nullptr;          // (the events still work)
     table[{dev, st}] = p;
     return p->ok ? p : nullptr;
 }
@@ -2480,6 +2526,23 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     const bool fuse_upd = mask && env_fuse_upd != 0 && b <= 8;      // (measured: 4 elements 25.0 -> 26.1 completed scans/s, 32 elements 75.0 -> 74.1: every block repeats the update)
     PoseState *Sb[2] = {S, S + b};
     double *ab[2] = {accum, accum + (size_t)b * kAcc};
+    // The two streams of a step hand over through DEVICE WORDS, not events (round 6): an event record between the transform and
+    // the splat and an event wait in front of the next transform each put ~3 us of command-processor latency on the step's critical
+    // path (14.1 -> 12.2 ms per 201 steps without them, measured with the ordering switched off).  The transform's blocks count
+    // themselves finished (release), a one-wave kernel on the side stream waits for that count in front of the Chamfer half;
+    // pose_grad's blocks count themselves, and thread 0 of every block of the NEXT transform waits for that count before it reads
+    // the sums (the fused update).  The last step of a start joins through an event as before (its update is a launch of its own).
+    static const int env_dual_flags = tune_env("GENPC_POSE_DUAL_FLAGS", 1, "alignment loop with a side stream: 1 = the streams hand over through device counters, 0 = through events");
+    const bool flags = dual && fuse_upd && env_dual_flags != 0 && dual->ctr != nullptr;
+    if (flags) {
+        if (dual->dirty) {          // an earlier call left early: counts and expectations may disagree
+            if (!check(hipStreamSynchronize(st), "hipStreamSynchronize") || !check(hipStreamSynchronize(dual->side), "hipStreamSynchronize") ||
+                !check(hipMemset(dual->ctr, 0, 4 * sizeof(unsigned)), "hipMemset(counters)"))
+                return 0;
+            dual->tp_count = dual->pg_count = 0;
+        }
+        dual->dirty = true;
+    }
     for (int s = 0; s < starts; s++) {
         if (adaptive) { probe_every = kPoseProbe; next_probe = 1; use_seeded = false; t_seeded = __builtin_inff(); }
         hipLaunchKernelGGL(pose_begin_kernel, dim3(gb), dim3(64), 0, st, b, S, accum, s, lock);
@@ -2496,7 +2559,9 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
                     fu.do_update = 1; fu.nc = nc; fu.np = np; fu.lr = lr;
                     fu.history = history ? history + (size_t)s * (iters + 1) + (it - 1) : (float *)nullptr;
                     fu.hstride = hstride;
+                    fu.pg_target = flags ? dual->pg_count : 0u;
                 }
+                fu.ctr = flags ? dual->ctr : (unsigned *)nullptr;
                 hipLaunchKernelGGL(pose_transform_project_kernel, dim3(g_t, b), dim3(kQBlock), 0, st, nc, complete,
                                    (const float *)center, 4, (const float *)Sc->params, kStateFloats, pts, 1.1f * radius, render_size,
                                    m.uvr, use_bins(render_size) ? m.bins : (int *)nullptr, render_blend() ? m.zex : (float *)nullptr, fu);
@@ -2505,7 +2570,10 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
                                    (const float *)center, 4, (const float *)Sc->params, kStateFloats, pts);
             // steps 0 and 2 time the filter (the first one carries the call's one-off costs: the smaller of the two counts),
             // step 1 and then every probe_every-th the seeded search
-            if (dual) {
+            if (flags) {
+                dual->tp_count += (unsigned)g_t * (unsigned)b;
+                hipLaunchKernelGGL(pose_wait_kernel, dim3(1), dim3(kWave), 0, sn, dual->ctr, 0, dual->tp_count);
+            } else if (dual) {
                 // fork: the side stream's launches of this step wait for the transform
                 (void)hipEventRecord(dual->fork[dual_step & 3], st);
                 (void)hipStreamWaitEvent(sn, dual->fork[dual_step & 3], 0);
@@ -2548,11 +2616,12 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
             }
             hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, sn, nc, complete, (const float *)center,
                                4, (const float *)Sc->params, kStateFloats, np, partial, (const float *)d1,
-                               (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, ac);
+                               (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, ac, flags ? dual->ctr : (unsigned *)nullptr);
+            if (flags) dual->pg_count += (unsigned)g_g * (unsigned)b;
             if (mask && !mask_step(b, nc, complete, complete_col, center, 4, Sc->params, kStateFloats, radius, render_size,
                                    mask_weight, m, ac, st, true))
                 return 0;
-            if (dual) {
+            if (dual && (!flags || it == iters)) {
                 // join: the update reads both halves' sums
                 (void)hipEventRecord(dual->join[dual_step & 3], sn);
                 (void)hipStreamWaitEvent(st, dual->join[dual_step & 3], 0);
@@ -2574,6 +2643,7 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
                            best_params);
     else
         hipLaunchKernelGGL(pose_end_kernel, dim3(gb), dim3(64), 0, st, b, S, 1, transform, best_params);
+    if (flags) dual->dirty = false;          // (every launch of the call has been enqueued: counts and expectations agree)
     return check(hipGetLastError(), "pose_optimize launch") ? 1 : 0;
 }
 

@@ -37,8 +37,8 @@ print("RESULT" + json.dumps(out))
 ''' % ROOT
 
 
-def _run(fuse, lockstep):
-    env = dict(os.environ, GENPC_POSE_FUSE_UPDATE=str(fuse), GENPC_POSE_LOCKSTEP=str(lockstep))
+def _run(fuse, lockstep, flags=1):
+    env = dict(os.environ, GENPC_POSE_FUSE_UPDATE=str(fuse), GENPC_POSE_LOCKSTEP=str(lockstep), GENPC_POSE_DUAL_FLAGS=str(flags))
     p = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1]
@@ -47,10 +47,11 @@ def _run(fuse, lockstep):
 
 def test_update_forms_agree():
     ref = _run(0, 1)
-    for fuse, lockstep in ((1, 1), (1, 0), (0, 0)):
-        got = _run(fuse, lockstep)
+    # (the last form: the loop's two streams hand over through events instead of device counters, csrc/pose.hip GENPC_POSE_DUAL_FLAGS)
+    for fuse, lockstep, flags in ((1, 1, 1), (1, 0, 1), (0, 0, 1), (1, 1, 0)):
+        got = _run(fuse, lockstep, flags)
         for iters in ("7", "8"):
             h, hr = np.array(got[iters]["hist"]), np.array(ref[iters]["hist"])
             assert h.shape == hr.shape == (4, int(iters) + 1) and np.isfinite(h).all()
-            np.testing.assert_allclose(h, hr, rtol=2e-5, err_msg="fuse %d lockstep %d iters %s" % (fuse, lockstep, iters))
+            np.testing.assert_allclose(h, hr, rtol=2e-5, err_msg="fuse %d lockstep %d flags %d iters %s" % (fuse, lockstep, flags, iters))
             np.testing.assert_allclose(np.array(got[iters]["T"]), np.array(ref[iters]["T"]), atol=2e-5)
