@@ -250,7 +250,8 @@ def run_in_lanes(fn, items, lanes, device):
     dev = torch.device(device)
     lanes = max(1, min(int(lanes), len(items), 8))
     caller = torch.cuda.current_stream(dev)
-    prepare_streams(dev)                 # (the single-scan path's side streams get their queues before the lanes' streams exist)
+    if __import__("os").environ.get("GENPC_PREPARE_STREAMS", "1") != "0":
+        prepare_streams(dev)             # (the single-scan path's side streams get their queues before the lanes' streams exist)
     results, errors = [None] * len(items), []
     nxt = [0]
     lock = threading.Lock()

@@ -36,15 +36,16 @@ def registration_icp(source, target, max_correspondence_distance, init=None, max
         init = np.eye(4)
     init_t = torch.as_tensor(np.asarray(init, np.float64)).reshape(-1, 4, 4).contiguous().to(dev)
     k = init_t.shape[0]
-    out_T = torch.empty(k, 16, dtype=torch.float64, device=dev)
-    stats = torch.empty(k, 3, dtype=torch.float64, device=dev)
+    buf = torch.empty(k * 19, dtype=torch.float64, device=dev)          # transforms and statistics: one copy back
+    out_T, stats = buf[:k * 16], buf[k * 16:]
     rc = _lib.on_device_of(source, _L.genpc_icp_batch, k, source.shape[0], _p(source), target.shape[0], _p(target),
                            float(max_correspondence_distance), _p(init_t), int(max_iteration),
                            float(relative_fitness), float(relative_rmse), _p(out_T), _p(stats))
     if rc != 1:
         raise RuntimeError("genpc_icp_batch failed (rc=%d): %s" % (rc, _lib.last_error()))
-    T = out_T.reshape(k, 4, 4).cpu().numpy()
-    st = stats.cpu().numpy()
+    host = buf.cpu().numpy()
+    T = host[:k * 16].reshape(k, 4, 4)
+    st = host[k * 16:].reshape(k, 3)
     if np.asarray(init).ndim == 2:
         return T[0], float(st[0, 0]), float(st[0, 1]), int(st[0, 2])
     return T, st[:, 0], st[:, 1], st[:, 2].astype(int)
