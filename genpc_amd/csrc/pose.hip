@@ -7,8 +7,10 @@
 // The reference runs this through torch autograd: per iteration ~40 tiny kernels,
 // two chamfer_3DDist calls (each computing BOTH directions and dropping one,
 // utils/loss_util.py:35-38), two backward launches with 6 atomics per point, and a
-// host round trip for the tqdm postfix.  Here an iteration is four launches with no
-// host synchronisation:
+// host round trip for the tqdm postfix.  Here an iteration of the Chamfer-only objective is four launches with no
+// host synchronisation (the full objective adds the silhouette half -- mask section below -- and, since round 6, folds the
+// update into the next iteration's transform and runs the two halves on two streams that hand over through device
+// counters: see PoseFuse and pose_publish_block):
 //   pose_transform_kernel   pts = (R ((v - c) s)^T)^T + c + t
 //   nn_forward_kernel       ONE bidirectional NN (chamfer.hip): d1/i1 and d2/i2 are
 //                           exactly the two partial-matching terms

@@ -262,7 +262,7 @@ def run_in_lanes(fn, items, lanes, device):
         try:
             _lib.apply_thread_state(state)
             _TLS.lanes = lanes
-            if lanes > 1:
+            if lanes > 1 and __import__("os").environ.get("GENPC_LANES_DUAL", "0") != "1":
                 # several scans in flight share the chip already: the alignment loop's second stream (csrc/pose.hip) costs
                 # throughput there (six lanes 30 scans/s with it, 40 without) where it saves a scan alone 6 % of its time
                 _lib.lib.genpc_pose_dual(0)
