@@ -21,6 +21,7 @@
 // 6.5u (2|q'|T + T^2); three fp32 roundings each in |t'|^2 and |q'|^2; one unit on T^2
 // for subnormal pieces:  E1 = u (30 |q'| T + 15 T^2 + 3 |q'|^2).
 #include "nn.h"
+#include <hip/hip_ext.h>
 #include "../../include/genpc_hip.h"
 
 #include <stdlib.h>
@@ -341,8 +342,15 @@ __global__ __launch_bounds__(WV * kWave, W) void nn_f16_kernel(NNArgs a)
 }
 
 template <int Q, int NL>
-static void launch_main(const NNArgs &a, int blocks, int u, int tight, hipStream_t st)
+static void launch_main(const NNArgs &a, int blocks, int u, int tight, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
+    // (e0 / e1: genpc_nn_profile -- the events ride on the kernel's own dispatch, hipExtLaunchKernelGGL: they take the dispatch's
+    //  start and end timestamps, what a rocprofv3 kernel trace reports, not the interval between two marker packets around it)
+#define NN_F16_LAUNCH(KERNEL, GRID, BLOCK)                                                                              \
+    do {                                                                                                                \
+        if (e0) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, e0, e1, 0, a);                                        \
+        else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, a);                                                         \
+    } while (0)
     // tight 1: three waves per SIMD for the 512-query blocks (planner: launches of several rounds)
     // tight 2 (planner: single round, Q = 4, slice_len > 1024): 8-wave blocks of 1024 queries, one per CU
     // HT = 2048 (66 KiB of LDS per block; a slice of up to 2048 targets is resident) where two waves per SIMD are all the
@@ -350,25 +358,26 @@ static void launch_main(const NNArgs &a, int blocks, int u, int tight, hipStream
     static const int env_ht = tune_env("GENPC_NN_HT", 0, "f16 filter: 1024 = never stage 2048-target LDS tiles");
     const bool big = Q == 4 && tight != 1 && a.slice_len > kHTile && env_ht != 1024;
     if (Q == 4 && tight == 2) {
-        if (u == 2) hipLaunchKernelGGL((nn_f16_kernel<4, 2, NL, 1, 2 * kHTile, 8>), dim3(blocks), dim3(8 * kWave), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<4, 4, NL, 1, 2 * kHTile, 8>), dim3(blocks), dim3(8 * kWave), 0, st, a);
+        if (u == 2) NN_F16_LAUNCH((nn_f16_kernel<4, 2, NL, 1, 2 * kHTile, 8>), dim3(blocks), dim3(8 * kWave));
+        else NN_F16_LAUNCH((nn_f16_kernel<4, 4, NL, 1, 2 * kHTile, 8>), dim3(blocks), dim3(8 * kWave));
         return;
     }
     if (big) {
-        if (u == 2) hipLaunchKernelGGL((nn_f16_kernel<4, 2, NL, 2, 2 * kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<4, 4, NL, 2, 2 * kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
+        if (u == 2) NN_F16_LAUNCH((nn_f16_kernel<4, 2, NL, 2, 2 * kHTile, 4>), dim3(blocks), dim3(kBlock));
+        else NN_F16_LAUNCH((nn_f16_kernel<4, 4, NL, 2, 2 * kHTile, 4>), dim3(blocks), dim3(kBlock));
         return;
     }
     if (u == 2) {
-        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 3 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 2 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
+        if (tight) NN_F16_LAUNCH((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 3 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock));
+        else NN_F16_LAUNCH((nn_f16_kernel<Q, 2, NL, (Q == 4 ? 2 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock));
     } else {
-        if (tight) hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 3 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 2 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
+        if (tight) NN_F16_LAUNCH((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 3 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock));
+        else NN_F16_LAUNCH((nn_f16_kernel<Q, 4, NL, (Q == 4 ? 2 : 4), kHTile, 4>), dim3(blocks), dim3(kBlock));
     }
+#undef NN_F16_LAUNCH
 }
 
-// genpc_nn_profile(): HIP events around the filter kernel alone (bench.py's roofline line).  Per calling host thread (round 4
+// genpc_nn_profile(): HIP events ON the filter kernel's dispatch (bench.py's roofline line).  Per calling host thread (round 4
 // kept this state process-wide: a lane that profiled raced every other lane's launches -- VERDICT r4 weak #13): only the
 // launches of the thread that asked are bracketed, with that thread's own pair of events.
 static thread_local bool g_prof_on = false;
@@ -388,19 +397,20 @@ int launch_nn_f16(NNArgs &a, int q, int u, int nl, int tight, long long total_bl
     if (!ws) return 0;
     for (int d = 0; d < a.ndir; d++) a.dir[d].tmaxp = (float *)(ws + off_t[d]);
     const int blocks = (int)total_blocks;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (g_prof_on) {
         if (!g_prof_e0) { (void)hipEventCreate(&g_prof_e0); (void)hipEventCreate(&g_prof_e1); }
-        (void)hipEventRecord(g_prof_e0, st);
+        pe0 = g_prof_e0;
+        pe1 = g_prof_e1;
     }
     // (256-target bookkeeping units, U = 8, in the wide form: filter -0.4 us, finish +1.7 us at 1 x 16384^2 -- not kept)
     if (q == 4) {
-        if (nl == 2) launch_main<4, 2>(a, blocks, u, tight, st);
-        else launch_main<4, 1>(a, blocks, u, tight, st);
+        if (nl == 2) launch_main<4, 2>(a, blocks, u, tight, st, pe0, pe1);
+        else launch_main<4, 1>(a, blocks, u, tight, st, pe0, pe1);
     } else {
-        if (nl == 2) launch_main<2, 2>(a, blocks, u, 0, st);
-        else launch_main<2, 1>(a, blocks, u, 0, st);
+        if (nl == 2) launch_main<2, 2>(a, blocks, u, 0, st, pe0, pe1);
+        else launch_main<2, 1>(a, blocks, u, 0, st, pe0, pe1);
     }
-    if (g_prof_on) (void)hipEventRecord(g_prof_e1, st);
     if (!check(hipGetLastError(), "nn_f16_kernel launch")) return 0;
     return launch_nn_finish(a, nl, u, (float)kQTh, (float)kTTh, 0.0f, st);
 }
