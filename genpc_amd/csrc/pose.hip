@@ -2476,7 +2476,8 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // (tools/time_c2_streams.py, one scan at a time: 24.4 scans/s without a side stream; 25.7 with it on the null stream but 21.2
     // on a stream of the caller's own; with its own class 25.3 / 25.9).
     static const int env_dual0 = tune_env("GENPC_POSE_DUAL", 1, "alignment loop, full objective, small clouds: 1 = the Chamfer half of a step (nearest neighbours + gradient) on a side stream beside the silhouette half, 0 = one stream");
-    const bool dual_small = mask && (t_pose_dual >= 0 ? t_pose_dual != 0 : env_dual0 != 0) && (long long)b * nc <= 24576;
+    static const int env_dual_max = tune_env("GENPC_POSE_DUAL_MAX", 65536, "alignment loop: the side stream for up to this many points per call (elements x points)");
+    const bool dual_small = mask && (t_pose_dual >= 0 ? t_pose_dual != 0 : env_dual0 != 0) && (long long)b * nc <= env_dual_max;
     int seed_mode = nc >= 256 && np >= 256 ? (t_pose_seeded >= 0 ? t_pose_seeded : env_seeded) : 0;
     if (dual_small && t_pose_seeded < 0 && seed_mode == 2) seed_mode = 0;
     // ... and so it is for small clouds in general: at the post-voxel sizes of reg() (4 x 4493 against 886 points) a step's
