@@ -133,16 +133,22 @@ __global__ void pose_wait_kernel(unsigned *ctr, int which, unsigned target)
 // [14] = sum sqrt(d2).  Thread t < nc: term of complete point t (pts -> partial);
 // nc <= t < nc+np: term of partial point t-nc (partial -> pts), attributed to the
 // complete point it matched.
-__global__ __launch_bounds__(kQBlock) void pose_grad_kernel(int nc, const float *__restrict__ v,
-                                                            const float *__restrict__ center, int cstride,
-                                                            const float *__restrict__ params, int pstride, int np,
-                                                            const float *__restrict__ partial,
-                                                            const float *__restrict__ d1, const int *__restrict__ i1,
-                                                            const float *__restrict__ d2, const int *__restrict__ i2,
-                                                            float cd_weight, double *__restrict__ accum, unsigned *ctr)
+struct PoseGradArgs {          // pose_grad_kernel's arguments, for the launch that carries it along (mask_grad_kernel)
+    int nc, cstride, pstride, np;
+    const float *v, *center, *params, *partial, *d1, *d2;
+    const int *i1, *i2;
+    float cd_weight;
+    double *accum;
+    int gx;                    // blocks per batch element; 0: nothing rides along
+};
+__device__ __forceinline__ void pose_grad_body(int bx, int gdx, int e, int nc, const float *__restrict__ v,
+                                               const float *__restrict__ center, int cstride,
+                                               const float *__restrict__ params, int pstride, int np,
+                                               const float *__restrict__ partial,
+                                               const float *__restrict__ d1, const int *__restrict__ i1,
+                                               const float *__restrict__ d2, const int *__restrict__ i2,
+                                               float cd_weight, double *__restrict__ accum, double (*red)[kQBlock / kWave])
 {
-    __shared__ double red[15][kQBlock / kWave];
-    const int e = blockIdx.y;
     v += (size_t)e * nc * 3;
     partial += (size_t)e * np * 3;
     d1 += (size_t)e * nc; i1 += (size_t)e * nc;
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(kQBlock) void pose_grad_kernel(int nc, const float 
     double a[15];
 #pragma unroll
     for (int k = 0; k < 15; k++) a[k] = 0.0;
-    for (int e = blockIdx.x * kQBlock + threadIdx.x; e < nc + np; e += gridDim.x * kQBlock) {
+    for (int e = bx * kQBlock + threadIdx.x; e < nc + np; e += gdx * kQBlock) {
         int j, k;
         float d;
         double w;
@@ -201,6 +207,18 @@ __global__ __launch_bounds__(kQBlock) void pose_grad_kernel(int nc, const float 
         for (int w2 = 0; w2 < kQBlock / kWave; w2++) x += red[threadIdx.x][w2];
         atomicAdd(&accum[threadIdx.x], x);
     }
+}
+
+__global__ __launch_bounds__(kQBlock) void pose_grad_kernel(int nc, const float *__restrict__ v,
+                                                            const float *__restrict__ center, int cstride,
+                                                            const float *__restrict__ params, int pstride, int np,
+                                                            const float *__restrict__ partial,
+                                                            const float *__restrict__ d1, const int *__restrict__ i1,
+                                                            const float *__restrict__ d2, const int *__restrict__ i2,
+                                                            float cd_weight, double *__restrict__ accum, unsigned *ctr)
+{
+    __shared__ double red[15][kQBlock / kWave];
+    pose_grad_body(blockIdx.x, gridDim.x, blockIdx.y, nc, v, center, cstride, params, pstride, np, partial, d1, i1, d2, i2, cd_weight, accum, red);
     if (ctr) pose_publish_block(ctr, 1);
 }
 
@@ -1773,9 +1791,17 @@ __global__ __launch_bounds__(kQBlock) void mask_grad_kernel(int n, const float *
                                                             const float4 *__restrict__ gpart, const float4 *__restrict__ uvr,
                                                             int gx, int nb, const float *__restrict__ planes = nullptr,
                                                             const float *__restrict__ mref = nullptr,
-                                                            const float *__restrict__ stats = nullptr, float mask_weight = 0.0f)
+                                                            const float *__restrict__ stats = nullptr, float mask_weight = 0.0f,
+                                                            PoseGradArgs pg = PoseGradArgs{})
 {
-    __shared__ double red[13][kQBlock / kWave];
+    __shared__ double red[15][kQBlock / kWave];
+    // (one stream, full objective: the Chamfer half's gradient rides along as the launch's last blocks -- a launch less per step)
+    if (pg.gx > 0 && (int)blockIdx.x >= gx * nb) {
+        const int r = (int)blockIdx.x - gx * nb;
+        pose_grad_body(r % pg.gx, pg.gx, r / pg.gx, pg.nc, pg.v, pg.center, pg.cstride, pg.params, pg.pstride, pg.np, pg.partial, pg.d1, pg.i1,
+                       pg.d2, pg.i2, pg.cd_weight, pg.accum, red);
+        return;
+    }
     const XcdBlock xb = xcd_block(gx, nb);
     const int e = xb.e;
     if (uvr) uvr += (size_t)e * n;
@@ -2080,10 +2106,17 @@ static int mask_prepare_ref(int b, int np, const float *partial, const float *pa
     return check(hipGetLastError(), "mask reference launch") ? 1 : 0;
 }
 
+// (the per-point silhouette gradient can carry pose_grad's blocks along; the per-tile form cannot)
+static bool mask_step_carries(int S)
+{
+    static const int env_tp = tune_env("GENPC_MASK_GRAD_TILES", -1, "alignment loop: 1 = the silhouette gradient through the per-tile lists (opt-in), 0 = per point");
+    return !(use_bins(S) && env_tp > 0);
+}
+
 // the launches of the mask term for the current parameters: accum[0..12] += gradient, accum[15] += loss
 static int mask_step(int b, int nc, const float *complete, const float *complete_col, const float *center, int cstride,
                      const float *params, int pstride, float radius, int S, float mask_weight, const MaskScratch &m,
-                     double *accum, hipStream_t st, bool projected = false)
+                     double *accum, hipStream_t st, bool projected = false, const PoseGradArgs *ride = nullptr)
 {
     const float rad = 1.1f * radius;      // diff_obj_pose.py:385: the posed cloud is drawn with 1.1 x the radius
     const int gp = lin_grid((long long)S * S);
@@ -2147,11 +2180,12 @@ static int mask_step(int b, int nc, const float *complete, const float *complete
         // themselves (measured at 4 x 16384 points, the four starts in lock-step: <1> 35 us, <8> 42)
         static const int env_sub = tune_env("GENPC_MASK_GRAD_SUB", 0, "alignment loop: lanes per point of the per-point silhouette gradient (0 = pick)");
         const int sub = env_sub ? env_sub : ((long long)b * nc <= 24576 || b <= 2 ? 8 : 1);
+        const PoseGradArgs pgx = ride ? *ride : PoseGradArgs{};
 #define GENPC_LAUNCH_MASK_GRAD3(SUB, BL, FW)                                                                                         \
-        hipLaunchKernelGGL((mask_grad_kernel<SUB, BL, FW>), dim3(lin_grid((long long)nc * SUB) * b), dim3(kQBlock), 0, st, nc, complete, \
+        hipLaunchKernelGGL((mask_grad_kernel<SUB, BL, FW>), dim3(lin_grid((long long)nc * SUB) * b + pgx.gx * b), dim3(kQBlock), 0, st, nc, complete, \
                            complete_col, center, cstride, params, pstride, rad, S, (const float *)m.W1, (const float4 *)m.W4, accum, \
                            (const float4 *)nullptr, (const float4 *)nullptr, lin_grid((long long)nc * SUB), b, (const float *)m.planes, \
-                           (const float *)m.mref, (const float *)m.stats, mask_weight)
+                           (const float *)m.mref, (const float *)m.stats, mask_weight, pgx)
 #define GENPC_LAUNCH_MASK_GRAD2(SUB, BL) do { if (fuse_w) GENPC_LAUNCH_MASK_GRAD3(SUB, BL, 1); else GENPC_LAUNCH_MASK_GRAD3(SUB, BL, 0); } while (0)
 #define GENPC_LAUNCH_MASK_GRAD(SUB) do { if (blend) GENPC_LAUNCH_MASK_GRAD2(SUB, 1); else GENPC_LAUNCH_MASK_GRAD2(SUB, 0); } while (0)
         if (sub == 8) GENPC_LAUNCH_MASK_GRAD(8);
@@ -2536,7 +2570,13 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
     // pose_grad's blocks count themselves, and thread 0 of every block of the NEXT transform waits for that count before it reads
     // the sums (the fused update).  The last step of a start joins through an event as before (its update is a launch of its own).
     static const int env_dual_flags = tune_env("GENPC_POSE_DUAL_FLAGS", 1, "alignment loop with a side stream: 1 = the streams hand over through device counters, 0 = through events");
-    const bool flags = dual && fuse_upd && env_dual_flags != 0 && dual->ctr != nullptr;
+    // (not under tools that run one kernel at a time -- rocprofv3's counter collection, AMD_SERIALIZE_KERNEL: a kernel that waits for
+    //  a count can then sit in front of the kernel that publishes it, until its spin gives up; the events order the launches instead)
+    static const bool serialised = [] {
+        const char *a = getenv("ROCPROF_COUNTER_COLLECTION"), *b2 = getenv("AMD_SERIALIZE_KERNEL");
+        return (a && *a && *a != '0') || (b2 && *b2 && *b2 != '0');
+    }();
+    const bool flags = dual && fuse_upd && env_dual_flags != 0 && dual->ctr != nullptr && !serialised;
     if (flags) {
         if (dual->dirty) {          // an earlier call left early: counts and expectations may disagree
             if (!check(hipStreamSynchronize(st), "hipStreamSynchronize") || !check(hipStreamSynchronize(dual->side), "hipStreamSynchronize") ||
@@ -2617,12 +2657,23 @@ GENPC_API int genpc_pose_optimize_batch(int b, int nc, const float *complete, co
                     use_seeded = it >= 2 && t_seeded < 0.9f * t_filter;
                 }
             }
-            hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, sn, nc, complete, (const float *)center,
-                               4, (const float *)Sc->params, kStateFloats, np, partial, (const float *)d1,
-                               (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, ac, flags ? dual->ctr : (unsigned *)nullptr);
-            if (flags) dual->pg_count += (unsigned)g_g * (unsigned)b;
+            // one stream and the full objective: pose_grad's blocks ride at the end of the silhouette gradient's launch
+            static const int env_ride = tune_env("GENPC_POSE_GRAD_RIDES", 1, "alignment loop, one stream, full objective: 1 = pose_grad's blocks in mask_grad's launch, 0 = a launch of its own");
+            const bool ride = mask && !dual && env_ride != 0 && mask_step_carries(render_size);
+            PoseGradArgs pga{};
+            if (ride) {
+                pga.nc = nc; pga.cstride = 4; pga.pstride = kStateFloats; pga.np = np;
+                pga.v = complete; pga.center = center; pga.params = Sc->params; pga.partial = partial;
+                pga.d1 = d1; pga.d2 = d2; pga.i1 = i1; pga.i2 = i2;
+                pga.cd_weight = 3.0f; pga.accum = ac; pga.gx = g_g;
+            } else {
+                hipLaunchKernelGGL(pose_grad_kernel, dim3(g_g, b), dim3(kQBlock), 0, sn, nc, complete, (const float *)center,
+                                   4, (const float *)Sc->params, kStateFloats, np, partial, (const float *)d1,
+                                   (const int *)i1, (const float *)d2, (const int *)i2, 3.0f, ac, flags ? dual->ctr : (unsigned *)nullptr);
+                if (flags) dual->pg_count += (unsigned)g_g * (unsigned)b;
+            }
             if (mask && !mask_step(b, nc, complete, complete_col, center, 4, Sc->params, kStateFloats, radius, render_size,
-                                   mask_weight, m, ac, st, true))
+                                   mask_weight, m, ac, st, true, ride ? &pga : nullptr))
                 return 0;
             if (dual && (!flags || it == iters)) {
                 // join: the update reads both halves' sums

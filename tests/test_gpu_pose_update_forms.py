@@ -37,8 +37,9 @@ print("RESULT" + json.dumps(out))
 ''' % ROOT
 
 
-def _run(fuse, lockstep, flags=1):
-    env = dict(os.environ, GENPC_POSE_FUSE_UPDATE=str(fuse), GENPC_POSE_LOCKSTEP=str(lockstep), GENPC_POSE_DUAL_FLAGS=str(flags))
+def _run(fuse, lockstep, flags=1, dual=1, rides=1):
+    env = dict(os.environ, GENPC_POSE_FUSE_UPDATE=str(fuse), GENPC_POSE_LOCKSTEP=str(lockstep), GENPC_POSE_DUAL_FLAGS=str(flags),
+               GENPC_POSE_DUAL=str(dual), GENPC_POSE_GRAD_RIDES=str(rides))
     p = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1]
@@ -48,10 +49,11 @@ def _run(fuse, lockstep, flags=1):
 def test_update_forms_agree():
     ref = _run(0, 1)
     # (the last form: the loop's two streams hand over through events instead of device counters, csrc/pose.hip GENPC_POSE_DUAL_FLAGS)
-    for fuse, lockstep, flags in ((1, 1, 1), (1, 0, 1), (0, 0, 1), (1, 1, 0)):
-        got = _run(fuse, lockstep, flags)
+    # (the last two: one stream -- pose_grad's blocks ride in the silhouette gradient's launch, or have a launch of their own)
+    for fuse, lockstep, flags, dual, rides in ((1, 1, 1, 1, 1), (1, 0, 1, 1, 1), (0, 0, 1, 1, 1), (1, 1, 0, 1, 1), (1, 1, 1, 0, 1), (1, 1, 1, 0, 0)):
+        got = _run(fuse, lockstep, flags, dual, rides)
         for iters in ("7", "8"):
             h, hr = np.array(got[iters]["hist"]), np.array(ref[iters]["hist"])
             assert h.shape == hr.shape == (4, int(iters) + 1) and np.isfinite(h).all()
-            np.testing.assert_allclose(h, hr, rtol=2e-5, err_msg="fuse %d lockstep %d flags %d iters %s" % (fuse, lockstep, flags, iters))
+            np.testing.assert_allclose(h, hr, rtol=2e-5, err_msg="fuse %d lockstep %d flags %d dual %d rides %d iters %s" % (fuse, lockstep, flags, dual, rides, iters))
             np.testing.assert_allclose(np.array(got[iters]["T"]), np.array(ref[iters]["T"]), atol=2e-5)
