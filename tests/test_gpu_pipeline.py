@@ -130,6 +130,32 @@ def test_stage1_under_the_alignment_loop_changes_nothing(env, golden):
                 assert torch.equal(torch.as_tensor(ma), torch.as_tensor(mb))
 
 
+def test_side_streams_and_the_deferred_sampling_check_change_nothing(env, golden):
+    """pipeline.prepare_streams (the single-scan path's side streams made and used up front) is idempotent, and a scan whose
+    samplings are checked beside the tail (genpc_fps_defer, the default) gives the bits of one whose check is in line."""
+    torch = env["torch"]
+    P = env["P"]
+    partial, gen, img, gt = c2_inputs(golden)
+    Pt, Gt, It, GTt = (torch.from_numpy(x).cuda() for x in (partial, gen, img, gt))
+    P.prepare_streams("cuda")
+    P.prepare_streams(torch.device("cuda", torch.cuda.current_device()))
+    keys = ("visible", "uv", "depth", "pixels", "point_colors", "fused", "pred_metric_points", "gt_metric_points")
+    was = P._FPS_DEFER
+    try:
+        P._FPS_DEFER = False
+        ref = P.complete_scan(Pt, Gt, It, GTt, cfg=env["cfg"], dp=env["dp"])
+        P._FPS_DEFER = True
+        for _ in range(2):
+            out = P.complete_scan(Pt, Gt, It, GTt, cfg=env["cfg"], dp=env["dp"])
+            for k in keys:
+                assert torch.equal(out[k], ref[k]), k
+            assert torch.equal(torch.as_tensor(out["metric"]), torch.as_tensor(ref["metric"]))
+    finally:
+        P._FPS_DEFER = was
+    from genpc_amd import _lib
+    assert _lib.on_device_of(Pt, _lib.lib.genpc_fps_deferred_check) == 0
+
+
 def test_scans_in_flight_side_by_side_change_nothing(env, golden):
     """pipeline.complete_scans: several scans at a time on one GPU (a host thread and a stream pair per lane); every scan's
     products are the bits of a call of complete_scan on its own."""
